@@ -1,0 +1,173 @@
+/*
+ * tnco_hip.h -- C ABI of libtnco_hip.so: batched simulated annealing of
+ * tensor-network contraction trees on one MI355X (gfx950).
+ *
+ * Drop-in boundary.  Each entry point names the reference interface it replaces
+ * (paths relative to the google-research/tnco checkout).  The reference exposes
+ * ONE replica per pybind11 object and is stepped from Python
+ * (tnco/app/infinite_memory/sa.py:199-209); this ABI carries MANY replicas per
+ * handle and a whole beta schedule per call.  Plain pointers and sizes only;
+ * every input is copied at create time and every output is copied into
+ * caller-owned buffers (the reference takes its ctree by value and clones the
+ * cost model, include/tnco/optimize/infinite_memory/optimizer.hpp:61-67).
+ *
+ * Threading: a handle is bound to one device and one stream and is not
+ * thread-safe; distinct handles are independent.
+ *
+ * Status codes: 0 ok; TNCO_HIP_EINVAL -> ValueError in the Python shim
+ * (std::invalid_argument / std::domain_error in the reference,
+ * include/tnco/ctree.hpp:48-50, infinite_memory/optimizer.hpp:77-87);
+ * TNCO_HIP_ERUNTIME -> RuntimeError; TNCO_HIP_ENOTIMPL -> NotImplementedError.
+ * tnco_hip_last_error() returns the message of the last failing call on the
+ * calling thread.
+ */
+#ifndef TNCO_HIP_H_
+#define TNCO_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TNCO_HIP_OK 0
+#define TNCO_HIP_EINVAL 1
+#define TNCO_HIP_ERUNTIME 2
+#define TNCO_HIP_ENOTIMPL 3
+
+/* Acceptance rule, include/tnco/optimize/prob/{base,greedy,mh}.hpp. */
+#define TNCO_HIP_PROB_BASE 0
+#define TNCO_HIP_PROB_GREEDY 1
+#define TNCO_HIP_PROB_MH 2
+
+/* cost_type / width_type, include/tnco/globals.hpp:81-117 (float64 / float32
+ * only; long double and float1024 are CPU-only in the reference). */
+#define TNCO_HIP_F64 0
+#define TNCO_HIP_F32 1
+
+typedef struct tnco_hip_ctx* tnco_hip_handle;
+
+/*
+ * Problem description = the arguments of
+ *   tnco_core.ContractionTree(nodes, inds, dims, check_shared_inds)
+ *     (include/tnco/ctree.hpp:59-94),
+ *   SimpleCostModel / SimpleSparseIndsCostModel
+ *     (include/tnco/optimize/infinite_memory/cost_model/simple.hpp:57-88,
+ *      simple_sparse_inds.hpp:51-93), and
+ *   Optimizer_<cost>(ctree, cmodel, seed=, disable_shared_inds=)
+ *     (include/tnco/optimize/infinite_memory/optimizer.hpp:61-88,
+ *      include/tnco/optimize/optimizer.hpp:57-82)
+ * for n_replicas replicas at once.  N = 2*n_leaves-1, W = ceil(n_inds/64)
+ * (at least 1); bit p of word p/64 of a mask <-> index position p.
+ */
+typedef struct tnco_hip_desc {
+  int32_t n_leaves;            /* leaves occupy node slots [0, n_leaves), root is slot N-1 */
+  int32_t n_inds;
+  int64_t n_replicas;
+  const uint64_t* leaf_masks;  /* [n_leaves][W]; identical for every replica */
+  const uint64_t* output_mask; /* [W] legs of the result tensor, or NULL (none) */
+  const int32_t* links;        /* per replica [3][N]: left[N], right[N], parent[N]; null = -1 */
+  int64_t links_stride;        /* int32 elements between replicas; 0 = one tree shared by all */
+  const uint64_t* node_masks;  /* optional per replica [N][W] legs of EVERY node (the reference
+                                  passes them in); NULL = derive them on the device from the
+                                  leaves (rule of tnco/ctree.py:163-189) */
+  int64_t node_masks_stride;   /* uint64 elements between replicas; 0 = shared */
+  uint64_t dim_uniform;        /* used when dims == NULL */
+  const uint64_t* dims;        /* [n_inds] or NULL; all-equal collapses to uniform (ctree.hpp:79-89) */
+  const uint64_t* sparse_mask; /* [W] or NULL -> SimpleCostModel */
+  uint64_t n_projs;            /* > 0 when sparse_mask != NULL */
+  int32_t cost_dtype;          /* TNCO_HIP_F64 | TNCO_HIP_F32 */
+  int32_t disable_shared_inds;
+  const uint32_t* seeds;       /* [n_replicas] std::mt19937 seeds (already reduced mod 2^32) */
+  int32_t device;              /* HIP device ordinal */
+  int32_t reserved;
+} tnco_hip_desc;
+
+/* Replaces the Optimizer_<cost> constructor for a batch: copies inputs, builds
+ * CostCache / HyperCache (include/tnco/optimize/infinite_memory/utils.hpp:22-116)
+ * and validates every tree (ctree.hpp:101-152).  EINVAL with "Contraction is
+ * not valid." / "Precision is too low." as the reference throws. */
+int tnco_hip_create(const tnco_hip_desc* desc, tnco_hip_handle* out);
+
+/* Replaces the Python step loop `for beta in betas: prob.beta = beta;
+ * opt.update(prob)` (tnco/app/infinite_memory/sa.py:199-209 over
+ * Optimizer::update, infinite_memory/optimizer.hpp:90-221): n_steps sweeps on
+ * every replica, sweep k using betas[k].  Asynchronous on the handle's stream;
+ * any getter synchronises. */
+int tnco_hip_run(tnco_hip_handle h, int prob_kind, const double* betas, int64_t n_steps);
+
+int tnco_hip_sync(tnco_hip_handle h);
+
+/* total_cost / min_total_cost properties (optimizer.hpp:253-257) of every
+ * replica as raw doubles (the reference prints them to a 6-digit Decimal,
+ * optimizer.hpp:278-289; callers wanting that format it host-side).
+ * Either pointer may be NULL. */
+int tnco_hip_get_costs(tnco_hip_handle h, double* total_cost, double* min_total_cost);
+
+/* ctree / min_ctree read-only properties (optimize/optimizer.hpp:207-208) of
+ * one replica.  which: 0 current, 1 best-so-far.  masks ([N][W]) may be NULL. */
+int tnco_hip_get_tree(tnco_hip_handle h, int64_t replica, int which, int32_t* left,
+                      int32_t* right, int32_t* parent, uint64_t* masks);
+
+/* CostCache / HyperCache contents of one replica (what is_valid() rebuilds and
+ * compares, optimizer.hpp:223-251); ccost/partial [N], hyper [N][W]; any may
+ * be NULL. */
+int tnco_hip_get_caches(tnco_hip_handle h, int64_t replica, double* ccost, double* partial,
+                        uint64_t* hyper);
+
+/* is_valid(atol) for every replica, recomputed from scratch on the device
+ * (optimizer.hpp:223-251).  n_bad = number of replicas failing; first_bad = one
+ * of them or -1. */
+int tnco_hip_validate(tnco_hip_handle h, double atol, int64_t* n_bad, int64_t* first_bad);
+
+/* prng_state property / string-seed constructor (optimize/optimizer.hpp:68-71,
+ * 191-195): 624 state words followed by the position, exactly the numbers
+ * `oss << std::mt19937` prints. */
+int tnco_hip_get_prng(tnco_hip_handle h, int64_t replica, uint32_t* state625);
+int tnco_hip_set_prng(tnco_hip_handle h, int64_t replica, const uint32_t* state625);
+
+/* The k replicas of lowest min_total_cost, ascending, ties by replica id
+ * (replaces `sorted(results)` of tnco/app/infinite_memory/sa.py:257 for the
+ * head of the list). */
+int tnco_hip_best(tnco_hip_handle h, int64_t k, double* costs, int64_t* replicas);
+
+/* Work counters summed over replicas: move evaluations (iterations of the
+ * while loop at optimizer.hpp:117-192), accepted moves, best-tree updates. */
+int tnco_hip_get_counters(tnco_hip_handle h, uint64_t* moves, uint64_t* accepted,
+                          uint64_t* improved);
+/* Per replica move counter ([n_replicas]). */
+int tnco_hip_get_moves(tnco_hip_handle h, uint64_t* moves_per_replica);
+
+/* Device time of the sweep kernel accumulated by tnco_hip_run since the last
+ * reset (HIP events on the handle's stream), and number of launches. */
+int tnco_hip_kernel_time(tnco_hip_handle h, double* ms, int64_t* launches, int reset);
+
+/* Bytes of device memory held by the handle. */
+int64_t tnco_hip_device_bytes(tnco_hip_handle h);
+
+/* Use an existing hipStream_t (e.g. torch's current stream) instead of the
+ * handle's own. NULL restores the private stream. */
+int tnco_hip_set_stream(tnco_hip_handle h, void* hip_stream);
+
+void tnco_hip_destroy(tnco_hip_handle h);
+
+/* Host helper replacing the per-run call
+ * get_random_contraction_path(...) + ContractionTree(path, ...)
+ * (tnco/app/infinite_memory/sa.py:173-190, tnco/utils/tn.py:109-273,
+ * tnco/ctree.py:108-251) for a batch: one seeded random initial tree per
+ * replica for ONE connected component, written as links [R][3][N].
+ * holders_off[n_inds+1] / holders[] = CSR list of the (ascending) leaves
+ * holding each index.  Algorithm documented in tnco_amd/ctree.py
+ * random_contraction (random Kruskal over a seeded index permutation). */
+int tnco_hip_random_trees(int32_t n_leaves, int32_t n_inds, const int32_t* holders_off,
+                          const int32_t* holders, int64_t n_replicas, const uint32_t* seeds,
+                          int32_t* links_out, int32_t n_threads);
+
+int tnco_hip_device_count(void);
+const char* tnco_hip_last_error(void);
+const char* tnco_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TNCO_HIP_H_ */

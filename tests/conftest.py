@@ -1,0 +1,20 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    from oracle import oracle as orc
+    orc.build()
+    return orc

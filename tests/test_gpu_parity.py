@@ -1,0 +1,176 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, same
+seeded inputs, bit-exact (integer tree structure, leg masks, PRNG state AND the
+float64 costs: with dims = 2 every cost is an exact power of two and all other
+operations are single IEEE add/sub/div; the only transcendental, pow() in the
+Metropolis rule, can flip a decision with probability ~1e-16 per move)."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def core():
+    from tnco_amd import core as c
+    return c
+
+
+def _run_both(core, orc, prob, seeds, betas, prob_kind="mh", n_check=None, **kw):
+    links = prob.links(seeds)
+    okw = {k: v for k, v in kw.items() if k in ("cost_type", "disable_shared_inds", "n_projs")}
+    gpu = core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, dims=prob.dims,
+                                output_mask=prob.output_mask, sparse_mask=prob.sparse_mask, **kw)
+    gpu.run(betas, prob_kind)
+    kind = {"base": 0, "greedy": 1, "mh": 2}[prob_kind]
+    tot, mn = gpu.costs()
+    moves = gpu.moves_per_replica()
+    n_check = len(seeds) if n_check is None else n_check
+    for r in range(n_check):
+        o = H.make_oracle(orc, prob, links[r], seeds[r], **okw)
+        o.run(kind, betas)
+        H.assert_replica_equal(gpu, r, o)
+        assert tot[r] == o.total_cost and mn[r] == o.min_total_cost
+        assert int(moves[r]) == o.counters()["moves"]
+    assert gpu.validate() == (0, -1)
+    return gpu
+
+
+def test_c2_64leaf_regular(core, oracle_lib):
+    """BASELINE config 2: 64-leaf 3-regular TN, 4096 replicas, fixed seeds."""
+    prob = H.regular_problem(64, graph_seed=7)
+    seeds = H.replica_seeds(4096)
+    betas = H.linear_betas(0, 100, 1000)
+    gpu = _run_both(core, oracle_lib, prob, seeds, betas, n_check=256)
+    c, ids = gpu.best(8)
+    _, mn = gpu.costs()
+    assert np.all(np.diff(c) >= 0) and c[0] == mn.min()
+
+
+def test_c3_512leaf_regular(core, oracle_lib):
+    """BASELINE config 3 topology (512 leaves, 768 indices, 12 words), fewer replicas."""
+    prob = H.regular_problem(512, graph_seed=11)
+    seeds = H.replica_seeds(256)
+    betas = H.linear_betas(0, 100, 400)
+    _run_both(core, oracle_lib, prob, seeds, betas, n_check=16)
+
+
+@pytest.mark.parametrize("n,deg", [(4, 3), (8, 3), (16, 3), (40, 5), (130, 3), (200, 4)])
+def test_sizes_and_lane_groups(core, oracle_lib, n, deg):
+    """W = 1, 1, 1, 2, 4, 7 words -> groups of 1, 1, 1, 2, 4, 8 lanes."""
+    prob = H.regular_problem(n, graph_seed=n, degree=deg)
+    seeds = H.replica_seeds(70, S=n)
+    _run_both(core, oracle_lib, prob, seeds, H.linear_betas(0, 50, 300))
+
+
+@pytest.mark.parametrize("kind", ["base", "greedy", "mh"])
+def test_prob_kinds(core, oracle_lib, kind):
+    prob = H.regular_problem(48, graph_seed=3)
+    seeds = H.replica_seeds(33, S=5)
+    _run_both(core, oracle_lib, prob, seeds, H.linear_betas(0.5, 20, 200), prob_kind=kind)
+
+
+def test_chunked_run_equals_single_run(core, oracle_lib):
+    prob = H.regular_problem(64, graph_seed=7)
+    seeds = H.replica_seeds(40, S=9)
+    betas = H.linear_betas(0, 100, 300)
+    links = prob.links(seeds)
+    a = core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds)
+    b = core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds)
+    a.run(betas)
+    for lo, hi in [(0, 1), (1, 17), (17, 18), (18, 300)]:
+        b.run(betas[lo:hi])
+    for r in range(len(seeds)):
+        for x, y in zip(a.tree(r), b.tree(r)):
+            assert np.array_equal(x, y)
+        assert np.array_equal(a.prng_state(r), b.prng_state(r))
+    assert np.array_equal(a.costs()[1], b.costs()[1])
+
+
+def test_hyper_output_dims(core, oracle_lib):
+    """Hyper-indices + output legs; uniform dims 3 (table path)."""
+    from tnco_amd import synthetic as syn
+    ts, dims, out = syn.random_hyper_tn(30, 70, k=4, n_output=6, seed=2)
+    prob = H.Problem(ts, 3, out)
+    seeds = H.replica_seeds(40, S=2)
+    _run_both(core, oracle_lib, prob, seeds, H.linear_betas(0, 30, 300))
+
+
+def test_hyper_pow2_dims(core, oracle_lib):
+    from tnco_amd import synthetic as syn
+    ts, dims, out = syn.random_hyper_tn(40, 90, k=3, n_output=5, seed=4)
+    prob = H.Problem(ts, 2, out)
+    seeds = H.replica_seeds(40, S=3)
+    _run_both(core, oracle_lib, prob, seeds, H.linear_betas(0, 30, 300))
+
+
+def test_vector_dims(core, oracle_lib):
+    from tnco_amd import synthetic as syn
+    ts, dims, out = syn.random_hyper_tn(24, 60, k=3, n_output=3, seed=5, dims_choices=(2, 3, 4, 7))
+    prob = H.Problem(ts, np.array(dims, np.uint64), out)
+    seeds = H.replica_seeds(20, S=4)
+    _run_both(core, oracle_lib, prob, seeds, H.linear_betas(0, 30, 200))
+
+
+def test_sparse_inds(core, oracle_lib):
+    from tnco_amd import synthetic as syn
+    ts, dims, out = syn.random_hyper_tn(24, 60, k=3, n_output=4, seed=6)
+    prob = H.Problem(ts, 2, out, sparse_inds=[1, 5, 9, 20, 33, 47])
+    seeds = H.replica_seeds(20, S=6)
+    _run_both(core, oracle_lib, prob, seeds, H.linear_betas(0, 30, 200), n_projs=5)
+
+
+def test_float32_cost(core, oracle_lib):
+    prob = H.regular_problem(32, graph_seed=8)
+    seeds = H.replica_seeds(24, S=8)
+    _run_both(core, oracle_lib, prob, seeds, H.linear_betas(0, 40, 300), cost_type="float32")
+
+
+def test_disable_shared_inds(core, oracle_lib):
+    prob = H.regular_problem(32, graph_seed=9)
+    seeds = H.replica_seeds(24, S=10)
+    _run_both(core, oracle_lib, prob, seeds, H.linear_betas(0, 40, 300), disable_shared_inds=True)
+
+
+def test_prng_roundtrip_and_resume(core, oracle_lib):
+    """prng_state export/import (optimize/optimizer.hpp:68-71,191-195): a replica
+    restarted from its exported state continues identically."""
+    prob = H.regular_problem(32, graph_seed=12)
+    seeds = H.replica_seeds(8, S=12)
+    links = prob.links(seeds)
+    betas = H.linear_betas(0, 30, 120)
+    a = core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds)
+    a.run(betas[:50])
+    # rebuild b from a's trees + prng states, then run both to the end
+    cur = np.stack([np.stack(a.tree(r)[:3]) for r in range(len(seeds))])
+    b = core.BatchedOptimizer(prob.leaf_masks, cur, seeds, n_inds=prob.n_inds)
+    for r in range(len(seeds)):
+        b.set_prng_state(r, a.prng_state(r))
+        assert np.array_equal(b.prng_state(r), a.prng_state(r))
+    a.run(betas[50:])
+    b.run(betas[50:])
+    for r in range(len(seeds)):
+        for x, y in zip(a.tree(r), b.tree(r)):
+            assert np.array_equal(x, y)
+
+
+def test_invalid_inputs(core):
+    prob = H.regular_problem(16, graph_seed=1)
+    seeds = H.replica_seeds(4)
+    links = prob.links(seeds)
+    bad = links.copy()
+    bad[2, 2, 0] = 5  # wrong parent
+    with pytest.raises(ValueError):
+        core.BatchedOptimizer(prob.leaf_masks, bad, seeds, n_inds=prob.n_inds)
+    with pytest.raises(NotImplementedError):
+        core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, cost_type="float128")
+    # a contraction of two tensors that share no index is rejected unless disable_shared_inds
+    from tnco_amd import ctree as ct
+    ts = [[0], [0, 1], [1, 2], [2]]
+    lm = ct.pack_masks(ts, 3)
+    l, r, p = ct.tree_from_contraction([(0, 3, 4), (1, 2, 5), (4, 5, 6)], 4)
+    lk = np.stack([l, r, p])
+    with pytest.raises(ValueError, match="Contraction is not valid"):
+        core.BatchedOptimizer(lm, lk, [1], n_inds=3)
+    core.BatchedOptimizer(lm, lk, [1], n_inds=3, disable_shared_inds=True).close()

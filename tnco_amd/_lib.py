@@ -1,0 +1,99 @@
+"""ctypes binding of libtnco_hip.so (the C ABI declared in include/tnco_hip.h).
+
+The shared object is built in-tree by `make -C tnco_amd/csrc` (hipcc,
+--offload-arch=gfx950).  There is NO fallback: if it cannot be loaded the
+import fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_PATH = Path(__file__).resolve().parent / "libtnco_hip.so"
+
+OK, EINVAL, ERUNTIME, ENOTIMPL = 0, 1, 2, 3
+PROB_BASE, PROB_GREEDY, PROB_MH = 0, 1, 2
+F64, F32 = 0, 1
+
+
+class Desc(C.Structure):
+    _fields_ = [
+        ("n_leaves", C.c_int32),
+        ("n_inds", C.c_int32),
+        ("n_replicas", C.c_int64),
+        ("leaf_masks", C.c_void_p),
+        ("output_mask", C.c_void_p),
+        ("links", C.c_void_p),
+        ("links_stride", C.c_int64),
+        ("node_masks", C.c_void_p),
+        ("node_masks_stride", C.c_int64),
+        ("dim_uniform", C.c_uint64),
+        ("dims", C.c_void_p),
+        ("sparse_mask", C.c_void_p),
+        ("n_projs", C.c_uint64),
+        ("cost_dtype", C.c_int32),
+        ("disable_shared_inds", C.c_int32),
+        ("seeds", C.c_void_p),
+        ("device", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+EXPORTS = [
+    "tnco_hip_create", "tnco_hip_run", "tnco_hip_sync", "tnco_hip_get_costs", "tnco_hip_get_tree",
+    "tnco_hip_get_caches", "tnco_hip_validate", "tnco_hip_get_prng", "tnco_hip_set_prng",
+    "tnco_hip_best", "tnco_hip_get_counters", "tnco_hip_get_moves", "tnco_hip_kernel_time",
+    "tnco_hip_device_bytes", "tnco_hip_set_stream", "tnco_hip_destroy", "tnco_hip_random_trees",
+    "tnco_hip_device_count", "tnco_hip_last_error", "tnco_hip_version",
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _PATH.exists():
+        raise ImportError(
+            f"{_PATH} is missing: build it with `make -C tnco_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "tnco_amd has no CPU fallback.")
+    L = C.CDLL(str(_PATH))
+    vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
+    L.tnco_hip_create.argtypes = [C.POINTER(Desc), C.POINTER(vp)]
+    L.tnco_hip_run.argtypes = [vp, C.c_int, vp, i64]
+    L.tnco_hip_sync.argtypes = [vp]
+    L.tnco_hip_get_costs.argtypes = [vp, vp, vp]
+    L.tnco_hip_get_tree.argtypes = [vp, i64, C.c_int, vp, vp, vp, vp]
+    L.tnco_hip_get_caches.argtypes = [vp, i64, vp, vp, vp]
+    L.tnco_hip_validate.argtypes = [vp, dbl, C.POINTER(i64), C.POINTER(i64)]
+    L.tnco_hip_get_prng.argtypes = [vp, i64, vp]
+    L.tnco_hip_set_prng.argtypes = [vp, i64, vp]
+    L.tnco_hip_best.argtypes = [vp, i64, vp, vp]
+    L.tnco_hip_get_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.tnco_hip_get_moves.argtypes = [vp, vp]
+    L.tnco_hip_kernel_time.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.c_int]
+    L.tnco_hip_device_bytes.argtypes = [vp]
+    L.tnco_hip_device_bytes.restype = i64
+    L.tnco_hip_set_stream.argtypes = [vp, vp]
+    L.tnco_hip_destroy.argtypes = [vp]
+    L.tnco_hip_destroy.restype = None
+    L.tnco_hip_random_trees.argtypes = [i32, i32, vp, vp, i64, vp, vp, i32]
+    L.tnco_hip_device_count.restype = C.c_int
+    L.tnco_hip_last_error.restype = C.c_char_p
+    L.tnco_hip_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    """Map a status code to the exception class the reference would raise."""
+    if rc == OK:
+        return
+    msg = load().tnco_hip_last_error().decode()
+    if rc == EINVAL:
+        raise ValueError(msg)
+    if rc == ENOTIMPL:
+        raise NotImplementedError(msg)
+    raise RuntimeError(msg)

@@ -1,0 +1,249 @@
+"""Batched optimizer handle: the build's counterpart of
+tnco_core.optimize.infinite_memory.Optimizer_<cost>
+(/root/reference/include/tnco/optimize/infinite_memory/optimizer.hpp:262-310) for
+MANY replicas on one GPU, through the C ABI of include/tnco_hip.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+
+from . import _lib
+from .ctree import n_words
+
+__all__ = ["BatchedOptimizer", "random_trees", "PROB_BASE", "PROB_GREEDY", "PROB_MH"]
+
+PROB_BASE, PROB_GREEDY, PROB_MH = _lib.PROB_BASE, _lib.PROB_GREEDY, _lib.PROB_MH
+_PROB = {"base": PROB_BASE, "greedy": PROB_GREEDY, "mh": PROB_MH,
+         "metropolishastings": PROB_MH, 0: 0, 1: 1, 2: 2}
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def holders_csr(leaf_positions: Sequence[Sequence[int]], n_inds: int):
+    """leaf -> index positions  ==>  CSR index -> ascending leaves."""
+    cnt = np.zeros(n_inds + 1, np.int32)
+    for xs in leaf_positions:
+        for p in xs:
+            cnt[p + 1] += 1
+    off = np.cumsum(cnt, dtype=np.int32)
+    fill = off[:-1].copy()
+    hold = np.zeros(int(off[-1]), np.int32)
+    for t, xs in enumerate(leaf_positions):
+        for p in xs:
+            hold[fill[p]] = t
+            fill[p] += 1
+    return off, hold
+
+
+def random_trees(leaf_positions, n_inds: int, seeds, n_threads: int = 0) -> np.ndarray:
+    """Seeded random initial trees for one connected component: links[R, 3, N].
+
+    Native batched twin of ctree.random_contraction (csrc/host_trees.cpp).
+    """
+    L = _lib.load()
+    n = len(leaf_positions)
+    off, hold = holders_csr(leaf_positions, n_inds)
+    seeds = np.ascontiguousarray(np.asarray(seeds, np.uint64) & np.uint64(0xFFFFFFFF), np.uint32)
+    out = np.empty((len(seeds), 3, 2 * n - 1), np.int32)
+    rc = L.tnco_hip_random_trees(n, n_inds, _ptr(off), _ptr(hold), len(seeds), _ptr(seeds), _ptr(out), n_threads)
+    if rc:
+        raise ValueError("tensor network component is not connected.")
+    return out
+
+
+class BatchedOptimizer:
+    """R independent SA replicas of one tensor network on one GPU.
+
+    Args:
+        leaf_masks: uint64 [n_leaves, W] legs of the input tensors.
+        links: int32 [R, 3, N] (left, right, parent per replica) or [3, N]
+            (one tree shared by all replicas).
+        seeds: R mt19937 seeds (taken mod 2**32 like prng.seed(size_t),
+            include/tnco/optimize/optimizer.hpp:73).
+        dims: int or per-index sequence.  output_mask / sparse_mask: uint64 [W].
+        node_masks: optional explicit legs of every node, [R, N, W] or [N, W].
+    """
+
+    def __init__(self, leaf_masks, links, seeds, *, n_inds: int, dims=2, output_mask=None,
+                 sparse_mask=None, n_projs: int | None = None, cost_type: str = "float64",
+                 disable_shared_inds: bool = False, node_masks=None, device: int = 0):
+        self._h = None
+        L = _lib.load()
+        if cost_type not in ("float64", "float32"):
+            raise NotImplementedError(f"cost_type={cost_type!r} is not supported on the GPU path "
+                                      "(float64 / float32 only).")
+        leaf_masks = np.ascontiguousarray(leaf_masks, np.uint64)
+        n = leaf_masks.shape[0]
+        W = n_words(n_inds)
+        if leaf_masks.shape != (n, W):
+            raise ValueError("'leaf_masks' has the wrong shape.")
+        N = 2 * n - 1
+        links = np.ascontiguousarray(links, np.int32)
+        seeds = np.ascontiguousarray(np.asarray(seeds, np.uint64) & np.uint64(0xFFFFFFFF), np.uint32)
+        R = len(seeds)
+        if links.shape == (3, N):
+            stride = 0
+        elif links.shape == (R, 3, N):
+            stride = 3 * N
+        else:
+            raise ValueError("'links' has the wrong shape.")
+        d = _lib.Desc()
+        d.n_leaves, d.n_inds, d.n_replicas = n, n_inds, R
+        d.leaf_masks = _ptr(leaf_masks)
+        om = None if output_mask is None else np.ascontiguousarray(output_mask, np.uint64)
+        d.output_mask = _ptr(om)
+        d.links, d.links_stride = _ptr(links), stride
+        nm = None
+        if node_masks is not None:
+            nm = np.ascontiguousarray(node_masks, np.uint64)
+            if nm.shape == (N, W):
+                d.node_masks_stride = 0
+            elif nm.shape == (R, N, W):
+                d.node_masks_stride = N * W
+            else:
+                raise ValueError("'node_masks' has the wrong shape.")
+            d.node_masks = _ptr(nm)
+        dv = None
+        if np.ndim(dims) == 0:
+            if int(dims) != dims or int(dims) <= 0:
+                raise ValueError("Dimensions must be positive numbers")
+            d.dim_uniform = int(dims)
+        else:
+            dv = np.ascontiguousarray(dims, np.uint64)
+            if dv.shape != (n_inds,):
+                raise ValueError("Wrong number of dimensions.")
+            d.dims = _ptr(dv)
+        sm = None
+        if sparse_mask is not None and np.any(np.asarray(sparse_mask)):
+            sm = np.ascontiguousarray(sparse_mask, np.uint64)
+            d.sparse_mask = _ptr(sm)
+            if not n_projs or n_projs <= 0:
+                raise RuntimeError("'n_projs' must be a positive number.")
+            d.n_projs = int(n_projs)
+        d.cost_dtype = _lib.F64 if cost_type == "float64" else _lib.F32
+        d.disable_shared_inds = int(bool(disable_shared_inds))
+        d.seeds = _ptr(seeds)
+        d.device = int(device)
+        h = C.c_void_p()
+        _lib.check(L.tnco_hip_create(C.byref(d), C.byref(h)))
+        self._h = h
+        self._L = L
+        self.n_leaves, self.n_nodes, self.n_inds, self.n_words, self.n_replicas = n, N, n_inds, W, R
+        self.cost_type = cost_type
+        self.device = int(device)
+
+    # -- lifetime -----------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._L.tnco_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- the hot path ---------------------------------------------------------
+    def run(self, betas, prob="mh", sync: bool = False) -> None:
+        """len(betas) sweeps per replica (one `update(prob)` per beta)."""
+        betas = np.ascontiguousarray(betas, np.float64)
+        kind = _PROB[prob.lower() if isinstance(prob, str) else prob]
+        _lib.check(self._L.tnco_hip_run(self._h, kind, _ptr(betas), len(betas)))
+        if sync:
+            self.sync()
+
+    def update(self, beta: float = 0.0, prob="mh") -> None:
+        self.run([beta], prob)
+
+    def sync(self) -> None:
+        _lib.check(self._L.tnco_hip_sync(self._h))
+
+    def set_stream(self, stream_ptr: int | None) -> None:
+        _lib.check(self._L.tnco_hip_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    # -- read-back ------------------------------------------------------------
+    def costs(self):
+        tot = np.empty(self.n_replicas, np.float64)
+        mn = np.empty(self.n_replicas, np.float64)
+        _lib.check(self._L.tnco_hip_get_costs(self._h, _ptr(tot), _ptr(mn)))
+        return tot, mn
+
+    @property
+    def total_cost(self) -> np.ndarray:
+        return self.costs()[0]
+
+    @property
+    def min_total_cost(self) -> np.ndarray:
+        return self.costs()[1]
+
+    def tree(self, replica: int, which_min: bool = False, with_masks: bool = True):
+        N, W = self.n_nodes, self.n_words
+        l, r, p = (np.empty(N, np.int32) for _ in range(3))
+        m = np.empty((N, W), np.uint64) if with_masks else None
+        _lib.check(self._L.tnco_hip_get_tree(self._h, int(replica), int(which_min), _ptr(l), _ptr(r), _ptr(p), _ptr(m)))
+        return l, r, p, m
+
+    def caches(self, replica: int):
+        N, W = self.n_nodes, self.n_words
+        cc, pc = np.empty(N, np.float64), np.empty(N, np.float64)
+        hy = np.empty((N, W), np.uint64)
+        _lib.check(self._L.tnco_hip_get_caches(self._h, int(replica), _ptr(cc), _ptr(pc), _ptr(hy)))
+        return cc, pc, hy
+
+    def validate(self, atol: float = 1e-5):
+        """(n_bad, first_bad): is_valid(atol) of every replica, recomputed on the device."""
+        nb, fb = C.c_int64(0), C.c_int64(-1)
+        _lib.check(self._L.tnco_hip_validate(self._h, float(atol), C.byref(nb), C.byref(fb)))
+        return nb.value, fb.value
+
+    def is_valid(self, atol: float = 1e-5) -> bool:
+        return self.validate(atol)[0] == 0
+
+    def prng_state(self, replica: int) -> np.ndarray:
+        out = np.empty(625, np.uint32)
+        _lib.check(self._L.tnco_hip_get_prng(self._h, int(replica), _ptr(out)))
+        return out
+
+    def set_prng_state(self, replica: int, state625) -> None:
+        st = np.ascontiguousarray(state625, np.uint32)
+        if st.shape != (625,):
+            raise ValueError("prng state must hold 625 words.")
+        _lib.check(self._L.tnco_hip_set_prng(self._h, int(replica), _ptr(st)))
+
+    def best(self, k: int = 1):
+        k = int(k)
+        c = np.empty(k, np.float64)
+        ids = np.empty(k, np.int64)
+        _lib.check(self._L.tnco_hip_best(self._h, k, _ptr(c), _ptr(ids)))
+        return c, ids
+
+    def counters(self) -> dict:
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _lib.check(self._L.tnco_hip_get_counters(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(moves=a.value, accepted=b.value, improved=c.value)
+
+    def moves_per_replica(self) -> np.ndarray:
+        out = np.empty(self.n_replicas, np.uint64)
+        _lib.check(self._L.tnco_hip_get_moves(self._h, _ptr(out)))
+        return out
+
+    def kernel_time_ms(self, reset: bool = False):
+        ms, n = C.c_double(0), C.c_int64(0)
+        _lib.check(self._L.tnco_hip_kernel_time(self._h, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
+    @property
+    def device_bytes(self) -> int:
+        return int(self._L.tnco_hip_device_bytes(self._h))

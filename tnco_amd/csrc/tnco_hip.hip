@@ -1,0 +1,794 @@
+// tnco_hip.hip -- C ABI (include/tnco_hip.h) over the gfx950 kernels of sa_kernels.h.
+// Host side: argument checking, device memory, launches, read-back.
+#include "../../include/tnco_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "sa_kernels.h"
+
+using namespace tnco;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(TNCO_HIP_ERUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+  } while (0)
+
+struct EventPair {
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct tnco_hip_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  Params P{};
+  int log2l = 0, L = 1;
+  bool hyper = false, generic = false;
+  std::vector<void*> allocs;
+  int64_t bytes = 0;
+  // host copies
+  std::vector<uint64_t> leafmask_w;  // [n][W]
+  std::vector<uint64_t> outmask_w;   // [W]
+  double* d_betas = nullptr;
+  int64_t betas_cap = 0;
+  std::vector<EventPair> pending, free_events;
+  double kernel_ms = 0;
+  int64_t launches = 0;
+
+  template <typename T>
+  hipError_t alloc(T** p, int64_t count) {
+    void* q = nullptr;
+    int64_t nb = std::max<int64_t>(count, 1) * (int64_t)sizeof(T);
+    hipError_t e = hipMalloc(&q, (size_t)nb);
+    if (e == hipSuccess) {
+      allocs.push_back(q);
+      bytes += nb;
+      *p = (T*)q;
+    }
+    return e;
+  }
+  void resolve_events() {
+    for (auto& ev : pending) {
+      float ms = 0;
+      if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess)
+        kernel_ms += ms;
+      free_events.push_back(ev);
+    }
+    pending.clear();
+  }
+  ~tnco_hip_ctx() {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    resolve_events();
+    for (auto& ev : free_events) {
+      (void)hipEventDestroy(ev.a);
+      (void)hipEventDestroy(ev.b);
+    }
+    for (void* p : allocs) (void)hipFree(p);
+    if (d_betas) (void)hipFree(d_betas);
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+  }
+};
+
+namespace {
+
+// ---- kernel dispatch over (LOG2L, HYPER, GENERIC) ---------------------------
+template <int LOG2L>
+void launch_run_l(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, dim3 grid) {
+  const Params& P = h->P;
+  hipStream_t s = h->stream;
+  if (h->hyper) {
+    if (h->generic)
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, true, true>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
+    else
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, true, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
+  } else {
+    if (h->generic)
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, false, true>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
+    else
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, false, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
+  }
+}
+
+#define DISPATCH_L(h, CALL)           \
+  switch ((h)->log2l) {               \
+    case 0: CALL(0); break;           \
+    case 1: CALL(1); break;           \
+    case 2: CALL(2); break;           \
+    case 3: CALL(3); break;           \
+    case 4: CALL(4); break;           \
+    case 5: CALL(5); break;           \
+    default: CALL(6); break;          \
+  }
+
+void launch_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind) {
+  const int gpb = 256 >> h->log2l;
+  dim3 grid((unsigned)((h->P.R + gpb - 1) / gpb));
+#define CALL_RUN(LL) launch_run_l<LL>(h, betas, n_steps, prob_kind, grid)
+  DISPATCH_L(h, CALL_RUN)
+#undef CALL_RUN
+}
+
+template <int LOG2L>
+void launch_build_l(tnco_hip_ctx* h, const Params& P, const BuildArgs& a) {
+  const int gpb = 256 >> LOG2L;
+  dim3 grid((unsigned)((a.count + gpb - 1) / gpb));
+  if (h->hyper)
+    hipLaunchKernelGGL((build_kernel<LOG2L, true>), grid, dim3(256), 0, h->stream, P, a);
+  else
+    hipLaunchKernelGGL((build_kernel<LOG2L, false>), grid, dim3(256), 0, h->stream, P, a);
+}
+void launch_build(tnco_hip_ctx* h, const Params& P, const BuildArgs& a) {
+#define CALL_BUILD(LL) launch_build_l<LL>(h, P, a)
+  DISPATCH_L(h, CALL_BUILD)
+#undef CALL_BUILD
+}
+
+template <int LOG2L>
+void launch_compare_l(tnco_hip_ctx* h, const BuildArgs& a, double atol, int32_t* out_bad) {
+  const int gpb = 256 >> LOG2L;
+  dim3 grid((unsigned)((a.count + gpb - 1) / gpb));
+  if (h->hyper)
+    hipLaunchKernelGGL((compare_kernel<LOG2L, true>), grid, dim3(256), 0, h->stream, h->P, a, atol, out_bad);
+  else
+    hipLaunchKernelGGL((compare_kernel<LOG2L, false>), grid, dim3(256), 0, h->stream, h->P, a, atol, out_bad);
+}
+void launch_compare(tnco_hip_ctx* h, const BuildArgs& a, double atol, int32_t* out_bad) {
+#define CALL_CMP(LL) launch_compare_l<LL>(h, a, atol, out_bad)
+  DISPATCH_L(h, CALL_CMP)
+#undef CALL_CMP
+}
+
+__global__ void finish_init_kernel(Params P, const double* sum, const double* total) {
+  const int64_t r = blockIdx.x;
+  const NodeRec* rec = P.rec + r * (int64_t)P.N;
+  Links* ml = P.minlinks + r * (int64_t)P.N;
+  for (int i = threadIdx.x; i < P.N; i += blockDim.x) {
+    Links o;
+    o.left = rec[i].left; o.right = rec[i].right; o.parent = rec[i].parent; o.pad = 0;
+    ml[i] = o;
+  }
+  if (threadIdx.x == 0) {
+    ReplicaState* rs = P.rs + r;
+    rs->min_cost = sum[r];
+    rs->init_total = total[r];
+    rs->n_moves = 0; rs->n_accepted = 0; rs->n_improved = 0;
+    rs->status = 0; rs->pad = 0; rs->pad2 = 0;
+  }
+}
+
+// ---- host-side tree checks: Node::is_valid (include/tnco/node.hpp:72-107) +
+// Tree::is_valid (include/tnco/tree.hpp:58-139) -----------------------------
+const char* tree_check(int32_t N, const int32_t* left, const int32_t* right, const int32_t* parent,
+                       std::vector<int32_t>& cp, std::vector<int32_t>& cc) {
+  const int32_t n = (N + 1) / 2;
+  int roots = 0, leaves = 0;
+  for (int32_t i = 0; i < N; ++i) {
+    const int32_t xs[3] = {parent[i], left[i], right[i]};
+    for (int k = 0; k < 3; ++k)
+      if (!(xs[k] == -1 || (xs[k] >= 0 && xs[k] < N))) return "Nodes are not valid";
+    if ((left[i] < 0) != (right[i] < 0)) return "Nodes are not valid";
+    if (left[i] >= 0 && left[i] == right[i]) return "Nodes are not valid";
+    if (left[i] >= 0 && parent[i] >= 0 && (parent[i] == left[i] || parent[i] == right[i]))
+      return "Nodes are not valid";
+    roots += parent[i] < 0;
+    leaves += left[i] < 0;
+  }
+  if (parent[N - 1] != -1) return "Last node should be root.";
+  if (roots != 1) return "There should be only one root.";
+  for (int32_t i = 0; i < n; ++i)
+    if (left[i] >= 0) return "All leaves should be first.";
+  if (leaves != n) return "Number of nodes is not constenst with the number of leaves.";
+  std::fill(cp.begin(), cp.end(), 0);
+  std::fill(cc.begin(), cc.end(), 0);
+  for (int32_t i = 0; i < N; ++i) {
+    if (left[i] >= 0) { cc[left[i]]++; cc[right[i]]++; }
+    if (parent[i] >= 0) cp[parent[i]]++;
+  }
+  for (int32_t i = 0; i < N; ++i) {
+    if (cp[i] != (left[i] < 0 ? 0 : 2)) return "Tree is not valid.";
+    if (cc[i] != (parent[i] < 0 ? 0 : 1)) return "Tree is not valid.";
+    if (left[i] >= 0 && (parent[left[i]] != i || parent[right[i]] != i)) return "Tree is not valid.";
+  }
+  return nullptr;
+}
+
+// Post-order of include/tnco/utils.hpp:34-51.
+void host_traverse(int32_t N, const int32_t* left, const int32_t* right, std::vector<int32_t>& order) {
+  std::vector<int32_t> stack;
+  std::vector<uint8_t> visited((size_t)N, 0);
+  order.clear();
+  stack.push_back(N - 1);
+  while (!stack.empty()) {
+    const int32_t pos = stack.back();
+    if (visited[pos] || left[pos] < 0) {
+      stack.pop_back();
+      order.push_back(pos);
+    } else {
+      visited[pos] = 1;
+      stack.push_back(right[pos]);
+      stack.push_back(left[pos]);
+    }
+  }
+}
+
+// Legs of every node from the leaves (tnco/ctree.py:163-189).
+void host_derive(const tnco_hip_ctx* h, const int32_t* left, const int32_t* right, uint64_t* masks) {
+  const int n = h->P.n, N = h->P.N, W = h->P.W;
+  std::vector<int32_t> order;
+  host_traverse(N, left, right, order);
+  std::vector<uint64_t> uni((size_t)N * W), outside((size_t)N * W, 0);
+  std::memcpy(uni.data(), h->leafmask_w.data(), sizeof(uint64_t) * (size_t)n * W);
+  std::memcpy(masks, h->leafmask_w.data(), sizeof(uint64_t) * (size_t)n * W);
+  for (int32_t p : order)
+    if (left[p] >= 0)
+      for (int w = 0; w < W; ++w) uni[(size_t)p * W + w] = uni[(size_t)left[p] * W + w] | uni[(size_t)right[p] * W + w];
+  for (int w = 0; w < W; ++w) outside[(size_t)(N - 1) * W + w] = h->outmask_w[w];
+  for (auto it = order.rbegin(); it != order.rend(); ++it) {
+    const int32_t p = *it;
+    if (left[p] < 0) continue;
+    for (int w = 0; w < W; ++w) {
+      outside[(size_t)left[p] * W + w] = outside[(size_t)p * W + w] | uni[(size_t)right[p] * W + w];
+      outside[(size_t)right[p] * W + w] = outside[(size_t)p * W + w] | uni[(size_t)left[p] * W + w];
+    }
+  }
+  for (int32_t p : order)
+    if (left[p] >= 0)
+      for (int w = 0; w < W; ++w) {
+        const uint64_t a = masks[(size_t)left[p] * W + w], b = masks[(size_t)right[p] * W + w];
+        masks[(size_t)p * W + w] = (a ^ b) | (a & b & outside[(size_t)p * W + w]);
+      }
+}
+
+const char* status_message(int st) {
+  switch (st) {
+    case 10:
+    case 11: return "Contraction is not valid.";
+    case 12: return "'node_masks' leaves differ from 'leaf_masks'.";
+    default: return "Tree is not valid.";
+  }
+}
+
+bool bad_log2(double x) {
+  const double l = std::log2(x);
+  return std::isinf(l) || std::isnan(l);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tnco_hip_last_error(void) { return g_err.c_str(); }
+const char* tnco_hip_version(void) { return "tnco_hip 0.1 (gfx950)"; }
+
+int tnco_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void tnco_hip_destroy(tnco_hip_handle h) { delete h; }
+
+int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
+  if (!d || !out) return fail(TNCO_HIP_EINVAL, "null argument.");
+  *out = nullptr;
+  if (d->n_leaves < 2) return fail(TNCO_HIP_EINVAL, "Precision is too low.");  // total cost 0 -> log2 = -inf (optimizer.hpp:77-80)
+  if (d->n_inds < 0 || d->n_replicas <= 0) return fail(TNCO_HIP_EINVAL, "'n_inds' / 'n_replicas' are not valid.");
+  if (!d->leaf_masks || !d->links || !d->seeds) return fail(TNCO_HIP_EINVAL, "null input array.");
+  if (d->cost_dtype != TNCO_HIP_F64 && d->cost_dtype != TNCO_HIP_F32)
+    return fail(TNCO_HIP_ENOTIMPL, "cost_type must be float64 or float32.");
+  const int n = d->n_leaves, N = 2 * n - 1, I = d->n_inds;
+  const int W = std::max(1, (I + 63) / 64);
+  if (W > 64) return fail(TNCO_HIP_ENOTIMPL, "more than 4096 indices are not supported yet.");
+  if (d->sparse_mask && d->n_projs == 0) return fail(TNCO_HIP_ERUNTIME, "'n_projs' must be a positive number.");
+  const int64_t R = d->n_replicas;
+
+  // dims (include/tnco/ctree.hpp:79-89, 121-135)
+  bool uniform = true;
+  uint64_t dim_u = d->dim_uniform;
+  if (d->dims) {
+    for (int i = 0; i < I; ++i)
+      if (d->dims[i] == 0) return fail(TNCO_HIP_EINVAL, "Dimensions must be positive numbers");
+    for (int i = 1; i < I; ++i) uniform &= d->dims[i] == d->dims[0];
+    if (I > 0 && uniform) dim_u = d->dims[0];
+    if (I == 0) uniform = false;
+  }
+  if (uniform && dim_u == 0) return fail(TNCO_HIP_EINVAL, "Dimensions must be positive numbers");
+
+  // host-side structural validation of every tree
+  {
+    const int64_t ntrees = d->links_stride == 0 ? 1 : R;
+    const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ntrees / 64 + 1, 16), std::thread::hardware_concurrency()));
+    std::vector<const char*> errs((size_t)nth, nullptr);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nth; ++t)
+      th.emplace_back([&, t]() {
+        std::vector<int32_t> cp((size_t)N), cc((size_t)N);
+        for (int64_t r = t; r < ntrees && !errs[t]; r += nth) {
+          const int32_t* lk = d->links + r * d->links_stride;
+          errs[t] = tree_check(N, lk, lk + N, lk + 2 * (int64_t)N, cp, cc);
+        }
+      });
+    for (auto& x : th) x.join();
+    for (auto e : errs)
+      if (e) return fail(TNCO_HIP_EINVAL, e);
+  }
+
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (d->device < 0 || d->device >= ndev) return fail(TNCO_HIP_EINVAL, "'device' is not valid.");
+  HIP_TRY(hipSetDevice(d->device));
+
+  tnco_hip_ctx* h = new tnco_hip_ctx();
+  struct Guard {
+    tnco_hip_ctx* h;
+    ~Guard() { delete h; }
+  } guard{h};
+  h->device = d->device;
+  HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+  h->stream = h->own_stream;
+
+  int log2l = 0;
+  while ((1 << log2l) < W) ++log2l;
+  h->log2l = log2l;
+  h->L = 1 << log2l;
+  const int L = h->L;
+
+  // hyper legs present?  (an index held by more than two of {leaves, output})
+  h->leafmask_w.assign(d->leaf_masks, d->leaf_masks + (size_t)n * W);
+  h->outmask_w.assign((size_t)W, 0);
+  if (d->output_mask) h->outmask_w.assign(d->output_mask, d->output_mask + W);
+  {
+    std::vector<int> cnt((size_t)W * 64, 0);
+    for (int t = 0; t < n; ++t)
+      for (int p = 0; p < W * 64; ++p) cnt[p] += (int)((h->leafmask_w[(size_t)t * W + (p >> 6)] >> (p & 63)) & 1);
+    bool hy = d->node_masks != nullptr;
+    for (int p = 0; p < W * 64; ++p) {
+      const int c = cnt[p] + (int)((h->outmask_w[p >> 6] >> (p & 63)) & 1);
+      if (c > 2) hy = true;
+      if (p >= I && cnt[p]) return fail(TNCO_HIP_EINVAL, "index position out of range in 'leaf_masks'.");
+    }
+    h->hyper = hy;
+  }
+  const bool f32 = d->cost_dtype == TNCO_HIP_F32;
+  const bool pow2u = uniform && (dim_u & (dim_u - 1)) == 0;
+  h->generic = !(pow2u && !d->sparse_mask && !f32);
+
+  Params& P = h->P;
+  P.n = n; P.N = N; P.I = I; P.W = W; P.R = R;
+  P.f32 = f32; P.disable_shared = d->disable_shared_inds ? 1 : 0;
+  P.cost_mode = uniform ? (pow2u ? 0 : 1) : 2;
+  P.log2d = 0;
+  if (pow2u) while ((1ull << P.log2d) < dim_u) ++P.log2d;
+  auto rc = [&](double x) { return f32 ? (double)(float)x : x; };
+  P.n_projs = d->sparse_mask ? rc((double)d->n_projs) : 0.0;
+
+  HIP_TRY(h->alloc(&P.rec, R * N));
+  HIP_TRY(h->alloc(&P.imask, R * (int64_t)(n - 1) * L));
+  if (h->hyper) HIP_TRY(h->alloc(&P.hyper, R * (int64_t)(n - 1) * L));
+  HIP_TRY(h->alloc(&P.mt, R * 624));
+  HIP_TRY(h->alloc(&P.rs, R));
+  HIP_TRY(h->alloc(&P.minlinks, R * N));
+
+  // shared tables
+  {
+    std::vector<uint64_t> lm((size_t)n * L, 0), om((size_t)L, 0), sp((size_t)L, 0);
+    for (int t = 0; t < n; ++t)
+      for (int w = 0; w < W; ++w) lm[(size_t)t * L + w] = h->leafmask_w[(size_t)t * W + w];
+    for (int w = 0; w < W; ++w) om[w] = h->outmask_w[w];
+    uint64_t *dl, *dom;
+    HIP_TRY(h->alloc(&dl, (int64_t)n * L));
+    HIP_TRY(h->alloc(&dom, L));
+    HIP_TRY(hipMemcpy(dl, lm.data(), lm.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dom, om.data(), om.size() * 8, hipMemcpyHostToDevice));
+    P.leafmask = dl;
+    P.outmask = dom;
+    if (d->sparse_mask) {
+      for (int w = 0; w < W; ++w) sp[w] = d->sparse_mask[w];
+      uint64_t* dsp;
+      HIP_TRY(h->alloc(&dsp, L));
+      HIP_TRY(hipMemcpy(dsp, sp.data(), sp.size() * 8, hipMemcpyHostToDevice));
+      P.sparse = dsp;
+    }
+    if (P.cost_mode == 1) {
+      // std::pow(size_t, size_t) -> double pow, converted to cost_type (simple.hpp:45)
+      std::vector<double> tab((size_t)W * 64 + 1);
+      for (size_t k = 0; k < tab.size(); ++k) tab[k] = rc(std::pow((double)dim_u, (double)k));
+      double* dt;
+      HIP_TRY(h->alloc(&dt, (int64_t)tab.size()));
+      HIP_TRY(hipMemcpy(dt, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+      P.ctab = dt;
+    } else if (P.cost_mode == 2) {
+      std::vector<double> dd((size_t)L * 64, 1.0);
+      for (int i = 0; i < I; ++i) dd[i] = rc((double)d->dims[i]);
+      double* dt;
+      HIP_TRY(h->alloc(&dt, (int64_t)dd.size()));
+      HIP_TRY(hipMemcpy(dt, dd.data(), dd.size() * 8, hipMemcpyHostToDevice));
+      P.dimsd = dt;
+    }
+  }
+
+  // seeds -> MT state
+  {
+    uint32_t* dseeds = nullptr;
+    HIP_TRY(hipMalloc((void**)&dseeds, (size_t)R * 4));
+    hipError_t e = hipMemcpy(dseeds, d->seeds, (size_t)R * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(mt_seed_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, h->stream, P.mt, P.rs, dseeds, R);
+      e = hipStreamSynchronize(h->stream);
+    }
+    (void)hipFree(dseeds);
+    HIP_TRY(e);
+  }
+
+  // links (+ optional explicit legs) -> caches
+  {
+    const int64_t ntrees = d->links_stride == 0 ? 1 : R;
+    int32_t* dlinks = nullptr;
+    uint64_t* dmasks = nullptr;
+    double *dtotal = nullptr, *dsum = nullptr;
+    int32_t* dstatus = nullptr;
+    std::vector<double> total((size_t)R), sum((size_t)R);
+    std::vector<int32_t> status((size_t)R);
+    auto cleanup = [&]() {
+      (void)hipFree(dlinks); (void)hipFree(dmasks); (void)hipFree(dtotal); (void)hipFree(dsum); (void)hipFree(dstatus);
+    };
+    hipError_t e = hipMalloc((void**)&dlinks, (size_t)ntrees * 3 * N * 4);
+    if (e == hipSuccess) {
+      if (d->links_stride == 0 || d->links_stride == 3 * (int64_t)N)
+        e = hipMemcpy(dlinks, d->links, (size_t)ntrees * 3 * N * 4, hipMemcpyHostToDevice);
+      else
+        e = hipMemcpy2D(dlinks, (size_t)3 * N * 4, d->links, (size_t)d->links_stride * 4, (size_t)3 * N * 4, (size_t)ntrees, hipMemcpyHostToDevice);
+    }
+    const int64_t nmasks = d->node_masks ? (d->node_masks_stride == 0 ? 1 : R) : 0;
+    if (e == hipSuccess && nmasks) {
+      e = hipMalloc((void**)&dmasks, (size_t)nmasks * N * W * 8);
+      if (e == hipSuccess) {
+        if (d->node_masks_stride == 0 || d->node_masks_stride == (int64_t)N * W)
+          e = hipMemcpy(dmasks, d->node_masks, (size_t)nmasks * N * W * 8, hipMemcpyHostToDevice);
+        else
+          e = hipMemcpy2D(dmasks, (size_t)N * W * 8, d->node_masks, (size_t)d->node_masks_stride * 8, (size_t)N * W * 8, (size_t)nmasks, hipMemcpyHostToDevice);
+      }
+    }
+    if (e == hipSuccess) e = hipMalloc((void**)&dtotal, (size_t)R * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&dsum, (size_t)R * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&dstatus, (size_t)R * 4);
+    if (e == hipSuccess) {
+      BuildArgs a{};
+      a.in_links = dlinks;
+      a.in_links_stride = d->links_stride == 0 ? 0 : 3 * (int64_t)N;
+      a.in_masks = dmasks;
+      a.in_masks_stride = (d->node_masks && d->node_masks_stride != 0) ? (int64_t)N * W : 0;
+      a.out_rec = P.rec; a.out_imask = P.imask; a.out_hyper = P.hyper;
+      a.scratch = reinterpret_cast<int32_t*>(P.minlinks);  // 16 B * N per replica = 4N int32
+      a.out_total = dtotal; a.out_sum = dsum; a.out_status = dstatus;
+      a.r0 = 0; a.count = R;
+      launch_build(h, P, a);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+      if (e == hipSuccess) e = hipMemcpy(total.data(), dtotal, (size_t)R * 8, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(sum.data(), dsum, (size_t)R * 8, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(status.data(), dstatus, (size_t)R * 4, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(finish_init_kernel, dim3((unsigned)R), dim3(64), 0, h->stream, P, dsum, dtotal);
+        e = hipStreamSynchronize(h->stream);
+      }
+    }
+    cleanup();
+    HIP_TRY(e);
+    for (int64_t r = 0; r < R; ++r)
+      if (status[r]) return fail(TNCO_HIP_EINVAL, status_message(status[r]));
+    for (int64_t r = 0; r < R; ++r)
+      if (bad_log2(total[r]) || bad_log2(sum[r])) return fail(TNCO_HIP_EINVAL, "Precision is too low.");
+  }
+
+  guard.h = nullptr;
+  *out = h;
+  return TNCO_HIP_OK;
+}
+
+int tnco_hip_set_stream(tnco_hip_handle h, void* s) {
+  if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->stream = s ? (hipStream_t)s : h->own_stream;
+  return TNCO_HIP_OK;
+}
+
+int tnco_hip_sync(tnco_hip_handle h) {
+  if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return TNCO_HIP_OK;
+}
+
+int tnco_hip_run(tnco_hip_handle h, int prob_kind, const double* betas, int64_t n_steps) {
+  if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
+  if (prob_kind < 0 || prob_kind > 2) return fail(TNCO_HIP_EINVAL, "'prob_kind' is not valid.");
+  if (n_steps < 0 || (n_steps > 0 && !betas)) return fail(TNCO_HIP_EINVAL, "'betas' is not valid.");
+  if (n_steps == 0) return TNCO_HIP_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  if (n_steps > h->betas_cap) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->d_betas) (void)hipFree(h->d_betas);
+    h->d_betas = nullptr;
+    HIP_TRY(hipMalloc((void**)&h->d_betas, (size_t)n_steps * 8));
+    h->betas_cap = n_steps;
+  } else {
+    // the previous launch may still be reading d_betas
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(h->d_betas, betas, (size_t)n_steps * 8, hipMemcpyHostToDevice, h->stream));
+  EventPair ev;
+  if (!h->free_events.empty()) {
+    ev = h->free_events.back();
+    h->free_events.pop_back();
+  } else {
+    HIP_TRY(hipEventCreate(&ev.a));
+    HIP_TRY(hipEventCreate(&ev.b));
+  }
+  HIP_TRY(hipEventRecord(ev.a, h->stream));
+  launch_run(h, h->d_betas, n_steps, prob_kind);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ev.b, h->stream));
+  h->pending.push_back(ev);
+  h->launches++;
+  if (h->pending.size() > 256) h->resolve_events();
+  return TNCO_HIP_OK;
+}
+
+int tnco_hip_kernel_time(tnco_hip_handle h, double* ms, int64_t* launches, int reset) {
+  if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->resolve_events();
+  if (ms) *ms = h->kernel_ms;
+  if (launches) *launches = h->launches;
+  if (reset) {
+    h->kernel_ms = 0;
+    h->launches = 0;
+  }
+  return TNCO_HIP_OK;
+}
+
+int64_t tnco_hip_device_bytes(tnco_hip_handle h) { return h ? h->bytes : 0; }
+
+static int fetch_rs(tnco_hip_handle h, std::vector<ReplicaState>& rs) {
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  rs.resize((size_t)h->P.R);
+  HIP_TRY(hipMemcpy(rs.data(), h->P.rs, (size_t)h->P.R * sizeof(ReplicaState), hipMemcpyDeviceToHost));
+  return TNCO_HIP_OK;
+}
+
+int tnco_hip_get_costs(tnco_hip_handle h, double* total_cost, double* min_total_cost) {
+  if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
+  const int64_t R = h->P.R;
+  const int N = h->P.N;
+  if (min_total_cost) {
+    std::vector<ReplicaState> rs;
+    if (int rc = fetch_rs(h, rs)) return rc;
+    for (int64_t r = 0; r < R; ++r) min_total_cost[r] = rs[r].min_cost;
+  }
+  if (total_cost) {
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    // partial of the root record of every replica (strided gather)
+    HIP_TRY(hipMemcpy2D(total_cost, 8, reinterpret_cast<const char*>(h->P.rec + (N - 1)) + offsetof(NodeRec, partial),
+                        (size_t)N * sizeof(NodeRec), 8, (size_t)R, hipMemcpyDeviceToHost));
+  }
+  return TNCO_HIP_OK;
+}
+
+int tnco_hip_get_tree(tnco_hip_handle h, int64_t r, int which, int32_t* left, int32_t* right,
+                      int32_t* parent, uint64_t* masks) {
+  if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
+  if (r < 0 || r >= h->P.R) return fail(TNCO_HIP_EINVAL, "'replica' out of range.");
+  if (!left || !right || !parent) return fail(TNCO_HIP_EINVAL, "null output array.");
+  const int n = h->P.n, N = h->P.N, W = h->P.W, L = h->L;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (which == 0) {
+    std::vector<NodeRec> rec((size_t)N);
+    HIP_TRY(hipMemcpy(rec.data(), h->P.rec + r * (int64_t)N, (size_t)N * sizeof(NodeRec), hipMemcpyDeviceToHost));
+    for (int i = 0; i < N; ++i) { left[i] = rec[i].left; right[i] = rec[i].right; parent[i] = rec[i].parent; }
+    if (masks) {
+      std::vector<uint64_t> im((size_t)(n - 1) * L);
+      HIP_TRY(hipMemcpy(im.data(), h->P.imask + r * (int64_t)(n - 1) * L, im.size() * 8, hipMemcpyDeviceToHost));
+      std::memcpy(masks, h->leafmask_w.data(), (size_t)n * W * 8);
+      for (int p = n; p < N; ++p)
+        for (int w = 0; w < W; ++w) masks[(size_t)p * W + w] = im[(size_t)(p - n) * L + w];
+    }
+  } else {
+    std::vector<Links> lk((size_t)N);
+    HIP_TRY(hipMemcpy(lk.data(), h->P.minlinks + r * (int64_t)N, (size_t)N * sizeof(Links), hipMemcpyDeviceToHost));
+    for (int i = 0; i < N; ++i) { left[i] = lk[i].left; right[i] = lk[i].right; parent[i] = lk[i].parent; }
+    if (masks) host_derive(h, left, right, masks);
+  }
+  return TNCO_HIP_OK;
+}
+
+int tnco_hip_get_caches(tnco_hip_handle h, int64_t r, double* ccost, double* partial, uint64_t* hyper) {
+  if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
+  if (r < 0 || r >= h->P.R) return fail(TNCO_HIP_EINVAL, "'replica' out of range.");
+  const int n = h->P.n, N = h->P.N, W = h->P.W, L = h->L;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  std::vector<NodeRec> rec((size_t)N);
+  HIP_TRY(hipMemcpy(rec.data(), h->P.rec + r * (int64_t)N, (size_t)N * sizeof(NodeRec), hipMemcpyDeviceToHost));
+  for (int i = 0; i < N; ++i) {
+    if (ccost) ccost[i] = rec[i].ccost;
+    if (partial) partial[i] = rec[i].partial;
+  }
+  if (hyper) {
+    std::memset(hyper, 0, (size_t)N * W * 8);
+    if (h->hyper) {
+      std::vector<uint64_t> hy((size_t)(n - 1) * L);
+      HIP_TRY(hipMemcpy(hy.data(), h->P.hyper + r * (int64_t)(n - 1) * L, hy.size() * 8, hipMemcpyDeviceToHost));
+      for (int p = n; p < N; ++p)
+        for (int w = 0; w < W; ++w) hyper[(size_t)p * W + w] = hy[(size_t)(p - n) * L + w];
+    }
+  }
+  return TNCO_HIP_OK;
+}
+
+int tnco_hip_validate(tnco_hip_handle h, double atol, int64_t* n_bad, int64_t* first_bad) {
+  if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
+  const Params& P = h->P;
+  const int n = P.n, N = P.N, L = h->L;
+  const int64_t R = P.R;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const int64_t per = (int64_t)N * sizeof(NodeRec) + (int64_t)(n - 1) * L * 8 * (h->hyper ? 2 : 1) + (int64_t)N * 16 + 64;
+  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(R, ((int64_t)1 << 30) / per));
+  NodeRec* trec = nullptr; uint64_t *tim = nullptr, *thy = nullptr; int32_t *tscr = nullptr, *tstat = nullptr, *tbad = nullptr;
+  double *ttot = nullptr, *tsum = nullptr;
+  auto cleanup = [&]() {
+    (void)hipFree(trec); (void)hipFree(tim); (void)hipFree(thy); (void)hipFree(tscr);
+    (void)hipFree(tstat); (void)hipFree(tbad); (void)hipFree(ttot); (void)hipFree(tsum);
+  };
+  hipError_t e = hipMalloc((void**)&trec, (size_t)chunk * N * sizeof(NodeRec));
+  if (e == hipSuccess) e = hipMalloc((void**)&tim, (size_t)chunk * (n - 1) * L * 8);
+  if (e == hipSuccess && h->hyper) e = hipMalloc((void**)&thy, (size_t)chunk * (n - 1) * L * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&tscr, (size_t)chunk * 4 * N * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&tstat, (size_t)chunk * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&tbad, (size_t)chunk * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&ttot, (size_t)chunk * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&tsum, (size_t)chunk * 8);
+  int64_t bad = 0, first = -1;
+  std::vector<ReplicaState> rs;
+  if (e == hipSuccess && fetch_rs(h, rs) != TNCO_HIP_OK) e = hipErrorUnknown;
+  std::vector<int32_t> hb((size_t)chunk), hs((size_t)chunk);
+  std::vector<double> hsum((size_t)chunk);
+  for (int64_t r0 = 0; r0 < R && e == hipSuccess; r0 += chunk) {
+    const int64_t cnt = std::min(chunk, R - r0);
+    BuildArgs a{};
+    a.out_rec = trec; a.out_imask = tim; a.out_hyper = thy; a.scratch = tscr;
+    a.out_total = ttot; a.out_sum = tsum; a.out_status = tstat; a.r0 = r0; a.count = cnt;
+    // (1) current tree: rebuild everything and compare
+    a.src_rec = P.rec;
+    launch_build(h, P, a);
+    launch_compare(h, a, atol, tbad);
+    e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(hb.data(), tbad, (size_t)cnt * 4, hipMemcpyDeviceToHost);
+    // (2) best tree: its cost must match min_total_cost
+    if (e == hipSuccess) {
+      a.src_rec = nullptr;
+      a.src_links = P.minlinks;
+      launch_build(h, P, a);
+      e = hipStreamSynchronize(h->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(hs.data(), tstat, (size_t)cnt * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(hsum.data(), tsum, (size_t)cnt * 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) break;
+    for (int64_t q = 0; q < cnt; ++q) {
+      bool b = hb[q] != 0 || hs[q] != 0;
+      const double x = hsum[q], y = rs[r0 + q].min_cost;
+      bool close = !(x < 0 || y < 0) && ((x == 0 || y == 0) ? (x == y) : (std::fabs(std::log(x) - std::log(y)) <= atol));
+      if (!close) b = true;
+      if (b) { ++bad; if (first < 0) first = r0 + q; }
+    }
+  }
+  cleanup();
+  HIP_TRY(e);
+  if (n_bad) *n_bad = bad;
+  if (first_bad) *first_bad = first;
+  return TNCO_HIP_OK;
+}
+
+int tnco_hip_get_prng(tnco_hip_handle h, int64_t r, uint32_t* out) {
+  if (!h || !out) return fail(TNCO_HIP_EINVAL, "null argument.");
+  if (r < 0 || r >= h->P.R) return fail(TNCO_HIP_EINVAL, "'replica' out of range.");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  ReplicaState rs;
+  HIP_TRY(hipMemcpy(&rs, h->P.rs + r, sizeof(rs), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, h->P.mt + r * 624, 624 * 4, hipMemcpyDeviceToHost));
+  // finish the lazily generated block sequence so the 624 words are what
+  // libstdc++ holds after _M_gen_rand() (random.tcc:396-430)
+  if (rs.mti < 624) {
+    for (int k = rs.mtw; k < 624; ++k) {
+      const uint32_t y = (out[k] & 0x80000000u) | (out[(k + 1) % 624] & 0x7fffffffu);
+      out[k] = out[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+  }
+  out[624] = (uint32_t)rs.mti;
+  return TNCO_HIP_OK;
+}
+
+int tnco_hip_set_prng(tnco_hip_handle h, int64_t r, const uint32_t* in) {
+  if (!h || !in) return fail(TNCO_HIP_EINVAL, "null argument.");
+  if (r < 0 || r >= h->P.R) return fail(TNCO_HIP_EINVAL, "'replica' out of range.");
+  if (in[624] > 624) return fail(TNCO_HIP_EINVAL, "prng position out of range.");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  ReplicaState rs;
+  HIP_TRY(hipMemcpy(&rs, h->P.rs + r, sizeof(rs), hipMemcpyDeviceToHost));
+  rs.mti = (int32_t)in[624];
+  rs.mtw = 624;
+  HIP_TRY(hipMemcpy(h->P.mt + r * 624, in, 624 * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->P.rs + r, &rs, sizeof(rs), hipMemcpyHostToDevice));
+  return TNCO_HIP_OK;
+}
+
+int tnco_hip_best(tnco_hip_handle h, int64_t k, double* costs, int64_t* replicas) {
+  if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
+  if (k < 0 || k > h->P.R) return fail(TNCO_HIP_EINVAL, "'k' out of range.");
+  std::vector<ReplicaState> rs;
+  if (int rc = fetch_rs(h, rs)) return rc;
+  std::vector<int64_t> idx((size_t)h->P.R);
+  std::iota(idx.begin(), idx.end(), (int64_t)0);
+  auto less = [&](int64_t a, int64_t b) {
+    return rs[a].min_cost < rs[b].min_cost || (rs[a].min_cost == rs[b].min_cost && a < b);
+  };
+  std::partial_sort(idx.begin(), idx.begin() + k, idx.end(), less);
+  for (int64_t i = 0; i < k; ++i) {
+    if (costs) costs[i] = rs[idx[i]].min_cost;
+    if (replicas) replicas[i] = idx[i];
+  }
+  return TNCO_HIP_OK;
+}
+
+int tnco_hip_get_counters(tnco_hip_handle h, uint64_t* moves, uint64_t* accepted, uint64_t* improved) {
+  if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
+  std::vector<ReplicaState> rs;
+  if (int rc = fetch_rs(h, rs)) return rc;
+  uint64_t m = 0, a = 0, i = 0;
+  for (auto& x : rs) { m += x.n_moves; a += x.n_accepted; i += x.n_improved; }
+  if (moves) *moves = m;
+  if (accepted) *accepted = a;
+  if (improved) *improved = i;
+  return TNCO_HIP_OK;
+}
+
+int tnco_hip_get_moves(tnco_hip_handle h, uint64_t* out) {
+  if (!h || !out) return fail(TNCO_HIP_EINVAL, "null argument.");
+  std::vector<ReplicaState> rs;
+  if (int rc = fetch_rs(h, rs)) return rc;
+  for (size_t r = 0; r < rs.size(); ++r) out[r] = rs[r].n_moves;
+  return TNCO_HIP_OK;
+}
+
+}  // extern "C"
