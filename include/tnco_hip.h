@@ -132,9 +132,11 @@ int tnco_hip_set_prng(tnco_hip_handle h, int64_t replica, const uint32_t* state6
 int tnco_hip_best(tnco_hip_handle h, int64_t k, double* costs, int64_t* replicas);
 
 /* Work counters summed over replicas: move evaluations (iterations of the
- * while loop at optimizer.hpp:117-192), accepted moves, best-tree updates. */
+ * while loop at optimizer.hpp:117-192), accepted moves, best-tree updates, and
+ * moves whose (D, E) order was drawn at random (optimize/optimizer.hpp:135-141).
+ * Any pointer may be NULL. */
 int tnco_hip_get_counters(tnco_hip_handle h, uint64_t* moves, uint64_t* accepted,
-                          uint64_t* improved);
+                          uint64_t* improved, uint64_t* random_picks);
 /* Per replica move counter ([n_replicas]). */
 int tnco_hip_get_moves(tnco_hip_handle h, uint64_t* moves_per_replica);
 

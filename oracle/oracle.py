@@ -92,6 +92,10 @@ def lib():
             getattr(L, pf + "get_counters").argtypes = [C.c_void_p, _u64p]
             getattr(L, pf + "get_slices_out").argtypes = [C.c_void_p, _u64p, _u64p]
             getattr(L, pf + "get_widths").argtypes = [C.c_void_p, _f64p]
+            f = getattr(L, pf + "run_batch")
+            f.restype = C.c_double
+            f.argtypes = [C.c_int64, C.c_int32, C.c_int32, _i32p, _u64p, C.c_void_p, C.c_uint64, _u32p,
+                          C.c_int, _f64p, C.c_int64, C.c_int, _f64p, _f64p, _u64p]
             f = getattr(L, pf + "prob")
             f.restype = C.c_double if pf == "orc_f64_" else C.c_float
             ct = C.c_double if pf == "orc_f64_" else C.c_float
@@ -287,6 +291,24 @@ class Oracle:
         w = np.zeros(self.N, np.float64)
         self._f("get_widths")(self._h, w)
         return w
+
+
+def run_batch(links, leaf_masks, seeds, betas, *, n_inds, dims=2, output_mask=None,
+              prob_kind=PROB_MH, n_threads=0, cost_type="float64"):
+    """R replicas over OpenMP threads; returns (seconds in the update loops, total, min, moves)."""
+    pf = {"float64": "orc_f64_", "float32": "orc_f32_"}[cost_type]
+    links = np.ascontiguousarray(links, np.int32)
+    R, _, N = links.shape
+    leaf_masks = np.ascontiguousarray(leaf_masks, np.uint64)
+    seeds = np.ascontiguousarray(np.asarray(seeds, np.uint64) & np.uint64(0xFFFFFFFF), np.uint32)
+    betas = np.ascontiguousarray(betas, np.float64)
+    om = None if output_mask is None else np.ascontiguousarray(output_mask, np.uint64)
+    tot, mn = np.empty(R, np.float64), np.empty(R, np.float64)
+    mv = np.zeros(R, np.uint64)
+    dt = getattr(lib(), pf + "run_batch")(R, (N + 1) // 2, n_inds, links.reshape(-1), leaf_masks.reshape(-1),
+                                           _opt_ptr(om), int(dims), seeds, prob_kind, betas, len(betas),
+                                           int(n_threads), tot, mn, mv)
+    return float(dt), tot, mn, mv
 
 
 def prob(kind: int, beta: float, delta: float, old: float, cost_type="float64") -> float:

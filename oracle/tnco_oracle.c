@@ -1064,3 +1064,84 @@ void PFX(get_widths)(const PFX(state_t)* o, double* width) {
   if (!o->fw) return;
   memcpy(width, o->width, sizeof(double) * (size_t)o->N);
 }
+
+/* ------------------------------------------------------------------------ */
+/* Batch driver used by bench.py's cpu_baseline leg: R independent replicas  */
+/* over OpenMP threads (the reference's n_runs over joblib processes,        */
+/* tnco/parallel.py:330-341).  Only the update loops are timed; tree         */
+/* flattening (tnco/ctree.py:163-189 rule) and cache construction are setup. */
+/* ------------------------------------------------------------------------ */
+#ifndef ORC_DERIVE_DEFINED
+#define ORC_DERIVE_DEFINED
+#include <omp.h>
+/* legs of every node from the leaves: z = (x ^ y) | (x & y & outside(z)),
+ * outside(z) = output legs + legs of leaves not below z (tnco/ctree.py:163-189
+ * hyper-count bookkeeping restated as sets). */
+void orc_derive_inds(int32_t N, int32_t W, const int32_t* left, const int32_t* right,
+                     const uint64_t* leaf_masks, const uint64_t* output_mask, uint64_t* inds) {
+  const int32_t n = (N + 1) / 2;
+  int32_t* order = (int32_t*)malloc(sizeof(int32_t) * (size_t)N);
+  uint64_t* uni = (uint64_t*)calloc((size_t)N * W, sizeof(uint64_t));
+  uint64_t* outside = (uint64_t*)calloc((size_t)N * W, sizeof(uint64_t));
+  int k = orc_traverse(N, left, right, order);
+  memcpy(uni, leaf_masks, sizeof(uint64_t) * (size_t)n * W);
+  memcpy(inds, leaf_masks, sizeof(uint64_t) * (size_t)n * W);
+  for (int i = 0; i < k; ++i) {
+    int32_t p = order[i];
+    if (left[p] >= 0)
+      for (int w = 0; w < W; ++w) uni[(size_t)p * W + w] = uni[(size_t)left[p] * W + w] | uni[(size_t)right[p] * W + w];
+  }
+  if (output_mask) memcpy(outside + (size_t)(N - 1) * W, output_mask, sizeof(uint64_t) * (size_t)W);
+  for (int i = k - 1; i >= 0; --i) {
+    int32_t p = order[i];
+    if (left[p] < 0) continue;
+    for (int w = 0; w < W; ++w) {
+      outside[(size_t)left[p] * W + w] = outside[(size_t)p * W + w] | uni[(size_t)right[p] * W + w];
+      outside[(size_t)right[p] * W + w] = outside[(size_t)p * W + w] | uni[(size_t)left[p] * W + w];
+    }
+  }
+  for (int i = 0; i < k; ++i) {
+    int32_t p = order[i];
+    if (left[p] < 0) continue;
+    for (int w = 0; w < W; ++w) {
+      uint64_t a = inds[(size_t)left[p] * W + w], b = inds[(size_t)right[p] * W + w];
+      inds[(size_t)p * W + w] = (a ^ b) | (a & b & outside[(size_t)p * W + w]);
+    }
+  }
+  free(order); free(uni); free(outside);
+}
+#endif
+
+double PFX(run_batch)(int64_t R, int32_t n_leaves, int32_t n_inds, const int32_t* links,
+                      const uint64_t* leaf_masks, const uint64_t* output_mask, uint64_t dim_uniform,
+                      const uint32_t* seeds, int prob_kind, const double* betas, int64_t n_steps,
+                      int n_threads, double* out_total, double* out_min, uint64_t* out_moves) {
+  const int32_t N = 2 * n_leaves - 1, W = (n_inds + 63) / 64 > 0 ? (n_inds + 63) / 64 : 1;
+  PFX(state_t)** st = (PFX(state_t)**)calloc((size_t)R, sizeof(void*));
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int64_t r = 0; r < R; ++r) {
+    const int32_t* lk = links + r * 3 * (int64_t)N;
+    uint64_t* inds = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)N * W);
+    orc_derive_inds(N, W, lk, lk + N, leaf_masks, output_mask, inds);
+    int status = 0;
+    st[r] = PFX(create)(n_leaves, n_inds, lk, lk + N, lk + 2 * (int64_t)N, inds, dim_uniform, NULL, NULL, 0, 0,
+                        seeds[r], NULL, &status);
+    free(inds);
+    if (status) { PFX(destroy)(st[r]); st[r] = NULL; }
+  }
+  const double t0 = omp_get_wtime();
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int64_t r = 0; r < R; ++r)
+    if (st[r]) PFX(run)(st[r], prob_kind, betas, n_steps);
+  const double dt = omp_get_wtime() - t0;
+  for (int64_t r = 0; r < R; ++r) {
+    if (!st[r]) { if (out_total) out_total[r] = -1; continue; }
+    if (out_total) out_total[r] = (double)st[r]->partial[N - 1];
+    if (out_min) out_min[r] = (double)st[r]->min_total_cost;
+    if (out_moves) out_moves[r] = st[r]->n_moves;
+    PFX(destroy)(st[r]);
+  }
+  free(st);
+  return dt;
+}

@@ -71,7 +71,7 @@ def load() -> C.CDLL:
     L.tnco_hip_get_prng.argtypes = [vp, i64, vp]
     L.tnco_hip_set_prng.argtypes = [vp, i64, vp]
     L.tnco_hip_best.argtypes = [vp, i64, vp, vp]
-    L.tnco_hip_get_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.tnco_hip_get_counters.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4
     L.tnco_hip_get_moves.argtypes = [vp, vp]
     L.tnco_hip_kernel_time.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.c_int]
     L.tnco_hip_device_bytes.argtypes = [vp]

@@ -38,7 +38,7 @@ struct __attribute__((aligned(64))) ReplicaState {
   int32_t mtw;     // state words already twisted in the current generation
   int32_t status;  // 0 ok, else validity code
   int32_t pad;
-  unsigned long long pad2;
+  unsigned long long n_randpick;  // moves whose (D, E) order was drawn at random
 };
 static_assert(sizeof(NodeRec) == 32, "NodeRec");
 static_assert(sizeof(ReplicaState) == 64, "ReplicaState");
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void sa_run_kernel(const Params P, const doubl
   rng.lig = lig;
 
   double min_cost = rs->min_cost;
-  unsigned long long n_moves = 0, n_acc = 0, n_impr = 0;
+  unsigned long long n_moves = 0, n_acc = 0, n_impr = 0, n_rpick = 0;
   const int f32 = GENERIC ? P.f32 : 0;
   const int log2d = P.log2d;
   const bool disable_shared = P.disable_shared != 0;
@@ -375,6 +375,7 @@ __global__ __launch_bounds__(256) void sa_run_kernel(const Params P, const doubl
     bool pick0;  // true: (D, E) = (child0, child1)
     if (disable_shared || (inter0 && inter1)) {
       pick0 = (rng.next() & 1u) != 0;  // optimize/optimizer.hpp:139
+      ++n_rpick;
     } else {
       pick0 = inter0;
     }
@@ -445,6 +446,7 @@ __global__ __launch_bounds__(256) void sa_run_kernel(const Params P, const doubl
     rs->n_moves += n_moves;
     rs->n_accepted += n_acc;
     rs->n_improved += n_impr;
+    rs->n_randpick += n_rpick;
     rs->mti = rng.mti;
     rs->mtw = rng.mtw;
   }

@@ -175,7 +175,7 @@ __global__ void finish_init_kernel(Params P, const double* sum, const double* to
     rs->min_cost = sum[r];
     rs->init_total = total[r];
     rs->n_moves = 0; rs->n_accepted = 0; rs->n_improved = 0;
-    rs->status = 0; rs->pad = 0; rs->pad2 = 0;
+    rs->status = 0; rs->pad = 0; rs->n_randpick = 0;
   }
 }
 
@@ -771,15 +771,17 @@ int tnco_hip_best(tnco_hip_handle h, int64_t k, double* costs, int64_t* replicas
   return TNCO_HIP_OK;
 }
 
-int tnco_hip_get_counters(tnco_hip_handle h, uint64_t* moves, uint64_t* accepted, uint64_t* improved) {
+int tnco_hip_get_counters(tnco_hip_handle h, uint64_t* moves, uint64_t* accepted, uint64_t* improved,
+                          uint64_t* random_picks) {
   if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
   std::vector<ReplicaState> rs;
   if (int rc = fetch_rs(h, rs)) return rc;
-  uint64_t m = 0, a = 0, i = 0;
-  for (auto& x : rs) { m += x.n_moves; a += x.n_accepted; i += x.n_improved; }
+  uint64_t m = 0, a = 0, i = 0, q = 0;
+  for (auto& x : rs) { m += x.n_moves; a += x.n_accepted; i += x.n_improved; q += x.n_randpick; }
   if (moves) *moves = m;
   if (accepted) *accepted = a;
   if (improved) *improved = i;
+  if (random_picks) *random_picks = q;
   return TNCO_HIP_OK;
 }
 
