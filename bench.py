@@ -166,6 +166,8 @@ def main() -> None:
                 "accept_rate": a,
                 "random_pick_rate": q,
                 "best_log10_flops": float(np.log10(best)),
+                "improvements_timed": c1["improved"] - c0["improved"],
+                "full_tree_copies_timed": c1["full_copies"] - c0["full_copies"],
                 "validated_bad_replicas": n_bad,
             },
             "roofline": {

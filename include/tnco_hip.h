@@ -137,6 +137,10 @@ int tnco_hip_best(tnco_hip_handle h, int64_t k, double* costs, int64_t* replicas
  * Any pointer may be NULL. */
 int tnco_hip_get_counters(tnco_hip_handle h, uint64_t* moves, uint64_t* accepted,
                           uint64_t* improved, uint64_t* random_picks);
+/* Number of whole-tree copies taken for min_ctree (summed over replicas).  The
+ * reference copies the tree on EVERY improvement (optimizer.hpp:198-201); this
+ * build journals rotations and copies only after a journal overflow. */
+int tnco_hip_get_full_copies(tnco_hip_handle h, uint64_t* n);
 /* Per replica move counter ([n_replicas]). */
 int tnco_hip_get_moves(tnco_hip_handle h, uint64_t* moves_per_replica);
 

@@ -88,6 +88,27 @@ def test_chunked_run_equals_single_run(core, oracle_lib):
     assert np.array_equal(a.costs()[1], b.costs()[1])
 
 
+def test_best_tree_journal_overflow(core, oracle_lib):
+    """min_ctree bookkeeping: > 256 accepted rotations without an improvement (journal overflow ->
+    full copy at the next improvement), then a long descent (journal replay), across launches."""
+    prob = H.regular_problem(96, graph_seed=21)
+    seeds = H.replica_seeds(48, S=21)
+    links = prob.links(seeds)
+    gpu = core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds)
+    phases = [("base", np.zeros(60)), ("greedy", np.zeros(150)), ("base", np.zeros(40)),
+              ("mh", H.linear_betas(1, 200, 300))]
+    for kind, betas in phases:
+        gpu.run(betas, kind)
+    c = gpu.counters()
+    assert c["full_copies"] > 0 and c["improved"] > c["full_copies"]
+    for r in range(len(seeds)):
+        o = H.make_oracle(oracle_lib, prob, links[r], seeds[r])
+        for kind, betas in phases:
+            o.run({"base": 0, "greedy": 1, "mh": 2}[kind], betas)
+        H.assert_replica_equal(gpu, r, o)
+    assert gpu.validate() == (0, -1)
+
+
 def test_hyper_output_dims(core, oracle_lib):
     """Hyper-indices + output legs; uniform dims 3 (table path)."""
     from tnco_amd import synthetic as syn

@@ -9,7 +9,9 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
-_PATH = Path(__file__).resolve().parent / "libtnco_hip.so"
+import os
+
+_PATH = Path(os.environ.get("TNCO_HIP_LIB", Path(__file__).resolve().parent / "libtnco_hip.so"))
 
 OK, EINVAL, ERUNTIME, ENOTIMPL = 0, 1, 2, 3
 PROB_BASE, PROB_GREEDY, PROB_MH = 0, 1, 2
@@ -42,7 +44,8 @@ class Desc(C.Structure):
 EXPORTS = [
     "tnco_hip_create", "tnco_hip_run", "tnco_hip_sync", "tnco_hip_get_costs", "tnco_hip_get_tree",
     "tnco_hip_get_caches", "tnco_hip_validate", "tnco_hip_get_prng", "tnco_hip_set_prng",
-    "tnco_hip_best", "tnco_hip_get_counters", "tnco_hip_get_moves", "tnco_hip_kernel_time",
+    "tnco_hip_best", "tnco_hip_get_counters", "tnco_hip_get_moves", "tnco_hip_get_full_copies",
+    "tnco_hip_kernel_time",
     "tnco_hip_device_bytes", "tnco_hip_set_stream", "tnco_hip_destroy", "tnco_hip_random_trees",
     "tnco_hip_device_count", "tnco_hip_last_error", "tnco_hip_version",
 ]
@@ -73,6 +76,7 @@ def load() -> C.CDLL:
     L.tnco_hip_best.argtypes = [vp, i64, vp, vp]
     L.tnco_hip_get_counters.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4
     L.tnco_hip_get_moves.argtypes = [vp, vp]
+    L.tnco_hip_get_full_copies.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.tnco_hip_kernel_time.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.c_int]
     L.tnco_hip_device_bytes.argtypes = [vp]
     L.tnco_hip_device_bytes.restype = i64

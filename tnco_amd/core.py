@@ -232,7 +232,10 @@ class BatchedOptimizer:
     def counters(self) -> dict:
         a, b, c, q = (C.c_uint64(0) for _ in range(4))
         _lib.check(self._L.tnco_hip_get_counters(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(q)))
-        return dict(moves=a.value, accepted=b.value, improved=c.value, random_picks=q.value)
+        f = C.c_uint64(0)
+        _lib.check(self._L.tnco_hip_get_full_copies(self._h, C.byref(f)))
+        return dict(moves=a.value, accepted=b.value, improved=c.value, random_picks=q.value,
+                    full_copies=f.value)
 
     def moves_per_replica(self) -> np.ndarray:
         out = np.empty(self.n_replicas, np.uint64)

@@ -30,18 +30,30 @@ struct __attribute__((aligned(32))) NodeRec {
 struct __attribute__((aligned(16))) Links {
   int32_t left, right, parent, pad;
 };
-struct __attribute__((aligned(64))) ReplicaState {
+struct __attribute__((aligned(128))) ReplicaState {
   double min_cost;  // min_total_cost
   double init_total;
   unsigned long long n_moves, n_accepted, n_improved;
   int32_t mti;     // outputs consumed in the current MT generation, 0..624
   int32_t mtw;     // state words already twisted in the current generation
   int32_t status;  // 0 ok, else validity code
-  int32_t pad;
+  int32_t jinvalid;               // journal overflowed: next improvement takes a full copy
   unsigned long long n_randpick;  // moves whose (D, E) order was drawn at random
+  // rotation journal (ring of JCAP entries): min_ctree == minlinks + entries [jhead, jmin)
+  uint32_t jhead, jmin, jtail, pad0;
+  unsigned long long n_fullcopy;
+  unsigned long long pad1[5];
 };
 static_assert(sizeof(NodeRec) == 32, "NodeRec");
-static_assert(sizeof(ReplicaState) == 64, "ReplicaState");
+static_assert(sizeof(ReplicaState) == 128, "ReplicaState");
+
+// One accepted rotation (Tree::swap_with_nn, include/tnco/tree.hpp:176-184), fully resolved so
+// that replaying it needs no loads: A.child[slotC] = E; B.child[slotE] = C; C.parent = B;
+// E.parent = A.  Bit 30 of a = slotC (1: right), bit 30 of b = slotE.
+struct __attribute__((aligned(16))) JEntry {
+  int32_t a, b, c, e;
+};
+constexpr int JCAP = 256;  // journal capacity per replica (power of two)
 
 struct Params {
   int32_t n, N, I, W;
@@ -51,7 +63,8 @@ struct Params {
   uint64_t* hyper;           // [R][n-1][L]   HyperCache (NULL when the TN has no hyper legs)
   uint32_t* mt;              // [R][624]
   ReplicaState* rs;          // [R]
-  Links* minlinks;           // [R][N]        min_ctree (links only; legs re-derived on read)
+  Links* minlinks;           // [R][N]        min_ctree checkpoint (links only; legs re-derived on read)
+  JEntry* journal;           // [R][JCAP]     rotations accepted since the checkpoint
   const uint64_t* leafmask;  // [n][L]
   const uint64_t* outmask;   // [L]
   int32_t cost_mode;         // 0: uniform dims = 2^log2d; 1: uniform dims table; 2: per-index dims
@@ -103,79 +116,6 @@ __device__ __forceinline__ double pow2_cost(int e, int f32) {
   double v = (e > 1023) ? __builtin_huge_val() : __hiloint2double((1023 + e) << 20, 0);
   return f32 ? (double)(float)v : v;
 }
-
-// ---------------------------------------------------------------------------
-// std::mt19937, generated lazily in blocks of 16 outputs per group.
-// State words live in HBM ([624] per replica); the tempered outputs of the
-// current block live in a 64-byte LDS slot of the group.
-// (libstdc++ random.tcc:396-471; seeding :326-343.)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t mt_temper(uint32_t z) {
-  z ^= (z >> 11);
-  z ^= (z << 7) & 0x9d2c5680u;
-  z ^= (z << 15) & 0xefc60000u;
-  z ^= (z >> 18);
-  return z;
-}
-
-template <int LOG2L>
-struct Rng {
-  uint32_t* st;            // replica's 624 state words (HBM)
-  volatile uint32_t* buf;  // group's 16-word LDS slot
-  int mti, mtw, cur_blk, lig;
-
-  __device__ __forceinline__ void refill(int blk) {
-    constexpr int L = 1 << LOG2L;
-    const bool twist = (blk * 16) >= mtw;
-    for (int t = lig; t < 16; t += L) {
-      const int k = blk * 16 + t;
-      uint32_t v;
-      if (twist) {
-        const uint32_t a = st[k];
-        const int k1 = (k + 1 == 624) ? 0 : k + 1;
-        const uint32_t b = st[k1];
-        int km = k + 397;
-        if (km >= 624) km -= 624;
-        const uint32_t c = st[km];
-        const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
-        v = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-        st[k] = v;
-      } else {
-        v = st[k];
-      }
-      buf[t] = mt_temper(v);
-      // passes must stay in ascending order: a later pass overwrites words an
-      // earlier pass read as "old" (cross-lane write-after-read).
-      __asm__ volatile("" ::: "memory");
-    }
-    if (twist) mtw = blk * 16 + 16;
-    cur_blk = blk;
-  }
-
-  __device__ __forceinline__ uint32_t next() {
-    if (mti >= 624) {
-      mti = 0;
-      mtw = 0;
-      cur_blk = -1;
-    }
-    const int blk = mti >> 4;
-    if (blk != cur_blk) refill(blk);
-    const uint32_t v = buf[mti & 15];
-    ++mti;
-    return v;
-  }
-
-  // std::uniform_real_distribution<double>{} == generate_canonical<double,53>
-  // (random.tcc:3348-3380): low word first, one rounding, scale by 2^-64.
-  __device__ __forceinline__ double uniform01() {
-    const uint32_t x1 = next();
-    const uint32_t x2 = next();
-    double s = (double)x1 + (double)x2 * 4294967296.0;
-    double r = s * 5.421010862427522170037e-20;  // 2^-64
-    if (r >= 1.0) r = 0.99999999999999988897769753748;  // nextafter(1, 0)
-    return r;
-  }
-};
 
 // ---------------------------------------------------------------------------
 // cost model, generic path (cost modes 0/1/2, optional sparse legs, f32/f64)
@@ -237,220 +177,36 @@ __device__ __forceinline__ double accept_prob(int kind, double beta, double delt
 }
 
 // ---------------------------------------------------------------------------
-// The sweep kernel: n_steps calls of Optimizer::update
-// (include/tnco/optimize/infinite_memory/optimizer.hpp:90-221) per replica.
+// Best-tree bookkeeping.  The reference deep-copies the whole tree on every
+// improvement (`min_ctree = ctree`, optimizer.hpp:198-201).  Here the best tree
+// is a checkpoint (minlinks) plus a prefix [jhead, jmin) of a ring journal of
+// accepted rotations; an improvement only moves jmin.  Entries are applied to
+// the checkpoint when the ring needs room and at the end of every launch.
 // ---------------------------------------------------------------------------
-template <int LOG2L, bool HYPER, bool GENERIC>
-__global__ __launch_bounds__(256) void sa_run_kernel(const Params P, const double* __restrict__ betas,
-                                                     const int64_t n_steps, const int prob_kind) {
+template <int LOG2L>
+__device__ __forceinline__ void journal_replay(Links* __restrict__ ml, const JEntry* __restrict__ jr,
+                                               uint32_t from, uint32_t to, int lig, int gbase) {
   constexpr int L = 1 << LOG2L;
-  constexpr int GPB = 256 >> LOG2L;  // groups (replicas) per block
-  __shared__ uint32_t rngbuf[GPB * 16];
-
-  const int tid = threadIdx.x;
-  const int lig = tid & (L - 1);
-  const int gib = tid >> LOG2L;
-  const int gbase = (tid & 63) & ~(L - 1);  // first lane of the group inside the wave
-  const int64_t r = (int64_t)blockIdx.x * GPB + gib;
-  if (r >= P.R || n_steps <= 0) return;
-  const bool lane0 = (lig == 0);
-
-  const int n = P.n, N = P.N;
-  NodeRec* __restrict__ rec = P.rec + r * (int64_t)N;
-  uint64_t* __restrict__ imask = P.imask + r * (int64_t)(n - 1) * L;
-  uint64_t* __restrict__ hyper = HYPER ? P.hyper + r * (int64_t)(n - 1) * L : nullptr;
-  const uint64_t* __restrict__ leafmask = P.leafmask;
-  ReplicaState* rs = P.rs + r;
-
-  Rng<LOG2L> rng;
-  rng.st = P.mt + r * 624;
-  rng.buf = rngbuf + gib * 16;
-  rng.mti = rs->mti;
-  rng.mtw = rs->mtw;
-  rng.cur_blk = -1;
-  rng.lig = lig;
-
-  double min_cost = rs->min_cost;
-  unsigned long long n_moves = 0, n_acc = 0, n_impr = 0, n_rpick = 0;
-  const int f32 = GENERIC ? P.f32 : 0;
-  const int log2d = P.log2d;
-  const bool disable_shared = P.disable_shared != 0;
-
-  auto load_mask = [&](int x) -> uint64_t {
-    return x < n ? leafmask[(int64_t)x * L + lig] : imask[(int64_t)(x - n) * L + lig];
-  };
-  auto load_partial = [&](int x) -> double { return x < n ? 0.0 : rec[x].partial; };
-
-  // ---- carried state: B and what is known about its two children ----------
-  int B, bl, br, bA;
-  double ccB, partB, total, beta;
-  uint64_t m0, m1, iB = 0, hB = 0;
-  double p0, p1;
-
-  auto start_sweep = [&](int64_t step) {
-    beta = betas[step];
-    // optimizer.hpp:103-112
-    const uint32_t x = rng.next();
-    const int leaf = (int)(x % (uint32_t)n);
-    B = rec[leaf].parent;
-    const NodeRec rb = rec[B];
-    bl = rb.left;
-    br = rb.right;
-    bA = rb.parent;
-    ccB = rb.ccost;
-    partB = rb.partial;
-    total = (B == N - 1) ? partB : rec[N - 1].partial;
-    m0 = load_mask(bl);
-    m1 = load_mask(br);
-    p0 = load_partial(bl);
-    p1 = load_partial(br);
-    if constexpr (HYPER) {
-      iB = imask[(int64_t)(B - n) * L + lig];
-      hB = hyper[(int64_t)(B - n) * L + lig];
-    }
-  };
-
-  int64_t step = 0;
-  start_sweep(0);
-
-  for (;;) {
-    if (bA < 0) {
-      // ---- B is the root: end of sweep (optimizer.hpp:194-201) ------------
-      if (lane0) {
-        NodeRec o;
-        o.left = bl; o.right = br; o.parent = -1; o.pad = 0; o.ccost = ccB; o.partial = partB;
-        rec[B] = o;
+  for (uint32_t k0 = from; k0 != to;) {
+    const uint32_t left = to - k0;
+    const int cnt = left < (uint32_t)L ? (int)left : L;
+    JEntry e{0, 0, 0, 0};
+    if (lig < cnt) e = jr[(k0 + (uint32_t)lig) & (JCAP - 1)];
+    for (int j = 0; j < cnt; ++j) {
+      const int a = __shfl(e.a, gbase + j), b = __shfl(e.b, gbase + j);
+      const int c = __shfl(e.c, gbase + j), ee = __shfl(e.e, gbase + j);
+      if (lig == 0) {
+        const int A = a & 0x3fffffff, B = b & 0x3fffffff;
+        if (a & 0x40000000) ml[A].right = ee; else ml[A].left = ee;
+        if (b & 0x40000000) ml[B].right = c; else ml[B].left = c;
+        ml[c].parent = B;
+        ml[ee].parent = A;
       }
-      if (partB < min_cost) {
-        min_cost = partB;
-        ++n_impr;
-        Links* __restrict__ ml = P.minlinks + r * (int64_t)N;
-        for (int i = lig; i < N; i += L) ml[i] = *reinterpret_cast<const Links*>(&rec[i]);
-      }
-      ++step;
-      if (step >= n_steps) break;
-      start_sweep(step);
-      if (bA < 0) continue;
     }
-
-    // ---- one move evaluation (optimizer.hpp:117-192) -----------------------
-    const int A = bA;
-    const NodeRec ra = rec[A];
-    int al = ra.left, ar = ra.right;
-    const int aP = ra.parent;
-    double ccA = ra.ccost;
-    // get_ctree_nn, optimize/optimizer.hpp:121-144
-    const bool c_is_right = (al == B);
-    const int C = c_is_right ? ar : al;
-    const uint64_t mC = load_mask(C);
-    const double pC = load_partial(C);
-    uint64_t iA = 0, hA = 0;
-    if constexpr (HYPER) {
-      iA = imask[(int64_t)(A - n) * L + lig];
-      hA = hyper[(int64_t)(A - n) * L + lig];
-    }
-    const uint64_t hy = HYPER ? (hA | hB) : 0ull;
-    // both candidate (D, E) assignments evaluated at once:
-    //   cand0: D = child0, E = child1;  cand1: D = child1, E = child0
-    const uint64_t nb0 = (m0 ^ mC) | hy;  // optimizer.hpp:147
-    const uint64_t nb1 = (m1 ^ mC) | hy;
-    bool inter0, inter1;
-    int pcA0 = 0, pcB0 = 0, pcA1 = 0, pcB1 = 0;
-    if constexpr (!GENERIC) {
-      uint32_t w0 = (uint32_t)__popcll(nb0 | m1) | ((uint32_t)__popcll(m0 | mC) << 13) |
-                    (((m0 & mC) != 0 ? 1u : 0u) << 26);
-      uint32_t w1 = (uint32_t)__popcll(nb1 | m0) | ((uint32_t)__popcll(m1 | mC) << 13) |
-                    (((m1 & mC) != 0 ? 1u : 0u) << 26);
-      w0 = gsum<LOG2L>(w0);
-      w1 = gsum<LOG2L>(w1);
-      inter0 = (w0 >> 26) != 0;
-      inter1 = (w1 >> 26) != 0;
-      pcA0 = (int)(w0 & 0x1fffu); pcB0 = (int)((w0 >> 13) & 0x1fffu);
-      pcA1 = (int)(w1 & 0x1fffu); pcB1 = (int)((w1 >> 13) & 0x1fffu);
-    } else {
-      const uint32_t w = gsum<LOG2L>(((m0 & mC) != 0 ? 1u : 0u) | (((m1 & mC) != 0 ? 1u : 0u) << 8));
-      inter0 = (w & 0xffu) != 0;
-      inter1 = (w >> 8) != 0;
-    }
-    bool pick0;  // true: (D, E) = (child0, child1)
-    if (disable_shared || (inter0 && inter1)) {
-      pick0 = (rng.next() & 1u) != 0;  // optimize/optimizer.hpp:139
-      ++n_rpick;
-    } else {
-      pick0 = inter0;
-    }
-    const uint64_t mD = pick0 ? m0 : m1, mE = pick0 ? m1 : m0;
-    const uint64_t newB = pick0 ? nb0 : nb1;
-    const double pD = pick0 ? p0 : p1, pE = pick0 ? p1 : p0;
-    const int E = pick0 ? br : bl;
-
-    double nA, nB;  // optimizer.hpp:152-155
-    if constexpr (!GENERIC) {
-      nA = pow2_cost(log2d * (pick0 ? pcA0 : pcA1), 0);
-      nB = pow2_cost(log2d * (pick0 ? pcB0 : pcB1), 0);
-    } else {
-      nA = generic_cost<LOG2L>(P, newB | mE, lig, gbase);
-      nB = generic_cost<LOG2L>(P, mD | mC, lig, gbase);
-    }
-    const double delta = rnd_cost(rnd_cost(nB - ccB, f32) + rnd_cost(nA - ccA, f32), f32);  // :158
-    ++n_moves;
-
-    const double u = rng.uniform01();  // :162 (always drawn)
-    const bool acc = u <= accept_prob(prob_kind, beta, delta, total, f32);
-
-    double pEcur = pE, pCcur = pC;  // partials of B's other child / A's other child after the move
-    uint64_t mBnow;                 // legs of B after the move
-    if (acc) {
-      ++n_acc;
-      // Tree::swap_with_nn(E): include/tnco/tree.hpp:176-184
-      if (pick0) br = C; else bl = C;
-      if (c_is_right) ar = E; else al = E;
-      if (lane0) {
-        rec[C].parent = B;
-        rec[E].parent = A;
-      }
-      imask[(int64_t)(B - n) * L + lig] = newB;  // :170
-      if constexpr (HYPER) {
-        hA = iA & newB & mE;  // :171
-        hB = newB & mD & mC;  // :172
-        hyper[(int64_t)(A - n) * L + lig] = hA;
-        hyper[(int64_t)(B - n) * L + lig] = hB;
-      }
-      ccB = nB;
-      ccA = nA;
-      total = rnd_cost(total + delta, f32);  // :177
-      pEcur = pC;
-      pCcur = pE;
-      mBnow = newB;
-    } else {
-      mBnow = HYPER ? iB : (m0 ^ m1);
-    }
-    // :185-188
-    partB = rnd_cost(rnd_cost(pD + pEcur, f32) + ccB, f32);
-    const double partA = rnd_cost(rnd_cost(partB + pCcur, f32) + ccA, f32);
-    if (lane0) {
-      NodeRec o;
-      o.left = bl; o.right = br; o.parent = A; o.pad = 0; o.ccost = ccB; o.partial = partB;
-      rec[B] = o;
-    }
-    // :191  B <- A, carrying what we already know about A's children
-    const uint64_t mX = acc ? mE : mC;  // legs of A's other child
-    if (c_is_right) { m0 = mBnow; p0 = partB; m1 = mX; p1 = pCcur; }
-    else            { m1 = mBnow; p1 = partB; m0 = mX; p0 = pCcur; }
-    B = A; bl = al; br = ar; bA = aP; ccB = ccA; partB = partA;
-    if constexpr (HYPER) { iB = iA; hB = hA; }
-  }
-
-  if (lane0) {
-    rs->min_cost = min_cost;
-    rs->n_moves += n_moves;
-    rs->n_accepted += n_acc;
-    rs->n_improved += n_impr;
-    rs->n_randpick += n_rpick;
-    rs->mti = rng.mti;
-    rs->mtw = rng.mtw;
+    k0 += (uint32_t)cnt;
   }
 }
+
 
 // ---------------------------------------------------------------------------
 // mt19937 seeding: one thread per replica (random.tcc:326-343).

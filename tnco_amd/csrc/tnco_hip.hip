@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "sa_kernels.h"
+#include "sa_sweep.h"
 
 using namespace tnco;
 
@@ -175,7 +176,8 @@ __global__ void finish_init_kernel(Params P, const double* sum, const double* to
     rs->min_cost = sum[r];
     rs->init_total = total[r];
     rs->n_moves = 0; rs->n_accepted = 0; rs->n_improved = 0;
-    rs->status = 0; rs->pad = 0; rs->n_randpick = 0;
+    rs->status = 0; rs->jinvalid = 0; rs->n_randpick = 0;
+    rs->jhead = 0; rs->jmin = 0; rs->jtail = 0; rs->pad0 = 0; rs->n_fullcopy = 0;
   }
 }
 
@@ -391,6 +393,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   HIP_TRY(h->alloc(&P.mt, R * 624));
   HIP_TRY(h->alloc(&P.rs, R));
   HIP_TRY(h->alloc(&P.minlinks, R * N));
+  HIP_TRY(h->alloc(&P.journal, R * (int64_t)JCAP));
 
   // shared tables
   {
@@ -782,6 +785,16 @@ int tnco_hip_get_counters(tnco_hip_handle h, uint64_t* moves, uint64_t* accepted
   if (accepted) *accepted = a;
   if (improved) *improved = i;
   if (random_picks) *random_picks = q;
+  return TNCO_HIP_OK;
+}
+
+int tnco_hip_get_full_copies(tnco_hip_handle h, uint64_t* n) {
+  if (!h || !n) return fail(TNCO_HIP_EINVAL, "null argument.");
+  std::vector<ReplicaState> rs;
+  if (int rc = fetch_rs(h, rs)) return rc;
+  uint64_t c = 0;
+  for (auto& x : rs) c += x.n_fullcopy;
+  *n = c;
   return TNCO_HIP_OK;
 }
 
