@@ -88,13 +88,16 @@ def test_chunked_run_equals_single_run(core, oracle_lib):
     assert np.array_equal(a.costs()[1], b.costs()[1])
 
 
-def test_best_tree_journal_overflow(core, oracle_lib):
-    """min_ctree bookkeeping: > 256 accepted rotations without an improvement (journal overflow ->
-    full copy at the next improvement), then a long descent (journal replay), across launches."""
+def test_best_tree_journal_overflow(core, oracle_lib, monkeypatch):
+    """min_ctree bookkeeping: more accepted rotations than the rotation log holds without an
+    improvement (overflow -> full copy at the next improvement), then a long descent (log replay on
+    read-back), across launches."""
     prob = H.regular_problem(96, graph_seed=21)
     seeds = H.replica_seeds(48, S=21)
     links = prob.links(seeds)
+    monkeypatch.setenv("TNCO_HIP_JLOG_CAP", "256")
     gpu = core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds)
+    monkeypatch.delenv("TNCO_HIP_JLOG_CAP")
     phases = [("base", np.zeros(60)), ("greedy", np.zeros(150)), ("base", np.zeros(40)),
               ("mh", H.linear_betas(1, 200, 300))]
     for kind, betas in phases:

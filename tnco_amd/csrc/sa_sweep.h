@@ -4,8 +4,8 @@
 // Latency structure (gfx950): the leaf->root walk is a dependent pointer chase and vmcnt
 // retires loads and stores IN ORDER, so a load issued after a store waits for the store's
 // acknowledgement.  The loop is therefore software-pipelined by hand:
-//   * the record of A(k+2) and the legs/partial cost of C(k+1) are requested at the TOP of
-//     move k, before move k's stores, and consumed one / two moves later;
+//   * the header of A(k+2) and the block of C(k+1) are requested at the TOP of move k, before
+//     move k's stores, and consumed one / two moves later;
 //   * the mt19937 inputs of the next 16-output block are requested when the current block is
 //     generated;
 // so that the only exposed memory latencies are at the start of a sweep.
@@ -109,13 +109,18 @@ struct Rng {
   }
 };
 
+// The double-precision pow of the Metropolis rule, kept out of line: it is reached with
+// probability ~1e-5 per uphill move and would otherwise dominate the kernel's register budget.
+__device__ __attribute__((noinline)) bool accept_exact(double x, double beta, double u, int f32) {
+  return u <= rnd_cost(pow(x, -beta), f32);
+}
+
 // ---------------------------------------------------------------------------
 // `uniform <= prob(delta, total)` (optimizer.hpp:162) for the rules of
 // include/tnco/optimize/prob/{base,greedy,mh}.hpp.  Metropolis: p = pow(1 + delta/total, -beta)
 // (mh.hpp:52-58).  The comparison is first decided in the log2 domain with single-precision
-// hardware logs and a rigorous error margin; only when u falls inside the margin (probability
-// ~1e-5 per uphill move) is the double-precision pow evaluated, so the decision is always the one
-// `u <= pow(...)` gives.
+// hardware logs and a rigorous error margin; only when u falls inside the margin is the
+// double-precision pow evaluated, so the decision is always the one `u <= pow(...)` gives.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ bool accept_move(int kind, double beta, double delta, double total, double u,
                                             int f32) {
@@ -132,16 +137,16 @@ __device__ __forceinline__ bool accept_move(int kind, double beta, double delta,
     if (lu < lp - margin) return true;
     if (lu > lp + margin) return false;
   }
-  return u <= rnd_cost(pow(x, -beta), f32);
+  return accept_exact(x, beta, u, f32);
 }
 
 // ---------------------------------------------------------------------------
 #ifndef TNCO_WAVES_PER_SIMD
-#define TNCO_WAVES_PER_SIMD 2
+#define TNCO_WAVES_PER_SIMD 4
 #endif
 template <int LOG2L, bool HYPER, bool GENERIC>
-__global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(const Params P, const double* __restrict__ betas,
-                                                     const int64_t n_steps, const int prob_kind) {
+__global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
+    const Params P, const double* __restrict__ betas, const int64_t n_steps, const int prob_kind) {
   constexpr int L = 1 << LOG2L;
   constexpr int GPB = 256 >> LOG2L;  // groups (replicas) per block
   __shared__ uint32_t rngbuf[GPB * Rng<LOG2L>::SB];
@@ -155,29 +160,22 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(const 
   const bool lane0 = (lig == 0);
 
   const int n = P.n, N = P.N;
-  NodeRec* __restrict__ rec = P.rec + r * (int64_t)N;
-  uint64_t* __restrict__ imask = P.imask + r * (int64_t)(n - 1) * L;
-  uint64_t* __restrict__ hyper = HYPER ? P.hyper + r * (int64_t)(n - 1) * L : nullptr;
-  const uint64_t* __restrict__ leafmask = P.leafmask;
+  View<LOG2L, HYPER> v;
+  v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n, lig);
   ReplicaState* rs = P.rs + r;
 
   Rng<LOG2L> rng;
   rng.init(P.mt + r * 624, rngbuf + gib * Rng<LOG2L>::SB, rs->mti, rs->mtw, lig);
 
   double min_cost = rs->min_cost;
-  unsigned long long n_moves = 0, n_acc = 0, n_impr = 0, n_rpick = 0, n_full = 0;
-  Links* __restrict__ ml = P.minlinks + r * (int64_t)N;
-  JEntry* __restrict__ jr = P.journal + r * (int64_t)JCAP;
-  uint32_t jhead = rs->jhead, jmin = rs->jmin, jtail = rs->jtail;
+  uint32_t n_moves = 0, n_acc = 0, n_impr = 0, n_rpick = 0, n_full = 0;
+  int32_t* __restrict__ jlog = P.jlog + r * (int64_t)P.jcap;
+  const uint32_t jcap = (uint32_t)P.jcap;
+  uint32_t jmin = rs->jmin, jtail = rs->jtail;
   bool jinvalid = rs->jinvalid != 0;
   const int f32 = GENERIC ? P.f32 : 0;
   const int log2d = P.log2d;
   const bool disable_shared = P.disable_shared != 0;
-
-  auto load_mask = [&](int x) -> uint64_t {
-    return x < n ? leafmask[(int64_t)x * L + lig] : imask[(int64_t)(x - n) * L + lig];
-  };
-  auto load_partial = [&](int x) -> double { return x < n ? 0.0 : rec[x].partial; };
 
   // ---- carried state: B and what is known about its two children ----------
   int B, bl, br, A;
@@ -185,8 +183,8 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(const 
   uint64_t m0, m1, iB = 0, hB = 0;
   double p0, p1;
   // ---- pipeline registers ---------------------------------------------------
-  NodeRec recA;   // record of A            (valid when A >= 0)
-  NodeRec recN;   // record of parent(A)    (valid when recA.parent >= 0)
+  NodeRec recA;   // header of A            (valid when A >= 0)
+  NodeRec recN;   // header of parent(A)    (valid when recA.parent >= 0)
   uint64_t mC = 0, iA = 0, hA = 0;  // legs of C, legs / hyper legs of A
   double pC = 0;
 
@@ -195,31 +193,31 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(const 
     // optimizer.hpp:103-112
     const uint32_t x = rng.next();
     const int leaf = (int)(x % (uint32_t)n);
-    B = rec[leaf].parent;
-    const NodeRec rb = rec[B];
+    B = v.lpar[leaf];
+    const NodeRec rb = *v.hdr(B);
     bl = rb.left;
     br = rb.right;
     A = rb.parent;
     ccB = rb.ccost;
     partB = rb.partial;
-    total = (B == N - 1) ? partB : rec[N - 1].partial;
-    if (A >= 0) recA = rec[A];
-    m0 = load_mask(bl);
-    m1 = load_mask(br);
-    p0 = load_partial(bl);
-    p1 = load_partial(br);
+    total = (B == N - 1) ? partB : v.hdr(N - 1)->partial;
+    if (A >= 0) recA = *v.hdr(A);
+    m0 = v.mask(bl);
+    m1 = v.mask(br);
+    p0 = v.partial(bl);
+    p1 = v.partial(br);
     if constexpr (HYPER) {
-      iB = imask[(int64_t)(B - n) * L + lig];
-      hB = hyper[(int64_t)(B - n) * L + lig];
+      iB = v.mask(B);
+      hB = v.hyper(B);
     }
     if (A >= 0) {
       const int C = (recA.left == B) ? recA.right : recA.left;
-      if (recA.parent >= 0) recN = rec[recA.parent];
-      mC = load_mask(C);
-      pC = load_partial(C);
+      if (recA.parent >= 0) recN = *v.hdr(recA.parent);
+      mC = v.mask(C);
+      pC = v.partial(C);
       if constexpr (HYPER) {
-        iA = imask[(int64_t)(A - n) * L + lig];
-        hA = hyper[(int64_t)(A - n) * L + lig];
+        iA = v.mask(A);
+        hA = v.hyper(A);
       }
     }
   };
@@ -233,15 +231,21 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(const 
       if (lane0) {
         NodeRec o;
         o.left = bl; o.right = br; o.parent = -1; o.pad = 0; o.ccost = ccB; o.partial = partB;
-        rec[B] = o;
+        *v.hdr(B) = o;
       }
+      if constexpr (HYPER) v.set_hyper(B, hB);
       if (partB < min_cost) {
         min_cost = partB;
         ++n_impr;
         if (jinvalid) {
-          // more than JCAP rotations since the last best tree: take a full copy
-          for (int i = lig; i < N; i += L) ml[i] = *reinterpret_cast<const Links*>(&rec[i]);
-          jhead = jtail;
+          // the rotation log overflowed since the last best tree: take a full copy
+          Links* __restrict__ ml = P.minlinks + r * (int64_t)N;
+          for (int i = lig; i < N; i += L) {
+            Links o;
+            o.left = v.left(i); o.right = v.right(i); o.parent = v.parent(i); o.pad = 0;
+            ml[i] = o;
+          }
+          jtail = 0;
           jinvalid = false;
           ++n_full;
         }
@@ -264,12 +268,12 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(const 
     double pCn = 0;
     if (aP >= 0) {
       const int Cn = (recN.left == A) ? recN.right : recN.left;
-      if (recN.parent >= 0) recNN = rec[recN.parent];
-      mCn = load_mask(Cn);
-      pCn = load_partial(Cn);
+      if (recN.parent >= 0) recNN = *v.hdr(recN.parent);
+      mCn = v.mask(Cn);
+      pCn = v.partial(Cn);
       if constexpr (HYPER) {
-        iAn = imask[(int64_t)(aP - n) * L + lig];
-        hAn = hyper[(int64_t)(aP - n) * L + lig];
+        iAn = v.mask(aP);
+        hAn = v.hyper(aP);
       }
     }
 
@@ -331,36 +335,21 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(const 
       if (pick0) br = C; else bl = C;
       if (c_is_right) ar = E; else al = E;
       if (!jinvalid) {
-        if (jtail - jhead == (uint32_t)JCAP) {
-          if (jmin != jhead) {
-            journal_replay<LOG2L>(ml, jr, jhead, jmin, lig, gbase);
-            jhead = jmin;
-          } else {
-            jinvalid = true;
-          }
-        }
-        if (!jinvalid) {
-          if (lane0) {
-            JEntry je;
-            je.a = A | (c_is_right ? 0x40000000 : 0);
-            je.b = B | (pick0 ? 0x40000000 : 0);
-            je.c = C;
-            je.e = E;
-            jr[jtail & (JCAP - 1)] = je;
-          }
+        if (jtail == jcap) {
+          jinvalid = true;  // log full: the next improvement re-bases the checkpoint
+        } else {
+          if (lane0) jlog[jtail] = E;
           ++jtail;
         }
       }
       if (lane0) {
-        rec[C].parent = B;
-        rec[E].parent = A;
+        v.set_parent(C, B);
+        v.set_parent(E, A);
       }
-      imask[(int64_t)(B - n) * L + lig] = newB;  // :170
+      v.set_mask(B, newB);  // :170
       if constexpr (HYPER) {
         hA = iA & newB & mE;  // :171
         hB = newB & mD & mC;  // :172
-        hyper[(int64_t)(A - n) * L + lig] = hA;
-        hyper[(int64_t)(B - n) * L + lig] = hB;
       }
       ccB = nB;
       ccA = nA;
@@ -377,8 +366,9 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(const 
     if (lane0) {
       NodeRec o;
       o.left = bl; o.right = br; o.parent = A; o.pad = 0; o.ccost = ccB; o.partial = partB;
-      rec[B] = o;
+      *v.hdr(B) = o;
     }
+    if constexpr (HYPER) v.set_hyper(B, hB);  // B's hyper legs may also have changed one level below
     // :191  B <- A, carrying what we already know about A's children
     const uint64_t mX = acc ? mE : mC;  // legs of A's other child
     if (c_is_right) { m0 = mBnow; p0 = partB; m1 = mX; p1 = pCcur; }
@@ -392,13 +382,8 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(const 
     pC = pCn;
   }
 
-  // leave the checkpoint equal to the best tree
-  if (jmin != jhead) {
-    journal_replay<LOG2L>(ml, jr, jhead, jmin, lig, gbase);
-    jhead = jmin;
-  }
   if (lane0) {
-    rs->jhead = jhead; rs->jmin = jmin; rs->jtail = jtail;
+    rs->jmin = jmin; rs->jtail = jtail;
     rs->jinvalid = jinvalid ? 1 : 0;
     rs->n_fullcopy += n_full;
     rs->min_cost = min_cost;

@@ -1,4 +1,4 @@
-// tnco_hip.hip -- C ABI (include/tnco_hip.h) over the gfx950 kernels of sa_kernels.h.
+// tnco_hip.hip -- C ABI (include/tnco_hip.h) over the gfx950 kernels of sa_kernels.h / sa_sweep.h.
 // Host side: argument checking, device memory, launches, read-back.
 #include "../../include/tnco_hip.h"
 
@@ -6,7 +6,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -38,6 +40,22 @@ struct EventPair {
   hipEvent_t a, b;
 };
 
+// frees a set of temporary device buffers on scope exit
+struct TempBufs {
+  std::vector<void*> ptrs;
+  template <typename T>
+  hipError_t alloc(T** p, int64_t count) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, (size_t)std::max<int64_t>(count, 1) * sizeof(T));
+    if (e == hipSuccess) ptrs.push_back(q);
+    *p = (T*)q;
+    return e;
+  }
+  ~TempBufs() {
+    for (void* p : ptrs) (void)hipFree(p);
+  }
+};
+
 }  // namespace
 
 struct tnco_hip_ctx {
@@ -49,7 +67,6 @@ struct tnco_hip_ctx {
   bool hyper = false, generic = false;
   std::vector<void*> allocs;
   int64_t bytes = 0;
-  // host copies
   std::vector<uint64_t> leafmask_w;  // [n][W]
   std::vector<uint64_t> outmask_w;   // [W]
   double* d_betas = nullptr;
@@ -91,6 +108,7 @@ struct tnco_hip_ctx {
     if (d_betas) (void)hipFree(d_betas);
     if (own_stream) (void)hipStreamDestroy(own_stream);
   }
+  int64_t block_bytes() const { return (int64_t)(P.n - 1) * P.BS; }
 };
 
 namespace {
@@ -133,16 +151,16 @@ void launch_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_
 }
 
 template <int LOG2L>
-void launch_build_l(tnco_hip_ctx* h, const Params& P, const BuildArgs& a) {
+void launch_build_l(tnco_hip_ctx* h, const BuildArgs& a) {
   const int gpb = 256 >> LOG2L;
   dim3 grid((unsigned)((a.count + gpb - 1) / gpb));
   if (h->hyper)
-    hipLaunchKernelGGL((build_kernel<LOG2L, true>), grid, dim3(256), 0, h->stream, P, a);
+    hipLaunchKernelGGL((build_kernel<LOG2L, true>), grid, dim3(256), 0, h->stream, h->P, a);
   else
-    hipLaunchKernelGGL((build_kernel<LOG2L, false>), grid, dim3(256), 0, h->stream, P, a);
+    hipLaunchKernelGGL((build_kernel<LOG2L, false>), grid, dim3(256), 0, h->stream, h->P, a);
 }
-void launch_build(tnco_hip_ctx* h, const Params& P, const BuildArgs& a) {
-#define CALL_BUILD(LL) launch_build_l<LL>(h, P, a)
+void launch_build(tnco_hip_ctx* h, const BuildArgs& a) {
+#define CALL_BUILD(LL) launch_build_l<LL>(h, a)
   DISPATCH_L(h, CALL_BUILD)
 #undef CALL_BUILD
 }
@@ -162,22 +180,30 @@ void launch_compare(tnco_hip_ctx* h, const BuildArgs& a, double atol, int32_t* o
 #undef CALL_CMP
 }
 
+// checkpoint := current tree, replica state := fresh
 __global__ void finish_init_kernel(Params P, const double* sum, const double* total) {
   const int64_t r = blockIdx.x;
-  const NodeRec* rec = P.rec + r * (int64_t)P.N;
+  const int n = P.n;
+  const uint8_t* blk = P.blocks + r * (int64_t)(n - 1) * P.BS;
+  const int32_t* lp = P.lpar + r * (int64_t)n;
   Links* ml = P.minlinks + r * (int64_t)P.N;
   for (int i = threadIdx.x; i < P.N; i += blockDim.x) {
     Links o;
-    o.left = rec[i].left; o.right = rec[i].right; o.parent = rec[i].parent; o.pad = 0;
+    if (i < n) {
+      o.left = -1; o.right = -1; o.parent = lp[i];
+    } else {
+      const NodeRec* hd = reinterpret_cast<const NodeRec*>(blk + (int64_t)(i - n) * P.BS);
+      o.left = hd->left; o.right = hd->right; o.parent = hd->parent;
+    }
+    o.pad = 0;
     ml[i] = o;
   }
   if (threadIdx.x == 0) {
     ReplicaState* rs = P.rs + r;
     rs->min_cost = sum[r];
     rs->init_total = total[r];
-    rs->n_moves = 0; rs->n_accepted = 0; rs->n_improved = 0;
-    rs->status = 0; rs->jinvalid = 0; rs->n_randpick = 0;
-    rs->jhead = 0; rs->jmin = 0; rs->jtail = 0; rs->pad0 = 0; rs->n_fullcopy = 0;
+    rs->n_moves = 0; rs->n_accepted = 0; rs->n_improved = 0; rs->n_randpick = 0; rs->n_fullcopy = 0;
+    rs->status = 0; rs->jinvalid = 0; rs->jmin = 0; rs->jtail = 0; rs->pad0 = 0; rs->pad2 = 0;
   }
 }
 
@@ -278,12 +304,26 @@ bool bad_log2(double x) {
   return std::isinf(l) || std::isnan(l);
 }
 
+bool logclose(double x, double y, double atol) {
+  if (x < 0 || y < 0) return false;
+  if (x == 0 || y == 0) return x == y;
+  return std::fabs(std::log(x) - std::log(y)) <= atol;
+}
+
+int fetch_rs(tnco_hip_handle h, std::vector<ReplicaState>& rs) {
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  rs.resize((size_t)h->P.R);
+  HIP_TRY(hipMemcpy(rs.data(), h->P.rs, (size_t)h->P.R * sizeof(ReplicaState), hipMemcpyDeviceToHost));
+  return TNCO_HIP_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
 const char* tnco_hip_last_error(void) { return g_err.c_str(); }
-const char* tnco_hip_version(void) { return "tnco_hip 0.1 (gfx950)"; }
+const char* tnco_hip_version(void) { return "tnco_hip 0.2 (gfx950)"; }
 
 int tnco_hip_device_count(void) {
   int n = 0;
@@ -380,6 +420,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
 
   Params& P = h->P;
   P.n = n; P.N = N; P.I = I; P.W = W; P.R = R;
+  P.BS = (32 + 8 * W * (h->hyper ? 2 : 1) + 31) / 32 * 32;
   P.f32 = f32; P.disable_shared = d->disable_shared_inds ? 1 : 0;
   P.cost_mode = uniform ? (pow2u ? 0 : 1) : 2;
   P.log2d = 0;
@@ -387,13 +428,23 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   auto rc = [&](double x) { return f32 ? (double)(float)x : x; };
   P.n_projs = d->sparse_mask ? rc((double)d->n_projs) : 0.0;
 
-  HIP_TRY(h->alloc(&P.rec, R * N));
-  HIP_TRY(h->alloc(&P.imask, R * (int64_t)(n - 1) * L));
-  if (h->hyper) HIP_TRY(h->alloc(&P.hyper, R * (int64_t)(n - 1) * L));
+  // Rotation log: one int32 per accepted move since the last re-base of the checkpoint.  HBM is
+  // plentiful (288 GB): give the log up to an eighth of the free memory, 4 Mi entries at most.
+  {
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    int64_t cap = (int64_t)(free_b / 8) / (R * 4);
+    cap = std::max<int64_t>(1024, std::min<int64_t>(cap, (int64_t)1 << 22));
+    if (const char* e = std::getenv("TNCO_HIP_JLOG_CAP")) cap = std::max<int64_t>(1, std::atoll(e));  // test knob
+    P.jcap = (int32_t)cap;
+  }
+
+  HIP_TRY(h->alloc(&P.blocks, R * h->block_bytes()));
+  HIP_TRY(h->alloc(&P.lpar, R * n));
   HIP_TRY(h->alloc(&P.mt, R * 624));
   HIP_TRY(h->alloc(&P.rs, R));
   HIP_TRY(h->alloc(&P.minlinks, R * N));
-  HIP_TRY(h->alloc(&P.journal, R * (int64_t)JCAP));
+  HIP_TRY(h->alloc(&P.jlog, R * (int64_t)P.jcap));
 
   // shared tables
   {
@@ -433,20 +484,17 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     }
   }
 
+  TempBufs tmp;
   // seeds -> MT state
   {
     uint32_t* dseeds = nullptr;
-    HIP_TRY(hipMalloc((void**)&dseeds, (size_t)R * 4));
-    hipError_t e = hipMemcpy(dseeds, d->seeds, (size_t)R * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-      hipLaunchKernelGGL(mt_seed_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, h->stream, P.mt, P.rs, dseeds, R);
-      e = hipStreamSynchronize(h->stream);
-    }
-    (void)hipFree(dseeds);
-    HIP_TRY(e);
+    HIP_TRY(tmp.alloc(&dseeds, R));
+    HIP_TRY(hipMemcpy(dseeds, d->seeds, (size_t)R * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(mt_seed_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, h->stream, P.mt, P.rs, dseeds, R);
+    HIP_TRY(hipStreamSynchronize(h->stream));
   }
 
-  // links (+ optional explicit legs) -> caches
+  // links (+ optional explicit legs) -> node blocks and caches
   {
     const int64_t ntrees = d->links_stride == 0 ? 1 : R;
     int32_t* dlinks = nullptr;
@@ -455,52 +503,39 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     int32_t* dstatus = nullptr;
     std::vector<double> total((size_t)R), sum((size_t)R);
     std::vector<int32_t> status((size_t)R);
-    auto cleanup = [&]() {
-      (void)hipFree(dlinks); (void)hipFree(dmasks); (void)hipFree(dtotal); (void)hipFree(dsum); (void)hipFree(dstatus);
-    };
-    hipError_t e = hipMalloc((void**)&dlinks, (size_t)ntrees * 3 * N * 4);
-    if (e == hipSuccess) {
-      if (d->links_stride == 0 || d->links_stride == 3 * (int64_t)N)
-        e = hipMemcpy(dlinks, d->links, (size_t)ntrees * 3 * N * 4, hipMemcpyHostToDevice);
-      else
-        e = hipMemcpy2D(dlinks, (size_t)3 * N * 4, d->links, (size_t)d->links_stride * 4, (size_t)3 * N * 4, (size_t)ntrees, hipMemcpyHostToDevice);
-    }
+    HIP_TRY(tmp.alloc(&dlinks, ntrees * 3 * N));
+    if (d->links_stride == 0 || d->links_stride == 3 * (int64_t)N)
+      HIP_TRY(hipMemcpy(dlinks, d->links, (size_t)ntrees * 3 * N * 4, hipMemcpyHostToDevice));
+    else
+      HIP_TRY(hipMemcpy2D(dlinks, (size_t)3 * N * 4, d->links, (size_t)d->links_stride * 4, (size_t)3 * N * 4, (size_t)ntrees, hipMemcpyHostToDevice));
     const int64_t nmasks = d->node_masks ? (d->node_masks_stride == 0 ? 1 : R) : 0;
-    if (e == hipSuccess && nmasks) {
-      e = hipMalloc((void**)&dmasks, (size_t)nmasks * N * W * 8);
-      if (e == hipSuccess) {
-        if (d->node_masks_stride == 0 || d->node_masks_stride == (int64_t)N * W)
-          e = hipMemcpy(dmasks, d->node_masks, (size_t)nmasks * N * W * 8, hipMemcpyHostToDevice);
-        else
-          e = hipMemcpy2D(dmasks, (size_t)N * W * 8, d->node_masks, (size_t)d->node_masks_stride * 8, (size_t)N * W * 8, (size_t)nmasks, hipMemcpyHostToDevice);
-      }
+    if (nmasks) {
+      HIP_TRY(tmp.alloc(&dmasks, nmasks * N * W));
+      if (d->node_masks_stride == 0 || d->node_masks_stride == (int64_t)N * W)
+        HIP_TRY(hipMemcpy(dmasks, d->node_masks, (size_t)nmasks * N * W * 8, hipMemcpyHostToDevice));
+      else
+        HIP_TRY(hipMemcpy2D(dmasks, (size_t)N * W * 8, d->node_masks, (size_t)d->node_masks_stride * 8, (size_t)N * W * 8, (size_t)nmasks, hipMemcpyHostToDevice));
     }
-    if (e == hipSuccess) e = hipMalloc((void**)&dtotal, (size_t)R * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&dsum, (size_t)R * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&dstatus, (size_t)R * 4);
-    if (e == hipSuccess) {
-      BuildArgs a{};
-      a.in_links = dlinks;
-      a.in_links_stride = d->links_stride == 0 ? 0 : 3 * (int64_t)N;
-      a.in_masks = dmasks;
-      a.in_masks_stride = (d->node_masks && d->node_masks_stride != 0) ? (int64_t)N * W : 0;
-      a.out_rec = P.rec; a.out_imask = P.imask; a.out_hyper = P.hyper;
-      a.scratch = reinterpret_cast<int32_t*>(P.minlinks);  // 16 B * N per replica = 4N int32
-      a.out_total = dtotal; a.out_sum = dsum; a.out_status = dstatus;
-      a.r0 = 0; a.count = R;
-      launch_build(h, P, a);
-      e = hipGetLastError();
-      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-      if (e == hipSuccess) e = hipMemcpy(total.data(), dtotal, (size_t)R * 8, hipMemcpyDeviceToHost);
-      if (e == hipSuccess) e = hipMemcpy(sum.data(), dsum, (size_t)R * 8, hipMemcpyDeviceToHost);
-      if (e == hipSuccess) e = hipMemcpy(status.data(), dstatus, (size_t)R * 4, hipMemcpyDeviceToHost);
-      if (e == hipSuccess) {
-        hipLaunchKernelGGL(finish_init_kernel, dim3((unsigned)R), dim3(64), 0, h->stream, P, dsum, dtotal);
-        e = hipStreamSynchronize(h->stream);
-      }
-    }
-    cleanup();
-    HIP_TRY(e);
+    HIP_TRY(tmp.alloc(&dtotal, R));
+    HIP_TRY(tmp.alloc(&dsum, R));
+    HIP_TRY(tmp.alloc(&dstatus, R));
+    BuildArgs a{};
+    a.in_links = dlinks;
+    a.in_links_stride = d->links_stride == 0 ? 0 : 3 * (int64_t)N;
+    a.in_masks = dmasks;
+    a.in_masks_stride = (d->node_masks && d->node_masks_stride != 0) ? (int64_t)N * W : 0;
+    a.out_blocks = P.blocks; a.out_lpar = P.lpar;
+    a.scratch = reinterpret_cast<int32_t*>(P.minlinks);  // 16 B * N per replica = 4N int32
+    a.out_total = dtotal; a.out_sum = dsum; a.out_status = dstatus;
+    a.r0 = 0; a.count = R;
+    launch_build(h, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(total.data(), dtotal, (size_t)R * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(sum.data(), dsum, (size_t)R * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(status.data(), dstatus, (size_t)R * 4, hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(finish_init_kernel, dim3((unsigned)R), dim3(64), 0, h->stream, P, dsum, dtotal);
+    HIP_TRY(hipStreamSynchronize(h->stream));
     for (int64_t r = 0; r < R; ++r)
       if (status[r]) return fail(TNCO_HIP_EINVAL, status_message(status[r]));
     for (int64_t r = 0; r < R; ++r)
@@ -533,31 +568,35 @@ int tnco_hip_run(tnco_hip_handle h, int prob_kind, const double* betas, int64_t 
   if (n_steps < 0 || (n_steps > 0 && !betas)) return fail(TNCO_HIP_EINVAL, "'betas' is not valid.");
   if (n_steps == 0) return TNCO_HIP_OK;
   HIP_TRY(hipSetDevice(h->device));
+  // the previous launch may still be reading d_betas
+  HIP_TRY(hipStreamSynchronize(h->stream));
   if (n_steps > h->betas_cap) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->d_betas) (void)hipFree(h->d_betas);
     h->d_betas = nullptr;
+    h->betas_cap = 0;
     HIP_TRY(hipMalloc((void**)&h->d_betas, (size_t)n_steps * 8));
     h->betas_cap = n_steps;
-  } else {
-    // the previous launch may still be reading d_betas
-    HIP_TRY(hipStreamSynchronize(h->stream));
   }
   HIP_TRY(hipMemcpyAsync(h->d_betas, betas, (size_t)n_steps * 8, hipMemcpyHostToDevice, h->stream));
-  EventPair ev;
-  if (!h->free_events.empty()) {
-    ev = h->free_events.back();
-    h->free_events.pop_back();
-  } else {
-    HIP_TRY(hipEventCreate(&ev.a));
-    HIP_TRY(hipEventCreate(&ev.b));
+  // per-launch work counters are 32-bit: at most (n_leaves - 1) moves per sweep
+  const int64_t max_steps = std::max<int64_t>(1, (int64_t)0xF0000000u / std::max(1, h->P.n));
+  for (int64_t s0 = 0; s0 < n_steps; s0 += max_steps) {
+    const int64_t cnt = std::min(max_steps, n_steps - s0);
+    EventPair ev;
+    if (!h->free_events.empty()) {
+      ev = h->free_events.back();
+      h->free_events.pop_back();
+    } else {
+      HIP_TRY(hipEventCreate(&ev.a));
+      HIP_TRY(hipEventCreate(&ev.b));
+    }
+    HIP_TRY(hipEventRecord(ev.a, h->stream));
+    launch_run(h, h->d_betas + s0, cnt, prob_kind);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev.b, h->stream));
+    h->pending.push_back(ev);
+    h->launches++;
   }
-  HIP_TRY(hipEventRecord(ev.a, h->stream));
-  launch_run(h, h->d_betas, n_steps, prob_kind);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(ev.b, h->stream));
-  h->pending.push_back(ev);
-  h->launches++;
   if (h->pending.size() > 256) h->resolve_events();
   return TNCO_HIP_OK;
 }
@@ -578,18 +617,9 @@ int tnco_hip_kernel_time(tnco_hip_handle h, double* ms, int64_t* launches, int r
 
 int64_t tnco_hip_device_bytes(tnco_hip_handle h) { return h ? h->bytes : 0; }
 
-static int fetch_rs(tnco_hip_handle h, std::vector<ReplicaState>& rs) {
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  rs.resize((size_t)h->P.R);
-  HIP_TRY(hipMemcpy(rs.data(), h->P.rs, (size_t)h->P.R * sizeof(ReplicaState), hipMemcpyDeviceToHost));
-  return TNCO_HIP_OK;
-}
-
 int tnco_hip_get_costs(tnco_hip_handle h, double* total_cost, double* min_total_cost) {
   if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
   const int64_t R = h->P.R;
-  const int N = h->P.N;
   if (min_total_cost) {
     std::vector<ReplicaState> rs;
     if (int rc = fetch_rs(h, rs)) return rc;
@@ -598,9 +628,9 @@ int tnco_hip_get_costs(tnco_hip_handle h, double* total_cost, double* min_total_
   if (total_cost) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    // partial of the root record of every replica (strided gather)
-    HIP_TRY(hipMemcpy2D(total_cost, 8, reinterpret_cast<const char*>(h->P.rec + (N - 1)) + offsetof(NodeRec, partial),
-                        (size_t)N * sizeof(NodeRec), 8, (size_t)R, hipMemcpyDeviceToHost));
+    // partial cost in the header of the root block of every replica (strided gather)
+    const uint8_t* src = h->P.blocks + (int64_t)(h->P.n - 2) * h->P.BS + offsetof(NodeRec, partial);
+    HIP_TRY(hipMemcpy2D(total_cost, 8, src, (size_t)h->block_bytes(), 8, (size_t)R, hipMemcpyDeviceToHost));
   }
   return TNCO_HIP_OK;
 }
@@ -610,24 +640,41 @@ int tnco_hip_get_tree(tnco_hip_handle h, int64_t r, int which, int32_t* left, in
   if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
   if (r < 0 || r >= h->P.R) return fail(TNCO_HIP_EINVAL, "'replica' out of range.");
   if (!left || !right || !parent) return fail(TNCO_HIP_EINVAL, "null output array.");
-  const int n = h->P.n, N = h->P.N, W = h->P.W, L = h->L;
+  const int n = h->P.n, N = h->P.N, W = h->P.W, BS = h->P.BS;
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (which == 0) {
-    std::vector<NodeRec> rec((size_t)N);
-    HIP_TRY(hipMemcpy(rec.data(), h->P.rec + r * (int64_t)N, (size_t)N * sizeof(NodeRec), hipMemcpyDeviceToHost));
-    for (int i = 0; i < N; ++i) { left[i] = rec[i].left; right[i] = rec[i].right; parent[i] = rec[i].parent; }
-    if (masks) {
-      std::vector<uint64_t> im((size_t)(n - 1) * L);
-      HIP_TRY(hipMemcpy(im.data(), h->P.imask + r * (int64_t)(n - 1) * L, im.size() * 8, hipMemcpyDeviceToHost));
-      std::memcpy(masks, h->leafmask_w.data(), (size_t)n * W * 8);
-      for (int p = n; p < N; ++p)
-        for (int w = 0; w < W; ++w) masks[(size_t)p * W + w] = im[(size_t)(p - n) * L + w];
+    std::vector<uint8_t> blk((size_t)h->block_bytes());
+    HIP_TRY(hipMemcpy(blk.data(), h->P.blocks + r * h->block_bytes(), blk.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(parent, h->P.lpar + r * (int64_t)n, (size_t)n * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) { left[i] = -1; right[i] = -1; }
+    if (masks) std::memcpy(masks, h->leafmask_w.data(), (size_t)n * W * 8);
+    for (int p = n; p < N; ++p) {
+      const uint8_t* b = blk.data() + (size_t)(p - n) * BS;
+      NodeRec hd;
+      std::memcpy(&hd, b, sizeof(hd));
+      left[p] = hd.left; right[p] = hd.right; parent[p] = hd.parent;
+      if (masks) std::memcpy(masks + (size_t)p * W, b + 32, (size_t)W * 8);
     }
   } else {
-    std::vector<Links> lk((size_t)N);
-    HIP_TRY(hipMemcpy(lk.data(), h->P.minlinks + r * (int64_t)N, (size_t)N * sizeof(Links), hipMemcpyDeviceToHost));
-    for (int i = 0; i < N; ++i) { left[i] = lk[i].left; right[i] = lk[i].right; parent[i] = lk[i].parent; }
+    // best tree = checkpoint + rotations jlog[0, jmin): Tree::swap_with_nn replayed on the host
+    std::vector<Links> t((size_t)N);
+    ReplicaState rs;
+    HIP_TRY(hipMemcpy(&rs, h->P.rs + r, sizeof(rs), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(t.data(), h->P.minlinks + r * (int64_t)N, (size_t)N * sizeof(Links), hipMemcpyDeviceToHost));
+    std::vector<int32_t> lg((size_t)rs.jmin);
+    if (rs.jmin)
+      HIP_TRY(hipMemcpy(lg.data(), h->P.jlog + r * (int64_t)h->P.jcap, (size_t)rs.jmin * 4, hipMemcpyDeviceToHost));
+    for (int32_t D : lg) {
+      const int B = t[D].parent;
+      const int A = t[B].parent;
+      const int C = (t[A].left == B) ? t[A].right : t[A].left;
+      if (t[A].left != C) t[A].right = D; else t[A].left = D;
+      if (t[B].left != D) t[B].right = C; else t[B].left = C;
+      t[C].parent = B;
+      t[D].parent = A;
+    }
+    for (int i = 0; i < N; ++i) { left[i] = t[i].left; right[i] = t[i].right; parent[i] = t[i].parent; }
     if (masks) host_derive(h, left, right, masks);
   }
   return TNCO_HIP_OK;
@@ -636,23 +683,19 @@ int tnco_hip_get_tree(tnco_hip_handle h, int64_t r, int which, int32_t* left, in
 int tnco_hip_get_caches(tnco_hip_handle h, int64_t r, double* ccost, double* partial, uint64_t* hyper) {
   if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
   if (r < 0 || r >= h->P.R) return fail(TNCO_HIP_EINVAL, "'replica' out of range.");
-  const int n = h->P.n, N = h->P.N, W = h->P.W, L = h->L;
+  const int n = h->P.n, N = h->P.N, W = h->P.W, BS = h->P.BS;
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  std::vector<NodeRec> rec((size_t)N);
-  HIP_TRY(hipMemcpy(rec.data(), h->P.rec + r * (int64_t)N, (size_t)N * sizeof(NodeRec), hipMemcpyDeviceToHost));
+  std::vector<uint8_t> blk((size_t)h->block_bytes());
+  HIP_TRY(hipMemcpy(blk.data(), h->P.blocks + r * h->block_bytes(), blk.size(), hipMemcpyDeviceToHost));
+  if (hyper) std::memset(hyper, 0, (size_t)N * W * 8);
   for (int i = 0; i < N; ++i) {
-    if (ccost) ccost[i] = rec[i].ccost;
-    if (partial) partial[i] = rec[i].partial;
-  }
-  if (hyper) {
-    std::memset(hyper, 0, (size_t)N * W * 8);
-    if (h->hyper) {
-      std::vector<uint64_t> hy((size_t)(n - 1) * L);
-      HIP_TRY(hipMemcpy(hy.data(), h->P.hyper + r * (int64_t)(n - 1) * L, hy.size() * 8, hipMemcpyDeviceToHost));
-      for (int p = n; p < N; ++p)
-        for (int w = 0; w < W; ++w) hyper[(size_t)p * W + w] = hy[(size_t)(p - n) * L + w];
-    }
+    NodeRec hd{};
+    if (i >= n) std::memcpy(&hd, blk.data() + (size_t)(i - n) * BS, sizeof(hd));
+    if (ccost) ccost[i] = i < n ? 0.0 : hd.ccost;
+    if (partial) partial[i] = i < n ? 0.0 : hd.partial;
+    if (hyper && h->hyper && i >= n)
+      std::memcpy(hyper + (size_t)i * W, blk.data() + (size_t)(i - n) * BS + 32 + (size_t)W * 8, (size_t)W * 8);
   }
   return TNCO_HIP_OK;
 }
@@ -660,62 +703,53 @@ int tnco_hip_get_caches(tnco_hip_handle h, int64_t r, double* ccost, double* par
 int tnco_hip_validate(tnco_hip_handle h, double atol, int64_t* n_bad, int64_t* first_bad) {
   if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
   const Params& P = h->P;
-  const int n = P.n, N = P.N, L = h->L;
+  const int n = P.n, N = P.N;
   const int64_t R = P.R;
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  const int64_t per = (int64_t)N * sizeof(NodeRec) + (int64_t)(n - 1) * L * 8 * (h->hyper ? 2 : 1) + (int64_t)N * 16 + 64;
+  const int64_t per = h->block_bytes() + (int64_t)n * 4 + (int64_t)N * 32 + 64;
   const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(R, ((int64_t)1 << 30) / per));
-  NodeRec* trec = nullptr; uint64_t *tim = nullptr, *thy = nullptr; int32_t *tscr = nullptr, *tstat = nullptr, *tbad = nullptr;
+  TempBufs tmp;
+  uint8_t* tblk = nullptr; int32_t *tlpar = nullptr, *tscr = nullptr, *tstat = nullptr, *tbad = nullptr;
   double *ttot = nullptr, *tsum = nullptr;
-  auto cleanup = [&]() {
-    (void)hipFree(trec); (void)hipFree(tim); (void)hipFree(thy); (void)hipFree(tscr);
-    (void)hipFree(tstat); (void)hipFree(tbad); (void)hipFree(ttot); (void)hipFree(tsum);
-  };
-  hipError_t e = hipMalloc((void**)&trec, (size_t)chunk * N * sizeof(NodeRec));
-  if (e == hipSuccess) e = hipMalloc((void**)&tim, (size_t)chunk * (n - 1) * L * 8);
-  if (e == hipSuccess && h->hyper) e = hipMalloc((void**)&thy, (size_t)chunk * (n - 1) * L * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&tscr, (size_t)chunk * 4 * N * 4);
-  if (e == hipSuccess) e = hipMalloc((void**)&tstat, (size_t)chunk * 4);
-  if (e == hipSuccess) e = hipMalloc((void**)&tbad, (size_t)chunk * 4);
-  if (e == hipSuccess) e = hipMalloc((void**)&ttot, (size_t)chunk * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&tsum, (size_t)chunk * 8);
+  Links* tlinks = nullptr;
+  HIP_TRY(tmp.alloc(&tblk, chunk * h->block_bytes()));
+  HIP_TRY(tmp.alloc(&tlpar, chunk * n));
+  HIP_TRY(tmp.alloc(&tscr, chunk * 4 * N));
+  HIP_TRY(tmp.alloc(&tlinks, chunk * N));
+  HIP_TRY(tmp.alloc(&tstat, chunk));
+  HIP_TRY(tmp.alloc(&tbad, chunk));
+  HIP_TRY(tmp.alloc(&ttot, chunk));
+  HIP_TRY(tmp.alloc(&tsum, chunk));
   int64_t bad = 0, first = -1;
   std::vector<ReplicaState> rs;
-  if (e == hipSuccess && fetch_rs(h, rs) != TNCO_HIP_OK) e = hipErrorUnknown;
+  if (int rc = fetch_rs(h, rs)) return rc;
   std::vector<int32_t> hb((size_t)chunk), hs((size_t)chunk);
   std::vector<double> hsum((size_t)chunk);
-  for (int64_t r0 = 0; r0 < R && e == hipSuccess; r0 += chunk) {
+  for (int64_t r0 = 0; r0 < R; r0 += chunk) {
     const int64_t cnt = std::min(chunk, R - r0);
     BuildArgs a{};
-    a.out_rec = trec; a.out_imask = tim; a.out_hyper = thy; a.scratch = tscr;
+    a.out_blocks = tblk; a.out_lpar = tlpar; a.scratch = tscr;
     a.out_total = ttot; a.out_sum = tsum; a.out_status = tstat; a.r0 = r0; a.count = cnt;
     // (1) current tree: rebuild everything and compare
-    a.src_rec = P.rec;
-    launch_build(h, P, a);
+    a.src_live = 1;
+    launch_build(h, a);
     launch_compare(h, a, atol, tbad);
-    e = hipStreamSynchronize(h->stream);
-    if (e == hipSuccess) e = hipMemcpy(hb.data(), tbad, (size_t)cnt * 4, hipMemcpyDeviceToHost);
-    // (2) best tree: its cost must match min_total_cost
-    if (e == hipSuccess) {
-      a.src_rec = nullptr;
-      a.src_links = P.minlinks;
-      launch_build(h, P, a);
-      e = hipStreamSynchronize(h->stream);
-    }
-    if (e == hipSuccess) e = hipMemcpy(hs.data(), tstat, (size_t)cnt * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(hsum.data(), tsum, (size_t)cnt * 8, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) break;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(hb.data(), tbad, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    // (2) best tree (checkpoint + rotation log): its cost must match min_total_cost
+    hipLaunchKernelGGL(materialize_min_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, h->stream, P, tlinks, r0, cnt);
+    a.src_live = 0;
+    a.src_links = tlinks;
+    launch_build(h, a);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(hs.data(), tstat, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hsum.data(), tsum, (size_t)cnt * 8, hipMemcpyDeviceToHost));
     for (int64_t q = 0; q < cnt; ++q) {
-      bool b = hb[q] != 0 || hs[q] != 0;
-      const double x = hsum[q], y = rs[r0 + q].min_cost;
-      bool close = !(x < 0 || y < 0) && ((x == 0 || y == 0) ? (x == y) : (std::fabs(std::log(x) - std::log(y)) <= atol));
-      if (!close) b = true;
+      const bool b = hb[q] != 0 || hs[q] != 0 || !logclose(hsum[q], rs[r0 + q].min_cost, atol);
       if (b) { ++bad; if (first < 0) first = r0 + q; }
     }
   }
-  cleanup();
-  HIP_TRY(e);
   if (n_bad) *n_bad = bad;
   if (first_bad) *first_bad = first;
   return TNCO_HIP_OK;
