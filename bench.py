@@ -35,6 +35,29 @@ def algorithmic_bytes_per_move(W: int, a: float, q: float) -> float:
     return 56 * W + 80 + a * (24 * W + 64) + 8 * (2 + q)
 
 
+def usable_cores() -> int:
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        c = len(os.sched_getaffinity(0))
+    except AttributeError:
+        c = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = Path(path).read_text().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    c = min(c, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+                    c = min(c, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return c
+
+
 def cpu_baseline(prob, links, seeds, betas, n_sample, cores):
     """The oracle (plain-C port of the reference algorithm) on the host cores, bounded sample.
 
@@ -184,7 +207,7 @@ def main() -> None:
             },
         }
         if args.cpu_sample > 0:
-            cores = os.cpu_count() or 1
+            cores = usable_cores()
             ns = min(args.cpu_sample, R)
             v, m, t, cpu_min = cpu_baseline(prob, links, seeds, betas, ns, cores)
             gpu_min = opt.costs()[1][:ns]

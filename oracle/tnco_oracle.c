@@ -291,15 +291,15 @@ int orc_tree_is_valid(int32_t N, const int32_t* left, const int32_t* right,
     if (left[i] >= 0) { cc[left[i]]++; cc[right[i]]++; }
     if (parent[i] >= 0) cp[parent[i]]++;
   }
+  /* tree.hpp:113-131 as written: the lambdas are `return c == node.is_leaf() ? 0 : 2;` and
+   * `return c == node.is_root() ? 0 : 1;`, which C++ parses as `(c == is_leaf) ? 0 : 2`, so the
+   * reference only requires count_parents != is_leaf and count_children != is_root (pinned by
+   * oracle/_ref).  The product's own check (tnco_hip_create) is deliberately stricter. */
   int bad = 0;
   for (int32_t i = 0; i < N; ++i) {
-    if (cp[i] != ((left[i] < 0) ? 0 : 2)) bad = 7;
-    if (cc[i] != ((parent[i] < 0) ? 0 : 1)) bad = 8;
+    if (cp[i] == ((left[i] < 0) ? 1 : 0)) bad = 7;
+    if (cc[i] == ((parent[i] < 0) ? 1 : 0)) bad = 8;
   }
-  /* children/parent links must agree (implied by the counts for a valid
-   * tree but made explicit here). */
-  for (int32_t i = 0; i < N && !bad; ++i)
-    if (left[i] >= 0 && (parent[left[i]] != i || parent[right[i]] != i)) bad = 8;
   free(cp);
   free(cc);
   return bad;

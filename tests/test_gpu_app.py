@@ -1,0 +1,105 @@
+"""GPU tests of the plugin API: tnco_amd.app.Optimizer(method='sa').optimize(...)
+(the call shape of /root/reference/README.md:93-106 and tests/test_app.py:117-329)."""
+import json
+import math
+import random
+from decimal import Decimal
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+from tnco_amd import ctree as ct
+from tnco_amd.app import Optimizer, load_tn
+from tnco_amd.app.infinite_memory.sa import expand_betas
+
+pytestmark = pytest.mark.gpu
+
+
+def _replay(tn, path):
+    """Contract symbolically along a linear path: returns (final legs, total cost)
+    (tests/test_contraction.py:57-181 replays min_ctree.path() the same way)."""
+    ts = [frozenset(x) for x in tn.ts_inds]
+    count = {}
+    for xs in ts:
+        for i in xs:
+            count[i] = count.get(i, 0) + 1
+    for i in tn.output_inds:
+        count[i] += 1
+    cost = 0
+    for x, y in path:
+        x, y = sorted((x, y))
+        b = ts.pop(y)
+        a = ts.pop(x)
+        cost += math.prod(tn.dims[i] for i in a | b)
+        out = set(a ^ b)
+        for i in a & b:
+            count[i] -= 1
+            if count[i] > 1 or (count[i] == 1 and (i in tn.output_inds or any(i in t for t in ts))):
+                out.add(i)
+        ts.append(frozenset(out))
+    return ts, cost
+
+
+def test_readme_chain_config1():
+    """BASELINE config 1: 3-index chain of the README, n_steps=100, n_runs=8 (un-fused)."""
+    opt = Optimizer(method="sa", seed=0)
+    tn, res = opt.optimize("2 a b\n2 b c\n2 c d", betas=(0, 100), n_steps=100, n_runs=8)
+    assert len(res) == 8 and [r.cost for r in res] == sorted(r.cost for r in res)
+    for r in res:
+        final, cost = _replay(tn, r.path)
+        assert len(final) == 1 and final[0] == tn.output_inds
+        assert Decimal("%g" % cost) == r.cost
+        assert len(r.path) == 3 and len(r.disconnected_paths) == 1
+        assert [tuple(sorted(p)) for p in r.disconnected_paths[0]] == [tuple(p) for p in r.path]
+    # the optimum of the open 4-chain: sweep from one end, 4 + 4 + 2 flops
+    assert res[0].cost == Decimal(10)
+
+
+def test_results_match_oracle_run_by_run(oracle_lib):
+    ts, dims, out = __import__("tnco_amd.synthetic", fromlist=["x"]).random_regular_tn(24, 3, 5)
+    spec = [(2, *[f"t{t}" for t in range(len(ts)) if k in ts[t]]) for k in range(36)]
+    opt = Optimizer(method="sa", seed=11)
+    n_runs, n_steps = 12, 150
+    tn, res = opt.optimize(spec, betas=(0, 50), n_steps=n_steps, n_runs=n_runs)
+    seeds = random.Random(11).choices(range(2**32), k=n_runs)
+    betas = expand_betas((0, 50), n_steps)
+    # bit position of an index = order of first appearance over the tensors (tnco/ctree.py:232,
+    # `_inds_order`); the initial-tree generator walks indices by position
+    imap = {x: k for k, x in enumerate(dict.fromkeys(i for xs in tn.ts_inds for i in xs))}
+    prob = H.Problem([[imap[i] for i in xs] for xs in tn.ts_inds], 2)
+    want = []
+    for s in seeds:
+        l, r, p = prob.tree(s)
+        o = H.make_oracle(oracle_lib, prob, (l, r, p), s)
+        o.run(oracle_lib.PROB_MH, betas)
+        ml, mr, _mp, _ = o.tree(which_min=True)
+        want.append((Decimal("%g" % o.min_total_cost), ct.ssa_to_linear(ct.get_contraction(ml, mr), len(ts))))
+    want.sort(key=lambda t: t[0])
+    assert [r.cost for r in res] == [w[0] for w in want]
+    got_paths = sorted(tuple(map(tuple, r.disconnected_paths[0])) for r in res)
+    assert got_paths == sorted(tuple(map(tuple, w[1])) for w in want)
+    for r in res:  # one component: the merged path is the component's path with sorted pairs
+        assert [tuple(p) for p in r.path] == [tuple(sorted(p)) for p in r.disconnected_paths[0]]
+    assert float(res[0].cost) <= float(tn.tags["best_raw_cost"]) * (1 + 1e-5)
+
+
+def test_disconnected_components_and_json():
+    spec = "2 a b\n2 b c\n3 x y\n3 y z\n3 z x\n2 lonely"
+    opt = Optimizer(method="sa", seed=3, output_format="json")
+    out = json.loads(opt.optimize(spec, betas=(0, 10), n_steps=30, n_runs=4))
+    assert len(out["res"]) == 4 and len(out["tn"]["tensors"]) == 7
+    tn = load_tn(spec)
+    for r in out["res"]:
+        assert len(r["path"]) == 6  # 7 tensors -> 6 contractions after autocomplete
+        assert len(r["disconnected_paths"]) == 3
+        final, _ = _replay(tn, [tuple(p) for p in r["path"]])
+        assert len(final) == 1
+
+
+def test_timeout_and_top_k():
+    ts, dims, out = __import__("tnco_amd.synthetic", fromlist=["x"]).random_regular_tn(64, 3, 7)
+    spec = [(2, *[f"t{t}" for t in range(64) if k in ts[t]]) for k in range(96)]
+    tn, res = Optimizer(method="sa", seed=1).optimize(spec, betas=(0, 100), n_steps=20000, n_runs=64,
+                                                      timeout=0.2, top_k=5, sweeps_per_launch=50)
+    assert len(res) == 5 and tn.tags["timed_out"] and tn.tags["n_runs"] == 64

@@ -1,0 +1,143 @@
+"""CPU tests of the host logic: tree flattening, paths, initial trees, schedule, loader, sharding."""
+import random
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+from tnco_amd import ctree as ct
+from tnco_amd import parallel
+from tnco_amd import synthetic as syn
+from tnco_amd.app import Optimizer, load_tn
+from tnco_amd.app.infinite_memory.sa import expand_betas, merge_contraction_paths
+
+
+def _random_linear_path(n, rng):
+    path, m = [], n
+    while m > 1:
+        i, j = rng.sample(range(m), 2)
+        path.append((i, j))
+        m -= 1
+    return path
+
+
+def _clusters(tree):
+    """Set of leaf sets of the internal nodes: the tree up to renumbering of intermediates."""
+    below = {}
+    for p in ct.traverse(tree.left, tree.right):
+        below[p] = frozenset([p]) if tree.left[p] < 0 else below[tree.left[p]] | below[tree.right[p]]
+    return {v for p, v in below.items() if tree.left[p] >= 0}
+
+
+def test_contraction_tree_matches_derive_and_roundtrips():
+    """ctree.py:108-251 flattening (hyper-count bookkeeping) == set rule; path() round trip
+    (tests/test_utils.py:351-572)."""
+    rng = random.Random(1)
+    for seed in range(8):
+        ts, dims, out = syn.random_hyper_tn(12, 26, k=3, n_output=3, seed=seed, dims_choices=(2, 3))
+        names = [[f"i{p}" for p in xs] for xs in ts]
+        path = _random_linear_path(len(ts), rng)
+        tree = ct.ContractionTree(path, names, {f"i{p}": d for p, d in enumerate(dims)},
+                                  output_inds=[f"i{p}" for p in out])
+        n = tree.n_leaves
+        assert len(tree) == 2 * n - 1 and tree.parent[-1] == -1
+        assert all(tree.left[i] < 0 for i in range(n))
+        derived = ct.derive_inds(tree.left, tree.right, tree.masks[:n], tree.output_mask)
+        assert np.array_equal(derived, tree.masks)
+        # path() reproduces a path whose tree is the same tree
+        again = ct.ContractionTree(tree.path(), names, {f"i{p}": d for p, d in enumerate(dims)},
+                                   output_inds=[f"i{p}" for p in out])
+        assert _clusters(again) == _clusters(tree)  # same tree up to the numbering of intermediates
+        # linear -> SSA -> linear keeps every step up to the order inside a pair (pairs are sorted
+        # on the way in, ctree.py:117)
+        assert ct.ssa_to_linear(ct.linear_to_ssa(path, len(ts)), len(ts)) == [tuple(sorted(p)) for p in path]
+
+
+def test_readme_example_tree():
+    """README.md:93-106 input '2 a b / 2 b c / 2 c d': 4 tensors in a chain."""
+    tn = load_tn("2 a b\n2 b c\n2 c d")
+    assert len(tn) == 4 and tn.output_inds == frozenset() and set(tn.dims.values()) == {2}
+    tree = ct.ContractionTree([(0, 1), (0, 1), (0, 1)], tn.ts_inds, 2, check_shared_inds=True)
+    assert tree.n_leaves == 4 and tree.max_width() == 2.0
+    with pytest.raises(ValueError):
+        ct.ContractionTree([(0, 3), (0, 1), (0, 1)], tn.ts_inds, 2, check_shared_inds=True)
+
+
+def test_random_contraction_is_valid_and_native_matches():
+    from tnco_amd import core
+    for n, seed in [(2, 0), (8, 1), (64, 2), (200, 3)]:
+        deg = 3 if n > 4 else 1
+        prob = H.regular_problem(n, graph_seed=seed, degree=deg) if n > 2 else H.Problem([[0], [0]], 2)
+        seeds = [0, 1, 2**32 - 1, 123456789]
+        links = core.random_trees(prob.ts_inds, prob.n_inds, seeds)
+        for k, s in enumerate(seeds):
+            l, r, p = prob.tree(s)
+            assert np.array_equal(links[k], np.stack([l, r, p]))
+            # every contraction shares an index (check_shared_inds, sa.py:186-190)
+            ct.derive_inds(l, r, prob.leaf_masks, prob.output_mask, check_shared_inds=True)
+    with pytest.raises(ValueError):
+        core.random_trees([[0], [0], [1], [1]], 2, [1])  # two components
+
+
+def test_merge_contraction_paths_docstring_example():
+    assert merge_contraction_paths(4, [[(0, 1)], [(2, 3)]]) == [(0, 1), (0, 1), (0, 1)]
+    assert merge_contraction_paths(3, [[], [], []]) == [(0, 1), (0, 1)]
+
+
+def test_expand_betas():
+    b = expand_betas((0.0, 100.0), 100)
+    assert len(b) == 100 and b[0] == 0.0 and b[1] == 1.0 and b[-1] == 99.0
+    assert list(expand_betas((10.0, 0.0), 4)) == [10.0, 7.5, 5.0, 2.5]
+    assert list(expand_betas([1, 2, 3], None)) == [1.0, 2.0, 3.0]
+    assert list(expand_betas([1, 2, 3], 2)) == [1.0, 2.0]
+    for bad in (0, -1, 1.5):
+        with pytest.raises(ValueError, match="'n_steps' must be a positive number."):
+            expand_betas((0, 1), bad)
+    with pytest.raises(ValueError, match="must be provided"):
+        expand_betas((0, 1), None)
+    with pytest.raises(ValueError, match="beta_ini != beta_end"):
+        expand_betas((1, 1), 5)
+
+
+def test_load_tn_formats_and_tokens():
+    tn = load_tn([(2, "a", "b"), (3, "b", "c", "*"), (2, "c", "/")])
+    assert len(tn) == 3 and tn.output_inds == {1} and tn.sparse_inds == {2} and tn.dims == {0: 2, 1: 3, 2: 2}
+    assert load_tn(tn) is tn
+    with pytest.raises(NotImplementedError):
+        load_tn("2 a b", fuse=4)
+    with pytest.raises(TypeError):
+        load_tn("hello world")
+    with pytest.raises(TypeError):
+        load_tn(3.5)
+
+
+def test_factory_dispatch_and_validation():
+    opt = Optimizer(method="sa", seed=1)
+    assert type(opt).__module__.endswith("app.infinite_memory.sa")
+    assert type(Optimizer(method="sa", max_width=20)).__module__.endswith("app.finite_width.sa")
+    assert type(Optimizer(method="sa", max_width=float("inf"))).__module__.endswith("app.infinite_memory.sa")
+    with pytest.raises(ModuleNotFoundError):
+        Optimizer(method="nope")
+    with pytest.raises(ValueError):
+        Optimizer(output_format="xml")
+    with pytest.raises(ValueError, match="'n_steps' must be a positive number."):
+        opt.optimize("2 a b\n2 b c", betas=(0, 1), n_steps=0)
+    with pytest.raises(NotImplementedError):
+        Optimizer(method="sa", max_width=4).optimize("2 a b\n2 b c", betas=(0, 1), n_steps=3)
+
+
+def test_shard_bounds_partition():
+    for n_runs in (1, 7, 64, 65537):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_bounds(n_runs, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n_runs
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        parallel.shard_bounds(4, 2, 2)
+
+
+def test_seed_list_is_the_reference_rule():
+    """seeds = Random(seed).choices(range(2**32), k=n_runs) (sa.py:237)."""
+    assert H.replica_seeds(3, S=0) == random.Random(0).choices(range(2**32), k=3)

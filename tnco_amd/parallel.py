@@ -29,6 +29,36 @@ def _dist():
     return torch, dist
 
 
+def rank_world() -> tuple[int, int]:
+    """(rank, world) of the default process group, (0, 1) when torch.distributed is not in use."""
+    try:
+        _torch, dist = _dist()
+    except ImportError:
+        return 0, 1
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def local_device() -> int:
+    """GPU ordinal of this rank: LOCAL_RANK under torchrun, else 0."""
+    import os
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def merge_heads(local: list, k: int, rank: int, world: int) -> list:
+    """Every rank contributes its best runs as tuples sorted by (cost, global run id, ...); all ranks
+    receive the k best overall in that order (the head of `sorted(results)`,
+    tnco/app/infinite_memory/sa.py:257)."""
+    if world == 1:
+        return sorted(local, key=lambda t: (t[0], t[1]))[:k]
+    _torch, dist = _dist()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, local)
+    merged = [t for part in gathered for t in part]
+    return sorted(merged, key=lambda t: (t[0], t[1]))[:k]
+
+
 def _tensor_device(dist, device):
     import torch
     if dist.get_backend() == "nccl":
