@@ -144,6 +144,9 @@ __device__ __forceinline__ bool accept_move(int kind, double beta, double delta,
 #ifndef TNCO_WAVES_PER_SIMD
 #define TNCO_WAVES_PER_SIMD 4
 #endif
+// "this value is needed here": forces the wait for a staged load at a chosen program point and
+// keeps memory operations from moving across it.
+#define TNCO_LANDED(x) __asm__ volatile("" : "+v"(x) : : "memory")
 template <int LOG2L, bool HYPER, bool GENERIC>
 __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
     const Params P, const double* __restrict__ betas, const int64_t n_steps, const int prob_kind) {
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
     double ccA = recA.ccost;
     const bool c_is_right = (al == B);
     const int C = c_is_right ? ar : al;
-    NodeRec recNN;
+    NodeRec recNN{-1, -1, -1, 0, 0.0, 0.0};
     uint64_t mCn = 0, iAn = 0, hAn = 0;
     double pCn = 0;
     if (aP >= 0) {
@@ -326,6 +329,16 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
 
     const double u = rng.uniform01();  // :162 (always drawn)
     const bool acc = accept_move(prob_kind, beta, delta, total, u, f32);
+
+    // vmcnt retires loads and stores in order and the compiler cannot count across the
+    // divergent regions of this loop, so it would wait for the staged operands AFTER this move's
+    // stores (i.e. for the stores' acknowledgements as well).  A fake use here, before the first
+    // store of the move, makes it wait for them now: they have had the whole evaluation above
+    // (plus the other waves of the SIMD) to arrive, and nothing younger is outstanding.
+    TNCO_LANDED(recNN.left); TNCO_LANDED(recNN.right); TNCO_LANDED(recNN.parent); TNCO_LANDED(recNN.ccost);
+    TNCO_LANDED(mCn); TNCO_LANDED(pCn);
+    if constexpr (HYPER) { TNCO_LANDED(iAn); TNCO_LANDED(hAn); }
+    TNCO_LANDED(rng.pa); TNCO_LANDED(rng.pb); TNCO_LANDED(rng.pc);
 
     double pEcur = pE, pCcur = pC;  // partials of B's other child / A's other child after the move
     uint64_t mBnow;                 // legs of B after the move
