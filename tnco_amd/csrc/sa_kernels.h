@@ -2,11 +2,12 @@
 // cost models, cache construction / validation.
 //
 // One replica (one annealing run of the reference, tnco/app/infinite_memory/sa.py:166-234) is
-// owned by a GROUP of L = 2^LOG2L adjacent lanes of a wavefront; lane w of the group holds word
-// w of every leg bitmask, so the set operations of
-// include/tnco/optimize/infinite_memory/optimizer.hpp:147,171-172 are one VALU op per lane and
-// popcounts / intersects are reduced across the group with DPP, never through memory.  Scalar
-// state is computed redundantly by every lane of the group and stored by lane 0.
+// owned by a GROUP of L = 2^LOG2L adjacent lanes of a wavefront; lane j of the group holds the
+// K consecutive words [j*K, j*K+K) of every leg bitmask (L*K >= W = ceil(n_inds/64)), so the set
+// operations of include/tnco/optimize/infinite_memory/optimizer.hpp:147,171-172 are K VALU ops
+// per lane and popcounts / intersects are reduced across the group with DPP, never through
+// memory.  Scalar state is computed redundantly by every lane of the group and stored by lane 0:
+// small groups (L = 4) keep that redundancy low and put 16 replicas in one wavefront.
 //
 // HBM layout, replica-major (everything of one replica is contiguous):
 //   node block of internal node p (BS bytes, BS = 32 + 8*W [*2 with hyper legs], rounded to 32):
@@ -56,51 +57,127 @@ struct Params {
   uint8_t* blocks;           // [R][n-1][BS]
   int32_t* lpar;             // [R][n]        parent of every leaf
   uint32_t* mt;              // [R][624]
+  uint32_t* mtshadow;        // [R][32]       generation-g words overwritten ahead of consumption
   ReplicaState* rs;          // [R]
   Links* minlinks;           // [R][N]        best-tree checkpoint (links only; legs re-derived on read)
   int32_t* jlog;             // [R][jcap]     node E of every accepted rotation since the checkpoint
-  const uint64_t* leafmask;  // [n][L]
-  const uint64_t* outmask;   // [L]
+  const uint64_t* leafmask;  // [n][L*K]
+  const uint64_t* outmask;   // [L*K]
   int32_t cost_mode;         // 0: uniform dims = 2^log2d; 1: uniform dims table; 2: per-index dims
   int32_t log2d;
   const double* ctab;        // [64*W+1]  d^k in cost_type (mode 1)
-  const double* dimsd;       // [L*64] dims in cost_type (mode 2)
-  const uint64_t* sparse;    // [L] or NULL
+  const double* dimsd;       // [L*K*64] dims in cost_type (mode 2)
+  const uint64_t* sparse;    // [L*K] or NULL
   double n_projs;            // (cost_type)n_projs
   int32_t f32;               // cost_type float32
   int32_t disable_shared;
 };
 
+// K words of a leg mask held by one lane.
+template <int K>
+struct Mask {
+  uint64_t w[K];
+};
+template <int K>
+__device__ __forceinline__ Mask<K> mzero() {
+  Mask<K> r;
+#pragma unroll
+  for (int k = 0; k < K; ++k) r.w[k] = 0;
+  return r;
+}
+#define TNCO_MASK_OP(NAME, EXPR)                                                  \
+  template <int K>                                                                \
+  __device__ __forceinline__ Mask<K> NAME(const Mask<K>& a, const Mask<K>& b) {   \
+    Mask<K> r;                                                                    \
+    _Pragma("unroll") for (int k = 0; k < K; ++k) r.w[k] = (EXPR);                \
+    return r;                                                                     \
+  }
+TNCO_MASK_OP(mand, a.w[k] & b.w[k])
+TNCO_MASK_OP(mor, a.w[k] | b.w[k])
+TNCO_MASK_OP(mxor, a.w[k] ^ b.w[k])
+TNCO_MASK_OP(mandn, a.w[k] & ~b.w[k])
+#undef TNCO_MASK_OP
+template <int K>
+__device__ __forceinline__ uint32_t mpopc(const Mask<K>& a) {
+  uint32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) c += (uint32_t)__popcll(a.w[k]);
+  return c;
+}
+template <int K>
+__device__ __forceinline__ bool mnonzero(const Mask<K>& a) {
+  uint64_t x = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) x |= a.w[k];
+  return x != 0;
+}
+template <int K>
+__device__ __forceinline__ bool mdiffer(const Mask<K>& a, const Mask<K>& b) {
+  return mnonzero<K>(mxor<K>(a, b));
+}
+template <int K>
+__device__ __forceinline__ Mask<K> msel(bool c, const Mask<K>& a, const Mask<K>& b) {
+  Mask<K> r;
+#pragma unroll
+  for (int k = 0; k < K; ++k) r.w[k] = c ? a.w[k] : b.w[k];
+  return r;
+}
+
 // Per-replica view of the node blocks.
-template <int LOG2L, bool HYPER>
+template <int LOG2L, int K, bool HYPER>
 struct View {
   static constexpr int L = 1 << LOG2L;
+  static constexpr int LK = L * K;
   uint8_t* blk;
   int32_t* lpar;
   const uint64_t* leafmask;
   int n, BS, W, lig;
-  bool wl;  // this lane holds a real mask word (lig < W)
 
   __device__ __forceinline__ void init(const Params& P, uint8_t* blk_, int32_t* lpar_, int lig_) {
     blk = blk_; lpar = lpar_; leafmask = P.leafmask; n = P.n; BS = P.BS; W = P.W; lig = lig_;
-    wl = lig_ < P.W;
   }
   __device__ __forceinline__ NodeRec* hdr(int p) const {
     return reinterpret_cast<NodeRec*>(blk + (int64_t)(p - n) * BS);
   }
-  __device__ __forceinline__ uint64_t* mword(int p) const {
-    return reinterpret_cast<uint64_t*>(blk + (int64_t)(p - n) * BS + 32) + lig;
+  __device__ __forceinline__ uint64_t* words(int p) const {
+    return reinterpret_cast<uint64_t*>(blk + (int64_t)(p - n) * BS + 32) + lig * K;
   }
-  __device__ __forceinline__ uint64_t* hword(int p) const {
-    return reinterpret_cast<uint64_t*>(blk + (int64_t)(p - n) * BS + 32) + W + lig;
+  __device__ __forceinline__ Mask<K> mask(int x) const {
+    Mask<K> r;
+    if (x < n) {
+      const uint64_t* s = leafmask + (int64_t)x * LK + lig * K;
+#pragma unroll
+      for (int k = 0; k < K; ++k) r.w[k] = s[k];
+    } else {
+      const uint64_t* s = words(x);
+#pragma unroll
+      for (int k = 0; k < K; ++k) r.w[k] = (lig * K + k < W) ? s[k] : 0ull;
+    }
+    return r;
   }
-  __device__ __forceinline__ uint64_t mask(int x) const {
-    if (x < n) return leafmask[(int64_t)x * L + lig];
-    return wl ? *mword(x) : 0ull;
+  __device__ __forceinline__ void set_mask(int p, const Mask<K>& v) const {
+    uint64_t* s = words(p);
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (lig * K + k < W) s[k] = v.w[k];
   }
-  __device__ __forceinline__ void set_mask(int p, uint64_t v) const { if (wl) *mword(p) = v; }
-  __device__ __forceinline__ uint64_t hyper(int p) const { return (HYPER && wl) ? *hword(p) : 0ull; }
-  __device__ __forceinline__ void set_hyper(int p, uint64_t v) const { if (HYPER && wl) *hword(p) = v; }
+  __device__ __forceinline__ Mask<K> hyper(int p) const {
+    Mask<K> r = mzero<K>();
+    if constexpr (HYPER) {
+      const uint64_t* s = words(p) + W;
+#pragma unroll
+      for (int k = 0; k < K; ++k) r.w[k] = (lig * K + k < W) ? s[k] : 0ull;
+    }
+    return r;
+  }
+  __device__ __forceinline__ void set_hyper(int p, const Mask<K>& v) const {
+    if constexpr (HYPER) {
+      uint64_t* s = words(p) + W;
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if (lig * K + k < W) s[k] = v.w[k];
+    }
+  }
   __device__ __forceinline__ double partial(int x) const { return x < n ? 0.0 : hdr(x)->partial; }
   __device__ __forceinline__ int parent(int x) const { return x < n ? lpar[x] : hdr(x)->parent; }
   __device__ __forceinline__ void set_parent(int x, int p) const {
@@ -155,18 +232,24 @@ __device__ __forceinline__ double pow2_cost(int e, int f32) {
 // include/tnco/optimize/infinite_memory/cost_model/simple.hpp:37-55,
 // simple_sparse_inds.hpp:37-49.
 // ---------------------------------------------------------------------------
-template <int LOG2L>
-__device__ __forceinline__ double seq_product(const Params& P, uint64_t u, int gbase) {
-  // running product in cost_type over ascending set bits (Bitset::visit order)
+template <int LOG2L, int K>
+__device__ __forceinline__ double seq_product(const Params& P, const Mask<K>& u, int gbase) {
+  // running product in cost_type over ascending set bits (Bitset::visit order): lane by lane,
+  // word by word
+  constexpr int L = 1 << LOG2L;
   double c = 1.0;
-  for (int w = 0; w < P.W; ++w) {
-    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)u, gbase + w);
-    const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(u >> 32), gbase + w);
-    uint64_t x = ((uint64_t)hi << 32) | lo;
-    while (x) {
-      const int b = __ffsll((unsigned long long)x) - 1;
-      c = rnd_cost(c * P.dimsd[w * 64 + b], P.f32);
-      x &= x - 1;
+  for (int j = 0; j < L; ++j) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)u.w[k], gbase + j);
+      const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(u.w[k] >> 32), gbase + j);
+      uint64_t x = ((uint64_t)hi << 32) | lo;
+      const int w = j * K + k;
+      while (x) {
+        const int b = __ffsll((unsigned long long)x) - 1;
+        c = rnd_cost(c * P.dimsd[w * 64 + b], P.f32);
+        x &= x - 1;
+      }
     }
   }
   return c;
@@ -176,22 +259,24 @@ __device__ __forceinline__ double uniform_cost(const Params& P, int pc) {
   return P.cost_mode == 0 ? pow2_cost(P.log2d * pc, P.f32) : P.ctab[pc];
 }
 
-// cost of contracting two tensors whose leg union is `u` (this lane's word).
-template <int LOG2L>
-__device__ __forceinline__ double generic_cost(const Params& P, uint64_t u, int lig, int gbase) {
+// cost of contracting two tensors whose leg union is `u` (this lane's words).
+template <int LOG2L, int K>
+__device__ __forceinline__ double generic_cost(const Params& P, const Mask<K>& u, int lig, int gbase) {
   if (P.sparse == nullptr) {
-    if (P.cost_mode <= 1) return uniform_cost(P, (int)gsum<LOG2L>((uint32_t)__popcll(u)));
-    return seq_product<LOG2L>(P, u, gbase);
+    if (P.cost_mode <= 1) return uniform_cost(P, (int)gsum<LOG2L>(mpopc<K>(u)));
+    return seq_product<LOG2L, K>(P, u, gbase);
   }
-  const uint64_t s = P.sparse[lig];
+  Mask<K> s;
+#pragma unroll
+  for (int k = 0; k < K; ++k) s.w[k] = P.sparse[lig * K + k];
   double c1, c2;
   if (P.cost_mode <= 1) {
-    const uint32_t v = gsum<LOG2L>((uint32_t)__popcll(u & ~s) | ((uint32_t)__popcll(u & s) << 16));
+    const uint32_t v = gsum<LOG2L>(mpopc<K>(mandn<K>(u, s)) | (mpopc<K>(mand<K>(u, s)) << 16));
     c1 = uniform_cost(P, (int)(v & 0xffffu));
     c2 = uniform_cost(P, (int)(v >> 16));
   } else {
-    c1 = seq_product<LOG2L>(P, u & ~s, gbase);
-    c2 = seq_product<LOG2L>(P, u & s, gbase);
+    c1 = seq_product<LOG2L, K>(P, mandn<K>(u, s), gbase);
+    c2 = seq_product<LOG2L, K>(P, mand<K>(u, s), gbase);
   }
   return rnd_cost(c1 * (c2 < P.n_projs ? c2 : P.n_projs), P.f32);
 }
@@ -240,10 +325,11 @@ struct BuildArgs {
   int64_t count;
 };
 
-template <int LOG2L, bool HYPER>
+template <int LOG2L, int K, bool HYPER>
 __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildArgs a) {
   constexpr int L = 1 << LOG2L;
   constexpr int GPB = 256 >> LOG2L;
+  using M = Mask<K>;
   const int tid = threadIdx.x;
   const int lig = tid & (L - 1);
   const int gbase = (tid & 63) & ~(L - 1);
@@ -253,14 +339,17 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
   const bool lane0 = lig == 0;
   const int n = P.n, N = P.N;
 
-  View<LOG2L, HYPER> v;
+  View<LOG2L, K, HYPER> v;
   v.init(P, a.out_blocks + q * (int64_t)(n - 1) * P.BS, a.out_lpar + q * (int64_t)n, lig);
-  View<LOG2L, HYPER> live;
+  View<LOG2L, K, HYPER> live;
   live.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n, lig);
   int32_t* stack = a.scratch + q * 4 * (int64_t)N;
   int32_t* order = stack + N;
   int32_t* visited = order + N;
   int status = 0;
+  M om;
+#pragma unroll
+  for (int k = 0; k < K; ++k) om.w[k] = P.outmask[lig * K + k];
 
   // -- links --------------------------------------------------------------
   for (int i = lig; i < N; i += L) {
@@ -286,7 +375,7 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // -- traverse (utils.hpp:34-51), every lane of the group redundantly -----
-  int sp = 1, k = 0;
+  int sp = 1, cnt = 0;
   if (lane0) stack[0] = N - 1;
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
   while (sp > 0) {
@@ -294,8 +383,8 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
     const int l = v.left(pos);
     if (visited[pos] || l < 0) {
       --sp;
-      if (lane0) order[k] = pos;
-      ++k;
+      if (lane0) order[cnt] = pos;
+      ++cnt;
     } else {
       const int rr = v.right(pos);
       if (lane0) { visited[pos] = 1; stack[sp] = rr; stack[sp + 1] = l; }
@@ -307,17 +396,19 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
   // -- legs of internal nodes ---------------------------------------------
   if (a.in_masks) {
     const uint64_t* im = a.in_masks + r * a.in_masks_stride;
-    for (int p = n; p < N; ++p) v.set_mask(p, im[(int64_t)p * P.W + (v.wl ? lig : 0)]);
-    for (int p = 0; p < n; ++p) {  // leaves must be the shared leaf table
-      const uint64_t x = v.wl ? im[(int64_t)p * P.W + lig] : 0ull;
-      if (gany<LOG2L>(x != P.leafmask[(int64_t)p * L + lig])) status = 12;
+    for (int p = 0; p < N; ++p) {
+      M x;
+#pragma unroll
+      for (int k = 0; k < K; ++k) x.w[k] = (lig * K + k < P.W) ? im[(int64_t)p * P.W + lig * K + k] : 0ull;
+      if (p >= n) v.set_mask(p, x);
+      else if (gany<LOG2L>(mdiffer<K>(x, v.mask(p)))) status = 12;  // leaves must be the shared table
     }
   } else if constexpr (!HYPER) {
     for (int i = 0; i < N; ++i) {
       const int p = order[i];
       const int l = v.left(p);
       if (l < 0) continue;
-      v.set_mask(p, v.mask(l) ^ v.mask(v.right(p)));
+      v.set_mask(p, mxor<K>(v.mask(l), v.mask(v.right(p))));
     }
   } else {
     // union of leaves below (in the legs slot), legs held outside (in the hyper slot), then
@@ -326,25 +417,25 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
       const int p = order[i];
       const int l = v.left(p);
       if (l < 0) continue;
-      v.set_mask(p, v.mask(l) | v.mask(v.right(p)));
+      v.set_mask(p, mor<K>(v.mask(l), v.mask(v.right(p))));
     }
     for (int i = N - 1; i >= 0; --i) {
       const int p = order[i];
       const int l = v.left(p);
       if (l < 0) continue;
       const int rr = v.right(p);
-      const uint64_t op = (p == N - 1) ? P.outmask[lig] : v.hyper(p);
-      const uint64_t ul = v.mask(l), ur = v.mask(rr);
-      if (l >= n) v.set_hyper(l, op | ur);
-      if (rr >= n) v.set_hyper(rr, op | ul);
+      const M op = (p == N - 1) ? om : v.hyper(p);
+      const M ul = v.mask(l), ur = v.mask(rr);
+      if (l >= n) v.set_hyper(l, mor<K>(op, ur));
+      if (rr >= n) v.set_hyper(rr, mor<K>(op, ul));
     }
     for (int i = 0; i < N; ++i) {
       const int p = order[i];
       const int l = v.left(p);
       if (l < 0) continue;
-      const uint64_t ia = v.mask(l), ib = v.mask(v.right(p));
-      const uint64_t op = (p == N - 1) ? P.outmask[lig] : v.hyper(p);
-      v.set_mask(p, (ia ^ ib) | (ia & ib & op));
+      const M ia = v.mask(l), ib = v.mask(v.right(p));
+      const M op = (p == N - 1) ? om : v.hyper(p);
+      v.set_mask(p, mor<K>(mxor<K>(ia, ib), mand<K>(mand<K>(ia, ib), op)));
     }
   }
 
@@ -355,11 +446,12 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
     const int l = v.left(p);
     if (l < 0) continue;
     const int rr = v.right(p);
-    const uint64_t ia = v.mask(l), ib = v.mask(rr), ip = v.mask(p);
-    if (!P.disable_shared && !gany<LOG2L>((ia & ib) != 0)) status = status ? status : 10;
-    if (gany<LOG2L>((((ia ^ ib) & ~ip) | (ip & ~(ia | ib))) != 0)) status = status ? status : 11;
-    v.set_hyper(p, ip & ia & ib);
-    const double c = generic_cost<LOG2L>(P, ia | ib, lig, gbase);
+    const M ia = v.mask(l), ib = v.mask(rr), ip = v.mask(p);
+    const M uni = mor<K>(ia, ib);
+    if (!P.disable_shared && !gany<LOG2L>(mnonzero<K>(mand<K>(ia, ib)))) status = status ? status : 10;
+    if (gany<LOG2L>(mnonzero<K>(mor<K>(mandn<K>(mxor<K>(ia, ib), ip), mandn<K>(ip, uni))))) status = status ? status : 11;
+    v.set_hyper(p, mand<K>(ip, mand<K>(ia, ib)));
+    const double c = generic_cost<LOG2L, K>(P, uni, lig, gbase);
     const double part = rnd_cost(rnd_cost(c + v.partial(l), P.f32) + v.partial(rr), P.f32);  // utils.hpp:54
     sum = rnd_cost(sum + c, P.f32);                                                          // utils.hpp:112
     if (lane0) { v.hdr(p)->ccost = c; v.hdr(p)->partial = part; }
@@ -374,7 +466,7 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
 
 // Compare a rebuilt cache set with the live one (is_valid,
 // infinite_memory/optimizer.hpp:223-251, is_logclose include/tnco/utils.hpp:78-87).
-template <int LOG2L, bool HYPER>
+template <int LOG2L, int K, bool HYPER>
 __global__ __launch_bounds__(256) void compare_kernel(const Params P, const BuildArgs a, double atol,
                                                       int32_t* out_bad) {
   constexpr int L = 1 << LOG2L;
@@ -385,7 +477,7 @@ __global__ __launch_bounds__(256) void compare_kernel(const Params P, const Buil
   if (q >= a.count) return;
   const int64_t r = a.r0 + q;
   const int n = P.n, N = P.N;
-  View<LOG2L, HYPER> ref, cur;
+  View<LOG2L, K, HYPER> ref, cur;
   ref.init(P, a.out_blocks + q * (int64_t)(n - 1) * P.BS, a.out_lpar + q * (int64_t)n, lig);
   cur.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n, lig);
   int bad = a.out_status[q];
@@ -405,8 +497,8 @@ __global__ __launch_bounds__(256) void compare_kernel(const Params P, const Buil
     }
   }
   for (int p = n; p < N; ++p) {
-    if (ref.mask(p) != cur.mask(p)) bad = bad ? bad : 34;
-    if (ref.hyper(p) != cur.hyper(p)) bad = bad ? bad : 33;
+    if (mdiffer<K>(ref.mask(p), cur.mask(p))) bad = bad ? bad : 34;
+    if (mdiffer<K>(ref.hyper(p), cur.hyper(p))) bad = bad ? bad : 33;
   }
   const uint32_t anybad = gsum<LOG2L>((uint32_t)(bad != 0));
   if (lig == 0) out_bad[q] = anybad ? (bad ? bad : 99) : 0;

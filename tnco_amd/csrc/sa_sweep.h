@@ -1,25 +1,36 @@
 // sa_sweep.h -- the sweep kernel: n_steps calls of Optimizer::update
 // (include/tnco/optimize/infinite_memory/optimizer.hpp:90-221) per replica, for all replicas.
 //
-// Latency structure (gfx950): the leaf->root walk is a dependent pointer chase and vmcnt
-// retires loads and stores IN ORDER, so a load issued after a store waits for the store's
-// acknowledgement.  The loop is therefore software-pipelined by hand:
-//   * the header of A(k+2) and the block of C(k+1) are requested at the TOP of move k, before
-//     move k's stores, and consumed one / two moves later;
-//   * the mt19937 inputs of the next 16-output block are requested when the current block is
-//     generated;
-// so that the only exposed memory latencies are at the start of a sweep.
+// Execution structure (gfx950).  A wavefront carries 64/L replicas (16 at L = 4), each at its own
+// position of its own leaf->root walk.  The walk is a dependent pointer chase, and vmcnt retires
+// loads and stores IN ORDER, so a load consumed after a store also waits for that store.  The
+// kernel is therefore a per-replica STATE MACHINE in which no load is consumed in the iteration
+// that issues it:
+//
+//     every iteration:   [issue the loads the NEXT iteration needs]
+//                        [work on what landed during the PREVIOUS iteration]
+//                        [landing fence: wait for this iteration's loads]   <- before any store
+//                        [this iteration's stores]
+//
+//   states:  BEGIN  draw the leaf, request its parent                     (optimizer.hpp:103)
+//            GOT_B  request the header of B = parent(leaf)                (:107)
+//            GOT_HB request legs / partial costs of B's children, header of A, total cost (:112)
+//            GOT_HA request the block of C (sibling of B) and the header of parent(A)
+//            MOVE   one move evaluation per iteration (:117-192), requesting the operands of the
+//                   next level at its top
+//            END    B is the root: best-tree update (:198-201), then BEGIN of the next sweep
+//
+// so a replica at the start of a sweep never stalls the other replicas of its wavefront, and the
+// memory latency of every load is covered by one full iteration of work of the whole SIMD.
+// The mt19937 stream is produced the same way: 16-word (L-word for L < 16) blocks are requested
+// one iteration, twisted + tempered into an LDS ring the next, stored in the store phase.
 #pragma once
 #include "sa_kernels.h"
 
 namespace tnco {
 
-// ---------------------------------------------------------------------------
-// std::mt19937, generated lazily in blocks of SB = min(L, 16) outputs per group.
-// State words live in HBM ([624] per replica); the tempered outputs of the current block
-// live in an LDS slot of the group; the raw inputs of the NEXT block are prefetched into
-// registers.  (libstdc++ random.tcc:396-471; seeding :326-343.)
-// ---------------------------------------------------------------------------
+#define TNCO_LANDED(x) __asm__ volatile("" : "+v"(x) : : "memory")
+
 __device__ __forceinline__ uint32_t mt_temper(uint32_t z) {
   z ^= (z >> 11);
   z ^= (z << 7) & 0x9d2c5680u;
@@ -28,75 +39,100 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t z) {
   return z;
 }
 
+// ---------------------------------------------------------------------------
+// std::mt19937 (libstdc++ random.tcc:326-471) as a staged producer / consumer.
+// Positions are VIRTUAL word indices vp = 624*generation + i, generation 0 being the one the
+// state array held at kernel entry.  `cons` outputs have been drawn, `prod` produced into the
+// ring (multiple of SB), state words below `tw` are twisted.  Blocks may be produced up to RING
+// outputs ahead of consumption; when that crosses into the next generation the overwritten
+// words are kept in a shadow so that the exported state is exactly libstdc++'s at `cons`.
+// ---------------------------------------------------------------------------
 template <int LOG2L>
 struct Rng {
   static constexpr int L = 1 << LOG2L;
   static constexpr int LOG2SB = LOG2L < 4 ? LOG2L : 4;
-  static constexpr int SB = 1 << LOG2SB;  // outputs per block
-  static constexpr int NB = 624 / SB;
+  static constexpr int SB = 1 << LOG2SB;           // words per block
+  static constexpr int RING = (2 * SB > 16) ? 2 * SB : 16;
 
   uint32_t* st;            // replica's 624 state words (HBM)
-  volatile uint32_t* buf;  // group's SB-word LDS slot
-  int mti, mtw, cur_blk, lig;
-  uint32_t pa, pb, pc;     // prefetched inputs of block pf_blk
-  int pf_blk;
+  uint32_t* shadow;        // replica's RING shadow words (HBM)
+  volatile uint32_t* ring; // group's LDS ring
+  int lig;
+  uint32_t cons, prod, tw;
+  bool pend, ptw;          // a block's inputs are in flight (for virtual position prod); it needs a twist
+  uint32_t pa, pb, pc;
+  bool sv, ssave;          // a twisted word awaits the store phase; its old value goes to the shadow
+  uint32_t sval, sold;
+  int sidx;
 
-  __device__ __forceinline__ void init(uint32_t* st_, volatile uint32_t* buf_, int mti_, int mtw_, int lig_) {
-    st = st_; buf = buf_; mti = mti_; mtw = mtw_; lig = lig_;
-    cur_blk = -1; pf_blk = -1; pa = pb = pc = 0;
-  }
+  __device__ __forceinline__ uint32_t gen_of_cons() const { return cons == 0 ? 0u : (cons - 1u) / 624u; }
 
-  __device__ __forceinline__ void load_inputs(int blk, bool twist, uint32_t& a, uint32_t& b, uint32_t& c) {
+  __device__ __forceinline__ void request() {
+    const uint32_t k0 = prod % 624u;
+    ptw = prod >= tw;
     if (lig < SB) {
-      const int k = blk * SB + lig;
-      a = st[k];
-      if (twist) {
+      const int k = (int)k0 + lig;
+      pa = st[k];
+      if (ptw) {
         const int k1 = (k + 1 == 624) ? 0 : k + 1;
         int km = k + 397;
         if (km >= 624) km -= 624;
-        b = st[k1];
-        c = st[km];
+        pb = st[k1];
+        pc = st[km];
       }
     }
+    pend = true;
   }
-
-  __device__ __forceinline__ void refill(int blk) {
-    const bool twist = (blk * SB) >= mtw;
-    uint32_t a = pa, b = pb, c = pc;
-    if (pf_blk != blk) load_inputs(blk, twist, a, b, c);
+  // inputs landed: twist + temper into the ring; the state store waits for the store phase
+  __device__ __forceinline__ void produce() {
     if (lig < SB) {
-      uint32_t v = a;
-      if (twist) {
-        const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
-        v = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-        st[blk * SB + lig] = v;
+      uint32_t v = pa;
+      if (ptw) {
+        const uint32_t y = (pa & 0x80000000u) | (pb & 0x7fffffffu);
+        v = pc ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
       }
-      buf[lig] = mt_temper(v);
+      ring[(prod + (uint32_t)lig) & (RING - 1)] = mt_temper(v);
+      sval = v;
+      sold = pa;
     }
-    if (twist) mtw = blk * SB + SB;
-    cur_blk = blk;
-    // request the next block's inputs now; they are consumed ~SB draws later.  The block after
-    // the last one is block 0 of the next generation (always twisted, from the words just
-    // completed).
-    const int nb = (blk + 1 == NB) ? 0 : blk + 1;
-    const bool ntwist = (blk + 1 == NB) ? true : ((nb * SB) >= mtw);
-    load_inputs(nb, ntwist, pa, pb, pc);
-    pf_blk = nb;
+    if (ptw) {
+      sv = true;
+      sidx = (int)(prod % 624u) + lig;
+      ssave = (prod / 624u) > gen_of_cons();
+      tw = prod + SB;
+    }
+    prod += SB;
+    pend = false;
   }
-
-  __device__ __forceinline__ uint32_t next() {
-    if (mti >= 624) {
-      mti = 0;
-      mtw = 0;
-      cur_blk = -1;
+  __device__ __forceinline__ void store_phase() {
+    if (sv) {
+      if (lig < SB) {
+        st[sidx] = sval;
+        if (ssave) shadow[sidx] = sold;  // sidx < RING here: at most RING words ahead of a boundary
+      }
+      sv = false;
     }
-    const int blk = mti >> LOG2SB;
-    if (blk != cur_blk) refill(blk);
-    const uint32_t v = buf[mti & (SB - 1)];
-    ++mti;
+  }
+  __device__ __forceinline__ bool room() const { return !pend && (prod - cons) + SB <= (uint32_t)RING; }
+
+  __device__ __forceinline__ void init(uint32_t* st_, uint32_t* shadow_, volatile uint32_t* ring_, int mti,
+                                       int mtw, int lig_) {
+    st = st_; shadow = shadow_; ring = ring_; lig = lig_;
+    pend = false; sv = false; ssave = false; ptw = false;
+    pa = pb = pc = sval = sold = 0; sidx = 0;
+    if (mti >= 624) { cons = 624; tw = 624; } else { cons = (uint32_t)mti; tw = (uint32_t)mtw; }
+    prod = cons & ~(uint32_t)(SB - 1);
+    while (room()) {  // synchronous prologue fill
+      request();
+      produce();
+      store_phase();
+    }
+  }
+  __device__ __forceinline__ uint32_t next() {
+    const uint32_t v = ring[cons & (RING - 1)];
+    ++cons;
     return v;
   }
-
   // std::uniform_real_distribution<double>{} == generate_canonical<double,53>
   // (random.tcc:3348-3380): low word first, one rounding, scale by 2^-64.
   __device__ __forceinline__ double uniform01() {
@@ -106,6 +142,20 @@ struct Rng {
     double r = s * 5.421010862427522170037e-20;  // 2^-64
     if (r >= 1.0) r = 0.99999999999999988897769753748;  // nextafter(1, 0)
     return r;
+  }
+  // leave (state array, mti, mtw) exactly as libstdc++ would hold them after `cons` draws
+  __device__ __forceinline__ void finish(int& mti, int& mtw) {
+    if (pend) produce();  // inputs already requested: completing the block keeps `tw` consistent
+    store_phase();
+    const uint32_t g = gen_of_cons();
+    mti = (int)(cons - 624u * g);
+    if (tw > 624u * (g + 1u)) {
+      const uint32_t nw = tw - 624u * (g + 1u);  // words of generation g+1 twisted ahead
+      for (uint32_t k = (uint32_t)lig; k < nw; k += L) st[k] = shadow[k];
+      mtw = 624;
+    } else {
+      mtw = (int)(tw - 624u * g);
+    }
   }
 };
 
@@ -142,17 +192,18 @@ __device__ __forceinline__ bool accept_move(int kind, double beta, double delta,
 
 // ---------------------------------------------------------------------------
 #ifndef TNCO_WAVES_PER_SIMD
-#define TNCO_WAVES_PER_SIMD 4
+#define TNCO_WAVES_PER_SIMD 3
 #endif
-// "this value is needed here": forces the wait for a staged load at a chosen program point and
-// keeps memory operations from moving across it.
-#define TNCO_LANDED(x) __asm__ volatile("" : "+v"(x) : : "memory")
-template <int LOG2L, bool HYPER, bool GENERIC>
+enum : int { S_BEGIN = 0, S_GOT_B = 1, S_GOT_HB = 2, S_GOT_HA = 3, S_MOVE = 4, S_END = 5 };
+
+template <int LOG2L, int K, bool HYPER, bool GENERIC>
 __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
     const Params P, const double* __restrict__ betas, const int64_t n_steps, const int prob_kind) {
   constexpr int L = 1 << LOG2L;
   constexpr int GPB = 256 >> LOG2L;  // groups (replicas) per block
-  __shared__ uint32_t rngbuf[GPB * Rng<LOG2L>::SB];
+  using M = Mask<K>;
+  using R = Rng<LOG2L>;
+  __shared__ uint32_t rngbuf[GPB * R::RING];
 
   const int tid = threadIdx.x;
   const int lig = tid & (L - 1);
@@ -163,12 +214,12 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
   const bool lane0 = (lig == 0);
 
   const int n = P.n, N = P.N;
-  View<LOG2L, HYPER> v;
+  View<LOG2L, K, HYPER> v;
   v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n, lig);
   ReplicaState* rs = P.rs + r;
 
-  Rng<LOG2L> rng;
-  rng.init(P.mt + r * 624, rngbuf + gib * Rng<LOG2L>::SB, rs->mti, rs->mtw, lig);
+  R rng;
+  rng.init(P.mt + r * 624, P.mtshadow + r * 32, rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
 
   double min_cost = rs->min_cost;
   uint32_t n_moves = 0, n_acc = 0, n_impr = 0, n_rpick = 0, n_full = 0;
@@ -181,67 +232,52 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
   const bool disable_shared = P.disable_shared != 0;
 
   // ---- carried state: B and what is known about its two children ----------
-  int B, bl, br, A;
-  double ccB, partB, total, beta;
-  uint64_t m0, m1, iB = 0, hB = 0;
-  double p0, p1;
-  // ---- pipeline registers ---------------------------------------------------
-  NodeRec recA;   // header of A            (valid when A >= 0)
-  NodeRec recN;   // header of parent(A)    (valid when recA.parent >= 0)
-  uint64_t mC = 0, iA = 0, hA = 0;  // legs of C, legs / hyper legs of A
+  int B = 0, bl = 0, br = 0, A = -1;
+  double ccB = 0, partB = 0, total = 0, beta = 0;
+  M m0 = mzero<K>(), m1 = mzero<K>(), iB = mzero<K>(), hB = mzero<K>();
+  double p0 = 0, p1 = 0;
+  // ---- staged operands ------------------------------------------------------
+  NodeRec recA{-1, -1, -1, 0, 0.0, 0.0};  // header of A
+  NodeRec recN{-1, -1, -1, 0, 0.0, 0.0};  // header of parent(A)
+  M mC = mzero<K>(), iA = mzero<K>(), hA = mzero<K>();
   double pC = 0;
-
-  auto start_sweep = [&](int64_t step) {
-    beta = betas[step];
-    // optimizer.hpp:103-112
-    const uint32_t x = rng.next();
-    const int leaf = (int)(x % (uint32_t)n);
-    B = v.lpar[leaf];
-    const NodeRec rb = *v.hdr(B);
-    bl = rb.left;
-    br = rb.right;
-    A = rb.parent;
-    ccB = rb.ccost;
-    partB = rb.partial;
-    total = (B == N - 1) ? partB : v.hdr(N - 1)->partial;
-    if (A >= 0) recA = *v.hdr(A);
-    m0 = v.mask(bl);
-    m1 = v.mask(br);
-    p0 = v.partial(bl);
-    p1 = v.partial(br);
-    if constexpr (HYPER) {
-      iB = v.mask(B);
-      hB = v.hyper(B);
-    }
-    if (A >= 0) {
-      const int C = (recA.left == B) ? recA.right : recA.left;
-      if (recA.parent >= 0) recN = *v.hdr(recA.parent);
-      mC = v.mask(C);
-      pC = v.partial(C);
-      if constexpr (HYPER) {
-        iA = v.mask(A);
-        hA = v.hyper(A);
-      }
-    }
-  };
-
+  int ldB = 0;                           // parent of the drawn leaf, in flight
   int64_t step = 0;
-  start_sweep(0);
+  int state = S_BEGIN;
 
   for (;;) {
-    if (A < 0) {
+    // ======================= issue / consume: mt19937 ========================
+    if (rng.pend) rng.produce();
+    if (rng.room()) rng.request();
+
+    // staging registers of a MOVE (declared here so that the fence below can name them)
+    NodeRec recNN{-1, -1, -1, 0, 0.0, 0.0};
+    M mCn = mzero<K>(), iAn = mzero<K>(), hAn = mzero<K>();
+    double pCn = 0;
+    // results of a MOVE that its store phase needs
+    bool acc = false, did_move = false, did_end = false;
+    int mvC = 0, mvE = 0, mvA = 0, mvB = 0;
+    M newB = mzero<K>();
+    int al = 0, ar = 0, aP = -1;
+    double ccA = 0, partA = 0;
+    bool c_is_right = false;
+    M mBnow = mzero<K>(), mX = mzero<K>();
+    double pCcur = 0;
+
+    if (state == S_END) {
       // ---- B is the root: end of sweep (optimizer.hpp:194-201) ------------
-      if (lane0) {
-        NodeRec o;
-        o.left = bl; o.right = br; o.parent = -1; o.pad = 0; o.ccost = ccB; o.partial = partB;
-        *v.hdr(B) = o;
-      }
-      if constexpr (HYPER) v.set_hyper(B, hB);
+      did_end = true;
       if (partB < min_cost) {
         min_cost = partB;
         ++n_impr;
         if (jinvalid) {
-          // the rotation log overflowed since the last best tree: take a full copy
+          // the rotation log overflowed since the last best tree: take a full copy (rare).  The
+          // root header of this sweep is still in registers: write it first.
+          if (lane0) {
+            NodeRec o;
+            o.left = bl; o.right = br; o.parent = -1; o.pad = 0; o.ccost = ccB; o.partial = partB;
+            *v.hdr(B) = o;
+          }
           Links* __restrict__ ml = P.minlinks + r * (int64_t)N;
           for (int i = lig; i < N; i += L) {
             Links o;
@@ -254,147 +290,213 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
         }
         jmin = jtail;
       }
+      mvB = B;
       ++step;
-      if (step >= n_steps) break;
-      start_sweep(step);
-      if (A < 0) continue;
+      state = (step >= n_steps) ? -1 : S_BEGIN;
     }
-
-    // ---- stage the NEXT move's operands before this move's stores -----------
-    int al = recA.left, ar = recA.right;
-    const int aP = recA.parent;
-    double ccA = recA.ccost;
-    const bool c_is_right = (al == B);
-    const int C = c_is_right ? ar : al;
-    NodeRec recNN{-1, -1, -1, 0, 0.0, 0.0};
-    uint64_t mCn = 0, iAn = 0, hAn = 0;
-    double pCn = 0;
-    if (aP >= 0) {
-      const int Cn = (recN.left == A) ? recN.right : recN.left;
-      if (recN.parent >= 0) recNN = *v.hdr(recN.parent);
-      mCn = v.mask(Cn);
-      pCn = v.partial(Cn);
+    if (state == S_BEGIN) {
+      // optimizer.hpp:103-107
+      beta = betas[step];
+      const uint32_t x = rng.next();
+      const int leaf = (int)(x % (uint32_t)n);
+      ldB = v.lpar[leaf];
+      state = S_GOT_B;
+    } else if (state == S_GOT_B) {
+      B = ldB;
+      const NodeRec rb = *v.hdr(B);
+      bl = rb.left; br = rb.right; A = rb.parent; ccB = rb.ccost; partB = rb.partial;
+      state = S_GOT_HB;
+    } else if (state == S_GOT_HB) {
+      // optimizer.hpp:112 and the operands of the first move
+      total = v.hdr(N - 1)->partial;
+      m0 = v.mask(bl);
+      m1 = v.mask(br);
+      p0 = v.partial(bl);
+      p1 = v.partial(br);
       if constexpr (HYPER) {
-        iAn = v.mask(aP);
-        hAn = v.hyper(aP);
+        iB = v.mask(B);
+        hB = v.hyper(B);
       }
-    }
-
-    // ---- one move evaluation (optimizer.hpp:117-192) -----------------------
-    const uint64_t hy = HYPER ? (hA | hB) : 0ull;
-    // both candidate (D, E) assignments evaluated at once:
-    //   cand0: D = child0, E = child1;  cand1: D = child1, E = child0
-    const uint64_t nb0 = (m0 ^ mC) | hy;  // optimizer.hpp:147
-    const uint64_t nb1 = (m1 ^ mC) | hy;
-    bool inter0, inter1;
-    int pcA0 = 0, pcB0 = 0, pcA1 = 0, pcB1 = 0;
-    if constexpr (!GENERIC) {
-      uint32_t w0 = (uint32_t)__popcll(nb0 | m1) | ((uint32_t)__popcll(m0 | mC) << 13) |
-                    (((m0 & mC) != 0 ? 1u : 0u) << 26);
-      uint32_t w1 = (uint32_t)__popcll(nb1 | m0) | ((uint32_t)__popcll(m1 | mC) << 13) |
-                    (((m1 & mC) != 0 ? 1u : 0u) << 26);
-      w0 = gsum<LOG2L>(w0);
-      w1 = gsum<LOG2L>(w1);
-      inter0 = (w0 >> 26) != 0;
-      inter1 = (w1 >> 26) != 0;
-      pcA0 = (int)(w0 & 0x1fffu); pcB0 = (int)((w0 >> 13) & 0x1fffu);
-      pcA1 = (int)(w1 & 0x1fffu); pcB1 = (int)((w1 >> 13) & 0x1fffu);
-    } else {
-      const uint32_t w = gsum<LOG2L>(((m0 & mC) != 0 ? 1u : 0u) | (((m1 & mC) != 0 ? 1u : 0u) << 8));
-      inter0 = (w & 0xffu) != 0;
-      inter1 = (w >> 8) != 0;
-    }
-    bool pick0;  // true: (D, E) = (child0, child1)   -- get_ctree_nn, optimize/optimizer.hpp:128-144
-    if (disable_shared || (inter0 && inter1)) {
-      pick0 = (rng.next() & 1u) != 0;  // optimize/optimizer.hpp:139
-      ++n_rpick;
-    } else {
-      pick0 = inter0;
-    }
-    const uint64_t mD = pick0 ? m0 : m1, mE = pick0 ? m1 : m0;
-    const uint64_t newB = pick0 ? nb0 : nb1;
-    const double pD = pick0 ? p0 : p1, pE = pick0 ? p1 : p0;
-    const int E = pick0 ? br : bl;
-
-    double nA, nB;  // optimizer.hpp:152-155
-    if constexpr (!GENERIC) {
-      nA = pow2_cost(log2d * (pick0 ? pcA0 : pcA1), 0);
-      nB = pow2_cost(log2d * (pick0 ? pcB0 : pcB1), 0);
-    } else {
-      nA = generic_cost<LOG2L>(P, newB | mE, lig, gbase);
-      nB = generic_cost<LOG2L>(P, mD | mC, lig, gbase);
-    }
-    const double delta = rnd_cost(rnd_cost(nB - ccB, f32) + rnd_cost(nA - ccA, f32), f32);  // :158
-    ++n_moves;
-
-    const double u = rng.uniform01();  // :162 (always drawn)
-    const bool acc = accept_move(prob_kind, beta, delta, total, u, f32);
-
-    // vmcnt retires loads and stores in order and the compiler cannot count across the
-    // divergent regions of this loop, so it would wait for the staged operands AFTER this move's
-    // stores (i.e. for the stores' acknowledgements as well).  A fake use here, before the first
-    // store of the move, makes it wait for them now: they have had the whole evaluation above
-    // (plus the other waves of the SIMD) to arrive, and nothing younger is outstanding.
-    TNCO_LANDED(recNN.left); TNCO_LANDED(recNN.right); TNCO_LANDED(recNN.parent); TNCO_LANDED(recNN.ccost);
-    TNCO_LANDED(mCn); TNCO_LANDED(pCn);
-    if constexpr (HYPER) { TNCO_LANDED(iAn); TNCO_LANDED(hAn); }
-    TNCO_LANDED(rng.pa); TNCO_LANDED(rng.pb); TNCO_LANDED(rng.pc);
-
-    double pEcur = pE, pCcur = pC;  // partials of B's other child / A's other child after the move
-    uint64_t mBnow;                 // legs of B after the move
-    if (acc) {
-      ++n_acc;
-      // Tree::swap_with_nn(E): include/tnco/tree.hpp:176-184
-      if (pick0) br = C; else bl = C;
-      if (c_is_right) ar = E; else al = E;
-      if (!jinvalid) {
-        if (jtail == jcap) {
-          jinvalid = true;  // log full: the next improvement re-bases the checkpoint
-        } else {
-          if (lane0) jlog[jtail] = E;
-          ++jtail;
+      if (A >= 0) {
+        recA = *v.hdr(A);
+        state = S_GOT_HA;
+      } else {
+        state = S_END;
+      }
+    } else if (state == S_GOT_HA) {
+      const int C = (recA.left == B) ? recA.right : recA.left;
+      mC = v.mask(C);
+      pC = v.partial(C);
+      if constexpr (HYPER) {
+        iA = v.mask(A);
+        hA = v.hyper(A);
+      }
+      if (recA.parent >= 0) recN = *v.hdr(recA.parent);
+      state = S_MOVE;
+    } else if (state == S_MOVE) {
+      // ---- stage the NEXT move's operands -----------------------------------
+      did_move = true;
+      al = recA.left; ar = recA.right; aP = recA.parent; ccA = recA.ccost;
+      c_is_right = (al == B);
+      const int C = c_is_right ? ar : al;
+      if (aP >= 0) {
+        const int Cn = (recN.left == A) ? recN.right : recN.left;
+        if (recN.parent >= 0) recNN = *v.hdr(recN.parent);
+        mCn = v.mask(Cn);
+        pCn = v.partial(Cn);
+        if constexpr (HYPER) {
+          iAn = v.mask(aP);
+          hAn = v.hyper(aP);
         }
       }
-      if (lane0) {
-        v.set_parent(C, B);
-        v.set_parent(E, A);
+
+      // ---- one move evaluation (optimizer.hpp:117-192) -----------------------
+      const M hy = HYPER ? mor<K>(hA, hB) : mzero<K>();
+      // both candidate (D, E) assignments evaluated at once:
+      //   cand0: D = child0, E = child1;  cand1: D = child1, E = child0
+      const M nb0 = mor<K>(mxor<K>(m0, mC), hy);  // optimizer.hpp:147
+      const M nb1 = mor<K>(mxor<K>(m1, mC), hy);
+      bool inter0, inter1;
+      int pcA0 = 0, pcB0 = 0, pcA1 = 0, pcB1 = 0;
+      if constexpr (!GENERIC) {
+        uint32_t w0 = mpopc<K>(mor<K>(nb0, m1)) | (mpopc<K>(mor<K>(m0, mC)) << 13) |
+                      ((mnonzero<K>(mand<K>(m0, mC)) ? 1u : 0u) << 26);
+        uint32_t w1 = mpopc<K>(mor<K>(nb1, m0)) | (mpopc<K>(mor<K>(m1, mC)) << 13) |
+                      ((mnonzero<K>(mand<K>(m1, mC)) ? 1u : 0u) << 26);
+        w0 = gsum<LOG2L>(w0);
+        w1 = gsum<LOG2L>(w1);
+        inter0 = (w0 >> 26) != 0;
+        inter1 = (w1 >> 26) != 0;
+        pcA0 = (int)(w0 & 0x1fffu); pcB0 = (int)((w0 >> 13) & 0x1fffu);
+        pcA1 = (int)(w1 & 0x1fffu); pcB1 = (int)((w1 >> 13) & 0x1fffu);
+      } else {
+        const uint32_t w = gsum<LOG2L>((mnonzero<K>(mand<K>(m0, mC)) ? 1u : 0u) |
+                                       ((mnonzero<K>(mand<K>(m1, mC)) ? 1u : 0u) << 8));
+        inter0 = (w & 0xffu) != 0;
+        inter1 = (w >> 8) != 0;
       }
-      v.set_mask(B, newB);  // :170
+      bool pick0;  // true: (D, E) = (child0, child1)   -- get_ctree_nn, optimize/optimizer.hpp:128-144
+      if (disable_shared || (inter0 && inter1)) {
+        pick0 = (rng.next() & 1u) != 0;  // optimize/optimizer.hpp:139
+        ++n_rpick;
+      } else {
+        pick0 = inter0;
+      }
+      const M mD = msel<K>(pick0, m0, m1), mE = msel<K>(pick0, m1, m0);
+      newB = msel<K>(pick0, nb0, nb1);
+      const double pD = pick0 ? p0 : p1, pE = pick0 ? p1 : p0;
+      const int E = pick0 ? br : bl;
+
+      double nA, nB;  // optimizer.hpp:152-155
+      if constexpr (!GENERIC) {
+        nA = pow2_cost(log2d * (pick0 ? pcA0 : pcA1), 0);
+        nB = pow2_cost(log2d * (pick0 ? pcB0 : pcB1), 0);
+      } else {
+        nA = generic_cost<LOG2L, K>(P, mor<K>(newB, mE), lig, gbase);
+        nB = generic_cost<LOG2L, K>(P, mor<K>(mD, mC), lig, gbase);
+      }
+      const double delta = rnd_cost(rnd_cost(nB - ccB, f32) + rnd_cost(nA - ccA, f32), f32);  // :158
+      ++n_moves;
+
+      const double u = rng.uniform01();  // :162 (always drawn)
+      acc = accept_move(prob_kind, beta, delta, total, u, f32);
+
+      double pEcur = pE;  // partial of B's other child after the move
+      pCcur = pC;         // partial of A's other child after the move
+      mvA = A; mvB = B; mvC = C; mvE = E;
+      if (acc) {
+        ++n_acc;
+        // Tree::swap_with_nn(E): include/tnco/tree.hpp:176-184
+        if (pick0) br = C; else bl = C;
+        if (c_is_right) ar = E; else al = E;
+        if constexpr (HYPER) {
+          hA = mand<K>(mand<K>(iA, newB), mE);  // :171
+          hB = mand<K>(mand<K>(newB, mD), mC);  // :172
+        }
+        ccB = nB;
+        ccA = nA;
+        total = rnd_cost(total + delta, f32);  // :177
+        pEcur = pC;
+        pCcur = pE;
+        mBnow = newB;
+        mX = mE;
+      } else {
+        mBnow = HYPER ? iB : mxor<K>(m0, m1);
+        mX = mC;
+      }
+      // :185-188
+      partB = rnd_cost(rnd_cost(pD + pEcur, f32) + ccB, f32);
+      partA = rnd_cost(rnd_cost(partB + pCcur, f32) + ccA, f32);
+    }
+
+    // ======================= landing fence ===================================
+    // Everything requested above is needed before the first store below: vmcnt is in order, so
+    // waiting for these loads later would also wait for the stores.
+    TNCO_LANDED(ldB);
+    TNCO_LANDED(bl); TNCO_LANDED(br); TNCO_LANDED(A); TNCO_LANDED(ccB); TNCO_LANDED(partB);
+    TNCO_LANDED(total); TNCO_LANDED(p0); TNCO_LANDED(p1); TNCO_LANDED(pC); TNCO_LANDED(pCn);
+    TNCO_LANDED(recA.left); TNCO_LANDED(recA.right); TNCO_LANDED(recA.parent); TNCO_LANDED(recA.ccost);
+    TNCO_LANDED(recN.left); TNCO_LANDED(recN.right); TNCO_LANDED(recN.parent); TNCO_LANDED(recN.ccost);
+    TNCO_LANDED(recNN.left); TNCO_LANDED(recNN.right); TNCO_LANDED(recNN.parent); TNCO_LANDED(recNN.ccost);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      TNCO_LANDED(m0.w[k]); TNCO_LANDED(m1.w[k]); TNCO_LANDED(mC.w[k]); TNCO_LANDED(mCn.w[k]);
       if constexpr (HYPER) {
-        hA = iA & newB & mE;  // :171
-        hB = newB & mD & mC;  // :172
+        TNCO_LANDED(iB.w[k]); TNCO_LANDED(hB.w[k]); TNCO_LANDED(iA.w[k]); TNCO_LANDED(hA.w[k]);
+        TNCO_LANDED(iAn.w[k]); TNCO_LANDED(hAn.w[k]);
       }
-      ccB = nB;
-      ccA = nA;
-      total = rnd_cost(total + delta, f32);  // :177
-      pEcur = pC;
-      pCcur = pE;
-      mBnow = newB;
-    } else {
-      mBnow = HYPER ? iB : (m0 ^ m1);
     }
-    // :185-188
-    partB = rnd_cost(rnd_cost(pD + pEcur, f32) + ccB, f32);
-    const double partA = rnd_cost(rnd_cost(partB + pCcur, f32) + ccA, f32);
-    if (lane0) {
-      NodeRec o;
-      o.left = bl; o.right = br; o.parent = A; o.pad = 0; o.ccost = ccB; o.partial = partB;
-      *v.hdr(B) = o;
+    TNCO_LANDED(rng.pa); TNCO_LANDED(rng.pb); TNCO_LANDED(rng.pc);
+
+    // ======================= store phase =====================================
+    rng.store_phase();
+    if (did_end) {
+      if (lane0) {
+        NodeRec o;
+        o.left = bl; o.right = br; o.parent = -1; o.pad = 0; o.ccost = ccB; o.partial = partB;
+        *v.hdr(mvB) = o;
+      }
+      if constexpr (HYPER) v.set_hyper(mvB, hB);
+      if (state < 0) break;
     }
-    if constexpr (HYPER) v.set_hyper(B, hB);  // B's hyper legs may also have changed one level below
-    // :191  B <- A, carrying what we already know about A's children
-    const uint64_t mX = acc ? mE : mC;  // legs of A's other child
-    if (c_is_right) { m0 = mBnow; p0 = partB; m1 = mX; p1 = pCcur; }
-    else            { m1 = mBnow; p1 = partB; m0 = mX; p0 = pCcur; }
-    B = A; bl = al; br = ar; ccB = ccA; partB = partA;
-    if constexpr (HYPER) { iB = iA; hB = hA; iA = iAn; hA = hAn; }
-    A = aP;
-    recA = recN;
-    recN = recNN;
-    mC = mCn;
-    pC = pCn;
+    if (did_move) {
+      if (acc) {
+        if (!jinvalid) {
+          if (jtail == jcap) {
+            jinvalid = true;  // log full: the next improvement re-bases the checkpoint
+          } else {
+            if (lane0) jlog[jtail] = mvE;
+            ++jtail;
+          }
+        }
+        if (lane0) {
+          v.set_parent(mvC, mvB);
+          v.set_parent(mvE, mvA);
+        }
+        v.set_mask(mvB, newB);  // :170
+      }
+      if (lane0) {
+        NodeRec o;
+        o.left = bl; o.right = br; o.parent = mvA; o.pad = 0; o.ccost = ccB; o.partial = partB;
+        *v.hdr(mvB) = o;
+      }
+      if constexpr (HYPER) v.set_hyper(mvB, hB);  // may also have changed one level below
+      // :191  B <- A, carrying what is already known about A's children
+      if (c_is_right) { m0 = mBnow; p0 = partB; m1 = mX; p1 = pCcur; }
+      else            { m1 = mBnow; p1 = partB; m0 = mX; p0 = pCcur; }
+      B = mvA; bl = al; br = ar; ccB = ccA; partB = partA;
+      if constexpr (HYPER) { iB = iA; hB = hA; iA = iAn; hA = hAn; }
+      A = aP;
+      recA = recN;
+      recN = recNN;
+      mC = mCn;
+      pC = pCn;
+      if (A < 0) state = S_END;
+    }
   }
 
+  int mti, mtw;
+  rng.finish(mti, mtw);
   if (lane0) {
     rs->jmin = jmin; rs->jtail = jtail;
     rs->jinvalid = jinvalid ? 1 : 0;
@@ -404,8 +506,8 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
     rs->n_accepted += n_acc;
     rs->n_improved += n_impr;
     rs->n_randpick += n_rpick;
-    rs->mti = rng.mti;
-    rs->mtw = rng.mtw;
+    rs->mti = mti;
+    rs->mtw = mtw;
   }
 }
 

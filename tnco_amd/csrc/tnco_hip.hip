@@ -63,7 +63,7 @@ struct tnco_hip_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   Params P{};
-  int log2l = 0, L = 1;
+  int log2l = 2, K = 1, L = 4;  // lanes per replica = L, mask words per lane = K
   bool hyper = false, generic = false;
   std::vector<void*> allocs;
   int64_t bytes = 0;
@@ -113,70 +113,81 @@ struct tnco_hip_ctx {
 
 namespace {
 
-// ---- kernel dispatch over (LOG2L, HYPER, GENERIC) ---------------------------
-template <int LOG2L>
-void launch_run_l(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, dim3 grid) {
+// ---- kernel dispatch over (LOG2L, K, HYPER, GENERIC) ------------------------
+// A replica's W mask words are spread over L = 2^LOG2L lanes, K words per lane.  Small groups
+// keep the per-replica scalar work (done by every lane of the group) cheap and put more replicas
+// in a wavefront:  W <= 16 -> 4 lanes;  W <= 32 -> 8 lanes;  W <= 64 -> 16 lanes.
+template <int LOG2L, int K>
+void launch_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind) {
   const Params& P = h->P;
   hipStream_t s = h->stream;
+  const int gpb = 256 >> LOG2L;
+  dim3 grid((unsigned)((P.R + gpb - 1) / gpb));
   if (h->hyper) {
     if (h->generic)
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, true, true>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, true>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
     else
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, true, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
   } else {
     if (h->generic)
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, false, true>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, true>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
     else
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, false, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
   }
 }
 
-#define DISPATCH_L(h, CALL)           \
-  switch ((h)->log2l) {               \
-    case 0: CALL(0); break;           \
-    case 1: CALL(1); break;           \
-    case 2: CALL(2); break;           \
-    case 3: CALL(3); break;           \
-    case 4: CALL(4); break;           \
-    case 5: CALL(5); break;           \
-    default: CALL(6); break;          \
+template <int LOG2L, int K>
+void launch_build_lk(tnco_hip_ctx* h, const BuildArgs& a) {
+  const int gpb = 256 >> LOG2L;
+  dim3 grid((unsigned)((a.count + gpb - 1) / gpb));
+  if (h->hyper)
+    hipLaunchKernelGGL((build_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, a);
+  else
+    hipLaunchKernelGGL((build_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, a);
+}
+
+template <int LOG2L, int K>
+void launch_compare_lk(tnco_hip_ctx* h, const BuildArgs& a, double atol, int32_t* out_bad) {
+  const int gpb = 256 >> LOG2L;
+  dim3 grid((unsigned)((a.count + gpb - 1) / gpb));
+  if (h->hyper)
+    hipLaunchKernelGGL((compare_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, a, atol, out_bad);
+  else
+    hipLaunchKernelGGL((compare_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, a, atol, out_bad);
+}
+
+// (LOG2L, K) for W mask words
+void choose_lanes(int W, int* log2l, int* K) {
+  if (W <= 16) { *log2l = 2; *K = (W + 3) / 4; }
+  else if (W <= 32) { *log2l = 3; *K = W <= 24 ? 3 : 4; }
+  else { *log2l = 4; *K = W <= 48 ? 3 : 4; }
+}
+
+#define DISPATCH_LK(h, CALL)                                  \
+  switch ((h)->log2l * 8 + (h)->K) {                          \
+    case 2 * 8 + 1: CALL(2, 1); break;                        \
+    case 2 * 8 + 2: CALL(2, 2); break;                        \
+    case 2 * 8 + 3: CALL(2, 3); break;                        \
+    case 2 * 8 + 4: CALL(2, 4); break;                        \
+    case 3 * 8 + 3: CALL(3, 3); break;                        \
+    case 3 * 8 + 4: CALL(3, 4); break;                        \
+    case 4 * 8 + 3: CALL(4, 3); break;                        \
+    default: CALL(4, 4); break;                               \
   }
 
 void launch_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind) {
-  const int gpb = 256 >> h->log2l;
-  dim3 grid((unsigned)((h->P.R + gpb - 1) / gpb));
-#define CALL_RUN(LL) launch_run_l<LL>(h, betas, n_steps, prob_kind, grid)
-  DISPATCH_L(h, CALL_RUN)
+#define CALL_RUN(LL, KK) launch_run_lk<LL, KK>(h, betas, n_steps, prob_kind)
+  DISPATCH_LK(h, CALL_RUN)
 #undef CALL_RUN
 }
-
-template <int LOG2L>
-void launch_build_l(tnco_hip_ctx* h, const BuildArgs& a) {
-  const int gpb = 256 >> LOG2L;
-  dim3 grid((unsigned)((a.count + gpb - 1) / gpb));
-  if (h->hyper)
-    hipLaunchKernelGGL((build_kernel<LOG2L, true>), grid, dim3(256), 0, h->stream, h->P, a);
-  else
-    hipLaunchKernelGGL((build_kernel<LOG2L, false>), grid, dim3(256), 0, h->stream, h->P, a);
-}
 void launch_build(tnco_hip_ctx* h, const BuildArgs& a) {
-#define CALL_BUILD(LL) launch_build_l<LL>(h, a)
-  DISPATCH_L(h, CALL_BUILD)
+#define CALL_BUILD(LL, KK) launch_build_lk<LL, KK>(h, a)
+  DISPATCH_LK(h, CALL_BUILD)
 #undef CALL_BUILD
 }
-
-template <int LOG2L>
-void launch_compare_l(tnco_hip_ctx* h, const BuildArgs& a, double atol, int32_t* out_bad) {
-  const int gpb = 256 >> LOG2L;
-  dim3 grid((unsigned)((a.count + gpb - 1) / gpb));
-  if (h->hyper)
-    hipLaunchKernelGGL((compare_kernel<LOG2L, true>), grid, dim3(256), 0, h->stream, h->P, a, atol, out_bad);
-  else
-    hipLaunchKernelGGL((compare_kernel<LOG2L, false>), grid, dim3(256), 0, h->stream, h->P, a, atol, out_bad);
-}
 void launch_compare(tnco_hip_ctx* h, const BuildArgs& a, double atol, int32_t* out_bad) {
-#define CALL_CMP(LL) launch_compare_l<LL>(h, a, atol, out_bad)
-  DISPATCH_L(h, CALL_CMP)
+#define CALL_CMP(LL, KK) launch_compare_lk<LL, KK>(h, a, atol, out_bad)
+  DISPATCH_LK(h, CALL_CMP)
 #undef CALL_CMP
 }
 
@@ -392,11 +403,9 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
 
-  int log2l = 0;
-  while ((1 << log2l) < W) ++log2l;
-  h->log2l = log2l;
-  h->L = 1 << log2l;
-  const int L = h->L;
+  choose_lanes(W, &h->log2l, &h->K);
+  h->L = 1 << h->log2l;
+  const int L = h->L * h->K;  // padded words per mask row in the shared tables
 
   // hyper legs present?  (an index held by more than two of {leaves, output})
   h->leafmask_w.assign(d->leaf_masks, d->leaf_masks + (size_t)n * W);
@@ -442,6 +451,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   HIP_TRY(h->alloc(&P.blocks, R * h->block_bytes()));
   HIP_TRY(h->alloc(&P.lpar, R * n));
   HIP_TRY(h->alloc(&P.mt, R * 624));
+  HIP_TRY(h->alloc(&P.mtshadow, R * 32));
   HIP_TRY(h->alloc(&P.rs, R));
   HIP_TRY(h->alloc(&P.minlinks, R * N));
   HIP_TRY(h->alloc(&P.jlog, R * (int64_t)P.jcap));
