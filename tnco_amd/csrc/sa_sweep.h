@@ -54,10 +54,13 @@ struct Rng {
   static constexpr int SB = 1 << LOG2SB;           // words per block
   static constexpr int RING = (2 * SB > 16) ? 2 * SB : 16;
 
-  uint32_t* st;            // replica's 624 state words (HBM)
-  uint32_t* shadow;        // replica's RING shadow words (HBM)
+  uint32_t* mt_base;       // P.mt      (uniform; the replica's words start at 624 * r)
+  uint32_t* sh_base;       // P.mtshadow (uniform; 32 * r)
+  uint32_t r32;            // replica index
   volatile uint32_t* ring; // group's LDS ring
   int lig;
+  __device__ __forceinline__ uint32_t* st() const { return mt_base + (uint64_t)r32 * 624u; }
+  __device__ __forceinline__ uint32_t* shadow() const { return sh_base + (uint64_t)r32 * 32u; }
   uint32_t cons, prod, tw;
   bool pend, ptw;          // a block's inputs are in flight (for virtual position prod); it needs a twist
   uint32_t pa, pb, pc;
@@ -72,13 +75,13 @@ struct Rng {
     ptw = prod >= tw;
     if (lig < SB) {
       const int k = (int)k0 + lig;
-      pa = st[k];
+      pa = st()[k];
       if (ptw) {
         const int k1 = (k + 1 == 624) ? 0 : k + 1;
         int km = k + 397;
         if (km >= 624) km -= 624;
-        pb = st[k1];
-        pc = st[km];
+        pb = st()[k1];
+        pc = st()[km];
       }
     }
     pend = true;
@@ -107,17 +110,17 @@ struct Rng {
   __device__ __forceinline__ void store_phase() {
     if (sv) {
       if (lig < SB) {
-        st[sidx] = sval;
-        if (ssave) shadow[sidx] = sold;  // sidx < RING here: at most RING words ahead of a boundary
+        st()[sidx] = sval;
+        if (ssave) shadow()[sidx] = sold;  // sidx < RING here: at most RING words ahead of a boundary
       }
       sv = false;
     }
   }
   __device__ __forceinline__ bool room() const { return !pend && (prod - cons) + SB <= (uint32_t)RING; }
 
-  __device__ __forceinline__ void init(uint32_t* st_, uint32_t* shadow_, volatile uint32_t* ring_, int mti,
-                                       int mtw, int lig_) {
-    st = st_; shadow = shadow_; ring = ring_; lig = lig_;
+  __device__ __forceinline__ void init(const Params& P, int64_t r, volatile uint32_t* ring_, int mti, int mtw,
+                                       int lig_) {
+    mt_base = P.mt; sh_base = P.mtshadow; r32 = (uint32_t)r; ring = ring_; lig = lig_;
     pend = false; sv = false; ssave = false; ptw = false;
     pa = pb = pc = sval = sold = 0; sidx = 0;
     if (mti >= 624) { cons = 624; tw = 624; } else { cons = (uint32_t)mti; tw = (uint32_t)mtw; }
@@ -151,7 +154,7 @@ struct Rng {
     mti = (int)(cons - 624u * g);
     if (tw > 624u * (g + 1u)) {
       const uint32_t nw = tw - 624u * (g + 1u);  // words of generation g+1 twisted ahead
-      for (uint32_t k = (uint32_t)lig; k < nw; k += L) st[k] = shadow[k];
+      for (uint32_t k = (uint32_t)lig; k < nw; k += L) st()[k] = shadow()[k];
       mtw = 624;
     } else {
       mtw = (int)(tw - 624u * g);
@@ -196,6 +199,12 @@ __device__ __forceinline__ bool accept_move(int kind, double beta, double delta,
 #endif
 enum : int { S_BEGIN = 0, S_GOT_B = 1, S_GOT_HB = 2, S_GOT_HA = 3, S_MOVE = 4, S_END = 5 };
 
+// Rarely touched per-replica state lives in LDS, not in registers (VGPRs bound the occupancy).
+struct ColdState {
+  double min_cost;
+  uint32_t jmin, n_impr, n_full, n_rpick;
+};
+
 template <int LOG2L, int K, bool HYPER, bool GENERIC>
 __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
     const Params P, const double* __restrict__ betas, const int64_t n_steps, const int prob_kind) {
@@ -204,6 +213,7 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
   using M = Mask<K>;
   using R = Rng<LOG2L>;
   __shared__ uint32_t rngbuf[GPB * R::RING];
+  __shared__ ColdState coldbuf[GPB];
 
   const int tid = threadIdx.x;
   const int lig = tid & (L - 1);
@@ -215,21 +225,28 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
 
   const int n = P.n, N = P.N;
   View<LOG2L, K, HYPER> v;
-  v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n, lig);
-  ReplicaState* rs = P.rs + r;
+  v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, nullptr, lig);
+  auto lpar = [&]() -> int32_t* { return P.lpar + r * (int64_t)n; };
+  volatile ColdState& cold = coldbuf[gib];
 
   R rng;
-  rng.init(P.mt + r * 624, P.mtshadow + r * 32, rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
-
-  double min_cost = rs->min_cost;
-  uint32_t n_moves = 0, n_acc = 0, n_impr = 0, n_rpick = 0, n_full = 0;
-  int32_t* __restrict__ jlog = P.jlog + r * (int64_t)P.jcap;
+  {
+    const ReplicaState* rs = P.rs + r;
+    rng.init(P, r, rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
+    if (lane0) {
+      cold.min_cost = rs->min_cost;
+      cold.jmin = rs->jmin;
+      cold.n_impr = 0; cold.n_full = 0; cold.n_rpick = 0;
+    }
+  }
+  uint32_t n_moves = 0, n_acc = 0;
   const uint32_t jcap = (uint32_t)P.jcap;
-  uint32_t jmin = rs->jmin, jtail = rs->jtail;
-  bool jinvalid = rs->jinvalid != 0;
+  uint32_t jtail = P.rs[r].jtail;
+  bool jinvalid = P.rs[r].jinvalid != 0;
   const int f32 = GENERIC ? P.f32 : 0;
   const int log2d = P.log2d;
   const bool disable_shared = P.disable_shared != 0;
+  const int nsteps32 = (int)n_steps;
 
   // ---- carried state: B and what is known about its two children ----------
   int B = 0, bl = 0, br = 0, A = -1;
@@ -237,12 +254,13 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
   M m0 = mzero<K>(), m1 = mzero<K>(), iB = mzero<K>(), hB = mzero<K>();
   double p0 = 0, p1 = 0;
   // ---- staged operands ------------------------------------------------------
-  NodeRec recA{-1, -1, -1, 0, 0.0, 0.0};  // header of A
-  NodeRec recN{-1, -1, -1, 0, 0.0, 0.0};  // header of parent(A)
+  int raL = -1, raR = -1, raP = -1;  // header of A
+  double raC = 0;
+  int rnL = -1, rnR = -1, rnP = -1;  // header of parent(A)
+  double rnC = 0;
   M mC = mzero<K>(), iA = mzero<K>(), hA = mzero<K>();
   double pC = 0;
-  int ldB = 0;                           // parent of the drawn leaf, in flight
-  int64_t step = 0;
+  int step = 0;
   int state = S_BEGIN;
 
   for (;;) {
@@ -251,25 +269,29 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
     if (rng.room()) rng.request();
 
     // staging registers of a MOVE (declared here so that the fence below can name them)
-    NodeRec recNN{-1, -1, -1, 0, 0.0, 0.0};
+    int nnL = -1, nnR = -1, nnP = -1;
+    double nnC = 0;
     M mCn = mzero<K>(), iAn = mzero<K>(), hAn = mzero<K>();
     double pCn = 0;
-    // results of a MOVE that its store phase needs
-    bool acc = false, did_move = false, did_end = false;
-    int mvC = 0, mvE = 0, mvA = 0, mvB = 0;
-    M newB = mzero<K>();
-    int al = 0, ar = 0, aP = -1;
-    double ccA = 0, partA = 0;
-    bool c_is_right = false;
-    M mBnow = mzero<K>(), mX = mzero<K>();
-    double pCcur = 0;
+    // what the store phase needs
+    bool acc = false, did_move = false, did_end = false, b_is_left_of_a = false;
+    int stB = 0, stA = -1, stC = 0, stE = 0, stL = 0, stR = 0;
+    double stCC = 0, stPart = 0;
+    M stH = mzero<K>();
+    int x_al = 0, x_ar = 0, x_aP = -1;
+    double x_ccA = 0, x_partA = 0, x_pCcur = 0;
+    M x_mBnow = mzero<K>(), x_mX = mzero<K>();
 
     if (state == S_END) {
       // ---- B is the root: end of sweep (optimizer.hpp:194-201) ------------
       did_end = true;
-      if (partB < min_cost) {
-        min_cost = partB;
-        ++n_impr;
+      stB = B; stA = -1; stL = bl; stR = br; stCC = ccB; stPart = partB;
+      if constexpr (HYPER) stH = hB;
+      if (partB < cold.min_cost) {
+        if (lane0) {
+          cold.min_cost = partB;
+          cold.n_impr = cold.n_impr + 1;
+        }
         if (jinvalid) {
           // the rotation log overflowed since the last best tree: take a full copy (rare).  The
           // root header of this sweep is still in registers: write it first.
@@ -278,6 +300,7 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
             o.left = bl; o.right = br; o.parent = -1; o.pad = 0; o.ccost = ccB; o.partial = partB;
             *v.hdr(B) = o;
           }
+          v.lpar = lpar();
           Links* __restrict__ ml = P.minlinks + r * (int64_t)N;
           for (int i = lig; i < N; i += L) {
             Links o;
@@ -286,23 +309,21 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
           }
           jtail = 0;
           jinvalid = false;
-          ++n_full;
+          if (lane0) cold.n_full = cold.n_full + 1;
         }
-        jmin = jtail;
+        if (lane0) cold.jmin = jtail;
       }
-      mvB = B;
       ++step;
-      state = (step >= n_steps) ? -1 : S_BEGIN;
+      state = (step >= nsteps32) ? -1 : S_BEGIN;
     }
     if (state == S_BEGIN) {
       // optimizer.hpp:103-107
       beta = betas[step];
       const uint32_t x = rng.next();
       const int leaf = (int)(x % (uint32_t)n);
-      ldB = v.lpar[leaf];
+      B = lpar()[leaf];
       state = S_GOT_B;
     } else if (state == S_GOT_B) {
-      B = ldB;
       const NodeRec rb = *v.hdr(B);
       bl = rb.left; br = rb.right; A = rb.parent; ccB = rb.ccost; partB = rb.partial;
       state = S_GOT_HB;
@@ -318,30 +339,39 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
         hB = v.hyper(B);
       }
       if (A >= 0) {
-        recA = *v.hdr(A);
+        const NodeRec ra = *v.hdr(A);
+        raL = ra.left; raR = ra.right; raP = ra.parent; raC = ra.ccost;
         state = S_GOT_HA;
       } else {
         state = S_END;
       }
     } else if (state == S_GOT_HA) {
-      const int C = (recA.left == B) ? recA.right : recA.left;
+      const int C = (raL == B) ? raR : raL;
       mC = v.mask(C);
       pC = v.partial(C);
       if constexpr (HYPER) {
         iA = v.mask(A);
         hA = v.hyper(A);
       }
-      if (recA.parent >= 0) recN = *v.hdr(recA.parent);
+      if (raP >= 0) {
+        const NodeRec rn = *v.hdr(raP);
+        rnL = rn.left; rnR = rn.right; rnP = rn.parent; rnC = rn.ccost;
+      }
       state = S_MOVE;
     } else if (state == S_MOVE) {
       // ---- stage the NEXT move's operands -----------------------------------
       did_move = true;
-      al = recA.left; ar = recA.right; aP = recA.parent; ccA = recA.ccost;
-      c_is_right = (al == B);
+      int al = raL, ar = raR;
+      const int aP = raP;
+      double ccA = raC;
+      const bool c_is_right = (al == B);
       const int C = c_is_right ? ar : al;
       if (aP >= 0) {
-        const int Cn = (recN.left == A) ? recN.right : recN.left;
-        if (recN.parent >= 0) recNN = *v.hdr(recN.parent);
+        const int Cn = (rnL == A) ? rnR : rnL;
+        if (rnP >= 0) {
+          const NodeRec nn = *v.hdr(rnP);
+          nnL = nn.left; nnR = nn.right; nnP = nn.parent; nnC = nn.ccost;
+        }
         mCn = v.mask(Cn);
         pCn = v.partial(Cn);
         if constexpr (HYPER) {
@@ -354,14 +384,13 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
       const M hy = HYPER ? mor<K>(hA, hB) : mzero<K>();
       // both candidate (D, E) assignments evaluated at once:
       //   cand0: D = child0, E = child1;  cand1: D = child1, E = child0
-      const M nb0 = mor<K>(mxor<K>(m0, mC), hy);  // optimizer.hpp:147
-      const M nb1 = mor<K>(mxor<K>(m1, mC), hy);
+      // new legs of B: (D ^ C) | hyper_A | hyper_B   (optimizer.hpp:147)
       bool inter0, inter1;
       int pcA0 = 0, pcB0 = 0, pcA1 = 0, pcB1 = 0;
       if constexpr (!GENERIC) {
-        uint32_t w0 = mpopc<K>(mor<K>(nb0, m1)) | (mpopc<K>(mor<K>(m0, mC)) << 13) |
+        uint32_t w0 = mpopc<K>(mor<K>(mor<K>(mxor<K>(m0, mC), hy), m1)) | (mpopc<K>(mor<K>(m0, mC)) << 13) |
                       ((mnonzero<K>(mand<K>(m0, mC)) ? 1u : 0u) << 26);
-        uint32_t w1 = mpopc<K>(mor<K>(nb1, m0)) | (mpopc<K>(mor<K>(m1, mC)) << 13) |
+        uint32_t w1 = mpopc<K>(mor<K>(mor<K>(mxor<K>(m1, mC), hy), m0)) | (mpopc<K>(mor<K>(m1, mC)) << 13) |
                       ((mnonzero<K>(mand<K>(m1, mC)) ? 1u : 0u) << 26);
         w0 = gsum<LOG2L>(w0);
         w1 = gsum<LOG2L>(w1);
@@ -378,12 +407,12 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
       bool pick0;  // true: (D, E) = (child0, child1)   -- get_ctree_nn, optimize/optimizer.hpp:128-144
       if (disable_shared || (inter0 && inter1)) {
         pick0 = (rng.next() & 1u) != 0;  // optimize/optimizer.hpp:139
-        ++n_rpick;
+        if (lane0) cold.n_rpick = cold.n_rpick + 1;
       } else {
         pick0 = inter0;
       }
       const M mD = msel<K>(pick0, m0, m1), mE = msel<K>(pick0, m1, m0);
-      newB = msel<K>(pick0, nb0, nb1);
+      const M newB = mor<K>(mxor<K>(mD, mC), hy);
       const double pD = pick0 ? p0 : p1, pE = pick0 ? p1 : p0;
       const int E = pick0 ? br : bl;
 
@@ -401,9 +430,9 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
       const double u = rng.uniform01();  // :162 (always drawn)
       acc = accept_move(prob_kind, beta, delta, total, u, f32);
 
-      double pEcur = pE;  // partial of B's other child after the move
-      pCcur = pC;         // partial of A's other child after the move
-      mvA = A; mvB = B; mvC = C; mvE = E;
+      double pEcur = pE, pCcur = pC;  // partials of B's / A's other child after the move
+      M mBnow, mX;                     // legs of B / of A's other child after the move
+      stB = B; stA = A; stC = C; stE = E;
       if (acc) {
         ++n_acc;
         // Tree::swap_with_nn(E): include/tnco/tree.hpp:176-184
@@ -426,18 +455,23 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
       }
       // :185-188
       partB = rnd_cost(rnd_cost(pD + pEcur, f32) + ccB, f32);
-      partA = rnd_cost(rnd_cost(partB + pCcur, f32) + ccA, f32);
+      const double partA = rnd_cost(rnd_cost(partB + pCcur, f32) + ccA, f32);
+      // what B's record becomes (written in the store phase); the B <- A shift (:191) follows it
+      stL = bl; stR = br; stCC = ccB; stPart = partB;
+      if constexpr (HYPER) stH = hB;
+      b_is_left_of_a = c_is_right;
+      x_al = al; x_ar = ar; x_aP = aP; x_ccA = ccA; x_partA = partA; x_mBnow = mBnow; x_mX = mX; x_pCcur = pCcur;
     }
 
     // ======================= landing fence ===================================
     // Everything requested above is needed before the first store below: vmcnt is in order, so
     // waiting for these loads later would also wait for the stores.
-    TNCO_LANDED(ldB);
+    TNCO_LANDED(B);
     TNCO_LANDED(bl); TNCO_LANDED(br); TNCO_LANDED(A); TNCO_LANDED(ccB); TNCO_LANDED(partB);
-    TNCO_LANDED(total); TNCO_LANDED(p0); TNCO_LANDED(p1); TNCO_LANDED(pC); TNCO_LANDED(pCn);
-    TNCO_LANDED(recA.left); TNCO_LANDED(recA.right); TNCO_LANDED(recA.parent); TNCO_LANDED(recA.ccost);
-    TNCO_LANDED(recN.left); TNCO_LANDED(recN.right); TNCO_LANDED(recN.parent); TNCO_LANDED(recN.ccost);
-    TNCO_LANDED(recNN.left); TNCO_LANDED(recNN.right); TNCO_LANDED(recNN.parent); TNCO_LANDED(recNN.ccost);
+    TNCO_LANDED(total); TNCO_LANDED(p0); TNCO_LANDED(p1); TNCO_LANDED(pC);
+    TNCO_LANDED(raL); TNCO_LANDED(raR); TNCO_LANDED(raP); TNCO_LANDED(raC);
+    TNCO_LANDED(rnL); TNCO_LANDED(rnR); TNCO_LANDED(rnP); TNCO_LANDED(rnC);
+    TNCO_LANDED(nnL); TNCO_LANDED(nnR); TNCO_LANDED(nnP); TNCO_LANDED(nnC); TNCO_LANDED(pCn);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       TNCO_LANDED(m0.w[k]); TNCO_LANDED(m1.w[k]); TNCO_LANDED(mC.w[k]); TNCO_LANDED(mCn.w[k]);
@@ -450,62 +484,58 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
 
     // ======================= store phase =====================================
     rng.store_phase();
-    if (did_end) {
+    if (did_move && acc) {
+      if (!jinvalid) {
+        if (jtail == jcap) {
+          jinvalid = true;  // log full: the next improvement re-bases the checkpoint
+        } else {
+          if (lane0) (P.jlog + r * (int64_t)P.jcap)[jtail] = stE;
+          ++jtail;
+        }
+      }
+      if (lane0) {
+        v.lpar = lpar();
+        v.set_parent(stC, stB);
+        v.set_parent(stE, stA);
+      }
+      v.set_mask(stB, x_mBnow);  // :170 (accepted: B's legs after the move are the new legs)
+    }
+    if (did_move || did_end) {
       if (lane0) {
         NodeRec o;
-        o.left = bl; o.right = br; o.parent = -1; o.pad = 0; o.ccost = ccB; o.partial = partB;
-        *v.hdr(mvB) = o;
+        o.left = stL; o.right = stR; o.parent = stA; o.pad = 0; o.ccost = stCC; o.partial = stPart;
+        *v.hdr(stB) = o;
       }
-      if constexpr (HYPER) v.set_hyper(mvB, hB);
+      if constexpr (HYPER) v.set_hyper(stB, stH);  // may also have changed one level below
       if (state < 0) break;
     }
     if (did_move) {
-      if (acc) {
-        if (!jinvalid) {
-          if (jtail == jcap) {
-            jinvalid = true;  // log full: the next improvement re-bases the checkpoint
-          } else {
-            if (lane0) jlog[jtail] = mvE;
-            ++jtail;
-          }
-        }
-        if (lane0) {
-          v.set_parent(mvC, mvB);
-          v.set_parent(mvE, mvA);
-        }
-        v.set_mask(mvB, newB);  // :170
-      }
-      if (lane0) {
-        NodeRec o;
-        o.left = bl; o.right = br; o.parent = mvA; o.pad = 0; o.ccost = ccB; o.partial = partB;
-        *v.hdr(mvB) = o;
-      }
-      if constexpr (HYPER) v.set_hyper(mvB, hB);  // may also have changed one level below
       // :191  B <- A, carrying what is already known about A's children
-      if (c_is_right) { m0 = mBnow; p0 = partB; m1 = mX; p1 = pCcur; }
-      else            { m1 = mBnow; p1 = partB; m0 = mX; p0 = pCcur; }
-      B = mvA; bl = al; br = ar; ccB = ccA; partB = partA;
+      if (b_is_left_of_a) { m0 = x_mBnow; p0 = stPart; m1 = x_mX; p1 = x_pCcur; }
+      else                { m1 = x_mBnow; p1 = stPart; m0 = x_mX; p0 = x_pCcur; }
+      B = stA; bl = x_al; br = x_ar; ccB = x_ccA; partB = x_partA;
       if constexpr (HYPER) { iB = iA; hB = hA; iA = iAn; hA = hAn; }
-      A = aP;
-      recA = recN;
-      recN = recNN;
+      A = x_aP;
+      raL = rnL; raR = rnR; raP = rnP; raC = rnC;
+      rnL = nnL; rnR = nnR; rnP = nnP; rnC = nnC;
       mC = mCn;
       pC = pCn;
-      if (A < 0) state = S_END;
+      state = (A < 0) ? S_END : S_MOVE;
     }
   }
 
   int mti, mtw;
   rng.finish(mti, mtw);
   if (lane0) {
-    rs->jmin = jmin; rs->jtail = jtail;
+    ReplicaState* rs = P.rs + r;
+    rs->jmin = cold.jmin; rs->jtail = jtail;
     rs->jinvalid = jinvalid ? 1 : 0;
-    rs->n_fullcopy += n_full;
-    rs->min_cost = min_cost;
+    rs->n_fullcopy += cold.n_full;
+    rs->min_cost = cold.min_cost;
     rs->n_moves += n_moves;
     rs->n_accepted += n_acc;
-    rs->n_improved += n_impr;
-    rs->n_randpick += n_rpick;
+    rs->n_improved += cold.n_impr;
+    rs->n_randpick += cold.n_rpick;
     rs->mti = mti;
     rs->mtw = mtw;
   }
