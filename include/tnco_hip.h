@@ -80,7 +80,14 @@ typedef struct tnco_hip_desc {
   int32_t disable_shared_inds;
   const uint32_t* seeds;       /* [n_replicas] std::mt19937 seeds (already reduced mod 2^32) */
   int32_t device;              /* HIP device ordinal */
-  int32_t reserved;
+  int32_t width_dtype;         /* TNCO_HIP_F32 (the reference's default width_type) */
+  /* Finite width (include/tnco/optimize/finite_width/greedy/optimizer.hpp:72-115 and
+   * finite_width/cost_model/simple.hpp:89-95): active when max_width is finite and >= 0; pass
+   * NAN / INFINITY for the infinite-memory optimizer. */
+  double max_width;
+  uint64_t max_number_new_slices; /* must be 0 (the only value the reference's app uses) */
+  const uint64_t* skip_slices;    /* [W] or NULL */
+  const uint64_t* slices;         /* [W] initial slices, or NULL = greedy initial slicing */
 } tnco_hip_desc;
 
 /* Replaces the Optimizer_<cost> constructor for a batch: copies inputs, builds
@@ -95,6 +102,16 @@ int tnco_hip_create(const tnco_hip_desc* desc, tnco_hip_handle* out);
  * every replica, sweep k using betas[k].  Asynchronous on the handle's stream;
  * any getter synchronises. */
 int tnco_hip_run(tnco_hip_handle h, int prob_kind, const double* betas, int64_t n_steps);
+
+/* Finite-width twin: `opt.update(prob, update_slices=(n % update_slices_every == 0))` for
+ * n = step_offset, step_offset + 1, ... (tnco/app/finite_width/sa.py:219-233 over
+ * finite_width/greedy/optimizer.hpp:117-390).  update_slices_every <= 0: never re-slice. */
+int tnco_hip_run_fw(tnco_hip_handle h, int prob_kind, const double* betas, int64_t n_steps,
+                    int64_t update_slices_every, int64_t step_offset);
+
+/* slices / min_slices properties (finite_width/greedy/optimizer.hpp:66-67) of one replica, [W]
+ * words each; either may be NULL. */
+int tnco_hip_get_slices(tnco_hip_handle h, int64_t replica, uint64_t* slices, uint64_t* min_slices);
 
 int tnco_hip_sync(tnco_hip_handle h);
 

@@ -1,0 +1,94 @@
+"""GPU parity of the finite-width (memory-constrained) optimizer against the oracle's restatement of
+finite_width::greedy::Optimizer (include/tnco/optimize/finite_width/greedy/optimizer.hpp:72-390):
+initial greedy slicing (draws from the PRNG through std::shuffle), width-gated moves, re-slicing
+every `update_slices` sweeps with full cost-cache rebuild, best tree + best slices."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+from tnco_amd import ctree as ct
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def core():
+    from tnco_amd import core as c
+    return c
+
+
+def _initial_max_width(prob, links_r):
+    l, r, p = links_r
+    inds = prob.node_masks(l, r)
+    return max(len(ct.unpack_mask(m)) for m in inds)
+
+
+def _check(core, orc, prob, seeds, betas, max_width, chunks, every=10, **kw):
+    links = prob.links(seeds)
+    gpu = core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, dims=prob.dims,
+                                output_mask=prob.output_mask, max_width=max_width, **kw)
+    lo = 0
+    for c in chunks:
+        gpu.run(betas[lo:lo + c], "mh", update_slices_every=every)
+        lo += c
+    assert lo == len(betas)
+    tot, mn = gpu.costs()
+    for r in range(len(seeds)):
+        o = H.make_oracle(orc, prob, links[r], seeds[r], max_width=max_width, width_type="float32",
+                          **{k: v for k, v in kw.items() if k in ("cost_type", "skip_slices", "slices")})
+        o.run(orc.PROB_MH, betas, update_slices_every=every)
+        assert o.is_valid() == 0
+        H.assert_replica_equal(gpu, r, o)
+        gs, gms = gpu.slices(r)
+        os_, oms = o.slices()
+        assert np.array_equal(gs, os_), f"replica {r} slices"
+        assert np.array_equal(gms, oms), f"replica {r} min_slices"
+        assert tot[r] == o.total_cost and mn[r] == o.min_total_cost
+    return gpu
+
+
+@pytest.mark.parametrize("n,frac", [(24, 0.5), (48, 0.6), (64, 0.4)])
+def test_fw_regular(core, oracle_lib, n, frac):
+    prob = H.regular_problem(n, graph_seed=n + 1)
+    seeds = H.replica_seeds(24, S=n)
+    w0 = _initial_max_width(prob, prob.tree(seeds[0]))
+    max_width = max(2, int(w0 * frac))
+    betas = H.linear_betas(0, 60, 120)
+    _check(core, oracle_lib, prob, seeds, betas, max_width, chunks=[120])
+
+
+def test_fw_chunked_launches_keep_the_reslice_phase(core, oracle_lib):
+    prob = H.regular_problem(40, graph_seed=5)
+    seeds = H.replica_seeds(12, S=5)
+    betas = H.linear_betas(0, 60, 95)
+    _check(core, oracle_lib, prob, seeds, betas, 6, chunks=[1, 9, 10, 33, 42], every=7)
+
+
+def test_fw_hyper_output_and_skip(core, oracle_lib):
+    from tnco_amd import synthetic as syn
+    ts, dims, out = syn.random_hyper_tn(30, 64, k=3, n_output=4, seed=3)
+    prob = H.Problem(ts, 2, out)
+    seeds = H.replica_seeds(10, S=3)
+    skip = ct.pack_masks([[0, 5, 9, 11, 30, 41]], prob.n_inds)[0]
+    betas = H.linear_betas(0, 40, 80)
+    _check(core, oracle_lib, prob, seeds, betas, 7, chunks=[80], skip_slices=skip)
+
+
+def test_fw_no_slicing_needed_equals_loose_bound(core, oracle_lib):
+    """A bound no tensor reaches: no slices, every move is evaluated."""
+    prob = H.regular_problem(24, graph_seed=2)
+    seeds = H.replica_seeds(6, S=2)
+    gpu = _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 30, 60), 60, chunks=[60])
+    assert not gpu.slices(0)[0].any()
+
+
+def test_fw_unsupported(core):
+    prob = H.regular_problem(16, graph_seed=1)
+    seeds = H.replica_seeds(2)
+    links = prob.links(seeds)
+    with pytest.raises(RuntimeError):
+        core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, max_width=-1)
+    with pytest.raises(NotImplementedError):
+        core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, max_width=4, max_number_new_slices=2)
+    with pytest.raises(NotImplementedError):
+        core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, max_width=4, width_type="float64")

@@ -37,12 +37,16 @@ class Desc(C.Structure):
         ("disable_shared_inds", C.c_int32),
         ("seeds", C.c_void_p),
         ("device", C.c_int32),
-        ("reserved", C.c_int32),
+        ("width_dtype", C.c_int32),
+        ("max_width", C.c_double),
+        ("max_number_new_slices", C.c_uint64),
+        ("skip_slices", C.c_void_p),
+        ("slices", C.c_void_p),
     ]
 
 
 EXPORTS = [
-    "tnco_hip_create", "tnco_hip_run", "tnco_hip_sync", "tnco_hip_get_costs", "tnco_hip_get_tree",
+    "tnco_hip_create", "tnco_hip_run", "tnco_hip_run_fw", "tnco_hip_get_slices", "tnco_hip_sync", "tnco_hip_get_costs", "tnco_hip_get_tree",
     "tnco_hip_get_caches", "tnco_hip_validate", "tnco_hip_get_prng", "tnco_hip_set_prng",
     "tnco_hip_best", "tnco_hip_get_counters", "tnco_hip_get_moves", "tnco_hip_get_full_copies",
     "tnco_hip_kernel_time",
@@ -66,6 +70,8 @@ def load() -> C.CDLL:
     vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
     L.tnco_hip_create.argtypes = [C.POINTER(Desc), C.POINTER(vp)]
     L.tnco_hip_run.argtypes = [vp, C.c_int, vp, i64]
+    L.tnco_hip_run_fw.argtypes = [vp, C.c_int, vp, i64, i64, i64]
+    L.tnco_hip_get_slices.argtypes = [vp, i64, vp, vp]
     L.tnco_hip_sync.argtypes = [vp]
     L.tnco_hip_get_costs.argtypes = [vp, vp, vp]
     L.tnco_hip_get_tree.argtypes = [vp, i64, C.c_int, vp, vp, vp, vp]

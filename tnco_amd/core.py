@@ -71,7 +71,12 @@ class BatchedOptimizer:
 
     def __init__(self, leaf_masks, links, seeds, *, n_inds: int, dims=2, output_mask=None,
                  sparse_mask=None, n_projs: int | None = None, cost_type: str = "float64",
-                 disable_shared_inds: bool = False, node_masks=None, device: int = 0):
+                 disable_shared_inds: bool = False, node_masks=None, device: int = 0,
+                 max_width: float | None = None, width_type: str = "float32",
+                 max_number_new_slices: int = 0, skip_slices=None, slices=None):
+        """Finite width (max_width finite): the batched counterpart of
+        finite_width.greedy.Optimizer_<cost>_<width>
+        (include/tnco/optimize/finite_width/greedy/optimizer.hpp:462-518)."""
         self._h = None
         L = _lib.load()
         if cost_type not in ("float64", "float32"):
@@ -129,6 +134,16 @@ class BatchedOptimizer:
         d.disable_shared_inds = int(bool(disable_shared_inds))
         d.seeds = _ptr(seeds)
         d.device = int(device)
+        self.finite_width = max_width is not None and max_width < float("inf")
+        d.max_width = float(max_width) if self.finite_width else float("nan")
+        if self.finite_width and width_type != "float32":
+            raise NotImplementedError("width_type must be 'float32' on the GPU path.")
+        d.width_dtype = _lib.F32
+        d.max_number_new_slices = int(max_number_new_slices)
+        sk = None if skip_slices is None else np.ascontiguousarray(skip_slices, np.uint64)
+        sl = None if slices is None else np.ascontiguousarray(slices, np.uint64)
+        d.skip_slices, d.slices = _ptr(sk), _ptr(sl)
+        self._steps_done = 0
         h = C.c_void_p()
         _lib.check(L.tnco_hip_create(C.byref(d), C.byref(h)))
         self._h = h
@@ -156,13 +171,28 @@ class BatchedOptimizer:
         self.close()
 
     # -- the hot path ---------------------------------------------------------
-    def run(self, betas, prob="mh", sync: bool = False) -> None:
-        """len(betas) sweeps per replica (one `update(prob)` per beta)."""
+    def run(self, betas, prob="mh", sync: bool = False, update_slices_every: int = 10) -> None:
+        """len(betas) sweeps per replica (one `update(prob)` per beta).
+
+        Finite width: sweep number n (counted over all calls) re-slices when
+        n % update_slices_every == 0, as tnco/app/finite_width/sa.py:228 drives it."""
         betas = np.ascontiguousarray(betas, np.float64)
         kind = _PROB[prob.lower() if isinstance(prob, str) else prob]
-        _lib.check(self._L.tnco_hip_run(self._h, kind, _ptr(betas), len(betas)))
+        if self.finite_width:
+            _lib.check(self._L.tnco_hip_run_fw(self._h, kind, _ptr(betas), len(betas),
+                                               int(update_slices_every), self._steps_done))
+        else:
+            _lib.check(self._L.tnco_hip_run(self._h, kind, _ptr(betas), len(betas)))
+        self._steps_done += len(betas)
         if sync:
             self.sync()
+
+    def slices(self, replica: int):
+        """(slices, min_slices) masks of one replica (finite width)."""
+        a = np.zeros(self.n_words, np.uint64)
+        b = np.zeros(self.n_words, np.uint64)
+        _lib.check(self._L.tnco_hip_get_slices(self._h, int(replica), _ptr(a), _ptr(b)))
+        return a, b
 
     def update(self, beta: float = 0.0, prob="mh") -> None:
         self.run([beta], prob)

@@ -1,0 +1,497 @@
+// fw_kernels.h -- memory-constrained twin of the sweep: finite_width::greedy::Optimizer
+// (include/tnco/optimize/finite_width/greedy/optimizer.hpp:43-460 of the reference) on gfx950.
+//
+// Same replica-per-lane-group mapping and node-block layout as sa_sweep.h.  On top of it, per
+// replica: the sliced-index mask `slices` / `min_slices` (W words each), the un-sliced width of
+// every internal node (float32, kept in the `pad` word of the node header; WidthCache,
+// finite_width/utils.hpp:49-76), and scratch for the greedy re-slice.
+//
+// This first version favours exactness over speed: every move reads its operands from memory
+// (no staging), and the re-slice (greedy/utils.hpp:21-125) + full CostCache rebuild
+// (greedy/optimizer.hpp:359-376) walk the whole tree serially per replica, as the reference does.
+// Supported: uniform dims, SimpleCostModel (no sparse legs), width_type float32,
+// max_number_new_slices = 0 (the only value the reference's app uses,
+// tnco/app/finite_width/sa.py:216).
+#pragma once
+#include "sa_sweep.h"
+
+namespace tnco {
+
+struct FwParams {
+  float max_width;          // (float)max_width
+  double log2d;             // std::log2(dims) as double (finite_width/cost_model/simple.hpp:46)
+  uint64_t* slices;         // [R][2][LK]  slices, min_slices
+  const uint64_t* skip;     // [LK] or NULL
+  int32_t* scratch_i;       // [R][3N + I64 + FW_MAXPOS/2]  order, stack, visited, n_big, candidate legs
+  double* scratch_d;        // [R][2N]        rebuilt ccost / partial
+  int32_t I64;              // 64 * LK (padded index count)
+  int32_t* status;          // [R] runtime problems (1: more than FW_MAXPOS candidate legs)
+};
+
+constexpr int FW_MAXPOS = 512;  // candidate legs of one tensor (scratch for the shuffle)
+
+// width of a leg set: log2(dims) * count as double, converted to width_type float
+// (finite_width/cost_model/simple.hpp:38-47)
+__device__ __forceinline__ float fw_width(const FwParams& F, uint32_t count) {
+  return (float)(F.log2d * (double)count);
+}
+
+// /usr/include/c++/11/bits/uniform_int_dist.h:246-321, 32-bit generator, range < 2^32
+template <int LOG2L>
+__device__ __forceinline__ uint32_t fw_uniform_int(Rng<LOG2L>& rng, uint32_t hi) {
+  const uint32_t uerange = hi + 1u;
+  uint64_t product = (uint64_t)rng.next_sync() * (uint64_t)uerange;
+  uint32_t low = (uint32_t)product;
+  if (low < uerange) {
+    const uint32_t threshold = (0u - uerange) % uerange;
+    while (low < threshold) {
+      product = (uint64_t)rng.next_sync() * (uint64_t)uerange;
+      low = (uint32_t)product;
+    }
+  }
+  return (uint32_t)(product >> 32);
+}
+
+// std::shuffle of /usr/include/c++/11/bits/stl_algo.h:3706-3792 on an LDS array (n < 65536: two
+// swap positions per variate).  Executed redundantly by every lane of the group; lane 0 writes.
+template <int LOG2L>
+__device__ __forceinline__ void fw_shuffle(Rng<LOG2L>& rng, volatile int16_t* a, int n, bool lane0) {
+  if (n <= 1) return;
+  int i = 1;
+  auto swp = [&](int x, int y) {
+    const int16_t ax = a[x], ay = a[y];
+    if (lane0) { a[x] = ay; a[y] = ax; }
+  };
+  if ((n % 2) == 0) {
+    const uint32_t j = fw_uniform_int<LOG2L>(rng, 1u);
+    swp(i, (int)j);
+    ++i;
+  }
+  while (i != n) {
+    const uint32_t swap_range = (uint32_t)i + 1u;
+    const uint32_t x = fw_uniform_int<LOG2L>(rng, swap_range * (swap_range + 1u) - 1u);
+    const uint32_t p0 = x / (swap_range + 1u), p1 = x % (swap_range + 1u);
+    swp(i, (int)p0);
+    ++i;
+    swp(i, (int)p1);
+    ++i;
+  }
+}
+
+// Post-order of include/tnco/utils.hpp:34-51 into order[N] (explicit stack in scratch).
+template <int LOG2L, int K, bool HYPER>
+__device__ __forceinline__ void fw_traverse(const View<LOG2L, K, HYPER>& v, int N, int32_t* order,
+                                            int32_t* stack, int32_t* visited, bool lane0) {
+  constexpr int L = 1 << LOG2L;
+  for (int i = v.lig; i < N; i += L) visited[i] = 0;
+  if (lane0) stack[0] = N - 1;
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int sp = 1, cnt = 0;
+  while (sp > 0) {
+    const int pos = stack[sp - 1];
+    const int l = v.left(pos);
+    if (visited[pos] || l < 0) {
+      --sp;
+      if (lane0) order[cnt] = pos;
+      ++cnt;
+    } else {
+      const int rr = v.right(pos);
+      if (lane0) { visited[pos] = 1; stack[sp] = rr; stack[sp + 1] = l; }
+      sp += 2;
+    }
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
+
+template <int K>
+__device__ __forceinline__ double fw_cost(const Params& P, uint32_t count) {
+  return uniform_cost(P, (int)count);
+}
+
+// CostCache(ctree, ccost, slices) (finite_width/utils.hpp:36-47) into scratch; returns
+// partial[root]; *sum = get_cost (finite_width/utils.hpp:24-33).
+template <int LOG2L, int K, bool HYPER>
+__device__ __forceinline__ double fw_rebuild(const Params& P, const View<LOG2L, K, HYPER>& v, const int32_t* order,
+                                             const Mask<K>& slices, double* cc_new, double* part_new, bool lane0,
+                                             double* sum) {
+  const int n = P.n, N = P.N;
+  double s = 0.0;
+  for (int i = 0; i < N; ++i) {
+    const int p = order[i];
+    const int l = v.left(p);
+    if (l < 0) continue;
+    const int rr = v.right(p);
+    const Mask<K> u = mor<K>(mor<K>(v.mask(l), v.mask(rr)), slices);
+    const double c = uniform_cost(P, (int)gsum<LOG2L>(mpopc<K>(u)));
+    const double pl = l < n ? 0.0 : part_new[l], pr = rr < n ? 0.0 : part_new[rr];
+    const double part = rnd_cost(rnd_cost(c + pl, P.f32) + pr, P.f32);
+    s = rnd_cost(s + c, P.f32);
+    if (lane0) { cc_new[p] = c; part_new[p] = part; }
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  *sum = s;
+  return part_new[N - 1];
+}
+
+template <int LOG2L, int K, bool HYPER>
+__device__ __forceinline__ void fw_commit(const Params& P, const View<LOG2L, K, HYPER>& v, const double* cc_new,
+                                          const double* part_new) {
+  constexpr int L = 1 << LOG2L;
+  for (int p = P.n + v.lig; p < P.N; p += L) {
+    v.hdr(p)->ccost = cc_new[p];
+    v.hdr(p)->partial = part_new[p];
+  }
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int LOG2L, int K, bool HYPER>
+__device__ __forceinline__ float fw_node_width(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
+                                               int t) {
+  if (t >= P.n) return __int_as_float(v.hdr(t)->pad);
+  return fw_width(F, gsum<LOG2L>(mpopc<K>(v.mask(t))));
+}
+
+// get_slices_impl, finite_width/greedy/utils.hpp:21-125.  `pos` = LDS scratch of the group.
+template <int LOG2L, int K, bool HYPER>
+__device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
+                                                 Rng<LOG2L>& rng, const int32_t* order, int32_t* n_big,
+                                                 volatile int16_t* pos, bool lane0, int gbase, int32_t* status) {
+  constexpr int L = 1 << LOG2L;
+  const int N = P.N, lig = v.lig;
+  Mask<K> slices = mzero<K>();
+  Mask<K> skip = mzero<K>();
+  if (F.skip) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) skip.w[k] = F.skip[lig * K + k];
+  }
+  // :41-48  number of too-wide tensors every index appears in
+  for (int i = lig; i < F.I64; i += L) n_big[i] = 0;
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int t = 0; t < N; ++t) {
+    if (fw_node_width<LOG2L, K, HYPER>(P, F, v, t) > F.max_width) {
+      const Mask<K> m = v.mask(t);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        uint64_t x = m.w[k];
+        while (x) {
+          const int b = __ffsll((unsigned long long)x) - 1;
+          n_big[(lig * K + k) * 64 + b] += 1;
+          x &= x - 1;
+        }
+      }
+    }
+  }
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // :62-101  post-order over the too-wide tensors
+  for (int i = 0; i < N; ++i) {
+    const int t = order[i];
+    if (!(fw_node_width<LOG2L, K, HYPER>(P, F, v, t) > F.max_width)) continue;
+    Mask<K> sliced_xs = mandn<K>(v.mask(t), slices);
+    float sliced_width = fw_width(F, gsum<LOG2L>(mpopc<K>(sliced_xs)));
+    if (!(sliced_width > F.max_width)) continue;
+    // candidate positions, ascending (Bitset::positions): lane-major, then word, then bit
+    const Mask<K> cand = mandn<K>(sliced_xs, skip);
+    const uint32_t mine = mpopc<K>(cand);
+    uint32_t before = 0, np = 0;
+    for (int j = 0; j < L; ++j) {
+      const uint32_t c = (uint32_t)__shfl((int)mine, gbase + j);
+      if (j < lig) before += c;
+      np += c;
+    }
+    if (np > (uint32_t)FW_MAXPOS) {
+      if (lane0) *status = 1;
+      np = FW_MAXPOS;
+    }
+    {
+      uint32_t o = before;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        uint64_t x = cand.w[k];
+        while (x) {
+          const int b = __ffsll((unsigned long long)x) - 1;
+          if (o < (uint32_t)FW_MAXPOS) pos[o] = (int16_t)((lig * K + k) * 64 + b);
+          ++o;
+          x &= x - 1;
+        }
+      }
+    }
+    // :80  std::shuffle(positions, prng)
+    fw_shuffle<LOG2L>(rng, pos, (int)np, lane0);
+    // :83-101  stable_sort by n_big descending, then slice until the tensor fits: equivalent to
+    // repeatedly taking the FIRST remaining position with the largest n_big.
+    for (uint32_t taken = 0; taken < np; ++taken) {
+      int best = -1, best_key = -1;
+      for (uint32_t q = 0; q < np; ++q) {
+        const int xp = pos[q];
+        if (xp < 0) continue;
+        const int key = n_big[xp];
+        if (key > best_key) { best_key = key; best = (int)q; }
+      }
+      const int xpos = pos[best];
+      if (lane0) pos[best] = -1;
+      // slices.set(xpos); sliced_width += delta_width (= -log2(dims) for a present index);
+      // sliced_xs.reset(xpos)
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        if ((xpos >> 6) == lig * K + k) {
+          slices.w[k] |= 1ull << (xpos & 63);
+          sliced_xs.w[k] &= ~(1ull << (xpos & 63));
+        }
+      }
+      sliced_width = sliced_width + (float)((double)(1 - 2 * 1) * F.log2d);
+      if (sliced_width <= F.max_width) break;
+    }
+  }
+  return slices;
+}
+
+struct FwInitArgs {
+  const uint64_t* slices_in;  // [LK] or NULL: use instead of the initial get_slices
+  double* out_total;          // [R]
+  double* out_sum;            // [R]
+};
+
+// finite_width/greedy/optimizer.hpp:72-115: WidthCache, slices (greedy, draws from the PRNG),
+// min_slices, CostCache(slices), min_total_cost = get_cost(min_ctree, min_slices).
+template <int LOG2L, int K, bool HYPER>
+__global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwParams F, const FwInitArgs a) {
+  constexpr int L = 1 << LOG2L;
+  constexpr int GPB = 256 >> LOG2L;
+  constexpr int LK = L * K;
+  using R = Rng<LOG2L>;
+  __shared__ uint32_t rngbuf[GPB * R::RING];
+  const int tid = threadIdx.x;
+  const int lig = tid & (L - 1);
+  const int gib = tid >> LOG2L;
+  const int gbase = (tid & 63) & ~(L - 1);
+  const int64_t r = (int64_t)blockIdx.x * GPB + gib;
+  if (r >= P.R) return;
+  const bool lane0 = lig == 0;
+  const int n = P.n, N = P.N;
+  View<LOG2L, K, HYPER> v;
+  v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n, lig);
+  ReplicaState* rs = P.rs + r;
+  R rng;
+  rng.init(P, r, rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
+  int32_t* si = F.scratch_i + r * (int64_t)(3 * N + F.I64 + FW_MAXPOS / 2);
+  int32_t *order = si, *stack = si + N, *visited = si + 2 * N, *n_big = si + 3 * N;
+  double* cc_new = F.scratch_d + r * 2 * (int64_t)N;
+  double* part_new = cc_new + N;
+  // widths of the internal nodes
+  for (int p = n; p < N; ++p) {
+    const float w = fw_width(F, gsum<LOG2L>(mpopc<K>(v.mask(p))));
+    if (lane0) v.hdr(p)->pad = __float_as_int(w);
+  }
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  fw_traverse<LOG2L, K, HYPER>(v, N, order, stack, visited, lane0);
+  Mask<K> slices;
+  if (a.slices_in) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) slices.w[k] = a.slices_in[lig * K + k];
+  } else {
+    volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + 3 * N + F.I64);
+    slices = fw_get_slices<LOG2L, K, HYPER>(P, F, v, rng, order, n_big, pos, lane0, gbase, F.status + r);
+  }
+  double sum = 0;
+  const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, order, slices, cc_new, part_new, lane0, &sum);
+  fw_commit<LOG2L, K, HYPER>(P, v, cc_new, part_new);
+  uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    sl[lig * K + k] = slices.w[k];
+    sl[LK + lig * K + k] = slices.w[k];
+  }
+  int mti, mtw;
+  rng.finish(mti, mtw);
+  if (lane0) {
+    rs->mti = mti; rs->mtw = mtw;
+    rs->min_cost = sum;
+    rs->init_total = tot;
+    a.out_total[r] = tot;
+    a.out_sum[r] = sum;
+  }
+}
+
+// update(prob, update_slices), finite_width/greedy/optimizer.hpp:117-390, n_steps times.
+// Sweep k of this launch re-slices when (step_offset + k) % update_every == 0
+// (tnco/app/finite_width/sa.py:228).
+template <int LOG2L, int K, bool HYPER>
+__global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwParams F, const double* __restrict__ betas,
+                                                     const int64_t n_steps, const int prob_kind,
+                                                     const int64_t step_offset, const int64_t update_every) {
+  constexpr int L = 1 << LOG2L;
+  constexpr int GPB = 256 >> LOG2L;
+  constexpr int LK = L * K;
+  using M = Mask<K>;
+  using R = Rng<LOG2L>;
+  __shared__ uint32_t rngbuf[GPB * R::RING];
+  const int tid = threadIdx.x;
+  const int lig = tid & (L - 1);
+  const int gib = tid >> LOG2L;
+  const int gbase = (tid & 63) & ~(L - 1);
+  const int64_t r = (int64_t)blockIdx.x * GPB + gib;
+  if (r >= P.R || n_steps <= 0) return;
+  const bool lane0 = lig == 0;
+  const int n = P.n, N = P.N;
+  const int f32 = P.f32;
+  View<LOG2L, K, HYPER> v;
+  v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n, lig);
+  ReplicaState* rs = P.rs + r;
+  R rng;
+  rng.init(P, r, rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
+  int32_t* si = F.scratch_i + r * (int64_t)(3 * N + F.I64 + FW_MAXPOS / 2);
+  int32_t *order = si, *stack = si + N, *visited = si + 2 * N, *n_big = si + 3 * N;
+  double* cc_new = F.scratch_d + r * 2 * (int64_t)N;
+  double* part_new = cc_new + N;
+  uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
+  M slices;
+#pragma unroll
+  for (int k = 0; k < K; ++k) slices.w[k] = sl[lig * K + k];
+  double min_cost = rs->min_cost;
+  uint32_t n_moves = 0, n_acc = 0, n_impr = 0, n_rpick = 0, n_full = 0;
+  int32_t* jlog = P.jlog + r * (int64_t)P.jcap;
+  uint32_t jmin = rs->jmin, jtail = rs->jtail;
+  bool jinvalid = rs->jinvalid != 0;
+
+  for (int64_t step = 0; step < n_steps; ++step) {
+    const double beta = betas[step];
+    // :130-139
+    const int leaf = (int)(rng.next_sync() % (uint32_t)n);
+    int B = v.lpar[leaf];
+    double total = v.hdr(N - 1)->partial;
+    for (;;) {
+      // get_ctree_nn, optimize/optimizer.hpp:112-144
+      const NodeRec hb = *v.hdr(B);
+      const int A = hb.parent;
+      if (A < 0) break;
+      const NodeRec ha = *v.hdr(A);
+      const bool c_is_right = (ha.left == B);
+      int C = c_is_right ? ha.right : ha.left;
+      const M mC = v.mask(C), m0 = v.mask(hb.left), m1 = v.mask(hb.right);
+      const uint32_t w = gsum<LOG2L>((mnonzero<K>(mand<K>(m0, mC)) ? 1u : 0u) |
+                                     ((mnonzero<K>(mand<K>(m1, mC)) ? 1u : 0u) << 8));
+      const bool inter0 = (w & 0xffu) != 0, inter1 = (w >> 8) != 0;
+      bool pick0;
+      if (P.disable_shared || (inter0 && inter1)) {
+        pick0 = (rng.next_sync() & 1u) != 0;
+        ++n_rpick;
+      } else {
+        pick0 = inter0;
+      }
+      const int D = pick0 ? hb.left : hb.right;
+      int E = pick0 ? hb.right : hb.left;
+      const M mD = msel<K>(pick0, m0, m1), mE = msel<K>(pick0, m1, m0);
+      const M iA = v.mask(A), hA = v.hyper(A), hB = v.hyper(B);
+      // :174-179
+      const M newB = mor<K>(mor<K>(mxor<K>(mD, mC), hA), hB);
+      const uint32_t cw = gsum<LOG2L>(mpopc<K>(newB) | (mpopc<K>(mandn<K>(newB, slices)) << 16));
+      const float new_width_B = fw_width(F, cw & 0xffffu);
+      const float new_sliced_width_B = fw_width(F, cw >> 16);
+      double ccB = hb.ccost, ccA = ha.ccost;
+      int bl = hb.left, br = hb.right, al = ha.left, ar = ha.right;
+      bool acc = false;
+      ++n_moves;
+      if (new_sliced_width_B <= F.max_width) {
+        // :190-201
+        const uint32_t pc = gsum<LOG2L>(mpopc<K>(mor<K>(mor<K>(newB, mE), slices)) |
+                                        (mpopc<K>(mor<K>(mor<K>(mD, mC), slices)) << 16));
+        const double nA = uniform_cost(P, (int)(pc & 0xffffu)), nB = uniform_cost(P, (int)(pc >> 16));
+        const double delta = rnd_cost(rnd_cost(nB - ccB, f32) + rnd_cost(nA - ccA, f32), f32);
+        double u;
+        {
+          const uint32_t x1 = rng.next_sync(), x2 = rng.next_sync();
+          const double s = (double)x1 + (double)x2 * 4294967296.0;
+          u = s * 5.421010862427522170037e-20;
+          if (u >= 1.0) u = 0.99999999999999988897769753748;
+        }
+        acc = accept_move(prob_kind, beta, delta, total, u, f32);
+        if (acc) {
+          ++n_acc;
+          // :203-219
+          if (pick0) br = C; else bl = C;
+          if (c_is_right) ar = E; else al = E;
+          if (!jinvalid) {
+            if (jtail == (uint32_t)P.jcap) jinvalid = true;
+            else { if (lane0) jlog[jtail] = E; ++jtail; }
+          }
+          if (lane0) {
+            v.set_parent(C, B);
+            v.set_parent(E, A);
+          }
+          v.set_mask(B, newB);
+          v.set_hyper(A, mand<K>(mand<K>(iA, newB), mE));
+          v.set_hyper(B, mand<K>(mand<K>(newB, mD), mC));
+          ccB = nB;
+          ccA = nA;
+          total = rnd_cost(total + delta, f32);
+          const int t = C; C = E; E = t;
+        }
+      }
+      // :324-331 (skip_cost_propagation is only set by the max_number_new_slices > 0 branch)
+      const double partB = rnd_cost(rnd_cost(v.partial(D) + v.partial(E), f32) + ccB, f32);
+      const double partA = rnd_cost(rnd_cost(partB + v.partial(C), f32) + ccA, f32);
+      if (lane0) {
+        NodeRec o;
+        o.left = bl; o.right = br; o.parent = A; o.ccost = ccB; o.partial = partB;
+        o.pad = acc ? __float_as_int(new_width_B) : hb.pad;
+        *v.hdr(B) = o;
+        NodeRec oa;
+        oa.left = al; oa.right = ar; oa.parent = ha.parent; oa.pad = ha.pad; oa.ccost = ccA; oa.partial = partA;
+        *v.hdr(A) = oa;
+      }
+      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      B = A;
+    }
+    // :360-376
+    const bool do_slices = update_every > 0 && ((step_offset + step) % update_every) == 0;
+    if (do_slices && gany<LOG2L>(mnonzero<K>(slices))) {
+      fw_traverse<LOG2L, K, HYPER>(v, N, order, stack, visited, lane0);
+      volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + 3 * N + F.I64);
+      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, rng, order, n_big, pos, lane0, gbase, F.status + r);
+      double sum;
+      const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, order, ns, cc_new, part_new, lane0, &sum);
+      if (tot < v.hdr(N - 1)->partial) {
+        slices = ns;
+        fw_commit<LOG2L, K, HYPER>(P, v, cc_new, part_new);
+      }
+    }
+    // :385-389
+    const double tc = v.hdr(N - 1)->partial;
+    if (tc < min_cost) {
+      min_cost = tc;
+      ++n_impr;
+      if (jinvalid) {
+        Links* __restrict__ ml = P.minlinks + r * (int64_t)N;
+        for (int i = lig; i < N; i += L) {
+          Links o;
+          o.left = v.left(i); o.right = v.right(i); o.parent = v.parent(i); o.pad = 0;
+          ml[i] = o;
+        }
+        jtail = 0;
+        jinvalid = false;
+        ++n_full;
+      }
+      jmin = jtail;
+#pragma unroll
+      for (int k = 0; k < K; ++k) sl[LK + lig * K + k] = slices.w[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) sl[lig * K + k] = slices.w[k];
+  int mti, mtw;
+  rng.finish(mti, mtw);
+  if (lane0) {
+    rs->jmin = jmin; rs->jtail = jtail;
+    rs->jinvalid = jinvalid ? 1 : 0;
+    rs->n_fullcopy += n_full;
+    rs->min_cost = min_cost;
+    rs->n_moves += n_moves;
+    rs->n_accepted += n_acc;
+    rs->n_improved += n_impr;
+    rs->n_randpick += n_rpick;
+    rs->mti = mti;
+    rs->mtw = mtw;
+  }
+}
+
+}  // namespace tnco

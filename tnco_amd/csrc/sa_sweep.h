@@ -136,6 +136,16 @@ struct Rng {
     ++cons;
     return v;
   }
+  // on-demand variant for code that is not staged (finite-width kernels): generate the next block
+  // right now if the ring is empty
+  __device__ __forceinline__ uint32_t next_sync() {
+    if (cons == prod) {
+      if (!pend) request();
+      produce();
+      store_phase();
+    }
+    return next();
+  }
   // std::uniform_real_distribution<double>{} == generate_canonical<double,53>
   // (random.tcc:3348-3380): low word first, one rounding, scale by 2^-64.
   __device__ __forceinline__ double uniform01() {

@@ -17,6 +17,7 @@
 
 #include "sa_kernels.h"
 #include "sa_sweep.h"
+#include "fw_kernels.h"
 
 using namespace tnco;
 
@@ -65,6 +66,8 @@ struct tnco_hip_ctx {
   Params P{};
   int log2l = 2, K = 1, L = 4;  // lanes per replica = L, mask words per lane = K
   bool hyper = false, generic = false;
+  bool fw = false;  // finite-width optimizer
+  FwParams F{};
   std::vector<void*> allocs;
   int64_t bytes = 0;
   std::vector<uint64_t> leafmask_w;  // [n][W]
@@ -189,6 +192,40 @@ void launch_compare(tnco_hip_ctx* h, const BuildArgs& a, double atol, int32_t* o
 #define CALL_CMP(LL, KK) launch_compare_lk<LL, KK>(h, a, atol, out_bad)
   DISPATCH_LK(h, CALL_CMP)
 #undef CALL_CMP
+}
+
+template <int LOG2L, int K>
+void launch_fw_init_lk(tnco_hip_ctx* h, const FwInitArgs& a) {
+  const int gpb = 256 >> LOG2L;
+  dim3 grid((unsigned)((h->P.R + gpb - 1) / gpb));
+  if (h->hyper)
+    hipLaunchKernelGGL((fw_init_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, h->F, a);
+  else
+    hipLaunchKernelGGL((fw_init_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, a);
+}
+void launch_fw_init(tnco_hip_ctx* h, const FwInitArgs& a) {
+#define CALL_FWI(LL, KK) launch_fw_init_lk<LL, KK>(h, a)
+  DISPATCH_LK(h, CALL_FWI)
+#undef CALL_FWI
+}
+
+template <int LOG2L, int K>
+void launch_fw_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, int64_t off,
+                      int64_t every) {
+  const int gpb = 256 >> LOG2L;
+  dim3 grid((unsigned)((h->P.R + gpb - 1) / gpb));
+  if (h->hyper)
+    hipLaunchKernelGGL((fw_run_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, h->F, betas, n_steps,
+                       prob_kind, off, every);
+  else
+    hipLaunchKernelGGL((fw_run_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, betas, n_steps,
+                       prob_kind, off, every);
+}
+void launch_fw_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, int64_t off,
+                   int64_t every) {
+#define CALL_FWR(LL, KK) launch_fw_run_lk<LL, KK>(h, betas, n_steps, prob_kind, off, every)
+  DISPATCH_LK(h, CALL_FWR)
+#undef CALL_FWR
 }
 
 // checkpoint := current tree, replica state := fresh
@@ -370,6 +407,16 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   }
   if (uniform && dim_u == 0) return fail(TNCO_HIP_EINVAL, "Dimensions must be positive numbers");
 
+  // finite width?  (tnco/app/app.py:866-870: finite max_width selects the finite_width optimizer)
+  const bool fw = std::isfinite(d->max_width);
+  if (fw) {
+    if (d->max_width < 0) return fail(TNCO_HIP_ERUNTIME, "'max_width' must be a non-negative number.");
+    if (!uniform) return fail(TNCO_HIP_ENOTIMPL, "finite width: per-index dims are not supported yet.");
+    if (d->sparse_mask) return fail(TNCO_HIP_ENOTIMPL, "finite width: sparse indices are not supported yet.");
+    if (d->width_dtype != TNCO_HIP_F32) return fail(TNCO_HIP_ENOTIMPL, "finite width: width_type must be float32.");
+    if (d->max_number_new_slices != 0) return fail(TNCO_HIP_ENOTIMPL, "finite width: max_number_new_slices must be 0.");
+  }
+
   // host-side structural validation of every tree
   {
     const int64_t ntrees = d->links_stride == 0 ? 1 : R;
@@ -548,8 +595,54 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (int64_t r = 0; r < R; ++r)
       if (status[r]) return fail(TNCO_HIP_EINVAL, status_message(status[r]));
-    for (int64_t r = 0; r < R; ++r)
+    if (!fw)
+      for (int64_t r = 0; r < R; ++r)
+        if (bad_log2(total[r]) || bad_log2(sum[r])) return fail(TNCO_HIP_EINVAL, "Precision is too low.");
+  }
+
+  // finite width: WidthCache, initial slices (greedy, draws from the PRNG), CostCache(slices)
+  // -- finite_width/greedy/optimizer.hpp:72-115
+  if (fw) {
+    h->fw = true;
+    FwParams& F = h->F;
+    F.max_width = (float)d->max_width;
+    F.log2d = std::log2((double)dim_u);
+    F.I64 = 64 * L;
+    HIP_TRY(h->alloc(&F.slices, R * 2 * (int64_t)L));
+    HIP_TRY(h->alloc(&F.scratch_i, R * (int64_t)(3 * N + F.I64 + FW_MAXPOS / 2)));
+    HIP_TRY(h->alloc(&F.scratch_d, R * 2 * (int64_t)N));
+    HIP_TRY(h->alloc(&F.status, R));
+    HIP_TRY(hipMemset(F.status, 0, (size_t)R * 4));
+    auto upload_mask = [&](const uint64_t* src, const uint64_t** dst) -> int {
+      std::vector<uint64_t> m((size_t)L, 0);
+      for (int w = 0; w < W; ++w) m[w] = src[w];
+      uint64_t* dm;
+      HIP_TRY(h->alloc(&dm, L));
+      HIP_TRY(hipMemcpy(dm, m.data(), m.size() * 8, hipMemcpyHostToDevice));
+      *dst = dm;
+      return TNCO_HIP_OK;
+    };
+    if (d->skip_slices)
+      if (int rc = upload_mask(d->skip_slices, &F.skip)) return rc;
+    FwInitArgs a{};
+    if (d->slices)
+      if (int rc = upload_mask(d->slices, &a.slices_in)) return rc;
+    double *dtotal = nullptr, *dsum = nullptr;
+    HIP_TRY(tmp.alloc(&dtotal, R));
+    HIP_TRY(tmp.alloc(&dsum, R));
+    a.out_total = dtotal; a.out_sum = dsum;
+    launch_fw_init(h, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::vector<double> total((size_t)R), sum((size_t)R);
+    std::vector<int32_t> st((size_t)R);
+    HIP_TRY(hipMemcpy(total.data(), dtotal, (size_t)R * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(sum.data(), dsum, (size_t)R * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(st.data(), F.status, (size_t)R * 4, hipMemcpyDeviceToHost));
+    for (int64_t r = 0; r < R; ++r) {
+      if (st[r]) return fail(TNCO_HIP_ENOTIMPL, "a tensor has more than 512 candidate legs to slice.");
       if (bad_log2(total[r]) || bad_log2(sum[r])) return fail(TNCO_HIP_EINVAL, "Precision is too low.");
+    }
   }
 
   guard.h = nullptr;
@@ -577,6 +670,7 @@ int tnco_hip_run(tnco_hip_handle h, int prob_kind, const double* betas, int64_t 
   if (prob_kind < 0 || prob_kind > 2) return fail(TNCO_HIP_EINVAL, "'prob_kind' is not valid.");
   if (n_steps < 0 || (n_steps > 0 && !betas)) return fail(TNCO_HIP_EINVAL, "'betas' is not valid.");
   if (n_steps == 0) return TNCO_HIP_OK;
+  if (h->fw) return fail(TNCO_HIP_EINVAL, "handle was created with 'max_width': use tnco_hip_run_fw.");
   HIP_TRY(hipSetDevice(h->device));
   // the previous launch may still be reading d_betas
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -608,6 +702,59 @@ int tnco_hip_run(tnco_hip_handle h, int prob_kind, const double* betas, int64_t 
     h->launches++;
   }
   if (h->pending.size() > 256) h->resolve_events();
+  return TNCO_HIP_OK;
+}
+
+int tnco_hip_run_fw(tnco_hip_handle h, int prob_kind, const double* betas, int64_t n_steps,
+                    int64_t update_slices_every, int64_t step_offset) {
+  if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
+  if (!h->fw) return fail(TNCO_HIP_EINVAL, "handle was created without 'max_width': use tnco_hip_run.");
+  if (prob_kind < 0 || prob_kind > 2) return fail(TNCO_HIP_EINVAL, "'prob_kind' is not valid.");
+  if (n_steps < 0 || (n_steps > 0 && !betas) || step_offset < 0) return fail(TNCO_HIP_EINVAL, "'betas' is not valid.");
+  if (n_steps == 0) return TNCO_HIP_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (n_steps > h->betas_cap) {
+    if (h->d_betas) (void)hipFree(h->d_betas);
+    h->d_betas = nullptr;
+    h->betas_cap = 0;
+    HIP_TRY(hipMalloc((void**)&h->d_betas, (size_t)n_steps * 8));
+    h->betas_cap = n_steps;
+  }
+  HIP_TRY(hipMemcpyAsync(h->d_betas, betas, (size_t)n_steps * 8, hipMemcpyHostToDevice, h->stream));
+  const int64_t max_steps = std::max<int64_t>(1, (int64_t)0xF0000000u / std::max(1, h->P.n));
+  for (int64_t s0 = 0; s0 < n_steps; s0 += max_steps) {
+    const int64_t cnt = std::min(max_steps, n_steps - s0);
+    EventPair ev;
+    if (!h->free_events.empty()) {
+      ev = h->free_events.back();
+      h->free_events.pop_back();
+    } else {
+      HIP_TRY(hipEventCreate(&ev.a));
+      HIP_TRY(hipEventCreate(&ev.b));
+    }
+    HIP_TRY(hipEventRecord(ev.a, h->stream));
+    launch_fw_run(h, h->d_betas + s0, cnt, prob_kind, step_offset + s0, update_slices_every);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev.b, h->stream));
+    h->pending.push_back(ev);
+    h->launches++;
+  }
+  if (h->pending.size() > 256) h->resolve_events();
+  return TNCO_HIP_OK;
+}
+
+int tnco_hip_get_slices(tnco_hip_handle h, int64_t r, uint64_t* slices, uint64_t* min_slices) {
+  if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
+  if (!h->fw) return fail(TNCO_HIP_EINVAL, "handle was created without 'max_width'.");
+  if (r < 0 || r >= h->P.R) return fail(TNCO_HIP_EINVAL, "'replica' out of range.");
+  const int LK = h->L * h->K, W = h->P.W;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  std::vector<uint64_t> s((size_t)2 * LK);
+  HIP_TRY(hipMemcpy(s.data(), h->F.slices + r * 2 * (int64_t)LK, s.size() * 8, hipMemcpyDeviceToHost));
+  if (slices) std::memcpy(slices, s.data(), (size_t)W * 8);
+  if (min_slices) std::memcpy(min_slices, s.data() + LK, (size_t)W * 8);
   return TNCO_HIP_OK;
 }
 
@@ -712,6 +859,7 @@ int tnco_hip_get_caches(tnco_hip_handle h, int64_t r, double* ccost, double* par
 
 int tnco_hip_validate(tnco_hip_handle h, double atol, int64_t* n_bad, int64_t* first_bad) {
   if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
+  if (h->fw) return fail(TNCO_HIP_ENOTIMPL, "validate() is not available for finite-width handles yet.");
   const Params& P = h->P;
   const int n = P.n, N = P.N;
   const int64_t R = P.R;
