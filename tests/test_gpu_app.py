@@ -97,6 +97,31 @@ def test_disconnected_components_and_json():
         assert len(final) == 1
 
 
+def test_finite_width_through_the_api():
+    """tests/test_app.py:117-329 + tests/test_contraction.py:184-352 of the reference: results carry
+    `slices`; every intermediate tensor fits `max_width` once the sliced indices are removed; the
+    cost is the sliced contraction's flops."""
+    ts, dims, out = __import__("tnco_amd.synthetic", fromlist=["x"]).random_regular_tn(40, 3, 9)
+    spec = [(2, *[f"t{t}" for t in range(40) if k in ts[t]]) for k in range(60)]
+    max_width = 5
+    tn, res = Optimizer(method="sa", max_width=max_width, seed=4).optimize(
+        spec, betas=(0, 80), n_steps=200, n_runs=6, update_slices=10)
+    assert len(res) == 6 and [r.cost for r in res] == sorted(r.cost for r in res)
+    for r in res:
+        assert r.slices == frozenset().union(*r.disconnected_slices) and len(r.slices) > 0
+        legs = [frozenset(x) for x in tn.ts_inds]
+        cost = 0
+        for x, y in r.path:
+            x, y = sorted((x, y))
+            b = legs.pop(y)
+            a = legs.pop(x)
+            cost += 2 ** len(a | b | r.slices)
+            new = a ^ b
+            assert len(new - r.slices) <= max_width
+            legs.append(new)
+        assert Decimal("%g" % cost) == r.cost
+
+
 def test_timeout_and_top_k():
     ts, dims, out = __import__("tnco_amd.synthetic", fromlist=["x"]).random_regular_tn(64, 3, 7)
     spec = [(2, *[f"t{t}" for t in range(64) if k in ts[t]]) for k in range(96)]

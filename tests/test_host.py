@@ -122,8 +122,8 @@ def test_factory_dispatch_and_validation():
         Optimizer(output_format="xml")
     with pytest.raises(ValueError, match="'n_steps' must be a positive number."):
         opt.optimize("2 a b\n2 b c", betas=(0, 1), n_steps=0)
-    with pytest.raises(NotImplementedError):
-        Optimizer(method="sa", max_width=4).optimize("2 a b\n2 b c", betas=(0, 1), n_steps=3)
+    with pytest.raises(ValueError, match="'update_slices' must be a positive number."):
+        Optimizer(method="sa", max_width=4).optimize("2 a b\n2 b c", betas=(0, 1), n_steps=3, update_slices=0)
 
 
 def test_shard_bounds_partition():

@@ -1,0 +1,183 @@
+"""The SA driver shared by method='sa' with and without a width bound.
+
+Host mirror of /root/reference/tnco/app/infinite_memory/sa.py:100-257 and
+tnco/app/finite_width/sa.py:117-289.  What the reference does per run in a loky worker process
+(random initial path -> ContractionTree -> Optimizer -> `for beta in betas: opt.update(prob)`) is
+done here for ALL runs at once on the GPU: one BatchedOptimizer per connected component, one
+kernel launch per chunk of the beta schedule.  With torch.distributed initialised, the run list is
+sharded over the ranks (one GPU each, tnco_amd/parallel.py) and merged with one all-reduce(min) +
+one all-gather of the heads.
+"""
+from __future__ import annotations
+
+from time import perf_counter
+from typing import Iterable
+
+import numpy as np
+
+from .. import core, parallel
+from ..ctree import get_contraction, pack_masks, ssa_to_linear, unpack_mask
+from .app import cost_to_decimal
+from .tn import get_connected_components
+
+__all__ = ["run_sa", "merge_contraction_paths", "expand_betas"]
+
+
+def merge_contraction_paths(n_tensors: int, paths: Iterable[list], *, autocomplete: bool = True) -> list:
+    """tnco/utils/tn.py:334-401."""
+    merged_pos = list(range(n_tensors))
+    merged_path = []
+    for i, path in enumerate(paths):
+        pos = list(range(n_tensors))
+        for x, y in path:
+            x, y = sorted((x, y))
+            y = pos.pop(y)
+            x = pos.pop(x)
+            pos.append((i, len(pos)))
+            try:
+                mx, my = sorted((merged_pos.index(x), merged_pos.index(y)))
+            except ValueError as e:
+                raise ValueError("'paths' are not valid or not disconnected.") from e
+            merged_path.append((mx, my))
+            merged_pos.pop(my)
+            merged_pos.pop(mx)
+            merged_pos.append(pos[-1])
+    if autocomplete:
+        merged_path += [(0, 1)] * (len(merged_pos) - 1)
+    return merged_path
+
+
+def expand_betas(betas, n_steps):
+    """Argument checks and schedule of sa.py:141-156 (more_itertools.numeric_range(b0, b1, step)
+    yields b0 + k*step while < b1 for step > 0, > b1 for step < 0)."""
+    if n_steps is not None:
+        if int(n_steps) != n_steps or n_steps <= 0:
+            raise ValueError("'n_steps' must be a positive number.")
+        n_steps = int(n_steps)
+    if isinstance(betas, tuple) and len(betas) == 2:
+        if n_steps is None:
+            raise ValueError("'n_steps' must be provided if 'betas' has the format '(beta_min, beta_max)'.")
+        if betas[0] == betas[1]:
+            raise ValueError("'betas' must use the format '(beta_ini, beta_end)', with 'beta_ini != beta_end'.")
+        b0, b1 = betas
+        step = (b1 - b0) / n_steps
+        out, k = [], 0
+        while True:
+            v = b0 + k * step
+            if (step > 0 and v >= b1) or (step < 0 and v <= b1):
+                break
+            out.append(v)
+            k += 1
+        betas = out
+    betas = [float(b) for b in betas]
+    if n_steps is not None:
+        betas = betas[:n_steps]  # `if n == n_steps: break`, sa.py:201
+    return np.asarray(betas, np.float64)
+
+
+class _Component:
+    """One connected component flattened to bit positions."""
+
+    def __init__(self, tn, cc):
+        self.tensors = tuple(cc)
+        ts = [tn.ts_inds[t] for t in cc]
+        self.inds_order = tuple(dict.fromkeys(i for xs in ts for i in xs))
+        imap = {x: k for k, x in enumerate(self.inds_order)}
+        self.n_inds = len(self.inds_order)
+        self.leaf_positions = [[imap[i] for i in xs] for xs in ts]
+        self.leaf_masks = pack_masks(self.leaf_positions, self.n_inds)
+        self.output_mask = pack_masks([[imap[i] for i in tn.output_inds if i in imap]], self.n_inds)[0]
+        sp = [imap[i] for i in tn.sparse_inds if i in imap]
+        self.sparse_mask = pack_masks([sp], self.n_inds)[0] if sp else None
+        dims = [tn.dims[x] for x in self.inds_order]
+        self.dims = dims[0] if dims and all(d == dims[0] for d in dims) else np.asarray(dims, np.uint64)
+        if not dims:
+            self.dims = 1
+
+    def path(self, left, right, n_tensors):
+        """Linear path over all original tensors (tnco/ctree.py:350-388)."""
+        nc = len(self.tensors)
+        shift = n_tensors - nc
+
+        def rescale(p):
+            return self.tensors[p] if p < nc else p + shift
+
+        return ssa_to_linear([tuple(rescale(p) for p in xs) for xs in get_contraction(left, right)], n_tensors)
+
+    def names(self, mask) -> frozenset:
+        return frozenset(self.inds_order[p] for p in unpack_mask(mask))
+
+
+def run_sa(opt, tn, betas, n_steps, n_runs, n_projs, timeout, *, top_k, sweeps_per_launch, prob, device,
+           update_slices: int | None):
+    """Returns (tn, merged) with merged = [(cost, global run id, per-component costs, per-component
+    paths, per-component slices | None)] sorted, the `top_k` best runs over all ranks."""
+    finite = update_slices is not None
+    betas = expand_betas(betas, n_steps)
+    n_runs = int(n_runs)
+    if n_runs <= 0:
+        raise ValueError("'n_runs' must be a positive number.")
+    if tn.sparse_inds and not n_projs:
+        raise ValueError("'n_projs' must be provided if 'tn' has sparse indices.")
+    seeds = opt._rng.choices(range(2**32), k=n_runs)  # sa.py:237
+
+    rank, world = parallel.rank_world()
+    lo, hi = parallel.shard_bounds(n_runs, world, rank)
+    if device is None:
+        device = parallel.local_device()
+    my_seeds = seeds[lo:hi]
+    top_k = min(n_runs, 1024) if top_k is None else max(1, min(int(top_k), n_runs))
+
+    comps = [_Component(tn, cc) for cc in get_connected_components(tn.ts_inds)]
+    n_local = len(my_seeds)
+    raw_cost = np.zeros((n_local, len(comps)), np.float64)
+    handles = []
+    t0 = perf_counter()
+    timed_out = False
+    for ci, comp in enumerate(comps):
+        if len(comp.tensors) <= 1 or n_local == 0:  # `if not path`, sa.py:179-183
+            handles.append(None)
+            continue
+        links = core.random_trees(comp.leaf_positions, comp.n_inds, my_seeds)
+        kw = dict(max_width=opt.max_width, width_type=opt.width_type) if finite else {}
+        h = core.BatchedOptimizer(comp.leaf_masks, links, my_seeds, n_inds=comp.n_inds, dims=comp.dims,
+                                  output_mask=comp.output_mask, sparse_mask=comp.sparse_mask,
+                                  n_projs=n_projs, cost_type=opt.cost_type, device=device, **kw)
+        for s in range(0, len(betas), max(1, int(sweeps_per_launch))):
+            if timeout is not None and perf_counter() - t0 > timeout:
+                timed_out = True
+                break
+            h.run(betas[s:s + sweeps_per_launch], prob, update_slices_every=update_slices or 0)
+            if timeout is not None:
+                h.sync()
+        raw_cost[:, ci] = h.costs()[1]
+        handles.append(h)
+    runtime = perf_counter() - t0
+
+    # cost of a run = sum of the per-component Decimals (sa.py:215-218)
+    dec = [[cost_to_decimal(raw_cost[r, ci]) if handles[ci] is not None else 0 for ci in range(len(comps))]
+           for r in range(n_local)]
+    totals = [sum(d) for d in dec]
+    order = sorted(range(n_local), key=lambda r: (totals[r], lo + r))[:top_k]
+    local = []
+    for r in order:
+        paths, slices = [], []
+        for ci, comp in enumerate(comps):
+            if handles[ci] is None:
+                paths.append([])
+                slices.append(frozenset())
+            else:
+                l, rr, _p, _m = handles[ci].tree(r, which_min=True, with_masks=False)
+                paths.append(comp.path(l, rr, len(tn)))
+                slices.append(comp.names(handles[ci].slices(r)[1]) if finite else frozenset())
+        local.append((totals[r], lo + r, dec[r], paths, slices))
+    best_raw = float(raw_cost.sum(axis=1).min()) if n_local else float("inf")
+    for h in handles:
+        if h is not None:
+            h.close()
+
+    merged = parallel.merge_heads(local, top_k, rank, world)
+    tn.tags["best_raw_cost"] = parallel.global_best(best_raw, rank, world, device)
+    tn.tags["n_runs"] = n_runs
+    tn.tags["timed_out"] = timed_out
+    return merged, runtime
