@@ -92,3 +92,33 @@ def test_fw_unsupported(core):
         core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, max_width=4, max_number_new_slices=2)
     with pytest.raises(NotImplementedError):
         core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, max_width=4, width_type="float64")
+
+
+def test_sycamore53_depth20_finite_width(core, oracle_lib):
+    """BASELINE config 5 topology (Sycamore-53-style RQC, depth 20: 541 tensors, 923 indices,
+    15 mask words -> 4 lanes x 4 words), memory-constrained, against the oracle."""
+    from tnco_amd import synthetic as syn
+    ts, dims, out = syn.sycamore53_tn(20)
+    prob = H.Problem(ts, 2, out)
+    assert prob.n == 541 and prob.n_inds == 923
+    seeds = H.replica_seeds(6, S=53)
+    betas = H.linear_betas(0, 100, 60)
+    gpu = _check(core, oracle_lib, prob, seeds, betas, 40, chunks=[25, 35], every=10)
+    s, ms = gpu.slices(0)
+    assert ms.any()
+
+
+def test_sycamore53_infinite_memory(core, oracle_lib):
+    from tnco_amd import synthetic as syn
+    ts, dims, out = syn.sycamore53_tn(20)
+    prob = H.Problem(ts, 2, out)
+    seeds = H.replica_seeds(32, S=54)
+    links = prob.links(seeds)
+    betas = H.linear_betas(0, 100, 300)
+    gpu = core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds)
+    gpu.run(betas)
+    for r in range(8):
+        o = H.make_oracle(oracle_lib, prob, links[r], seeds[r])
+        o.run(oracle_lib.PROB_MH, betas)
+        H.assert_replica_equal(gpu, r, o)
+    assert gpu.validate() == (0, -1)

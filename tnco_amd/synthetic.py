@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["random_regular_tn", "random_hyper_tn", "chain_tn"]
+__all__ = ["random_regular_tn", "random_hyper_tn", "chain_tn", "sycamore53_tn"]
 
 
 def _connected(n: int, edges: np.ndarray) -> bool:
@@ -69,6 +69,52 @@ def chain_tn(n: int):
     for k in range(n - 1):
         ts_inds[k].append(k)
         ts_inds[k + 1].append(k)
+    return ts_inds, 2, ()
+
+
+def sycamore53_tn(depth: int = 20, dead=(0, 0)):
+    """Tensor network of a Sycamore-53-style random quantum circuit amplitude <x|U|0>.
+
+    BASELINE config 5 names a "Sycamore-53 depth-20 RQC"; the reference ships no such network (its
+    circuit front-end needs cirq), so the topology is generated here: 54 qubits on a rotated square
+    lattice of 9 rows x 6 (qubit (r, j) at column 2j + r % 2, diagonal nearest neighbours, 88
+    couplers), one dead qubit removed (53 qubits, 86 couplers); couplers split into the four
+    patterns A, B, C, D by (parity of the row gap, diagonal direction); every cycle applies one
+    pattern in the order A B C D C D A B; single-qubit gates are absorbed into the two-qubit gates.
+    Tensors: one 1-leg tensor per qubit at the input and at the output, one 4-leg tensor per
+    two-qubit gate; indices: the wire segments between consecutive tensors of a qubit, all of
+    dimension 2.  depth 20 -> 435 gates, 541 tensors, 923 indices (15 mask words).
+
+    Returns (ts_inds, dims, output_inds) like random_regular_tn.
+    """
+    qubits = [(r, 2 * j + (r % 2)) for r in range(9) for j in range(6) if (r, 2 * j + (r % 2)) != tuple(dead)]
+    qset = set(qubits)
+    patterns = {"A": [], "B": [], "C": [], "D": []}
+    for (r, c) in qubits:
+        for dc, name_even, name_odd in ((+1, "A", "C"), (-1, "B", "D")):
+            other = (r + 1, c + dc)
+            if other in qset:
+                patterns[name_even if r % 2 == 0 else name_odd].append(((r, c), other))
+    order = "ABCDCDAB"
+    wire = {q: None for q in qubits}  # current open index of every qubit
+    ts_inds, n_idx = [], 0
+
+    def new_index():
+        nonlocal n_idx
+        n_idx += 1
+        return n_idx - 1
+
+    for q in qubits:  # |0> on every qubit
+        wire[q] = new_index()
+        ts_inds.append([wire[q]])
+    for cycle in range(depth):
+        for qa, qb in patterns[order[cycle % len(order)]]:
+            ia, ib = wire[qa], wire[qb]
+            oa, ob = new_index(), new_index()
+            ts_inds.append([ia, ib, oa, ob])
+            wire[qa], wire[qb] = oa, ob
+    for q in qubits:  # <x| on every qubit
+        ts_inds.append([wire[q]])
     return ts_inds, 2, ()
 
 
