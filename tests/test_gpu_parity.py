@@ -64,6 +64,25 @@ def test_sizes_and_lane_groups(core, oracle_lib, n, deg):
     _run_both(core, oracle_lib, prob, seeds, H.linear_betas(0, 50, 300))
 
 
+@pytest.mark.parametrize("n,deg,R,sweeps", [(2, 1, 5, 20), (3, 2, 5, 30), (900, 3, 6, 60), (1300, 3, 5, 50),
+                                            (1400, 3, 5, 50), (2600, 3, 4, 40)])
+def test_edge_sizes_and_wide_masks(core, oracle_lib, n, deg, R, sweeps):
+    """Smallest trees (no move / one move per sweep) and every wide lane layout: 22 words -> 8 lanes
+    x 3, 31 -> 8 x 4, 33 -> 16 x 3, 61 -> 16 x 4."""
+    prob = H.regular_problem(n, graph_seed=n % 97, degree=deg)
+    seeds = H.replica_seeds(R, S=n)
+    gpu = _run_both(core, oracle_lib, prob, seeds, H.linear_betas(0, 80, sweeps))
+    gpu.run([], "mh")  # zero sweeps: no-op
+    assert gpu.validate() == (0, -1)
+
+
+def test_too_many_indices_is_refused(core):
+    prob = H.regular_problem(2800, graph_seed=3)  # 4200 indices > 4096
+    seeds = H.replica_seeds(1)
+    with pytest.raises(NotImplementedError):
+        core.BatchedOptimizer(prob.leaf_masks, prob.links(seeds), seeds, n_inds=prob.n_inds)
+
+
 @pytest.mark.parametrize("kind", ["base", "greedy", "mh"])
 def test_prob_kinds(core, oracle_lib, kind):
     prob = H.regular_problem(48, graph_seed=3)
