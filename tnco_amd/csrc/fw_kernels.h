@@ -162,7 +162,7 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
   Mask<K> skip = mzero<K>();
   if (F.skip) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) skip.w[k] = F.skip[lig * K + k];
+    for (int k = 0; k < K; ++k) skip.w[k] = F.skip[v.widx(k)];
   }
   // :41-48  number of too-wide tensors every index appears in
   for (int i = lig; i < F.I64; i += L) n_big[i] = 0;
@@ -175,7 +175,7 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
         uint64_t x = m.w[k];
         while (x) {
           const int b = __ffsll((unsigned long long)x) - 1;
-          n_big[(lig * K + k) * 64 + b] += 1;
+          n_big[v.widx(k) * 64 + b] += 1;
           x &= x - 1;
         }
       }
@@ -189,31 +189,31 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
     Mask<K> sliced_xs = mandn<K>(v.mask(t), slices);
     float sliced_width = fw_width(F, gsum<LOG2L>(mpopc<K>(sliced_xs)));
     if (!(sliced_width > F.max_width)) continue;
-    // candidate positions, ascending (Bitset::positions): lane-major, then word, then bit
+    // candidate positions, ascending (Bitset::positions): word k*L + j is slot k of lane j
     const Mask<K> cand = mandn<K>(sliced_xs, skip);
-    const uint32_t mine = mpopc<K>(cand);
-    uint32_t before = 0, np = 0;
-    for (int j = 0; j < L; ++j) {
-      const uint32_t c = (uint32_t)__shfl((int)mine, gbase + j);
-      if (j < lig) before += c;
-      np += c;
+    uint32_t np = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t mine = (uint32_t)__popcll(cand.w[k]);
+      uint32_t before = 0, tot = 0;
+      for (int j = 0; j < L; ++j) {
+        const uint32_t c = (uint32_t)__shfl((int)mine, gbase + j);
+        if (j < lig) before += c;
+        tot += c;
+      }
+      uint32_t o = np + before;
+      uint64_t x = cand.w[k];
+      while (x) {
+        const int b = __ffsll((unsigned long long)x) - 1;
+        if (o < (uint32_t)FW_MAXPOS) pos[o] = (int16_t)(v.widx(k) * 64 + b);
+        ++o;
+        x &= x - 1;
+      }
+      np += tot;
     }
     if (np > (uint32_t)FW_MAXPOS) {
       if (lane0) *status = 1;
       np = FW_MAXPOS;
-    }
-    {
-      uint32_t o = before;
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        uint64_t x = cand.w[k];
-        while (x) {
-          const int b = __ffsll((unsigned long long)x) - 1;
-          if (o < (uint32_t)FW_MAXPOS) pos[o] = (int16_t)((lig * K + k) * 64 + b);
-          ++o;
-          x &= x - 1;
-        }
-      }
     }
     // :80  std::shuffle(positions, prng)
     fw_shuffle<LOG2L>(rng, pos, (int)np, lane0);
@@ -233,7 +233,7 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
       // sliced_xs.reset(xpos)
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        if ((xpos >> 6) == lig * K + k) {
+        if ((xpos >> 6) == v.widx(k)) {
           slices.w[k] |= 1ull << (xpos & 63);
           sliced_xs.w[k] &= ~(1ull << (xpos & 63));
         }
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwPa
   v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n, lig);
   ReplicaState* rs = P.rs + r;
   R rng;
-  rng.init(P, r, rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
+  rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
   int32_t* si = F.scratch_i + r * (int64_t)(3 * N + F.I64 + FW_MAXPOS / 2);
   int32_t *order = si, *stack = si + N, *visited = si + 2 * N, *n_big = si + 3 * N;
   double* cc_new = F.scratch_d + r * 2 * (int64_t)N;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwPa
   Mask<K> slices;
   if (a.slices_in) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) slices.w[k] = a.slices_in[lig * K + k];
+    for (int k = 0; k < K; ++k) slices.w[k] = a.slices_in[v.widx(k)];
   } else {
     volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + 3 * N + F.I64);
     slices = fw_get_slices<LOG2L, K, HYPER>(P, F, v, rng, order, n_big, pos, lane0, gbase, F.status + r);
@@ -298,8 +298,8 @@ __global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwPa
   uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    sl[lig * K + k] = slices.w[k];
-    sl[LK + lig * K + k] = slices.w[k];
+    sl[v.widx(k)] = slices.w[k];
+    sl[LK + v.widx(k)] = slices.w[k];
   }
   int mti, mtw;
   rng.finish(mti, mtw);
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
   v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n, lig);
   ReplicaState* rs = P.rs + r;
   R rng;
-  rng.init(P, r, rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
+  rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
   int32_t* si = F.scratch_i + r * (int64_t)(3 * N + F.I64 + FW_MAXPOS / 2);
   int32_t *order = si, *stack = si + N, *visited = si + 2 * N, *n_big = si + 3 * N;
   double* cc_new = F.scratch_d + r * 2 * (int64_t)N;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
   uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
   M slices;
 #pragma unroll
-  for (int k = 0; k < K; ++k) slices.w[k] = sl[lig * K + k];
+  for (int k = 0; k < K; ++k) slices.w[k] = sl[v.widx(k)];
   double min_cost = rs->min_cost;
   uint32_t n_moves = 0, n_acc = 0, n_impr = 0, n_rpick = 0, n_full = 0;
   int32_t* jlog = P.jlog + r * (int64_t)P.jcap;
@@ -473,11 +473,11 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
       }
       jmin = jtail;
 #pragma unroll
-      for (int k = 0; k < K; ++k) sl[LK + lig * K + k] = slices.w[k];
+      for (int k = 0; k < K; ++k) sl[LK + v.widx(k)] = slices.w[k];
     }
   }
 #pragma unroll
-  for (int k = 0; k < K; ++k) sl[lig * K + k] = slices.w[k];
+  for (int k = 0; k < K; ++k) sl[v.widx(k)] = slices.w[k];
   int mti, mtw;
   rng.finish(mti, mtw);
   if (lane0) {

@@ -139,19 +139,22 @@ struct View {
   __device__ __forceinline__ NodeRec* hdr(int p) const {
     return reinterpret_cast<NodeRec*>(blk + (int64_t)(p - n) * BS);
   }
+  // word index held in slot k of this lane: k-major, so that the 4/8/16 lanes of a group access
+  // L consecutive words (one contiguous 8L-byte piece of the line) per instruction
+  __device__ __forceinline__ int widx(int k) const { return k * L + lig; }
   __device__ __forceinline__ uint64_t* words(int p) const {
-    return reinterpret_cast<uint64_t*>(blk + (int64_t)(p - n) * BS + 32) + lig * K;
+    return reinterpret_cast<uint64_t*>(blk + (int64_t)(p - n) * BS + 32);
   }
   __device__ __forceinline__ Mask<K> mask(int x) const {
     Mask<K> r;
     if (x < n) {
-      const uint64_t* s = leafmask + (int64_t)x * LK + lig * K;
+      const uint64_t* s = leafmask + (int64_t)x * LK;
 #pragma unroll
-      for (int k = 0; k < K; ++k) r.w[k] = s[k];
+      for (int k = 0; k < K; ++k) r.w[k] = s[widx(k)];
     } else {
       const uint64_t* s = words(x);
 #pragma unroll
-      for (int k = 0; k < K; ++k) r.w[k] = (lig * K + k < W) ? s[k] : 0ull;
+      for (int k = 0; k < K; ++k) r.w[k] = (widx(k) < W) ? s[widx(k)] : 0ull;
     }
     return r;
   }
@@ -159,14 +162,14 @@ struct View {
     uint64_t* s = words(p);
 #pragma unroll
     for (int k = 0; k < K; ++k)
-      if (lig * K + k < W) s[k] = v.w[k];
+      if (widx(k) < W) s[widx(k)] = v.w[k];
   }
   __device__ __forceinline__ Mask<K> hyper(int p) const {
     Mask<K> r = mzero<K>();
     if constexpr (HYPER) {
       const uint64_t* s = words(p) + W;
 #pragma unroll
-      for (int k = 0; k < K; ++k) r.w[k] = (lig * K + k < W) ? s[k] : 0ull;
+      for (int k = 0; k < K; ++k) r.w[k] = (widx(k) < W) ? s[widx(k)] : 0ull;
     }
     return r;
   }
@@ -175,7 +178,7 @@ struct View {
       uint64_t* s = words(p) + W;
 #pragma unroll
       for (int k = 0; k < K; ++k)
-        if (lig * K + k < W) s[k] = v.w[k];
+        if (widx(k) < W) s[widx(k)] = v.w[k];
     }
   }
   __device__ __forceinline__ double partial(int x) const { return x < n ? 0.0 : hdr(x)->partial; }
@@ -234,17 +237,17 @@ __device__ __forceinline__ double pow2_cost(int e, int f32) {
 // ---------------------------------------------------------------------------
 template <int LOG2L, int K>
 __device__ __forceinline__ double seq_product(const Params& P, const Mask<K>& u, int gbase) {
-  // running product in cost_type over ascending set bits (Bitset::visit order): lane by lane,
-  // word by word
+  // running product in cost_type over ascending set bits (Bitset::visit order): word k*L + j is
+  // slot k of lane j
   constexpr int L = 1 << LOG2L;
   double c = 1.0;
-  for (int j = 0; j < L; ++j) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
+  for (int k = 0; k < K; ++k) {
+    for (int j = 0; j < L; ++j) {
       const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)u.w[k], gbase + j);
       const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(u.w[k] >> 32), gbase + j);
       uint64_t x = ((uint64_t)hi << 32) | lo;
-      const int w = j * K + k;
+      const int w = k * L + j;
       while (x) {
         const int b = __ffsll((unsigned long long)x) - 1;
         c = rnd_cost(c * P.dimsd[w * 64 + b], P.f32);
@@ -268,7 +271,7 @@ __device__ __forceinline__ double generic_cost(const Params& P, const Mask<K>& u
   }
   Mask<K> s;
 #pragma unroll
-  for (int k = 0; k < K; ++k) s.w[k] = P.sparse[lig * K + k];
+  for (int k = 0; k < K; ++k) s.w[k] = P.sparse[k * (1 << LOG2L) + lig];
   double c1, c2;
   if (P.cost_mode <= 1) {
     const uint32_t v = gsum<LOG2L>(mpopc<K>(mandn<K>(u, s)) | (mpopc<K>(mand<K>(u, s)) << 16));
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
   int status = 0;
   M om;
 #pragma unroll
-  for (int k = 0; k < K; ++k) om.w[k] = P.outmask[lig * K + k];
+  for (int k = 0; k < K; ++k) om.w[k] = P.outmask[v.widx(k)];
 
   // -- links --------------------------------------------------------------
   for (int i = lig; i < N; i += L) {
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
     for (int p = 0; p < N; ++p) {
       M x;
 #pragma unroll
-      for (int k = 0; k < K; ++k) x.w[k] = (lig * K + k < P.W) ? im[(int64_t)p * P.W + lig * K + k] : 0ull;
+      for (int k = 0; k < K; ++k) x.w[k] = (v.widx(k) < P.W) ? im[(int64_t)p * P.W + v.widx(k)] : 0ull;
       if (p >= n) v.set_mask(p, x);
       else if (gany<LOG2L>(mdiffer<K>(x, v.mask(p)))) status = 12;  // leaves must be the shared table
     }

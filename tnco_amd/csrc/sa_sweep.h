@@ -31,6 +31,11 @@ namespace tnco {
 
 #define TNCO_LANDED(x) __asm__ volatile("" : "+v"(x) : : "memory")
 
+// LDS pointers must keep their address space: a generic (flat) pointer to LDS makes every access a
+// flat_load / flat_store, which counts in vmcnt and drags an `s_waitcnt vmcnt(0)` behind it.
+#define TNCO_LDS __attribute__((address_space(3)))
+typedef TNCO_LDS volatile uint32_t lds_vu32;
+
 __device__ __forceinline__ uint32_t mt_temper(uint32_t z) {
   z ^= (z >> 11);
   z ^= (z << 7) & 0x9d2c5680u;
@@ -57,7 +62,7 @@ struct Rng {
   uint32_t* mt_base;       // P.mt      (uniform; the replica's words start at 624 * r)
   uint32_t* sh_base;       // P.mtshadow (uniform; 32 * r)
   uint32_t r32;            // replica index
-  volatile uint32_t* ring; // group's LDS ring
+  lds_vu32* ring;          // group's LDS ring
   int lig;
   __device__ __forceinline__ uint32_t* st() const { return mt_base + (uint64_t)r32 * 624u; }
   __device__ __forceinline__ uint32_t* shadow() const { return sh_base + (uint64_t)r32 * 32u; }
@@ -118,7 +123,7 @@ struct Rng {
   }
   __device__ __forceinline__ bool room() const { return !pend && (prod - cons) + SB <= (uint32_t)RING; }
 
-  __device__ __forceinline__ void init(const Params& P, int64_t r, volatile uint32_t* ring_, int mti, int mtw,
+  __device__ __forceinline__ void init(const Params& P, int64_t r, lds_vu32* ring_, int mti, int mtw,
                                        int lig_) {
     mt_base = P.mt; sh_base = P.mtshadow; r32 = (uint32_t)r; ring = ring_; lig = lig_;
     pend = false; sv = false; ssave = false; ptw = false;
@@ -214,6 +219,7 @@ struct ColdState {
   double min_cost;
   uint32_t jmin, n_impr, n_full, n_rpick;
 };
+typedef TNCO_LDS volatile ColdState lds_cold;
 
 template <int LOG2L, int K, bool HYPER, bool GENERIC>
 __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
@@ -237,12 +243,12 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
   View<LOG2L, K, HYPER> v;
   v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, nullptr, lig);
   auto lpar = [&]() -> int32_t* { return P.lpar + r * (int64_t)n; };
-  volatile ColdState& cold = coldbuf[gib];
+  lds_cold& cold = *((lds_cold*)coldbuf + gib);
 
   R rng;
   {
     const ReplicaState* rs = P.rs + r;
-    rng.init(P, r, rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
+    rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
     if (lane0) {
       cold.min_cost = rs->min_cost;
       cold.jmin = rs->jmin;
