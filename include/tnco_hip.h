@@ -160,6 +160,11 @@ int tnco_hip_get_counters(tnco_hip_handle h, uint64_t* moves, uint64_t* accepted
 int tnco_hip_get_full_copies(tnco_hip_handle h, uint64_t* n);
 /* Per replica move counter ([n_replicas]). */
 int tnco_hip_get_moves(tnco_hip_handle h, uint64_t* moves_per_replica);
+/* Diagnostic (no reference counterpart): shader cycles per stage of the sweep
+ * loop summed over replicas -- [mt19937, state branches, landing fence, store
+ * phase, loop iterations].  All zero unless the library was built with
+ * -DTNCO_PROFILE (tools/stage_cycles.sh). */
+int tnco_hip_get_stage_cycles(tnco_hip_handle h, uint64_t* out5);
 
 /* Device time of the sweep kernel accumulated by tnco_hip_run since the last
  * reset (HIP events on the handle's stream), and number of launches. */

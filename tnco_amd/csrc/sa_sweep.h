@@ -22,8 +22,8 @@
 //
 // so a replica at the start of a sweep never stalls the other replicas of its wavefront, and the
 // memory latency of every load is covered by one full iteration of work of the whole SIMD.
-// The mt19937 stream is produced the same way: 16-word (L-word for L < 16) blocks are requested
-// one iteration, twisted + tempered into an LDS ring the next, stored in the store phase.
+// The mt19937 stream is produced the same way: 16-word blocks (4 words per lane) are requested in
+// one iteration, twisted + tempered into an LDS ring in the next, stored in its store phase.
 #pragma once
 #include "sa_kernels.h"
 
@@ -55,9 +55,11 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t z) {
 template <int LOG2L>
 struct Rng {
   static constexpr int L = 1 << LOG2L;
-  static constexpr int LOG2SB = LOG2L < 4 ? LOG2L : 4;
-  static constexpr int SB = 1 << LOG2SB;           // words per block
+  static constexpr int NL = L < 4 ? L : 4;         // lanes of the group that work on a block
+  static constexpr int SB = 4 * NL;                // words per block: 4 per lane (one dwordx4); 624 % 16 == 0
   static constexpr int RING = (2 * SB > 16) ? 2 * SB : 16;
+
+  struct __attribute__((packed, aligned(4))) U4 { uint32_t x[4]; };  // 4 words at any word address
 
   uint32_t* mt_base;       // P.mt      (uniform; the replica's words start at 624 * r)
   uint32_t* sh_base;       // P.mtshadow (uniform; 32 * r)
@@ -68,72 +70,80 @@ struct Rng {
   __device__ __forceinline__ uint32_t* shadow() const { return sh_base + (uint64_t)r32 * 32u; }
   uint32_t cons, prod, tw;
   bool pend, ptw;          // a block's inputs are in flight (for virtual position prod); it needs a twist
-  uint32_t pa, pb, pc;
-  bool sv, ssave;          // a twisted word awaits the store phase; its old value goes to the shadow
-  uint32_t sval, sold;
-  int sidx;
+  // this lane's inputs: mt[k..k+3], mt[k+4], mt[k+397..k+400] (indices mod 624); written ONLY by
+  // the loads of request(), so that the loads land directly in these registers
+  uint32_t pa[4], pb, pc[4];
 
   __device__ __forceinline__ uint32_t gen_of_cons() const { return cons == 0 ? 0u : (cons - 1u) / 624u; }
 
+  // A block is requested in one loop iteration and produced in a later one.  One 16-word block costs
+  // ~3 memory requests (64 B aligned, 64 B unaligned, 64 B store): the state stream is the only
+  // per-draw traffic, so wide blocks matter -- HBM here is bound by the NUMBER of requests.
   __device__ __forceinline__ void request() {
     const uint32_t k0 = prod % 624u;
     ptw = prod >= tw;
-    if (lig < SB) {
-      const int k = (int)k0 + lig;
-      pa = st()[k];
+    if (lig < NL) {
+      const int k = (int)k0 + 4 * lig;
+      const uint32_t* s = st();
+      const uint4 a = *reinterpret_cast<const uint4*>(s + k);
+      pa[0] = a.x; pa[1] = a.y; pa[2] = a.z; pa[3] = a.w;
       if (ptw) {
-        const int k1 = (k + 1 == 624) ? 0 : k + 1;
-        int km = k + 397;
-        if (km >= 624) km -= 624;
-        pb = st()[k1];
-        pc = st()[km];
+        pb = s[(k + 4 == 624) ? 0 : k + 4];
+        if (k == 224) {  // 224 + 397 = 621: the only group of 4 that straddles the wrap
+          pc[0] = s[621]; pc[1] = s[622]; pc[2] = s[623]; pc[3] = s[0];
+        } else {
+          int km = k + 397;
+          if (km >= 624) km -= 624;
+          const U4 c = *reinterpret_cast<const U4*>(s + km);
+          pc[0] = c.x[0]; pc[1] = c.x[1]; pc[2] = c.x[2]; pc[3] = c.x[3];
+        }
       }
     }
     pend = true;
   }
-  // inputs landed: twist + temper into the ring; the state store waits for the store phase
+  // inputs landed: twist + temper into the ring and store the twisted words.  The store is issued
+  // at the TOP of an iteration, as far from the next wait (the landing fence at its end) as the
+  // loads of that iteration are, so it costs no extra wait and no registers across the body.
   __device__ __forceinline__ void produce() {
-    if (lig < SB) {
-      uint32_t v = pa;
-      if (ptw) {
-        const uint32_t y = (pa & 0x80000000u) | (pb & 0x7fffffffu);
-        v = pc ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    if (lig < NL) {
+      const uint32_t nx[4] = {pa[1], pa[2], pa[3], pb};
+      uint32_t v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = pa[j];
+        if (ptw) {
+          const uint32_t y = (pa[j] & 0x80000000u) | (nx[j] & 0x7fffffffu);
+          v[j] = pc[j] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        ring[(prod + (uint32_t)(4 * lig + j)) & (RING - 1)] = mt_temper(v[j]);
       }
-      ring[(prod + (uint32_t)lig) & (RING - 1)] = mt_temper(v);
-      sval = v;
-      sold = pa;
+      if (ptw) {
+        const int sidx = (int)(prod % 624u) + 4 * lig;
+        *reinterpret_cast<uint4*>(st() + sidx) = make_uint4(v[0], v[1], v[2], v[3]);
+        // a block of the generation after the one being consumed: keep the old words (sidx < RING
+        // <= 32: production runs at most RING words ahead of consumption)
+        if ((prod / 624u) > gen_of_cons())
+          *reinterpret_cast<uint4*>(shadow() + sidx) = make_uint4(pa[0], pa[1], pa[2], pa[3]);
+      }
     }
-    if (ptw) {
-      sv = true;
-      sidx = (int)(prod % 624u) + lig;
-      ssave = (prod / 624u) > gen_of_cons();
-      tw = prod + SB;
-    }
+    if (ptw) tw = prod + SB;
     prod += SB;
     pend = false;
-  }
-  __device__ __forceinline__ void store_phase() {
-    if (sv) {
-      if (lig < SB) {
-        st()[sidx] = sval;
-        if (ssave) shadow()[sidx] = sold;  // sidx < RING here: at most RING words ahead of a boundary
-      }
-      sv = false;
-    }
   }
   __device__ __forceinline__ bool room() const { return !pend && (prod - cons) + SB <= (uint32_t)RING; }
 
   __device__ __forceinline__ void init(const Params& P, int64_t r, lds_vu32* ring_, int mti, int mtw,
                                        int lig_) {
     mt_base = P.mt; sh_base = P.mtshadow; r32 = (uint32_t)r; ring = ring_; lig = lig_;
-    pend = false; sv = false; ssave = false; ptw = false;
-    pa = pb = pc = sval = sold = 0; sidx = 0;
+    pend = false; ptw = false;
+    pb = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pa[j] = pc[j] = 0;
     if (mti >= 624) { cons = 624; tw = 624; } else { cons = (uint32_t)mti; tw = (uint32_t)mtw; }
     prod = cons & ~(uint32_t)(SB - 1);
     while (room()) {  // synchronous prologue fill
       request();
       produce();
-      store_phase();
     }
   }
   __device__ __forceinline__ uint32_t next() {
@@ -147,7 +157,6 @@ struct Rng {
     if (cons == prod) {
       if (!pend) request();
       produce();
-      store_phase();
     }
     return next();
   }
@@ -164,7 +173,6 @@ struct Rng {
   // leave (state array, mti, mtw) exactly as libstdc++ would hold them after `cons` draws
   __device__ __forceinline__ void finish(int& mti, int& mtw) {
     if (pend) produce();  // inputs already requested: completing the block keeps `tw` consistent
-    store_phase();
     const uint32_t g = gen_of_cons();
     mti = (int)(cons - 624u * g);
     if (tw > 624u * (g + 1u)) {
@@ -220,6 +228,26 @@ struct ColdState {
   uint32_t jmin, n_impr, n_full, n_rpick;
 };
 typedef TNCO_LDS volatile ColdState lds_cold;
+
+// Stage timing (diagnostic builds only, -DTNCO_PROFILE): shader cycles between five points of the
+// loop body, accumulated per replica into ReplicaState::pad1 (tnco_hip_get_stage_cycles).
+#ifdef TNCO_PROFILE
+#define TNCO_PROF_DECL unsigned long long pt_[5] = {0, 0, 0, 0, 0}, pa_[5] = {0, 0, 0, 0, 0}
+#define TNCO_PROF_T(i) pt_[i] = __builtin_amdgcn_s_memtime()
+#define TNCO_PROF_ACC                                            \
+  do {                                                           \
+    pa_[0] += pt_[1] - pt_[0]; pa_[1] += pt_[2] - pt_[1];        \
+    pa_[2] += pt_[3] - pt_[2]; pa_[3] += pt_[4] - pt_[3];        \
+    pa_[4] += 1;                                                 \
+  } while (0)
+#define TNCO_PROF_OUT(rs) \
+  for (int k_ = 0; k_ < 5; ++k_) (rs)->pad1[k_] += pa_[k_]
+#else
+#define TNCO_PROF_DECL
+#define TNCO_PROF_T(i)
+#define TNCO_PROF_ACC
+#define TNCO_PROF_OUT(rs)
+#endif
 
 template <int LOG2L, int K, bool HYPER, bool GENERIC>
 __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
@@ -279,10 +307,13 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
   int step = 0;
   int state = S_BEGIN;
 
+  TNCO_PROF_DECL;
   for (;;) {
+    TNCO_PROF_T(0);
     // ======================= issue / consume: mt19937 ========================
     if (rng.pend) rng.produce();
-    if (rng.room()) rng.request();
+    else if (rng.room()) rng.request();
+    TNCO_PROF_T(1);
 
     // staging registers of a MOVE (declared here so that the fence below can name them)
     int nnL = -1, nnR = -1, nnP = -1;
@@ -479,6 +510,7 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
       x_al = al; x_ar = ar; x_aP = aP; x_ccA = ccA; x_partA = partA; x_mBnow = mBnow; x_mX = mX; x_pCcur = pCcur;
     }
 
+    TNCO_PROF_T(2);
     // ======================= landing fence ===================================
     // Everything requested above is needed before the first store below: vmcnt is in order, so
     // waiting for these loads later would also wait for the stores.
@@ -496,10 +528,12 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
         TNCO_LANDED(iAn.w[k]); TNCO_LANDED(hAn.w[k]);
       }
     }
-    TNCO_LANDED(rng.pa); TNCO_LANDED(rng.pb); TNCO_LANDED(rng.pc);
+    TNCO_LANDED(rng.pb);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { TNCO_LANDED(rng.pa[j]); TNCO_LANDED(rng.pc[j]); }
 
+    TNCO_PROF_T(3);
     // ======================= store phase =====================================
-    rng.store_phase();
     if (did_move && acc) {
       if (!jinvalid) {
         if (jtail == jcap) {
@@ -525,6 +559,8 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
       if constexpr (HYPER) v.set_hyper(stB, stH);  // may also have changed one level below
       if (state < 0) break;
     }
+    TNCO_PROF_T(4);
+    TNCO_PROF_ACC;
     if (did_move) {
       // :191  B <- A, carrying what is already known about A's children
       if (b_is_left_of_a) { m0 = x_mBnow; p0 = stPart; m1 = x_mX; p1 = x_pCcur; }
@@ -554,6 +590,7 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
     rs->n_randpick += cold.n_rpick;
     rs->mti = mti;
     rs->mtw = mtw;
+    TNCO_PROF_OUT(rs);
   }
 }
 

@@ -990,6 +990,16 @@ int tnco_hip_get_full_copies(tnco_hip_handle h, uint64_t* n) {
   return TNCO_HIP_OK;
 }
 
+int tnco_hip_get_stage_cycles(tnco_hip_handle h, uint64_t* out5) {
+  if (!h || !out5) return fail(TNCO_HIP_EINVAL, "null argument.");
+  std::vector<ReplicaState> rs;
+  if (int rc = fetch_rs(h, rs)) return rc;
+  for (int k = 0; k < 5; ++k) out5[k] = 0;
+  for (auto& x : rs)
+    for (int k = 0; k < 5; ++k) out5[k] += x.pad1[k];
+  return TNCO_HIP_OK;
+}
+
 int tnco_hip_get_moves(tnco_hip_handle h, uint64_t* out) {
   if (!h || !out) return fail(TNCO_HIP_EINVAL, "null argument.");
   std::vector<ReplicaState> rs;

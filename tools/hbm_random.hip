@@ -1,0 +1,115 @@
+// hbm_random.hip -- what does MI355X HBM deliver for the access pattern of the sweep kernel?
+//
+// The kernel touches, per move, a few RANDOM 128-byte node blocks of a multi-GB working set (no
+// reuse: 65536 replicas x ~70 KB); each block is accessed by the 4 lanes of one replica group.
+// This microbenchmark issues exactly that: groups of 4 lanes read (and optionally write back) random
+// GRAIN-byte pieces (32 / 64 / 128 B, naturally aligned) of a large buffer, many independent requests
+// in flight, full occupancy.  The GB/s it reaches is the practical roofline for the pattern, to set
+// beside the 8 TB/s streaming peak used in bench.py's `roofline` object.
+//
+//   hipcc -O3 --offload-arch=gfx950 -o hbm_random tools/hbm_random.hip && ./hbm_random
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CHECK(x)                                                                     \
+  do {                                                                               \
+    hipError_t e_ = (x);                                                             \
+    if (e_ != hipSuccess) {                                                          \
+      fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_));      \
+      exit(1);                                                                       \
+    }                                                                                \
+  } while (0)
+
+__device__ __forceinline__ uint64_t mix(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
+  x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
+  x ^= x >> 33;
+  return x;
+}
+
+// GRAIN bytes per group access, 4 lanes per group -> GRAIN/4 bytes per lane (8, 16 or 32).
+// MODE 0: read only; 1: read then write the same piece back; 2: write only.
+template <int GRAIN, int MODE, int UNROLL>
+__global__ __launch_bounds__(256) void rnd_kernel(uint8_t* buf, uint64_t n_grains, int iters, uint64_t* sink) {
+  const int lane = threadIdx.x & 3;
+  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  constexpr int BPL = GRAIN / 4;  // bytes per lane
+  constexpr int WPL = BPL / 8;    // 64-bit words per lane
+  uint64_t acc = 0;
+  for (int it = 0; it < iters; it += UNROLL) {
+    uint64_t v[UNROLL][WPL > 0 ? WPL : 1];
+    uint64_t* p[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint64_t g = mix(gid * 0x9e3779b97f4a7c15ull + (uint64_t)(it + u)) % n_grains;
+      p[u] = reinterpret_cast<uint64_t*>(buf + g * GRAIN + lane * BPL);
+      if (MODE != 2) {
+#pragma unroll
+        for (int w = 0; w < WPL; ++w) v[u][w] = p[u][w];
+      } else {
+#pragma unroll
+        for (int w = 0; w < WPL; ++w) v[u][w] = g + w;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+#pragma unroll
+      for (int w = 0; w < WPL; ++w) {
+        acc += v[u][w];
+        if (MODE != 0) p[u][w] = v[u][w] + 1;
+      }
+    }
+  }
+  if (acc == 0x1234567) sink[0] = acc;
+}
+
+template <int GRAIN, int MODE, int UNROLL>
+static void run(uint8_t* buf, size_t bytes, uint64_t* sink, int waves_per_simd) {
+  const int blocks = 256 * waves_per_simd;  // 256 CUs x (4 waves per block = 1 per SIMD) x waves_per_simd
+  const int iters = 2048;
+  hipEvent_t a, b;
+  CHECK(hipEventCreate(&a));
+  CHECK(hipEventCreate(&b));
+  const uint64_t n_grains = bytes / GRAIN;
+  rnd_kernel<GRAIN, MODE, UNROLL><<<blocks, 256>>>(buf, n_grains, 64, sink);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(a));
+  rnd_kernel<GRAIN, MODE, UNROLL><<<blocks, 256>>>(buf, n_grains, iters, sink);
+  CHECK(hipEventRecord(b));
+  CHECK(hipEventSynchronize(b));
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, a, b));
+  const double groups = (double)blocks * 64;
+  const double acc = groups * iters;
+  const double bytes_moved = acc * GRAIN * (MODE == 1 ? 2 : 1);
+  printf("grain %3d B  %-10s  in-flight/group %d  waves/SIMD %d : %7.1f G accesses/s  %8.1f GB/s\n", GRAIN,
+         MODE == 0 ? "read" : (MODE == 1 ? "read+write" : "write"), UNROLL, waves_per_simd, acc / ms * 1e-6,
+         bytes_moved / ms * 1e-6);
+}
+
+int main(int argc, char** argv) {
+  size_t gib = argc > 1 ? (size_t)atoi(argv[1]) : 8;
+  size_t bytes = gib << 30;
+  uint8_t* buf;
+  uint64_t* sink;
+  CHECK(hipMalloc(&buf, bytes));
+  CHECK(hipMalloc(&sink, 64));
+  CHECK(hipMemset(buf, 1, bytes));
+  printf("working set %zu GiB, groups of 4 lanes, random naturally aligned pieces\n", gib);
+  for (int w : {3, 8}) {
+    run<128, 0, 4>(buf, bytes, sink, w);
+    run<128, 0, 8>(buf, bytes, sink, w);
+    run<64, 0, 8>(buf, bytes, sink, w);
+    run<32, 0, 8>(buf, bytes, sink, w);
+    run<128, 1, 4>(buf, bytes, sink, w);
+    run<128, 2, 8>(buf, bytes, sink, w);
+    run<32, 1, 8>(buf, bytes, sink, w);
+    run<32, 2, 8>(buf, bytes, sink, w);
+  }
+  // streaming reference: same kernel shape, consecutive grains
+  CHECK(hipFree(buf));
+  CHECK(hipFree(sink));
+  return 0;
+}

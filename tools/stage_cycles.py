@@ -1,0 +1,51 @@
+"""Where do the cycles of one loop iteration of the sweep kernel go?  Needs a library built with
+-DTNCO_PROFILE (make -C tnco_amd/csrc profile -> build_variants/lib_profile.so):
+
+    TNCO_HIP_LIB=$PWD/build_variants/lib_profile.so python tools/stage_cycles.py
+"""
+import argparse
+import ctypes as C
+import sys
+import pathlib
+
+import numpy as np
+
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+from tnco_amd import _lib, core, ctree, synthetic  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--leaves", type=int, default=512)
+    ap.add_argument("--replicas", type=int, default=65536)
+    ap.add_argument("--sweeps", type=int, default=100)
+    a = ap.parse_args()
+    ts, dims, out = synthetic.random_regular_tn(a.leaves, 3, 0)
+    n_inds = 1 + max(i for xs in ts for i in xs)
+    lm = ctree.pack_masks(ts, n_inds)
+    seeds = np.arange(1, a.replicas + 1, dtype=np.uint32)
+    links = core.random_trees(ts, n_inds, seeds)
+    opt = core.BatchedOptimizer(lm, links, seeds, n_inds=n_inds)
+    betas = np.linspace(0, 100, a.sweeps)
+    opt.run(betas[:5])
+    L = _lib.load()
+    base = np.zeros(5, np.uint64)
+    L.tnco_hip_get_stage_cycles(opt._h, base.ctypes.data_as(C.c_void_p))
+    m0 = opt.counters()["moves"]
+    opt.run(betas)
+    opt.sync()
+    cyc = np.zeros(5, np.uint64)
+    L.tnco_hip_get_stage_cycles(opt._h, cyc.ctypes.data_as(C.c_void_p))
+    cyc = (cyc - base).astype(np.float64)
+    moves = opt.counters()["moves"] - m0
+    it = cyc[4]
+    names = ["mt19937", "state branches", "landing fence", "store phase"]
+    tot = cyc[:4].sum()
+    print(f"replica-iterations {it:.3e}  moves {moves:.3e}  moves/iteration {moves / it:.3f}")
+    for k in range(4):
+        print(f"  {names[k]:16s} {cyc[k] / it:9.1f} cycles/iteration  {100 * cyc[k] / tot:5.1f} %")
+    print(f"  total            {tot / it:9.1f} cycles/iteration (s_memtime ticks)")
+
+
+if __name__ == "__main__":
+    main()
