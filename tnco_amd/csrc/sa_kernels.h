@@ -158,6 +158,20 @@ struct View {
     }
     return r;
   }
+  // Same value as mask(x), as ONE load sequence for leaves and internal nodes (the address is
+  // selected, not the result): the destination registers have a single definition, so nothing has
+  // to read them -- and wait for them -- before the landing fence of the sweep kernel.
+  __device__ __forceinline__ Mask<K> mask_staged(int x) const {
+    const bool leaf = x < n;
+    const uint64_t* s = leaf ? leafmask + (int64_t)x * LK : words(x);
+    Mask<K> r;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      r.w[k] = 0ull;
+      if (leaf || widx(k) < W) r.w[k] = s[widx(k)];
+    }
+    return r;
+  }
   __device__ __forceinline__ void set_mask(int p, const Mask<K>& v) const {
     uint64_t* s = words(p);
 #pragma unroll

@@ -72,7 +72,9 @@ struct Rng {
   bool pend, ptw;          // a block's inputs are in flight (for virtual position prod); it needs a twist
   // this lane's inputs: mt[k..k+3], mt[k+4], mt[k+397..k+400] (indices mod 624); written ONLY by
   // the loads of request(), so that the loads land directly in these registers
-  uint32_t pa[4], pb, pc[4];
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 pa;                // one 128-bit register tuple: the dwordx4 load lands in place
+  uint32_t pb, pc[4];
 
   __device__ __forceinline__ uint32_t gen_of_cons() const { return cons == 0 ? 0u : (cons - 1u) / 624u; }
 
@@ -85,8 +87,7 @@ struct Rng {
     if (lig < NL) {
       const int k = (int)k0 + 4 * lig;
       const uint32_t* s = st();
-      const uint4 a = *reinterpret_cast<const uint4*>(s + k);
-      pa[0] = a.x; pa[1] = a.y; pa[2] = a.z; pa[3] = a.w;
+      pa = *reinterpret_cast<const u32x4*>(s + k);
       if (ptw) {
         pb = s[(k + 4 == 624) ? 0 : k + 4];
         if (k == 224) {  // 224 + 397 = 621: the only group of 4 that straddles the wrap
@@ -137,8 +138,9 @@ struct Rng {
     mt_base = P.mt; sh_base = P.mtshadow; r32 = (uint32_t)r; ring = ring_; lig = lig_;
     pend = false; ptw = false;
     pb = 0;
+    pa = (u32x4)(0u);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) pa[j] = pc[j] = 0;
+    for (int j = 0; j < 4; ++j) pc[j] = 0;
     if (mti >= 624) { cons = 624; tw = 624; } else { cons = (uint32_t)mti; tw = (uint32_t)mtw; }
     prod = cons & ~(uint32_t)(SB - 1);
     while (room()) {  // synchronous prologue fill
@@ -220,7 +222,7 @@ __device__ __forceinline__ bool accept_move(int kind, double beta, double delta,
 #ifndef TNCO_WAVES_PER_SIMD
 #define TNCO_WAVES_PER_SIMD 3
 #endif
-enum : int { S_BEGIN = 0, S_GOT_B = 1, S_GOT_HB = 2, S_GOT_HA = 3, S_MOVE = 4, S_END = 5 };
+enum : int { S_BEGIN = 0, S_GOT_B = 1, S_GOT_HB = 2, S_GOT_B1 = 3, S_GOT_HA = 4, S_MOVE = 5, S_END = 6 };
 
 // Rarely touched per-replica state lives in LDS, not in registers (VGPRs bound the occupancy).
 struct ColdState {
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
   double ccB = 0, partB = 0, total = 0, beta = 0;
   M m0 = mzero<K>(), m1 = mzero<K>(), iB = mzero<K>(), hB = mzero<K>();
   double p0 = 0, p1 = 0;
-  // ---- staged operands ------------------------------------------------------
+  // ---- operands of the coming moves (landed in earlier iterations) -----------
   int raL = -1, raR = -1, raP = -1;  // header of A
   double raC = 0;
   int rnL = -1, rnR = -1, rnP = -1;  // header of parent(A)
@@ -310,18 +312,15 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
   TNCO_PROF_DECL;
   for (;;) {
     TNCO_PROF_T(0);
-    // ======================= issue / consume: mt19937 ========================
+    // ======================= mt19937: consume what landed =====================
+    // (the next block is requested further down, with the other loads: registers are tracked per
+    // wave, not per lane -- a block requested by one replica AHEAD of another replica's produce()
+    // in program order would make that produce() wait for it)
     if (rng.pend) rng.produce();
-    else if (rng.room()) rng.request();
     TNCO_PROF_T(1);
 
-    // staging registers of a MOVE (declared here so that the fence below can name them)
-    int nnL = -1, nnR = -1, nnP = -1;
-    double nnC = 0;
-    M mCn = mzero<K>(), iAn = mzero<K>(), hAn = mzero<K>();
-    double pCn = 0;
     // what the store phase needs
-    bool acc = false, did_move = false, did_end = false, b_is_left_of_a = false;
+    bool acc = false, did_move = false, did_end = false, improved = false, b_is_left_of_a = false;
     int stB = 0, stA = -1, stC = 0, stE = 0, stL = 0, stR = 0;
     double stCC = 0, stPart = 0;
     M stH = mzero<K>();
@@ -358,74 +357,78 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
           jinvalid = false;
           if (lane0) cold.n_full = cold.n_full + 1;
         }
-        if (lane0) cold.jmin = jtail;
+        improved = true;  // cold.jmin = jtail: in the store phase (nothing may read jtail's register here)
       }
       ++step;
       state = (step >= nsteps32) ? -1 : S_BEGIN;
     }
+
+    // ======================= what does each replica need next? ================
+    // Every state asks for at most: one node header (hN), the legs + partial cost of one node
+    // (x1), 8 bytes from anywhere (xa) and, with hyper-indices, the own + hyper legs of one node
+    // (yN).  Only addresses are decided per state; the loads below are one sequence for all.
+    int hN = -1, x1 = -1, yN = -1;
+    const uint32_t* xa = nullptr;
     if (state == S_BEGIN) {
-      // optimizer.hpp:103-107
-      beta = betas[step];
+      // optimizer.hpp:103-107: a random leaf; its parent is B
       const uint32_t x = rng.next();
-      const int leaf = (int)(x % (uint32_t)n);
-      B = lpar()[leaf];
-      state = S_GOT_B;
+      xa = reinterpret_cast<const uint32_t*>(lpar() + (int)(x % (uint32_t)n));
     } else if (state == S_GOT_B) {
-      const NodeRec rb = *v.hdr(B);
-      bl = rb.left; br = rb.right; A = rb.parent; ccB = rb.ccost; partB = rb.partial;
-      state = S_GOT_HB;
+      hN = B;
+      xa = reinterpret_cast<const uint32_t*>(betas + step);
     } else if (state == S_GOT_HB) {
-      // optimizer.hpp:112 and the operands of the first move
-      total = v.hdr(N - 1)->partial;
-      m0 = v.mask(bl);
-      m1 = v.mask(br);
-      p0 = v.partial(bl);
-      p1 = v.partial(br);
-      if constexpr (HYPER) {
-        iB = v.mask(B);
-        hB = v.hyper(B);
-      }
-      if (A >= 0) {
-        const NodeRec ra = *v.hdr(A);
-        raL = ra.left; raR = ra.right; raP = ra.parent; raC = ra.ccost;
-        state = S_GOT_HA;
-      } else {
-        state = S_END;
-      }
+      x1 = bl;
+      hN = A;
+      yN = B;
+      xa = reinterpret_cast<const uint32_t*>(&v.hdr(N - 1)->partial);  // optimizer.hpp:112
+    } else if (state == S_GOT_B1) {
+      x1 = br;
+      if (A >= 0) { hN = raP; yN = A; }
     } else if (state == S_GOT_HA) {
-      const int C = (raL == B) ? raR : raL;
-      mC = v.mask(C);
-      pC = v.partial(C);
-      if constexpr (HYPER) {
-        iA = v.mask(A);
-        hA = v.hyper(A);
-      }
-      if (raP >= 0) {
-        const NodeRec rn = *v.hdr(raP);
-        rnL = rn.left; rnR = rn.right; rnP = rn.parent; rnC = rn.ccost;
-      }
-      state = S_MOVE;
+      x1 = (raL == B) ? raR : raL;  // C, the sibling of B
     } else if (state == S_MOVE) {
-      // ---- stage the NEXT move's operands -----------------------------------
+      if (raP >= 0) {
+        x1 = (rnL == A) ? rnR : rnL;  // the sibling of A: C of the next move
+        hN = rnP;
+        yN = raP;
+      }
+    }
+
+    // ======================= requests (staging registers) ====================
+    // Nothing below reads these registers before the landing fence.
+    int gL = -1, gR = -1, gP = -1;
+    double gC = 0, gPart = 0;
+    if (hN >= 0) {
+      const NodeRec* q = v.hdr(hN);
+      gL = q->left; gR = q->right; gP = q->parent; gC = q->ccost; gPart = q->partial;
+    }
+    M gM = mzero<K>();
+    double gMp = 0;
+    if (x1 >= 0) {
+      gM = v.mask_staged(x1);
+      if (x1 >= n) gMp = v.hdr(x1)->partial;
+    }
+    uint32_t gXlo = 0, gXhi = 0;
+    if (xa != nullptr) {
+      gXlo = xa[0];
+      gXhi = xa[1];
+    }
+    M gI = mzero<K>(), gH = mzero<K>();
+    if constexpr (HYPER) {
+      if (yN >= 0) {
+        gI = v.mask_staged(yN);
+        gH = v.hyper(yN);
+      }
+    }
+    if (rng.room()) rng.request();
+
+    if (state == S_MOVE) {
       did_move = true;
       int al = raL, ar = raR;
       const int aP = raP;
       double ccA = raC;
       const bool c_is_right = (al == B);
       const int C = c_is_right ? ar : al;
-      if (aP >= 0) {
-        const int Cn = (rnL == A) ? rnR : rnL;
-        if (rnP >= 0) {
-          const NodeRec nn = *v.hdr(rnP);
-          nnL = nn.left; nnR = nn.right; nnP = nn.parent; nnC = nn.ccost;
-        }
-        mCn = v.mask(Cn);
-        pCn = v.partial(Cn);
-        if constexpr (HYPER) {
-          iAn = v.mask(aP);
-          hAn = v.hyper(aP);
-        }
-      }
 
       // ---- one move evaluation (optimizer.hpp:117-192) -----------------------
       const M hy = HYPER ? mor<K>(hA, hB) : mzero<K>();
@@ -514,23 +517,17 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
     // ======================= landing fence ===================================
     // Everything requested above is needed before the first store below: vmcnt is in order, so
     // waiting for these loads later would also wait for the stores.
-    TNCO_LANDED(B);
-    TNCO_LANDED(bl); TNCO_LANDED(br); TNCO_LANDED(A); TNCO_LANDED(ccB); TNCO_LANDED(partB);
-    TNCO_LANDED(total); TNCO_LANDED(p0); TNCO_LANDED(p1); TNCO_LANDED(pC);
-    TNCO_LANDED(raL); TNCO_LANDED(raR); TNCO_LANDED(raP); TNCO_LANDED(raC);
-    TNCO_LANDED(rnL); TNCO_LANDED(rnR); TNCO_LANDED(rnP); TNCO_LANDED(rnC);
-    TNCO_LANDED(nnL); TNCO_LANDED(nnR); TNCO_LANDED(nnP); TNCO_LANDED(nnC); TNCO_LANDED(pCn);
+    TNCO_LANDED(gL); TNCO_LANDED(gR); TNCO_LANDED(gP); TNCO_LANDED(gC); TNCO_LANDED(gPart);
+    TNCO_LANDED(gMp); TNCO_LANDED(gXlo); TNCO_LANDED(gXhi);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      TNCO_LANDED(m0.w[k]); TNCO_LANDED(m1.w[k]); TNCO_LANDED(mC.w[k]); TNCO_LANDED(mCn.w[k]);
-      if constexpr (HYPER) {
-        TNCO_LANDED(iB.w[k]); TNCO_LANDED(hB.w[k]); TNCO_LANDED(iA.w[k]); TNCO_LANDED(hA.w[k]);
-        TNCO_LANDED(iAn.w[k]); TNCO_LANDED(hAn.w[k]);
-      }
+      TNCO_LANDED(gM.w[k]);
+      if constexpr (HYPER) { TNCO_LANDED(gI.w[k]); TNCO_LANDED(gH.w[k]); }
     }
     TNCO_LANDED(rng.pb);
+    TNCO_LANDED(rng.pa);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { TNCO_LANDED(rng.pa[j]); TNCO_LANDED(rng.pc[j]); }
+    for (int j = 0; j < 4; ++j) TNCO_LANDED(rng.pc[j]);
 
     TNCO_PROF_T(3);
     // ======================= store phase =====================================
@@ -557,22 +554,46 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
         *v.hdr(stB) = o;
       }
       if constexpr (HYPER) v.set_hyper(stB, stH);  // may also have changed one level below
+      if (improved && lane0) cold.jmin = jtail;
       if (state < 0) break;
     }
     TNCO_PROF_T(4);
     TNCO_PROF_ACC;
+
+    // ======================= what landed goes where ==========================
     if (did_move) {
       // :191  B <- A, carrying what is already known about A's children
       if (b_is_left_of_a) { m0 = x_mBnow; p0 = stPart; m1 = x_mX; p1 = x_pCcur; }
       else                { m1 = x_mBnow; p1 = stPart; m0 = x_mX; p0 = x_pCcur; }
       B = stA; bl = x_al; br = x_ar; ccB = x_ccA; partB = x_partA;
-      if constexpr (HYPER) { iB = iA; hB = hA; iA = iAn; hA = hAn; }
+      if constexpr (HYPER) { iB = iA; hB = hA; iA = gI; hA = gH; }
       A = x_aP;
       raL = rnL; raR = rnR; raP = rnP; raC = rnC;
-      rnL = nnL; rnR = nnR; rnP = nnP; rnC = nnC;
-      mC = mCn;
-      pC = pCn;
+      rnL = gL; rnR = gR; rnP = gP; rnC = gC;
+      mC = gM;
+      pC = gMp;
       state = (A < 0) ? S_END : S_MOVE;
+    } else if (state == S_BEGIN) {
+      B = (int)gXlo;
+      state = S_GOT_B;
+    } else if (state == S_GOT_B) {
+      bl = gL; br = gR; A = gP; ccB = gC; partB = gPart;
+      beta = __hiloint2double((int)gXhi, (int)gXlo);
+      state = S_GOT_HB;
+    } else if (state == S_GOT_HB) {
+      m0 = gM; p0 = gMp;
+      total = __hiloint2double((int)gXhi, (int)gXlo);
+      raL = gL; raR = gR; raP = gP; raC = gC;
+      if constexpr (HYPER) { iB = gI; hB = gH; }
+      state = S_GOT_B1;
+    } else if (state == S_GOT_B1) {
+      m1 = gM; p1 = gMp;
+      rnL = gL; rnR = gR; rnP = gP; rnC = gC;
+      if constexpr (HYPER) { iA = gI; hA = gH; }
+      state = (A < 0) ? S_END : S_GOT_HA;
+    } else if (state == S_GOT_HA) {
+      mC = gM; pC = gMp;
+      state = S_MOVE;
     }
   }
 

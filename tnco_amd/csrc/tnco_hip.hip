@@ -496,7 +496,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   }
 
   HIP_TRY(h->alloc(&P.blocks, R * h->block_bytes()));
-  HIP_TRY(h->alloc(&P.lpar, R * n));
+  HIP_TRY(h->alloc(&P.lpar, R * n + 16));  // the sweep kernel reads 8 bytes at lpar[leaf]
   HIP_TRY(h->alloc(&P.mt, R * 624));
   HIP_TRY(h->alloc(&P.mtshadow, R * 32));
   HIP_TRY(h->alloc(&P.rs, R));
