@@ -80,7 +80,8 @@ def main() -> None:
     ap.add_argument("--leaves", type=int, default=512)
     ap.add_argument("--replicas", type=int, default=65536, help="replicas per GPU")
     ap.add_argument("--graph-seed", type=int, default=11)
-    ap.add_argument("--cpu-sample", type=int, default=4096, help="replicas timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1,
+                    help="replicas timed on the CPU oracle (0 = skip, -1 = as many as take ~15 s)")
     ap.add_argument("--validate", action="store_true", help="device-side is_valid() of every replica after the run")
     args = ap.parse_args()
 
@@ -206,9 +207,14 @@ def main() -> None:
                 "launches": launches,
             },
         }
-        if args.cpu_sample > 0:
+        if args.cpu_sample != 0 and world == 1:
             cores = usable_cores()
-            ns = min(args.cpu_sample, R)
+            if args.cpu_sample > 0:
+                ns = min(args.cpu_sample, R)
+            else:  # auto: a probe sets the sample so that the timed run is ~15 s of CPU work
+                probe = min(256, R)
+                pv, pm, _pt, _ = cpu_baseline(prob, links, seeds, betas, probe, cores)
+                ns = int(min(R, max(probe, 15.0 * pv / (pm / probe))))
             v, m, t, cpu_min = cpu_baseline(prob, links, seeds, betas, ns, cores)
             gpu_min = opt.costs()[1][:ns]
             out["config"]["cpu_sample_min_cost_bit_exact"] = bool(np.array_equal(cpu_min, gpu_min))

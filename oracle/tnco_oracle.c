@@ -1117,30 +1117,40 @@ double PFX(run_batch)(int64_t R, int32_t n_leaves, int32_t n_inds, const int32_t
                       const uint32_t* seeds, int prob_kind, const double* betas, int64_t n_steps,
                       int n_threads, double* out_total, double* out_min, uint64_t* out_moves) {
   const int32_t N = 2 * n_leaves - 1, W = (n_inds + 63) / 64 > 0 ? (n_inds + 63) / 64 : 1;
-  PFX(state_t)** st = (PFX(state_t)**)calloc((size_t)R, sizeof(void*));
+  /* chunks of CHUNK replicas: bounded memory (a state is ~0.3 MB at 512 leaves) however large the
+   * sample; only the update loops are timed */
+  enum { CHUNK = 2048 };
+  PFX(state_t)** st = (PFX(state_t)**)calloc((size_t)CHUNK, sizeof(void*));
   if (n_threads > 0) omp_set_num_threads(n_threads);
+  double dt = 0;
+  for (int64_t r0 = 0; r0 < R; r0 += CHUNK) {
+    const int64_t cnt = (R - r0 < CHUNK) ? R - r0 : CHUNK;
 #pragma omp parallel for schedule(dynamic, 1)
-  for (int64_t r = 0; r < R; ++r) {
-    const int32_t* lk = links + r * 3 * (int64_t)N;
-    uint64_t* inds = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)N * W);
-    orc_derive_inds(N, W, lk, lk + N, leaf_masks, output_mask, inds);
-    int status = 0;
-    st[r] = PFX(create)(n_leaves, n_inds, lk, lk + N, lk + 2 * (int64_t)N, inds, dim_uniform, NULL, NULL, 0, 0,
-                        seeds[r], NULL, &status);
-    free(inds);
-    if (status) { PFX(destroy)(st[r]); st[r] = NULL; }
-  }
-  const double t0 = omp_get_wtime();
+    for (int64_t i = 0; i < cnt; ++i) {
+      const int64_t r = r0 + i;
+      const int32_t* lk = links + r * 3 * (int64_t)N;
+      uint64_t* inds = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)N * W);
+      orc_derive_inds(N, W, lk, lk + N, leaf_masks, output_mask, inds);
+      int status = 0;
+      st[i] = PFX(create)(n_leaves, n_inds, lk, lk + N, lk + 2 * (int64_t)N, inds, dim_uniform, NULL, NULL, 0, 0,
+                          seeds[r], NULL, &status);
+      free(inds);
+      if (status) { PFX(destroy)(st[i]); st[i] = NULL; }
+    }
+    const double t0 = omp_get_wtime();
 #pragma omp parallel for schedule(dynamic, 1)
-  for (int64_t r = 0; r < R; ++r)
-    if (st[r]) PFX(run)(st[r], prob_kind, betas, n_steps);
-  const double dt = omp_get_wtime() - t0;
-  for (int64_t r = 0; r < R; ++r) {
-    if (!st[r]) { if (out_total) out_total[r] = -1; continue; }
-    if (out_total) out_total[r] = (double)st[r]->partial[N - 1];
-    if (out_min) out_min[r] = (double)st[r]->min_total_cost;
-    if (out_moves) out_moves[r] = st[r]->n_moves;
-    PFX(destroy)(st[r]);
+    for (int64_t i = 0; i < cnt; ++i)
+      if (st[i]) PFX(run)(st[i], prob_kind, betas, n_steps);
+    dt += omp_get_wtime() - t0;
+    for (int64_t i = 0; i < cnt; ++i) {
+      const int64_t r = r0 + i;
+      if (!st[i]) { if (out_total) out_total[r] = -1; continue; }
+      if (out_total) out_total[r] = (double)st[i]->partial[N - 1];
+      if (out_min) out_min[r] = (double)st[i]->min_total_cost;
+      if (out_moves) out_moves[r] = st[i]->n_moves;
+      PFX(destroy)(st[i]);
+      st[i] = NULL;
+    }
   }
   free(st);
   return dt;

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwPa
   const bool lane0 = lig == 0;
   const int n = P.n, N = P.N;
   View<LOG2L, K, HYPER> v;
-  v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n, lig);
+  v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n * LPS, lig);
   ReplicaState* rs = P.rs + r;
   R rng;
   rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
   const int n = P.n, N = P.N;
   const int f32 = P.f32;
   View<LOG2L, K, HYPER> v;
-  v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n, lig);
+  v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n * LPS, lig);
   ReplicaState* rs = P.rs + r;
   R rng;
   rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
     const double beta = betas[step];
     // :130-139
     const int leaf = (int)(rng.next_sync() % (uint32_t)n);
-    int B = v.lpar[leaf];
+    int B = v.parent(leaf);
     double total = v.hdr(N - 1)->partial;
     for (;;) {
       // get_ctree_nn, optimize/optimizer.hpp:112-144

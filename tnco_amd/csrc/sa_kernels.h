@@ -24,6 +24,16 @@
 
 namespace tnco {
 
+// Stride (in int32) of the leaf-parent array.  1: packed int32[n] per replica.  16 (experiment,
+// -DTNCO_LPS=16): every leaf's parent is a 64-byte record of its own, rewritten whole, because HBM
+// writes whole 64-byte pieces and a 4-byte update is a read-modify-write there
+// (tools/hbm_random.hip).  Measured -1.5 % on the 512-leaf workload: the packed array of 65536
+// replicas (128 MiB) lives in the 256-MiB Infinity Cache, the 2-GiB record array does not.
+#ifndef TNCO_LPS
+#define TNCO_LPS 1
+#endif
+constexpr int LPS = TNCO_LPS;
+
 struct __attribute__((aligned(32))) NodeRec {
   int32_t left, right, parent, pad;
   double ccost;    // CostCache::contraction_cost
@@ -55,7 +65,7 @@ struct Params {
   int32_t jcap;              // rotation-log entries per replica
   int64_t R;
   uint8_t* blocks;           // [R][n-1][BS]
-  int32_t* lpar;             // [R][n]        parent of every leaf
+  int32_t* lpar;             // [R][n][LPS]   parent of every leaf (one 64-byte record per leaf)
   uint32_t* mt;              // [R][624]
   uint32_t* mtshadow;        // [R][32]       generation-g words overwritten ahead of consumption
   ReplicaState* rs;          // [R]
@@ -178,6 +188,10 @@ struct View {
     for (int k = 0; k < K; ++k)
       if (widx(k) < W) s[widx(k)] = v.w[k];
   }
+  // words 0..L-1 only (slot 0 of every lane): with the 32-byte header, the first 64 bytes of a block
+  __device__ __forceinline__ void set_mask_first(int p, const Mask<K>& v) const {
+    if (widx(0) < W) words(p)[widx(0)] = v.w[0];
+  }
   __device__ __forceinline__ Mask<K> hyper(int p) const {
     Mask<K> r = mzero<K>();
     if constexpr (HYPER) {
@@ -196,9 +210,21 @@ struct View {
     }
   }
   __device__ __forceinline__ double partial(int x) const { return x < n ? 0.0 : hdr(x)->partial; }
-  __device__ __forceinline__ int parent(int x) const { return x < n ? lpar[x] : hdr(x)->parent; }
+  __device__ __forceinline__ int parent(int x) const { return x < n ? lpar[(int64_t)x * LPS] : hdr(x)->parent; }
   __device__ __forceinline__ void set_parent(int x, int p) const {
-    if (x < n) lpar[x] = p; else hdr(x)->parent = p;
+    if (x < n) lpar[(int64_t)x * LPS] = p; else hdr(x)->parent = p;
+  }
+  // the same, called by ALL lanes of the group: a leaf's whole record is rewritten (16 bytes per lane)
+  __device__ __forceinline__ void set_parent_group(int x, int p) const {
+    if (x < n) {
+      if constexpr (LPS == 16) {
+        if (lig < 4) *reinterpret_cast<int4*>(lpar + (int64_t)x * LPS + 4 * lig) = make_int4(p, p, p, p);
+      } else {
+        if (lig == 0) lpar[(int64_t)x * LPS] = p;
+      }
+    } else if (lig == 0) {
+      hdr(x)->parent = p;
+    }
   }
   __device__ __forceinline__ int left(int x) const { return x < n ? -1 : hdr(x)->left; }
   __device__ __forceinline__ int right(int x) const { return x < n ? -1 : hdr(x)->right; }
@@ -333,7 +359,7 @@ struct BuildArgs {
   const Links* src_links;      // [count][N] or NULL (indexed by q, not r)
   const uint64_t* in_masks; int64_t in_masks_stride;  // optional explicit legs [N][W]
   uint8_t* out_blocks;         // [count][n-1][BS]
-  int32_t* out_lpar;           // [count][n]
+  int32_t* out_lpar;           // [count][n][LPS]
   int32_t* scratch;            // [count][4N]
   double* out_total;           // [count] partial[root]
   double* out_sum;             // [count] get_cost() sum
@@ -357,9 +383,9 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
   const int n = P.n, N = P.N;
 
   View<LOG2L, K, HYPER> v;
-  v.init(P, a.out_blocks + q * (int64_t)(n - 1) * P.BS, a.out_lpar + q * (int64_t)n, lig);
+  v.init(P, a.out_blocks + q * (int64_t)(n - 1) * P.BS, a.out_lpar + q * (int64_t)n * LPS, lig);
   View<LOG2L, K, HYPER> live;
-  live.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n, lig);
+  live.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n * LPS, lig);
   int32_t* stack = a.scratch + q * 4 * (int64_t)N;
   int32_t* order = stack + N;
   int32_t* visited = order + N;
@@ -381,7 +407,7 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
       l = s.left; rr = s.right; p = s.parent;
     }
     if (i < n) {
-      v.lpar[i] = p;
+      v.lpar[(int64_t)i * LPS] = p;
     } else {
       NodeRec o;
       o.left = l; o.right = rr; o.parent = p; o.pad = 0; o.ccost = 0; o.partial = 0;
@@ -495,8 +521,8 @@ __global__ __launch_bounds__(256) void compare_kernel(const Params P, const Buil
   const int64_t r = a.r0 + q;
   const int n = P.n, N = P.N;
   View<LOG2L, K, HYPER> ref, cur;
-  ref.init(P, a.out_blocks + q * (int64_t)(n - 1) * P.BS, a.out_lpar + q * (int64_t)n, lig);
-  cur.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n, lig);
+  ref.init(P, a.out_blocks + q * (int64_t)(n - 1) * P.BS, a.out_lpar + q * (int64_t)n * LPS, lig);
+  cur.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n * LPS, lig);
   int bad = a.out_status[q];
   auto logclose = [&](double x, double y) -> bool {
     if (x < 0 || y < 0) return false;

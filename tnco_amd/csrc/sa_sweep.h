@@ -7,23 +7,30 @@
 // kernel is therefore a per-replica STATE MACHINE in which no load is consumed in the iteration
 // that issues it:
 //
-//     every iteration:   [issue the loads the NEXT iteration needs]
-//                        [work on what landed during the PREVIOUS iteration]
-//                        [landing fence: wait for this iteration's loads]   <- before any store
+//     every iteration:   [per state: decide WHICH node header / node legs / 8 bytes are needed next]
+//                        [one load sequence for all replicas, into staging registers]
+//                        [MOVE replicas: one move evaluation on what landed in EARLIER iterations]
+//                        [landing fence: wait for this iteration's loads]   <- the only wait
 //                        [this iteration's stores]
+//                        [per state: staging registers -> carried state]
 //
-//   states:  BEGIN  draw the leaf, request its parent                     (optimizer.hpp:103)
-//            GOT_B  request the header of B = parent(leaf)                (:107)
-//            GOT_HB request legs / partial costs of B's children, header of A, total cost (:112)
-//            GOT_HA request the block of C (sibling of B) and the header of parent(A)
-//            MOVE   one move evaluation per iteration (:117-192), requesting the operands of the
-//                   next level at its top
-//            END    B is the root: best-tree update (:198-201), then BEGIN of the next sweep
+//   states:  BEGIN   draw the leaf, request its parent B                  (optimizer.hpp:103)
+//            GOT_B   request the header of B                              (:107)
+//            GOT_HB  request legs + partial cost of B's left child, header of A, total cost (:112)
+//            GOT_B1  request legs + partial cost of B's right child, header of parent(A), beta
+//            GOT_HA  request the block of C (sibling of B)
+//            MOVE    one move evaluation per iteration (:117-192), requesting the sibling and the
+//                    grandparent header of the next level
+//            END     B is the root: best-tree update (:198-201), then BEGIN of the next sweep
 //
-// so a replica at the start of a sweep never stalls the other replicas of its wavefront, and the
-// memory latency of every load is covered by one full iteration of work of the whole SIMD.
-// The mt19937 stream is produced the same way: 16-word blocks (4 words per lane) are requested in
-// one iteration, twisted + tempered into an LDS ring in the next, stored in its store phase.
+// Two rules keep the compiler from putting waits anywhere but the fence.  (1) Registers are
+// tracked per wave, not per lane: a load issued for a replica in one state into a register that the
+// code of another state reads later in the same iteration makes that code wait.  So loads only
+// ever target the staging registers, which nothing reads before the fence.  (2) A loaded value
+// must have ONE definition (no merge of "loaded here" and "loaded there"), or the merge copies --
+// and waits -- right after the load: leaf / internal-node legs select the address, not the value.
+// The mt19937 stream is produced the same way: a 16-word block (4 words per lane) is requested
+// with the other loads and twisted + tempered into an LDS ring at the top of a later iteration.
 #pragma once
 #include "sa_kernels.h"
 
@@ -235,7 +242,18 @@ typedef TNCO_LDS volatile ColdState lds_cold;
 // loop body, accumulated per replica into ReplicaState::pad1 (tnco_hip_get_stage_cycles).
 #ifdef TNCO_PROFILE
 #define TNCO_PROF_DECL unsigned long long pt_[5] = {0, 0, 0, 0, 0}, pa_[5] = {0, 0, 0, 0, 0}
+#if TNCO_PROFILE == 2
+// fine split of the "state branches" stage: [end-of-sweep block, addresses, load issue, move]
+#define TNCO_PROF_T(i)                                           \
+  do {                                                           \
+    if ((i) == 1) pt_[0] = __builtin_amdgcn_s_memtime();         \
+    if ((i) == 2) pt_[4] = __builtin_amdgcn_s_memtime();         \
+  } while (0)
+#define TNCO_PROF_F(i) pt_[i] = __builtin_amdgcn_s_memtime()
+#else
 #define TNCO_PROF_T(i) pt_[i] = __builtin_amdgcn_s_memtime()
+#define TNCO_PROF_F(i)
+#endif
 #define TNCO_PROF_ACC                                            \
   do {                                                           \
     pa_[0] += pt_[1] - pt_[0]; pa_[1] += pt_[2] - pt_[1];        \
@@ -247,12 +265,13 @@ typedef TNCO_LDS volatile ColdState lds_cold;
 #else
 #define TNCO_PROF_DECL
 #define TNCO_PROF_T(i)
+#define TNCO_PROF_F(i)
 #define TNCO_PROF_ACC
 #define TNCO_PROF_OUT(rs)
 #endif
 
 template <int LOG2L, int K, bool HYPER, bool GENERIC>
-__global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
+__global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : TNCO_WAVES_PER_SIMD)) void sa_run_kernel(
     const Params P, const double* __restrict__ betas, const int64_t n_steps, const int prob_kind) {
   constexpr int L = 1 << LOG2L;
   constexpr int GPB = 256 >> LOG2L;  // groups (replicas) per block
@@ -260,6 +279,7 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
   using R = Rng<LOG2L>;
   __shared__ uint32_t rngbuf[GPB * R::RING];
   __shared__ ColdState coldbuf[GPB];
+  __shared__ int32_t jbuf[GPB * 16];
 
   const int tid = threadIdx.x;
   const int lig = tid & (L - 1);
@@ -272,7 +292,7 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
   const int n = P.n, N = P.N;
   View<LOG2L, K, HYPER> v;
   v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, nullptr, lig);
-  auto lpar = [&]() -> int32_t* { return P.lpar + r * (int64_t)n; };
+  auto lpar = [&]() -> int32_t* { return P.lpar + r * (int64_t)n * LPS; };
   lds_cold& cold = *((lds_cold*)coldbuf + gib);
 
   R rng;
@@ -289,6 +309,23 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
   const uint32_t jcap = (uint32_t)P.jcap;
   uint32_t jtail = P.rs[r].jtail;
   bool jinvalid = P.rs[r].jinvalid != 0;
+  // The tail of the rotation log is assembled in LDS and written 16 entries at a time: HBM writes
+  // whole 64-byte pieces, a 4-byte append evicted on its own is a read-modify-write there.
+  typedef TNCO_LDS volatile int32_t lds_vi32;
+  auto jb = [&](int i) -> lds_vi32& { return *((lds_vi32*)jbuf + (threadIdx.x >> LOG2L) * 16 + i); };
+  // (recomputed at every use, opaquely: as a loop invariant it would be spilled and its reload
+  // would put a vmcnt(0) wait into the store phase)
+  auto jlog = [&]() -> int32_t* {
+    uint32_t rr = rng.r32;
+    __asm__ volatile("" : "+v"(rr));
+    return P.jlog + (int64_t)rr * (int64_t)P.jcap;
+  };
+  if ((jtail & 15u) != 0u) {
+    for (int q = lig; q < 4; q += L) {
+      const int4 t = *reinterpret_cast<const int4*>(jlog() + (jtail & ~15u) + 4 * q);
+      jb(4 * q + 0) = t.x; jb(4 * q + 1) = t.y; jb(4 * q + 2) = t.z; jb(4 * q + 3) = t.w;
+    }
+  }
   const int f32 = GENERIC ? P.f32 : 0;
   const int log2d = P.log2d;
   const bool disable_shared = P.disable_shared != 0;
@@ -326,7 +363,6 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
     M stH = mzero<K>();
     int x_al = 0, x_ar = 0, x_aP = -1;
     double x_ccA = 0, x_partA = 0, x_pCcur = 0;
-    M x_mBnow = mzero<K>(), x_mX = mzero<K>();
 
     if (state == S_END) {
       // ---- B is the root: end of sweep (optimizer.hpp:194-201) ------------
@@ -363,6 +399,7 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
       state = (step >= nsteps32) ? -1 : S_BEGIN;
     }
 
+    TNCO_PROF_F(1);
     // ======================= what does each replica need next? ================
     // Every state asks for at most: one node header (hN), the legs + partial cost of one node
     // (x1), 8 bytes from anywhere (xa) and, with hyper-indices, the own + hyper legs of one node
@@ -372,10 +409,10 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
     if (state == S_BEGIN) {
       // optimizer.hpp:103-107: a random leaf; its parent is B
       const uint32_t x = rng.next();
-      xa = reinterpret_cast<const uint32_t*>(lpar() + (int)(x % (uint32_t)n));
+      xa = reinterpret_cast<const uint32_t*>(lpar() + (int64_t)(x % (uint32_t)n) * LPS);
     } else if (state == S_GOT_B) {
       hN = B;
-      xa = reinterpret_cast<const uint32_t*>(betas + step);
+      xa = reinterpret_cast<const uint32_t*>(&v.hdr(B)->partial);
     } else if (state == S_GOT_HB) {
       x1 = bl;
       hN = A;
@@ -383,6 +420,7 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
       xa = reinterpret_cast<const uint32_t*>(&v.hdr(N - 1)->partial);  // optimizer.hpp:112
     } else if (state == S_GOT_B1) {
       x1 = br;
+      xa = reinterpret_cast<const uint32_t*>(betas + step);
       if (A >= 0) { hN = raP; yN = A; }
     } else if (state == S_GOT_HA) {
       x1 = (raL == B) ? raR : raL;  // C, the sibling of B
@@ -394,13 +432,14 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
       }
     }
 
+    TNCO_PROF_F(2);
     // ======================= requests (staging registers) ====================
     // Nothing below reads these registers before the landing fence.
     int gL = -1, gR = -1, gP = -1;
-    double gC = 0, gPart = 0;
+    double gC = 0;
     if (hN >= 0) {
       const NodeRec* q = v.hdr(hN);
-      gL = q->left; gR = q->right; gP = q->parent; gC = q->ccost; gPart = q->partial;
+      gL = q->left; gR = q->right; gP = q->parent; gC = q->ccost;
     }
     M gM = mzero<K>();
     double gMp = 0;
@@ -421,6 +460,7 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
       }
     }
     if (rng.room()) rng.request();
+    TNCO_PROF_F(3);
 
     if (state == S_MOVE) {
       did_move = true;
@@ -510,14 +550,17 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
       stL = bl; stR = br; stCC = ccB; stPart = partB;
       if constexpr (HYPER) stH = hB;
       b_is_left_of_a = c_is_right;
-      x_al = al; x_ar = ar; x_aP = aP; x_ccA = ccA; x_partA = partA; x_mBnow = mBnow; x_mX = mX; x_pCcur = pCcur;
+      x_al = al; x_ar = ar; x_aP = aP; x_ccA = ccA; x_partA = partA; x_pCcur = pCcur;
+      // :191, legs only (registers: the scalars follow after the store phase).  B becomes a child
+      // of the next B: its legs, and those of A's other child, are what the next move starts from.
+      if (c_is_right) { m0 = mBnow; m1 = mX; } else { m1 = mBnow; m0 = mX; }
     }
 
     TNCO_PROF_T(2);
     // ======================= landing fence ===================================
     // Everything requested above is needed before the first store below: vmcnt is in order, so
     // waiting for these loads later would also wait for the stores.
-    TNCO_LANDED(gL); TNCO_LANDED(gR); TNCO_LANDED(gP); TNCO_LANDED(gC); TNCO_LANDED(gPart);
+    TNCO_LANDED(gL); TNCO_LANDED(gR); TNCO_LANDED(gP); TNCO_LANDED(gC);
     TNCO_LANDED(gMp); TNCO_LANDED(gXlo); TNCO_LANDED(gXhi);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -536,16 +579,19 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
         if (jtail == jcap) {
           jinvalid = true;  // log full: the next improvement re-bases the checkpoint
         } else {
-          if (lane0) (P.jlog + r * (int64_t)P.jcap)[jtail] = stE;
+          if (lane0) jb((int)(jtail & 15u)) = stE;
           ++jtail;
+          if ((jtail & 15u) == 0u) {  // a 64-byte piece is complete: 16 bytes per lane
+            for (int q = lig; q < 4; q += L)
+              *reinterpret_cast<int4*>(jlog() + (jtail - 16u) + 4 * q) =
+                  make_int4(jb(4 * q + 0), jb(4 * q + 1), jb(4 * q + 2), jb(4 * q + 3));
+          }
         }
       }
-      if (lane0) {
-        v.lpar = lpar();
-        v.set_parent(stC, stB);
-        v.set_parent(stE, stA);
-      }
-      v.set_mask(stB, x_mBnow);  // :170 (accepted: B's legs after the move are the new legs)
+      v.lpar = lpar();
+      v.set_parent_group(stC, stB);
+      v.set_parent_group(stE, stA);
+      v.set_mask(stB, msel<K>(b_is_left_of_a, m0, m1));  // :170 (accepted: B's legs are the new legs)
     }
     if (did_move || did_end) {
       if (lane0) {
@@ -553,6 +599,14 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
         o.left = stL; o.right = stR; o.parent = stA; o.pad = 0; o.ccost = stCC; o.partial = stPart;
         *v.hdr(stB) = o;
       }
+      // Experiment (off): HBM writes whole 64-byte pieces and a shorter write is a read-modify-write
+      // there (tools/hbm_random.hip), so complete the 32-byte header with legs 0..3, unchanged.
+      // Measured -1.5 %: the block was read a few iterations ago and the L2 / Infinity Cache still
+      // hold it, so the short write never reaches HBM on its own; the extra store only costs issue.
+#ifdef TNCO_FIRST64
+      if (!(did_move && acc))
+        v.set_mask_first(stB, did_move ? msel<K>(b_is_left_of_a, m0, m1) : (HYPER ? iB : mxor<K>(m0, m1)));
+#endif
       if constexpr (HYPER) v.set_hyper(stB, stH);  // may also have changed one level below
       if (improved && lane0) cold.jmin = jtail;
       if (state < 0) break;
@@ -563,8 +617,8 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
     // ======================= what landed goes where ==========================
     if (did_move) {
       // :191  B <- A, carrying what is already known about A's children
-      if (b_is_left_of_a) { m0 = x_mBnow; p0 = stPart; m1 = x_mX; p1 = x_pCcur; }
-      else                { m1 = x_mBnow; p1 = stPart; m0 = x_mX; p0 = x_pCcur; }
+      if (b_is_left_of_a) { p0 = stPart; p1 = x_pCcur; }
+      else                { p1 = stPart; p0 = x_pCcur; }
       B = stA; bl = x_al; br = x_ar; ccB = x_ccA; partB = x_partA;
       if constexpr (HYPER) { iB = iA; hB = hA; iA = gI; hA = gH; }
       A = x_aP;
@@ -577,8 +631,8 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
       B = (int)gXlo;
       state = S_GOT_B;
     } else if (state == S_GOT_B) {
-      bl = gL; br = gR; A = gP; ccB = gC; partB = gPart;
-      beta = __hiloint2double((int)gXhi, (int)gXlo);
+      bl = gL; br = gR; A = gP; ccB = gC;
+      partB = __hiloint2double((int)gXhi, (int)gXlo);
       state = S_GOT_HB;
     } else if (state == S_GOT_HB) {
       m0 = gM; p0 = gMp;
@@ -588,6 +642,7 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
       state = S_GOT_B1;
     } else if (state == S_GOT_B1) {
       m1 = gM; p1 = gMp;
+      beta = __hiloint2double((int)gXhi, (int)gXlo);
       rnL = gL; rnR = gR; rnP = gP; rnC = gC;
       if constexpr (HYPER) { iA = gI; hA = gH; }
       state = (A < 0) ? S_END : S_GOT_HA;
@@ -597,6 +652,11 @@ __global__ __launch_bounds__(256, TNCO_WAVES_PER_SIMD) void sa_run_kernel(
     }
   }
 
+  if ((jtail & 15u) != 0u) {  // the unfinished piece of the rotation log (entries past jtail: don't care)
+    for (int q = lig; q < 4; q += L)
+      *reinterpret_cast<int4*>(jlog() + (jtail & ~15u) + 4 * q) =
+          make_int4(jb(4 * q + 0), jb(4 * q + 1), jb(4 * q + 2), jb(4 * q + 3));
+  }
   int mti, mtw;
   rng.finish(mti, mtw);
   if (lane0) {

@@ -168,6 +168,7 @@ void choose_lanes(int W, int* log2l, int* K) {
 
 #define DISPATCH_LK(h, CALL)                                  \
   switch ((h)->log2l * 8 + (h)->K) {                          \
+    case 1 * 8 + 6: CALL(1, 6); break;                        \
     case 2 * 8 + 1: CALL(2, 1); break;                        \
     case 2 * 8 + 2: CALL(2, 2); break;                        \
     case 2 * 8 + 3: CALL(2, 3); break;                        \
@@ -233,12 +234,12 @@ __global__ void finish_init_kernel(Params P, const double* sum, const double* to
   const int64_t r = blockIdx.x;
   const int n = P.n;
   const uint8_t* blk = P.blocks + r * (int64_t)(n - 1) * P.BS;
-  const int32_t* lp = P.lpar + r * (int64_t)n;
+  const int32_t* lp = P.lpar + r * (int64_t)n * LPS;
   Links* ml = P.minlinks + r * (int64_t)P.N;
   for (int i = threadIdx.x; i < P.N; i += blockDim.x) {
     Links o;
     if (i < n) {
-      o.left = -1; o.right = -1; o.parent = lp[i];
+      o.left = -1; o.right = -1; o.parent = lp[(int64_t)i * LPS];
     } else {
       const NodeRec* hd = reinterpret_cast<const NodeRec*>(blk + (int64_t)(i - n) * P.BS);
       o.left = hd->left; o.right = hd->right; o.parent = hd->parent;
@@ -451,6 +452,9 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   h->stream = h->own_stream;
 
   choose_lanes(W, &h->log2l, &h->K);
+  if (const char* e = std::getenv("TNCO_HIP_LANES")) {  // experiment knob: 2 lanes x 6 words
+    if (std::atoi(e) == 2 && W > 10 && W <= 12) { h->log2l = 1; h->K = 6; }
+  }
   h->L = 1 << h->log2l;
   const int L = h->L * h->K;  // padded words per mask row in the shared tables
 
@@ -492,11 +496,12 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     int64_t cap = (int64_t)(free_b / 8) / (R * 4);
     cap = std::max<int64_t>(1024, std::min<int64_t>(cap, (int64_t)1 << 22));
     if (const char* e = std::getenv("TNCO_HIP_JLOG_CAP")) cap = std::max<int64_t>(1, std::atoll(e));  // test knob
+    cap = (cap + 15) & ~(int64_t)15;  // the sweep kernel appends in whole 16-entry (64-byte) pieces
     P.jcap = (int32_t)cap;
   }
 
   HIP_TRY(h->alloc(&P.blocks, R * h->block_bytes()));
-  HIP_TRY(h->alloc(&P.lpar, R * n + 16));  // the sweep kernel reads 8 bytes at lpar[leaf]
+  HIP_TRY(h->alloc(&P.lpar, R * n * LPS + 16));  // the sweep kernel reads 8 bytes at a leaf's record
   HIP_TRY(h->alloc(&P.mt, R * 624));
   HIP_TRY(h->alloc(&P.mtshadow, R * 32));
   HIP_TRY(h->alloc(&P.rs, R));
@@ -803,7 +808,8 @@ int tnco_hip_get_tree(tnco_hip_handle h, int64_t r, int which, int32_t* left, in
   if (which == 0) {
     std::vector<uint8_t> blk((size_t)h->block_bytes());
     HIP_TRY(hipMemcpy(blk.data(), h->P.blocks + r * h->block_bytes(), blk.size(), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(parent, h->P.lpar + r * (int64_t)n, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy2D(parent, 4, h->P.lpar + r * (int64_t)n * LPS, (size_t)LPS * 4, 4, (size_t)n,
+                        hipMemcpyDeviceToHost));
     for (int i = 0; i < n; ++i) { left[i] = -1; right[i] = -1; }
     if (masks) std::memcpy(masks, h->leafmask_w.data(), (size_t)n * W * 8);
     for (int p = n; p < N; ++p) {
@@ -872,7 +878,7 @@ int tnco_hip_validate(tnco_hip_handle h, double atol, int64_t* n_bad, int64_t* f
   double *ttot = nullptr, *tsum = nullptr;
   Links* tlinks = nullptr;
   HIP_TRY(tmp.alloc(&tblk, chunk * h->block_bytes()));
-  HIP_TRY(tmp.alloc(&tlpar, chunk * n));
+  HIP_TRY(tmp.alloc(&tlpar, chunk * n * LPS));
   HIP_TRY(tmp.alloc(&tscr, chunk * 4 * N));
   HIP_TRY(tmp.alloc(&tlinks, chunk * N));
   HIP_TRY(tmp.alloc(&tstat, chunk));

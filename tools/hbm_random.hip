@@ -65,6 +65,105 @@ __global__ __launch_bounds__(256) void rnd_kernel(uint8_t* buf, uint64_t n_grain
   if (acc == 0x1234567) sink[0] = acc;
 }
 
+// The memory side of ONE move of the sweep kernel and nothing else (tnco_amd/csrc/sa_sweep.h):
+//   read  32 B  header of an ancestor            (random 128-B node block X)
+//   read 128 B  legs + partial cost of a sibling (random block Y)
+//   write 32 B header (+ 96 B legs when the move is accepted: ACC of 4 moves) of block Z
+//   write  4 B  parent field of two further blocks U, V (accepted moves only)
+// PARENTS = 0: the two parent writes are left out (what a layout without per-node parent pointers
+// would cost); 1: 4-byte writes; 2: every write is a whole aligned 64-byte piece (the parent field
+// together with the rest of the first half of the block, and the header together with legs 0..3).
+// moves/s of this kernel = the memory system's ceiling for the pattern.
+template <int UNROLL, int ACC, int PARENTS>
+__global__ __launch_bounds__(256) void move_pattern_kernel(uint8_t* buf, uint64_t n_lines, int iters, uint64_t* sink) {
+  const int lane = threadIdx.x & 3;
+  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  uint64_t acc = 0;
+  for (int it = 0; it < iters; it += UNROLL) {
+    uint64_t hx[UNROLL], y[UNROLL][4];
+    uint64_t base[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      base[u] = mix(gid * 0x9e3779b97f4a7c15ull + (uint64_t)(it + u));
+      const uint64_t X = base[u] % n_lines, Y = mix(base[u] + 1) % n_lines;
+      hx[u] = *reinterpret_cast<const uint64_t*>(buf + X * 128 + lane * 8);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) y[u][w] = *reinterpret_cast<const uint64_t*>(buf + Y * 128 + w * 32 + lane * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint64_t Z = mix(base[u] + 2) % n_lines, U = mix(base[u] + 3) % n_lines, V = mix(base[u] + 4) % n_lines;
+      const uint64_t s = hx[u] + y[u][0] + y[u][1] + y[u][2] + y[u][3];
+      acc += s;
+      const bool accepted = ((it + u) & 3) < ACC;
+      *reinterpret_cast<uint64_t*>(buf + Z * 128 + lane * 8) = s;
+      if (PARENTS == 2) *reinterpret_cast<uint64_t*>(buf + Z * 128 + 32 + lane * 8) = s + 1;
+      if (accepted) {
+#pragma unroll
+        for (int w = (PARENTS == 2 ? 2 : 1); w < 4; ++w)
+          *reinterpret_cast<uint64_t*>(buf + Z * 128 + w * 32 + lane * 8) = s + w;
+        if (PARENTS == 1 && lane == 0) {
+          *reinterpret_cast<uint32_t*>(buf + U * 128 + 8) = (uint32_t)s;
+          *reinterpret_cast<uint32_t*>(buf + V * 128 + 8) = (uint32_t)s + 1;
+        }
+        if (PARENTS == 2) {
+          *reinterpret_cast<uint4*>(buf + U * 128 + lane * 16) = make_uint4((uint32_t)s, 1, 2, 3);
+          *reinterpret_cast<uint4*>(buf + V * 128 + lane * 16) = make_uint4((uint32_t)s, 4, 5, 6);
+        }
+      }
+    }
+  }
+  if (acc == 0x1234567) sink[0] = acc;
+}
+
+template <int UNROLL, int ACC, int PARENTS>
+static void run_pattern(uint8_t* buf, size_t bytes, uint64_t* sink, int waves_per_simd) {
+  const int blocks = 256 * waves_per_simd;
+  const int iters = 1024;
+  hipEvent_t a, b;
+  CHECK(hipEventCreate(&a));
+  CHECK(hipEventCreate(&b));
+  const uint64_t n_lines = bytes / 128;
+  move_pattern_kernel<UNROLL, ACC, PARENTS><<<blocks, 256>>>(buf, n_lines, 64, sink);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(a));
+  move_pattern_kernel<UNROLL, ACC, PARENTS><<<blocks, 256>>>(buf, n_lines, iters, sink);
+  CHECK(hipEventRecord(b));
+  CHECK(hipEventSynchronize(b));
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, a, b));
+  const double moves = (double)blocks * 64 * iters;
+  printf("move pattern, accepted %d/4, parent writes %s, in-flight/group %d, waves/SIMD %d : %6.2f G moves/s\n", ACC,
+         PARENTS == 0 ? "no " : (PARENTS == 1 ? "4 B" : "64B"), UNROLL, waves_per_simd, moves / ms * 1e-6);
+}
+
+// lane 0 of every group writes 4 bytes into a random 128-B block (a parent-pointer update)
+template <int UNROLL>
+__global__ __launch_bounds__(256) void tiny_write_kernel(uint8_t* buf, uint64_t n_lines, int iters) {
+  const int lane = threadIdx.x & 3;
+  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  for (int it = 0; it < iters; ++it) {
+    const uint64_t g = mix(gid * 0x9e3779b97f4a7c15ull + (uint64_t)it) % n_lines;
+    if (lane == 0) *reinterpret_cast<uint32_t*>(buf + g * 128 + 8) = (uint32_t)g;
+  }
+}
+static void run_tiny(uint8_t* buf, size_t bytes, int waves_per_simd) {
+  const int blocks = 256 * waves_per_simd, iters = 2048;
+  hipEvent_t a, b;
+  CHECK(hipEventCreate(&a));
+  CHECK(hipEventCreate(&b));
+  tiny_write_kernel<1><<<blocks, 256>>>(buf, bytes / 128, 64);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(a));
+  tiny_write_kernel<1><<<blocks, 256>>>(buf, bytes / 128, iters);
+  CHECK(hipEventRecord(b));
+  CHECK(hipEventSynchronize(b));
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, a, b));
+  printf("grain   4 B  write (1 lane)                    waves/SIMD %d : %7.1f G accesses/s\n", waves_per_simd,
+         (double)blocks * 64 * iters / ms * 1e-6);
+}
+
 template <int GRAIN, int MODE, int UNROLL>
 static void run(uint8_t* buf, size_t bytes, uint64_t* sink, int waves_per_simd) {
   const int blocks = 256 * waves_per_simd;  // 256 CUs x (4 waves per block = 1 per SIMD) x waves_per_simd
@@ -107,6 +206,13 @@ int main(int argc, char** argv) {
     run<128, 2, 8>(buf, bytes, sink, w);
     run<32, 1, 8>(buf, bytes, sink, w);
     run<32, 2, 8>(buf, bytes, sink, w);
+    run<64, 2, 8>(buf, bytes, sink, w);
+    run_tiny(buf, bytes, w);
+    run_pattern<4, 3, 1>(buf, bytes, sink, w);
+    run_pattern<4, 3, 0>(buf, bytes, sink, w);
+    run_pattern<4, 3, 2>(buf, bytes, sink, w);
+    run_pattern<4, 4, 2>(buf, bytes, sink, w);
+    run_pattern<4, 0, 2>(buf, bytes, sink, w);
   }
   // streaming reference: same kernel shape, consecutive grains
   CHECK(hipFree(buf));

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--leaves", type=int, default=512)
     ap.add_argument("--replicas", type=int, default=65536)
     ap.add_argument("--sweeps", type=int, default=100)
+    ap.add_argument("--fine", action="store_true")
     a = ap.parse_args()
     ts, dims, out = synthetic.random_regular_tn(a.leaves, 3, 0)
     n_inds = 1 + max(i for xs in ts for i in xs)
@@ -40,6 +41,8 @@ def main():
     moves = opt.counters()["moves"] - m0
     it = cyc[4]
     names = ["mt19937", "state branches", "landing fence", "store phase"]
+    if a.fine:  # library built with -DTNCO_PROFILE=2
+        names = ["end-of-sweep blk", "addresses", "load issue", "move evaluation"]
     tot = cyc[:4].sum()
     print(f"replica-iterations {it:.3e}  moves {moves:.3e}  moves/iteration {moves / it:.3f}")
     for k in range(4):
