@@ -80,7 +80,7 @@ typedef struct tnco_hip_desc {
   int32_t disable_shared_inds;
   const uint32_t* seeds;       /* [n_replicas] std::mt19937 seeds (already reduced mod 2^32) */
   int32_t device;              /* HIP device ordinal */
-  int32_t width_dtype;         /* TNCO_HIP_F32 (the reference's default width_type) */
+  int32_t width_dtype;         /* TNCO_HIP_F32 (the reference's default width_type) | TNCO_HIP_F64 */
   /* Finite width (include/tnco/optimize/finite_width/greedy/optimizer.hpp:72-115 and
    * finite_width/cost_model/simple.hpp:89-95): active when max_width is finite and >= 0; pass
    * NAN / INFINITY for the infinite-memory optimizer. */

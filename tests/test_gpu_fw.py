@@ -26,7 +26,7 @@ def _initial_max_width(prob, links_r):
 def _check(core, orc, prob, seeds, betas, max_width, chunks, every=10, **kw):
     links = prob.links(seeds)
     gpu = core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, dims=prob.dims,
-                                output_mask=prob.output_mask, max_width=max_width, **kw)
+                                output_mask=prob.output_mask, sparse_mask=prob.sparse_mask, max_width=max_width, **kw)
     lo = 0
     for c in chunks:
         gpu.run(betas[lo:lo + c], "mh", update_slices_every=every)
@@ -34,8 +34,9 @@ def _check(core, orc, prob, seeds, betas, max_width, chunks, every=10, **kw):
     assert lo == len(betas)
     tot, mn = gpu.costs()
     for r in range(len(seeds)):
-        o = H.make_oracle(orc, prob, links[r], seeds[r], max_width=max_width, width_type="float32",
-                          **{k: v for k, v in kw.items() if k in ("cost_type", "skip_slices", "slices")})
+        okw = {k: v for k, v in kw.items() if k in ("cost_type", "skip_slices", "slices", "width_type",
+                                                     "max_number_new_slices", "n_projs", "disable_shared_inds")}
+        o = H.make_oracle(orc, prob, links[r], seeds[r], max_width=max_width, **okw)
         o.run(orc.PROB_MH, betas, update_slices_every=every)
         assert o.is_valid() == 0
         H.assert_replica_equal(gpu, r, o)
@@ -89,9 +90,52 @@ def test_fw_unsupported(core):
     with pytest.raises(RuntimeError):
         core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, max_width=-1)
     with pytest.raises(NotImplementedError):
-        core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, max_width=4, max_number_new_slices=2)
-    with pytest.raises(NotImplementedError):
-        core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, max_width=4, width_type="float64")
+        core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, max_width=4, width_type="float16")
+
+
+def test_fw_float64_width(core, oracle_lib):
+    prob = H.regular_problem(40, graph_seed=8)
+    seeds = H.replica_seeds(10, S=8)
+    _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 60, 90), 6, chunks=[40, 50], width_type="float64")
+
+
+@pytest.mark.parametrize("width_type", ["float32", "float64"])
+def test_fw_per_index_dims(core, oracle_lib, width_type):
+    """finite_width/cost_model/simple.hpp:48-56: width = running sum (in width_type) of log2(dims[p]);
+    the greedy slicer breaks ties on log2(dims) (greedy/utils.hpp:50-60)."""
+    from tnco_amd import synthetic as syn
+    ts, dims, out = syn.random_hyper_tn(28, 60, k=3, n_output=3, seed=7, dims_choices=(2, 3, 4, 6))
+    prob = H.Problem(ts, np.array(dims, np.uint64), out)
+    seeds = H.replica_seeds(10, S=7)
+    _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 40, 80), 9.5, chunks=[80], width_type=width_type)
+
+
+def test_fw_sparse_inds(core, oracle_lib):
+    """finite_width/cost_model/simple_sparse_inds.hpp: width(inds - S) + min(width(inds & S), log2(n_projs))."""
+    from tnco_amd import synthetic as syn
+    ts, dims, out = syn.random_hyper_tn(28, 64, k=3, n_output=4, seed=9)
+    prob = H.Problem(ts, 2, out, sparse_inds=[1, 5, 9, 20, 33, 47, 50, 51, 52])
+    seeds = H.replica_seeds(10, S=9)
+    _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 40, 80), 6, chunks=[30, 50], n_projs=5)
+
+
+def test_fw_sparse_inds_per_index_dims(core, oracle_lib):
+    from tnco_amd import synthetic as syn
+    ts, dims, out = syn.random_hyper_tn(24, 56, k=3, n_output=2, seed=10, dims_choices=(2, 3, 5))
+    prob = H.Problem(ts, np.array(dims, np.uint64), out, sparse_inds=[0, 2, 7, 11, 19, 23, 40])
+    seeds = H.replica_seeds(8, S=10)
+    _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 40, 70), 8.0, chunks=[70], n_projs=7)
+
+
+@pytest.mark.parametrize("m", [1, 3])
+def test_fw_max_number_new_slices(core, oracle_lib, m):
+    """greedy/optimizer.hpp:226-321: a move that does not fit may slice up to m random further legs
+    and is then tried against a full rebuild of the cost cache."""
+    prob = H.regular_problem(36, graph_seed=12)
+    seeds = H.replica_seeds(10, S=12)
+    gpu = _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 50, 70), 5, chunks=[20, 50],
+                 max_number_new_slices=m)
+    assert gpu.counters()["accepted"] > 0
 
 
 def test_sycamore53_depth20_finite_width(core, oracle_lib):

@@ -136,9 +136,10 @@ class BatchedOptimizer:
         d.device = int(device)
         self.finite_width = max_width is not None and max_width < float("inf")
         d.max_width = float(max_width) if self.finite_width else float("nan")
-        if self.finite_width and width_type != "float32":
-            raise NotImplementedError("width_type must be 'float32' on the GPU path.")
-        d.width_dtype = _lib.F32
+        if self.finite_width and width_type not in ("float32", "float64"):
+            raise NotImplementedError(f"width_type={width_type!r} is not supported on the GPU path "
+                                      "(float32, float64).")
+        d.width_dtype = _lib.F64 if width_type == "float64" else _lib.F32
         d.max_number_new_slices = int(max_number_new_slices)
         sk = None if skip_slices is None else np.ascontiguousarray(skip_slices, np.uint64)
         sl = None if slices is None else np.ascontiguousarray(slices, np.uint64)

@@ -3,37 +3,127 @@
 //
 // Same replica-per-lane-group mapping and node-block layout as sa_sweep.h.  On top of it, per
 // replica: the sliced-index mask `slices` / `min_slices` (W words each), the un-sliced width of
-// every internal node (float32, kept in the `pad` word of the node header; WidthCache,
-// finite_width/utils.hpp:49-76), and scratch for the greedy re-slice.
+// every internal node (WidthCache, finite_width/utils.hpp:49-76: float32 in the `pad` word of the
+// node header, or a float64 array of its own), and scratch for the greedy re-slice.
 //
-// This first version favours exactness over speed: every move reads its operands from memory
-// (no staging), and the re-slice (greedy/utils.hpp:21-125) + full CostCache rebuild
+// This version favours exactness over speed: every move reads its operands from memory (no
+// staging), and the re-slice (greedy/utils.hpp:21-125) + full CostCache rebuild
 // (greedy/optimizer.hpp:359-376) walk the whole tree serially per replica, as the reference does.
-// Supported: uniform dims, SimpleCostModel (no sparse legs), width_type float32,
-// max_number_new_slices = 0 (the only value the reference's app uses,
-// tnco/app/finite_width/sa.py:216).
+// Covered: SimpleCostModel and SimpleSparseIndsCostModel (finite_width/cost_model/simple.hpp,
+// simple_sparse_inds.hpp), uniform and per-index dims, width_type float32 / float64, and the
+// max_number_new_slices > 0 branch (greedy/optimizer.hpp:226-321).
 #pragma once
 #include "sa_sweep.h"
 
 namespace tnco {
 
 struct FwParams {
-  float max_width;          // (float)max_width
-  double log2d;             // std::log2(dims) as double (finite_width/cost_model/simple.hpp:46)
+  double max_width;         // width_type(max_width), held as double
+  double log2d;             // std::log2((double)dims), uniform dims (cost_model/simple.hpp:46)
+  const double* log2dims;   // [LK*64] std::log2((double)dims[p]), per-index dims; else NULL
+  double log2np;            // std::log2((double)n_projs) (simple_sparse_inds.hpp:45)
+  int32_t width_f32;        // width_type float32 (else float64)
+  int32_t I64;              // 64 * LK (padded index count)
+  int64_t max_new_slices;   // max_number_new_slices
   uint64_t* slices;         // [R][2][LK]  slices, min_slices
   const uint64_t* skip;     // [LK] or NULL
   int32_t* scratch_i;       // [R][3N + I64 + FW_MAXPOS/2]  order, stack, visited, n_big, candidate legs
   double* scratch_d;        // [R][2N]        rebuilt ccost / partial
-  int32_t I64;              // 64 * LK (padded index count)
+  double* width64;          // [R][N] widths of the internal nodes when width_type is float64
   int32_t* status;          // [R] runtime problems (1: more than FW_MAXPOS candidate legs)
 };
 
 constexpr int FW_MAXPOS = 512;  // candidate legs of one tensor (scratch for the shuffle)
 
-// width of a leg set: log2(dims) * count as double, converted to width_type float
-// (finite_width/cost_model/simple.hpp:38-47)
-__device__ __forceinline__ float fw_width(const FwParams& F, uint32_t count) {
-  return (float)(F.log2d * (double)count);
+// a value of width_type, held in a double
+__device__ __forceinline__ double fw_wr(const FwParams& F, double x) {
+  return F.width_f32 ? (double)(float)x : x;
+}
+
+// SimpleCostModel::width, finite_width/cost_model/simple.hpp:38-57: scalar dims ->
+// log2(dims) * count in double, converted to width_type; per-index dims -> running sum in
+// width_type of log2(dims[p]) over ascending positions (word k*L + j is slot k of lane j).
+template <int LOG2L, int K>
+__device__ __forceinline__ double fw_width_simple(const FwParams& F, const Mask<K>& m, int gbase) {
+  constexpr int L = 1 << LOG2L;
+  if (F.log2dims == nullptr) return fw_wr(F, F.log2d * (double)gsum<LOG2L>(mpopc<K>(m)));
+  double ws = 0.0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    for (int j = 0; j < L; ++j) {
+      const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)m.w[k], gbase + j);
+      const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(m.w[k] >> 32), gbase + j);
+      uint64_t x = ((uint64_t)hi << 32) | lo;
+      const int w = k * L + j;
+      while (x) {
+        const int b = __ffsll((unsigned long long)x) - 1;
+        ws = fw_wr(F, ws + F.log2dims[w * 64 + b]);
+        x &= x - 1;
+      }
+    }
+  }
+  return ws;
+}
+
+template <int LOG2L, int K>
+__device__ __forceinline__ Mask<K> fw_sparse_mask(const Params& P, int lig) {
+  Mask<K> s;
+#pragma unroll
+  for (int k = 0; k < K; ++k) s.w[k] = P.sparse[k * (1 << LOG2L) + lig];
+  return s;
+}
+
+// width of a leg set; with sparse legs: width(inds - S) + min(width(inds & S), log2(n_projs))
+// (simple_sparse_inds.hpp:38-52)
+template <int LOG2L, int K>
+__device__ __forceinline__ double fw_width(const Params& P, const FwParams& F, const Mask<K>& m, int lig, int gbase) {
+  if (P.sparse == nullptr) return fw_width_simple<LOG2L, K>(F, m, gbase);
+  const Mask<K> s = fw_sparse_mask<LOG2L, K>(P, lig);
+  const double w1 = fw_width_simple<LOG2L, K>(F, mandn<K>(m, s), gbase);
+  const double w2 = fw_width_simple<LOG2L, K>(F, mand<K>(m, s), gbase);
+  const double mn = (w2 < F.log2np) ? w2 : fw_wr(F, F.log2np);
+  return fw_wr(F, w1 + mn);
+}
+
+template <int LOG2L, int K, bool HYPER>
+__device__ __forceinline__ bool fw_test(const View<LOG2L, K, HYPER>& v, const Mask<K>& m, int pos) {
+  bool mine = false;
+#pragma unroll
+  for (int k = 0; k < K; ++k) mine |= ((pos >> 6) == v.widx(k)) && ((m.w[k] >> (pos & 63)) & 1ull);
+  return gany<LOG2L>(mine);
+}
+template <int LOG2L, int K, bool HYPER>
+__device__ __forceinline__ void fw_flip(const View<LOG2L, K, HYPER>& v, Mask<K>& m, int pos) {
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    if ((pos >> 6) == v.widx(k)) m.w[k] ^= 1ull << (pos & 63);
+}
+
+// get_delta_width: change of the width when position `pos` is toggled in `m`
+// (simple.hpp:59-76, simple_sparse_inds.hpp:54-82)
+template <int LOG2L, int K, bool HYPER>
+__device__ __forceinline__ double fw_delta_width(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
+                                                 const Mask<K>& m, int pos, int gbase) {
+  if (P.sparse != nullptr) {
+    const Mask<K> s = fw_sparse_mask<LOG2L, K>(P, v.lig);
+    if (fw_test<LOG2L, K, HYPER>(v, s, pos)) {
+      const Mask<K> cur = mand<K>(m, s);
+      Mask<K> nxt = cur;
+      fw_flip<LOG2L, K, HYPER>(v, nxt, pos);
+      const double a = fw_width_simple<LOG2L, K>(F, nxt, gbase), b = fw_width_simple<LOG2L, K>(F, cur, gbase);
+      const double ma = (a < F.log2np) ? a : fw_wr(F, F.log2np);
+      const double mb = (b < F.log2np) ? b : fw_wr(F, F.log2np);
+      return fw_wr(F, ma - mb);
+    }
+  }
+  const int test = fw_test<LOG2L, K, HYPER>(v, m, pos) ? 1 : 0;
+  const double l2 = F.log2dims ? F.log2dims[pos] : F.log2d;
+  return fw_wr(F, (double)(1 - 2 * test) * l2);
+}
+
+// DimsCache::log2_dims, finite_width/utils.hpp:91-108
+__device__ __forceinline__ double fw_log2dim(const FwParams& F, int pos) {
+  return fw_wr(F, F.log2dims ? F.log2dims[pos] : F.log2d);
 }
 
 // /usr/include/c++/11/bits/uniform_int_dist.h:246-321, 32-bit generator, range < 2^32
@@ -52,7 +142,7 @@ __device__ __forceinline__ uint32_t fw_uniform_int(Rng<LOG2L>& rng, uint32_t hi)
   return (uint32_t)(product >> 32);
 }
 
-// std::shuffle of /usr/include/c++/11/bits/stl_algo.h:3706-3792 on an LDS array (n < 65536: two
+// std::shuffle of /usr/include/c++/11/bits/stl_algo.h:3706-3792 on a scratch array (n < 65536: two
 // swap positions per variate).  Executed redundantly by every lane of the group; lane 0 writes.
 template <int LOG2L>
 __device__ __forceinline__ void fw_shuffle(Rng<LOG2L>& rng, volatile int16_t* a, int n, bool lane0) {
@@ -103,17 +193,13 @@ __device__ __forceinline__ void fw_traverse(const View<LOG2L, K, HYPER>& v, int 
   }
 }
 
-template <int K>
-__device__ __forceinline__ double fw_cost(const Params& P, uint32_t count) {
-  return uniform_cost(P, (int)count);
-}
-
 // CostCache(ctree, ccost, slices) (finite_width/utils.hpp:36-47) into scratch; returns
-// partial[root]; *sum = get_cost (finite_width/utils.hpp:24-33).
+// partial[root]; *sum = get_cost (finite_width/utils.hpp:24-33).  The contraction cost is taken
+// over in1 | in2 | slices (finite_width/cost_model/simple.hpp:139-144).
 template <int LOG2L, int K, bool HYPER>
 __device__ __forceinline__ double fw_rebuild(const Params& P, const View<LOG2L, K, HYPER>& v, const int32_t* order,
                                              const Mask<K>& slices, double* cc_new, double* part_new, bool lane0,
-                                             double* sum) {
+                                             int gbase, double* sum) {
   const int n = P.n, N = P.N;
   double s = 0.0;
   for (int i = 0; i < N; ++i) {
@@ -122,7 +208,7 @@ __device__ __forceinline__ double fw_rebuild(const Params& P, const View<LOG2L, 
     if (l < 0) continue;
     const int rr = v.right(p);
     const Mask<K> u = mor<K>(mor<K>(v.mask(l), v.mask(rr)), slices);
-    const double c = uniform_cost(P, (int)gsum<LOG2L>(mpopc<K>(u)));
+    const double c = generic_cost<LOG2L, K>(P, u, v.lig, gbase);
     const double pl = l < n ? 0.0 : part_new[l], pr = rr < n ? 0.0 : part_new[rr];
     const double part = rnd_cost(rnd_cost(c + pl, P.f32) + pr, P.f32);
     s = rnd_cost(s + c, P.f32);
@@ -144,18 +230,60 @@ __device__ __forceinline__ void fw_commit(const Params& P, const View<LOG2L, K, 
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// WidthCache: width of internal node p as stored / of a leaf as computed
 template <int LOG2L, int K, bool HYPER>
-__device__ __forceinline__ float fw_node_width(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
-                                               int t) {
-  if (t >= P.n) return __int_as_float(v.hdr(t)->pad);
-  return fw_width(F, gsum<LOG2L>(mpopc<K>(v.mask(t))));
+__device__ __forceinline__ double fw_node_width(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
+                                                const double* w64, int t, int gbase) {
+  if (t >= P.n) return F.width_f32 ? (double)__int_as_float(v.hdr(t)->pad) : w64[t];
+  return fw_width<LOG2L, K>(P, F, v.mask(t), v.lig, gbase);
+}
+template <int LOG2L, int K, bool HYPER>
+__device__ __forceinline__ void fw_set_node_width(const FwParams& F, const View<LOG2L, K, HYPER>& v, double* w64,
+                                                  int p, double w, bool lane0) {
+  if (!lane0) return;
+  if (F.width_f32) v.hdr(p)->pad = __float_as_int((float)w);
+  else w64[p] = w;
 }
 
-// get_slices_impl, finite_width/greedy/utils.hpp:21-125.  `pos` = LDS scratch of the group.
+// positions of `cand`, ascending (Bitset::positions), into pos[]; returns their number
+template <int LOG2L, int K, bool HYPER>
+__device__ __forceinline__ uint32_t fw_positions(const View<LOG2L, K, HYPER>& v, const Mask<K>& cand,
+                                                 volatile int16_t* pos, int gbase, bool lane0, int32_t* status) {
+  constexpr int L = 1 << LOG2L;
+  uint32_t np = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const uint32_t mine = (uint32_t)__popcll(cand.w[k]);
+    uint32_t before = 0, tot = 0;
+    for (int j = 0; j < L; ++j) {
+      const uint32_t c = (uint32_t)__shfl((int)mine, gbase + j);
+      if (j < v.lig) before += c;
+      tot += c;
+    }
+    uint32_t o = np + before;
+    uint64_t x = cand.w[k];
+    while (x) {
+      const int b = __ffsll((unsigned long long)x) - 1;
+      if (o < (uint32_t)FW_MAXPOS) pos[o] = (int16_t)(v.widx(k) * 64 + b);
+      ++o;
+      x &= x - 1;
+    }
+    np += tot;
+  }
+  if (np > (uint32_t)FW_MAXPOS) {
+    if (lane0) *status = 1;
+    np = FW_MAXPOS;
+  }
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  return np;
+}
+
+// get_slices_impl, finite_width/greedy/utils.hpp:21-125.  `pos` = scratch of the group.
 template <int LOG2L, int K, bool HYPER>
 __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
-                                                 Rng<LOG2L>& rng, const int32_t* order, int32_t* n_big,
-                                                 volatile int16_t* pos, bool lane0, int gbase, int32_t* status) {
+                                                 const double* w64, Rng<LOG2L>& rng, const int32_t* order,
+                                                 int32_t* n_big, volatile int16_t* pos, bool lane0, int gbase,
+                                                 int32_t* status) {
   constexpr int L = 1 << LOG2L;
   const int N = P.N, lig = v.lig;
   Mask<K> slices = mzero<K>();
@@ -168,7 +296,7 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
   for (int i = lig; i < F.I64; i += L) n_big[i] = 0;
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (int t = 0; t < N; ++t) {
-    if (fw_node_width<LOG2L, K, HYPER>(P, F, v, t) > F.max_width) {
+    if (fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t, gbase) > F.max_width) {
       const Mask<K> m = v.mask(t);
 #pragma unroll
       for (int k = 0; k < K; ++k) {
@@ -185,60 +313,40 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
   // :62-101  post-order over the too-wide tensors
   for (int i = 0; i < N; ++i) {
     const int t = order[i];
-    if (!(fw_node_width<LOG2L, K, HYPER>(P, F, v, t) > F.max_width)) continue;
+    if (!(fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t, gbase) > F.max_width)) continue;
     Mask<K> sliced_xs = mandn<K>(v.mask(t), slices);
-    float sliced_width = fw_width(F, gsum<LOG2L>(mpopc<K>(sliced_xs)));
+    double sliced_width = fw_width<LOG2L, K>(P, F, sliced_xs, lig, gbase);
     if (!(sliced_width > F.max_width)) continue;
-    // candidate positions, ascending (Bitset::positions): word k*L + j is slot k of lane j
-    const Mask<K> cand = mandn<K>(sliced_xs, skip);
-    uint32_t np = 0;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const uint32_t mine = (uint32_t)__popcll(cand.w[k]);
-      uint32_t before = 0, tot = 0;
-      for (int j = 0; j < L; ++j) {
-        const uint32_t c = (uint32_t)__shfl((int)mine, gbase + j);
-        if (j < lig) before += c;
-        tot += c;
-      }
-      uint32_t o = np + before;
-      uint64_t x = cand.w[k];
-      while (x) {
-        const int b = __ffsll((unsigned long long)x) - 1;
-        if (o < (uint32_t)FW_MAXPOS) pos[o] = (int16_t)(v.widx(k) * 64 + b);
-        ++o;
-        x &= x - 1;
-      }
-      np += tot;
-    }
-    if (np > (uint32_t)FW_MAXPOS) {
-      if (lane0) *status = 1;
-      np = FW_MAXPOS;
-    }
+    // candidate positions, ascending
+    uint32_t np = fw_positions<LOG2L, K, HYPER>(v, mandn<K>(sliced_xs, skip), pos, gbase, lane0, status);
     // :80  std::shuffle(positions, prng)
     fw_shuffle<LOG2L>(rng, pos, (int)np, lane0);
-    // :83-101  stable_sort by n_big descending, then slice until the tensor fits: equivalent to
-    // repeatedly taking the FIRST remaining position with the largest n_big.
+    // :83-101  stable_sort with `greater` (:50-60: more too-wide tensors first; with per-index dims
+    // ties go to the larger log2(dims)), then slice until the tensor fits: equivalent to repeatedly
+    // taking the FIRST remaining position with the largest key.
     for (uint32_t taken = 0; taken < np; ++taken) {
       int best = -1, best_key = -1;
+      double best_l2 = 0.0;
       for (uint32_t q = 0; q < np; ++q) {
         const int xp = pos[q];
         if (xp < 0) continue;
         const int key = n_big[xp];
-        if (key > best_key) { best_key = key; best = (int)q; }
+        if (F.log2dims == nullptr) {
+          if (key > best_key) { best_key = key; best = (int)q; }
+        } else {
+          const double l2 = fw_log2dim(F, xp);
+          if (best < 0 || key > best_key || (key == best_key && l2 > best_l2)) {
+            best_key = key; best_l2 = l2; best = (int)q;
+          }
+        }
       }
       const int xpos = pos[best];
       if (lane0) pos[best] = -1;
-      // slices.set(xpos); sliced_width += delta_width (= -log2(dims) for a present index);
-      // sliced_xs.reset(xpos)
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        if ((xpos >> 6) == v.widx(k)) {
-          slices.w[k] |= 1ull << (xpos & 63);
-          sliced_xs.w[k] &= ~(1ull << (xpos & 63));
-        }
-      }
-      sliced_width = sliced_width + (float)((double)(1 - 2 * 1) * F.log2d);
+      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // slices.set(xpos); sliced_width += delta_width(sliced_xs, xpos); sliced_xs.reset(xpos)
+      fw_flip<LOG2L, K, HYPER>(v, slices, xpos);  // xpos is not in slices: sliced_xs = inds - slices
+      sliced_width = fw_wr(F, sliced_width + fw_delta_width<LOG2L, K, HYPER>(P, F, v, sliced_xs, xpos, gbase));
+      fw_flip<LOG2L, K, HYPER>(v, sliced_xs, xpos);
       if (sliced_width <= F.max_width) break;
     }
   }
@@ -277,11 +385,10 @@ __global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwPa
   int32_t *order = si, *stack = si + N, *visited = si + 2 * N, *n_big = si + 3 * N;
   double* cc_new = F.scratch_d + r * 2 * (int64_t)N;
   double* part_new = cc_new + N;
+  double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
   // widths of the internal nodes
-  for (int p = n; p < N; ++p) {
-    const float w = fw_width(F, gsum<LOG2L>(mpopc<K>(v.mask(p))));
-    if (lane0) v.hdr(p)->pad = __float_as_int(w);
-  }
+  for (int p = n; p < N; ++p)
+    fw_set_node_width<LOG2L, K, HYPER>(F, v, w64, p, fw_width<LOG2L, K>(P, F, v.mask(p), lig, gbase), lane0);
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
   fw_traverse<LOG2L, K, HYPER>(v, N, order, stack, visited, lane0);
   Mask<K> slices;
@@ -290,10 +397,10 @@ __global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwPa
     for (int k = 0; k < K; ++k) slices.w[k] = a.slices_in[v.widx(k)];
   } else {
     volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + 3 * N + F.I64);
-    slices = fw_get_slices<LOG2L, K, HYPER>(P, F, v, rng, order, n_big, pos, lane0, gbase, F.status + r);
+    slices = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, n_big, pos, lane0, gbase, F.status + r);
   }
   double sum = 0;
-  const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, order, slices, cc_new, part_new, lane0, &sum);
+  const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, order, slices, cc_new, part_new, lane0, gbase, &sum);
   fw_commit<LOG2L, K, HYPER>(P, v, cc_new, part_new);
   uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
 #pragma unroll
@@ -341,17 +448,37 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
   rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
   int32_t* si = F.scratch_i + r * (int64_t)(3 * N + F.I64 + FW_MAXPOS / 2);
   int32_t *order = si, *stack = si + N, *visited = si + 2 * N, *n_big = si + 3 * N;
+  volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + 3 * N + F.I64);
   double* cc_new = F.scratch_d + r * 2 * (int64_t)N;
   double* part_new = cc_new + N;
+  double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
   uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
   M slices;
+  M skip = mzero<K>();
 #pragma unroll
   for (int k = 0; k < K; ++k) slices.w[k] = sl[v.widx(k)];
+  if (F.skip) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) skip.w[k] = F.skip[v.widx(k)];
+  }
   double min_cost = rs->min_cost;
   uint32_t n_moves = 0, n_acc = 0, n_impr = 0, n_rpick = 0, n_full = 0;
   int32_t* jlog = P.jlog + r * (int64_t)P.jcap;
   uint32_t jmin = rs->jmin, jtail = rs->jtail;
   bool jinvalid = rs->jinvalid != 0;
+  auto log_rotation = [&](int E) {
+    if (!jinvalid) {
+      if (jtail == (uint32_t)P.jcap) jinvalid = true;
+      else { if (lane0) jlog[jtail] = E; ++jtail; }
+    }
+  };
+  auto uniform01 = [&]() {
+    const uint32_t x1 = rng.next_sync(), x2 = rng.next_sync();
+    const double s = (double)x1 + (double)x2 * 4294967296.0;
+    double u = s * 5.421010862427522170037e-20;
+    if (u >= 1.0) u = 0.99999999999999988897769753748;
+    return u;
+  };
 
   for (int64_t step = 0; step < n_steps; ++step) {
     const double beta = betas[step];
@@ -384,36 +511,25 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
       const M iA = v.mask(A), hA = v.hyper(A), hB = v.hyper(B);
       // :174-179
       const M newB = mor<K>(mor<K>(mxor<K>(mD, mC), hA), hB);
-      const uint32_t cw = gsum<LOG2L>(mpopc<K>(newB) | (mpopc<K>(mandn<K>(newB, slices)) << 16));
-      const float new_width_B = fw_width(F, cw & 0xffffu);
-      const float new_sliced_width_B = fw_width(F, cw >> 16);
+      const double new_width_B = fw_width<LOG2L, K>(P, F, newB, lig, gbase);
+      double new_sliced_width_B = fw_width<LOG2L, K>(P, F, mandn<K>(newB, slices), lig, gbase);
       double ccB = hb.ccost, ccA = ha.ccost;
       int bl = hb.left, br = hb.right, al = ha.left, ar = ha.right;
-      bool acc = false;
+      bool acc = false, skip_cost_propagation = false;
       ++n_moves;
       if (new_sliced_width_B <= F.max_width) {
         // :190-201
-        const uint32_t pc = gsum<LOG2L>(mpopc<K>(mor<K>(mor<K>(newB, mE), slices)) |
-                                        (mpopc<K>(mor<K>(mor<K>(mD, mC), slices)) << 16));
-        const double nA = uniform_cost(P, (int)(pc & 0xffffu)), nB = uniform_cost(P, (int)(pc >> 16));
+        const double nA = generic_cost<LOG2L, K>(P, mor<K>(mor<K>(newB, mE), slices), lig, gbase);
+        const double nB = generic_cost<LOG2L, K>(P, mor<K>(mor<K>(mD, mC), slices), lig, gbase);
         const double delta = rnd_cost(rnd_cost(nB - ccB, f32) + rnd_cost(nA - ccA, f32), f32);
-        double u;
-        {
-          const uint32_t x1 = rng.next_sync(), x2 = rng.next_sync();
-          const double s = (double)x1 + (double)x2 * 4294967296.0;
-          u = s * 5.421010862427522170037e-20;
-          if (u >= 1.0) u = 0.99999999999999988897769753748;
-        }
+        const double u = uniform01();
         acc = accept_move(prob_kind, beta, delta, total, u, f32);
         if (acc) {
           ++n_acc;
           // :203-219
           if (pick0) br = C; else bl = C;
           if (c_is_right) ar = E; else al = E;
-          if (!jinvalid) {
-            if (jtail == (uint32_t)P.jcap) jinvalid = true;
-            else { if (lane0) jlog[jtail] = E; ++jtail; }
-          }
+          log_rotation(E);
           if (lane0) {
             v.set_parent(C, B);
             v.set_parent(E, A);
@@ -426,18 +542,81 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
           total = rnd_cost(total + delta, f32);
           const int t = C; C = E; E = t;
         }
+      } else if (F.max_new_slices > 0) {
+        // :226-321  slice up to max_number_new_slices random further legs of the new B; if it then
+        // fits, try the rotation against a FULL rebuild of the cost cache with the new slices
+        M new_slices = slices;
+        uint32_t n_pos = fw_positions<LOG2L, K, HYPER>(v, mandn<K>(mandn<K>(newB, slices), skip), pos, gbase, lane0,
+                                                       F.status + r);
+        int64_t n_new = 0;
+        while (n_new < F.max_new_slices && new_sliced_width_B > F.max_width && n_pos > 0) {
+          const uint32_t j = rng.next_sync() % n_pos;  // :245
+          const int16_t pj = pos[j], pl = pos[n_pos - 1];
+          if (lane0) { pos[j] = pl; pos[n_pos - 1] = pj; }
+          __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          const int xp = pj;
+          fw_flip<LOG2L, K, HYPER>(v, new_slices, xp);
+          new_sliced_width_B = fw_wr(F, new_sliced_width_B - fw_log2dim(F, xp));
+          --n_pos;
+          ++n_new;
+        }
+        if (new_sliced_width_B <= F.max_width) {
+          // :287-290  B takes its new legs, rotate, rebuild
+          const M oldB = v.mask(B);
+          if (lane0) {
+            NodeRec o = hb, oa = ha;
+            if (pick0) o.right = C; else o.left = C;
+            if (c_is_right) oa.right = E; else oa.left = E;
+            *v.hdr(B) = o;
+            *v.hdr(A) = oa;
+            v.set_parent(C, B);
+            v.set_parent(E, A);
+          }
+          v.set_mask(B, newB);
+          __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          fw_traverse<LOG2L, K, HYPER>(v, N, order, stack, visited, lane0);
+          double sum;
+          const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, order, new_slices, cc_new, part_new, lane0, gbase, &sum);
+          const double delta = rnd_cost(tot - total, f32);
+          const double u = uniform01();
+          if (accept_move(prob_kind, beta, delta, total, u, f32)) {
+            // :296-312
+            fw_commit<LOG2L, K, HYPER>(P, v, cc_new, part_new);
+            v.set_hyper(A, mand<K>(mand<K>(iA, newB), mE));
+            v.set_hyper(B, mand<K>(mand<K>(newB, mD), mC));
+            fw_set_node_width<LOG2L, K, HYPER>(F, v, w64, B, new_width_B, lane0);
+            total = tot;
+            slices = new_slices;
+            skip_cost_propagation = true;
+            log_rotation(E);
+            ++n_acc;
+          } else {
+            // :317-318  undo
+            if (lane0) {
+              *v.hdr(B) = hb;
+              *v.hdr(A) = ha;
+              v.set_parent(C, A);
+              v.set_parent(E, B);
+            }
+            v.set_mask(B, oldB);
+          }
+          __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
       }
-      // :324-331 (skip_cost_propagation is only set by the max_number_new_slices > 0 branch)
-      const double partB = rnd_cost(rnd_cost(v.partial(D) + v.partial(E), f32) + ccB, f32);
-      const double partA = rnd_cost(rnd_cost(partB + v.partial(C), f32) + ccA, f32);
-      if (lane0) {
-        NodeRec o;
-        o.left = bl; o.right = br; o.parent = A; o.ccost = ccB; o.partial = partB;
-        o.pad = acc ? __float_as_int(new_width_B) : hb.pad;
-        *v.hdr(B) = o;
-        NodeRec oa;
-        oa.left = al; oa.right = ar; oa.parent = ha.parent; oa.pad = ha.pad; oa.ccost = ccA; oa.partial = partA;
-        *v.hdr(A) = oa;
+      // :324-331
+      if (!skip_cost_propagation) {
+        const double partB = rnd_cost(rnd_cost(v.partial(D) + v.partial(E), f32) + ccB, f32);
+        const double partA = rnd_cost(rnd_cost(partB + v.partial(C), f32) + ccA, f32);
+        if (lane0) {
+          NodeRec o;
+          o.left = bl; o.right = br; o.parent = A; o.ccost = ccB; o.partial = partB;
+          o.pad = (acc && F.width_f32) ? __float_as_int((float)new_width_B) : hb.pad;
+          *v.hdr(B) = o;
+          NodeRec oa;
+          oa.left = al; oa.right = ar; oa.parent = ha.parent; oa.pad = ha.pad; oa.ccost = ccA; oa.partial = partA;
+          *v.hdr(A) = oa;
+          if (acc && !F.width_f32) w64[B] = new_width_B;
+        }
       }
       __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
       B = A;
@@ -446,10 +625,9 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
     const bool do_slices = update_every > 0 && ((step_offset + step) % update_every) == 0;
     if (do_slices && gany<LOG2L>(mnonzero<K>(slices))) {
       fw_traverse<LOG2L, K, HYPER>(v, N, order, stack, visited, lane0);
-      volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + 3 * N + F.I64);
-      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, rng, order, n_big, pos, lane0, gbase, F.status + r);
+      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, n_big, pos, lane0, gbase, F.status + r);
       double sum;
-      const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, order, ns, cc_new, part_new, lane0, &sum);
+      const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, order, ns, cc_new, part_new, lane0, gbase, &sum);
       if (tot < v.hdr(N - 1)->partial) {
         slices = ns;
         fw_commit<LOG2L, K, HYPER>(P, v, cc_new, part_new);

@@ -412,10 +412,8 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   const bool fw = std::isfinite(d->max_width);
   if (fw) {
     if (d->max_width < 0) return fail(TNCO_HIP_ERUNTIME, "'max_width' must be a non-negative number.");
-    if (!uniform) return fail(TNCO_HIP_ENOTIMPL, "finite width: per-index dims are not supported yet.");
-    if (d->sparse_mask) return fail(TNCO_HIP_ENOTIMPL, "finite width: sparse indices are not supported yet.");
-    if (d->width_dtype != TNCO_HIP_F32) return fail(TNCO_HIP_ENOTIMPL, "finite width: width_type must be float32.");
-    if (d->max_number_new_slices != 0) return fail(TNCO_HIP_ENOTIMPL, "finite width: max_number_new_slices must be 0.");
+    if (d->width_dtype != TNCO_HIP_F32 && d->width_dtype != TNCO_HIP_F64)
+      return fail(TNCO_HIP_ENOTIMPL, "finite width: width_type must be float32 or float64.");
   }
 
   // host-side structural validation of every tree
@@ -610,9 +608,21 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   if (fw) {
     h->fw = true;
     FwParams& F = h->F;
-    F.max_width = (float)d->max_width;
-    F.log2d = std::log2((double)dim_u);
+    F.width_f32 = d->width_dtype == TNCO_HIP_F32 ? 1 : 0;
+    F.max_width = F.width_f32 ? (double)(float)d->max_width : d->max_width;
+    F.log2d = uniform ? std::log2((double)dim_u) : 0.0;
+    F.log2np = d->sparse_mask ? std::log2((double)d->n_projs) : 0.0;
+    F.max_new_slices = (int64_t)std::min<uint64_t>(d->max_number_new_slices, (uint64_t)1 << 40);
     F.I64 = 64 * L;
+    if (!uniform) {
+      std::vector<double> l2((size_t)L * 64, 0.0);
+      for (int i = 0; i < I; ++i) l2[i] = std::log2((double)d->dims[i]);
+      double* dl2;
+      HIP_TRY(h->alloc(&dl2, (int64_t)l2.size()));
+      HIP_TRY(hipMemcpy(dl2, l2.data(), l2.size() * 8, hipMemcpyHostToDevice));
+      F.log2dims = dl2;
+    }
+    if (!F.width_f32) HIP_TRY(h->alloc(&F.width64, R * (int64_t)N));
     HIP_TRY(h->alloc(&F.slices, R * 2 * (int64_t)L));
     HIP_TRY(h->alloc(&F.scratch_i, R * (int64_t)(3 * N + F.I64 + FW_MAXPOS / 2)));
     HIP_TRY(h->alloc(&F.scratch_d, R * 2 * (int64_t)N));
