@@ -44,7 +44,7 @@ def _replay(tn, path):
 def test_readme_chain_config1():
     """BASELINE config 1: 3-index chain of the README, n_steps=100, n_runs=8 (un-fused)."""
     opt = Optimizer(method="sa", seed=0)
-    tn, res = opt.optimize("2 a b\n2 b c\n2 c d", betas=(0, 100), n_steps=100, n_runs=8)
+    tn, res = opt.optimize("2 a b\n2 b c\n2 c d", betas=(0, 100), n_steps=100, n_runs=8, fuse=None)
     assert len(res) == 8 and [r.cost for r in res] == sorted(r.cost for r in res)
     for r in res:
         final, cost = _replay(tn, r.path)
@@ -61,7 +61,7 @@ def test_results_match_oracle_run_by_run(oracle_lib):
     spec = [(2, *[f"t{t}" for t in range(len(ts)) if k in ts[t]]) for k in range(36)]
     opt = Optimizer(method="sa", seed=11)
     n_runs, n_steps = 12, 150
-    tn, res = opt.optimize(spec, betas=(0, 50), n_steps=n_steps, n_runs=n_runs)
+    tn, res = opt.optimize(spec, betas=(0, 50), n_steps=n_steps, n_runs=n_runs, fuse=None)
     seeds = random.Random(11).choices(range(2**32), k=n_runs)
     betas = expand_betas((0, 50), n_steps)
     # bit position of an index = order of first appearance over the tensors (tnco/ctree.py:232,
@@ -87,9 +87,9 @@ def test_results_match_oracle_run_by_run(oracle_lib):
 def test_disconnected_components_and_json():
     spec = "2 a b\n2 b c\n3 x y\n3 y z\n3 z x\n2 lonely"
     opt = Optimizer(method="sa", seed=3, output_format="json")
-    out = json.loads(opt.optimize(spec, betas=(0, 10), n_steps=30, n_runs=4))
+    out = json.loads(opt.optimize(spec, betas=(0, 10), n_steps=30, n_runs=4, fuse=None))
     assert len(out["res"]) == 4 and len(out["tn"]["tensors"]) == 7
-    tn = load_tn(spec)
+    tn = load_tn(spec, fuse=None)
     for r in out["res"]:
         assert len(r["path"]) == 6  # 7 tensors -> 6 contractions after autocomplete
         assert len(r["disconnected_paths"]) == 3
@@ -105,7 +105,7 @@ def test_finite_width_through_the_api():
     spec = [(2, *[f"t{t}" for t in range(40) if k in ts[t]]) for k in range(60)]
     max_width = 5
     tn, res = Optimizer(method="sa", max_width=max_width, seed=4).optimize(
-        spec, betas=(0, 80), n_steps=200, n_runs=6, update_slices=10)
+        spec, betas=(0, 80), n_steps=200, n_runs=6, update_slices=10, fuse=None)
     assert len(res) == 6 and [r.cost for r in res] == sorted(r.cost for r in res)
     for r in res:
         assert r.slices == frozenset().union(*r.disconnected_slices) and len(r.slices) > 0
@@ -122,9 +122,39 @@ def test_finite_width_through_the_api():
         assert Decimal("%g" % cost) == r.cost
 
 
+def test_readme_chain_default_fuse():
+    """README.md:93-106 with the default `fuse=4`: every index of the 4-tensor chain is pre-contracted
+    (all intermediates have width <= 2), one tensor without indices is left and the SA loop is skipped
+    (tnco/app/infinite_memory/sa.py:179-183): cost 0, empty path, tn.tags['fuse_path'] holds the fusing."""
+    import warnings
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        tn, res = Optimizer(method="sa", seed=0).optimize("2 a b\n2 b c\n2 c d", betas=(0, 100), n_steps=100, n_runs=8)
+    assert any("hyper-indices" in str(x.message) for x in w)
+    assert len(tn.tensors) == 1 and tn.tensors[0].inds == () and len(tn.tags["fuse_path"]) == 3
+    assert len(res) == 8
+    for r in res:
+        assert r.cost == 0 and list(r.path) == [] and list(r.disconnected_paths) == [[]]
+
+
+def test_fused_network_runs_on_the_gpu():
+    """fuse=4 on a 3-regular network merges some tensors; the optimizer runs on the fused network
+    and fuse_path + path contract the original network to its outputs."""
+    ts, dims, out = __import__("tnco_amd.synthetic", fromlist=["x"]).random_regular_tn(40, 3, 3)
+    spec = [(2, *[f"t{t}" for t in range(40) if k in ts[t]]) for k in range(60)]
+    tn0 = load_tn(spec, fuse=None, decompose_hyper_inds=False)
+    tn, res = Optimizer(method="sa", seed=2).optimize(spec, betas=(0, 50), n_steps=100, n_runs=4, fuse=4,
+                                                      decompose_hyper_inds=False)
+    assert 1 < len(tn.tensors) < 40
+    final, _ = _replay(tn0, list(tn.tags["fuse_path"]) + [tuple(p) for p in res[0].path])
+    assert len(final) == 1 and final[0] == tn0.output_inds
+    final, cost = _replay(tn, res[0].path)
+    assert Decimal("%g" % cost) == res[0].cost
+
+
 def test_timeout_and_top_k():
     ts, dims, out = __import__("tnco_amd.synthetic", fromlist=["x"]).random_regular_tn(64, 3, 7)
     spec = [(2, *[f"t{t}" for t in range(64) if k in ts[t]]) for k in range(96)]
     tn, res = Optimizer(method="sa", seed=1).optimize(spec, betas=(0, 100), n_steps=20000, n_runs=64,
-                                                      timeout=0.2, top_k=5, sweeps_per_launch=50)
+                                                      timeout=0.2, top_k=5, sweeps_per_launch=50, fuse=None)
     assert len(res) == 5 and tn.tags["timed_out"] and tn.tags["n_runs"] == 64

@@ -55,7 +55,7 @@ def test_contraction_tree_matches_derive_and_roundtrips():
 
 def test_readme_example_tree():
     """README.md:93-106 input '2 a b / 2 b c / 2 c d': 4 tensors in a chain."""
-    tn = load_tn("2 a b\n2 b c\n2 c d")
+    tn = load_tn("2 a b\n2 b c\n2 c d", fuse=None, decompose_hyper_inds=False)
     assert len(tn) == 4 and tn.output_inds == frozenset() and set(tn.dims.values()) == {2}
     tree = ct.ContractionTree([(0, 1), (0, 1), (0, 1)], tn.ts_inds, 2, check_shared_inds=True)
     assert tree.n_leaves == 4 and tree.max_width() == 2.0
@@ -100,11 +100,12 @@ def test_expand_betas():
 
 
 def test_load_tn_formats_and_tokens():
-    tn = load_tn([(2, "a", "b"), (3, "b", "c", "*"), (2, "c", "/")])
+    with pytest.warns(UserWarning, match="sparse indices"):  # app.py:330-336: no fusing with sparse indices
+        tn = load_tn([(2, "a", "b"), (3, "b", "c", "*"), (2, "c", "/")])
     assert len(tn) == 3 and tn.output_inds == {1} and tn.sparse_inds == {2} and tn.dims == {0: 2, 1: 3, 2: 2}
-    assert load_tn(tn) is tn
-    with pytest.raises(NotImplementedError):
-        load_tn("2 a b", fuse=4)
+    assert load_tn(tn, fuse=None, decompose_hyper_inds=False) is tn
+    with pytest.warns(UserWarning, match="Cannot decompose hyper-indices"):
+        assert len(load_tn("2 a b", fuse=4)) == 1
     with pytest.raises(TypeError):
         load_tn("hello world")
     with pytest.raises(TypeError):

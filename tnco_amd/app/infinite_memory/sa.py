@@ -4,8 +4,8 @@ Host mirror of /root/reference/tnco/app/infinite_memory/sa.py:63-257; the driver
 tnco_amd/app/_sa_driver.py.  Differences a caller can observe:
   * the initial tree of a run comes from this build's generator, not opt_einsum's greedy
     (third-party, unpinned in the reference);
-  * `load_tn` takes index lists only and does not pre-fuse (`fuse` defaults to None, the reference
-    to 4);
+  * `load_tn` takes index lists only (no circuits, no arrays); pre-fusing (`fuse`, default 4) is this
+    build's restatement of tnco/utils/tn.py:598-824;
   * only the `top_k` best runs (default min(n_runs, 1024)) are materialised as results.
 """
 from __future__ import annotations

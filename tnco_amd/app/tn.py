@@ -3,10 +3,10 @@
 Host mirror of the slice of /root/reference/tnco/app/tn.py:76-362 (Tensor,
 TensorNetwork) and tnco/app/app.py:154-500 (load_tn) that feeds the SA path:
 index-list inputs (list or string form, `*` output token, `/` sparse token;
-tnco/utils/tn.py:520-569 read_inds).  Circuits, arrays, hyper-index
-decomposition and pre-fusing (`fuse`) belong to the reference's front-end and
-are out of scope: asking for them raises
-NotImplementedError instead of silently doing something else.
+tnco/utils/tn.py:520-569 read_inds) and the symbolic pre-fusing of tensors
+(`fuse`, tnco/utils/tn.py:598-824; app.py:373-414).  Circuits, arrays and
+hyper-index decomposition belong to the reference's front-end and are out of
+scope.
 """
 from __future__ import annotations
 
@@ -16,7 +16,8 @@ from collections import defaultdict
 from dataclasses import dataclass, field
 from typing import Any, Iterable
 
-__all__ = ["Tensor", "TensorNetwork", "load_tn", "read_inds", "get_connected_components"]
+__all__ = ["Tensor", "TensorNetwork", "load_tn", "read_inds", "get_connected_components", "get_hyper_count",
+           "fuse", "contract"]
 
 
 @dataclass(frozen=True)
@@ -128,27 +129,151 @@ def get_connected_components(ts_inds) -> list[tuple[int, ...]]:
     return [tuple(v) for v in comps.values()]
 
 
+def get_hyper_count(ts_inds, output_inds=None) -> dict:
+    """index -> (number of tensors holding it) - 1, + 1 for an output index (tnco/utils/tn.py:572-595)."""
+    count = {}
+    for xs in ts_inds:
+        for x in xs:
+            count[x] = count.get(x, -1) + 1
+    for x in (output_inds or ()):
+        count[x] = count.get(x, 0) + 1
+    return count
+
+
+def fuse(ts_inds, dims, max_width, output_inds=None, *, exclude_inds=(), seed=None,
+         return_fused_inds: bool = False):
+    """Random pairwise pre-contraction of tensors while the result stays within `max_width`
+    (log2 of its size); returns the contraction path in linear form.
+
+    Behaviour of tnco/utils/tn.py:598-824, restated: indices that are still to be contracted are
+    drawn at random (`Random(seed).randrange` over the list of candidates, in order of first
+    appearance); two of the tensors holding the drawn index are drawn (`Random.sample`) and merged
+    unless the merged tensor would be wider than `max_width` or would hold an excluded index, in
+    which case the index is dropped from the candidates; an index that is still shared after a
+    merge (a hyper-index) goes back to the end of the candidate list.  The legs of a merged tensor
+    are ordered as they appear in the first, then in the second tensor.
+
+    Parity with the reference is by reading only: tnco.utils.tn cannot be imported in the build
+    image (more_itertools, opt_einsum, autoray are absent), so no vectors could be captured.
+    """
+    import math
+    import random
+    rng = random.Random(seed)
+    live = {t: tuple(xs) for t, xs in enumerate(ts_inds)}
+    every = list(dict.fromkeys(x for xs in live.values() for x in xs))  # first-appearance order
+    exclude = frozenset(exclude_inds)
+    if not exclude <= set(every):
+        raise ValueError("'exclude_inds' contains indices not in 'ts_inds'.")
+    try:
+        dims = dict.fromkeys(every, int(dims))
+    except (TypeError, ValueError):
+        dims = dict(dims)
+    if not set(every) <= dims.keys():
+        raise ValueError("'dims' is missing some indices.")
+    left = get_hyper_count(live.values())  # contractions each index still takes part in
+    if output_inds is None:
+        if any(c > 1 for c in left.values()):
+            raise ValueError("'output_inds' must be provided if 'ts_inds' has hyper-indices.")
+        output_inds = [x for x, c in left.items() if c == 0]
+    output = frozenset(output_inds)
+    if not output <= set(every):
+        raise ValueError("'output_inds' is not consistent with 'ts_inds'.")
+    holders = {}
+    for t, xs in live.items():
+        for x in xs:
+            holders.setdefault(x, set()).add(t)
+    candidates = [x for x in every if x not in exclude and left[x] != 0]
+    next_id = len(live)
+    merges = []
+    while candidates:
+        index = candidates.pop(rng.randrange(len(candidates)))
+        if not left.get(index):
+            continue
+        ta, tb = rng.sample(tuple(holders[index]), k=2)
+        xa, xb = live[ta], live[tb]
+        sa, sb = frozenset(xa), frozenset(xb)
+        if (sa | sb) & exclude:
+            continue
+        shared = sa & sb
+        still_shared = frozenset(x for x in shared if left[x] > 1)
+        keep = (sa ^ sb) | still_shared | (output & (sa | sb))
+        merged = tuple(dict.fromkeys(x for x in xa + xb if x in keep))
+        if sum(math.log2(dims[x]) for x in merged) > max_width:
+            continue
+        for x in shared:
+            left[x] -= 1
+        for x in merged:
+            holders[x] -= {ta, tb}
+            holders[x] |= {next_id}
+        for x in shared - still_shared - output:
+            del holders[x]
+        del live[ta], live[tb]
+        live[next_id] = merged
+        if left.get(index):
+            candidates.append(index)
+        merges.append((ta, tb, merged))
+        next_id += 1
+    # tensor ids -> positions in the shrinking list (every new tensor is appended last)
+    slots = list(range(next_id))
+    path, fused = [], []
+    for ta, tb, merged in merges:
+        lo, hi = sorted((ta, tb))
+        phi = slots.index(hi)
+        del slots[phi]
+        plo = slots.index(lo)
+        del slots[plo]
+        path.append((plo, phi))
+        fused.append(merged)
+    return (path, fused) if return_fused_inds else path
+
+
+def contract(path, ts_inds, output_inds=None, dims=None):
+    """Symbolic contraction along a linear path: (remaining tensors' indices, remaining output
+    indices) -- the `arrays=None` case of tnco/utils/tn.py:906-1072.  An index shared by the two
+    tensors survives while other tensors (or the output) still hold it."""
+    ts = [tuple(xs) for xs in ts_inds]
+    left = get_hyper_count(ts)
+    if output_inds is None:
+        if any(c > 1 for c in left.values()):
+            raise ValueError("'output_inds' must be provided if 'ts_inds' has hyper-indices.")
+        output_inds = [x for x, c in left.items() if c == 0]
+    output = frozenset(output_inds)
+    if not output <= {x for xs in ts for x in xs}:
+        raise ValueError("'output_inds' is not consistent with 'ts_inds'.")
+    for a, b in path:
+        a, b = sorted((a, b))
+        if a == b:
+            raise ValueError("'path' is not valid.")
+        yb = ts.pop(b)
+        xa = ts.pop(a)
+        shared = frozenset(xa) & frozenset(yb)
+        stay = frozenset(x for x in shared if left[x] > 1) | (output & shared)
+        for x in shared:
+            left[x] -= 1
+        ts.append(tuple(x for x in xa if x in stay) + tuple(x for x in xa if x not in shared)
+                  + tuple(y for y in yb if y not in shared))
+    return ts, output & {x for xs in ts for x in xs}
+
+
 _LINE = re.compile(r"^\d+(\s+\S+)*\s*$")
 
 
-def load_tn(obj: Any, *, fuse=None, decompose_hyper_inds: bool = False, output_index_token="*",
-            sparse_index_token="/", **unsupported) -> TensorNetwork:
-    """Index-list loader (the `load_tn` cases of tnco/app/app.py:438-492).
+def load_tn(obj: Any, *, fuse=4, decompose_hyper_inds: bool = True, output_index_token="*",
+            sparse_index_token="/", seed=None, **unsupported) -> TensorNetwork:
+    """Index-list loader (the `load_tn` cases of tnco/app/app.py:438-492) + pre-fusing.
 
-    `fuse` (default 4 in the reference, app.py:156) and `decompose_hyper_inds` are front-end
-    transformations outside this build's scope: only falsy values are accepted.
+    `fuse` (default 4, app.py:156): tensors are pre-contracted at random while no intermediate
+    exceeds that width; `tn.tags['fuse_path']` holds the path (app.py:373-414).  Arrays are not
+    part of this build, so hyper-indices are never decomposed: like the reference without arrays
+    (app.py:339-343) a warning is emitted when the network has hyper-indices.
     """
     unsupported = {k: v for k, v in unsupported.items()
-                   if k not in ("atol", "dtype", "backend", "seed", "verbose", "simplify_circuit",
+                   if k not in ("atol", "dtype", "backend", "verbose", "simplify_circuit",
                                 "initial_state", "final_state")}
     if unsupported:
         raise TypeError(f"Got unexpected keyword arguments: {sorted(unsupported)}")
-    if fuse:
-        raise NotImplementedError("pre-fusing tensors (fuse > 0) is not part of this build; pass fuse=None.")
-    if decompose_hyper_inds:
-        raise NotImplementedError("hyper-index decomposition is not part of this build.")
     if isinstance(obj, TensorNetwork):
-        return obj
+        return _fused(obj, fuse, decompose_hyper_inds, seed)
     if isinstance(obj, str):
         lines = [ln for ln in obj.splitlines() if ln.strip() and not ln.lstrip().startswith("#")]
         if not lines or not all(_LINE.match(ln.strip()) for ln in lines):
@@ -162,5 +287,33 @@ def load_tn(obj: Any, *, fuse=None, decompose_hyper_inds: bool = False, output_i
         raise TypeError("'obj' is not recognized.")
     tensor_map, dims, output_inds, sparse_inds = read_inds(
         dict(enumerate(obj)), output_index_token=output_index_token, sparse_index_token=sparse_index_token)
-    return TensorNetwork((Tensor(xs, [dims[x] for x in xs], tags=dict(name=name)) for name, xs in tensor_map.items()),
-                         output_inds=output_inds, sparse_inds=sparse_inds)
+    tn = TensorNetwork((Tensor(xs, [dims[x] for x in xs], tags=dict(name=name)) for name, xs in tensor_map.items()),
+                       output_inds=output_inds, sparse_inds=sparse_inds)
+    return _fused(tn, fuse, decompose_hyper_inds, seed)
+
+
+def _fused(tn: TensorNetwork, fuse_width, decompose_hyper_inds, seed) -> TensorNetwork:
+    """The TensorNetwork branch of load_tn (tnco/app/app.py:314-420) for networks without arrays."""
+    import warnings
+    if tn.sparse_inds and (decompose_hyper_inds or fuse_width):
+        warnings.warn("The decomposition of hyper-indices and the fusion of indices is not yet supported "
+                      "if there are sparse indices")
+        decompose_hyper_inds, fuse_width = False, False
+    if decompose_hyper_inds and len(tn):
+        warnings.warn("Cannot decompose hyper-indices if not all arrays are provided.")
+    if fuse_width is None or not fuse_width > 0:
+        return tn
+    if "fuse_path" in tn.tags:
+        raise ValueError("'TensorNetwork' has already the tag 'fuse_path'.")
+    dims = tn.dims
+    path = fuse(tn.ts_inds, dims, max_width=fuse_width, output_inds=tn.output_inds, seed=seed)
+    ts_inds, output_inds = contract(path, tn.ts_inds, tn.output_inds, dims=dims)
+    ts_tags = [t.tags or None for t in tn.tensors]
+    for a, b in map(sorted, path):
+        tb = ts_tags.pop(b)
+        ta = ts_tags.pop(a)
+        ts_tags.append(tb if ta is None else ta if tb is None else dict(x=ta, y=tb))
+    tags = dict(tn.tags)
+    tags["fuse_path"] = path
+    return TensorNetwork((Tensor(xs, [dims[x] for x in xs], tags=tg or {}) for xs, tg in zip(ts_inds, ts_tags)),
+                         output_inds=output_inds, sparse_inds=tn.sparse_inds, tags=tags)

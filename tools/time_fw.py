@@ -1,0 +1,50 @@
+"""Throughput of the finite-width kernels on the BASELINE config-5 topology (Sycamore-53-style
+depth-20 circuit, 541 tensors, 923 indices), memory-constrained.
+
+    python tools/time_fw.py [--replicas 4096] [--sweeps 100] [--max-width 40]
+"""
+import argparse
+import pathlib
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+from tnco_amd import core, ctree, synthetic  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--replicas", type=int, default=4096)
+    ap.add_argument("--sweeps", type=int, default=100)
+    ap.add_argument("--max-width", type=float, default=40)
+    ap.add_argument("--update-slices", type=int, default=10)
+    ap.add_argument("--depth", type=int, default=20)
+    a = ap.parse_args()
+    ts, dims, out = synthetic.sycamore53_tn(a.depth)
+    n_inds = 1 + max(i for xs in ts for i in xs)
+    lm = ctree.pack_masks(ts, n_inds)
+    seeds = np.arange(1, a.replicas + 1, dtype=np.uint32)
+    t0 = time.perf_counter()
+    links = core.random_trees(ts, n_inds, seeds)
+    t1 = time.perf_counter()
+    opt = core.BatchedOptimizer(lm, links, seeds, n_inds=n_inds, max_width=a.max_width)
+    opt.sync()
+    t2 = time.perf_counter()
+    betas = np.linspace(0, 100, a.sweeps)
+    opt.run(betas, update_slices_every=a.update_slices)
+    opt.sync()
+    t3 = time.perf_counter()
+    c = opt.counters()
+    tot, mn = opt.costs()
+    print(f"{len(ts)} tensors, {n_inds} indices, {a.replicas} replicas, max_width {a.max_width}")
+    print(f"initial trees {t1 - t0:.2f} s, create (incl. initial slicing) {t2 - t1:.2f} s, "
+          f"{a.sweeps} sweeps {t3 - t2:.2f} s")
+    print(f"moves {c['moves']:.3e}  accepted {c['accepted'] / max(c['moves'], 1):.3f}  "
+          f"-> {c['moves'] / (t3 - t2):.3e} move-evals/s;  best log2(cost) {np.log2(mn.min()):.2f}, "
+          f"slices of the best: {int(np.unpackbits(opt.slices(int(mn.argmin()))[1].view(np.uint8)).sum())}")
+
+
+if __name__ == "__main__":
+    main()
