@@ -217,3 +217,38 @@ def test_invalid_inputs(core):
     with pytest.raises(ValueError, match="Contraction is not valid"):
         core.BatchedOptimizer(lm, lk, [1], n_inds=3)
     core.BatchedOptimizer(lm, lk, [1], n_inds=3, disable_shared_inds=True).close()
+
+
+def test_c3_full_size_properties(core, oracle_lib):
+    """BASELINE config 3 at FULL size (512 leaves, 65 536 replicas): size-independent properties
+    the reference's own tests assert (tests/test_utils.py:575-769) -- every replica is_valid() on the
+    device (tree links, leg masks and both caches against a from-scratch rebuild), min <= cur, a
+    greedy run never increases the cost, chunked launches == one launch -- plus bit-exact agreement
+    of a sample of replicas spread over the whole batch with the oracle."""
+    prob = H.regular_problem(512, graph_seed=11)
+    R = 65536
+    seeds = H.replica_seeds(R)
+    links = core.random_trees(prob.ts_inds, prob.n_inds, seeds)
+    betas = H.linear_betas(0, 100, 60)
+    gpu = core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds)
+    tot0, mn0 = gpu.costs()
+    gpu.run(betas[:25])
+    gpu.run(betas[25:])
+    assert gpu.validate() == (0, -1)
+    tot, mn = gpu.costs()
+    assert np.all(mn <= tot) and np.all(mn <= mn0) and np.all(np.isfinite(tot))
+    c, ids = gpu.best(16)
+    assert np.all(np.diff(c) >= 0) and c[0] == mn.min() and mn[ids[0]] == c[0]
+    for r in list(range(0, R, R // 24)) + [R - 1]:
+        o = H.make_oracle(oracle_lib, prob, links[r], seeds[r])
+        o.run(oracle_lib.PROB_MH, betas)
+        H.assert_replica_equal(gpu, r, o)
+        assert tot[r] == o.total_cost and mn[r] == o.min_total_cost
+    # one launch of the whole schedule on a fresh handle gives the same batch
+    one = core.BatchedOptimizer(prob.leaf_masks, links[:4096], seeds[:4096], n_inds=prob.n_inds)
+    one.run(betas)
+    assert np.array_equal(one.costs()[0], tot[:4096]) and np.array_equal(one.costs()[1], mn[:4096])
+    # greedy from here: the cost of no replica goes up
+    gpu.run(np.zeros(10), "greedy")
+    tot2, mn2 = gpu.costs()
+    assert np.all(tot2 <= tot) and np.all(mn2 <= mn) and gpu.validate() == (0, -1)

@@ -144,12 +144,12 @@ __device__ __forceinline__ uint32_t fw_uniform_int(Rng<LOG2L>& rng, uint32_t hi)
 
 // std::shuffle of /usr/include/c++/11/bits/stl_algo.h:3706-3792 on a scratch array (n < 65536: two
 // swap positions per variate).  Executed redundantly by every lane of the group; lane 0 writes.
-template <int LOG2L>
-__device__ __forceinline__ void fw_shuffle(Rng<LOG2L>& rng, volatile int16_t* a, int n, bool lane0) {
+template <int LOG2L, typename A>
+__device__ __forceinline__ void fw_shuffle(Rng<LOG2L>& rng, A a, int n, bool lane0) {
   if (n <= 1) return;
   int i = 1;
   auto swp = [&](int x, int y) {
-    const int16_t ax = a[x], ay = a[y];
+    const int ax = a[x], ay = a[y];
     if (lane0) { a[x] = ay; a[y] = ax; }
   };
   if ((n % 2) == 0) {
@@ -245,10 +245,17 @@ __device__ __forceinline__ void fw_set_node_width(const FwParams& F, const View<
   else w64[p] = w;
 }
 
-// positions of `cand`, ascending (Bitset::positions), into pos[]; returns their number
-template <int LOG2L, int K, bool HYPER>
-__device__ __forceinline__ uint32_t fw_positions(const View<LOG2L, K, HYPER>& v, const Mask<K>& cand,
-                                                 volatile int16_t* pos, int gbase, bool lane0, int32_t* status) {
+// number of set positions of `cand` over the group
+template <int LOG2L, int K>
+__device__ __forceinline__ uint32_t fw_count(const Mask<K>& cand) {
+  return gsum<LOG2L>(mpopc<K>(cand));
+}
+
+// positions of `cand`, ascending (Bitset::positions), into pos[] (at most `cap`; global scratch or
+// LDS); returns their number
+template <int LOG2L, int K, bool HYPER, typename A>
+__device__ __forceinline__ uint32_t fw_positions(const View<LOG2L, K, HYPER>& v, const Mask<K>& cand, A pos,
+                                                 uint32_t cap, int gbase, bool lane0, int32_t* status) {
   constexpr int L = 1 << LOG2L;
   uint32_t np = 0;
 #pragma unroll
@@ -264,26 +271,28 @@ __device__ __forceinline__ uint32_t fw_positions(const View<LOG2L, K, HYPER>& v,
     uint64_t x = cand.w[k];
     while (x) {
       const int b = __ffsll((unsigned long long)x) - 1;
-      if (o < (uint32_t)FW_MAXPOS) pos[o] = (int16_t)(v.widx(k) * 64 + b);
+      if (o < cap) pos[o] = (int16_t)(v.widx(k) * 64 + b);
       ++o;
       x &= x - 1;
     }
     np += tot;
   }
-  if (np > (uint32_t)FW_MAXPOS) {
+  if (np > cap) {
     if (lane0) *status = 1;
-    np = FW_MAXPOS;
+    np = cap;
   }
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
   return np;
 }
 
+constexpr int FW_LDSPOS = 128;  // candidate legs per tensor that fit the LDS fast path
+
 // get_slices_impl, finite_width/greedy/utils.hpp:21-125.  `pos` = scratch of the group.
 template <int LOG2L, int K, bool HYPER>
 __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
                                                  const double* w64, Rng<LOG2L>& rng, const int32_t* order,
-                                                 int32_t* n_big, volatile int16_t* pos, bool lane0, int gbase,
-                                                 int32_t* status) {
+                                                 int32_t* n_big, volatile int16_t* pos, lds_vi32* lpos, bool lane0,
+                                                 int gbase, int32_t* status) {
   constexpr int L = 1 << LOG2L;
   const int N = P.N, lig = v.lig;
   Mask<K> slices = mzero<K>();
@@ -318,7 +327,37 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
     double sliced_width = fw_width<LOG2L, K>(P, F, sliced_xs, lig, gbase);
     if (!(sliced_width > F.max_width)) continue;
     // candidate positions, ascending
-    uint32_t np = fw_positions<LOG2L, K, HYPER>(v, mandn<K>(sliced_xs, skip), pos, gbase, lane0, status);
+    const Mask<K> cand = mandn<K>(sliced_xs, skip);
+    if (F.log2dims == nullptr && fw_count<LOG2L, K>(cand) <= (uint32_t)FW_LDSPOS) {
+      // Fast path (uniform dims, the usual number of candidates): the candidate list lives in LDS.
+      // Same draws, same order: shuffle, then the keys are attached ((n_big << 16) | position) and
+      // every pick is a scan shared by the lanes of the group + one DPP max; a taken entry keeps
+      // key 0 (a candidate's key is >= 1: the tensor itself is too wide).
+      const uint32_t np = fw_positions<LOG2L, K, HYPER>(v, cand, lpos, (uint32_t)FW_LDSPOS, gbase, lane0, status);
+      fw_shuffle<LOG2L>(rng, lpos, (int)np, lane0);
+      for (uint32_t q = (uint32_t)lig; q < np; q += L) {
+        const int xp = lpos[q];
+        lpos[q] = (n_big[xp] << 16) | xp;
+      }
+      for (uint32_t taken = 0; taken < np; ++taken) {
+        uint32_t best = 0;
+        for (uint32_t q = (uint32_t)lig; q < np; q += L) {
+          const uint32_t key = (uint32_t)lpos[q] >> 16;
+          const uint32_t c = (key << 16) | (0xFFFFu - q);
+          if (key != 0u && c > best) best = c;
+        }
+        best = gmax<LOG2L>(best);
+        const uint32_t qb = 0xFFFFu - (best & 0xFFFFu);
+        const int xpos = lpos[qb] & 0xFFFF;
+        if (lane0) lpos[qb] = xpos;
+        fw_flip<LOG2L, K, HYPER>(v, slices, xpos);
+        sliced_width = fw_wr(F, sliced_width + fw_delta_width<LOG2L, K, HYPER>(P, F, v, sliced_xs, xpos, gbase));
+        fw_flip<LOG2L, K, HYPER>(v, sliced_xs, xpos);
+        if (sliced_width <= F.max_width) break;
+      }
+      continue;
+    }
+    uint32_t np = fw_positions<LOG2L, K, HYPER>(v, cand, pos, (uint32_t)FW_MAXPOS, gbase, lane0, status);
     // :80  std::shuffle(positions, prng)
     fw_shuffle<LOG2L>(rng, pos, (int)np, lane0);
     // :83-101  stable_sort with `greater` (:50-60: more too-wide tensors first; with per-index dims
@@ -368,12 +407,14 @@ __global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwPa
   constexpr int LK = L * K;
   using R = Rng<LOG2L>;
   __shared__ uint32_t rngbuf[GPB * R::RING];
+  __shared__ int32_t posbuf[GPB * FW_LDSPOS];
   const int tid = threadIdx.x;
   const int lig = tid & (L - 1);
   const int gib = tid >> LOG2L;
   const int gbase = (tid & 63) & ~(L - 1);
   const int64_t r = (int64_t)blockIdx.x * GPB + gib;
   if (r >= P.R) return;
+  lds_vi32* lpos = (lds_vi32*)posbuf + gib * FW_LDSPOS;
   const bool lane0 = lig == 0;
   const int n = P.n, N = P.N;
   View<LOG2L, K, HYPER> v;
@@ -397,7 +438,7 @@ __global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwPa
     for (int k = 0; k < K; ++k) slices.w[k] = a.slices_in[v.widx(k)];
   } else {
     volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + 3 * N + F.I64);
-    slices = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, n_big, pos, lane0, gbase, F.status + r);
+    slices = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, n_big, pos, lpos, lane0, gbase, F.status + r);
   }
   double sum = 0;
   const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, order, slices, cc_new, part_new, lane0, gbase, &sum);
@@ -432,12 +473,14 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
   using M = Mask<K>;
   using R = Rng<LOG2L>;
   __shared__ uint32_t rngbuf[GPB * R::RING];
+  __shared__ int32_t posbuf[GPB * FW_LDSPOS];
   const int tid = threadIdx.x;
   const int lig = tid & (L - 1);
   const int gib = tid >> LOG2L;
   const int gbase = (tid & 63) & ~(L - 1);
   const int64_t r = (int64_t)blockIdx.x * GPB + gib;
   if (r >= P.R || n_steps <= 0) return;
+  lds_vi32* lpos = (lds_vi32*)posbuf + gib * FW_LDSPOS;
   const bool lane0 = lig == 0;
   const int n = P.n, N = P.N;
   const int f32 = P.f32;
@@ -546,8 +589,8 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
         // :226-321  slice up to max_number_new_slices random further legs of the new B; if it then
         // fits, try the rotation against a FULL rebuild of the cost cache with the new slices
         M new_slices = slices;
-        uint32_t n_pos = fw_positions<LOG2L, K, HYPER>(v, mandn<K>(mandn<K>(newB, slices), skip), pos, gbase, lane0,
-                                                       F.status + r);
+        uint32_t n_pos = fw_positions<LOG2L, K, HYPER>(v, mandn<K>(mandn<K>(newB, slices), skip), pos,
+                                                       (uint32_t)FW_MAXPOS, gbase, lane0, F.status + r);
         int64_t n_new = 0;
         while (n_new < F.max_new_slices && new_sliced_width_B > F.max_width && n_pos > 0) {
           const uint32_t j = rng.next_sync() % n_pos;  // :245
@@ -625,7 +668,8 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
     const bool do_slices = update_every > 0 && ((step_offset + step) % update_every) == 0;
     if (do_slices && gany<LOG2L>(mnonzero<K>(slices))) {
       fw_traverse<LOG2L, K, HYPER>(v, N, order, stack, visited, lane0);
-      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, n_big, pos, lane0, gbase, F.status + r);
+      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, n_big, pos, lpos, lane0, gbase,
+                                                  F.status + r);
       double sum;
       const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, order, ns, cc_new, part_new, lane0, gbase, &sum);
       if (tot < v.hdr(N - 1)->partial) {

@@ -255,6 +255,19 @@ __device__ __forceinline__ uint32_t gsum(uint32_t v) {
   return v;
 }
 
+// Maximum of v over the lanes of the group, result in every lane.
+template <int LOG2L>
+__device__ __forceinline__ uint32_t gmax(uint32_t v) {
+  auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+  if constexpr (LOG2L >= 1) v = mx(v, dpp<TNCO_DPP_XOR1>(v));
+  if constexpr (LOG2L >= 2) v = mx(v, dpp<TNCO_DPP_XOR2>(v));
+  if constexpr (LOG2L >= 3) v = mx(v, dpp<TNCO_DPP_HALF_MIRROR>(v));
+  if constexpr (LOG2L >= 4) v = mx(v, dpp<TNCO_DPP_MIRROR>(v));
+  if constexpr (LOG2L >= 5) v = mx(v, (uint32_t)__shfl_xor((int)v, 16));
+  if constexpr (LOG2L >= 6) v = mx(v, (uint32_t)__shfl_xor((int)v, 32));
+  return v;
+}
+
 template <int LOG2L>
 __device__ __forceinline__ bool gany(bool p) {
   return gsum<LOG2L>(p ? 1u : 0u) != 0u;

@@ -42,6 +42,7 @@ namespace tnco {
 // flat_load / flat_store, which counts in vmcnt and drags an `s_waitcnt vmcnt(0)` behind it.
 #define TNCO_LDS __attribute__((address_space(3)))
 typedef TNCO_LDS volatile uint32_t lds_vu32;
+typedef TNCO_LDS volatile int32_t lds_vi32;
 
 __device__ __forceinline__ uint32_t mt_temper(uint32_t z) {
   z ^= (z >> 11);
@@ -311,7 +312,6 @@ __global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : TNCO_WAVES_PER_SIMD)) void s
   bool jinvalid = P.rs[r].jinvalid != 0;
   // The tail of the rotation log is assembled in LDS and written 16 entries at a time: HBM writes
   // whole 64-byte pieces, a 4-byte append evicted on its own is a read-modify-write there.
-  typedef TNCO_LDS volatile int32_t lds_vi32;
   auto jb = [&](int i) -> lds_vi32& { return *((lds_vi32*)jbuf + (threadIdx.x >> LOG2L) * 16 + i); };
   // (recomputed at every use, opaquely: as a loop invariant it would be spilled and its reload
   // would put a vmcnt(0) wait into the store phase)
