@@ -8,7 +8,8 @@
 //
 // This version favours exactness over speed: every move reads its operands from memory (no
 // staging), and the re-slice (greedy/utils.hpp:21-125) + full CostCache rebuild
-// (greedy/optimizer.hpp:359-376) walk the whole tree serially per replica, as the reference does.
+// (greedy/optimizer.hpp:359-376) walk the whole tree serially per replica, as the reference does
+// (post-order by walking the links, candidate legs of a tensor shuffled and picked in LDS).
 // Covered: SimpleCostModel and SimpleSparseIndsCostModel (finite_width/cost_model/simple.hpp,
 // simple_sparse_inds.hpp), uniform and per-index dims, width_type float32 / float64, and the
 // max_number_new_slices > 0 branch (greedy/optimizer.hpp:226-321).
@@ -168,40 +169,48 @@ __device__ __forceinline__ void fw_shuffle(Rng<LOG2L>& rng, A a, int n, bool lan
   }
 }
 
-// Post-order of include/tnco/utils.hpp:34-51 into order[N] (explicit stack in scratch).
+// Post-order of include/tnco/utils.hpp:34-51 (child 0's subtree, child 1's subtree, the node) into
+// order[N], by walking the links: the successor of x is its parent if x is the right child, else the
+// left-most leaf below its sibling.  No stack, no stores to wait for.
 template <int LOG2L, int K, bool HYPER>
-__device__ __forceinline__ void fw_traverse(const View<LOG2L, K, HYPER>& v, int N, int32_t* order,
-                                            int32_t* stack, int32_t* visited, bool lane0) {
-  constexpr int L = 1 << LOG2L;
-  for (int i = v.lig; i < N; i += L) visited[i] = 0;
-  if (lane0) stack[0] = N - 1;
-  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  int sp = 1, cnt = 0;
-  while (sp > 0) {
-    const int pos = stack[sp - 1];
-    const int l = v.left(pos);
-    if (visited[pos] || l < 0) {
-      --sp;
-      if (lane0) order[cnt] = pos;
-      ++cnt;
-    } else {
-      const int rr = v.right(pos);
-      if (lane0) { visited[pos] = 1; stack[sp] = rr; stack[sp + 1] = l; }
-      sp += 2;
-    }
-    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+__device__ __forceinline__ void fw_traverse(const View<LOG2L, K, HYPER>& v, int N, int32_t* order, bool lane0) {
+  int x = N - 1;
+  for (;;) {
+    const int l = v.left(x);
+    if (l < 0) break;
+    x = l;
   }
+  int cnt = 0;
+  for (;;) {
+    if (lane0) order[cnt] = x;
+    ++cnt;
+    const int p = v.parent(x);
+    if (p < 0) break;
+    const int rr = v.right(p);
+    if (rr == x) {
+      x = p;
+      continue;
+    }
+    x = rr;
+    for (;;) {
+      const int l = v.left(x);
+      if (l < 0) break;
+      x = l;
+    }
+  }
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // CostCache(ctree, ccost, slices) (finite_width/utils.hpp:36-47) into scratch; returns
 // partial[root]; *sum = get_cost (finite_width/utils.hpp:24-33).  The contraction cost is taken
-// over in1 | in2 | slices (finite_width/cost_model/simple.hpp:139-144).
+// over in1 | in2 | slices (finite_width/cost_model/simple.hpp:139-144).  The chain of partial sums
+// is lane 0's alone (its own stores, its own loads: no wait between nodes).
 template <int LOG2L, int K, bool HYPER>
 __device__ __forceinline__ double fw_rebuild(const Params& P, const View<LOG2L, K, HYPER>& v, const int32_t* order,
                                              const Mask<K>& slices, double* cc_new, double* part_new, bool lane0,
                                              int gbase, double* sum) {
   const int n = P.n, N = P.N;
-  double s = 0.0;
+  double s = 0.0, part = 0.0;
   for (int i = 0; i < N; ++i) {
     const int p = order[i];
     const int l = v.left(p);
@@ -209,14 +218,18 @@ __device__ __forceinline__ double fw_rebuild(const Params& P, const View<LOG2L, 
     const int rr = v.right(p);
     const Mask<K> u = mor<K>(mor<K>(v.mask(l), v.mask(rr)), slices);
     const double c = generic_cost<LOG2L, K>(P, u, v.lig, gbase);
-    const double pl = l < n ? 0.0 : part_new[l], pr = rr < n ? 0.0 : part_new[rr];
-    const double part = rnd_cost(rnd_cost(c + pl, P.f32) + pr, P.f32);
     s = rnd_cost(s + c, P.f32);
-    if (lane0) { cc_new[p] = c; part_new[p] = part; }
-    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane0) {
+      const double pl = l < n ? 0.0 : part_new[l], pr = rr < n ? 0.0 : part_new[rr];
+      part = rnd_cost(rnd_cost(c + pl, P.f32) + pr, P.f32);
+      cc_new[p] = c;
+      part_new[p] = part;
+    }
   }
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
   *sum = s;
-  return part_new[N - 1];
+  const int lo = __shfl(__double2loint(part), gbase), hi = __shfl(__double2hiint(part), gbase);
+  return __hiloint2double(hi, lo);
 }
 
 template <int LOG2L, int K, bool HYPER>
@@ -423,7 +436,7 @@ __global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwPa
   R rng;
   rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
   int32_t* si = F.scratch_i + r * (int64_t)(3 * N + F.I64 + FW_MAXPOS / 2);
-  int32_t *order = si, *stack = si + N, *visited = si + 2 * N, *n_big = si + 3 * N;
+  int32_t *order = si, *n_big = si + 3 * N;
   double* cc_new = F.scratch_d + r * 2 * (int64_t)N;
   double* part_new = cc_new + N;
   double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
@@ -431,7 +444,7 @@ __global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwPa
   for (int p = n; p < N; ++p)
     fw_set_node_width<LOG2L, K, HYPER>(F, v, w64, p, fw_width<LOG2L, K>(P, F, v.mask(p), lig, gbase), lane0);
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  fw_traverse<LOG2L, K, HYPER>(v, N, order, stack, visited, lane0);
+  fw_traverse<LOG2L, K, HYPER>(v, N, order, lane0);
   Mask<K> slices;
   if (a.slices_in) {
 #pragma unroll
@@ -490,7 +503,7 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
   R rng;
   rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
   int32_t* si = F.scratch_i + r * (int64_t)(3 * N + F.I64 + FW_MAXPOS / 2);
-  int32_t *order = si, *stack = si + N, *visited = si + 2 * N, *n_big = si + 3 * N;
+  int32_t *order = si, *n_big = si + 3 * N;
   volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + 3 * N + F.I64);
   double* cc_new = F.scratch_d + r * 2 * (int64_t)N;
   double* part_new = cc_new + N;
@@ -617,7 +630,7 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
           }
           v.set_mask(B, newB);
           __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          fw_traverse<LOG2L, K, HYPER>(v, N, order, stack, visited, lane0);
+          fw_traverse<LOG2L, K, HYPER>(v, N, order, lane0);
           double sum;
           const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, order, new_slices, cc_new, part_new, lane0, gbase, &sum);
           const double delta = rnd_cost(tot - total, f32);
@@ -667,7 +680,7 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
     // :360-376
     const bool do_slices = update_every > 0 && ((step_offset + step) % update_every) == 0;
     if (do_slices && gany<LOG2L>(mnonzero<K>(slices))) {
-      fw_traverse<LOG2L, K, HYPER>(v, N, order, stack, visited, lane0);
+      fw_traverse<LOG2L, K, HYPER>(v, N, order, lane0);
       const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, n_big, pos, lpos, lane0, gbase,
                                                   F.status + r);
       double sum;
