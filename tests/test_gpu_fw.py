@@ -45,6 +45,9 @@ def _check(core, orc, prob, seeds, betas, max_width, chunks, every=10, **kw):
         assert np.array_equal(gs, os_), f"replica {r} slices"
         assert np.array_equal(gms, oms), f"replica {r} min_slices"
         assert tot[r] == o.total_cost and mn[r] == o.min_total_cost
+    # is_valid of every replica on the device (finite_width/greedy/optimizer.hpp:392-444): the
+    # infinite-memory checks with the sliced cost cache, widths after slicing, the width cache
+    assert gpu.validate() == (0, -1)
     return gpu
 
 

@@ -729,4 +729,41 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
   }
 }
 
+// is_valid of the finite-width optimizer, the part on top of the infinite-memory checks
+// (finite_width/greedy/optimizer.hpp:404-444): every tensor of the tree in `ref` (blocks rebuilt
+// from scratch by build_kernel) fits max_width once the sliced indices are removed, and -- for the
+// current tree -- the cached widths are the recomputed ones.
+template <int LOG2L, int K, bool HYPER>
+__global__ __launch_bounds__(256) void fw_check_kernel(const Params P, const FwParams F, const BuildArgs a,
+                                                       const int which_min, const double atol, int32_t* out_bad) {
+  constexpr int L = 1 << LOG2L;
+  constexpr int GPB = 256 >> LOG2L;
+  constexpr int LK = L * K;
+  const int tid = threadIdx.x;
+  const int lig = tid & (L - 1);
+  const int gbase = (tid & 63) & ~(L - 1);
+  const int64_t q = (int64_t)blockIdx.x * GPB + (tid >> LOG2L);
+  if (q >= a.count) return;
+  const int64_t r = a.r0 + q;
+  const int n = P.n, N = P.N;
+  View<LOG2L, K, HYPER> ref, cur;
+  ref.init(P, a.out_blocks + q * (int64_t)(n - 1) * P.BS, a.out_lpar + q * (int64_t)n * LPS, lig);
+  cur.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n * LPS, lig);
+  const double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
+  Mask<K> sl;
+#pragma unroll
+  for (int k = 0; k < K; ++k) sl.w[k] = F.slices[r * 2 * (int64_t)LK + (which_min ? LK : 0) + ref.widx(k)];
+  int bad = 0;
+  for (int t = 0; t < N; ++t) {
+    const Mask<K> m = ref.mask(t);
+    if (fw_width<LOG2L, K>(P, F, mandn<K>(m, sl), lig, gbase) > F.max_width) bad = bad ? bad : 35;
+    if (!which_min && t >= n) {
+      const double w = fw_width<LOG2L, K>(P, F, m, lig, gbase);
+      const double c = F.width_f32 ? (double)__int_as_float(cur.hdr(t)->pad) : w64[t];
+      if (!(fabs(w - c) <= atol)) bad = bad ? bad : 36;
+    }
+  }
+  if (lig == 0 && bad && out_bad[q] == 0) out_bad[q] = bad;
+}
+
 }  // namespace tnco

@@ -379,6 +379,9 @@ struct BuildArgs {
   int32_t* out_status;         // [count]
   int64_t r0;                  // first replica handled by this launch
   int64_t count;
+  // finite width: legs OR-ed into every contraction (sliced indices; finite_width/utils.hpp:36-47),
+  // [LK] words per replica at cost_slices + r * cost_slices_stride; NULL: none
+  const uint64_t* cost_slices; int64_t cost_slices_stride;
 };
 
 template <int LOG2L, int K, bool HYPER>
@@ -496,6 +499,11 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
   }
 
   // -- validity, hyper cache, cost caches ----------------------------------
+  M csl = mzero<K>();
+  if (a.cost_slices) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) csl.w[k] = a.cost_slices[r * a.cost_slices_stride + v.widx(k)];
+  }
   double sum = 0.0;
   for (int i = 0; i < N; ++i) {
     const int p = order[i];
@@ -507,7 +515,7 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
     if (!P.disable_shared && !gany<LOG2L>(mnonzero<K>(mand<K>(ia, ib)))) status = status ? status : 10;
     if (gany<LOG2L>(mnonzero<K>(mor<K>(mandn<K>(mxor<K>(ia, ib), ip), mandn<K>(ip, uni))))) status = status ? status : 11;
     v.set_hyper(p, mand<K>(ip, mand<K>(ia, ib)));
-    const double c = generic_cost<LOG2L, K>(P, uni, lig, gbase);
+    const double c = generic_cost<LOG2L, K>(P, mor<K>(uni, csl), lig, gbase);
     const double part = rnd_cost(rnd_cost(c + v.partial(l), P.f32) + v.partial(rr), P.f32);  // utils.hpp:54
     sum = rnd_cost(sum + c, P.f32);                                                          // utils.hpp:112
     if (lane0) { v.hdr(p)->ccost = c; v.hdr(p)->partial = part; }

@@ -204,6 +204,21 @@ void launch_fw_init_lk(tnco_hip_ctx* h, const FwInitArgs& a) {
   else
     hipLaunchKernelGGL((fw_init_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, a);
 }
+template <int LOG2L, int K>
+void launch_fw_check_lk(tnco_hip_ctx* h, const BuildArgs& a, int which_min, double atol, int32_t* out_bad) {
+  const int gpb = 256 >> LOG2L;
+  dim3 grid((unsigned)((a.count + gpb - 1) / gpb));
+  if (h->hyper)
+    hipLaunchKernelGGL((fw_check_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, h->F, a, which_min, atol, out_bad);
+  else
+    hipLaunchKernelGGL((fw_check_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, a, which_min, atol, out_bad);
+}
+void launch_fw_check(tnco_hip_ctx* h, const BuildArgs& a, int which_min, double atol, int32_t* out_bad) {
+#define CALL_FWC(LL, KK) launch_fw_check_lk<LL, KK>(h, a, which_min, atol, out_bad)
+  DISPATCH_LK(h, CALL_FWC)
+#undef CALL_FWC
+}
+
 void launch_fw_init(tnco_hip_ctx* h, const FwInitArgs& a) {
 #define CALL_FWI(LL, KK) launch_fw_init_lk<LL, KK>(h, a)
   DISPATCH_LK(h, CALL_FWI)
@@ -875,8 +890,8 @@ int tnco_hip_get_caches(tnco_hip_handle h, int64_t r, double* ccost, double* par
 
 int tnco_hip_validate(tnco_hip_handle h, double atol, int64_t* n_bad, int64_t* first_bad) {
   if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
-  if (h->fw) return fail(TNCO_HIP_ENOTIMPL, "validate() is not available for finite-width handles yet.");
   const Params& P = h->P;
+  const int64_t LK = (int64_t)h->L * h->K;
   const int n = P.n, N = P.N;
   const int64_t R = P.R;
   HIP_TRY(hipSetDevice(h->device));
@@ -907,15 +922,27 @@ int tnco_hip_validate(tnco_hip_handle h, double atol, int64_t* n_bad, int64_t* f
     a.out_total = ttot; a.out_sum = tsum; a.out_status = tstat; a.r0 = r0; a.count = cnt;
     // (1) current tree: rebuild everything and compare
     a.src_live = 1;
+    if (h->fw) { a.cost_slices = h->F.slices; a.cost_slices_stride = 2 * LK; }
     launch_build(h, a);
     launch_compare(h, a, atol, tbad);
+    if (h->fw) launch_fw_check(h, a, 0, atol, tbad);
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(hb.data(), tbad, (size_t)cnt * 4, hipMemcpyDeviceToHost));
     // (2) best tree (checkpoint + rotation log): its cost must match min_total_cost
     hipLaunchKernelGGL(materialize_min_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, h->stream, P, tlinks, r0, cnt);
     a.src_live = 0;
     a.src_links = tlinks;
+    if (h->fw) { a.cost_slices = h->F.slices + LK; a.cost_slices_stride = 2 * LK; }
     launch_build(h, a);
+    if (h->fw) {  // the widths of the best tree, against min_slices
+      HIP_TRY(hipMemsetAsync(tbad, 0, (size_t)cnt * 4, h->stream));
+      launch_fw_check(h, a, 1, atol, tbad);
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      std::vector<int32_t> hb2((size_t)cnt);
+      HIP_TRY(hipMemcpy(hb2.data(), tbad, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+      for (int64_t q = 0; q < cnt; ++q)
+        if (hb2[q]) hb[q] = hb[q] ? hb[q] : hb2[q];
+    }
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(hs.data(), tstat, (size_t)cnt * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(hsum.data(), tsum, (size_t)cnt * 8, hipMemcpyDeviceToHost));
