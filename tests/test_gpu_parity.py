@@ -219,6 +219,18 @@ def test_invalid_inputs(core):
     core.BatchedOptimizer(lm, lk, [1], n_inds=3, disable_shared_inds=True).close()
 
 
+def test_precision_too_low(core, oracle_lib):
+    """optimizer.hpp:77-84: a total cost whose log2 is not finite (here: float32 overflow on a
+    512-leaf random tree, costs ~2^150) is refused at construction, by the oracle and by the GPU path."""
+    prob = H.regular_problem(512, graph_seed=11)
+    seeds = H.replica_seeds(2)
+    links = prob.links(seeds)
+    with pytest.raises(ValueError, match="Precision is too low."):
+        H.make_oracle(oracle_lib, prob, links[0], seeds[0], cost_type="float32")
+    with pytest.raises(ValueError, match="Precision is too low."):
+        core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, cost_type="float32")
+
+
 def test_c3_full_size_properties(core, oracle_lib):
     """BASELINE config 3 at FULL size (512 leaves, 65 536 replicas): size-independent properties
     the reference's own tests assert (tests/test_utils.py:575-769) -- every replica is_valid() on the
