@@ -2,8 +2,9 @@
 // cost models, cache construction / validation.
 //
 // One replica (one annealing run of the reference, tnco/app/infinite_memory/sa.py:166-234) is
-// owned by a GROUP of L = 2^LOG2L adjacent lanes of a wavefront; lane j of the group holds the
-// K consecutive words [j*K, j*K+K) of every leg bitmask (L*K >= W = ceil(n_inds/64)), so the set
+// owned by a GROUP of L = 2^LOG2L adjacent lanes of a wavefront; lane j of the group holds the K
+// words j, L+j, 2L+j, ... of every leg bitmask (L*K >= W = ceil(n_inds/64); one load instruction
+// of the group covers L consecutive words = one contiguous piece of the block), so the set
 // operations of include/tnco/optimize/infinite_memory/optimizer.hpp:147,171-172 are K VALU ops
 // per lane and popcounts / intersects are reduced across the group with DPP, never through
 // memory.  Scalar state is computed redundantly by every lane of the group and stored by lane 0:
