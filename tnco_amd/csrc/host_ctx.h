@@ -1,0 +1,88 @@
+// host_ctx.h -- host-side context of a handle and the per-(LOG2L, K) launchers (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+#include "sa_kernels.h"
+#include "sa_sweep.h"
+#include "fw_kernels.h"
+
+struct EventPair {
+  hipEvent_t a, b;
+};
+
+
+struct tnco_hip_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  tnco::Params P{};
+  int log2l = 2, K = 1, L = 4;  // lanes per replica = L, mask words per lane = K
+  bool hyper = false, generic = false;
+  bool fw = false;  // finite-width optimizer
+  tnco::FwParams F{};
+  std::vector<void*> allocs;
+  int64_t bytes = 0;
+  std::vector<uint64_t> leafmask_w;  // [n][W]
+  std::vector<uint64_t> outmask_w;   // [W]
+  double* d_betas = nullptr;
+  int64_t betas_cap = 0;
+  std::vector<EventPair> pending, free_events;
+  double kernel_ms = 0;
+  int64_t launches = 0;
+
+  template <typename T>
+  hipError_t alloc(T** p, int64_t count) {
+    void* q = nullptr;
+    int64_t nb = std::max<int64_t>(count, 1) * (int64_t)sizeof(T);
+    hipError_t e = hipMalloc(&q, (size_t)nb);
+    if (e == hipSuccess) {
+      allocs.push_back(q);
+      bytes += nb;
+      *p = (T*)q;
+    }
+    return e;
+  }
+  void resolve_events() {
+    for (auto& ev : pending) {
+      float ms = 0;
+      if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess)
+        kernel_ms += ms;
+      free_events.push_back(ev);
+    }
+    pending.clear();
+  }
+  ~tnco_hip_ctx() {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    resolve_events();
+    for (auto& ev : free_events) {
+      (void)hipEventDestroy(ev.a);
+      (void)hipEventDestroy(ev.b);
+    }
+    for (void* p : allocs) (void)hipFree(p);
+    if (d_betas) (void)hipFree(d_betas);
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+  }
+  int64_t block_bytes() const { return (int64_t)(P.n - 1) * P.BS; }
+};
+
+
+// Launchers of the kernels of one (LOG2L, K) pair; defined in launch_impl.h, instantiated once per
+// pair in inst_<LOG2L>_<K>.hip so that the pairs compile in parallel.
+template <int LOG2L, int K>
+void launch_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind);
+template <int LOG2L, int K>
+void launch_build_lk(tnco_hip_ctx* h, const tnco::BuildArgs& a);
+template <int LOG2L, int K>
+void launch_compare_lk(tnco_hip_ctx* h, const tnco::BuildArgs& a, double atol, int32_t* out_bad);
+template <int LOG2L, int K>
+void launch_fw_init_lk(tnco_hip_ctx* h, const tnco::FwInitArgs& a);
+template <int LOG2L, int K>
+void launch_fw_check_lk(tnco_hip_ctx* h, const tnco::BuildArgs& a, int which_min, double atol, int32_t* out_bad);
+template <int LOG2L, int K>
+void launch_fw_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, int64_t off,
+                      int64_t every);

@@ -1,0 +1,4 @@
+// kernels + launchers for groups of 4 lanes x 3 mask words per lane
+#define TNCO_INST_L 2
+#define TNCO_INST_K 3
+#include "launch_impl.h"

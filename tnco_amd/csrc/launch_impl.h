@@ -1,0 +1,85 @@
+// launch_impl.h -- definitions of the per-(LOG2L, K) launchers + their explicit instantiation for
+// the pair named by TNCO_INST_L / TNCO_INST_K (see inst_*.hip).
+#pragma once
+#include "host_ctx.h"
+
+using namespace tnco;
+
+template <int LOG2L, int K>
+void launch_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind) {
+  const Params& P = h->P;
+  hipStream_t s = h->stream;
+  const int gpb = 256 >> LOG2L;
+  dim3 grid((unsigned)((P.R + gpb - 1) / gpb));
+  if (h->hyper) {
+    if (h->generic)
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, true>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
+    else
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
+  } else {
+    if (h->generic)
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, true>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
+    else
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
+  }
+}
+
+template <int LOG2L, int K>
+void launch_build_lk(tnco_hip_ctx* h, const BuildArgs& a) {
+  const int gpb = 256 >> LOG2L;
+  dim3 grid((unsigned)((a.count + gpb - 1) / gpb));
+  if (h->hyper)
+    hipLaunchKernelGGL((build_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, a);
+  else
+    hipLaunchKernelGGL((build_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, a);
+}
+
+template <int LOG2L, int K>
+void launch_compare_lk(tnco_hip_ctx* h, const BuildArgs& a, double atol, int32_t* out_bad) {
+  const int gpb = 256 >> LOG2L;
+  dim3 grid((unsigned)((a.count + gpb - 1) / gpb));
+  if (h->hyper)
+    hipLaunchKernelGGL((compare_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, a, atol, out_bad);
+  else
+    hipLaunchKernelGGL((compare_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, a, atol, out_bad);
+}
+
+
+template <int LOG2L, int K>
+void launch_fw_init_lk(tnco_hip_ctx* h, const FwInitArgs& a) {
+  const int gpb = 256 >> LOG2L;
+  dim3 grid((unsigned)((h->P.R + gpb - 1) / gpb));
+  if (h->hyper)
+    hipLaunchKernelGGL((fw_init_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, h->F, a);
+  else
+    hipLaunchKernelGGL((fw_init_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, a);
+}
+template <int LOG2L, int K>
+void launch_fw_check_lk(tnco_hip_ctx* h, const BuildArgs& a, int which_min, double atol, int32_t* out_bad) {
+  const int gpb = 256 >> LOG2L;
+  dim3 grid((unsigned)((a.count + gpb - 1) / gpb));
+  if (h->hyper)
+    hipLaunchKernelGGL((fw_check_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, h->F, a, which_min, atol, out_bad);
+  else
+    hipLaunchKernelGGL((fw_check_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, a, which_min, atol, out_bad);
+}
+
+template <int LOG2L, int K>
+void launch_fw_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, int64_t off,
+                      int64_t every) {
+  const int gpb = 256 >> LOG2L;
+  dim3 grid((unsigned)((h->P.R + gpb - 1) / gpb));
+  if (h->hyper)
+    hipLaunchKernelGGL((fw_run_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, h->F, betas, n_steps,
+                       prob_kind, off, every);
+  else
+    hipLaunchKernelGGL((fw_run_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, betas, n_steps,
+                       prob_kind, off, every);
+}
+
+template void launch_run_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const double*, int64_t, int);
+template void launch_build_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const BuildArgs&);
+template void launch_compare_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const BuildArgs&, double, int32_t*);
+template void launch_fw_init_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const FwInitArgs&);
+template void launch_fw_check_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const BuildArgs&, int, double, int32_t*);
+template void launch_fw_run_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const double*, int64_t, int, int64_t, int64_t);

@@ -341,7 +341,7 @@ __device__ __forceinline__ double generic_cost(const Params& P, const Mask<K>& u
 // ---------------------------------------------------------------------------
 // mt19937 seeding: one thread per replica (random.tcc:326-343).
 // ---------------------------------------------------------------------------
-__global__ void mt_seed_kernel(uint32_t* mt, ReplicaState* rs, const uint32_t* seeds, int64_t R) {
+static __global__ void mt_seed_kernel(uint32_t* mt, ReplicaState* rs, const uint32_t* seeds, int64_t R) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   uint32_t* st = mt + r * 624;
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256) void compare_kernel(const Params P, const Buil
 // Best tree of every replica = checkpoint + rotations jlog[0, jmin): apply
 // Tree::swap_with_nn (include/tnco/tree.hpp:141-192) to a copy.  One thread per replica
 // (diagnostic path: validate()).
-__global__ void materialize_min_kernel(const Params P, Links* out, int64_t r0, int64_t count) {
+static __global__ void materialize_min_kernel(const Params P, Links* out, int64_t r0, int64_t count) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= count) return;
   const int64_t r = r0 + q;

@@ -15,9 +15,7 @@
 #include <thread>
 #include <vector>
 
-#include "sa_kernels.h"
-#include "sa_sweep.h"
-#include "fw_kernels.h"
+#include "host_ctx.h"
 
 using namespace tnco;
 
@@ -37,10 +35,6 @@ int fail(int code, const std::string& msg) {
       return fail(TNCO_HIP_ERUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_));   \
   } while (0)
 
-struct EventPair {
-  hipEvent_t a, b;
-};
-
 // frees a set of temporary device buffers on scope exit
 struct TempBufs {
   std::vector<void*> ptrs;
@@ -59,105 +53,7 @@ struct TempBufs {
 
 }  // namespace
 
-struct tnco_hip_ctx {
-  int device = 0;
-  hipStream_t own_stream = nullptr;
-  hipStream_t stream = nullptr;
-  Params P{};
-  int log2l = 2, K = 1, L = 4;  // lanes per replica = L, mask words per lane = K
-  bool hyper = false, generic = false;
-  bool fw = false;  // finite-width optimizer
-  FwParams F{};
-  std::vector<void*> allocs;
-  int64_t bytes = 0;
-  std::vector<uint64_t> leafmask_w;  // [n][W]
-  std::vector<uint64_t> outmask_w;   // [W]
-  double* d_betas = nullptr;
-  int64_t betas_cap = 0;
-  std::vector<EventPair> pending, free_events;
-  double kernel_ms = 0;
-  int64_t launches = 0;
-
-  template <typename T>
-  hipError_t alloc(T** p, int64_t count) {
-    void* q = nullptr;
-    int64_t nb = std::max<int64_t>(count, 1) * (int64_t)sizeof(T);
-    hipError_t e = hipMalloc(&q, (size_t)nb);
-    if (e == hipSuccess) {
-      allocs.push_back(q);
-      bytes += nb;
-      *p = (T*)q;
-    }
-    return e;
-  }
-  void resolve_events() {
-    for (auto& ev : pending) {
-      float ms = 0;
-      if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess)
-        kernel_ms += ms;
-      free_events.push_back(ev);
-    }
-    pending.clear();
-  }
-  ~tnco_hip_ctx() {
-    (void)hipSetDevice(device);
-    if (stream) (void)hipStreamSynchronize(stream);
-    resolve_events();
-    for (auto& ev : free_events) {
-      (void)hipEventDestroy(ev.a);
-      (void)hipEventDestroy(ev.b);
-    }
-    for (void* p : allocs) (void)hipFree(p);
-    if (d_betas) (void)hipFree(d_betas);
-    if (own_stream) (void)hipStreamDestroy(own_stream);
-  }
-  int64_t block_bytes() const { return (int64_t)(P.n - 1) * P.BS; }
-};
-
 namespace {
-
-// ---- kernel dispatch over (LOG2L, K, HYPER, GENERIC) ------------------------
-// A replica's W mask words are spread over L = 2^LOG2L lanes, K words per lane.  Small groups
-// keep the per-replica scalar work (done by every lane of the group) cheap and put more replicas
-// in a wavefront:  W <= 16 -> 4 lanes;  W <= 32 -> 8 lanes;  W <= 64 -> 16 lanes.
-template <int LOG2L, int K>
-void launch_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind) {
-  const Params& P = h->P;
-  hipStream_t s = h->stream;
-  const int gpb = 256 >> LOG2L;
-  dim3 grid((unsigned)((P.R + gpb - 1) / gpb));
-  if (h->hyper) {
-    if (h->generic)
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, true>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
-    else
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
-  } else {
-    if (h->generic)
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, true>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
-    else
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
-  }
-}
-
-template <int LOG2L, int K>
-void launch_build_lk(tnco_hip_ctx* h, const BuildArgs& a) {
-  const int gpb = 256 >> LOG2L;
-  dim3 grid((unsigned)((a.count + gpb - 1) / gpb));
-  if (h->hyper)
-    hipLaunchKernelGGL((build_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, a);
-  else
-    hipLaunchKernelGGL((build_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, a);
-}
-
-template <int LOG2L, int K>
-void launch_compare_lk(tnco_hip_ctx* h, const BuildArgs& a, double atol, int32_t* out_bad) {
-  const int gpb = 256 >> LOG2L;
-  dim3 grid((unsigned)((a.count + gpb - 1) / gpb));
-  if (h->hyper)
-    hipLaunchKernelGGL((compare_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, a, atol, out_bad);
-  else
-    hipLaunchKernelGGL((compare_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, a, atol, out_bad);
-}
 
 // (LOG2L, K) for W mask words
 void choose_lanes(int W, int* log2l, int* K) {
@@ -166,6 +62,10 @@ void choose_lanes(int W, int* log2l, int* K) {
   else { *log2l = 4; *K = W <= 48 ? 3 : 4; }
 }
 
+// A replica's W mask words are spread over L = 2^LOG2L lanes, K words per lane.  Small groups
+// keep the per-replica scalar work (done by every lane of the group) cheap and put more replicas
+// in a wavefront:  W <= 16 -> 4 lanes;  W <= 32 -> 8 lanes;  W <= 64 -> 16 lanes.  The kernels of
+// one (LOG2L, K) pair are compiled in a translation unit of their own (inst_<L>_<K>.hip).
 #define DISPATCH_LK(h, CALL)                                  \
   switch ((h)->log2l * 8 + (h)->K) {                          \
     case 1 * 8 + 6: CALL(1, 6); break;                        \
@@ -195,24 +95,6 @@ void launch_compare(tnco_hip_ctx* h, const BuildArgs& a, double atol, int32_t* o
 #undef CALL_CMP
 }
 
-template <int LOG2L, int K>
-void launch_fw_init_lk(tnco_hip_ctx* h, const FwInitArgs& a) {
-  const int gpb = 256 >> LOG2L;
-  dim3 grid((unsigned)((h->P.R + gpb - 1) / gpb));
-  if (h->hyper)
-    hipLaunchKernelGGL((fw_init_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, h->F, a);
-  else
-    hipLaunchKernelGGL((fw_init_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, a);
-}
-template <int LOG2L, int K>
-void launch_fw_check_lk(tnco_hip_ctx* h, const BuildArgs& a, int which_min, double atol, int32_t* out_bad) {
-  const int gpb = 256 >> LOG2L;
-  dim3 grid((unsigned)((a.count + gpb - 1) / gpb));
-  if (h->hyper)
-    hipLaunchKernelGGL((fw_check_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, h->F, a, which_min, atol, out_bad);
-  else
-    hipLaunchKernelGGL((fw_check_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, a, which_min, atol, out_bad);
-}
 void launch_fw_check(tnco_hip_ctx* h, const BuildArgs& a, int which_min, double atol, int32_t* out_bad) {
 #define CALL_FWC(LL, KK) launch_fw_check_lk<LL, KK>(h, a, which_min, atol, out_bad)
   DISPATCH_LK(h, CALL_FWC)
@@ -225,18 +107,6 @@ void launch_fw_init(tnco_hip_ctx* h, const FwInitArgs& a) {
 #undef CALL_FWI
 }
 
-template <int LOG2L, int K>
-void launch_fw_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, int64_t off,
-                      int64_t every) {
-  const int gpb = 256 >> LOG2L;
-  dim3 grid((unsigned)((h->P.R + gpb - 1) / gpb));
-  if (h->hyper)
-    hipLaunchKernelGGL((fw_run_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, h->F, betas, n_steps,
-                       prob_kind, off, every);
-  else
-    hipLaunchKernelGGL((fw_run_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, betas, n_steps,
-                       prob_kind, off, every);
-}
 void launch_fw_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, int64_t off,
                    int64_t every) {
 #define CALL_FWR(LL, KK) launch_fw_run_lk<LL, KK>(h, betas, n_steps, prob_kind, off, every)
