@@ -24,6 +24,7 @@ struct FwParams {
   const double* log2dims;   // [LK*64] std::log2((double)dims[p]), per-index dims; else NULL
   double log2np;            // std::log2((double)n_projs) (simple_sparse_inds.hpp:45)
   int32_t width_f32;        // width_type float32 (else float64)
+  int32_t leaf_wide;        // 1 unless it is known that no leaf tensor is wider than max_width
   int32_t I64;              // 64 * LK (padded index count)
   int64_t max_new_slices;   // max_number_new_slices
   uint64_t* slices;         // [R][2][LK]  slices, min_slices
@@ -317,7 +318,8 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
   // :41-48  number of too-wide tensors every index appears in
   for (int i = lig; i < F.I64; i += L) n_big[i] = 0;
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  for (int t = 0; t < N; ++t) {
+  // (leaves never change: when none of them is too wide -- the usual case -- they are skipped)
+  for (int t = F.leaf_wide ? 0 : P.n; t < N; ++t) {
     if (fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t, gbase) > F.max_width) {
       const Mask<K> m = v.mask(t);
 #pragma unroll
@@ -325,7 +327,8 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
         uint64_t x = m.w[k];
         while (x) {
           const int b = __ffsll((unsigned long long)x) - 1;
-          n_big[v.widx(k) * 64 + b] += 1;
+          // no-return atomic: fire and forget (a plain += is a load the next += has to wait for)
+          (void)__hip_atomic_fetch_add(&n_big[v.widx(k) * 64 + b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           x &= x - 1;
         }
       }
@@ -335,6 +338,7 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
   // :62-101  post-order over the too-wide tensors
   for (int i = 0; i < N; ++i) {
     const int t = order[i];
+    if (t < P.n && !F.leaf_wide) continue;
     if (!(fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t, gbase) > F.max_width)) continue;
     Mask<K> sliced_xs = mandn<K>(v.mask(t), slices);
     double sliced_width = fw_width<LOG2L, K>(P, F, sliced_xs, lig, gbase);
@@ -473,6 +477,27 @@ __global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwPa
   }
 }
 
+// Stage timing of a re-slicing sweep (diagnostic builds, -DTNCO_PROFILE): shader cycles of
+// [moves, post-order, get_slices, rebuild + commit] and the number of re-slices, per replica, in
+// ReplicaState::pad1 (tnco_hip_get_stage_cycles; tools/stage_cycles.py --fw).
+#ifdef TNCO_PROFILE
+#define FW_PROF_DECL unsigned long long ft_[5] = {0, 0, 0, 0, 0}, fa_[5] = {0, 0, 0, 0, 0}
+#define FW_PROF_T(i) ft_[i] = __builtin_amdgcn_s_memtime()
+#define FW_PROF_ACC                                              \
+  do {                                                           \
+    fa_[0] += ft_[1] - ft_[0]; fa_[1] += ft_[2] - ft_[1];        \
+    fa_[2] += ft_[3] - ft_[2]; fa_[3] += ft_[4] - ft_[3];        \
+    fa_[4] += 1;                                                 \
+  } while (0)
+#define FW_PROF_OUT(rs) \
+  for (int k_ = 0; k_ < 5; ++k_) (rs)->pad1[k_] += fa_[k_]
+#else
+#define FW_PROF_DECL
+#define FW_PROF_T(i)
+#define FW_PROF_ACC
+#define FW_PROF_OUT(rs)
+#endif
+
 // update(prob, update_slices), finite_width/greedy/optimizer.hpp:117-390, n_steps times.
 // Sweep k of this launch re-slices when (step_offset + k) % update_every == 0
 // (tnco/app/finite_width/sa.py:228).
@@ -536,7 +561,9 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
     return u;
   };
 
+  FW_PROF_DECL;
   for (int64_t step = 0; step < n_steps; ++step) {
+    FW_PROF_T(0);
     const double beta = betas[step];
     // :130-139
     const int leaf = (int)(rng.next_sync() % (uint32_t)n);
@@ -679,16 +706,21 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
     }
     // :360-376
     const bool do_slices = update_every > 0 && ((step_offset + step) % update_every) == 0;
+    FW_PROF_T(1);
     if (do_slices && gany<LOG2L>(mnonzero<K>(slices))) {
       fw_traverse<LOG2L, K, HYPER>(v, N, order, lane0);
+      FW_PROF_T(2);
       const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, n_big, pos, lpos, lane0, gbase,
                                                   F.status + r);
+      FW_PROF_T(3);
       double sum;
       const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, order, ns, cc_new, part_new, lane0, gbase, &sum);
       if (tot < v.hdr(N - 1)->partial) {
         slices = ns;
         fw_commit<LOG2L, K, HYPER>(P, v, cc_new, part_new);
       }
+      FW_PROF_T(4);
+      FW_PROF_ACC;
     }
     // :385-389
     const double tc = v.hdr(N - 1)->partial;
@@ -726,6 +758,7 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
     rs->n_randpick += n_rpick;
     rs->mti = mti;
     rs->mtw = mtw;
+    FW_PROF_OUT(rs);
   }
 }
 

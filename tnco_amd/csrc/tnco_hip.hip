@@ -499,6 +499,17 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     F.log2np = d->sparse_mask ? std::log2((double)d->n_projs) : 0.0;
     F.max_new_slices = (int64_t)std::min<uint64_t>(d->max_number_new_slices, (uint64_t)1 << 40);
     F.I64 = 64 * L;
+    F.leaf_wide = 1;
+    if (uniform && !d->sparse_mask) {  // the re-slice skips the leaves when none of them is too wide
+      int wide = 0;
+      for (int t = 0; t < n && !wide; ++t) {
+        int cnt = 0;
+        for (int w = 0; w < W; ++w) cnt += __builtin_popcountll(h->leafmask_w[(size_t)t * W + w]);
+        const double wd = F.log2d * (double)cnt;
+        if ((F.width_f32 ? (double)(float)wd : wd) > F.max_width) wide = 1;
+      }
+      F.leaf_wide = wide;
+    }
     if (!uniform) {
       std::vector<double> l2((size_t)L * 64, 0.0);
       for (int i = 0; i < I; ++i) l2[i] = std::log2((double)d->dims[i]);

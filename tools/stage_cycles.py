@@ -20,7 +20,10 @@ def main():
     ap.add_argument("--replicas", type=int, default=65536)
     ap.add_argument("--sweeps", type=int, default=100)
     ap.add_argument("--fine", action="store_true")
+    ap.add_argument("--fw", action="store_true", help="finite-width kernels on the config-5 topology")
     a = ap.parse_args()
+    if a.fw:
+        return fw(a)
     ts, dims, out = synthetic.random_regular_tn(a.leaves, 3, 0)
     n_inds = 1 + max(i for xs in ts for i in xs)
     lm = ctree.pack_masks(ts, n_inds)
@@ -48,6 +51,27 @@ def main():
     for k in range(4):
         print(f"  {names[k]:16s} {cyc[k] / it:9.1f} cycles/iteration  {100 * cyc[k] / tot:5.1f} %")
     print(f"  total            {tot / it:9.1f} cycles/iteration (s_memtime ticks)")
+
+
+def fw(a):
+    ts, dims, out = synthetic.sycamore53_tn(20)
+    n_inds = 1 + max(i for xs in ts for i in xs)
+    lm = ctree.pack_masks(ts, n_inds)
+    seeds = np.arange(1, a.replicas + 1, dtype=np.uint32)
+    links = core.random_trees(ts, n_inds, seeds)
+    opt = core.BatchedOptimizer(lm, links, seeds, n_inds=n_inds, max_width=40)
+    L = _lib.load()
+    base = np.zeros(5, np.uint64)
+    L.tnco_hip_get_stage_cycles(opt._h, base.ctypes.data_as(C.c_void_p))
+    opt.run(np.linspace(0, 100, a.sweeps), update_slices_every=10)
+    opt.sync()
+    cyc = np.zeros(5, np.uint64)
+    L.tnco_hip_get_stage_cycles(opt._h, cyc.ctypes.data_as(C.c_void_p))
+    cyc = (cyc - base).astype(np.float64)
+    names = ["moves of the sweep", "post-order", "get_slices", "rebuild + commit"]
+    print(f"re-slices {cyc[4]:.3e} over {a.replicas} replicas (re-slicing sweeps only)")
+    for k in range(4):
+        print(f"  {names[k]:20s} {cyc[k] / cyc[4]:12.0f} cycles per re-slicing sweep  {100 * cyc[k] / cyc[:4].sum():5.1f} %")
 
 
 if __name__ == "__main__":
