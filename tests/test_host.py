@@ -142,3 +142,43 @@ def test_shard_bounds_partition():
 def test_seed_list_is_the_reference_rule():
     """seeds = Random(seed).choices(range(2**32), k=n_runs) (sa.py:237)."""
     assert H.replica_seeds(3, S=0) == random.Random(0).choices(range(2**32), k=3)
+
+
+def test_dump_results_formats_and_files(tmp_path):
+    """dump_results (tnco/app/app.py:573-712): raw tuple, JSON string, pickle / JSON files with
+    'auto' compression from the suffix, refusal to overwrite."""
+    import bz2
+    import gzip
+    import json
+    import pickle
+    from decimal import Decimal
+    from tnco_amd.app.app import dump_results
+    from tnco_amd.app.infinite_memory.sa import ContractionResults
+    tn = load_tn("2 a b\n2 b c", fuse=None, decompose_hyper_inds=False)
+    res = [ContractionResults(cost=Decimal("8"), runtime_s=0.5, path=[(0, 1), (0, 1)],
+                              disconnected_costs=[Decimal("8")], disconnected_paths=[[(0, 1), (0, 1)]])]
+    assert dump_results(tn, res) == (tn, res)
+    js = json.loads(dump_results(tn, res, output_format="json"))
+    assert len(js["tn"]["tensors"]) == 3 and js["res"][0]["path"] == [[0, 1], [0, 1]]
+    assert js["res"][0]["disconnected_paths"] == [[[0, 1], [0, 1]]]
+    for name, opener in (("out.pkl", open), ("out.gzip", gzip.open), ("out.bz2", bz2.open)):
+        f = tmp_path / name
+        assert dump_results(tn, res, output_filename=f) is None
+        with opener(f, "rb") as fh:
+            t2, r2 = pickle.load(fh)
+        assert t2.ts_inds == tn.ts_inds and r2[0].cost == Decimal("8") and r2[0].path == [(0, 1), (0, 1)]
+        with pytest.raises(FileExistsError):
+            dump_results(tn, res, output_filename=f)
+        assert dump_results(tn, res, output_filename=f, overwrite_output_file=True) is None
+    f = tmp_path / "out.json.gzip"
+    dump_results(tn, res, output_format="json", output_filename=f)
+    with gzip.open(f, "rb") as fh:
+        assert json.loads(fh.read().decode())["res"][0]["runtime_s"] == 0.5
+    f = tmp_path / "plain.json"
+    dump_results(tn, res, output_format="json", output_filename=f, output_compression="none")
+    assert json.loads(f.read_text())["res"][0]["path"] == [[0, 1], [0, 1]]
+    with pytest.raises(ValueError):
+        dump_results(tn, res, output_compression="zip")
+    with pytest.raises(TypeError):
+        dump_results(tn, res, nope=1)
+    assert res[0] < ContractionResults(cost=Decimal("9"), runtime_s=0, path=[], disconnected_costs=[], disconnected_paths=[])
