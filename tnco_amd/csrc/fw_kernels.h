@@ -306,7 +306,7 @@ template <int LOG2L, int K, bool HYPER>
 __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
                                                  const double* w64, Rng<LOG2L>& rng, const int32_t* order,
                                                  int32_t* n_big, volatile int16_t* pos, lds_vi32* lpos, bool lane0,
-                                                 int gbase, int32_t* status) {
+                                                 int gbase, int32_t* status, unsigned long long* prof = nullptr) {
   constexpr int L = 1 << LOG2L;
   const int N = P.N, lig = v.lig;
   Mask<K> slices = mzero<K>();
@@ -335,6 +335,9 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
     }
   }
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef TNCO_PROFILE
+  if (prof) prof[1] = __builtin_amdgcn_s_memtime();
+#endif
   // :62-101  post-order over the too-wide tensors
   for (int i = 0; i < N; ++i) {
     const int t = order[i];
@@ -710,8 +713,15 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
     if (do_slices && gany<LOG2L>(mnonzero<K>(slices))) {
       fw_traverse<LOG2L, K, HYPER>(v, N, order, lane0);
       FW_PROF_T(2);
+#ifdef TNCO_PROFILE
+      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, n_big, pos, lpos, lane0, gbase,
+                                                  F.status + r, ft_);  // ft_[1] := end of the first pass
+      fa_[0] += ft_[1] - ft_[2];                                       // slot 0: first pass of get_slices
+      ft_[1] = ft_[0];
+#else
       const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, n_big, pos, lpos, lane0, gbase,
                                                   F.status + r);
+#endif
       FW_PROF_T(3);
       double sum;
       const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, order, ns, cc_new, part_new, lane0, gbase, &sum);
