@@ -29,13 +29,16 @@ struct FwParams {
   int64_t max_new_slices;   // max_number_new_slices
   uint64_t* slices;         // [R][2][LK]  slices, min_slices
   const uint64_t* skip;     // [LK] or NULL
-  int32_t* scratch_i;       // [R][3N + I64 + FW_MAXPOS/2]  order, stack, visited, n_big, candidate legs
+  int32_t* scratch_i;       // [R][fw_scratch_ints]  post-order, too-wide counts, candidate legs
   double* scratch_d;        // [R][2N]        rebuilt ccost / partial
   double* width64;          // [R][N] widths of the internal nodes when width_type is float64
   int32_t* status;          // [R] runtime problems (1: more than FW_MAXPOS candidate legs)
 };
 
 constexpr int FW_MAXPOS = 512;  // candidate legs of one tensor (scratch for the shuffle)
+
+// int32 of scratch per replica: post-order [N], too-wide counts [I64], candidate legs (int16) [FW_MAXPOS]
+__host__ __device__ inline int64_t fw_scratch_ints(int N, int I64) { return (int64_t)N + I64 + FW_MAXPOS / 2; }
 
 // a value of width_type, held in a double
 __device__ __forceinline__ double fw_wr(const FwParams& F, double x) {
@@ -442,8 +445,8 @@ __global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwPa
   ReplicaState* rs = P.rs + r;
   R rng;
   rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
-  int32_t* si = F.scratch_i + r * (int64_t)(3 * N + F.I64 + FW_MAXPOS / 2);
-  int32_t *order = si, *n_big = si + 3 * N;
+  int32_t* si = F.scratch_i + r * fw_scratch_ints(N, F.I64);
+  int32_t *order = si, *n_big = si + N;
   double* cc_new = F.scratch_d + r * 2 * (int64_t)N;
   double* part_new = cc_new + N;
   double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwPa
 #pragma unroll
     for (int k = 0; k < K; ++k) slices.w[k] = a.slices_in[v.widx(k)];
   } else {
-    volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + 3 * N + F.I64);
+    volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + N + F.I64);
     slices = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, n_big, pos, lpos, lane0, gbase, F.status + r);
   }
   double sum = 0;
@@ -530,9 +533,9 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
   ReplicaState* rs = P.rs + r;
   R rng;
   rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
-  int32_t* si = F.scratch_i + r * (int64_t)(3 * N + F.I64 + FW_MAXPOS / 2);
-  int32_t *order = si, *n_big = si + 3 * N;
-  volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + 3 * N + F.I64);
+  int32_t* si = F.scratch_i + r * fw_scratch_ints(N, F.I64);
+  int32_t *order = si, *n_big = si + N;
+  volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + N + F.I64);
   double* cc_new = F.scratch_d + r * 2 * (int64_t)N;
   double* part_new = cc_new + N;
   double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;

@@ -589,14 +589,8 @@ __global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : TNCO_WAVES_PER_SIMD)) void s
         }
       }
       v.lpar = lpar();
-#if defined(TNCO_EXP_NOPARENT) && TNCO_EXP_NOPARENT == 2  // (measurement only: wrong results)
-#elif defined(TNCO_EXP_NOPARENT)
-      if (stC < n) v.set_parent_group(stC, stB);
-      if (stE < n) v.set_parent_group(stE, stA);
-#else
       v.set_parent_group(stC, stB);
       v.set_parent_group(stE, stA);
-#endif
       v.set_mask(stB, msel<K>(b_is_left_of_a, m0, m1));  // :170 (accepted: B's legs are the new legs)
     }
     if (did_move || did_end) {

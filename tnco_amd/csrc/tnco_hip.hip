@@ -520,7 +520,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     }
     if (!F.width_f32) HIP_TRY(h->alloc(&F.width64, R * (int64_t)N));
     HIP_TRY(h->alloc(&F.slices, R * 2 * (int64_t)L));
-    HIP_TRY(h->alloc(&F.scratch_i, R * (int64_t)(3 * N + F.I64 + FW_MAXPOS / 2)));
+    HIP_TRY(h->alloc(&F.scratch_i, R * fw_scratch_ints(N, F.I64)));
     HIP_TRY(h->alloc(&F.scratch_d, R * 2 * (int64_t)N));
     HIP_TRY(h->alloc(&F.status, R));
     HIP_TRY(hipMemset(F.status, 0, (size_t)R * 4));
