@@ -264,3 +264,23 @@ def test_c3_full_size_properties(core, oracle_lib):
     gpu.run(np.zeros(10), "greedy")
     tot2, mn2 = gpu.costs()
     assert np.all(tot2 <= tot) and np.all(mn2 <= mn) and gpu.validate() == (0, -1)
+
+
+def test_prng_state_string_is_libstdcxx_text(core):
+    """`prng_state` (optimize/optimizer.hpp:191-195) is the text libstdc++ streams for the generator:
+    compared with the strings the REAL std::mt19937 of the build image printed
+    (tests/golden/stdlib_rng.json, oracle/stdlib_rng.cpp), after 0 draws, and restored from text."""
+    import json
+    import pathlib
+    golden = json.loads((pathlib.Path(__file__).parent / "golden" / "stdlib_rng.json").read_text())
+    cases = {c["seed"]: {s["draws"]: s["str"] for s in c["state"]} for c in golden["cases"] if c["state"]}
+    assert set(cases) >= {0, 42}
+    prob = H.regular_problem(16, graph_seed=1)
+    seeds = [0, 42]
+    links = prob.links(seeds)
+    gpu = core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds)
+    for r, s in enumerate(seeds):
+        assert gpu.prng_state_string(r) == cases[s][0]
+    # a state given as text (700 draws of seed 42) goes in and comes back unchanged
+    gpu.set_prng_state(0, cases[42][700])
+    assert gpu.prng_state_string(0) == cases[42][700]

@@ -247,7 +247,14 @@ class BatchedOptimizer:
         _lib.check(self._L.tnco_hip_get_prng(self._h, int(replica), _ptr(out)))
         return out
 
+    def prng_state_string(self, replica: int) -> str:
+        """The `prng_state` property of the reference (optimize/optimizer.hpp:191-195): the text
+        libstdc++ streams for a std::mt19937, 624 state words and the position, space separated."""
+        return " ".join(str(int(x)) for x in self.prng_state(replica))
+
     def set_prng_state(self, replica: int, state625) -> None:
+        if isinstance(state625, str):  # a string seed restores the full state (optimizer.hpp:68-71)
+            state625 = [int(x) for x in state625.split()]
         st = np.ascontiguousarray(state625, np.uint32)
         if st.shape != (625,):
             raise ValueError("prng state must hold 625 words.")
