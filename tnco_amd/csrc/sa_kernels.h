@@ -198,7 +198,8 @@ struct View {
     if constexpr (HYPER) {
       const uint64_t* s = words(p) + W;
 #pragma unroll
-      for (int k = 0; k < K; ++k) r.w[k] = (widx(k) < W) ? s[widx(k)] : 0ull;
+      for (int k = 0; k < K; ++k)
+        if (widx(k) < W) r.w[k] = s[widx(k)];  // (a predicated load, not a select on the loaded value)
     }
     return r;
   }
