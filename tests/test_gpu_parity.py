@@ -284,3 +284,17 @@ def test_prng_state_string_is_libstdcxx_text(core):
     # a state given as text (700 draws of seed 42) goes in and comes back unchanged
     gpu.set_prng_state(0, cases[42][700])
     assert gpu.prng_state_string(0) == cases[42][700]
+
+
+def test_vector_dims_powers_of_two(core, oracle_lib):
+    """Per-index dims that are all powers of two take the exponent-class path (one masked popcount
+    per class instead of the reference's loop over the legs): same bits, f64 and f32, with and
+    without sparse legs."""
+    from tnco_amd import synthetic as syn
+    ts, dims, out = syn.random_hyper_tn(28, 70, k=3, n_output=3, seed=8, dims_choices=(2, 4, 8, 2, 16))
+    prob = H.Problem(ts, np.array(dims, np.uint64), out)
+    seeds = H.replica_seeds(20, S=8)
+    _run_both(core, oracle_lib, prob, seeds, H.linear_betas(0, 30, 200))
+    _run_both(core, oracle_lib, prob, seeds, H.linear_betas(0, 30, 100), cost_type="float32")
+    probs = H.Problem(ts, np.array(dims, np.uint64), out, sparse_inds=[2, 3, 11, 30, 31, 60])
+    _run_both(core, oracle_lib, probs, seeds, H.linear_betas(0, 30, 100), n_projs=6)

@@ -74,7 +74,8 @@ struct Params {
   int32_t* jlog;             // [R][jcap]     node E of every accepted rotation since the checkpoint
   const uint64_t* leafmask;  // [n][L*K]
   const uint64_t* outmask;   // [L*K]
-  int32_t cost_mode;         // 0: uniform dims = 2^log2d; 1: uniform dims table; 2: per-index dims
+  int32_t cost_mode;         // 0: uniform dims = 2^log2d; 1: uniform dims table; 2: per-index dims;
+                             // 3: per-index dims that are all powers of two
   int32_t log2d;
   const double* ctab;        // [64*W+1]  d^k in cost_type (mode 1)
   const double* dimsd;       // [L*K*64] dims in cost_type (mode 2)
@@ -82,6 +83,8 @@ struct Params {
   double n_projs;            // (cost_type)n_projs
   int32_t f32;               // cost_type float32
   int32_t disable_shared;
+  const uint64_t* dimclass;  // [n_dimclass][L*K] mode 3: legs whose dimension is 2^(j+1), j = 0..n_dimclass-1
+  int32_t n_dimclass;
 };
 
 // K words of a leg mask held by one lane.
@@ -286,7 +289,7 @@ __device__ __forceinline__ double pow2_cost(int e, int f32) {
 }
 
 // ---------------------------------------------------------------------------
-// cost model, generic path (cost modes 0/1/2, optional sparse legs, f32/f64)
+// cost model, generic path (cost modes 0/1/2/3, optional sparse legs, f32/f64)
 // include/tnco/optimize/infinite_memory/cost_model/simple.hpp:37-55,
 // simple_sparse_inds.hpp:37-49.
 // ---------------------------------------------------------------------------
@@ -313,6 +316,28 @@ __device__ __forceinline__ double seq_product(const Params& P, const Mask<K>& u,
   return c;
 }
 
+// Per-index dims that are all powers of two: every partial product of simple.hpp:51-53 is an exact
+// power of two (or overflows to inf at the same point whatever the order), so the running product is
+// 2^(sum of exponents): one masked popcount per exponent class instead of a loop over the legs.
+template <int LOG2L, int K>
+__device__ __forceinline__ double pow2_product(const Params& P, const Mask<K>& u, int lig) {
+  constexpr int L = 1 << LOG2L;
+  uint32_t e = 0;
+  for (int j = 0; j < P.n_dimclass; ++j) {
+    const uint64_t* m = P.dimclass + (int64_t)j * (L * K);
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) c += (uint32_t)__popcll(u.w[k] & m[k * L + lig]);
+    e += (uint32_t)(j + 1) * c;
+  }
+  return pow2_cost((int)gsum<LOG2L>(e), P.f32);
+}
+
+template <int LOG2L, int K>
+__device__ __forceinline__ double product_cost(const Params& P, const Mask<K>& u, int lig, int gbase) {
+  return P.cost_mode == 3 ? pow2_product<LOG2L, K>(P, u, lig) : seq_product<LOG2L, K>(P, u, gbase);
+}
+
 __device__ __forceinline__ double uniform_cost(const Params& P, int pc) {
   return P.cost_mode == 0 ? pow2_cost(P.log2d * pc, P.f32) : P.ctab[pc];
 }
@@ -322,7 +347,7 @@ template <int LOG2L, int K>
 __device__ __forceinline__ double generic_cost(const Params& P, const Mask<K>& u, int lig, int gbase) {
   if (P.sparse == nullptr) {
     if (P.cost_mode <= 1) return uniform_cost(P, (int)gsum<LOG2L>(mpopc<K>(u)));
-    return seq_product<LOG2L, K>(P, u, gbase);
+    return product_cost<LOG2L, K>(P, u, lig, gbase);
   }
   Mask<K> s;
 #pragma unroll
@@ -333,8 +358,8 @@ __device__ __forceinline__ double generic_cost(const Params& P, const Mask<K>& u
     c1 = uniform_cost(P, (int)(v & 0xffffu));
     c2 = uniform_cost(P, (int)(v >> 16));
   } else {
-    c1 = seq_product<LOG2L, K>(P, mandn<K>(u, s), gbase);
-    c2 = seq_product<LOG2L, K>(P, mand<K>(u, s), gbase);
+    c1 = product_cost<LOG2L, K>(P, mandn<K>(u, s), lig, gbase);
+    c2 = product_cost<LOG2L, K>(P, mand<K>(u, s), lig, gbase);
   }
   return rnd_cost(c1 * (c2 < P.n_projs ? c2 : P.n_projs), P.f32);
 }

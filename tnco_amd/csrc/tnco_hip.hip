@@ -366,6 +366,18 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   P.BS = (32 + 8 * W * (h->hyper ? 2 : 1) + 31) / 32 * 32;
   P.f32 = f32; P.disable_shared = d->disable_shared_inds ? 1 : 0;
   P.cost_mode = uniform ? (pow2u ? 0 : 1) : 2;
+  int max_log2 = 0;  // per-index dims, all powers of two (<= 2^16): exponent classes instead of the leg loop
+  if (!uniform) {
+    bool allp2 = true;
+    for (int i = 0; i < I && allp2; ++i) {
+      const uint64_t x = d->dims[i];
+      allp2 = (x & (x - 1)) == 0 && x <= 65536;
+      int e = 0;
+      while ((1ull << e) < x) ++e;
+      max_log2 = std::max(max_log2, e);
+    }
+    if (allp2 && !std::getenv("TNCO_HIP_NO_POW2_CLASSES")) P.cost_mode = 3;
+  }
   P.log2d = 0;
   if (pow2u) while ((1ull << P.log2d) < dim_u) ++P.log2d;
   auto rc = [&](double x) { return f32 ? (double)(float)x : x; };
@@ -419,6 +431,18 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       HIP_TRY(h->alloc(&dt, (int64_t)tab.size()));
       HIP_TRY(hipMemcpy(dt, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
       P.ctab = dt;
+    } else if (P.cost_mode == 3) {
+      std::vector<uint64_t> cls((size_t)std::max(max_log2, 1) * L, 0);
+      for (int i = 0; i < I; ++i) {
+        int e = 0;
+        while ((1ull << e) < d->dims[i]) ++e;
+        if (e > 0) cls[(size_t)(e - 1) * L + (i >> 6)] |= 1ull << (i & 63);
+      }
+      uint64_t* dc;
+      HIP_TRY(h->alloc(&dc, (int64_t)cls.size()));
+      HIP_TRY(hipMemcpy(dc, cls.data(), cls.size() * 8, hipMemcpyHostToDevice));
+      P.dimclass = dc;
+      P.n_dimclass = max_log2;
     } else if (P.cost_mode == 2) {
       std::vector<double> dd((size_t)L * 64, 1.0);
       for (int i = 0; i < I; ++i) dd[i] = rc((double)d->dims[i]);

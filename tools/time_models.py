@@ -45,6 +45,7 @@ def main():
     run("  same, dims 3 (cost table)", ts, I, R, S, dims=3)
     rng = np.random.RandomState(0)
     run("  same, per-index dims in {2,3,4} (sequential product)", ts, I, R, S, dims=rng.choice([2, 3, 4], size=I).astype(np.uint64))
+    run("  same, per-index dims in {2,4,8} (exponent classes)", ts, I, R, S, dims=rng.choice([2, 4, 8], size=I).astype(np.uint64))
     sp = ctree.pack_masks([list(range(0, I, 7))], I)[0]
     run("  same, dims 2, 110 sparse legs, n_projs 1000", ts, I, R, S, sparse_mask=sp, n_projs=1000)
     hts, hd, hout = synthetic.random_hyper_tn(512, 768, k=3, n_output=8, seed=3)
