@@ -293,8 +293,11 @@ __device__ __forceinline__ double pow2_cost(int e, int f32) {
 // include/tnco/optimize/infinite_memory/cost_model/simple.hpp:37-55,
 // simple_sparse_inds.hpp:37-49.
 // ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) const double lds_cdouble;
+
 template <int LOG2L, int K>
-__device__ __forceinline__ double seq_product(const Params& P, const Mask<K>& u, int gbase) {
+__device__ __forceinline__ double seq_product(const Params& P, const Mask<K>& u, int gbase,
+                                              lds_cdouble* sdims = nullptr) {
   // running product in cost_type over ascending set bits (Bitset::visit order): word k*L + j is
   // slot k of lane j
   constexpr int L = 1 << LOG2L;
@@ -308,7 +311,8 @@ __device__ __forceinline__ double seq_product(const Params& P, const Mask<K>& u,
       const int w = k * L + j;
       while (x) {
         const int b = __ffsll((unsigned long long)x) - 1;
-        c = rnd_cost(c * P.dimsd[w * 64 + b], P.f32);
+        // (one dependent table look-up per leg: from LDS when the caller staged the table there)
+        c = rnd_cost(c * (sdims ? sdims[w * 64 + b] : P.dimsd[w * 64 + b]), P.f32);
         x &= x - 1;
       }
     }
@@ -334,8 +338,9 @@ __device__ __forceinline__ double pow2_product(const Params& P, const Mask<K>& u
 }
 
 template <int LOG2L, int K>
-__device__ __forceinline__ double product_cost(const Params& P, const Mask<K>& u, int lig, int gbase) {
-  return P.cost_mode == 3 ? pow2_product<LOG2L, K>(P, u, lig) : seq_product<LOG2L, K>(P, u, gbase);
+__device__ __forceinline__ double product_cost(const Params& P, const Mask<K>& u, int lig, int gbase,
+                                               lds_cdouble* sdims = nullptr) {
+  return P.cost_mode == 3 ? pow2_product<LOG2L, K>(P, u, lig) : seq_product<LOG2L, K>(P, u, gbase, sdims);
 }
 
 __device__ __forceinline__ double uniform_cost(const Params& P, int pc) {
@@ -344,10 +349,11 @@ __device__ __forceinline__ double uniform_cost(const Params& P, int pc) {
 
 // cost of contracting two tensors whose leg union is `u` (this lane's words).
 template <int LOG2L, int K>
-__device__ __forceinline__ double generic_cost(const Params& P, const Mask<K>& u, int lig, int gbase) {
+__device__ __forceinline__ double generic_cost(const Params& P, const Mask<K>& u, int lig, int gbase,
+                                               lds_cdouble* sdims = nullptr) {
   if (P.sparse == nullptr) {
     if (P.cost_mode <= 1) return uniform_cost(P, (int)gsum<LOG2L>(mpopc<K>(u)));
-    return product_cost<LOG2L, K>(P, u, lig, gbase);
+    return product_cost<LOG2L, K>(P, u, lig, gbase, sdims);
   }
   Mask<K> s;
 #pragma unroll
@@ -358,8 +364,8 @@ __device__ __forceinline__ double generic_cost(const Params& P, const Mask<K>& u
     c1 = uniform_cost(P, (int)(v & 0xffffu));
     c2 = uniform_cost(P, (int)(v >> 16));
   } else {
-    c1 = product_cost<LOG2L, K>(P, mandn<K>(u, s), lig, gbase);
-    c2 = product_cost<LOG2L, K>(P, mand<K>(u, s), lig, gbase);
+    c1 = product_cost<LOG2L, K>(P, mandn<K>(u, s), lig, gbase, sdims);
+    c2 = product_cost<LOG2L, K>(P, mand<K>(u, s), lig, gbase, sdims);
   }
   return rnd_cost(c1 * (c2 < P.n_projs ? c2 : P.n_projs), P.f32);
 }

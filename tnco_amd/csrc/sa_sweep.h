@@ -281,6 +281,16 @@ __global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : TNCO_WAVES_PER_SIMD)) void s
   __shared__ uint32_t rngbuf[GPB * R::RING];
   __shared__ ColdState coldbuf[GPB];
   __shared__ int32_t jbuf[GPB * 16];
+  // general per-index dims: the table of the sequential product (one dependent look-up per leg)
+  __shared__ double sdimbuf[GENERIC ? (L * K * 64) : 1];
+  lds_cdouble* sdims = nullptr;
+  if constexpr (GENERIC) {
+    if (P.cost_mode == 2) {
+      for (int i = threadIdx.x; i < L * K * 64; i += 256) sdimbuf[i] = P.dimsd[i];
+      __syncthreads();
+      sdims = (lds_cdouble*)sdimbuf;
+    }
+  }
 
   const int tid = threadIdx.x;
   const int lig = tid & (L - 1);
@@ -511,8 +521,8 @@ __global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : TNCO_WAVES_PER_SIMD)) void s
         nA = pow2_cost(log2d * (pick0 ? pcA0 : pcA1), 0);
         nB = pow2_cost(log2d * (pick0 ? pcB0 : pcB1), 0);
       } else {
-        nA = generic_cost<LOG2L, K>(P, mor<K>(newB, mE), lig, gbase);
-        nB = generic_cost<LOG2L, K>(P, mor<K>(mD, mC), lig, gbase);
+        nA = generic_cost<LOG2L, K>(P, mor<K>(newB, mE), lig, gbase, sdims);
+        nB = generic_cost<LOG2L, K>(P, mor<K>(mD, mC), lig, gbase, sdims);
       }
       const double delta = rnd_cost(rnd_cost(nB - ccB, f32) + rnd_cost(nA - ccA, f32), f32);  // :158
       ++n_moves;
