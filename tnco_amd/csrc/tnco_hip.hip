@@ -244,9 +244,21 @@ bool logclose(double x, double y, double atol) {
   return std::fabs(std::log(x) - std::log(y)) <= atol;
 }
 
+// finite width: problems a kernel met after `create` (a tensor with more candidate legs than the
+// re-slice has scratch for); the stream must be idle
+int fw_runtime_status(tnco_hip_handle h) {
+  if (!h->fw) return TNCO_HIP_OK;
+  std::vector<int32_t> st((size_t)h->P.R);
+  HIP_TRY(hipMemcpy(st.data(), h->F.status, st.size() * 4, hipMemcpyDeviceToHost));
+  for (int32_t x : st)
+    if (x) return fail(TNCO_HIP_ENOTIMPL, "a tensor has more than 512 candidate legs to slice.");
+  return TNCO_HIP_OK;
+}
+
 int fetch_rs(tnco_hip_handle h, std::vector<ReplicaState>& rs) {
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (int rc = fw_runtime_status(h)) return rc;
   rs.resize((size_t)h->P.R);
   HIP_TRY(hipMemcpy(rs.data(), h->P.rs, (size_t)h->P.R * sizeof(ReplicaState), hipMemcpyDeviceToHost));
   return TNCO_HIP_OK;
@@ -597,7 +609,7 @@ int tnco_hip_sync(tnco_hip_handle h) {
   if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  return TNCO_HIP_OK;
+  return fw_runtime_status(h);
 }
 
 int tnco_hip_run(tnco_hip_handle h, int prob_kind, const double* betas, int64_t n_steps) {
