@@ -34,6 +34,15 @@ def test_desc_struct_matches_header():
     assert ctypes.sizeof(_lib.Desc) == 152
 
 
+def test_integration_stub_matches_header():
+    """The reference-side ctypes stub shown in INTEGRATION.md declares the descriptor with the fields
+    of the header, in its order."""
+    from tnco_amd import _lib
+    md = (ROOT / "INTEGRATION.md").read_text()
+    stub = md[md.index("class Desc(C.Structure)"):md.index("_lib.tnco_hip_create.argtypes")]
+    assert re.findall(r'\("(\w+)", C\.', stub) == [f[0] for f in _lib.Desc._fields_]
+
+
 def test_error_reporting_without_gpu():
     """Argument errors are reported through the status code + last_error, before any device use."""
     from tnco_amd import _lib
