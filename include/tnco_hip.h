@@ -163,7 +163,8 @@ int tnco_hip_get_moves(tnco_hip_handle h, uint64_t* moves_per_replica);
 /* Diagnostic (no reference counterpart): shader cycles per stage of the sweep
  * loop summed over replicas -- [mt19937, state branches, landing fence, store
  * phase, loop iterations].  All zero unless the library was built with
- * -DTNCO_PROFILE (tools/stage_cycles.sh). */
+ * -DTNCO_PROFILE (`make -C tnco_amd/csrc profile`, tools/stage_cycles.py); with a finite-width
+ * handle the slots are [too-wide counts, post-order, get_slices, rebuild + commit, re-slices]. */
 int tnco_hip_get_stage_cycles(tnco_hip_handle h, uint64_t* out5);
 
 /* Device time of the sweep kernel accumulated by tnco_hip_run since the last
