@@ -171,12 +171,10 @@ def test_sycamore53_infinite_memory(core, oracle_lib):
     assert gpu.validate() == (0, -1)
 
 
-def test_fw_too_many_candidate_legs_is_reported(core):
-    """The re-slice has scratch for 512 candidate legs of one tensor: a star with a 600-leg centre and
-    a tiny max_width is refused loudly (NotImplementedError), not sliced wrongly."""
+def test_fw_tensor_with_many_candidate_legs(core, oracle_lib):
+    """A star with a 600-leg centre and a tiny max_width: 600 candidate legs in one shuffle (beyond the
+    LDS fast path of the re-slice: the global-scratch path), bit-exact with the oracle."""
     ts = [list(range(600))] + [[i] for i in range(600)]
     prob = H.Problem(ts, 2)
-    seeds = H.replica_seeds(2, S=1)
-    with pytest.raises(NotImplementedError, match="512 candidate legs"):
-        core.BatchedOptimizer(prob.leaf_masks, prob.links(seeds), seeds, n_inds=prob.n_inds, max_width=10)
-    core.BatchedOptimizer(prob.leaf_masks, prob.links(seeds), seeds, n_inds=prob.n_inds, max_width=1000).close()
+    seeds = H.replica_seeds(3, S=1)
+    _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 20, 12), 10, chunks=[12], every=5)

@@ -32,13 +32,13 @@ struct FwParams {
   int32_t* scratch_i;       // [R][fw_scratch_ints]  post-order, too-wide counts, candidate legs
   double* scratch_d;        // [R][2N]        rebuilt ccost / partial
   double* width64;          // [R][N] widths of the internal nodes when width_type is float64
-  int32_t* status;          // [R] runtime problems (1: more than FW_MAXPOS candidate legs)
+  int32_t* status;          // [R] runtime problems (1: candidate legs beyond the scratch; cannot happen
+                            //     since the scratch holds every index)
 };
 
-constexpr int FW_MAXPOS = 512;  // candidate legs of one tensor (scratch for the shuffle)
-
-// int32 of scratch per replica: post-order [N], too-wide counts [I64], candidate legs (int16) [FW_MAXPOS]
-__host__ __device__ inline int64_t fw_scratch_ints(int N, int I64) { return (int64_t)N + I64 + FW_MAXPOS / 2; }
+// int32 of scratch per replica: post-order [N], too-wide counts [I64], candidate legs of one tensor
+// (int16, for the shuffle when they do not fit the LDS fast path) [I64: every index can be one]
+__host__ __device__ inline int64_t fw_scratch_ints(int N, int I64) { return (int64_t)N + I64 + I64 / 2; }
 
 // a value of width_type, held in a double
 __device__ __forceinline__ double fw_wr(const FwParams& F, double x) {
@@ -380,7 +380,7 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
       }
       continue;
     }
-    uint32_t np = fw_positions<LOG2L, K, HYPER>(v, cand, pos, (uint32_t)FW_MAXPOS, gbase, lane0, status);
+    uint32_t np = fw_positions<LOG2L, K, HYPER>(v, cand, pos, (uint32_t)F.I64, gbase, lane0, status);
     // :80  std::shuffle(positions, prng)
     fw_shuffle<LOG2L>(rng, pos, (int)np, lane0);
     // :83-101  stable_sort with `greater` (:50-60: more too-wide tensors first; with per-index dims
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
         // fits, try the rotation against a FULL rebuild of the cost cache with the new slices
         M new_slices = slices;
         uint32_t n_pos = fw_positions<LOG2L, K, HYPER>(v, mandn<K>(mandn<K>(newB, slices), skip), pos,
-                                                       (uint32_t)FW_MAXPOS, gbase, lane0, F.status + r);
+                                                       (uint32_t)F.I64, gbase, lane0, F.status + r);
         int64_t n_new = 0;
         while (n_new < F.max_new_slices && new_sliced_width_B > F.max_width && n_pos > 0) {
           const uint32_t j = rng.next_sync() % n_pos;  // :245

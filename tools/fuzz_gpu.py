@@ -20,6 +20,9 @@ def main():
     ap.add_argument("--cases", type=int, default=2000)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--which", default="both")
+    ap.add_argument("--nmin", type=int, default=0, help="override the range of the number of tensors")
+    ap.add_argument("--nmax", type=int, default=0, help="(wide masks: 8- and 16-lane layouts from ~450 tensors on)")
+    ap.add_argument("--dims", default="", help="restrict dims_kind (e.g. 'two': big random trees overflow otherwise)")
     a = ap.parse_args()
     orc.build()
     rng = random.Random(a.seed)
@@ -28,8 +31,8 @@ def main():
     bad = 0
     for i in range(a.cases):
         if a.which in ("im", "both"):
-            kw = dict(seed=rng.randrange(10**6), n=rng.randint(4, 40), k=rng.choice([2, 3, 4]),
-                      dims_kind=rng.choice(["two", "three", "four", "vector"]), n_sparse=rng.choice([0, 0, 3, 8]),
+            kw = dict(seed=rng.randrange(10**6), n=rng.randint(a.nmin or 4, a.nmax or 40), k=rng.choice([2, 3, 4]),
+                      dims_kind=a.dims or rng.choice(["two", "three", "four", "vector"]), n_sparse=rng.choice([0, 0, 3, 8]),
                       cost_type=rng.choice(["float64", "float64", "float32"]),
                       kind=rng.choice(["mh", "mh", "greedy", "base"]), dsi=rng.random() < 0.5)
             try:
@@ -39,8 +42,8 @@ def main():
                 print("FAIL infinite_memory", kw)
                 print("   ", traceback.format_exc().strip().splitlines()[-1])
         if a.which in ("fw", "both"):
-            kw = dict(seed=rng.randrange(10**6), n=rng.randint(6, 36), k=rng.choice([2, 3]),
-                      dims_kind=rng.choice(["two", "two", "four", "vector"]), n_sparse=rng.choice([0, 0, 4]),
+            kw = dict(seed=rng.randrange(10**6), n=rng.randint(a.nmin or 6, a.nmax or 36), k=rng.choice([2, 3]),
+                      dims_kind=a.dims or rng.choice(["two", "two", "four", "vector"]), n_sparse=rng.choice([0, 0, 4]),
                       frac=rng.uniform(0.3, 1.1), every=rng.choice([1, 3, 10]),
                       width_type=rng.choice(["float32", "float64"]), new_slices=rng.choice([0, 0, 2]))
             try:
