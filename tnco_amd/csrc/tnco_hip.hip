@@ -251,7 +251,7 @@ int fw_runtime_status(tnco_hip_handle h) {
   std::vector<int32_t> st((size_t)h->P.R);
   HIP_TRY(hipMemcpy(st.data(), h->F.status, st.size() * 4, hipMemcpyDeviceToHost));
   for (int32_t x : st)
-    if (x) return fail(TNCO_HIP_ENOTIMPL, "a tensor has more than 512 candidate legs to slice.");
+    if (x) return fail(TNCO_HIP_ENOTIMPL, "finite width: candidate legs beyond the re-slice scratch (internal error).");
   return TNCO_HIP_OK;
 }
 
@@ -587,7 +587,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     HIP_TRY(hipMemcpy(sum.data(), dsum, (size_t)R * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(st.data(), F.status, (size_t)R * 4, hipMemcpyDeviceToHost));
     for (int64_t r = 0; r < R; ++r) {
-      if (st[r]) return fail(TNCO_HIP_ENOTIMPL, "a tensor has more than 512 candidate legs to slice.");
+      if (st[r]) return fail(TNCO_HIP_ENOTIMPL, "finite width: candidate legs beyond the re-slice scratch (internal error).");
       if (bad_log2(total[r]) || bad_log2(sum[r])) return fail(TNCO_HIP_EINVAL, "Precision is too low.");
     }
   }
