@@ -303,13 +303,16 @@ __device__ __forceinline__ uint32_t fw_positions(const View<LOG2L, K, HYPER>& v,
 }
 
 constexpr int FW_LDSPOS = 128;  // candidate legs per tensor that fit the LDS fast path
+constexpr int FW_WIDEW = 4;     // LDS bitmap of the too-wide tensors: FW_WIDEW * L * K words per replica
 
 // get_slices_impl, finite_width/greedy/utils.hpp:21-125.  `pos` = scratch of the group.
 template <int LOG2L, int K, bool HYPER>
 __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
                                                  const double* w64, Rng<LOG2L>& rng, const int32_t* order,
-                                                 int32_t* n_big, volatile int16_t* pos, lds_vi32* lpos, bool lane0,
-                                                 int gbase, int32_t* status, unsigned long long* prof = nullptr) {
+                                                 int32_t* n_big, volatile int16_t* pos, lds_vi32* lpos,
+                                                 lds_vi32* lwide, bool lane0, int gbase, int32_t* status,
+                                                 unsigned long long* prof = nullptr,
+                                                 unsigned long long* cnt = nullptr) {
   constexpr int L = 1 << LOG2L;
   const int N = P.N, lig = v.lig;
   Mask<K> slices = mzero<K>();
@@ -318,37 +321,71 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
 #pragma unroll
     for (int k = 0; k < K; ++k) skip.w[k] = F.skip[v.widx(k)];
   }
-  // :41-48  number of too-wide tensors every index appears in
+  // :41-48  number of too-wide tensors every index appears in.  The tensors found too wide are
+  // also marked in an LDS bitmap, so that the post-order pass below does not have to fetch a
+  // width per node (one dependent HBM round trip each).
+  const bool usebm = lwide != nullptr && N <= 32 * FW_WIDEW * L * K;
+  if (usebm)
+    for (int i = lig; i < (N + 31) / 32; i += L) lwide[i] = 0;
   for (int i = lig; i < F.I64; i += L) n_big[i] = 0;
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  // (leaves never change: when none of them is too wide -- the usual case -- they are skipped)
-  for (int t = F.leaf_wide ? 0 : P.n; t < N; ++t) {
-    if (fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t, gbase) > F.max_width) {
-      const Mask<K> m = v.mask(t);
+  auto too_wide = [&](int t) {
+    if (usebm && lane0) lwide[t >> 5] = lwide[t >> 5] | (1 << (t & 31));
+    const Mask<K> m = v.mask(t);
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        uint64_t x = m.w[k];
-        while (x) {
-          const int b = __ffsll((unsigned long long)x) - 1;
-          // no-return atomic: fire and forget (a plain += is a load the next += has to wait for)
-          (void)__hip_atomic_fetch_add(&n_big[v.widx(k) * 64 + b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          x &= x - 1;
-        }
+    for (int k = 0; k < K; ++k) {
+      uint64_t x = m.w[k];
+      while (x) {
+        const int b = __ffsll((unsigned long long)x) - 1;
+        // no-return atomic: fire and forget (a plain += is a load the next += has to wait for)
+        (void)__hip_atomic_fetch_add(&n_big[v.widx(k) * 64 + b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x &= x - 1;
       }
     }
+  };
+  // (leaves never change: when none of them is too wide -- the usual case -- they are skipped)
+  if (F.leaf_wide)
+    for (int t = 0; t < P.n; ++t)
+      if (fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t, gbase) > F.max_width) too_wide(t);
+  // internal nodes: cached widths, four loads in flight
+  for (int t0 = P.n; t0 < N; t0 += 4) {
+    double wa = 0, wb = 0, wc = 0, wd = 0;
+    wa = fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t0, gbase);
+    if (t0 + 1 < N) wb = fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t0 + 1, gbase);
+    if (t0 + 2 < N) wc = fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t0 + 2, gbase);
+    if (t0 + 3 < N) wd = fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t0 + 3, gbase);
+    if (wa > F.max_width) too_wide(t0);
+    if (t0 + 1 < N && wb > F.max_width) too_wide(t0 + 1);
+    if (t0 + 2 < N && wc > F.max_width) too_wide(t0 + 2);
+    if (t0 + 3 < N && wd > F.max_width) too_wide(t0 + 3);
   }
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef TNCO_PROFILE
   if (prof) prof[1] = __builtin_amdgcn_s_memtime();
 #endif
-  // :62-101  post-order over the too-wide tensors
+  // :62-101  post-order over the too-wide tensors (the post-order is fetched four entries ahead)
+  int oa = order[0], ob = N > 1 ? order[1] : 0, oc = N > 2 ? order[2] : 0, od = N > 3 ? order[3] : 0;
   for (int i = 0; i < N; ++i) {
-    const int t = order[i];
-    if (t < P.n && !F.leaf_wide) continue;
-    if (!(fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t, gbase) > F.max_width)) continue;
+    const int t = oa;
+    oa = ob; ob = oc; oc = od;
+    if ((i & 3) == 3) {  // the window is used up: fetch the next four
+      const int j = i + 1;
+      if (j < N) oa = order[j];
+      if (j + 1 < N) ob = order[j + 1];
+      if (j + 2 < N) oc = order[j + 2];
+      if (j + 3 < N) od = order[j + 3];
+    }
+    if (usebm) {
+      if (!((lwide[t >> 5] >> (t & 31)) & 1)) continue;
+    } else {
+      if (t < P.n && !F.leaf_wide) continue;
+      if (!(fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t, gbase) > F.max_width)) continue;
+    }
+    if (cnt) cnt[0] += 1;  // too-wide tensors
     Mask<K> sliced_xs = mandn<K>(v.mask(t), slices);
     double sliced_width = fw_width<LOG2L, K>(P, F, sliced_xs, lig, gbase);
     if (!(sliced_width > F.max_width)) continue;
+    if (cnt) cnt[1] += 1;  // ... still too wide after the slices so far: shuffled and picked from
     // candidate positions, ascending
     const Mask<K> cand = mandn<K>(sliced_xs, skip);
     if (F.log2dims == nullptr && fw_count<LOG2L, K>(cand) <= (uint32_t)FW_LDSPOS) {
@@ -358,6 +395,7 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
       // key 0 (a candidate's key is >= 1: the tensor itself is too wide).
       const uint32_t np = fw_positions<LOG2L, K, HYPER>(v, cand, lpos, (uint32_t)FW_LDSPOS, gbase, lane0, status);
       fw_shuffle<LOG2L>(rng, lpos, (int)np, lane0);
+      if (cnt) cnt[2] += np;  // candidate legs
       for (uint32_t q = (uint32_t)lig; q < np; q += L) {
         const int xp = lpos[q];
         lpos[q] = (n_big[xp] << 16) | xp;
@@ -376,6 +414,7 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
         fw_flip<LOG2L, K, HYPER>(v, slices, xpos);
         sliced_width = fw_wr(F, sliced_width + fw_delta_width<LOG2L, K, HYPER>(P, F, v, sliced_xs, xpos, gbase));
         fw_flip<LOG2L, K, HYPER>(v, sliced_xs, xpos);
+        if (cnt) cnt[3] += 1;  // picks
         if (sliced_width <= F.max_width) break;
       }
       continue;
@@ -431,6 +470,7 @@ __global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwPa
   using R = Rng<LOG2L>;
   __shared__ uint32_t rngbuf[GPB * R::RING];
   __shared__ int32_t posbuf[GPB * FW_LDSPOS];
+  __shared__ int32_t widebuf[GPB * FW_WIDEW * L * K];
   const int tid = threadIdx.x;
   const int lig = tid & (L - 1);
   const int gib = tid >> LOG2L;
@@ -438,6 +478,7 @@ __global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwPa
   const int64_t r = (int64_t)blockIdx.x * GPB + gib;
   if (r >= P.R) return;
   lds_vi32* lpos = (lds_vi32*)posbuf + gib * FW_LDSPOS;
+  lds_vi32* lwide = (lds_vi32*)widebuf + gib * (FW_WIDEW * L * K);
   const bool lane0 = lig == 0;
   const int n = P.n, N = P.N;
   View<LOG2L, K, HYPER> v;
@@ -461,7 +502,7 @@ __global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwPa
     for (int k = 0; k < K; ++k) slices.w[k] = a.slices_in[v.widx(k)];
   } else {
     volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + N + F.I64);
-    slices = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, n_big, pos, lpos, lane0, gbase, F.status + r);
+    slices = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, n_big, pos, lpos, lwide, lane0, gbase, F.status + r);
   }
   double sum = 0;
   const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, order, slices, cc_new, part_new, lane0, gbase, &sum);
@@ -487,7 +528,9 @@ __global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwPa
 // [moves, post-order, get_slices, rebuild + commit] and the number of re-slices, per replica, in
 // ReplicaState::pad1 (tnco_hip_get_stage_cycles; tools/stage_cycles.py --fw).
 #ifdef TNCO_PROFILE
-#define FW_PROF_DECL unsigned long long ft_[5] = {0, 0, 0, 0, 0}, fa_[5] = {0, 0, 0, 0, 0}
+#define FW_PROF_DECL \
+  unsigned long long ft_[5] = {0, 0, 0, 0, 0}, fa_[5] = {0, 0, 0, 0, 0}; \
+  [[maybe_unused]] unsigned long long fc_[5] = {0, 0, 0, 0, 0}
 #define FW_PROF_T(i) ft_[i] = __builtin_amdgcn_s_memtime()
 #define FW_PROF_ACC                                              \
   do {                                                           \
@@ -495,8 +538,14 @@ __global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwPa
     fa_[2] += ft_[3] - ft_[2]; fa_[3] += ft_[4] - ft_[3];        \
     fa_[4] += 1;                                                 \
   } while (0)
+#if TNCO_PROFILE == 3
+#define FW_PROF_OUT(rs)                                          \
+  for (int k_ = 0; k_ < 4; ++k_) (rs)->pad1[k_] += fc_[k_];      \
+  (rs)->pad1[4] += fa_[4]
+#else
 #define FW_PROF_OUT(rs) \
   for (int k_ = 0; k_ < 5; ++k_) (rs)->pad1[k_] += fa_[k_]
+#endif
 #else
 #define FW_PROF_DECL
 #define FW_PROF_T(i)
@@ -518,6 +567,7 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
   using R = Rng<LOG2L>;
   __shared__ uint32_t rngbuf[GPB * R::RING];
   __shared__ int32_t posbuf[GPB * FW_LDSPOS];
+  __shared__ int32_t widebuf[GPB * FW_WIDEW * L * K];
   const int tid = threadIdx.x;
   const int lig = tid & (L - 1);
   const int gib = tid >> LOG2L;
@@ -525,6 +575,7 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
   const int64_t r = (int64_t)blockIdx.x * GPB + gib;
   if (r >= P.R || n_steps <= 0) return;
   lds_vi32* lpos = (lds_vi32*)posbuf + gib * FW_LDSPOS;
+  lds_vi32* lwide = (lds_vi32*)widebuf + gib * (FW_WIDEW * L * K);
   const bool lane0 = lig == 0;
   const int n = P.n, N = P.N;
   const int f32 = P.f32;
@@ -716,13 +767,16 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
     if (do_slices && gany<LOG2L>(mnonzero<K>(slices))) {
       fw_traverse<LOG2L, K, HYPER>(v, N, order, lane0);
       FW_PROF_T(2);
-#ifdef TNCO_PROFILE
-      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, n_big, pos, lpos, lane0, gbase,
+#if defined(TNCO_PROFILE) && TNCO_PROFILE == 3  // event counts instead of cycles
+      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, n_big, pos, lpos, lwide, lane0, gbase,
+                                                  F.status + r, nullptr, fc_);
+#elif defined(TNCO_PROFILE)
+      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, n_big, pos, lpos, lwide, lane0, gbase,
                                                   F.status + r, ft_);  // ft_[1] := end of the first pass
       fa_[0] += ft_[1] - ft_[2];                                       // slot 0: first pass of get_slices
       ft_[1] = ft_[0];
 #else
-      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, n_big, pos, lpos, lane0, gbase,
+      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, n_big, pos, lpos, lwide, lane0, gbase,
                                                   F.status + r);
 #endif
       FW_PROF_T(3);
