@@ -36,9 +36,10 @@ struct FwParams {
                             //     since the scratch holds every index)
 };
 
-// int32 of scratch per replica: post-order [N], too-wide counts [I64], candidate legs of one tensor
-// (int16, for the shuffle when they do not fit the LDS fast path) [I64: every index can be one]
-__host__ __device__ inline int64_t fw_scratch_ints(int N, int I64) { return (int64_t)N + I64 + I64 / 2; }
+// int32 of scratch per replica: post-order [N], the too-wide tensors in post-order [N], too-wide
+// counts [I64], candidate legs of one tensor (int16, for the shuffle when they do not fit the LDS
+// fast path) [I64: every index can be one]
+__host__ __device__ inline int64_t fw_scratch_ints(int N, int I64) { return 2 * (int64_t)N + I64 + I64 / 2; }
 
 // a value of width_type, held in a double
 __device__ __forceinline__ double fw_wr(const FwParams& F, double x) {
@@ -176,18 +177,25 @@ __device__ __forceinline__ void fw_shuffle(Rng<LOG2L>& rng, A a, int n, bool lan
 // Post-order of include/tnco/utils.hpp:34-51 (child 0's subtree, child 1's subtree, the node) into
 // order[N], by walking the links: the successor of x is its parent if x is the right child, else the
 // left-most leaf below its sibling.  No stack, no stores to wait for.
+// With a bitmap `lwide` (LDS) the marked nodes are also listed, in the same order, in wlist[]; their
+// number is returned.
 template <int LOG2L, int K, bool HYPER>
-__device__ __forceinline__ void fw_traverse(const View<LOG2L, K, HYPER>& v, int N, int32_t* order, bool lane0) {
+__device__ __forceinline__ int fw_traverse(const View<LOG2L, K, HYPER>& v, int N, int32_t* order, bool lane0,
+                                           lds_vi32* lwide = nullptr, int32_t* wlist = nullptr) {
   int x = N - 1;
   for (;;) {
     const int l = v.left(x);
     if (l < 0) break;
     x = l;
   }
-  int cnt = 0;
+  int cnt = 0, nw = 0;
   for (;;) {
     if (lane0) order[cnt] = x;
     ++cnt;
+    if (lwide != nullptr && ((lwide[x >> 5] >> (x & 31)) & 1)) {
+      if (lane0) wlist[nw] = x;
+      ++nw;
+    }
     const int p = v.parent(x);
     if (p < 0) break;
     const int rr = v.right(p);
@@ -203,6 +211,7 @@ __device__ __forceinline__ void fw_traverse(const View<LOG2L, K, HYPER>& v, int 
     }
   }
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  return nw;
 }
 
 // CostCache(ctree, ccost, slices) (finite_width/utils.hpp:36-47) into scratch; returns
@@ -302,13 +311,103 @@ __device__ __forceinline__ uint32_t fw_positions(const View<LOG2L, K, HYPER>& v,
   return np;
 }
 
-constexpr int FW_LDSPOS = 128;  // candidate legs per tensor that fit the LDS fast path
+#ifndef TNCO_FW_LDSPOS
+#define TNCO_FW_LDSPOS 128
+#endif
+constexpr int FW_LDSPOS = TNCO_FW_LDSPOS;  // candidate legs per tensor that fit the LDS fast path
 constexpr int FW_WIDEW = 4;     // LDS bitmap of the too-wide tensors: FW_WIDEW * L * K words per replica
 
-// get_slices_impl, finite_width/greedy/utils.hpp:21-125.  `pos` = scratch of the group.
+// One too-wide tensor `t` of get_slices_impl's post-order pass (finite_width/greedy/utils.hpp:62-101):
+// if it is still too wide after the slices chosen so far, shuffle its candidate legs and slice them
+// in the order of `greater` until it fits.
+template <int LOG2L, int K, bool HYPER>
+__device__ __forceinline__ void fw_slice_tensor(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
+                                                Rng<LOG2L>& rng, const int32_t* n_big, volatile int16_t* pos,
+                                                lds_vi32* lpos, bool lane0, int gbase, int32_t* status,
+                                                const Mask<K>& skip, int t, Mask<K>& slices,
+                                                unsigned long long* cnt) {
+  constexpr int L = 1 << LOG2L;
+  const int lig = v.lig;
+  if (cnt) cnt[0] += 1;  // too-wide tensors
+  Mask<K> sliced_xs = mandn<K>(v.mask(t), slices);
+  double sliced_width = fw_width<LOG2L, K>(P, F, sliced_xs, lig, gbase);
+  if (!(sliced_width > F.max_width)) return;
+  if (cnt) cnt[1] += 1;  // ... still too wide after the slices so far: shuffled and picked from
+  // candidate positions, ascending
+  const Mask<K> cand = mandn<K>(sliced_xs, skip);
+  if (F.log2dims == nullptr && fw_count<LOG2L, K>(cand) <= (uint32_t)FW_LDSPOS) {
+    // Fast path (uniform dims, the usual number of candidates): the candidate list lives in LDS.
+    // Same draws, same order: shuffle, then the keys are attached ((n_big << 16) | position) and
+    // every pick is a scan shared by the lanes of the group + one DPP max; a taken entry keeps
+    // key 0 (a candidate's key is >= 1: the tensor itself is too wide).
+    const uint32_t np = fw_positions<LOG2L, K, HYPER>(v, cand, lpos, (uint32_t)FW_LDSPOS, gbase, lane0, status);
+    fw_shuffle<LOG2L>(rng, lpos, (int)np, lane0);
+    if (cnt) cnt[2] += np;  // candidate legs
+    for (uint32_t q = (uint32_t)lig; q < np; q += L) {
+      const int xp = lpos[q];
+      lpos[q] = (n_big[xp] << 16) | xp;
+    }
+    for (uint32_t taken = 0; taken < np; ++taken) {
+      uint32_t best = 0;
+      for (uint32_t q = (uint32_t)lig; q < np; q += L) {
+        const uint32_t key = (uint32_t)lpos[q] >> 16;
+        const uint32_t c = (key << 16) | (0xFFFFu - q);
+        if (key != 0u && c > best) best = c;
+      }
+      best = gmax<LOG2L>(best);
+      const uint32_t qb = 0xFFFFu - (best & 0xFFFFu);
+      const int xpos = lpos[qb] & 0xFFFF;
+      if (lane0) lpos[qb] = xpos;
+      fw_flip<LOG2L, K, HYPER>(v, slices, xpos);
+      sliced_width = fw_wr(F, sliced_width + fw_delta_width<LOG2L, K, HYPER>(P, F, v, sliced_xs, xpos, gbase));
+      fw_flip<LOG2L, K, HYPER>(v, sliced_xs, xpos);
+      if (cnt) cnt[3] += 1;  // picks
+      if (sliced_width <= F.max_width) break;
+    }
+    return;
+  }
+  uint32_t np = fw_positions<LOG2L, K, HYPER>(v, cand, pos, (uint32_t)F.I64, gbase, lane0, status);
+  // :80  std::shuffle(positions, prng)
+  fw_shuffle<LOG2L>(rng, pos, (int)np, lane0);
+  // :83-101  stable_sort with `greater` (:50-60: more too-wide tensors first; with per-index dims
+  // ties go to the larger log2(dims)), then slice until the tensor fits: equivalent to repeatedly
+  // taking the FIRST remaining position with the largest key.
+  for (uint32_t taken = 0; taken < np; ++taken) {
+    int best = -1, best_key = -1;
+    double best_l2 = 0.0;
+    for (uint32_t q = 0; q < np; ++q) {
+      const int xp = pos[q];
+      if (xp < 0) continue;
+      const int key = n_big[xp];
+      if (F.log2dims == nullptr) {
+        if (key > best_key) { best_key = key; best = (int)q; }
+      } else {
+        const double l2 = fw_log2dim(F, xp);
+        if (best < 0 || key > best_key || (key == best_key && l2 > best_l2)) {
+          best_key = key; best_l2 = l2; best = (int)q;
+        }
+      }
+    }
+    const int xpos = pos[best];
+    if (lane0) pos[best] = -1;
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // slices.set(xpos); sliced_width += delta_width(sliced_xs, xpos); sliced_xs.reset(xpos)
+    fw_flip<LOG2L, K, HYPER>(v, slices, xpos);  // xpos is not in slices: sliced_xs = inds - slices
+    sliced_width = fw_wr(F, sliced_width + fw_delta_width<LOG2L, K, HYPER>(P, F, v, sliced_xs, xpos, gbase));
+    fw_flip<LOG2L, K, HYPER>(v, sliced_xs, xpos);
+    if (sliced_width <= F.max_width) break;
+  }
+}
+
+// get_slices_impl, finite_width/greedy/utils.hpp:21-125; also leaves the post-order of the tree in
+// order[].  The 16 replicas of a wavefront find their too-wide tensors at different places of their
+// trees, and the work on one such tensor is long: run per replica "as it comes", that work would
+// execute once per replica and tensor with 1/16 of the lanes.  So every stage first finds the
+// too-wide tensors cheaply (an LDS bitmap per replica, a list in post-order), then all replicas of
+// the wavefront work on their k-th one together.
 template <int LOG2L, int K, bool HYPER>
 __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
-                                                 const double* w64, Rng<LOG2L>& rng, const int32_t* order,
+                                                 const double* w64, Rng<LOG2L>& rng, int32_t* order, int32_t* wlist,
                                                  int32_t* n_big, volatile int16_t* pos, lds_vi32* lpos,
                                                  lds_vi32* lwide, bool lane0, int gbase, int32_t* status,
                                                  unsigned long long* prof = nullptr,
@@ -321,16 +420,14 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
 #pragma unroll
     for (int k = 0; k < K; ++k) skip.w[k] = F.skip[v.widx(k)];
   }
-  // :41-48  number of too-wide tensors every index appears in.  The tensors found too wide are
-  // also marked in an LDS bitmap, so that the post-order pass below does not have to fetch a
-  // width per node (one dependent HBM round trip each).
+  // :41-48  number of too-wide tensors every index appears in
   const bool usebm = lwide != nullptr && N <= 32 * FW_WIDEW * L * K;
+  const int nwords = (N + 31) / 32;
   if (usebm)
-    for (int i = lig; i < (N + 31) / 32; i += L) lwide[i] = 0;
+    for (int i = lig; i < nwords; i += L) lwide[i] = 0;
   for (int i = lig; i < F.I64; i += L) n_big[i] = 0;
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  auto too_wide = [&](int t) {
-    if (usebm && lane0) lwide[t >> 5] = lwide[t >> 5] | (1 << (t & 31));
+  auto count_legs = [&](int t) {
     const Mask<K> m = v.mask(t);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -343,10 +440,17 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
       }
     }
   };
+  auto found = [&](int t) {
+    if (usebm) {
+      if (lane0) lwide[t >> 5] = lwide[t >> 5] | (1 << (t & 31));
+    } else {
+      count_legs(t);
+    }
+  };
   // (leaves never change: when none of them is too wide -- the usual case -- they are skipped)
   if (F.leaf_wide)
     for (int t = 0; t < P.n; ++t)
-      if (fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t, gbase) > F.max_width) too_wide(t);
+      if (fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t, gbase) > F.max_width) found(t);
   // internal nodes: cached widths, four loads in flight
   for (int t0 = P.n; t0 < N; t0 += 4) {
     double wa = 0, wb = 0, wc = 0, wd = 0;
@@ -354,101 +458,50 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
     if (t0 + 1 < N) wb = fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t0 + 1, gbase);
     if (t0 + 2 < N) wc = fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t0 + 2, gbase);
     if (t0 + 3 < N) wd = fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t0 + 3, gbase);
-    if (wa > F.max_width) too_wide(t0);
-    if (t0 + 1 < N && wb > F.max_width) too_wide(t0 + 1);
-    if (t0 + 2 < N && wc > F.max_width) too_wide(t0 + 2);
-    if (t0 + 3 < N && wd > F.max_width) too_wide(t0 + 3);
+    if (wa > F.max_width) found(t0);
+    if (t0 + 1 < N && wb > F.max_width) found(t0 + 1);
+    if (t0 + 2 < N && wc > F.max_width) found(t0 + 2);
+    if (t0 + 3 < N && wd > F.max_width) found(t0 + 3);
+  }
+  if (usebm) {  // the k-th marked tensor of every replica, together
+    int wi = 0;
+    uint32_t bits = (uint32_t)lwide[0];
+    for (;;) {
+      while (bits == 0u && ++wi < nwords) bits = (uint32_t)lwide[wi];
+      if (wi >= nwords) break;
+      const int t = wi * 32 + __ffs((int)bits) - 1;
+      bits &= bits - 1u;
+      count_legs(t);
+    }
   }
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef TNCO_PROFILE
+  if (prof) prof[0] = __builtin_amdgcn_s_memtime();
+#endif
+  const int nw = fw_traverse<LOG2L, K, HYPER>(v, N, order, lane0, usebm ? lwide : nullptr, wlist);
+#ifdef TNCO_PROFILE
   if (prof) prof[1] = __builtin_amdgcn_s_memtime();
 #endif
-  // :62-101  post-order over the too-wide tensors (the post-order is fetched four entries ahead)
-  int oa = order[0], ob = N > 1 ? order[1] : 0, oc = N > 2 ? order[2] : 0, od = N > 3 ? order[3] : 0;
-  for (int i = 0; i < N; ++i) {
-    const int t = oa;
-    oa = ob; ob = oc; oc = od;
-    if ((i & 3) == 3) {  // the window is used up: fetch the next four
-      const int j = i + 1;
-      if (j < N) oa = order[j];
-      if (j + 1 < N) ob = order[j + 1];
-      if (j + 2 < N) oc = order[j + 2];
-      if (j + 3 < N) od = order[j + 3];
+  // :62-101  post-order over the too-wide tensors
+  if (usebm) {
+    int oa = nw > 0 ? wlist[0] : 0, ob = nw > 1 ? wlist[1] : 0, oc = nw > 2 ? wlist[2] : 0, od = nw > 3 ? wlist[3] : 0;
+    for (int j = 0; j < nw; ++j) {
+      const int t = oa;
+      oa = ob; ob = oc; oc = od;
+      if ((j & 3) == 3) {  // the window is used up: fetch the next four
+        if (j + 1 < nw) oa = wlist[j + 1];
+        if (j + 2 < nw) ob = wlist[j + 2];
+        if (j + 3 < nw) oc = wlist[j + 3];
+        if (j + 4 < nw) od = wlist[j + 4];
+      }
+      fw_slice_tensor<LOG2L, K, HYPER>(P, F, v, rng, n_big, pos, lpos, lane0, gbase, status, skip, t, slices, cnt);
     }
-    if (usebm) {
-      if (!((lwide[t >> 5] >> (t & 31)) & 1)) continue;
-    } else {
+  } else {
+    for (int i = 0; i < N; ++i) {
+      const int t = order[i];
       if (t < P.n && !F.leaf_wide) continue;
       if (!(fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t, gbase) > F.max_width)) continue;
-    }
-    if (cnt) cnt[0] += 1;  // too-wide tensors
-    Mask<K> sliced_xs = mandn<K>(v.mask(t), slices);
-    double sliced_width = fw_width<LOG2L, K>(P, F, sliced_xs, lig, gbase);
-    if (!(sliced_width > F.max_width)) continue;
-    if (cnt) cnt[1] += 1;  // ... still too wide after the slices so far: shuffled and picked from
-    // candidate positions, ascending
-    const Mask<K> cand = mandn<K>(sliced_xs, skip);
-    if (F.log2dims == nullptr && fw_count<LOG2L, K>(cand) <= (uint32_t)FW_LDSPOS) {
-      // Fast path (uniform dims, the usual number of candidates): the candidate list lives in LDS.
-      // Same draws, same order: shuffle, then the keys are attached ((n_big << 16) | position) and
-      // every pick is a scan shared by the lanes of the group + one DPP max; a taken entry keeps
-      // key 0 (a candidate's key is >= 1: the tensor itself is too wide).
-      const uint32_t np = fw_positions<LOG2L, K, HYPER>(v, cand, lpos, (uint32_t)FW_LDSPOS, gbase, lane0, status);
-      fw_shuffle<LOG2L>(rng, lpos, (int)np, lane0);
-      if (cnt) cnt[2] += np;  // candidate legs
-      for (uint32_t q = (uint32_t)lig; q < np; q += L) {
-        const int xp = lpos[q];
-        lpos[q] = (n_big[xp] << 16) | xp;
-      }
-      for (uint32_t taken = 0; taken < np; ++taken) {
-        uint32_t best = 0;
-        for (uint32_t q = (uint32_t)lig; q < np; q += L) {
-          const uint32_t key = (uint32_t)lpos[q] >> 16;
-          const uint32_t c = (key << 16) | (0xFFFFu - q);
-          if (key != 0u && c > best) best = c;
-        }
-        best = gmax<LOG2L>(best);
-        const uint32_t qb = 0xFFFFu - (best & 0xFFFFu);
-        const int xpos = lpos[qb] & 0xFFFF;
-        if (lane0) lpos[qb] = xpos;
-        fw_flip<LOG2L, K, HYPER>(v, slices, xpos);
-        sliced_width = fw_wr(F, sliced_width + fw_delta_width<LOG2L, K, HYPER>(P, F, v, sliced_xs, xpos, gbase));
-        fw_flip<LOG2L, K, HYPER>(v, sliced_xs, xpos);
-        if (cnt) cnt[3] += 1;  // picks
-        if (sliced_width <= F.max_width) break;
-      }
-      continue;
-    }
-    uint32_t np = fw_positions<LOG2L, K, HYPER>(v, cand, pos, (uint32_t)F.I64, gbase, lane0, status);
-    // :80  std::shuffle(positions, prng)
-    fw_shuffle<LOG2L>(rng, pos, (int)np, lane0);
-    // :83-101  stable_sort with `greater` (:50-60: more too-wide tensors first; with per-index dims
-    // ties go to the larger log2(dims)), then slice until the tensor fits: equivalent to repeatedly
-    // taking the FIRST remaining position with the largest key.
-    for (uint32_t taken = 0; taken < np; ++taken) {
-      int best = -1, best_key = -1;
-      double best_l2 = 0.0;
-      for (uint32_t q = 0; q < np; ++q) {
-        const int xp = pos[q];
-        if (xp < 0) continue;
-        const int key = n_big[xp];
-        if (F.log2dims == nullptr) {
-          if (key > best_key) { best_key = key; best = (int)q; }
-        } else {
-          const double l2 = fw_log2dim(F, xp);
-          if (best < 0 || key > best_key || (key == best_key && l2 > best_l2)) {
-            best_key = key; best_l2 = l2; best = (int)q;
-          }
-        }
-      }
-      const int xpos = pos[best];
-      if (lane0) pos[best] = -1;
-      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      // slices.set(xpos); sliced_width += delta_width(sliced_xs, xpos); sliced_xs.reset(xpos)
-      fw_flip<LOG2L, K, HYPER>(v, slices, xpos);  // xpos is not in slices: sliced_xs = inds - slices
-      sliced_width = fw_wr(F, sliced_width + fw_delta_width<LOG2L, K, HYPER>(P, F, v, sliced_xs, xpos, gbase));
-      fw_flip<LOG2L, K, HYPER>(v, sliced_xs, xpos);
-      if (sliced_width <= F.max_width) break;
+      fw_slice_tensor<LOG2L, K, HYPER>(P, F, v, rng, n_big, pos, lpos, lane0, gbase, status, skip, t, slices, cnt);
     }
   }
   return slices;
@@ -463,7 +516,7 @@ struct FwInitArgs {
 // finite_width/greedy/optimizer.hpp:72-115: WidthCache, slices (greedy, draws from the PRNG),
 // min_slices, CostCache(slices), min_total_cost = get_cost(min_ctree, min_slices).
 template <int LOG2L, int K, bool HYPER>
-__global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwParams F, const FwInitArgs a) {
+__global__ __launch_bounds__(256, 2) void fw_init_kernel(const Params P, const FwParams F, const FwInitArgs a) {
   constexpr int L = 1 << LOG2L;
   constexpr int GPB = 256 >> LOG2L;
   constexpr int LK = L * K;
@@ -487,7 +540,7 @@ __global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwPa
   R rng;
   rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
   int32_t* si = F.scratch_i + r * fw_scratch_ints(N, F.I64);
-  int32_t *order = si, *n_big = si + N;
+  int32_t *order = si, *wlist = si + N, *n_big = si + 2 * N;
   double* cc_new = F.scratch_d + r * 2 * (int64_t)N;
   double* part_new = cc_new + N;
   double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
@@ -495,14 +548,15 @@ __global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwPa
   for (int p = n; p < N; ++p)
     fw_set_node_width<LOG2L, K, HYPER>(F, v, w64, p, fw_width<LOG2L, K>(P, F, v.mask(p), lig, gbase), lane0);
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  fw_traverse<LOG2L, K, HYPER>(v, N, order, lane0);
   Mask<K> slices;
   if (a.slices_in) {
+    fw_traverse<LOG2L, K, HYPER>(v, N, order, lane0);
 #pragma unroll
     for (int k = 0; k < K; ++k) slices.w[k] = a.slices_in[v.widx(k)];
   } else {
-    volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + N + F.I64);
-    slices = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, n_big, pos, lpos, lwide, lane0, gbase, F.status + r);
+    volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + 2 * N + F.I64);
+    slices = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, wlist, n_big, pos, lpos, lwide, lane0, gbase,
+                                            F.status + r);
   }
   double sum = 0;
   const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, order, slices, cc_new, part_new, lane0, gbase, &sum);
@@ -557,7 +611,8 @@ __global__ __launch_bounds__(256) void fw_init_kernel(const Params P, const FwPa
 // Sweep k of this launch re-slices when (step_offset + k) % update_every == 0
 // (tnco/app/finite_width/sa.py:228).
 template <int LOG2L, int K, bool HYPER>
-__global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwParams F, const double* __restrict__ betas,
+// (2 waves per SIMD: the kernel sits at the 256-VGPR edge, and one register more would halve the occupancy)
+__global__ __launch_bounds__(256, 2) void fw_run_kernel(const Params P, const FwParams F, const double* __restrict__ betas,
                                                      const int64_t n_steps, const int prob_kind,
                                                      const int64_t step_offset, const int64_t update_every) {
   constexpr int L = 1 << LOG2L;
@@ -585,8 +640,8 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
   R rng;
   rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
   int32_t* si = F.scratch_i + r * fw_scratch_ints(N, F.I64);
-  int32_t *order = si, *n_big = si + N;
-  volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + N + F.I64);
+  int32_t *order = si, *wlist = si + N, *n_big = si + 2 * N;
+  volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + 2 * N + F.I64);
   double* cc_new = F.scratch_d + r * 2 * (int64_t)N;
   double* part_new = cc_new + N;
   double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
@@ -765,19 +820,20 @@ __global__ __launch_bounds__(256) void fw_run_kernel(const Params P, const FwPar
     const bool do_slices = update_every > 0 && ((step_offset + step) % update_every) == 0;
     FW_PROF_T(1);
     if (do_slices && gany<LOG2L>(mnonzero<K>(slices))) {
-      fw_traverse<LOG2L, K, HYPER>(v, N, order, lane0);
-      FW_PROF_T(2);
 #if defined(TNCO_PROFILE) && TNCO_PROFILE == 3  // event counts instead of cycles
-      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, n_big, pos, lpos, lwide, lane0, gbase,
-                                                  F.status + r, nullptr, fc_);
+      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, wlist, n_big, pos, lpos, lwide, lane0,
+                                                  gbase, F.status + r, nullptr, fc_);
 #elif defined(TNCO_PROFILE)
-      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, n_big, pos, lpos, lwide, lane0, gbase,
-                                                  F.status + r, ft_);  // ft_[1] := end of the first pass
-      fa_[0] += ft_[1] - ft_[2];                                       // slot 0: first pass of get_slices
-      ft_[1] = ft_[0];
+      unsigned long long fp_[2] = {0, 0};  // end of the first pass, end of the post-order
+      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, wlist, n_big, pos, lpos, lwide, lane0,
+                                                  gbase, F.status + r, fp_);
+      ft_[2] = fp_[0];
+      ft_[0] = ft_[1];                  // slot 0: too-wide counts (from the start of the re-slice)
+      ft_[1] = ft_[2];                  // slot 1: post-order
+      ft_[2] = fp_[1];                  // slot 2: the greedy pass (up to T(3))
 #else
-      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, n_big, pos, lpos, lwide, lane0, gbase,
-                                                  F.status + r);
+      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, wlist, n_big, pos, lpos, lwide, lane0,
+                                                  gbase, F.status + r);
 #endif
       FW_PROF_T(3);
       double sum;
