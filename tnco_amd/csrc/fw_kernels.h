@@ -36,10 +36,11 @@ struct FwParams {
                             //     since the scratch holds every index)
 };
 
-// int32 of scratch per replica: post-order [N], the too-wide tensors in post-order [N], too-wide
-// counts [I64], candidate legs of one tensor (int16, for the shuffle when they do not fit the LDS
-// fast path) [I64: every index can be one]
-__host__ __device__ inline int64_t fw_scratch_ints(int N, int I64) { return 2 * (int64_t)N + I64 + I64 / 2; }
+// int32 of scratch per replica: post-order [N], the too-wide tensors in post-order [N], the internal
+// nodes in post-order [N], deep part of the traversal stack [N], too-wide counts [I64], candidate legs
+// of one tensor (int16, for the shuffle when they do not fit the LDS fast path) [I64: every index can
+// be one]
+__host__ __device__ inline int64_t fw_scratch_ints(int N, int I64) { return 4 * (int64_t)N + I64 + I64 / 2; }
 
 // a value of width_type, held in a double
 __device__ __forceinline__ double fw_wr(const FwParams& F, double x) {
@@ -174,40 +175,92 @@ __device__ __forceinline__ void fw_shuffle(Rng<LOG2L>& rng, A a, int n, bool lan
   }
 }
 
-// Post-order of include/tnco/utils.hpp:34-51 (child 0's subtree, child 1's subtree, the node) into
-// order[N], by walking the links: the successor of x is its parent if x is the right child, else the
-// left-most leaf below its sibling.  No stack, no stores to wait for.
-// With a bitmap `lwide` (LDS) the marked nodes are also listed, in the same order, in wlist[]; their
-// number is returned.
+// Post-order of include/tnco/utils.hpp:34-51 (child 0's subtree, child 1's subtree, the node).
+// Emits: order[N] (every node), iorder[N - n] (the internal nodes only, same order: what the cache
+// rebuild iterates over) and, with a bitmap `lwide` (LDS), wlist[] = the marked nodes in that order
+// (their number is returned).
+//
+// With a stack (entries: node | right child << 13 | right-visited << 26; the first `cap` of them in
+// LDS `lstk`, deeper ones in the global scratch `gstk`) every internal node's header is fetched ONCE,
+// on the way down -- 1 dependent HBM load per internal node.  Without one the links are walked
+// instead (the successor of x is its parent if x is the right child, else the left-most leaf below
+// its sibling): ~5 dependent loads per internal node.
 template <int LOG2L, int K, bool HYPER>
-__device__ __forceinline__ int fw_traverse(const View<LOG2L, K, HYPER>& v, int N, int32_t* order, bool lane0,
-                                           lds_vi32* lwide = nullptr, int32_t* wlist = nullptr) {
-  int x = N - 1;
-  for (;;) {
-    const int l = v.left(x);
-    if (l < 0) break;
-    x = l;
-  }
-  int cnt = 0, nw = 0;
-  for (;;) {
+__device__ __forceinline__ int fw_traverse(const View<LOG2L, K, HYPER>& v, int N, int32_t* order, int32_t* iorder,
+                                           bool lane0, lds_vi32* lstk = nullptr, int cap = 0,
+                                           volatile int32_t* gstk = nullptr, lds_vi32* lwide = nullptr,
+                                           int32_t* wlist = nullptr) {
+  const int n = v.n;
+  int cnt = 0, ni = 0, nw = 0;
+  auto emit = [&](int x) {
     if (lane0) order[cnt] = x;
     ++cnt;
+    if (x >= n) {
+      if (lane0) iorder[ni] = x;
+      ++ni;
+    }
     if (lwide != nullptr && ((lwide[x >> 5] >> (x & 31)) & 1)) {
       if (lane0) wlist[nw] = x;
       ++nw;
     }
-    const int p = v.parent(x);
-    if (p < 0) break;
-    const int rr = v.right(p);
-    if (rr == x) {
-      x = p;
-      continue;
+  };
+  const bool walk = (lstk == nullptr) || (gstk == nullptr) || N > 8192;
+  if (!walk) {
+    auto top = [&](int sp) -> int { return sp <= cap ? (int)lstk[sp - 1] : (int)gstk[sp - 1 - cap]; };
+    auto put = [&](int sp, int e) {  // entry number sp (1-based)
+      if (lane0) {
+        if (sp <= cap) lstk[sp - 1] = e; else gstk[sp - 1 - cap] = e;
+      }
+    };
+    int sp = 0, x = N - 1;
+    for (;;) {
+      while (x >= n) {  // down: push (x, right child), go left
+        const NodeRec* h = v.hdr(x);
+        const int l = h->left, rr = h->right;
+        ++sp;
+        put(sp, x | (rr << 13));
+        x = l;
+      }
+      emit(x);  // a leaf
+      bool down = false;
+      while (sp > 0) {  // up: into the right subtree of the innermost open node, or close it
+        if (sp > cap) __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (lane 0's store, every lane's load)
+        const int e = top(sp);
+        if ((e >> 26) == 0) {
+          put(sp, e | (1 << 26));
+          x = (e >> 13) & 0x1FFF;
+          down = true;
+          break;
+        }
+        --sp;
+        emit(e & 0x1FFF);
+      }
+      if (!down) break;
     }
-    x = rr;
+  }
+  if (walk) {
+    cnt = ni = nw = 0;
+    int x = N - 1;
     for (;;) {
       const int l = v.left(x);
       if (l < 0) break;
       x = l;
+    }
+    for (;;) {
+      emit(x);
+      const int p = v.parent(x);
+      if (p < 0) break;
+      const int rr = v.right(p);
+      if (rr == x) {
+        x = p;
+        continue;
+      }
+      x = rr;
+      for (;;) {
+        const int l = v.left(x);
+        if (l < 0) break;
+        x = l;
+      }
     }
   }
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -216,19 +269,34 @@ __device__ __forceinline__ int fw_traverse(const View<LOG2L, K, HYPER>& v, int N
 
 // CostCache(ctree, ccost, slices) (finite_width/utils.hpp:36-47) into scratch; returns
 // partial[root]; *sum = get_cost (finite_width/utils.hpp:24-33).  The contraction cost is taken
-// over in1 | in2 | slices (finite_width/cost_model/simple.hpp:139-144).  The chain of partial sums
-// is lane 0's alone (its own stores, its own loads: no wait between nodes).
+// over in1 | in2 | slices (finite_width/cost_model/simple.hpp:139-144).  Iterates over the internal
+// nodes in post-order (`iorder`, fetched four ahead together with their child links): every
+// iteration is work for every replica of the wavefront.  The chain of partial sums is lane 0's
+// alone (its own stores, its own loads: no wait between nodes).
 template <int LOG2L, int K, bool HYPER>
-__device__ __forceinline__ double fw_rebuild(const Params& P, const View<LOG2L, K, HYPER>& v, const int32_t* order,
+__device__ __forceinline__ double fw_rebuild(const Params& P, const View<LOG2L, K, HYPER>& v, const int32_t* iorder,
                                              const Mask<K>& slices, double* cc_new, double* part_new, bool lane0,
                                              int gbase, double* sum) {
-  const int n = P.n, N = P.N;
+  const int n = P.n, ni = P.N - P.n;
   double s = 0.0, part = 0.0;
-  for (int i = 0; i < N; ++i) {
-    const int p = order[i];
-    const int l = v.left(p);
-    if (l < 0) continue;
-    const int rr = v.right(p);
+  int pa = 0, pb = 0, pc = 0, pd = 0;          // window of four nodes ...
+  int2 ca = {0, 0}, cb = {0, 0}, cc = {0, 0}, cd = {0, 0};  // ... and their (left, right)
+  auto fetch = [&](int j) {
+    if (j < ni) { pa = iorder[j]; }
+    if (j + 1 < ni) { pb = iorder[j + 1]; }
+    if (j + 2 < ni) { pc = iorder[j + 2]; }
+    if (j + 3 < ni) { pd = iorder[j + 3]; }
+    if (j < ni) ca = *reinterpret_cast<const int2*>(v.hdr(pa));
+    if (j + 1 < ni) cb = *reinterpret_cast<const int2*>(v.hdr(pb));
+    if (j + 2 < ni) cc = *reinterpret_cast<const int2*>(v.hdr(pc));
+    if (j + 3 < ni) cd = *reinterpret_cast<const int2*>(v.hdr(pd));
+  };
+  fetch(0);
+  for (int j = 0; j < ni; ++j) {
+    const int p = pa, l = ca.x, rr = ca.y;
+    pa = pb; pb = pc; pc = pd;
+    ca = cb; cb = cc; cc = cd;
+    if ((j & 3) == 3) fetch(j + 1);
     const Mask<K> u = mor<K>(mor<K>(v.mask(l), v.mask(rr)), slices);
     const double c = generic_cost<LOG2L, K>(P, u, v.lig, gbase);
     s = rnd_cost(s + c, P.f32);
@@ -408,7 +476,7 @@ __device__ __forceinline__ void fw_slice_tensor(const Params& P, const FwParams&
 template <int LOG2L, int K, bool HYPER>
 __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
                                                  const double* w64, Rng<LOG2L>& rng, int32_t* order, int32_t* wlist,
-                                                 int32_t* n_big, volatile int16_t* pos, lds_vi32* lpos,
+                                                 int32_t* iorder, int32_t* gstk, int32_t* n_big, volatile int16_t* pos, lds_vi32* lpos,
                                                  lds_vi32* lwide, bool lane0, int gbase, int32_t* status,
                                                  unsigned long long* prof = nullptr,
                                                  unsigned long long* cnt = nullptr) {
@@ -478,7 +546,9 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
 #ifdef TNCO_PROFILE
   if (prof) prof[0] = __builtin_amdgcn_s_memtime();
 #endif
-  const int nw = fw_traverse<LOG2L, K, HYPER>(v, N, order, lane0, usebm ? lwide : nullptr, wlist);
+  // (the traversal borrows the LDS of the candidate list for its stack)
+  const int nw = fw_traverse<LOG2L, K, HYPER>(v, N, order, iorder, lane0, lpos, FW_LDSPOS, gstk,
+                                              usebm ? lwide : nullptr, wlist);
 #ifdef TNCO_PROFILE
   if (prof) prof[1] = __builtin_amdgcn_s_memtime();
 #endif
@@ -540,7 +610,7 @@ __global__ __launch_bounds__(256, 2) void fw_init_kernel(const Params P, const F
   R rng;
   rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
   int32_t* si = F.scratch_i + r * fw_scratch_ints(N, F.I64);
-  int32_t *order = si, *wlist = si + N, *n_big = si + 2 * N;
+  int32_t *order = si, *wlist = si + N, *iorder = si + 2 * N, *gstk = si + 3 * N, *n_big = si + 4 * N;
   double* cc_new = F.scratch_d + r * 2 * (int64_t)N;
   double* part_new = cc_new + N;
   double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
@@ -550,16 +620,16 @@ __global__ __launch_bounds__(256, 2) void fw_init_kernel(const Params P, const F
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
   Mask<K> slices;
   if (a.slices_in) {
-    fw_traverse<LOG2L, K, HYPER>(v, N, order, lane0);
+    fw_traverse<LOG2L, K, HYPER>(v, N, order, iorder, lane0, lpos, FW_LDSPOS, gstk);
 #pragma unroll
     for (int k = 0; k < K; ++k) slices.w[k] = a.slices_in[v.widx(k)];
   } else {
-    volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + 2 * N + F.I64);
-    slices = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, wlist, n_big, pos, lpos, lwide, lane0, gbase,
-                                            F.status + r);
+    volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + 4 * N + F.I64);
+    slices = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, wlist, iorder, gstk, n_big, pos, lpos, lwide, lane0,
+                                            gbase, F.status + r);
   }
   double sum = 0;
-  const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, order, slices, cc_new, part_new, lane0, gbase, &sum);
+  const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, iorder, slices, cc_new, part_new, lane0, gbase, &sum);
   fw_commit<LOG2L, K, HYPER>(P, v, cc_new, part_new);
   uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
 #pragma unroll
@@ -640,8 +710,8 @@ __global__ __launch_bounds__(256, 2) void fw_run_kernel(const Params P, const Fw
   R rng;
   rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
   int32_t* si = F.scratch_i + r * fw_scratch_ints(N, F.I64);
-  int32_t *order = si, *wlist = si + N, *n_big = si + 2 * N;
-  volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + 2 * N + F.I64);
+  int32_t *order = si, *wlist = si + N, *iorder = si + 2 * N, *gstk = si + 3 * N, *n_big = si + 4 * N;
+  volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + 4 * N + F.I64);
   double* cc_new = F.scratch_d + r * 2 * (int64_t)N;
   double* part_new = cc_new + N;
   double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
@@ -769,9 +839,9 @@ __global__ __launch_bounds__(256, 2) void fw_run_kernel(const Params P, const Fw
           }
           v.set_mask(B, newB);
           __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          fw_traverse<LOG2L, K, HYPER>(v, N, order, lane0);
+          fw_traverse<LOG2L, K, HYPER>(v, N, order, iorder, lane0, lpos, FW_LDSPOS, gstk);
           double sum;
-          const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, order, new_slices, cc_new, part_new, lane0, gbase, &sum);
+          const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, iorder, new_slices, cc_new, part_new, lane0, gbase, &sum);
           const double delta = rnd_cost(tot - total, f32);
           const double u = uniform01();
           if (accept_move(prob_kind, beta, delta, total, u, f32)) {
@@ -821,23 +891,23 @@ __global__ __launch_bounds__(256, 2) void fw_run_kernel(const Params P, const Fw
     FW_PROF_T(1);
     if (do_slices && gany<LOG2L>(mnonzero<K>(slices))) {
 #if defined(TNCO_PROFILE) && TNCO_PROFILE == 3  // event counts instead of cycles
-      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, wlist, n_big, pos, lpos, lwide, lane0,
-                                                  gbase, F.status + r, nullptr, fc_);
+      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, wlist, iorder, gstk, n_big, pos, lpos, lwide,
+                                                  lane0, gbase, F.status + r, nullptr, fc_);
 #elif defined(TNCO_PROFILE)
       unsigned long long fp_[2] = {0, 0};  // end of the first pass, end of the post-order
-      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, wlist, n_big, pos, lpos, lwide, lane0,
-                                                  gbase, F.status + r, fp_);
+      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, wlist, iorder, gstk, n_big, pos, lpos, lwide,
+                                                  lane0, gbase, F.status + r, fp_);
       ft_[2] = fp_[0];
       ft_[0] = ft_[1];                  // slot 0: too-wide counts (from the start of the re-slice)
       ft_[1] = ft_[2];                  // slot 1: post-order
       ft_[2] = fp_[1];                  // slot 2: the greedy pass (up to T(3))
 #else
-      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, wlist, n_big, pos, lpos, lwide, lane0,
-                                                  gbase, F.status + r);
+      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, wlist, iorder, gstk, n_big, pos, lpos, lwide,
+                                                  lane0, gbase, F.status + r);
 #endif
       FW_PROF_T(3);
       double sum;
-      const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, order, ns, cc_new, part_new, lane0, gbase, &sum);
+      const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, iorder, ns, cc_new, part_new, lane0, gbase, &sum);
       if (tot < v.hdr(N - 1)->partial) {
         slices = ns;
         fw_commit<LOG2L, K, HYPER>(P, v, cc_new, part_new);
