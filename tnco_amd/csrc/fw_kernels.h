@@ -176,7 +176,7 @@ __device__ __forceinline__ void fw_shuffle(Rng<LOG2L>& rng, A a, int n, bool lan
 }
 
 // Post-order of include/tnco/utils.hpp:34-51 (child 0's subtree, child 1's subtree, the node).
-// Emits: order[N] (every node), iorder[N - n] (the internal nodes only, same order: what the cache
+// Emits: order[N] (every node; not when `order` is NULL), iorder[N - n] (the internal nodes only, same order: what the cache
 // rebuild iterates over) and, with a bitmap `lwide` (LDS), wlist[] = the marked nodes in that order
 // (their number is returned).
 //
@@ -189,12 +189,14 @@ template <int LOG2L, int K, bool HYPER>
 __device__ __forceinline__ int fw_traverse(const View<LOG2L, K, HYPER>& v, int N, int32_t* order, int32_t* iorder,
                                            bool lane0, lds_vi32* lstk = nullptr, int cap = 0,
                                            volatile int32_t* gstk = nullptr, lds_vi32* lwide = nullptr,
-                                           int32_t* wlist = nullptr) {
+                                           int32_t* wlist = nullptr, unsigned long long* dbg = nullptr) {
   const int n = v.n;
   int cnt = 0, ni = 0, nw = 0;
   auto emit = [&](int x) {
-    if (lane0) order[cnt] = x;
-    ++cnt;
+    if (order != nullptr) {
+      if (lane0) order[cnt] = x;
+      ++cnt;
+    }
     if (x >= n) {
       if (lane0) iorder[ni] = x;
       ++ni;
@@ -206,36 +208,54 @@ __device__ __forceinline__ int fw_traverse(const View<LOG2L, K, HYPER>& v, int N
   };
   const bool walk = (lstk == nullptr) || (gstk == nullptr) || N > 8192;
   if (!walk) {
-    auto top = [&](int sp) -> int { return sp <= cap ? (int)lstk[sp - 1] : (int)gstk[sp - 1 - cap]; };
+    auto top = [&](int sp) -> int {
+      if (sp <= cap) return (int)lstk[sp - 1];
+      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (lane 0's store, every lane's load)
+      return (int)gstk[sp - 1 - cap];
+    };
     auto put = [&](int sp, int e) {  // entry number sp (1-based)
       if (lane0) {
         if (sp <= cap) lstk[sp - 1] = e; else gstk[sp - 1 - cap] = e;
       }
     };
+    // Every iteration of the outer loop is ONE header fetch for every replica of the wavefront that
+    // is not done (the replicas' trees differ; a loop nest that follows one tree's shape would cost
+    // every replica the longest descent / ascent among the sixteen).  What follows the fetch -- leaves
+    // emitted, finished nodes popped -- touches the stack only.
     int sp = 0, x = N - 1;
-    for (;;) {
-      while (x >= n) {  // down: push (x, right child), go left
-        const NodeRec* h = v.hdr(x);
-        const int l = h->left, rr = h->right;
-        ++sp;
-        put(sp, x | (rr << 13));
-        x = l;
-      }
-      emit(x);  // a leaf
-      bool down = false;
-      while (sp > 0) {  // up: into the right subtree of the innermost open node, or close it
-        if (sp > cap) __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (lane 0's store, every lane's load)
-        const int e = top(sp);
-        if ((e >> 26) == 0) {
-          put(sp, e | (1 << 26));
-          x = (e >> 13) & 0x1FFF;
-          down = true;
+    if (x < n) emit(x);
+    bool active = x >= n;
+    while (active) {
+      const int2 c = *reinterpret_cast<const int2*>(v.hdr(x));  // (left, right)
+      ++sp;
+      put(sp, x | (c.y << 13));
+      x = c.x;
+      if (x >= n) continue;
+#if defined(TNCO_PROFILE) && TNCO_PROFILE == 4
+      const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#endif
+      emit(x);  // the left child is a leaf
+      for (;;) {  // up: into the right subtree of the innermost open node, or close it
+        if (sp == 0) {
+          active = false;
           break;
         }
+        const int e = top(sp);
+        const int node = e & 0x1FFF, rr = (e >> 13) & 0x1FFF;
+        if ((e >> 26) == 0) {
+          if (rr >= n) {
+            put(sp, e | (1 << 26));
+            x = rr;
+            break;
+          }
+          emit(rr);  // the right child is a leaf: the node is finished as well
+        }
         --sp;
-        emit(e & 0x1FFF);
+        emit(node);
       }
-      if (!down) break;
+#if defined(TNCO_PROFILE) && TNCO_PROFILE == 4
+      if (dbg) *dbg += __builtin_amdgcn_s_memtime() - t0_;  // (slot "counts" += the stack-only part)
+#endif
     }
   }
   if (walk) {
@@ -270,41 +290,89 @@ __device__ __forceinline__ int fw_traverse(const View<LOG2L, K, HYPER>& v, int N
 // CostCache(ctree, ccost, slices) (finite_width/utils.hpp:36-47) into scratch; returns
 // partial[root]; *sum = get_cost (finite_width/utils.hpp:24-33).  The contraction cost is taken
 // over in1 | in2 | slices (finite_width/cost_model/simple.hpp:139-144).  Iterates over the internal
-// nodes in post-order (`iorder`, fetched four ahead together with their child links): every
-// iteration is work for every replica of the wavefront.  The chain of partial sums is lane 0's
-// alone (its own stores, its own loads: no wait between nodes).
+// nodes in post-order (`iorder`): every iteration is work for every replica of the wavefront.
+//
+// Four nodes per iteration: their eight child masks are requested together (one memory latency per
+// four nodes), with the child links of the next four and the node numbers of the four after those.
+// The chain of partial sums is lane 0's alone.  In post-order an internal right child is the node
+// just before its parent; a left child's sum comes from memory (lane 0's own earlier store) unless
+// it was computed in the same group of four.
 template <int LOG2L, int K, bool HYPER>
 __device__ __forceinline__ double fw_rebuild(const Params& P, const View<LOG2L, K, HYPER>& v, const int32_t* iorder,
                                              const Mask<K>& slices, double* cc_new, double* part_new, bool lane0,
                                              int gbase, double* sum) {
+  constexpr int B = 4;
   const int n = P.n, ni = P.N - P.n;
   double s = 0.0, part = 0.0;
-  int pa = 0, pb = 0, pc = 0, pd = 0;          // window of four nodes ...
-  int2 ca = {0, 0}, cb = {0, 0}, cc = {0, 0}, cd = {0, 0};  // ... and their (left, right)
-  auto fetch = [&](int j) {
-    if (j < ni) { pa = iorder[j]; }
-    if (j + 1 < ni) { pb = iorder[j + 1]; }
-    if (j + 2 < ni) { pc = iorder[j + 2]; }
-    if (j + 3 < ni) { pd = iorder[j + 3]; }
-    if (j < ni) ca = *reinterpret_cast<const int2*>(v.hdr(pa));
-    if (j + 1 < ni) cb = *reinterpret_cast<const int2*>(v.hdr(pb));
-    if (j + 2 < ni) cc = *reinterpret_cast<const int2*>(v.hdr(pc));
-    if (j + 3 < ni) cd = *reinterpret_cast<const int2*>(v.hdr(pd));
-  };
-  fetch(0);
-  for (int j = 0; j < ni; ++j) {
-    const int p = pa, l = ca.x, rr = ca.y;
-    pa = pb; pb = pc; pc = pd;
-    ca = cb; cb = cc; cc = cd;
-    if ((j & 3) == 3) fetch(j + 1);
-    const Mask<K> u = mor<K>(mor<K>(v.mask(l), v.mask(rr)), slices);
-    const double c = generic_cost<LOG2L, K>(P, u, v.lig, gbase);
-    s = rnd_cost(s + c, P.f32);
-    if (lane0) {
-      const double pl = l < n ? 0.0 : part_new[l], pr = rr < n ? 0.0 : part_new[rr];
-      part = rnd_cost(rnd_cost(c + pl, P.f32) + pr, P.f32);
-      cc_new[p] = c;
-      part_new[p] = part;
+  if (ni <= 0) {
+    *sum = 0.0;
+    return 0.0;
+  }
+  auto ld_node = [&](int j) -> int { return j < ni ? iorder[j] : n; };  // (past the end: any internal node)
+  auto ld_links = [&](int x) -> int2 { return *reinterpret_cast<const int2*>(v.hdr(x)); };
+  int nd[B], nn[B];
+  int2 lk[B];
+#pragma unroll
+  for (int i = 0; i < B; ++i) nd[i] = ld_node(i);
+#pragma unroll
+  for (int i = 0; i < B; ++i) nn[i] = ld_node(B + i);
+#pragma unroll
+  for (int i = 0; i < B; ++i) lk[i] = ld_links(nd[i]);
+  int prev = -1;
+  for (int j0 = 0; j0 < ni; j0 += B) {
+    Mask<K> ml[B], mr[B];
+    double plv[B];
+    int2 lkn[B];
+    int n2[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      ml[i] = v.mask(lk[i].x);
+      mr[i] = v.mask(lk[i].y);
+    }
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      plv[i] = 0.0;
+      if (lane0 && lk[i].x >= n) plv[i] = part_new[lk[i].x];  // (stale if computed in this group: see below)
+    }
+#pragma unroll
+    for (int i = 0; i < B; ++i) lkn[i] = ld_links(nn[i]);
+#pragma unroll
+    for (int i = 0; i < B; ++i) n2[i] = ld_node(j0 + 2 * B + i);
+    double pv[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      pv[i] = 0.0;
+      if (j0 + i < ni) {
+        const int p = nd[i], l = lk[i].x, rr = lk[i].y;
+        const Mask<K> u = mor<K>(mor<K>(ml[i], mr[i]), slices);
+        const double c = generic_cost<LOG2L, K>(P, u, v.lig, gbase);
+        s = rnd_cost(s + c, P.f32);
+        if (lane0) {
+          double pl = plv[i];
+#pragma unroll
+          for (int k = 0; k < i; ++k)
+            if (l == nd[k]) pl = pv[k];
+          double pr = 0.0;
+          if (rr >= n) {
+            pr = part;
+            if (rr != prev) {  // (never, in post-order)
+              __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              pr = part_new[rr];
+            }
+          }
+          part = rnd_cost(rnd_cost(c + pl, P.f32) + pr, P.f32);
+          cc_new[p] = c;
+          part_new[p] = part;
+        }
+        pv[i] = part;
+        prev = p;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      nd[i] = nn[i];
+      lk[i] = lkn[i];
+      nn[i] = n2[i];
     }
   }
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -317,9 +385,26 @@ template <int LOG2L, int K, bool HYPER>
 __device__ __forceinline__ void fw_commit(const Params& P, const View<LOG2L, K, HYPER>& v, const double* cc_new,
                                           const double* part_new) {
   constexpr int L = 1 << LOG2L;
-  for (int p = P.n + v.lig; p < P.N; p += L) {
-    v.hdr(p)->ccost = cc_new[p];
-    v.hdr(p)->partial = part_new[p];
+  constexpr int B = 4;  // loads in flight per lane: 2 * B
+  for (int p0 = P.n + v.lig; p0 < P.N; p0 += B * L) {
+    double c[B], q[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const int p = p0 + i * L;
+      c[i] = q[i] = 0.0;
+      if (p < P.N) {
+        c[i] = cc_new[p];
+        q[i] = part_new[p];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const int p = p0 + i * L;
+      if (p < P.N) {
+        v.hdr(p)->ccost = c[i];
+        v.hdr(p)->partial = q[i];
+      }
+    }
   }
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -385,21 +470,17 @@ __device__ __forceinline__ uint32_t fw_positions(const View<LOG2L, K, HYPER>& v,
 constexpr int FW_LDSPOS = TNCO_FW_LDSPOS;  // candidate legs per tensor that fit the LDS fast path
 constexpr int FW_WIDEW = 4;     // LDS bitmap of the too-wide tensors: FW_WIDEW * L * K words per replica
 
-// One too-wide tensor `t` of get_slices_impl's post-order pass (finite_width/greedy/utils.hpp:62-101):
-// if it is still too wide after the slices chosen so far, shuffle its candidate legs and slice them
-// in the order of `greater` until it fits.
+// A tensor that is still too wide after the slices chosen so far (sliced_xs = its legs - slices, of
+// width sliced_width): shuffle its candidate legs and slice them in the order of `greater` until it
+// fits (finite_width/greedy/utils.hpp:72-101).
 template <int LOG2L, int K, bool HYPER>
-__device__ __forceinline__ void fw_slice_tensor(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
-                                                Rng<LOG2L>& rng, const int32_t* n_big, volatile int16_t* pos,
-                                                lds_vi32* lpos, bool lane0, int gbase, int32_t* status,
-                                                const Mask<K>& skip, int t, Mask<K>& slices,
-                                                unsigned long long* cnt) {
+__device__ __forceinline__ void fw_slice_wide(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
+                                              Rng<LOG2L>& rng, const int32_t* n_big, volatile int16_t* pos,
+                                              lds_vi32* lpos, bool lane0, int gbase, int32_t* status,
+                                              const Mask<K>& skip, Mask<K> sliced_xs, double sliced_width,
+                                              Mask<K>& slices, unsigned long long* cnt) {
   constexpr int L = 1 << LOG2L;
   const int lig = v.lig;
-  if (cnt) cnt[0] += 1;  // too-wide tensors
-  Mask<K> sliced_xs = mandn<K>(v.mask(t), slices);
-  double sliced_width = fw_width<LOG2L, K>(P, F, sliced_xs, lig, gbase);
-  if (!(sliced_width > F.max_width)) return;
   if (cnt) cnt[1] += 1;  // ... still too wide after the slices so far: shuffled and picked from
   // candidate positions, ascending
   const Mask<K> cand = mandn<K>(sliced_xs, skip);
@@ -467,6 +548,23 @@ __device__ __forceinline__ void fw_slice_tensor(const Params& P, const FwParams&
   }
 }
 
+// One too-wide tensor `t` of get_slices_impl's post-order pass (finite_width/greedy/utils.hpp:62-101):
+// if it is still too wide after the slices chosen so far, shuffle its candidate legs and slice them
+// in the order of `greater` until it fits.
+template <int LOG2L, int K, bool HYPER>
+__device__ __forceinline__ void fw_slice_tensor(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
+                                                Rng<LOG2L>& rng, const int32_t* n_big, volatile int16_t* pos,
+                                                lds_vi32* lpos, bool lane0, int gbase, int32_t* status,
+                                                const Mask<K>& skip, int t, Mask<K>& slices,
+                                                unsigned long long* cnt) {
+  if (cnt) cnt[0] += 1;  // too-wide tensors
+  Mask<K> sliced_xs = mandn<K>(v.mask(t), slices);
+  double sliced_width = fw_width<LOG2L, K>(P, F, sliced_xs, v.lig, gbase);
+  if (!(sliced_width > F.max_width)) return;
+  fw_slice_wide<LOG2L, K, HYPER>(P, F, v, rng, n_big, pos, lpos, lane0, gbase, status, skip, sliced_xs, sliced_width,
+                                 slices, cnt);
+}
+
 // get_slices_impl, finite_width/greedy/utils.hpp:21-125; also leaves the post-order of the tree in
 // order[].  The 16 replicas of a wavefront find their too-wide tensors at different places of their
 // trees, and the work on one such tensor is long: run per replica "as it comes", that work would
@@ -491,9 +589,11 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
   // :41-48  number of too-wide tensors every index appears in
   const bool usebm = lwide != nullptr && N <= 32 * FW_WIDEW * L * K;
   const int nwords = (N + 31) / 32;
-  if (usebm)
+  if (usebm) {
     for (int i = lig; i < nwords; i += L) lwide[i] = 0;
-  for (int i = lig; i < F.I64; i += L) n_big[i] = 0;
+  } else {
+    for (int i = lig; i < F.I64; i += L) n_big[i] = 0;
+  }
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
   auto count_legs = [&](int t) {
     const Mask<K> m = v.mask(t);
@@ -531,40 +631,125 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
     if (t0 + 2 < N && wc > F.max_width) found(t0 + 2);
     if (t0 + 3 < N && wd > F.max_width) found(t0 + 3);
   }
-  if (usebm) {  // the k-th marked tensor of every replica, together
+  if (usebm) {
+    // The k-th marked tensor of every replica, together.  Every index belongs to one lane (bit b of
+    // its word k), so the counts are kept there, bit-sliced: plane p holds bit p of the 64 * K
+    // counters of the lane, adding a tensor's mask is a ripple-carry over the planes (no memory
+    // traffic at all; the first version issued one atomic per leg: 5 000 per replica on config 5,
+    // bound by the L2's atomic rate).  The planes are written out as int32 counts once per
+    // 2^NP - 1 tensors.
+    constexpr int NP = K <= 4 ? 8 : 5;  // (registers: 2 * K * NP)
+    Mask<K> pl[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) pl[p] = mzero<K>();
+    bool first = true;
+    auto flush = [&]() {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          uint32_t w[NP];
+#pragma unroll
+          for (int p = 0; p < NP; ++p) w[p] = (uint32_t)(pl[p].w[k] >> (32 * h));
+          int4* dst = reinterpret_cast<int4*>(n_big + v.widx(k) * 64 + 32 * h);
+          for (int j = 0; j < 8; ++j) {
+            int4 c = {0, 0, 0, 0};
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+              c.x |= (int)((w[p] & 1u) << p);
+              c.y |= (int)(((w[p] >> 1) & 1u) << p);
+              c.z |= (int)(((w[p] >> 2) & 1u) << p);
+              c.w |= (int)(((w[p] >> 3) & 1u) << p);
+              w[p] >>= 4;
+            }
+            if (!first) {
+              const int4 o = dst[j];
+              c.x += o.x; c.y += o.y; c.z += o.z; c.w += o.w;
+            }
+            dst[j] = c;
+          }
+        }
+      }
+      first = false;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) pl[p] = mzero<K>();
+    };
     int wi = 0;
     uint32_t bits = (uint32_t)lwide[0];
-    for (;;) {
+    auto next_t = [&]() -> int {
       while (bits == 0u && ++wi < nwords) bits = (uint32_t)lwide[wi];
-      if (wi >= nwords) break;
+      if (wi >= nwords) return -1;
       const int t = wi * 32 + __ffs((int)bits) - 1;
       bits &= bits - 1u;
-      count_legs(t);
+      return t;
+    };
+    int t0 = next_t(), inchunk = 0;
+    Mask<K> m0 = mzero<K>();
+    if (t0 >= 0) m0 = v.mask(t0);
+    const bool any = t0 >= 0;
+    while (t0 >= 0) {
+      const int t1 = next_t();  // (the next mask is on its way while this one is added)
+      Mask<K> m1 = mzero<K>();
+      if (t1 >= 0) m1 = v.mask(t1);
+      Mask<K> carry = m0;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const uint64_t tt = pl[p].w[k] & carry.w[k];
+          pl[p].w[k] ^= carry.w[k];
+          carry.w[k] = tt;
+        }
+      }
+      if (++inchunk == (1 << NP) - 1) {
+        flush();
+        inchunk = 0;
+      }
+      t0 = t1;
+      m0 = m1;
     }
+    if (any && (inchunk > 0 || first)) flush();
   }
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef TNCO_PROFILE
   if (prof) prof[0] = __builtin_amdgcn_s_memtime();
 #endif
   // (the traversal borrows the LDS of the candidate list for its stack)
-  const int nw = fw_traverse<LOG2L, K, HYPER>(v, N, order, iorder, lane0, lpos, FW_LDSPOS, gstk,
-                                              usebm ? lwide : nullptr, wlist);
+  const int nw = fw_traverse<LOG2L, K, HYPER>(v, N, usebm ? nullptr : order, iorder, lane0, lpos, FW_LDSPOS, gstk,
+                                              usebm ? lwide : nullptr, wlist, prof);
 #ifdef TNCO_PROFILE
   if (prof) prof[1] = __builtin_amdgcn_s_memtime();
 #endif
-  // :62-101  post-order over the too-wide tensors
+  // :62-101  post-order over the too-wide tensors.  Most of them fit once earlier ones have been
+  // sliced (config 5: 110 marked, 24 still too wide when their turn comes), WHICH ones differs from
+  // replica to replica, and the work on one that does not fit is long.  So every replica first runs
+  // ahead to its next tensor that does not fit (a cheap scan: masks requested one tensor ahead), then
+  // the replicas of the wavefront do the long part together.
   if (usebm) {
-    int oa = nw > 0 ? wlist[0] : 0, ob = nw > 1 ? wlist[1] : 0, oc = nw > 2 ? wlist[2] : 0, od = nw > 3 ? wlist[3] : 0;
-    for (int j = 0; j < nw; ++j) {
-      const int t = oa;
-      oa = ob; ob = oc; oc = od;
-      if ((j & 3) == 3) {  // the window is used up: fetch the next four
-        if (j + 1 < nw) oa = wlist[j + 1];
-        if (j + 2 < nw) ob = wlist[j + 2];
-        if (j + 3 < nw) oc = wlist[j + 3];
-        if (j + 4 < nw) od = wlist[j + 4];
+    int j = 0;
+    int ta = nw > 0 ? wlist[0] : 0, tb = nw > 1 ? wlist[1] : 0;
+    Mask<K> ma = mzero<K>();
+    if (nw > 0) ma = v.mask(ta);
+    for (;;) {
+      bool have = false;
+      Mask<K> sx = mzero<K>();
+      double sw = 0.0;
+      while (j < nw) {
+        const Mask<K> m = ma;
+        ta = tb;
+        ++j;
+        if (j < nw) ma = v.mask(ta);
+        if (j + 1 < nw) tb = wlist[j + 1];
+        if (cnt) cnt[0] += 1;  // too-wide tensors
+        sx = mandn<K>(m, slices);
+        sw = fw_width<LOG2L, K>(P, F, sx, lig, gbase);
+        if (sw > F.max_width) {
+          have = true;
+          break;
+        }
       }
-      fw_slice_tensor<LOG2L, K, HYPER>(P, F, v, rng, n_big, pos, lpos, lane0, gbase, status, skip, t, slices, cnt);
+      if (!have) break;
+      fw_slice_wide<LOG2L, K, HYPER>(P, F, v, rng, n_big, pos, lpos, lane0, gbase, status, skip, sx, sw, slices, cnt);
     }
   } else {
     for (int i = 0; i < N; ++i) {
@@ -620,7 +805,7 @@ __global__ __launch_bounds__(256, 2) void fw_init_kernel(const Params P, const F
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
   Mask<K> slices;
   if (a.slices_in) {
-    fw_traverse<LOG2L, K, HYPER>(v, N, order, iorder, lane0, lpos, FW_LDSPOS, gstk);
+    fw_traverse<LOG2L, K, HYPER>(v, N, nullptr, iorder, lane0, lpos, FW_LDSPOS, gstk);
 #pragma unroll
     for (int k = 0; k < K; ++k) slices.w[k] = a.slices_in[v.widx(k)];
   } else {
@@ -677,30 +862,33 @@ __global__ __launch_bounds__(256, 2) void fw_init_kernel(const Params P, const F
 #define FW_PROF_OUT(rs)
 #endif
 
-// update(prob, update_slices), finite_width/greedy/optimizer.hpp:117-390, n_steps times.
-// Sweep k of this launch re-slices when (step_offset + k) % update_every == 0
-// (tnco/app/finite_width/sa.py:228).
-template <int LOG2L, int K, bool HYPER>
-// (2 waves per SIMD: the kernel sits at the 256-VGPR edge, and one register more would halve the occupancy)
-__global__ __launch_bounds__(256, 2) void fw_run_kernel(const Params P, const FwParams F, const double* __restrict__ betas,
-                                                     const int64_t n_steps, const int prob_kind,
-                                                     const int64_t step_offset, const int64_t update_every) {
+// update(prob, update_slices), finite_width/greedy/optimizer.hpp:117-390, is two kernels here: the
+// moves of n_steps sweeps (:130-331, this one) and the re-slice at the end of a sweep (:360-376,
+// fw_reslice_kernel) -- the host launches [moves up to and including a re-slicing sweep][re-slice]...
+// (sweep k re-slices when (step_offset + k) % update_every == 0, tnco/app/finite_width/sa.py:228).
+// Two kernels because the two phases want different register budgets: as one kernel the moves ran
+// at the occupancy of the greedy pass and the greedy pass spilled.
+//
+// :385-389 (the best-so-far bookkeeping that ends every sweep) is done here for every sweep but,
+// when `tail_last` is 0, the last: that one is followed by a re-slice, which does it afterwards.
+// MAXNEW: with the max_number_new_slices > 0 branch (:226-321).
+template <int LOG2L, int K, bool HYPER, bool MAXNEW>
+__global__ __launch_bounds__(256, 2) void fw_move_kernel(const Params P, const FwParams F, const double* __restrict__ betas,
+                                                      const int64_t n_steps, const int prob_kind, const int tail_last) {
   constexpr int L = 1 << LOG2L;
   constexpr int GPB = 256 >> LOG2L;
   constexpr int LK = L * K;
   using M = Mask<K>;
   using R = Rng<LOG2L>;
   __shared__ uint32_t rngbuf[GPB * R::RING];
-  __shared__ int32_t posbuf[GPB * FW_LDSPOS];
-  __shared__ int32_t widebuf[GPB * FW_WIDEW * L * K];
+  __shared__ int32_t posbuf[MAXNEW ? GPB * FW_LDSPOS : 1];
   const int tid = threadIdx.x;
   const int lig = tid & (L - 1);
   const int gib = tid >> LOG2L;
   const int gbase = (tid & 63) & ~(L - 1);
   const int64_t r = (int64_t)blockIdx.x * GPB + gib;
   if (r >= P.R || n_steps <= 0) return;
-  lds_vi32* lpos = (lds_vi32*)posbuf + gib * FW_LDSPOS;
-  lds_vi32* lwide = (lds_vi32*)widebuf + gib * (FW_WIDEW * L * K);
+  [[maybe_unused]] lds_vi32* lpos = (lds_vi32*)posbuf + (MAXNEW ? gib * FW_LDSPOS : 0);
   const bool lane0 = lig == 0;
   const int n = P.n, N = P.N;
   const int f32 = P.f32;
@@ -710,8 +898,8 @@ __global__ __launch_bounds__(256, 2) void fw_run_kernel(const Params P, const Fw
   R rng;
   rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
   int32_t* si = F.scratch_i + r * fw_scratch_ints(N, F.I64);
-  int32_t *order = si, *wlist = si + N, *iorder = si + 2 * N, *gstk = si + 3 * N, *n_big = si + 4 * N;
-  volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + 4 * N + F.I64);
+  [[maybe_unused]] int32_t *iorder = si + 2 * N, *gstk = si + 3 * N;
+  [[maybe_unused]] volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + 4 * N + F.I64);
   double* cc_new = F.scratch_d + r * 2 * (int64_t)N;
   double* part_new = cc_new + N;
   double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
@@ -743,9 +931,7 @@ __global__ __launch_bounds__(256, 2) void fw_run_kernel(const Params P, const Fw
     return u;
   };
 
-  FW_PROF_DECL;
   for (int64_t step = 0; step < n_steps; ++step) {
-    FW_PROF_T(0);
     const double beta = betas[step];
     // :130-139
     const int leaf = (int)(rng.next_sync() % (uint32_t)n);
@@ -807,7 +993,8 @@ __global__ __launch_bounds__(256, 2) void fw_run_kernel(const Params P, const Fw
           total = rnd_cost(total + delta, f32);
           const int t = C; C = E; E = t;
         }
-      } else if (F.max_new_slices > 0) {
+      } else if constexpr (MAXNEW) {
+       if (F.max_new_slices > 0) {
         // :226-321  slice up to max_number_new_slices random further legs of the new B; if it then
         // fits, try the rotation against a FULL rebuild of the cost cache with the new slices
         M new_slices = slices;
@@ -839,7 +1026,7 @@ __global__ __launch_bounds__(256, 2) void fw_run_kernel(const Params P, const Fw
           }
           v.set_mask(B, newB);
           __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          fw_traverse<LOG2L, K, HYPER>(v, N, order, iorder, lane0, lpos, FW_LDSPOS, gstk);
+          fw_traverse<LOG2L, K, HYPER>(v, N, nullptr, iorder, lane0, lpos, FW_LDSPOS, gstk);
           double sum;
           const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, iorder, new_slices, cc_new, part_new, lane0, gbase, &sum);
           const double delta = rnd_cost(tot - total, f32);
@@ -867,6 +1054,7 @@ __global__ __launch_bounds__(256, 2) void fw_run_kernel(const Params P, const Fw
           }
           __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+       }
       }
       // :324-331
       if (!skip_cost_propagation) {
@@ -886,35 +1074,7 @@ __global__ __launch_bounds__(256, 2) void fw_run_kernel(const Params P, const Fw
       __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
       B = A;
     }
-    // :360-376
-    const bool do_slices = update_every > 0 && ((step_offset + step) % update_every) == 0;
-    FW_PROF_T(1);
-    if (do_slices && gany<LOG2L>(mnonzero<K>(slices))) {
-#if defined(TNCO_PROFILE) && TNCO_PROFILE == 3  // event counts instead of cycles
-      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, wlist, iorder, gstk, n_big, pos, lpos, lwide,
-                                                  lane0, gbase, F.status + r, nullptr, fc_);
-#elif defined(TNCO_PROFILE)
-      unsigned long long fp_[2] = {0, 0};  // end of the first pass, end of the post-order
-      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, wlist, iorder, gstk, n_big, pos, lpos, lwide,
-                                                  lane0, gbase, F.status + r, fp_);
-      ft_[2] = fp_[0];
-      ft_[0] = ft_[1];                  // slot 0: too-wide counts (from the start of the re-slice)
-      ft_[1] = ft_[2];                  // slot 1: post-order
-      ft_[2] = fp_[1];                  // slot 2: the greedy pass (up to T(3))
-#else
-      const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, wlist, iorder, gstk, n_big, pos, lpos, lwide,
-                                                  lane0, gbase, F.status + r);
-#endif
-      FW_PROF_T(3);
-      double sum;
-      const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, iorder, ns, cc_new, part_new, lane0, gbase, &sum);
-      if (tot < v.hdr(N - 1)->partial) {
-        slices = ns;
-        fw_commit<LOG2L, K, HYPER>(P, v, cc_new, part_new);
-      }
-      FW_PROF_T(4);
-      FW_PROF_ACC;
-    }
+    if (step == n_steps - 1 && !tail_last) break;  // (fw_reslice_kernel goes on from here)
     // :385-389
     const double tc = v.hdr(N - 1)->partial;
     if (tc < min_cost) {
@@ -951,6 +1111,111 @@ __global__ __launch_bounds__(256, 2) void fw_run_kernel(const Params P, const Fw
     rs->n_randpick += n_rpick;
     rs->mti = mti;
     rs->mtw = mtw;
+  }
+}
+
+// The end of a re-slicing sweep, finite_width/greedy/optimizer.hpp:360-389: new slices for the
+// current tree (get_slices), the cost cache rebuilt with them, kept if the total improves; then the
+// best-so-far bookkeeping of the sweep (:385-389).
+template <int LOG2L, int K, bool HYPER>
+__global__ __launch_bounds__(256, 2) void fw_reslice_kernel(const Params P, const FwParams F) {
+  constexpr int L = 1 << LOG2L;
+  constexpr int GPB = 256 >> LOG2L;
+  constexpr int LK = L * K;
+  using M = Mask<K>;
+  using R = Rng<LOG2L>;
+  __shared__ uint32_t rngbuf[GPB * R::RING];
+  __shared__ int32_t posbuf[GPB * FW_LDSPOS];
+  __shared__ int32_t widebuf[GPB * FW_WIDEW * L * K];
+  const int tid = threadIdx.x;
+  const int lig = tid & (L - 1);
+  const int gib = tid >> LOG2L;
+  const int gbase = (tid & 63) & ~(L - 1);
+  const int64_t r = (int64_t)blockIdx.x * GPB + gib;
+  if (r >= P.R) return;
+  lds_vi32* lpos = (lds_vi32*)posbuf + gib * FW_LDSPOS;
+  lds_vi32* lwide = (lds_vi32*)widebuf + gib * (FW_WIDEW * L * K);
+  const bool lane0 = lig == 0;
+  const int n = P.n, N = P.N;
+  View<LOG2L, K, HYPER> v;
+  v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n * LPS, lig);
+  ReplicaState* rs = P.rs + r;
+  int32_t* si = F.scratch_i + r * fw_scratch_ints(N, F.I64);
+  int32_t *order = si, *wlist = si + N, *iorder = si + 2 * N, *gstk = si + 3 * N, *n_big = si + 4 * N;
+  volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + 4 * N + F.I64);
+  double* cc_new = F.scratch_d + r * 2 * (int64_t)N;
+  double* part_new = cc_new + N;
+  double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
+  uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
+  M slices;
+#pragma unroll
+  for (int k = 0; k < K; ++k) slices.w[k] = sl[v.widx(k)];
+  FW_PROF_DECL;
+  FW_PROF_T(1);
+  if (gany<LOG2L>(mnonzero<K>(slices))) {
+    R rng;
+    rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
+#if defined(TNCO_PROFILE) && TNCO_PROFILE == 3  // event counts instead of cycles
+    const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, wlist, iorder, gstk, n_big, pos, lpos, lwide,
+                                                lane0, gbase, F.status + r, nullptr, fc_);
+#elif defined(TNCO_PROFILE)
+    unsigned long long fp_[2] = {0, 0};  // end of the first pass, end of the post-order
+    const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, wlist, iorder, gstk, n_big, pos, lpos, lwide,
+                                                lane0, gbase, F.status + r, fp_);
+    ft_[2] = fp_[0];
+    ft_[0] = ft_[1];                  // slot 0: too-wide counts (from the start of the re-slice)
+    ft_[1] = ft_[2];                  // slot 1: post-order
+    ft_[2] = fp_[1];                  // slot 2: the greedy pass (up to T(3))
+#else
+    const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, wlist, iorder, gstk, n_big, pos, lpos, lwide,
+                                                lane0, gbase, F.status + r);
+#endif
+    FW_PROF_T(3);
+    double sum;
+    const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, iorder, ns, cc_new, part_new, lane0, gbase, &sum);
+    if (tot < v.hdr(N - 1)->partial) {
+      slices = ns;
+      fw_commit<LOG2L, K, HYPER>(P, v, cc_new, part_new);
+#pragma unroll
+      for (int k = 0; k < K; ++k) sl[v.widx(k)] = slices.w[k];
+    }
+    int mti, mtw;
+    rng.finish(mti, mtw);
+    if (lane0) {
+      rs->mti = mti;
+      rs->mtw = mtw;
+    }
+    FW_PROF_T(4);
+    FW_PROF_ACC;
+  }
+  // :385-389
+  const double tc = v.hdr(N - 1)->partial;
+  if (tc < rs->min_cost) {
+    uint32_t jtail = rs->jtail;
+    if (rs->jinvalid != 0) {
+      Links* __restrict__ ml = P.minlinks + r * (int64_t)N;
+      for (int i = lig; i < N; i += L) {
+        Links o;
+        o.left = v.left(i); o.right = v.right(i); o.parent = v.parent(i); o.pad = 0;
+        ml[i] = o;
+      }
+      jtail = 0;
+      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (every lane has read rs->jinvalid)
+      if (lane0) {
+        rs->jtail = 0;
+        rs->jinvalid = 0;
+        rs->n_fullcopy += 1;
+      }
+    }
+    if (lane0) {
+      rs->min_cost = tc;
+      rs->n_improved += 1;
+      rs->jmin = jtail;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) sl[LK + v.widx(k)] = slices.w[k];
+  }
+  if (lane0) {
     FW_PROF_OUT(rs);
   }
 }

@@ -84,5 +84,6 @@ void launch_fw_init_lk(tnco_hip_ctx* h, const tnco::FwInitArgs& a);
 template <int LOG2L, int K>
 void launch_fw_check_lk(tnco_hip_ctx* h, const tnco::BuildArgs& a, int which_min, double atol, int32_t* out_bad);
 template <int LOG2L, int K>
-void launch_fw_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, int64_t off,
-                      int64_t every);
+void launch_fw_move_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, int tail_last);
+template <int LOG2L, int K>
+void launch_fw_reslice_lk(tnco_hip_ctx* h);

@@ -65,16 +65,28 @@ void launch_fw_check_lk(tnco_hip_ctx* h, const BuildArgs& a, int which_min, doub
 }
 
 template <int LOG2L, int K>
-void launch_fw_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, int64_t off,
-                      int64_t every) {
+void launch_fw_move_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, int tail_last) {
+  const int gpb = 256 >> LOG2L;
+  dim3 grid((unsigned)((h->P.R + gpb - 1) / gpb));
+  const bool maxnew = h->F.max_new_slices > 0;
+#define TNCO_FW_MOVE(HY, MN)                                                                                        \
+  hipLaunchKernelGGL((fw_move_kernel<LOG2L, K, HY, MN>), grid, dim3(256), 0, h->stream, h->P, h->F, betas, n_steps, \
+                     prob_kind, tail_last)
+  if (h->hyper) {
+    if (maxnew) TNCO_FW_MOVE(true, true); else TNCO_FW_MOVE(true, false);
+  } else {
+    if (maxnew) TNCO_FW_MOVE(false, true); else TNCO_FW_MOVE(false, false);
+  }
+#undef TNCO_FW_MOVE
+}
+template <int LOG2L, int K>
+void launch_fw_reslice_lk(tnco_hip_ctx* h) {
   const int gpb = 256 >> LOG2L;
   dim3 grid((unsigned)((h->P.R + gpb - 1) / gpb));
   if (h->hyper)
-    hipLaunchKernelGGL((fw_run_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, h->F, betas, n_steps,
-                       prob_kind, off, every);
+    hipLaunchKernelGGL((fw_reslice_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, h->F);
   else
-    hipLaunchKernelGGL((fw_run_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, betas, n_steps,
-                       prob_kind, off, every);
+    hipLaunchKernelGGL((fw_reslice_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F);
 }
 
 template void launch_run_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const double*, int64_t, int);
@@ -82,4 +94,5 @@ template void launch_build_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const Bui
 template void launch_compare_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const BuildArgs&, double, int32_t*);
 template void launch_fw_init_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const FwInitArgs&);
 template void launch_fw_check_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const BuildArgs&, int, double, int32_t*);
-template void launch_fw_run_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const double*, int64_t, int, int64_t, int64_t);
+template void launch_fw_move_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const double*, int64_t, int, int);
+template void launch_fw_reslice_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*);

@@ -107,11 +107,30 @@ void launch_fw_init(tnco_hip_ctx* h, const FwInitArgs& a) {
 #undef CALL_FWI
 }
 
+// n_steps sweeps of the finite-width optimizer: [moves up to and including the next re-slicing
+// sweep][re-slice] ... [the remaining moves]  (sweep k re-slices when (off + k) % every == 0)
 void launch_fw_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, int64_t off,
                    int64_t every) {
-#define CALL_FWR(LL, KK) launch_fw_run_lk<LL, KK>(h, betas, n_steps, prob_kind, off, every)
-  DISPATCH_LK(h, CALL_FWR)
-#undef CALL_FWR
+  int64_t cur = 0;
+  while (cur < n_steps) {
+    int64_t next = n_steps;  // first re-slicing sweep >= cur
+    if (every > 0) {
+      const int64_t rem = (off + cur) % every;
+      next = cur + (rem == 0 ? 0 : every - rem);
+    }
+    const bool reslice = next < n_steps;
+    const int64_t cnt = (reslice ? next + 1 : n_steps) - cur;
+    const int tail_last = reslice ? 0 : 1;
+#define CALL_FWM(LL, KK) launch_fw_move_lk<LL, KK>(h, betas + cur, cnt, prob_kind, tail_last)
+    DISPATCH_LK(h, CALL_FWM)
+#undef CALL_FWM
+    if (reslice) {
+#define CALL_FWS(LL, KK) launch_fw_reslice_lk<LL, KK>(h)
+      DISPATCH_LK(h, CALL_FWS)
+#undef CALL_FWS
+    }
+    cur += cnt;
+  }
 }
 
 // checkpoint := current tree, replica state := fresh
