@@ -6,10 +6,17 @@
 // every internal node (WidthCache, finite_width/utils.hpp:49-76: float32 in the `pad` word of the
 // node header, or a float64 array of its own), and scratch for the greedy re-slice.
 //
-// This version favours exactness over speed: every move reads its operands from memory (no
-// staging), and the re-slice (greedy/utils.hpp:21-125) + full CostCache rebuild
-// (greedy/optimizer.hpp:359-376) walk the whole tree serially per replica, as the reference does
-// (post-order by walking the links, candidate legs of a tensor shuffled and picked in LDS).
+// Two kernels: fw_move_kernel (the moves of a run of sweeps; every move reads its operands from
+// memory, no staging as in sa_sweep.h) and fw_reslice_kernel (the end of a re-slicing sweep:
+// greedy/utils.hpp:21-125 + the full CostCache rebuild of greedy/optimizer.hpp:359-376).  The
+// re-slice is organised around what bounds it on this machine -- the number of random memory
+// transactions (tools/mem_latency.hip: ~47 G/s chip-wide, so a dependent load takes 0.8 us with two
+// wavefronts per SIMD all waiting) and the divergence of 16 different trees per wavefront:
+//   * ONE walk over the tree reads every node header once and leaves sequential lists (internal
+//     nodes in post-order with their links; the too-wide tensors in post-order);
+//   * every later stage iterates over those lists, the k-th entry of all 16 replicas together, with
+//     the loads of the next entries in flight;
+//   * counters, candidate lists, shuffles and picks live in registers / LDS.
 // Covered: SimpleCostModel and SimpleSparseIndsCostModel (finite_width/cost_model/simple.hpp,
 // simple_sparse_inds.hpp), uniform and per-index dims, width_type float32 / float64, and the
 // max_number_new_slices > 0 branch (greedy/optimizer.hpp:226-321).
@@ -29,18 +36,39 @@ struct FwParams {
   int64_t max_new_slices;   // max_number_new_slices
   uint64_t* slices;         // [R][2][LK]  slices, min_slices
   const uint64_t* skip;     // [LK] or NULL
-  int32_t* scratch_i;       // [R][fw_scratch_ints]  post-order, too-wide counts, candidate legs
-  double* scratch_d;        // [R][2N]        rebuilt ccost / partial
+  int32_t* scratch_i;       // [R][fw_scratch_ints]  see FwScratch
+  double* scratch_d;        // [R][2N]        see FwScratch
   double* width64;          // [R][N] widths of the internal nodes when width_type is float64
   int32_t* status;          // [R] runtime problems (1: candidate legs beyond the scratch; cannot happen
                             //     since the scratch holds every index)
 };
 
-// int32 of scratch per replica: post-order [N], the too-wide tensors in post-order [N], the internal
-// nodes in post-order [N], deep part of the traversal stack [N], too-wide counts [I64], candidate legs
-// of one tensor (int16, for the shuffle when they do not fit the LDS fast path) [I64: every index can
-// be one]
-__host__ __device__ inline int64_t fw_scratch_ints(int N, int I64) { return 4 * (int64_t)N + I64 + I64 / 2; }
+// int32 scratch of one replica (FwParams::scratch_i): the too-wide counts of every index [I64],
+// the candidate legs of one tensor (int16, for the shuffle when they do not fit the LDS fast path)
+// [I64: every index can be one], the post-order records of the internal nodes (fw_rec, 8 bytes)
+// [n - 1], the too-wide tensors in post-order [N], the deep part of the traversal stack [N].
+__host__ __device__ inline int64_t fw_np(int N) { return (N + 3) & ~3; }
+__host__ __device__ inline int64_t fw_scratch_ints(int N, int I64) { return I64 + I64 / 2 + 3 * fw_np(N); }
+struct FwScratch {
+  int32_t* n_big;
+  volatile int16_t* pos;
+  uint64_t* rec;
+  int32_t* wlist;
+  int32_t* gstk;
+  double2* cp;   // FwParams::scratch_d: rebuilt (cost, partial sum) by post-order number [n - 1]
+  double* pstk;  // ... and the stack of partial sums [N]
+  __device__ __forceinline__ FwScratch(const FwParams& F, int64_t r, int N) {
+    int32_t* si = F.scratch_i + r * fw_scratch_ints(N, F.I64);
+    n_big = si;
+    pos = reinterpret_cast<volatile int16_t*>(si + F.I64);
+    rec = reinterpret_cast<uint64_t*>(si + F.I64 + F.I64 / 2);
+    wlist = si + F.I64 + F.I64 / 2 + fw_np(N);
+    gstk = wlist + fw_np(N);
+    double* sd = F.scratch_d + r * 2 * (int64_t)N;
+    cp = reinterpret_cast<double2*>(sd);
+    pstk = sd + N;
+  }
+};
 
 // a value of width_type, held in a double
 __device__ __forceinline__ double fw_wr(const FwParams& F, double x) {
@@ -175,91 +203,120 @@ __device__ __forceinline__ void fw_shuffle(Rng<LOG2L>& rng, A a, int n, bool lan
   }
 }
 
+typedef TNCO_LDS volatile uint16_t lds_vu16;
+
+// One internal node of the post-order list: node | left << 21 | right << 42.
+__device__ __forceinline__ uint64_t fw_rec(int node, int l, int rr) {
+  return (uint64_t)(uint32_t)node | ((uint64_t)(uint32_t)l << 21) | ((uint64_t)(uint32_t)rr << 42);
+}
+__device__ __forceinline__ int fw_rec_node(uint64_t x) { return (int)(x & 0x1FFFFFu); }
+__device__ __forceinline__ int fw_rec_left(uint64_t x) { return (int)((x >> 21) & 0x1FFFFFu); }
+__device__ __forceinline__ int fw_rec_right(uint64_t x) { return (int)(x >> 42); }
+
+// LDS of one replica for the traversal: `cap` stack entries (int32) + their left children (uint16)
+struct FwStack {
+  lds_vi32* e;
+  lds_vu16* l;
+  int cap;
+};
+
 // Post-order of include/tnco/utils.hpp:34-51 (child 0's subtree, child 1's subtree, the node).
-// Emits: order[N] (every node; not when `order` is NULL), iorder[N - n] (the internal nodes only, same order: what the cache
-// rebuild iterates over) and, with a bitmap `lwide` (LDS), wlist[] = the marked nodes in that order
-// (their number is returned).
+// The re-slice is bound by the number of memory transactions, so this walk is the only time the
+// tree's node headers are read: it leaves
+//   rec[N - n]   the internal nodes in post-order WITH their child links (fw_rec; sequential 8-byte
+//                records: what the cache rebuild iterates over),
+//   wlist[]      (when not NULL) the tensors wider than max_width, in post-order -- the cached width
+//                sits in the header line that is fetched for the links anyway (WidthCache,
+//                finite_width/utils.hpp:49-76); their number is returned.
 //
-// With a stack (entries: node | right child << 13 | right-visited << 26; the first `cap` of them in
-// LDS `lstk`, deeper ones in the global scratch `gstk`) every internal node's header is fetched ONCE,
-// on the way down -- 1 dependent HBM load per internal node.  Without one the links are walked
-// instead (the successor of x is its parent if x is the right child, else the left-most leaf below
-// its sibling): ~5 dependent loads per internal node.
+// With a stack (entry: node | right child << 13 | right-visited << 26 | too-wide << 27, left child
+// beside it; the first st.cap entries in LDS, deeper ones in the global scratch `gstk`) every header
+// is fetched ONCE, on the way down.  Every iteration of the outer loop is one header fetch for
+// every replica of the wavefront that is not done (the replicas' trees differ; a loop nest that
+// follows one tree's shape would cost every replica the longest descent / ascent among the sixteen).
+// What follows the fetch -- leaves emitted, finished nodes popped -- touches the stack only.
+// Trees of more than 8192 nodes (or no stack) walk the links instead: the successor of x is its
+// parent if x is the right child, else the left-most leaf below its sibling.
 template <int LOG2L, int K, bool HYPER>
-__device__ __forceinline__ int fw_traverse(const View<LOG2L, K, HYPER>& v, int N, int32_t* order, int32_t* iorder,
-                                           bool lane0, lds_vi32* lstk = nullptr, int cap = 0,
-                                           volatile int32_t* gstk = nullptr, lds_vi32* lwide = nullptr,
-                                           int32_t* wlist = nullptr, unsigned long long* dbg = nullptr) {
-  const int n = v.n;
-  int cnt = 0, ni = 0, nw = 0;
-  auto emit = [&](int x) {
-    if (order != nullptr) {
-      if (lane0) order[cnt] = x;
-      ++cnt;
-    }
-    if (x >= n) {
-      if (lane0) iorder[ni] = x;
-      ++ni;
-    }
-    if (lwide != nullptr && ((lwide[x >> 5] >> (x & 31)) & 1)) {
+__device__ __forceinline__ int fw_traverse(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
+                                           const double* w64, uint64_t* rec, int32_t* wlist, bool lane0, int gbase,
+                                           FwStack st, volatile int32_t* gstk) {
+  const int n = v.n, N = P.N;
+  int ni = 0, nw = 0;
+  auto emit_leaf = [&](int x) {
+    if (wlist != nullptr && F.leaf_wide && fw_width<LOG2L, K>(P, F, v.mask(x), v.lig, gbase) > F.max_width) {
       if (lane0) wlist[nw] = x;
       ++nw;
     }
   };
-  const bool walk = (lstk == nullptr) || (gstk == nullptr) || N > 8192;
+  auto emit_node = [&](int x, int l, int rr, bool wide) {
+    if (lane0) rec[ni] = fw_rec(x, l, rr);
+    ++ni;
+    if (wide) {
+      if (lane0) wlist[nw] = x;
+      ++nw;
+    }
+  };
+  auto is_wide = [&](int x, int pad) -> bool {
+    if (wlist == nullptr) return false;
+    const double w = F.width_f32 ? (double)__int_as_float(pad) : w64[x];
+    return w > F.max_width;
+  };
+  const bool walk = (st.e == nullptr) || (gstk == nullptr) || N > 8192;
   if (!walk) {
-    auto top = [&](int sp) -> int {
-      if (sp <= cap) return (int)lstk[sp - 1];
-      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (lane 0's store, every lane's load)
-      return (int)gstk[sp - 1 - cap];
-    };
-    auto put = [&](int sp, int e) {  // entry number sp (1-based)
-      if (lane0) {
-        if (sp <= cap) lstk[sp - 1] = e; else gstk[sp - 1 - cap] = e;
-      }
-    };
-    // Every iteration of the outer loop is ONE header fetch for every replica of the wavefront that
-    // is not done (the replicas' trees differ; a loop nest that follows one tree's shape would cost
-    // every replica the longest descent / ascent among the sixteen).  What follows the fetch -- leaves
-    // emitted, finished nodes popped -- touches the stack only.
+    const int cap = st.cap;
+    const int gh = (N + 1) / 2;  // gstk: [0, gh) entries, [gh, 2 gh) their left children
     int sp = 0, x = N - 1;
-    if (x < n) emit(x);
+    if (x < n) emit_leaf(x);
     bool active = x >= n;
     while (active) {
-      const int2 c = *reinterpret_cast<const int2*>(v.hdr(x));  // (left, right)
+      const int4 h = *reinterpret_cast<const int4*>(v.hdr(x));  // (left, right, parent, width)
+      const bool wide = is_wide(x, h.w);
       ++sp;
-      put(sp, x | (c.y << 13));
-      x = c.x;
+      if (lane0) {
+        const int e = x | (h.y << 13) | (wide ? (1 << 27) : 0);
+        if (sp <= cap) {
+          st.e[sp - 1] = e;
+          st.l[sp - 1] = (uint16_t)h.x;
+        } else {
+          gstk[sp - 1 - cap] = e;
+          gstk[gh + sp - 1 - cap] = h.x;
+        }
+      }
+      x = h.x;
       if (x >= n) continue;
-#if defined(TNCO_PROFILE) && TNCO_PROFILE == 4
-      const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
-#endif
-      emit(x);  // the left child is a leaf
+      emit_leaf(x);  // the left child is a leaf
       for (;;) {  // up: into the right subtree of the innermost open node, or close it
         if (sp == 0) {
           active = false;
           break;
         }
-        const int e = top(sp);
+        int e, l;
+        if (sp <= cap) {
+          e = st.e[sp - 1];
+          l = st.l[sp - 1];
+        } else {
+          __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (lane 0's store, every lane's load)
+          e = gstk[sp - 1 - cap];
+          l = gstk[gh + sp - 1 - cap];
+        }
         const int node = e & 0x1FFF, rr = (e >> 13) & 0x1FFF;
-        if ((e >> 26) == 0) {
+        if (((e >> 26) & 1) == 0) {
           if (rr >= n) {
-            put(sp, e | (1 << 26));
+            if (lane0) {
+              if (sp <= cap) st.e[sp - 1] = e | (1 << 26); else gstk[sp - 1 - cap] = e | (1 << 26);
+            }
             x = rr;
             break;
           }
-          emit(rr);  // the right child is a leaf: the node is finished as well
+          emit_leaf(rr);  // the right child is a leaf: the node is finished as well
         }
         --sp;
-        emit(node);
+        emit_node(node, l, rr, ((e >> 27) & 1) != 0);
       }
-#if defined(TNCO_PROFILE) && TNCO_PROFILE == 4
-      if (dbg) *dbg += __builtin_amdgcn_s_memtime() - t0_;  // (slot "counts" += the stack-only part)
-#endif
     }
   }
   if (walk) {
-    cnt = ni = nw = 0;
     int x = N - 1;
     for (;;) {
       const int l = v.left(x);
@@ -267,7 +324,12 @@ __device__ __forceinline__ int fw_traverse(const View<LOG2L, K, HYPER>& v, int N
       x = l;
     }
     for (;;) {
-      emit(x);
+      if (x < n) {
+        emit_leaf(x);
+      } else {
+        const int4 h = *reinterpret_cast<const int4*>(v.hdr(x));
+        emit_node(x, h.x, h.y, is_wide(x, h.w));
+      }
       const int p = v.parent(x);
       if (p < 0) break;
       const int rr = v.right(p);
@@ -290,90 +352,69 @@ __device__ __forceinline__ int fw_traverse(const View<LOG2L, K, HYPER>& v, int N
 // CostCache(ctree, ccost, slices) (finite_width/utils.hpp:36-47) into scratch; returns
 // partial[root]; *sum = get_cost (finite_width/utils.hpp:24-33).  The contraction cost is taken
 // over in1 | in2 | slices (finite_width/cost_model/simple.hpp:139-144).  Iterates over the internal
-// nodes in post-order (`iorder`): every iteration is work for every replica of the wavefront.
+// nodes in post-order (`rec`): every iteration is work for every replica of the wavefront.
 //
-// Four nodes per iteration: their eight child masks are requested together (one memory latency per
-// four nodes), with the child links of the next four and the node numbers of the four after those.
-// The chain of partial sums is lane 0's alone.  In post-order an internal right child is the node
-// just before its parent; a left child's sum comes from memory (lane 0's own earlier store) unless
-// it was computed in the same group of four.
-template <int LOG2L, int K, bool HYPER>
-__device__ __forceinline__ double fw_rebuild(const Params& P, const View<LOG2L, K, HYPER>& v, const int32_t* iorder,
-                                             const Mask<K>& slices, double* cc_new, double* part_new, bool lane0,
+// B (four) nodes per iteration: their eight child masks are requested together (one memory latency
+// per B nodes) with the records of the next B.  The (cost, partial sum) of node number j of the list
+// goes to cp[j]: sequential 16-byte stores of lane 0, full lines by the time they leave the L2 (kept
+// by node number they were two 8-byte read-modify-writes per node, and a third of the time of this
+// function).  The partial sums are a stack machine of lane 0's: in post-order an internal right
+// child is the node just before its parent and its sum still in a register (`part`); an internal
+// left child's sum is the top of the stack of finished subtrees; a node with two leaf children
+// pushes (pstk[]: consecutive doubles, the same few lines again and again).
+template <int LOG2L, int K, bool HYPER, int B = 4>
+__device__ __forceinline__ double fw_rebuild(const Params& P, const View<LOG2L, K, HYPER>& v, const uint64_t* rec,
+                                             const Mask<K>& slices, double2* cp, double* pstk, bool lane0,
                                              int gbase, double* sum) {
-  constexpr int B = 4;
   const int n = P.n, ni = P.N - P.n;
   double s = 0.0, part = 0.0;
   if (ni <= 0) {
     *sum = 0.0;
     return 0.0;
   }
-  auto ld_node = [&](int j) -> int { return j < ni ? iorder[j] : n; };  // (past the end: any internal node)
-  auto ld_links = [&](int x) -> int2 { return *reinterpret_cast<const int2*>(v.hdr(x)); };
-  int nd[B], nn[B];
-  int2 lk[B];
+  auto ld_rec = [&](int j) -> uint64_t { return rec[j < ni ? j : ni - 1]; };
+  uint64_t rc[B];
 #pragma unroll
-  for (int i = 0; i < B; ++i) nd[i] = ld_node(i);
-#pragma unroll
-  for (int i = 0; i < B; ++i) nn[i] = ld_node(B + i);
-#pragma unroll
-  for (int i = 0; i < B; ++i) lk[i] = ld_links(nd[i]);
-  int prev = -1;
+  for (int i = 0; i < B; ++i) rc[i] = ld_rec(i);
+  int sp = 0;  // finished subtrees not yet consumed: the newest in `part`, the others in pstk[0 .. sp - 2]
   for (int j0 = 0; j0 < ni; j0 += B) {
     Mask<K> ml[B], mr[B];
-    double plv[B];
-    int2 lkn[B];
-    int n2[B];
+    uint64_t rn[B];
 #pragma unroll
     for (int i = 0; i < B; ++i) {
-      ml[i] = v.mask(lk[i].x);
-      mr[i] = v.mask(lk[i].y);
+      ml[i] = v.mask(fw_rec_left(rc[i]));
+      mr[i] = v.mask(fw_rec_right(rc[i]));
     }
 #pragma unroll
-    for (int i = 0; i < B; ++i) {
-      plv[i] = 0.0;
-      if (lane0 && lk[i].x >= n) plv[i] = part_new[lk[i].x];  // (stale if computed in this group: see below)
-    }
-#pragma unroll
-    for (int i = 0; i < B; ++i) lkn[i] = ld_links(nn[i]);
-#pragma unroll
-    for (int i = 0; i < B; ++i) n2[i] = ld_node(j0 + 2 * B + i);
-    double pv[B];
+    for (int i = 0; i < B; ++i) rn[i] = ld_rec(j0 + B + i);
 #pragma unroll
     for (int i = 0; i < B; ++i) {
-      pv[i] = 0.0;
       if (j0 + i < ni) {
-        const int p = nd[i], l = lk[i].x, rr = lk[i].y;
+        const int l = fw_rec_left(rc[i]), rr = fw_rec_right(rc[i]);
         const Mask<K> u = mor<K>(mor<K>(ml[i], mr[i]), slices);
         const double c = generic_cost<LOG2L, K>(P, u, v.lig, gbase);
         s = rnd_cost(s + c, P.f32);
+        const bool li = l >= n, ri = rr >= n;
         if (lane0) {
-          double pl = plv[i];
-#pragma unroll
-          for (int k = 0; k < i; ++k)
-            if (l == nd[k]) pl = pv[k];
-          double pr = 0.0;
-          if (rr >= n) {
+          double pl = 0.0, pr = 0.0;
+          if (li && ri) {
             pr = part;
-            if (rr != prev) {  // (never, in post-order)
-              __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-              pr = part_new[rr];
-            }
+            pl = pstk[sp - 2];  // (lane 0's own store: an L2 hit)
+          } else if (ri) {
+            pr = part;
+          } else if (li) {
+            pl = part;
+          } else if (sp >= 1) {
+            pstk[sp - 1] = part;
           }
           part = rnd_cost(rnd_cost(c + pl, P.f32) + pr, P.f32);
-          cc_new[p] = c;
-          part_new[p] = part;
+          cp[j0 + i] = make_double2(c, part);
         }
-        pv[i] = part;
-        prev = p;
+        sp += (li && ri) ? -1 : ((!li && !ri) ? 1 : 0);
       }
     }
 #pragma unroll
-    for (int i = 0; i < B; ++i) {
-      nd[i] = nn[i];
-      lk[i] = lkn[i];
-      nn[i] = n2[i];
-    }
+    for (int i = 0; i < B; ++i) rc[i] = rn[i];
   }
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
   *sum = s;
@@ -381,29 +422,30 @@ __device__ __forceinline__ double fw_rebuild(const Params& P, const View<LOG2L, 
   return __hiloint2double(hi, lo);
 }
 
+// the rebuilt (cost, partial sum) of every internal node into its header
 template <int LOG2L, int K, bool HYPER>
-__device__ __forceinline__ void fw_commit(const Params& P, const View<LOG2L, K, HYPER>& v, const double* cc_new,
-                                          const double* part_new) {
+__device__ __forceinline__ void fw_commit(const Params& P, const View<LOG2L, K, HYPER>& v, const uint64_t* rec,
+                                          const double2* cp) {
   constexpr int L = 1 << LOG2L;
   constexpr int B = 4;  // loads in flight per lane: 2 * B
-  for (int p0 = P.n + v.lig; p0 < P.N; p0 += B * L) {
-    double c[B], q[B];
+  const int ni = P.N - P.n;
+  for (int j0 = v.lig; j0 < ni; j0 += B * L) {
+    uint64_t x[B];
+    double2 c[B];
 #pragma unroll
     for (int i = 0; i < B; ++i) {
-      const int p = p0 + i * L;
-      c[i] = q[i] = 0.0;
-      if (p < P.N) {
-        c[i] = cc_new[p];
-        q[i] = part_new[p];
+      const int j = j0 + i * L;
+      x[i] = 0;
+      c[i] = make_double2(0.0, 0.0);
+      if (j < ni) {
+        x[i] = rec[j];
+        c[i] = cp[j];
       }
     }
 #pragma unroll
     for (int i = 0; i < B; ++i) {
-      const int p = p0 + i * L;
-      if (p < P.N) {
-        v.hdr(p)->ccost = c[i];
-        v.hdr(p)->partial = q[i];
-      }
+      const int j = j0 + i * L;
+      if (j < ni) *reinterpret_cast<double2*>(&v.hdr(fw_rec_node(x[i]))->ccost) = c[i];
     }
   }
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -468,7 +510,6 @@ __device__ __forceinline__ uint32_t fw_positions(const View<LOG2L, K, HYPER>& v,
 #define TNCO_FW_LDSPOS 128
 #endif
 constexpr int FW_LDSPOS = TNCO_FW_LDSPOS;  // candidate legs per tensor that fit the LDS fast path
-constexpr int FW_WIDEW = 4;     // LDS bitmap of the too-wide tensors: FW_WIDEW * L * K words per replica
 
 // A tensor that is still too wide after the slices chosen so far (sliced_xs = its legs - slices, of
 // width sliced_width): shuffle its candidate legs and slice them in the order of `greater` until it
@@ -548,149 +589,74 @@ __device__ __forceinline__ void fw_slice_wide(const Params& P, const FwParams& F
   }
 }
 
-// One too-wide tensor `t` of get_slices_impl's post-order pass (finite_width/greedy/utils.hpp:62-101):
-// if it is still too wide after the slices chosen so far, shuffle its candidate legs and slice them
-// in the order of `greater` until it fits.
-template <int LOG2L, int K, bool HYPER>
-__device__ __forceinline__ void fw_slice_tensor(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
-                                                Rng<LOG2L>& rng, const int32_t* n_big, volatile int16_t* pos,
-                                                lds_vi32* lpos, bool lane0, int gbase, int32_t* status,
-                                                const Mask<K>& skip, int t, Mask<K>& slices,
-                                                unsigned long long* cnt) {
-  if (cnt) cnt[0] += 1;  // too-wide tensors
-  Mask<K> sliced_xs = mandn<K>(v.mask(t), slices);
-  double sliced_width = fw_width<LOG2L, K>(P, F, sliced_xs, v.lig, gbase);
-  if (!(sliced_width > F.max_width)) return;
-  fw_slice_wide<LOG2L, K, HYPER>(P, F, v, rng, n_big, pos, lpos, lane0, gbase, status, skip, sliced_xs, sliced_width,
-                                 slices, cnt);
-}
-
-// get_slices_impl, finite_width/greedy/utils.hpp:21-125; also leaves the post-order of the tree in
-// order[].  The 16 replicas of a wavefront find their too-wide tensors at different places of their
-// trees, and the work on one such tensor is long: run per replica "as it comes", that work would
-// execute once per replica and tensor with 1/16 of the lanes.  So every stage first finds the
-// too-wide tensors cheaply (an LDS bitmap per replica, a list in post-order), then all replicas of
+// get_slices_impl, finite_width/greedy/utils.hpp:21-125.  The 16 replicas of a wavefront find their
+// too-wide tensors at different places of their trees, and the work on one such tensor is long: run
+// per replica "as it comes", that work would execute once per replica and tensor with 1/16 of the
+// lanes.  So the too-wide tensors are listed first (by the walk over the tree), then all replicas of
 // the wavefront work on their k-th one together.
+//
+// Part 1, :41-48: the walk (sc.rec, sc.wlist; see fw_traverse), then for every index the number of
+// too-wide tensors it appears in (sc.n_big[]).  Returns the number of too-wide tensors.
 template <int LOG2L, int K, bool HYPER>
-__device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
-                                                 const double* w64, Rng<LOG2L>& rng, int32_t* order, int32_t* wlist,
-                                                 int32_t* iorder, int32_t* gstk, int32_t* n_big, volatile int16_t* pos, lds_vi32* lpos,
-                                                 lds_vi32* lwide, bool lane0, int gbase, int32_t* status,
-                                                 unsigned long long* prof = nullptr,
-                                                 unsigned long long* cnt = nullptr) {
-  constexpr int L = 1 << LOG2L;
-  const int N = P.N, lig = v.lig;
-  Mask<K> slices = mzero<K>();
-  Mask<K> skip = mzero<K>();
-  if (F.skip) {
+__device__ __forceinline__ int fw_gs_mark(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
+                                          const double* w64, const FwScratch& sc, FwStack st, bool lane0, int gbase,
+                                          unsigned long long* prof = nullptr) {
+  const int nw = fw_traverse<LOG2L, K, HYPER>(P, F, v, w64, sc.rec, sc.wlist, lane0, gbase, st, sc.gstk);
+#ifdef TNCO_PROFILE
+  if (prof) prof[0] = __builtin_amdgcn_s_memtime();
+#endif
+  // The k-th too-wide tensor of every replica, together.  Every index belongs to one lane (bit b of
+  // its word k), so the counts are kept there, bit-sliced: plane p holds bit p of the 64 * K
+  // counters of the lane, adding a tensor's mask is a ripple-carry over the planes (no memory
+  // traffic at all; the first version issued one atomic per leg: 5 000 per replica on config 5,
+  // bound by the L2's atomic rate).  The planes are written out as int32 counts once per
+  // 2^NP - 1 tensors.
+  int32_t* n_big = sc.n_big;
+  constexpr int NP = K <= 4 ? 8 : 5;  // (registers: 2 * K * NP)
+  Mask<K> pl[NP];
 #pragma unroll
-    for (int k = 0; k < K; ++k) skip.w[k] = F.skip[v.widx(k)];
-  }
-  // :41-48  number of too-wide tensors every index appears in
-  const bool usebm = lwide != nullptr && N <= 32 * FW_WIDEW * L * K;
-  const int nwords = (N + 31) / 32;
-  if (usebm) {
-    for (int i = lig; i < nwords; i += L) lwide[i] = 0;
-  } else {
-    for (int i = lig; i < F.I64; i += L) n_big[i] = 0;
-  }
-  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  auto count_legs = [&](int t) {
-    const Mask<K> m = v.mask(t);
+  for (int p = 0; p < NP; ++p) pl[p] = mzero<K>();
+  bool first = true;
+  auto flush = [&]() {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      uint64_t x = m.w[k];
-      while (x) {
-        const int b = __ffsll((unsigned long long)x) - 1;
-        // no-return atomic: fire and forget (a plain += is a load the next += has to wait for)
-        (void)__hip_atomic_fetch_add(&n_big[v.widx(k) * 64 + b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        x &= x - 1;
-      }
-    }
-  };
-  auto found = [&](int t) {
-    if (usebm) {
-      if (lane0) lwide[t >> 5] = lwide[t >> 5] | (1 << (t & 31));
-    } else {
-      count_legs(t);
-    }
-  };
-  // (leaves never change: when none of them is too wide -- the usual case -- they are skipped)
-  if (F.leaf_wide)
-    for (int t = 0; t < P.n; ++t)
-      if (fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t, gbase) > F.max_width) found(t);
-  // internal nodes: cached widths, four loads in flight
-  for (int t0 = P.n; t0 < N; t0 += 4) {
-    double wa = 0, wb = 0, wc = 0, wd = 0;
-    wa = fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t0, gbase);
-    if (t0 + 1 < N) wb = fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t0 + 1, gbase);
-    if (t0 + 2 < N) wc = fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t0 + 2, gbase);
-    if (t0 + 3 < N) wd = fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t0 + 3, gbase);
-    if (wa > F.max_width) found(t0);
-    if (t0 + 1 < N && wb > F.max_width) found(t0 + 1);
-    if (t0 + 2 < N && wc > F.max_width) found(t0 + 2);
-    if (t0 + 3 < N && wd > F.max_width) found(t0 + 3);
-  }
-  if (usebm) {
-    // The k-th marked tensor of every replica, together.  Every index belongs to one lane (bit b of
-    // its word k), so the counts are kept there, bit-sliced: plane p holds bit p of the 64 * K
-    // counters of the lane, adding a tensor's mask is a ripple-carry over the planes (no memory
-    // traffic at all; the first version issued one atomic per leg: 5 000 per replica on config 5,
-    // bound by the L2's atomic rate).  The planes are written out as int32 counts once per
-    // 2^NP - 1 tensors.
-    constexpr int NP = K <= 4 ? 8 : 5;  // (registers: 2 * K * NP)
-    Mask<K> pl[NP];
 #pragma unroll
-    for (int p = 0; p < NP; ++p) pl[p] = mzero<K>();
-    bool first = true;
-    auto flush = [&]() {
+      for (int h = 0; h < 2; ++h) {
+        uint32_t w[NP];
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
+        for (int p = 0; p < NP; ++p) w[p] = (uint32_t)(pl[p].w[k] >> (32 * h));
+        int4* dst = reinterpret_cast<int4*>(n_big + v.widx(k) * 64 + 32 * h);
+        for (int j = 0; j < 8; ++j) {
+          int4 c = {0, 0, 0, 0};
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          uint32_t w[NP];
-#pragma unroll
-          for (int p = 0; p < NP; ++p) w[p] = (uint32_t)(pl[p].w[k] >> (32 * h));
-          int4* dst = reinterpret_cast<int4*>(n_big + v.widx(k) * 64 + 32 * h);
-          for (int j = 0; j < 8; ++j) {
-            int4 c = {0, 0, 0, 0};
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-              c.x |= (int)((w[p] & 1u) << p);
-              c.y |= (int)(((w[p] >> 1) & 1u) << p);
-              c.z |= (int)(((w[p] >> 2) & 1u) << p);
-              c.w |= (int)(((w[p] >> 3) & 1u) << p);
-              w[p] >>= 4;
-            }
-            if (!first) {
-              const int4 o = dst[j];
-              c.x += o.x; c.y += o.y; c.z += o.z; c.w += o.w;
-            }
-            dst[j] = c;
+          for (int p = 0; p < NP; ++p) {
+            c.x |= (int)((w[p] & 1u) << p);
+            c.y |= (int)(((w[p] >> 1) & 1u) << p);
+            c.z |= (int)(((w[p] >> 2) & 1u) << p);
+            c.w |= (int)(((w[p] >> 3) & 1u) << p);
+            w[p] >>= 4;
           }
+          if (!first) {
+            const int4 o = dst[j];
+            c.x += o.x; c.y += o.y; c.z += o.z; c.w += o.w;
+          }
+          dst[j] = c;
         }
       }
-      first = false;
+    }
+    first = false;
 #pragma unroll
-      for (int p = 0; p < NP; ++p) pl[p] = mzero<K>();
-    };
-    int wi = 0;
-    uint32_t bits = (uint32_t)lwide[0];
-    auto next_t = [&]() -> int {
-      while (bits == 0u && ++wi < nwords) bits = (uint32_t)lwide[wi];
-      if (wi >= nwords) return -1;
-      const int t = wi * 32 + __ffs((int)bits) - 1;
-      bits &= bits - 1u;
-      return t;
-    };
-    int t0 = next_t(), inchunk = 0;
-    Mask<K> m0 = mzero<K>();
-    if (t0 >= 0) m0 = v.mask(t0);
-    const bool any = t0 >= 0;
-    while (t0 >= 0) {
-      const int t1 = next_t();  // (the next mask is on its way while this one is added)
-      Mask<K> m1 = mzero<K>();
-      if (t1 >= 0) m1 = v.mask(t1);
+    for (int p = 0; p < NP; ++p) pl[p] = mzero<K>();
+  };
+  if (nw > 0) {
+    int inchunk = 0;
+    int ta = sc.wlist[0], tb = nw > 1 ? sc.wlist[1] : 0;
+    Mask<K> m0 = v.mask(ta);
+    for (int j = 0; j < nw; ++j) {
+      Mask<K> m1 = mzero<K>();  // (the next mask is on its way while this one is added)
+      ta = tb;
+      if (j + 1 < nw) m1 = v.mask(ta);
+      if (j + 2 < nw) tb = sc.wlist[j + 2];
       Mask<K> carry = m0;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
@@ -705,27 +671,39 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
         flush();
         inchunk = 0;
       }
-      t0 = t1;
       m0 = m1;
     }
-    if (any && (inchunk > 0 || first)) flush();
+    if (inchunk > 0 || first) flush();
   }
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef TNCO_PROFILE
-  if (prof) prof[0] = __builtin_amdgcn_s_memtime();
-#endif
-  // (the traversal borrows the LDS of the candidate list for its stack)
-  const int nw = fw_traverse<LOG2L, K, HYPER>(v, N, usebm ? nullptr : order, iorder, lane0, lpos, FW_LDSPOS, gstk,
-                                              usebm ? lwide : nullptr, wlist, prof);
-#ifdef TNCO_PROFILE
   if (prof) prof[1] = __builtin_amdgcn_s_memtime();
 #endif
+  return nw;
+}
+
+// Part 2, :62-101: the greedy pass over the nw too-wide tensors in post-order; returns the new slices.
+template <int LOG2L, int K, bool HYPER>
+__device__ __forceinline__ Mask<K> fw_gs_pick(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
+                                              Rng<LOG2L>& rng, const FwScratch& sc, int nw, lds_vi32* lpos,
+                                              bool lane0, int gbase, int32_t* status,
+                                              unsigned long long* cnt = nullptr) {
+  const int lig = v.lig;
+  const int32_t* wlist = sc.wlist;
+  const int32_t* n_big = sc.n_big;
+  volatile int16_t* pos = sc.pos;
+  Mask<K> slices = mzero<K>();
+  Mask<K> skip = mzero<K>();
+  if (F.skip) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) skip.w[k] = F.skip[v.widx(k)];
+  }
   // :62-101  post-order over the too-wide tensors.  Most of them fit once earlier ones have been
   // sliced (config 5: 110 marked, 24 still too wide when their turn comes), WHICH ones differs from
   // replica to replica, and the work on one that does not fit is long.  So every replica first runs
   // ahead to its next tensor that does not fit (a cheap scan: masks requested one tensor ahead), then
   // the replicas of the wavefront do the long part together.
-  if (usebm) {
+  {
     int j = 0;
     int ta = nw > 0 ? wlist[0] : 0, tb = nw > 1 ? wlist[1] : 0;
     Mask<K> ma = mzero<K>();
@@ -751,15 +729,18 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
       if (!have) break;
       fw_slice_wide<LOG2L, K, HYPER>(P, F, v, rng, n_big, pos, lpos, lane0, gbase, status, skip, sx, sw, slices, cnt);
     }
-  } else {
-    for (int i = 0; i < N; ++i) {
-      const int t = order[i];
-      if (t < P.n && !F.leaf_wide) continue;
-      if (!(fw_node_width<LOG2L, K, HYPER>(P, F, v, w64, t, gbase) > F.max_width)) continue;
-      fw_slice_tensor<LOG2L, K, HYPER>(P, F, v, rng, n_big, pos, lpos, lane0, gbase, status, skip, t, slices, cnt);
-    }
   }
   return slices;
+}
+
+template <int LOG2L, int K, bool HYPER>
+__device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
+                                                 const double* w64, Rng<LOG2L>& rng, const FwScratch& sc, FwStack st,
+                                                 lds_vi32* lpos, bool lane0, int gbase, int32_t* status,
+                                                 unsigned long long* prof = nullptr,
+                                                 unsigned long long* cnt = nullptr) {
+  const int nw = fw_gs_mark<LOG2L, K, HYPER>(P, F, v, w64, sc, st, lane0, gbase, prof);
+  return fw_gs_pick<LOG2L, K, HYPER>(P, F, v, rng, sc, nw, lpos, lane0, gbase, status, cnt);
 }
 
 struct FwInitArgs {
@@ -777,8 +758,8 @@ __global__ __launch_bounds__(256, 2) void fw_init_kernel(const Params P, const F
   constexpr int LK = L * K;
   using R = Rng<LOG2L>;
   __shared__ uint32_t rngbuf[GPB * R::RING];
-  __shared__ int32_t posbuf[GPB * FW_LDSPOS];
-  __shared__ int32_t widebuf[GPB * FW_WIDEW * L * K];
+  __shared__ int32_t posbuf[GPB * FW_LDSPOS];   // candidate legs of a tensor / traversal stack
+  __shared__ uint16_t leftbuf[GPB * FW_LDSPOS];  // traversal stack: left children
   const int tid = threadIdx.x;
   const int lig = tid & (L - 1);
   const int gib = tid >> LOG2L;
@@ -786,7 +767,7 @@ __global__ __launch_bounds__(256, 2) void fw_init_kernel(const Params P, const F
   const int64_t r = (int64_t)blockIdx.x * GPB + gib;
   if (r >= P.R) return;
   lds_vi32* lpos = (lds_vi32*)posbuf + gib * FW_LDSPOS;
-  lds_vi32* lwide = (lds_vi32*)widebuf + gib * (FW_WIDEW * L * K);
+  const FwStack st{lpos, (lds_vu16*)leftbuf + gib * FW_LDSPOS, FW_LDSPOS};
   const bool lane0 = lig == 0;
   const int n = P.n, N = P.N;
   View<LOG2L, K, HYPER> v;
@@ -794,10 +775,7 @@ __global__ __launch_bounds__(256, 2) void fw_init_kernel(const Params P, const F
   ReplicaState* rs = P.rs + r;
   R rng;
   rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
-  int32_t* si = F.scratch_i + r * fw_scratch_ints(N, F.I64);
-  int32_t *order = si, *wlist = si + N, *iorder = si + 2 * N, *gstk = si + 3 * N, *n_big = si + 4 * N;
-  double* cc_new = F.scratch_d + r * 2 * (int64_t)N;
-  double* part_new = cc_new + N;
+  const FwScratch sc(F, r, N);
   double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
   // widths of the internal nodes
   for (int p = n; p < N; ++p)
@@ -805,17 +783,15 @@ __global__ __launch_bounds__(256, 2) void fw_init_kernel(const Params P, const F
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
   Mask<K> slices;
   if (a.slices_in) {
-    fw_traverse<LOG2L, K, HYPER>(v, N, nullptr, iorder, lane0, lpos, FW_LDSPOS, gstk);
+    fw_traverse<LOG2L, K, HYPER>(P, F, v, w64, sc.rec, nullptr, lane0, gbase, st, sc.gstk);
 #pragma unroll
     for (int k = 0; k < K; ++k) slices.w[k] = a.slices_in[v.widx(k)];
   } else {
-    volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + 4 * N + F.I64);
-    slices = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, wlist, iorder, gstk, n_big, pos, lpos, lwide, lane0,
-                                            gbase, F.status + r);
+    slices = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, sc, st, lpos, lane0, gbase, F.status + r);
   }
   double sum = 0;
-  const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, iorder, slices, cc_new, part_new, lane0, gbase, &sum);
-  fw_commit<LOG2L, K, HYPER>(P, v, cc_new, part_new);
+  const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, sc.rec, slices, sc.cp, sc.pstk, lane0, gbase, &sum);
+  fw_commit<LOG2L, K, HYPER>(P, v, sc.rec, sc.cp);
   uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -834,7 +810,7 @@ __global__ __launch_bounds__(256, 2) void fw_init_kernel(const Params P, const F
 }
 
 // Stage timing of a re-slicing sweep (diagnostic builds, -DTNCO_PROFILE): shader cycles of
-// [moves, post-order, get_slices, rebuild + commit] and the number of re-slices, per replica, in
+// [walk, too-wide counts, greedy pass, rebuild + commit] and the number of re-slices, per replica, in
 // ReplicaState::pad1 (tnco_hip_get_stage_cycles; tools/stage_cycles.py --fw).
 #ifdef TNCO_PROFILE
 #define FW_PROF_DECL \
@@ -872,8 +848,11 @@ __global__ __launch_bounds__(256, 2) void fw_init_kernel(const Params P, const F
 // :385-389 (the best-so-far bookkeeping that ends every sweep) is done here for every sweep but,
 // when `tail_last` is 0, the last: that one is followed by a re-slice, which does it afterwards.
 // MAXNEW: with the max_number_new_slices > 0 branch (:226-321).
+#ifndef TNCO_FW_MOVE_WAVES
+#define TNCO_FW_MOVE_WAVES 2
+#endif
 template <int LOG2L, int K, bool HYPER, bool MAXNEW>
-__global__ __launch_bounds__(256, 2) void fw_move_kernel(const Params P, const FwParams F, const double* __restrict__ betas,
+__global__ __launch_bounds__(256, MAXNEW ? 2 : TNCO_FW_MOVE_WAVES) void fw_move_kernel(const Params P, const FwParams F, const double* __restrict__ betas,
                                                       const int64_t n_steps, const int prob_kind, const int tail_last) {
   constexpr int L = 1 << LOG2L;
   constexpr int GPB = 256 >> LOG2L;
@@ -882,13 +861,15 @@ __global__ __launch_bounds__(256, 2) void fw_move_kernel(const Params P, const F
   using R = Rng<LOG2L>;
   __shared__ uint32_t rngbuf[GPB * R::RING];
   __shared__ int32_t posbuf[MAXNEW ? GPB * FW_LDSPOS : 1];
+  __shared__ uint16_t leftbuf[MAXNEW ? GPB * FW_LDSPOS : 1];
   const int tid = threadIdx.x;
   const int lig = tid & (L - 1);
   const int gib = tid >> LOG2L;
   const int gbase = (tid & 63) & ~(L - 1);
   const int64_t r = (int64_t)blockIdx.x * GPB + gib;
   if (r >= P.R || n_steps <= 0) return;
-  [[maybe_unused]] lds_vi32* lpos = (lds_vi32*)posbuf + (MAXNEW ? gib * FW_LDSPOS : 0);
+  [[maybe_unused]] const FwStack st{(lds_vi32*)posbuf + (MAXNEW ? gib * FW_LDSPOS : 0),
+                                    (lds_vu16*)leftbuf + (MAXNEW ? gib * FW_LDSPOS : 0), FW_LDSPOS};
   const bool lane0 = lig == 0;
   const int n = P.n, N = P.N;
   const int f32 = P.f32;
@@ -897,11 +878,8 @@ __global__ __launch_bounds__(256, 2) void fw_move_kernel(const Params P, const F
   ReplicaState* rs = P.rs + r;
   R rng;
   rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
-  int32_t* si = F.scratch_i + r * fw_scratch_ints(N, F.I64);
-  [[maybe_unused]] int32_t *iorder = si + 2 * N, *gstk = si + 3 * N;
-  [[maybe_unused]] volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + 4 * N + F.I64);
-  double* cc_new = F.scratch_d + r * 2 * (int64_t)N;
-  double* part_new = cc_new + N;
+  [[maybe_unused]] const FwScratch sc(F, r, N);
+  [[maybe_unused]] volatile int16_t* pos = sc.pos;
   double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
   uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
   M slices;
@@ -1026,14 +1004,14 @@ __global__ __launch_bounds__(256, 2) void fw_move_kernel(const Params P, const F
           }
           v.set_mask(B, newB);
           __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          fw_traverse<LOG2L, K, HYPER>(v, N, nullptr, iorder, lane0, lpos, FW_LDSPOS, gstk);
+          fw_traverse<LOG2L, K, HYPER>(P, F, v, w64, sc.rec, nullptr, lane0, gbase, st, sc.gstk);
           double sum;
-          const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, iorder, new_slices, cc_new, part_new, lane0, gbase, &sum);
+          const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, sc.rec, new_slices, sc.cp, sc.pstk, lane0, gbase, &sum);
           const double delta = rnd_cost(tot - total, f32);
           const double u = uniform01();
           if (accept_move(prob_kind, beta, delta, total, u, f32)) {
             // :296-312
-            fw_commit<LOG2L, K, HYPER>(P, v, cc_new, part_new);
+            fw_commit<LOG2L, K, HYPER>(P, v, sc.rec, sc.cp);
             v.set_hyper(A, mand<K>(mand<K>(iA, newB), mE));
             v.set_hyper(B, mand<K>(mand<K>(newB, mD), mC));
             fw_set_node_width<LOG2L, K, HYPER>(F, v, w64, B, new_width_B, lane0);
@@ -1114,80 +1092,13 @@ __global__ __launch_bounds__(256, 2) void fw_move_kernel(const Params P, const F
   }
 }
 
-// The end of a re-slicing sweep, finite_width/greedy/optimizer.hpp:360-389: new slices for the
-// current tree (get_slices), the cost cache rebuilt with them, kept if the total improves; then the
-// best-so-far bookkeeping of the sweep (:385-389).
+// finite_width/greedy/optimizer.hpp:385-389, the end of a sweep, from the replica state in memory
 template <int LOG2L, int K, bool HYPER>
-__global__ __launch_bounds__(256, 2) void fw_reslice_kernel(const Params P, const FwParams F) {
+__device__ __forceinline__ void fw_sweep_tail(const Params& P, const View<LOG2L, K, HYPER>& v, ReplicaState* rs,
+                                              int64_t r, uint64_t* sl, const Mask<K>& slices, bool lane0) {
   constexpr int L = 1 << LOG2L;
-  constexpr int GPB = 256 >> LOG2L;
   constexpr int LK = L * K;
-  using M = Mask<K>;
-  using R = Rng<LOG2L>;
-  __shared__ uint32_t rngbuf[GPB * R::RING];
-  __shared__ int32_t posbuf[GPB * FW_LDSPOS];
-  __shared__ int32_t widebuf[GPB * FW_WIDEW * L * K];
-  const int tid = threadIdx.x;
-  const int lig = tid & (L - 1);
-  const int gib = tid >> LOG2L;
-  const int gbase = (tid & 63) & ~(L - 1);
-  const int64_t r = (int64_t)blockIdx.x * GPB + gib;
-  if (r >= P.R) return;
-  lds_vi32* lpos = (lds_vi32*)posbuf + gib * FW_LDSPOS;
-  lds_vi32* lwide = (lds_vi32*)widebuf + gib * (FW_WIDEW * L * K);
-  const bool lane0 = lig == 0;
-  const int n = P.n, N = P.N;
-  View<LOG2L, K, HYPER> v;
-  v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n * LPS, lig);
-  ReplicaState* rs = P.rs + r;
-  int32_t* si = F.scratch_i + r * fw_scratch_ints(N, F.I64);
-  int32_t *order = si, *wlist = si + N, *iorder = si + 2 * N, *gstk = si + 3 * N, *n_big = si + 4 * N;
-  volatile int16_t* pos = reinterpret_cast<volatile int16_t*>(si + 4 * N + F.I64);
-  double* cc_new = F.scratch_d + r * 2 * (int64_t)N;
-  double* part_new = cc_new + N;
-  double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
-  uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
-  M slices;
-#pragma unroll
-  for (int k = 0; k < K; ++k) slices.w[k] = sl[v.widx(k)];
-  FW_PROF_DECL;
-  FW_PROF_T(1);
-  if (gany<LOG2L>(mnonzero<K>(slices))) {
-    R rng;
-    rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
-#if defined(TNCO_PROFILE) && TNCO_PROFILE == 3  // event counts instead of cycles
-    const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, wlist, iorder, gstk, n_big, pos, lpos, lwide,
-                                                lane0, gbase, F.status + r, nullptr, fc_);
-#elif defined(TNCO_PROFILE)
-    unsigned long long fp_[2] = {0, 0};  // end of the first pass, end of the post-order
-    const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, wlist, iorder, gstk, n_big, pos, lpos, lwide,
-                                                lane0, gbase, F.status + r, fp_);
-    ft_[2] = fp_[0];
-    ft_[0] = ft_[1];                  // slot 0: too-wide counts (from the start of the re-slice)
-    ft_[1] = ft_[2];                  // slot 1: post-order
-    ft_[2] = fp_[1];                  // slot 2: the greedy pass (up to T(3))
-#else
-    const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, order, wlist, iorder, gstk, n_big, pos, lpos, lwide,
-                                                lane0, gbase, F.status + r);
-#endif
-    FW_PROF_T(3);
-    double sum;
-    const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, iorder, ns, cc_new, part_new, lane0, gbase, &sum);
-    if (tot < v.hdr(N - 1)->partial) {
-      slices = ns;
-      fw_commit<LOG2L, K, HYPER>(P, v, cc_new, part_new);
-#pragma unroll
-      for (int k = 0; k < K; ++k) sl[v.widx(k)] = slices.w[k];
-    }
-    int mti, mtw;
-    rng.finish(mti, mtw);
-    if (lane0) {
-      rs->mti = mti;
-      rs->mtw = mtw;
-    }
-    FW_PROF_T(4);
-    FW_PROF_ACC;
-  }
+  const int N = P.N, lig = v.lig;
   // :385-389
   const double tc = v.hdr(N - 1)->partial;
   if (tc < rs->min_cost) {
@@ -1215,6 +1126,76 @@ __global__ __launch_bounds__(256, 2) void fw_reslice_kernel(const Params P, cons
 #pragma unroll
     for (int k = 0; k < K; ++k) sl[LK + v.widx(k)] = slices.w[k];
   }
+}
+
+// The end of a re-slicing sweep, finite_width/greedy/optimizer.hpp:360-389: new slices for the
+// current tree (get_slices), the cost cache rebuilt with them, kept if the total improves; then the
+// best-so-far bookkeeping of the sweep (:385-389).
+template <int LOG2L, int K, bool HYPER>
+__global__ __launch_bounds__(256, 2) void fw_reslice_kernel(const Params P, const FwParams F) {
+  constexpr int L = 1 << LOG2L;
+  constexpr int GPB = 256 >> LOG2L;
+  constexpr int LK = L * K;
+  using M = Mask<K>;
+  using R = Rng<LOG2L>;
+  __shared__ uint32_t rngbuf[GPB * R::RING];
+  __shared__ int32_t posbuf[GPB * FW_LDSPOS];   // candidate legs of a tensor / traversal stack
+  __shared__ uint16_t leftbuf[GPB * FW_LDSPOS];  // traversal stack: left children
+  const int tid = threadIdx.x;
+  const int lig = tid & (L - 1);
+  const int gib = tid >> LOG2L;
+  const int gbase = (tid & 63) & ~(L - 1);
+  const int64_t r = (int64_t)blockIdx.x * GPB + gib;
+  if (r >= P.R) return;
+  lds_vi32* lpos = (lds_vi32*)posbuf + gib * FW_LDSPOS;
+  const FwStack st{lpos, (lds_vu16*)leftbuf + gib * FW_LDSPOS, FW_LDSPOS};
+  const bool lane0 = lig == 0;
+  const int n = P.n, N = P.N;
+  View<LOG2L, K, HYPER> v;
+  v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n * LPS, lig);
+  ReplicaState* rs = P.rs + r;
+  const FwScratch sc(F, r, N);
+  double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
+  uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
+  M slices;
+#pragma unroll
+  for (int k = 0; k < K; ++k) slices.w[k] = sl[v.widx(k)];
+  FW_PROF_DECL;
+  FW_PROF_T(1);
+  if (gany<LOG2L>(mnonzero<K>(slices))) {
+    R rng;
+    rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
+#if defined(TNCO_PROFILE) && TNCO_PROFILE == 3  // event counts instead of cycles
+    const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, sc, st, lpos, lane0, gbase, F.status + r, nullptr, fc_);
+#elif defined(TNCO_PROFILE)
+    unsigned long long fp_[2] = {0, 0};  // end of the walk, end of the counts
+    const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, sc, st, lpos, lane0, gbase, F.status + r, fp_);
+    ft_[2] = fp_[0];
+    ft_[0] = ft_[1];                  // slot 0: the walk (from the start of the re-slice)
+    ft_[1] = ft_[2];                  // slot 1: too-wide counts
+    ft_[2] = fp_[1];                  // slot 2: the greedy pass (up to T(3))
+#else
+    const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, sc, st, lpos, lane0, gbase, F.status + r);
+#endif
+    FW_PROF_T(3);
+    double sum;
+    const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, sc.rec, ns, sc.cp, sc.pstk, lane0, gbase, &sum);
+    if (tot < v.hdr(N - 1)->partial) {
+      slices = ns;
+      fw_commit<LOG2L, K, HYPER>(P, v, sc.rec, sc.cp);
+#pragma unroll
+      for (int k = 0; k < K; ++k) sl[v.widx(k)] = slices.w[k];
+    }
+    int mti, mtw;
+    rng.finish(mti, mtw);
+    if (lane0) {
+      rs->mti = mti;
+      rs->mtw = mtw;
+    }
+    FW_PROF_T(4);
+    FW_PROF_ACC;
+  }
+  fw_sweep_tail<LOG2L, K, HYPER>(P, v, rs, r, sl, slices, lane0);
   if (lane0) {
     FW_PROF_OUT(rs);
   }

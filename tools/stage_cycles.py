@@ -68,7 +68,7 @@ def fw(a):
     cyc = np.zeros(5, np.uint64)
     L.tnco_hip_get_stage_cycles(opt._h, cyc.ctypes.data_as(C.c_void_p))
     cyc = (cyc - base).astype(np.float64)
-    names = ["get_slices: too-wide counts", "post-order", "get_slices: greedy pass", "rebuild + commit"]
+    names = ["walk (post-order, widths)", "get_slices: too-wide counts", "get_slices: greedy pass", "rebuild + commit"]
     print(f"re-slices {cyc[4]:.3e} over {a.replicas} replicas (re-slicing sweeps only)")
     for k in range(4):
         print(f"  {names[k]:28s} {cyc[k] / cyc[4]:12.0f} cycles per re-slicing sweep  {100 * cyc[k] / cyc[:4].sum():5.1f} %")
