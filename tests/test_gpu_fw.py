@@ -178,3 +178,17 @@ def test_fw_tensor_with_many_candidate_legs(core, oracle_lib):
     prob = H.Problem(ts, 2)
     seeds = H.replica_seeds(3, S=1)
     _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 20, 12), 10, chunks=[12], every=5)
+
+
+@pytest.mark.parametrize("stack", ["0", "3"])
+def test_fw_traversal_fallbacks(core, oracle_lib, monkeypatch, stack):
+    """The walk over the tree without its LDS stack (TNCO_HIP_FW_STACK=0: the links are walked, what
+    trees of more than 8192 nodes get) and with a 3-entry one (everything deeper goes through the
+    global spill, what trees deeper than the LDS stack get): same results, bit for bit."""
+    monkeypatch.setenv("TNCO_HIP_FW_STACK", stack)
+    prob = H.regular_problem(64, graph_seed=3)
+    seeds = H.replica_seeds(6, S=11)
+    w0 = _initial_max_width(prob, prob.tree(seeds[0]))
+    _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 60, 60), max(2, int(0.4 * w0)), chunks=[25, 35], every=5)
+    prob = H.regular_problem(36, graph_seed=12)
+    _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 50, 40), 5, chunks=[40], max_number_new_slices=2)

@@ -31,8 +31,11 @@ struct FwParams {
   const double* log2dims;   // [LK*64] std::log2((double)dims[p]), per-index dims; else NULL
   double log2np;            // std::log2((double)n_projs) (simple_sparse_inds.hpp:45)
   int32_t width_f32;        // width_type float32 (else float64)
-  int32_t leaf_wide;        // 1 unless it is known that no leaf tensor is wider than max_width
+  int32_t leaf_wide;        // 1 when some leaf tensor is wider than max_width ...
+  const uint32_t* leaf_bits;  // ... [ceil(n / 32)] which ones (fw_leaf_bits_kernel; leaves never change)
   int32_t I64;              // 64 * LK (padded index count)
+  int32_t stack_cap;        // LDS entries of the traversal stack (<= FW_LDSPOS; 0: walk the links instead);
+                            // FW_LDSPOS unless TNCO_HIP_FW_STACK says otherwise (tests of the fallbacks)
   int64_t max_new_slices;   // max_number_new_slices
   uint64_t* slices;         // [R][2][LK]  slices, min_slices
   const uint64_t* skip;     // [LK] or NULL
@@ -231,10 +234,8 @@ struct FwStack {
 //
 // With a stack (entry: node | right child << 13 | right-visited << 26 | too-wide << 27, left child
 // beside it; the first st.cap entries in LDS, deeper ones in the global scratch `gstk`) every header
-// is fetched ONCE, on the way down.  Every iteration of the outer loop is one header fetch for
-// every replica of the wavefront that is not done (the replicas' trees differ; a loop nest that
-// follows one tree's shape would cost every replica the longest descent / ascent among the sixteen).
-// What follows the fetch -- leaves emitted, finished nodes popped -- touches the stack only.
+// is fetched ONCE, on the way down (the replicas' trees differ: a loop nest that follows one tree's
+// shape would cost every replica the longest descent / ascent among the sixteen -- see below).
 // Trees of more than 8192 nodes (or no stack) walk the links instead: the successor of x is its
 // parent if x is the right child, else the left-most leaf below its sibling.
 template <int LOG2L, int K, bool HYPER>
@@ -244,7 +245,7 @@ __device__ __forceinline__ int fw_traverse(const Params& P, const FwParams& F, c
   const int n = v.n, N = P.N;
   int ni = 0, nw = 0;
   auto emit_leaf = [&](int x) {
-    if (wlist != nullptr && F.leaf_wide && fw_width<LOG2L, K>(P, F, v.mask(x), v.lig, gbase) > F.max_width) {
+    if (wlist != nullptr && F.leaf_wide && ((F.leaf_bits[x >> 5] >> (x & 31)) & 1u)) {
       if (lane0) wlist[nw] = x;
       ++nw;
     }
@@ -264,33 +265,43 @@ __device__ __forceinline__ int fw_traverse(const Params& P, const FwParams& F, c
   };
   const bool walk = (st.e == nullptr) || (gstk == nullptr) || N > 8192;
   if (!walk) {
+    // One step per replica and iteration, whatever the shapes of the sixteen trees: a replica either
+    // goes down (x: the node whose header to fetch; push it, on to its left child) or comes up
+    // (x < 0: the top of the stack is entered to the right if that is still to do, else it is
+    // finished and popped).  Every replica needs the same number of steps (two or three per internal
+    // node), so the wavefront is done when each of them is.  Measured alternatives, all slower: a
+    // loop nest following the tree (descend-loop, pop-loop: every replica pays the longest run
+    // among the sixteen), several pops per iteration (1 / 2 / 4 / 8: 4.2 / 4.4 / 5.0 / 5.9 M cycles),
+    // header loads issued ahead of the pops (the loop is bound by its instructions, not the load).
     const int cap = st.cap;
     const int gh = (N + 1) / 2;  // gstk: [0, gh) entries, [gh, 2 gh) their left children
     int sp = 0, x = N - 1;
-    if (x < n) emit_leaf(x);
-    bool active = x >= n;
-    while (active) {
-      const int4 h = *reinterpret_cast<const int4*>(v.hdr(x));  // (left, right, parent, width)
-      const bool wide = is_wide(x, h.w);
-      ++sp;
-      if (lane0) {
-        const int e = x | (h.y << 13) | (wide ? (1 << 27) : 0);
-        if (sp <= cap) {
-          st.e[sp - 1] = e;
-          st.l[sp - 1] = (uint16_t)h.x;
-        } else {
-          gstk[sp - 1 - cap] = e;
-          gstk[gh + sp - 1 - cap] = h.x;
+    bool done = false;
+    if (x < n) {
+      emit_leaf(x);
+      done = true;
+    }
+    while (!done) {
+      if (x >= n) {
+        const int4 h = *reinterpret_cast<const int4*>(v.hdr(x));  // (left, right, parent, width)
+        const bool wide = is_wide(x, h.w);
+        ++sp;
+        if (lane0) {
+          const int e = x | (h.y << 13) | (wide ? (1 << 27) : 0);
+          if (sp <= cap) {
+            st.e[sp - 1] = e;
+            st.l[sp - 1] = (uint16_t)h.x;
+          } else {
+            gstk[sp - 1 - cap] = e;
+            gstk[gh + sp - 1 - cap] = h.x;
+          }
         }
-      }
-      x = h.x;
-      if (x >= n) continue;
-      emit_leaf(x);  // the left child is a leaf
-      for (;;) {  // up: into the right subtree of the innermost open node, or close it
-        if (sp == 0) {
-          active = false;
-          break;
+        x = h.x;
+        if (x < n) {
+          emit_leaf(x);  // the left child is a leaf: up from here
+          x = -1;
         }
+      } else {
         int e, l;
         if (sp <= cap) {
           e = st.e[sp - 1];
@@ -301,18 +312,18 @@ __device__ __forceinline__ int fw_traverse(const Params& P, const FwParams& F, c
           l = gstk[gh + sp - 1 - cap];
         }
         const int node = e & 0x1FFF, rr = (e >> 13) & 0x1FFF;
-        if (((e >> 26) & 1) == 0) {
-          if (rr >= n) {
-            if (lane0) {
-              if (sp <= cap) st.e[sp - 1] = e | (1 << 26); else gstk[sp - 1 - cap] = e | (1 << 26);
-            }
-            x = rr;
-            break;
+        const bool fresh = ((e >> 26) & 1) == 0;
+        if (fresh && rr >= n) {  // into the right subtree
+          if (lane0) {
+            if (sp <= cap) st.e[sp - 1] = e | (1 << 26); else gstk[sp - 1 - cap] = e | (1 << 26);
           }
-          emit_leaf(rr);  // the right child is a leaf: the node is finished as well
+          x = rr;
+        } else {  // the node is finished (after its right child, if that is a leaf)
+          if (fresh) emit_leaf(rr);
+          --sp;
+          emit_node(node, l, rr, ((e >> 27) & 1) != 0);
+          if (sp == 0) done = true;
         }
-        --sp;
-        emit_node(node, l, rr, ((e >> 27) & 1) != 0);
       }
     }
   }
@@ -743,6 +754,24 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
   return fw_gs_pick<LOG2L, K, HYPER>(P, F, v, rng, sc, nw, lpos, lane0, gbase, status, cnt);
 }
 
+// Which leaf tensors are wider than max_width (the leaves are the same in every replica and never
+// change): bits[t >> 5] |= 1 << (t & 31), *any = 1 if there is one.  One workgroup.
+template <int LOG2L, int K>
+__global__ __launch_bounds__(256) void fw_leaf_bits_kernel(const Params P, const FwParams F, uint32_t* bits, int32_t* any) {
+  constexpr int L = 1 << LOG2L;
+  const int tid = threadIdx.x;
+  const int lig = tid & (L - 1);
+  const int gbase = (tid & 63) & ~(L - 1);
+  View<LOG2L, K, false> v;
+  v.init(P, P.blocks, P.lpar, lig);
+  for (int t = tid >> LOG2L; t < P.n; t += 256 >> LOG2L) {
+    if (fw_width<LOG2L, K>(P, F, v.mask(t), lig, gbase) > F.max_width && lig == 0) {
+      atomicOr(&bits[t >> 5], 1u << (t & 31));
+      *any = 1;
+    }
+  }
+}
+
 struct FwInitArgs {
   const uint64_t* slices_in;  // [LK] or NULL: use instead of the initial get_slices
   double* out_total;          // [R]
@@ -767,7 +796,7 @@ __global__ __launch_bounds__(256, 2) void fw_init_kernel(const Params P, const F
   const int64_t r = (int64_t)blockIdx.x * GPB + gib;
   if (r >= P.R) return;
   lds_vi32* lpos = (lds_vi32*)posbuf + gib * FW_LDSPOS;
-  const FwStack st{lpos, (lds_vu16*)leftbuf + gib * FW_LDSPOS, FW_LDSPOS};
+  const FwStack st{F.stack_cap > 0 ? lpos : nullptr, (lds_vu16*)leftbuf + gib * FW_LDSPOS, F.stack_cap};
   const bool lane0 = lig == 0;
   const int n = P.n, N = P.N;
   View<LOG2L, K, HYPER> v;
@@ -868,8 +897,8 @@ __global__ __launch_bounds__(256, MAXNEW ? 2 : TNCO_FW_MOVE_WAVES) void fw_move_
   const int gbase = (tid & 63) & ~(L - 1);
   const int64_t r = (int64_t)blockIdx.x * GPB + gib;
   if (r >= P.R || n_steps <= 0) return;
-  [[maybe_unused]] const FwStack st{(lds_vi32*)posbuf + (MAXNEW ? gib * FW_LDSPOS : 0),
-                                    (lds_vu16*)leftbuf + (MAXNEW ? gib * FW_LDSPOS : 0), FW_LDSPOS};
+  [[maybe_unused]] const FwStack st{F.stack_cap > 0 ? (lds_vi32*)posbuf + (MAXNEW ? gib * FW_LDSPOS : 0) : nullptr,
+                                    (lds_vu16*)leftbuf + (MAXNEW ? gib * FW_LDSPOS : 0), F.stack_cap};
   const bool lane0 = lig == 0;
   const int n = P.n, N = P.N;
   const int f32 = P.f32;
@@ -1148,7 +1177,7 @@ __global__ __launch_bounds__(256, 2) void fw_reslice_kernel(const Params P, cons
   const int64_t r = (int64_t)blockIdx.x * GPB + gib;
   if (r >= P.R) return;
   lds_vi32* lpos = (lds_vi32*)posbuf + gib * FW_LDSPOS;
-  const FwStack st{lpos, (lds_vu16*)leftbuf + gib * FW_LDSPOS, FW_LDSPOS};
+  const FwStack st{F.stack_cap > 0 ? lpos : nullptr, (lds_vu16*)leftbuf + gib * FW_LDSPOS, F.stack_cap};
   const bool lane0 = lig == 0;
   const int n = P.n, N = P.N;
   View<LOG2L, K, HYPER> v;

@@ -80,6 +80,8 @@ void launch_build_lk(tnco_hip_ctx* h, const tnco::BuildArgs& a);
 template <int LOG2L, int K>
 void launch_compare_lk(tnco_hip_ctx* h, const tnco::BuildArgs& a, double atol, int32_t* out_bad);
 template <int LOG2L, int K>
+void launch_fw_leaf_bits_lk(tnco_hip_ctx* h, uint32_t* bits, int32_t* any);
+template <int LOG2L, int K>
 void launch_fw_init_lk(tnco_hip_ctx* h, const tnco::FwInitArgs& a);
 template <int LOG2L, int K>
 void launch_fw_check_lk(tnco_hip_ctx* h, const tnco::BuildArgs& a, int which_min, double atol, int32_t* out_bad);

@@ -46,6 +46,10 @@ void launch_compare_lk(tnco_hip_ctx* h, const BuildArgs& a, double atol, int32_t
 
 
 template <int LOG2L, int K>
+void launch_fw_leaf_bits_lk(tnco_hip_ctx* h, uint32_t* bits, int32_t* any) {
+  hipLaunchKernelGGL((fw_leaf_bits_kernel<LOG2L, K>), dim3(1), dim3(256), 0, h->stream, h->P, h->F, bits, any);
+}
+template <int LOG2L, int K>
 void launch_fw_init_lk(tnco_hip_ctx* h, const FwInitArgs& a) {
   const int gpb = 256 >> LOG2L;
   dim3 grid((unsigned)((h->P.R + gpb - 1) / gpb));
@@ -92,6 +96,7 @@ void launch_fw_reslice_lk(tnco_hip_ctx* h) {
 template void launch_run_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const double*, int64_t, int);
 template void launch_build_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const BuildArgs&);
 template void launch_compare_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const BuildArgs&, double, int32_t*);
+template void launch_fw_leaf_bits_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, uint32_t*, int32_t*);
 template void launch_fw_init_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const FwInitArgs&);
 template void launch_fw_check_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const BuildArgs&, int, double, int32_t*);
 template void launch_fw_move_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const double*, int64_t, int, int);

@@ -554,17 +554,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     F.log2np = d->sparse_mask ? std::log2((double)d->n_projs) : 0.0;
     F.max_new_slices = (int64_t)std::min<uint64_t>(d->max_number_new_slices, (uint64_t)1 << 40);
     F.I64 = 64 * L;
-    F.leaf_wide = 1;
-    if (uniform && !d->sparse_mask) {  // the re-slice skips the leaves when none of them is too wide
-      int wide = 0;
-      for (int t = 0; t < n && !wide; ++t) {
-        int cnt = 0;
-        for (int w = 0; w < W; ++w) cnt += __builtin_popcountll(h->leafmask_w[(size_t)t * W + w]);
-        const double wd = F.log2d * (double)cnt;
-        if ((F.width_f32 ? (double)(float)wd : wd) > F.max_width) wide = 1;
-      }
-      F.leaf_wide = wide;
-    }
+    F.leaf_wide = 0;
     if (!uniform) {
       std::vector<double> l2((size_t)L * 64, 0.0);
       for (int i = 0; i < I; ++i) l2[i] = std::log2((double)d->dims[i]);
@@ -579,6 +569,8 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     HIP_TRY(h->alloc(&F.scratch_d, R * 2 * (int64_t)N));
     HIP_TRY(h->alloc(&F.status, R));
     HIP_TRY(hipMemset(F.status, 0, (size_t)R * 4));
+    F.stack_cap = FW_LDSPOS;
+    if (const char* e = std::getenv("TNCO_HIP_FW_STACK")) F.stack_cap = std::max(0, std::min(FW_LDSPOS, std::atoi(e)));
     auto upload_mask = [&](const uint64_t* src, const uint64_t** dst) -> int {
       std::vector<uint64_t> m((size_t)L, 0);
       for (int w = 0; w < W; ++w) m[w] = src[w];
@@ -590,6 +582,24 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     };
     if (d->skip_slices)
       if (int rc = upload_mask(d->skip_slices, &F.skip)) return rc;
+    {  // the leaf tensors wider than max_width (usually none: the walk of the re-slice skips the leaves then)
+      uint32_t* bits;
+      int32_t* any;
+      const int nb = (n + 31) / 32;
+      HIP_TRY(h->alloc(&bits, nb));
+      HIP_TRY(tmp.alloc(&any, 1));
+      HIP_TRY(hipMemsetAsync(bits, 0, (size_t)nb * 4, h->stream));
+      HIP_TRY(hipMemsetAsync(any, 0, 4, h->stream));
+      F.leaf_bits = bits;
+#define CALL_FWL(LL, KK) launch_fw_leaf_bits_lk<LL, KK>(h, bits, any)
+      DISPATCH_LK(h, CALL_FWL)
+#undef CALL_FWL
+      HIP_TRY(hipGetLastError());
+      int32_t a1 = 0;
+      HIP_TRY(hipMemcpyAsync(&a1, any, 4, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      F.leaf_wide = a1 ? 1 : 0;
+    }
     FwInitArgs a{};
     if (d->slices)
       if (int rc = upload_mask(d->slices, &a.slices_in)) return rc;
