@@ -938,21 +938,67 @@ __global__ __launch_bounds__(256, MAXNEW ? 2 : TNCO_FW_MOVE_WAVES) void fw_move_
     return u;
   };
 
-  for (int64_t step = 0; step < n_steps; ++step) {
-    const double beta = betas[step];
+  // The replicas of a wavefront walk leaf-to-root paths of different lengths: were the sweeps kept in
+  // step, every sweep would cost each of them the longest of sixteen paths.  So every replica runs
+  // its n_steps sweeps at its own pace -- one loop over moves, a replica that reaches the root closes
+  // its sweep (:385-389) and starts its next one in the same iteration.
+  //
+  // Two dependent rounds of loads per move: [A's header, the masks and partial sums of B's children,
+  // A's legs, both hyper masks] once B's header is known, [C's mask and partial sum] once A's is.
+  // B's header itself is carried over from the move before (the next B is this move's A, whose new
+  // header has just been written from registers).
+  int64_t step = 0;
+  double beta = 0.0, total = 0.0;
+  int B = 0;
+  NodeRec hb;
+  auto begin_sweep = [&](double root_partial) {
+    beta = betas[step];
     // :130-139
     const int leaf = (int)(rng.next_sync() % (uint32_t)n);
-    int B = v.parent(leaf);
-    double total = v.hdr(N - 1)->partial;
+    B = v.parent(leaf);
+    total = root_partial;
+    hb = *v.hdr(B);
+  };
+  begin_sweep(v.hdr(N - 1)->partial);
+  {
     for (;;) {
       // get_ctree_nn, optimize/optimizer.hpp:112-144
-      const NodeRec hb = *v.hdr(B);
       const int A = hb.parent;
-      if (A < 0) break;
+      if (A < 0) {  // B is the root: the sweep is over
+        const double tc = hb.partial;
+        if (!(step == n_steps - 1 && !tail_last)) {  // (else fw_reslice_kernel goes on from here)
+          // :385-389
+          if (tc < min_cost) {
+            min_cost = tc;
+            ++n_impr;
+            if (jinvalid) {
+              Links* __restrict__ ml = P.minlinks + r * (int64_t)N;
+              for (int i = lig; i < N; i += L) {
+                Links o;
+                o.left = v.left(i); o.right = v.right(i); o.parent = v.parent(i); o.pad = 0;
+                ml[i] = o;
+              }
+              jtail = 0;
+              jinvalid = false;
+              ++n_full;
+            }
+            jmin = jtail;
+#pragma unroll
+            for (int k = 0; k < K; ++k) sl[LK + v.widx(k)] = slices.w[k];
+          }
+        }
+        if (++step >= n_steps) break;
+        begin_sweep(tc);
+        continue;
+      }
       const NodeRec ha = *v.hdr(A);
+      const M m0 = v.mask(hb.left), m1 = v.mask(hb.right);
+      const double p0 = v.partial(hb.left), p1 = v.partial(hb.right);
+      const M iA = v.mask(A), hA = v.hyper(A), hB = v.hyper(B);
       const bool c_is_right = (ha.left == B);
       int C = c_is_right ? ha.right : ha.left;
-      const M mC = v.mask(C), m0 = v.mask(hb.left), m1 = v.mask(hb.right);
+      const M mC = v.mask(C);
+      const double pC = v.partial(C);
       const uint32_t w = gsum<LOG2L>((mnonzero<K>(mand<K>(m0, mC)) ? 1u : 0u) |
                                      ((mnonzero<K>(mand<K>(m1, mC)) ? 1u : 0u) << 8));
       const bool inter0 = (w & 0xffu) != 0, inter1 = (w >> 8) != 0;
@@ -966,7 +1012,7 @@ __global__ __launch_bounds__(256, MAXNEW ? 2 : TNCO_FW_MOVE_WAVES) void fw_move_
       const int D = pick0 ? hb.left : hb.right;
       int E = pick0 ? hb.right : hb.left;
       const M mD = msel<K>(pick0, m0, m1), mE = msel<K>(pick0, m1, m0);
-      const M iA = v.mask(A), hA = v.hyper(A), hB = v.hyper(B);
+      const double pD = pick0 ? p0 : p1, pE = pick0 ? p1 : p0;
       // :174-179
       const M newB = mor<K>(mor<K>(mxor<K>(mD, mC), hA), hB);
       const double new_width_B = fw_width<LOG2L, K>(P, F, newB, lig, gbase);
@@ -1065,42 +1111,27 @@ __global__ __launch_bounds__(256, MAXNEW ? 2 : TNCO_FW_MOVE_WAVES) void fw_move_
       }
       // :324-331
       if (!skip_cost_propagation) {
-        const double partB = rnd_cost(rnd_cost(v.partial(D) + v.partial(E), f32) + ccB, f32);
-        const double partA = rnd_cost(rnd_cost(partB + v.partial(C), f32) + ccA, f32);
+        // (an accepted move has swapped C and E: B holds D and the old C, A holds B and the old E)
+        const double partB = rnd_cost(rnd_cost(pD + (acc ? pC : pE), f32) + ccB, f32);
+        const double partA = rnd_cost(rnd_cost(partB + (acc ? pE : pC), f32) + ccA, f32);
+        NodeRec oa;
+        oa.left = al; oa.right = ar; oa.parent = ha.parent; oa.pad = ha.pad; oa.ccost = ccA; oa.partial = partA;
         if (lane0) {
           NodeRec o;
           o.left = bl; o.right = br; o.parent = A; o.ccost = ccB; o.partial = partB;
           o.pad = (acc && F.width_f32) ? __float_as_int((float)new_width_B) : hb.pad;
           *v.hdr(B) = o;
-          NodeRec oa;
-          oa.left = al; oa.right = ar; oa.parent = ha.parent; oa.pad = ha.pad; oa.ccost = ccA; oa.partial = partA;
           *v.hdr(A) = oa;
           if (acc && !F.width_f32) w64[B] = new_width_B;
         }
+        hb = oa;
+        // (no wait for the stores: the next move's loads come after them in this wavefront's
+        // instruction stream, and memory operations of one wavefront to the same address stay in order)
+      } else {
+        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        hb = *v.hdr(A);  // (rebuilt by fw_commit)
       }
-      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
       B = A;
-    }
-    if (step == n_steps - 1 && !tail_last) break;  // (fw_reslice_kernel goes on from here)
-    // :385-389
-    const double tc = v.hdr(N - 1)->partial;
-    if (tc < min_cost) {
-      min_cost = tc;
-      ++n_impr;
-      if (jinvalid) {
-        Links* __restrict__ ml = P.minlinks + r * (int64_t)N;
-        for (int i = lig; i < N; i += L) {
-          Links o;
-          o.left = v.left(i); o.right = v.right(i); o.parent = v.parent(i); o.pad = 0;
-          ml[i] = o;
-        }
-        jtail = 0;
-        jinvalid = false;
-        ++n_full;
-      }
-      jmin = jtail;
-#pragma unroll
-      for (int k = 0; k < K; ++k) sl[LK + v.widx(k)] = slices.w[k];
     }
   }
 #pragma unroll
