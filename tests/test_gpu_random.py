@@ -6,7 +6,7 @@ import os
 
 import numpy as np
 import pytest
-from hypothesis import HealthCheck, given, settings, strategies as st
+from hypothesis import HealthCheck, example, given, settings, strategies as st
 
 from tests import helpers as H
 from tnco_amd import synthetic as syn
@@ -83,6 +83,12 @@ def test_random_infinite_memory(core, oracle_lib, seed, n, k, dims_kind, n_spars
        dims_kind=st.sampled_from(["two", "two", "four", "vector"]), n_sparse=st.sampled_from([0, 0, 4]),
        frac=st.floats(0.3, 1.1), every=st.sampled_from([1, 3, 10]), width_type=st.sampled_from(["float32", "float64"]),
        new_slices=st.sampled_from([0, 0, 2]))
+# (large networks, found by tools/fuzz_gpu.py --nmin 150 --nmax 700: 12- and 15-word masks, trees deeper
+# than the LDS traversal stack, the max_number_new_slices branch with its full rebuilds)
+@example(seed=717032, n=501, k=3, dims_kind="two", n_sparse=0, frac=0.3146844055637413, every=3,
+         width_type="float32", new_slices=2)
+@example(seed=368628, n=315, k=3, dims_kind="two", n_sparse=0, frac=0.7781581243643569, every=10,
+         width_type="float64", new_slices=0)
 def test_random_finite_width(core, oracle_lib, seed, n, k, dims_kind, n_sparse, frac, every, width_type, new_slices):
     prob = _problem(seed, n, k, dims_kind, n_sparse)
     seeds = H.replica_seeds(5, S=seed)

@@ -880,8 +880,11 @@ __global__ __launch_bounds__(256, 2) void fw_init_kernel(const Params P, const F
 #ifndef TNCO_FW_MOVE_WAVES
 #define TNCO_FW_MOVE_WAVES 2
 #endif
+#ifndef TNCO_FW_MAXNEW_WAVES
+#define TNCO_FW_MAXNEW_WAVES 2
+#endif
 template <int LOG2L, int K, bool HYPER, bool MAXNEW>
-__global__ __launch_bounds__(256, MAXNEW ? 2 : TNCO_FW_MOVE_WAVES) void fw_move_kernel(const Params P, const FwParams F, const double* __restrict__ betas,
+__global__ __launch_bounds__(256, MAXNEW ? TNCO_FW_MAXNEW_WAVES : TNCO_FW_MOVE_WAVES) void fw_move_kernel(const Params P, const FwParams F, const double* __restrict__ betas,
                                                       const int64_t n_steps, const int prob_kind, const int tail_last) {
   constexpr int L = 1 << LOG2L;
   constexpr int GPB = 256 >> LOG2L;
@@ -951,15 +954,18 @@ __global__ __launch_bounds__(256, MAXNEW ? 2 : TNCO_FW_MOVE_WAVES) void fw_move_
   double beta = 0.0, total = 0.0;
   int B = 0;
   NodeRec hb;
-  auto begin_sweep = [&](double root_partial) {
-    beta = betas[step];
-    // :130-139
-    const int leaf = (int)(rng.next_sync() % (uint32_t)n);
-    B = v.parent(leaf);
-    total = root_partial;
-    hb = *v.hdr(B);
-  };
-  begin_sweep(v.hdr(N - 1)->partial);
+  // (a macro, not a lambda: as a lambda capturing `hb` by reference, the finite-width kernel with the
+  // max_number_new_slices branch kept the struct in private memory behind a generic pointer and
+  // faulted at address 0 on large networks -- tools/fuzz_gpu.py --nmin 150 --nmax 700 --new-slices 2)
+#define TNCO_BEGIN_SWEEP(root_partial)                                  \
+  do {                                                                  \
+    beta = betas[step];                                                 \
+    const int leaf_ = (int)(rng.next_sync() % (uint32_t)n); /* :130-139 */ \
+    B = v.parent(leaf_);                                                \
+    total = (root_partial);                                             \
+    hb = *v.hdr(B);                                                     \
+  } while (0)
+  TNCO_BEGIN_SWEEP(v.hdr(N - 1)->partial);
   {
     for (;;) {
       // get_ctree_nn, optimize/optimizer.hpp:112-144
@@ -988,7 +994,7 @@ __global__ __launch_bounds__(256, MAXNEW ? 2 : TNCO_FW_MOVE_WAVES) void fw_move_
           }
         }
         if (++step >= n_steps) break;
-        begin_sweep(tc);
+        TNCO_BEGIN_SWEEP(tc);
         continue;
       }
       const NodeRec ha = *v.hdr(A);

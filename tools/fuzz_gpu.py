@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--nmin", type=int, default=0, help="override the range of the number of tensors")
     ap.add_argument("--nmax", type=int, default=0, help="(wide masks: 8- and 16-lane layouts from ~450 tensors on)")
     ap.add_argument("--dims", default="", help="restrict dims_kind (e.g. 'two': big random trees overflow otherwise)")
+    ap.add_argument("--new-slices", type=int, default=-1, help="force max_number_new_slices of the finite-width cases")
+    ap.add_argument("--verbose", action="store_true", help="print every case before it runs (a GPU fault kills the process)")
     a = ap.parse_args()
     orc.build()
     rng = random.Random(a.seed)
@@ -35,6 +37,8 @@ def main():
                       dims_kind=a.dims or rng.choice(["two", "three", "four", "vector"]), n_sparse=rng.choice([0, 0, 3, 8]),
                       cost_type=rng.choice(["float64", "float64", "float32"]),
                       kind=rng.choice(["mh", "mh", "greedy", "base"]), dsi=rng.random() < 0.5)
+            if a.verbose:
+                print("infinite_memory", kw, flush=True)
             try:
                 im(core, orc, **kw)
             except Exception:
@@ -46,6 +50,10 @@ def main():
                       dims_kind=a.dims or rng.choice(["two", "two", "four", "vector"]), n_sparse=rng.choice([0, 0, 4]),
                       frac=rng.uniform(0.3, 1.1), every=rng.choice([1, 3, 10]),
                       width_type=rng.choice(["float32", "float64"]), new_slices=rng.choice([0, 0, 2]))
+            if a.new_slices >= 0:
+                kw["new_slices"] = a.new_slices
+            if a.verbose:
+                print("finite_width", kw, flush=True)
             try:
                 fw(core, orc, **kw)
             except Exception:
