@@ -544,9 +544,15 @@ __device__ __forceinline__ void fw_slice_wide(const Params& P, const FwParams& F
     const uint32_t np = fw_positions<LOG2L, K, HYPER>(v, cand, lpos, (uint32_t)FW_LDSPOS, gbase, lane0, status);
     fw_shuffle<LOG2L>(rng, lpos, (int)np, lane0);
     if (cnt) cnt[2] += np;  // candidate legs
-    for (uint32_t q = (uint32_t)lig; q < np; q += L) {
-      const int xp = lpos[q];
-      lpos[q] = (n_big[xp] << 16) | xp;
+    for (uint32_t q0 = (uint32_t)lig; q0 < np; q0 += 4 * L) {  // (four gathers in flight per lane)
+      int xp[4], kb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xp[i] = q0 + i * L < np ? (int)lpos[q0 + i * L] : 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) kb[i] = n_big[xp[i]];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (q0 + i * L < np) lpos[q0 + i * L] = (kb[i] << 16) | xp[i];
     }
     for (uint32_t taken = 0; taken < np; ++taken) {
       uint32_t best = 0;
