@@ -670,10 +670,11 @@ __device__ __forceinline__ int fw_gs_mark(const Params& P, const FwParams& F, co
     int ta = sc.wlist[0], tb = nw > 1 ? sc.wlist[1] : 0;
     Mask<K> m0 = v.mask(ta);
     for (int j = 0; j < nw; ++j) {
-      Mask<K> m1 = mzero<K>();  // (the next mask is on its way while this one is added)
+      // (the next mask is on its way while this one is added; past the end of the list: any tensor --
+      // unconditional loads, one definition each)
       ta = tb;
-      if (j + 1 < nw) m1 = v.mask(ta);
-      if (j + 2 < nw) tb = sc.wlist[j + 2];
+      const Mask<K> m1 = v.mask(ta);
+      tb = sc.wlist[j + 2 < nw ? j + 2 : nw - 1];
       Mask<K> carry = m0;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
@@ -733,8 +734,8 @@ __device__ __forceinline__ Mask<K> fw_gs_pick(const Params& P, const FwParams& F
         const Mask<K> m = ma;
         ta = tb;
         ++j;
-        if (j < nw) ma = v.mask(ta);
-        if (j + 1 < nw) tb = wlist[j + 1];
+        ma = v.mask(ta);  // (past the end of the list: any tensor)
+        tb = wlist[j + 1 < nw ? j + 1 : nw - 1];
         if (cnt) cnt[0] += 1;  // too-wide tensors
         sx = mandn<K>(m, slices);
         sw = fw_width<LOG2L, K>(P, F, sx, lig, gbase);

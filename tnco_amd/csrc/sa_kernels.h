@@ -159,17 +159,22 @@ struct View {
   __device__ __forceinline__ uint64_t* words(int p) const {
     return reinterpret_cast<uint64_t*>(blk + (int64_t)(p - n) * BS + 32);
   }
+  // Legs of node x (this lane's words).  The ADDRESS is selected (leaf table / node block), not the
+  // value: one load per word, one definition -- two loads in the arms of a branch merge where the
+  // arms meet, and the merge waits ("a loaded value has ONE definition"); several masks
+  // requested back to back then really are in flight together.
   __device__ __forceinline__ Mask<K> mask(int x) const {
+    const bool leaf = x < n;
+    const uint64_t* s = leaf ? leafmask + (int64_t)x * LK : words(x);
     Mask<K> r;
-    if (x < n) {
-      const uint64_t* s = leafmask + (int64_t)x * LK;
 #pragma unroll
-      for (int k = 0; k < K; ++k) r.w[k] = s[widx(k)];
-    } else {
-      const uint64_t* s = words(x);
-#pragma unroll
-      for (int k = 0; k < K; ++k) r.w[k] = (widx(k) < W) ? s[widx(k)] : 0ull;
+    for (int k = 0; k < K; ++k) {
+      const int i = widx(k);
+      r.w[k] = s[(leaf || i < W) ? i : W - 1];  // (a node block holds W words, a leaf row LK)
     }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (!leaf && widx(k) >= W) r.w[k] = 0ull;
     return r;
   }
   // Same value as mask(x), as ONE load sequence for leaves and internal nodes (the address is
