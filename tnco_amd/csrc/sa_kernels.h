@@ -219,8 +219,15 @@ struct View {
         if (widx(k) < W) s[widx(k)] = v.w[k];
     }
   }
-  __device__ __forceinline__ double partial(int x) const { return x < n ? 0.0 : hdr(x)->partial; }
-  __device__ __forceinline__ int parent(int x) const { return x < n ? lpar[(int64_t)x * LPS] : hdr(x)->parent; }
+  // (address selected, value fixed up afterwards: see mask())
+  __device__ __forceinline__ double partial(int x) const {
+    const double p = hdr(x < n ? n : x)->partial;
+    return x < n ? 0.0 : p;
+  }
+  __device__ __forceinline__ int parent(int x) const {
+    const int32_t* a = x < n ? lpar + (int64_t)x * LPS : &hdr(x)->parent;
+    return *a;
+  }
   __device__ __forceinline__ void set_parent(int x, int p) const {
     if (x < n) lpar[(int64_t)x * LPS] = p; else hdr(x)->parent = p;
   }
