@@ -267,9 +267,9 @@ __device__ __forceinline__ int fw_traverse(const Params& P, const FwParams& F, c
   if (!walk) {
     // One step per replica and iteration, whatever the shapes of the sixteen trees: a replica either
     // goes down (x: the node whose header to fetch; push it, on to its left child) or comes up
-    // (x < 0: the top of the stack is entered to the right if that is still to do, else it is
-    // finished and popped).  Every replica needs the same number of steps (two or three per internal
-    // node), so the wavefront is done when each of them is.  Measured alternatives, all slower: a
+    // (x < 0: the top of the stack is entered to the right if that is still to do -- and that node's
+    // header fetched in the same iteration -- else it is finished and popped).  Every replica needs
+    // the same number of steps (two per internal node), so the wavefront is done when each of them is.  Measured alternatives, all slower: a
     // loop nest following the tree (descend-loop, pop-loop: every replica pays the longest run
     // among the sixteen), several pops per iteration (1 / 2 / 4 / 8: 4.2 / 4.4 / 5.0 / 5.9 M cycles),
     // header loads issued ahead of the pops (the loop is bound by its instructions, not the load).
@@ -282,7 +282,31 @@ __device__ __forceinline__ int fw_traverse(const Params& P, const FwParams& F, c
       done = true;
     }
     while (!done) {
-      if (x >= n) {
+      if (x < 0) {  // up
+        int e, l;
+        if (sp <= cap) {
+          e = st.e[sp - 1];
+          l = st.l[sp - 1];
+        } else {
+          __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (lane 0's store, every lane's load)
+          e = gstk[sp - 1 - cap];
+          l = gstk[gh + sp - 1 - cap];
+        }
+        const int node = e & 0x1FFF, rr = (e >> 13) & 0x1FFF;
+        const bool fresh = ((e >> 26) & 1) == 0;
+        if (fresh && rr >= n) {  // into the right subtree (its header is fetched in this same iteration)
+          if (lane0) {
+            if (sp <= cap) st.e[sp - 1] = e | (1 << 26); else gstk[sp - 1 - cap] = e | (1 << 26);
+          }
+          x = rr;
+        } else {  // the node is finished (after its right child, if that is a leaf)
+          if (fresh) emit_leaf(rr);
+          --sp;
+          emit_node(node, l, rr, ((e >> 27) & 1) != 0);
+          if (sp == 0) done = true;
+        }
+      }
+      if (x >= n) {  // down
         const int4 h = *reinterpret_cast<const int4*>(v.hdr(x));  // (left, right, parent, width)
         const bool wide = is_wide(x, h.w);
         ++sp;
@@ -300,29 +324,6 @@ __device__ __forceinline__ int fw_traverse(const Params& P, const FwParams& F, c
         if (x < n) {
           emit_leaf(x);  // the left child is a leaf: up from here
           x = -1;
-        }
-      } else {
-        int e, l;
-        if (sp <= cap) {
-          e = st.e[sp - 1];
-          l = st.l[sp - 1];
-        } else {
-          __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (lane 0's store, every lane's load)
-          e = gstk[sp - 1 - cap];
-          l = gstk[gh + sp - 1 - cap];
-        }
-        const int node = e & 0x1FFF, rr = (e >> 13) & 0x1FFF;
-        const bool fresh = ((e >> 26) & 1) == 0;
-        if (fresh && rr >= n) {  // into the right subtree
-          if (lane0) {
-            if (sp <= cap) st.e[sp - 1] = e | (1 << 26); else gstk[sp - 1 - cap] = e | (1 << 26);
-          }
-          x = rr;
-        } else {  // the node is finished (after its right child, if that is a leaf)
-          if (fresh) emit_leaf(rr);
-          --sp;
-          emit_node(node, l, rr, ((e >> 27) & 1) != 0);
-          if (sp == 0) done = true;
         }
       }
     }
