@@ -281,8 +281,7 @@ __device__ __forceinline__ int fw_traverse(const Params& P, const FwParams& F, c
       emit_leaf(x);
       done = true;
     }
-    while (!done) {
-      if (x < 0) {  // up
+    auto up = [&]() {
         int e, l;
         if (sp <= cap) {
           e = st.e[sp - 1];
@@ -305,7 +304,9 @@ __device__ __forceinline__ int fw_traverse(const Params& P, const FwParams& F, c
           emit_node(node, l, rr, ((e >> 27) & 1) != 0);
           if (sp == 0) done = true;
         }
-      }
+    };
+    while (!done) {
+      if (x < 0) up();
       if (x >= n) {  // down
         const int4 h = *reinterpret_cast<const int4*>(v.hdr(x));  // (left, right, parent, width)
         const bool wide = is_wide(x, h.w);
@@ -326,6 +327,7 @@ __device__ __forceinline__ int fw_traverse(const Params& P, const FwParams& F, c
           x = -1;
         }
       }
+      if (!done && x < 0) up();  // (a second chance per iteration: an up step before and after the fetch)
     }
   }
   if (walk) {
