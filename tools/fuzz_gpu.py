@@ -30,7 +30,7 @@ def main():
     rng = random.Random(a.seed)
     im = T.test_random_infinite_memory.hypothesis.inner_test
     fw = T.test_random_finite_width.hypothesis.inner_test
-    bad = 0
+    bad = skipped = 0
     for i in range(a.cases):
         if a.which in ("im", "both"):
             kw = dict(seed=rng.randrange(10**6), n=rng.randint(a.nmin or 4, a.nmax or 40), k=rng.choice([2, 3, 4]),
@@ -41,7 +41,10 @@ def main():
                 print("infinite_memory", kw, flush=True)
             try:
                 im(core, orc, **kw)
-            except Exception:
+            except Exception as e:
+                if "Precision is too low" in str(e):
+                    skipped += 1
+                    continue
                 bad += 1
                 print("FAIL infinite_memory", kw)
                 print("   ", traceback.format_exc().strip().splitlines()[-1])
@@ -56,11 +59,14 @@ def main():
                 print("finite_width", kw, flush=True)
             try:
                 fw(core, orc, **kw)
-            except Exception:
+            except Exception as e:
+                if "Precision is too low" in str(e):  # (the reference's own verdict on costs beyond the float range)
+                    skipped += 1
+                    continue
                 bad += 1
                 print("FAIL finite_width", kw)
                 print("   ", traceback.format_exc().strip().splitlines()[-1])
-    print(f"{a.cases} cases each, {bad} failures")
+    print(f"{a.cases} cases each, {bad} failures, {skipped} skipped ('Precision is too low.')")
 
 
 if __name__ == "__main__":
