@@ -221,7 +221,9 @@ struct View {
   }
   // (address selected, value fixed up afterwards: see mask())
   __device__ __forceinline__ double partial(int x) const {
-    const double p = hdr(x < n ? n : x)->partial;
+    // (a leaf: any 8 bytes that are surely in the L2 -- the leaf table, shared by all replicas)
+    const double* a = x < n ? reinterpret_cast<const double*>(leafmask) : &hdr(x)->partial;
+    const double p = *a;
     return x < n ? 0.0 : p;
   }
   __device__ __forceinline__ int parent(int x) const {
