@@ -1,24 +1,40 @@
 #!/usr/bin/env python3
-"""bench.py -- SA move-evaluations/s of the HIP path on synthetic 3-regular tensor networks.
+"""bench.py -- SA move-evaluations/s of the HIP path on synthetic tensor networks.
 
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
 is launched by torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
 
-A "step" = one launch of the sweep kernel: `--sweeps-per-step` calls of Optimizer::update
-(include/tnco/optimize/infinite_memory/optimizer.hpp:90-221 of the reference) on EVERY replica
-resident on the GPU.  The beta schedule is linear 0 -> 100 over all (W + K) * sweeps_per_step
-sweeps, as tnco/app/infinite_memory/sa.py:147-156 builds it.  Inputs (trees, masks, PRNG state) are
-resident in HBM before the timed region.  Workload at N = 1: BASELINE.json configs[2], the
-configuration the metric is quoted on: 512-leaf random 3-regular TN (bond dim 2), 65536 replicas.
-For N > 1 every rank owns 65536 replicas of the same TN (weak scaling, configs[3] at N = 8);
-the only collective is one RCCL all-reduce(min) of the best cost inside the timed region.
+Headline leg ("im", the line's top-level fields).  A "step" = one launch of the sweep kernel:
+`--sweeps-per-step` calls of Optimizer::update (include/tnco/optimize/infinite_memory/
+optimizer.hpp:90-221 of the reference) on EVERY replica resident on the GPU.  The beta schedule is
+linear 0 -> 100 over all (W + K) * sweeps_per_step sweeps, as tnco/app/infinite_memory/sa.py:147-156
+builds it.  Inputs (trees, masks, PRNG state) are resident in HBM before the timed region.
+Workload at N = 1: BASELINE.json configs[2], the configuration the metric is quoted on: 512-leaf
+random 3-regular TN (bond dim 2), 65536 replicas.  For N > 1 every rank owns 65536 replicas of the
+same TN (weak scaling, configs[3] at N = 8); the only collective is one RCCL all-reduce(min) of the
+best cost inside the timed region.
+
+Second leg ("fw" object of the same line): BASELINE.json configs[4], the memory-constrained
+optimizer (finite_width/greedy/optimizer.hpp:117-390) on a Sycamore-53-style depth-20 circuit
+network, max_width 40, re-slicing every 10 sweeps, 65536 replicas per GPU; a step = one
+tnco_hip_run_fw call of `--sweeps-per-step` sweeps (11 move launches + 10 re-slice launches).
+
+`roofline.traffic` and the request counts are measured in THIS run: after the timed legs, rank 0
+(N = 1 only) re-runs the same command under `rocprofv3 --pmc` as child processes, one pass per
+counter group, and reads the counters of the timed launches (`--pmc 0` skips it; a file under
+profiles/ is used only if it was written for the same library version and workload).
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 from pathlib import Path
 
@@ -27,12 +43,36 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "HBM"
+# Random fabric requests the chip retires per second whatever their size (32 / 64 / 128 B):
+# tools/hbm_random.hip, profiles/r01v7_hbm_random.txt (47-52e9; 47e9 with dependent loads,
+# tools/mem_latency.hip).  The sweep kernels are bound by THIS, not by bytes.
+RANDOM_REQ_PEAK = 47e9
+METRIC = "SA move-evaluations/s (whole node) + best log10(flops) vs ref, 512-leaf TN"
+PMC_GROUPS = (("FETCH_SIZE",), ("WRITE_SIZE",), ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum"),
+              ("TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"))
+FW_MOVE_LAUNCHES = lambda sps, every: (sps + every - 1) // every + 1  # noqa: E731
+FW_RESLICE_LAUNCHES = lambda sps, every: (sps + every - 1) // every   # noqa: E731
 
 
 def algorithmic_bytes_per_move(W: int, a: float, q: float) -> float:
     """B_move = 56W + 80 + a(24W + 64) + 8(2 + q)."""
     return 56 * W + 80 + a * (24 * W + 64) + 8 * (2 + q)
+
+
+def algorithmic_bytes_per_move_fw(W: int, a: float, q: float) -> float:
+    """The same move of the finite-width optimizer: + the slices mask read
+    (8W, finite_width/greedy/optimizer.hpp:177,191-193) + the cached width written on accept (4a, :216)."""
+    return algorithmic_bytes_per_move(W, a, q) + 8 * W + 4 * a
+
+
+def algorithmic_bytes_per_reslice(n: int, W: int) -> float:
+    """One replica's re-slice (greedy/optimizer.hpp:359-376), no caching credit: the width cache
+    (4N) and node links (12 per internal node) read by get_slices' traverse; the CostCache rebuild
+    reads two child masks + two child partial sums and writes (ccost, partial) per internal node.
+    The too-wide tensors' masks (read twice, a data-dependent number) are left out."""
+    N = 2 * n - 1
+    return 4 * N + (n - 1) * (12 + 16 * W + 16 + 16)
 
 
 def usable_cores() -> int:
@@ -58,10 +98,12 @@ def usable_cores() -> int:
     return c
 
 
-def cpu_baseline(prob, links, seeds, betas, n_sample, cores):
-    """The oracle (plain-C port of the reference algorithm) on the host cores, bounded sample.
-
-    Only the update loops are timed (OpenMP over replicas inside oracle/tnco_oracle.c); tree
+# ------------------------------------------------------------------------------------------------
+# CPU baseline legs: the oracle (plain-C restatement of the reference), only here as the checker /
+# the reported baseline -- never on the product path
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline_im(prob, links, seeds, betas, n_sample, cores):
+    """Only the update loops are timed (OpenMP over replicas inside oracle/tnco_oracle.c); tree
     flattening and cache construction are setup, as on the GPU side."""
     from oracle import oracle as orc
     orc.build()
@@ -69,6 +111,189 @@ def cpu_baseline(prob, links, seeds, betas, n_sample, cores):
                                      n_inds=prob.n_inds, dims=2, n_threads=cores)
     moves = int(mv.sum())
     return moves / dt, moves, dt, mn
+
+
+def cpu_baseline_fw(prob, links, seeds, betas, n_sample, cores, max_width, every):
+    """n_sample replicas of the finite-width optimizer through the oracle, one replica per host
+    thread at a time (the C call releases the GIL); only the update loops are timed."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    from tnco_amd import ctree
+    orc.build()
+
+    def make(r):
+        l, rr, p = (np.ascontiguousarray(links[r, j]) for j in range(3))
+        inds = ctree.derive_inds(l, rr, prob.leaf_masks, None)
+        return orc.Oracle(l, rr, p, inds, n_inds=prob.n_inds, dims=2, seed=int(seeds[r]), max_width=max_width)
+
+    def run(o):
+        o.run(orc.PROB_MH, betas, update_slices_every=every)
+        return o.counters()["moves"], o.min_total_cost
+
+    with ThreadPoolExecutor(cores) as ex:
+        states = list(ex.map(make, range(n_sample)))
+        t0 = time.perf_counter()
+        out = list(ex.map(run, states))
+        dt = time.perf_counter() - t0
+    moves = sum(m for m, _ in out)
+    return moves / dt, moves, dt, np.array([c for _, c in out])
+
+
+# ------------------------------------------------------------------------------------------------
+# one timed leg on this rank's GPU
+# ------------------------------------------------------------------------------------------------
+class Leg:
+    def __init__(self, kind, args, rank, world, local_rank):
+        from tnco_amd import core, synthetic
+        self.kind, self.args, self.rank, self.world, self.local_rank = kind, args, rank, world, local_rank
+        R = args.replicas
+        if kind == "im":
+            self.prob = synthetic.regular_problem(args.leaves, graph_seed=args.graph_seed)
+            kw = {}
+        else:
+            self.prob = synthetic.sycamore_problem(args.fw_depth)
+            kw = dict(max_width=args.fw_max_width)
+        all_seeds = synthetic.replica_seeds(R * world, S=0)
+        self.seeds = all_seeds[rank * R:(rank + 1) * R]
+        self.links = core.random_trees(self.prob.ts_inds, self.prob.n_inds, self.seeds)
+        self.sps = args.sweeps_per_step
+        self.total_sweeps = (args.warmup + args.steps) * self.sps
+        self.betas = synthetic.linear_betas(0.0, 100.0, self.total_sweeps)
+        self.opt = core.BatchedOptimizer(self.prob.leaf_masks, self.links, self.seeds, n_inds=self.prob.n_inds,
+                                         dims=2, device=local_rank, **kw)
+
+    def step(self, s):
+        self.opt.run(self.betas[s * self.sps:(s + 1) * self.sps], update_slices_every=self.args.fw_update_slices)
+
+    def run(self, barrier, dist):
+        """W untimed steps, then exactly K timed ones between two barriers; the best-cost reduction
+        (the path's only collective) is inside the timed region."""
+        from tnco_amd import parallel
+        a, opt = self.args, self.opt
+        for s in range(a.warmup):
+            self.step(s)
+        barrier(opt)
+        c0 = opt.counters()
+        opt.kernel_times_ms(reset=True)
+        t0 = time.perf_counter()
+        for s in range(a.warmup, a.warmup + a.steps):
+            self.step(s)
+        best = parallel.global_best(opt, rank=self.rank, world=self.world, device=self.local_rank)
+        barrier(opt)
+        dt = time.perf_counter() - t0
+        c1 = opt.counters()
+        kt = opt.kernel_times_ms()
+        d = {k: c1[k] - c0[k] for k in c1}
+        return dict(dt=dt, best=best, kt=kt, **d)
+
+
+def reduce_legs(res, world, dist, torch):
+    """max over ranks of the times, sum of the work; plus what every rank did (all-gather), so that
+    the line itself shows how many ranks took part."""
+    names = ("sa_run_kernel", "fw_move_kernel", "fw_reslice_kernel")
+    mine = [res["dt"], float(res["moves"]), float(res["accepted"]), float(res["random_picks"]),
+            float(res["improved"]), float(res["full_copies"])] + [res["kt"][k][0] for k in names]
+    per_rank = [mine]
+    if world > 1:
+        t = torch.tensor(mine, dtype=torch.float64).cuda()
+        allv = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allv, t)
+        per_rank = [[float(x) for x in v] for v in allv]
+    arr = np.array(per_rank)
+    out = dict(res)
+    out["dt"] = float(arr[:, 0].max())
+    for j, k in enumerate(("moves", "accepted", "random_picks", "improved", "full_copies")):
+        out[k] = float(arr[:, 1 + j].sum())
+    out["kt"] = {k: (float(arr[:, 6 + j].max()), res["kt"][k][1]) for j, k in enumerate(names)}
+    out["per_rank"] = [dict(rank=i, wall_s=v[0], moves=v[1], kernel_ms=sum(v[6:9])) for i, v in enumerate(per_rank)]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# PMC passes (rank 0, N = 1): the same command under rocprofv3, one child process per counter group
+# ------------------------------------------------------------------------------------------------
+def pmc_passes(args, lib_version):
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = Path(tempfile.mkdtemp(prefix="tnco_pmc_", dir="/tmp"))
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd_tail = [sys.executable, str(ROOT / "bench.py"), "--steps", str(args.steps), "--warmup", str(args.warmup),
+                "--sweeps-per-step", str(args.sweeps_per_step), "--leaves", str(args.leaves),
+                "--replicas", str(args.replicas), "--graph-seed", str(args.graph_seed),
+                "--workload", args.workload, "--fw-max-width", str(args.fw_max_width),
+                "--fw-update-slices", str(args.fw_update_slices), "--fw-depth", str(args.fw_depth),
+                "--cpu-sample", "0", "--pmc", "0"]
+    vals = {}  # (kernel short name, counter) -> per-dispatch values in dispatch order
+    t0 = time.perf_counter()
+    for gi, grp in enumerate(PMC_GROUPS):
+        out = tmp / f"g{gi}"
+        cmd = [exe, "--pmc", *grp, "--kernel-trace", "--output-format", "csv", "-d", str(out), "-o", "pmc", "--", *cmd_tail]
+        try:
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=args.pmc_timeout)
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(tmp, ignore_errors=True)
+            return None, f"rocprofv3 pass {grp} timed out"
+        files = glob.glob(str(out / "**" / "*counter_collection.csv"), recursive=True)
+        if p.returncode != 0 or not files:
+            shutil.rmtree(tmp, ignore_errors=True)
+            return None, f"rocprofv3 pass {grp} failed (rc {p.returncode}): {p.stderr[-300:]}"
+        rows = []
+        for f in files:
+            with open(f) as fh:
+                rows += list(csv.DictReader(fh))
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        for r in rows:
+            name = r["Kernel_Name"]
+            for short in ("sa_run_kernel", "fw_move_kernel", "fw_reslice_kernel"):
+                if short in name:
+                    vals.setdefault((short, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+    shutil.rmtree(tmp, ignore_errors=True)
+    every = args.fw_update_slices
+    per_step = {"sa_run_kernel": 1, "fw_move_kernel": FW_MOVE_LAUNCHES(args.sweeps_per_step, every),
+                "fw_reslice_kernel": FW_RESLICE_LAUNCHES(args.sweeps_per_step, every)}
+    res = {"library": lib_version, "seconds": None, "kernels": {}}
+    for (short, ctr), v in vals.items():
+        n = per_step[short]
+        timed = v[args.warmup * n:(args.warmup + args.steps) * n]  # the timed steps' dispatches
+        if len(timed) != args.steps * n:
+            continue
+        res["kernels"].setdefault(short, {})[ctr] = sum(timed) / args.steps  # per step
+    res["seconds"] = time.perf_counter() - t0
+    return res, None
+
+
+def pmc_from_file(lib_version, key):
+    """profiles/pmc_traffic.json, only when it was taken from the same library and workload."""
+    f = ROOT / "profiles" / "pmc_traffic.json"
+    try:
+        j = json.loads(f.read_text())
+    except (OSError, ValueError):
+        return None
+    if j.get("library") != lib_version or j.get("workload_key") != key:
+        return None
+    return j
+
+
+def traffic_fields(k, moves_per_step, step_s):
+    """From one kernel's per-step counters: HBM bytes with the guide's gfx950 correction
+    (FETCH_SIZE in KiB, tallied at 64 B per 128-B request: x2; WRITE_SIZE in KiB as is), and the
+    fabric request counts the kernel is really bound by."""
+    out = {}
+    if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+        rd_raw, wr = k["FETCH_SIZE"] * 1024.0, k["WRITE_SIZE"] * 1024.0
+        out["traffic"] = 2 * rd_raw + wr
+        out["traffic_raw"] = rd_raw + wr
+        out["traffic_frac"] = out["traffic"] / step_s / 1e9 / HBM_PEAK_GBS
+        out["traffic_frac_raw"] = out["traffic_raw"] / step_s / 1e9 / HBM_PEAK_GBS
+    if "TCC_EA0_RDREQ_sum" in k and "TCC_EA0_WRREQ_sum" in k:
+        rd, wr = k["TCC_EA0_RDREQ_sum"], k["TCC_EA0_WRREQ_sum"]
+        out["requests_per_move"] = {"read": rd / moves_per_step, "write": wr / moves_per_step,
+                                    "read_32B": k.get("TCC_EA0_RDREQ_32B_sum", 0.0) / moves_per_step,
+                                    "write_64B": k.get("TCC_EA0_WRREQ_64B_sum", 0.0) / moves_per_step}
+        out["request_rate"] = (rd + wr) / step_s
+        out["request_rate_frac"] = out["request_rate"] / RANDOM_REQ_PEAK
+    return out
 
 
 def main() -> None:
@@ -80,8 +305,16 @@ def main() -> None:
     ap.add_argument("--leaves", type=int, default=512)
     ap.add_argument("--replicas", type=int, default=65536, help="replicas per GPU")
     ap.add_argument("--graph-seed", type=int, default=11)
+    ap.add_argument("--workload", choices=("both", "im", "fw"), default="both",
+                    help="im: the headline leg only; fw: the finite-width leg as the headline; both: im + 'fw' object")
+    ap.add_argument("--fw-max-width", type=float, default=40.0)
+    ap.add_argument("--fw-update-slices", type=int, default=10)
+    ap.add_argument("--fw-depth", type=int, default=20)
     ap.add_argument("--cpu-sample", type=int, default=-1,
-                    help="replicas timed on the CPU oracle (0 = skip, -1 = as many as take ~15 s)")
+                    help="replicas timed on the CPU oracle (0 = skip, -1 = as many as take ~10-15 s per leg)")
+    ap.add_argument("--pmc", type=int, default=1, help="1: measure HBM traffic / fabric requests under rocprofv3 --pmc (N = 1)")
+    ap.add_argument("--pmc-timeout", type=float, default=240.0)
+    ap.add_argument("--pmc-out", default=None, help="also write the per-step PMC counters of the timed kernels to this file")
     ap.add_argument("--validate", action="store_true", help="device-side is_valid() of every replica after the run")
     args = ap.parse_args()
 
@@ -101,130 +334,162 @@ def main() -> None:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from tnco_amd import core, parallel
-    from tests import helpers as H
+    from tnco_amd import _lib
+    lib_version = _lib.load().tnco_hip_version().decode()
 
-    n, R = args.leaves, args.replicas
-    prob = H.regular_problem(n, graph_seed=args.graph_seed)
-    all_seeds = H.replica_seeds(R * world, S=0)
-    seeds = all_seeds[rank * R:(rank + 1) * R]
-    links = core.random_trees(prob.ts_inds, prob.n_inds, seeds)
-    total_sweeps = (args.warmup + args.steps) * args.sweeps_per_step
-    betas = H.linear_betas(0.0, 100.0, total_sweeps)
-
-    opt = core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, dims=2, device=local_rank)
-    sps = args.sweeps_per_step
-
-    def barrier():
+    def barrier(opt):
         opt.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for s in range(args.warmup):
-        opt.run(betas[s * sps:(s + 1) * sps])
-    barrier()
-    c0 = opt.counters()
-    opt.kernel_time_ms(reset=True)
-    t0 = time.perf_counter()
-    for s in range(args.warmup, args.warmup + args.steps):
-        opt.run(betas[s * sps:(s + 1) * sps])
-    best = parallel.global_best(opt, rank=rank, world=world, device=local_rank)
-    barrier()
-    dt = time.perf_counter() - t0
-    c1 = opt.counters()
-    kernel_ms, launches = opt.kernel_time_ms()
+    legs = {"both": ("im", "fw"), "im": ("im",), "fw": ("fw",)}[args.workload]
+    results, objs = {}, {}
+    for kind in legs:
+        leg = Leg(kind, args, rank, world, local_rank)
+        res = reduce_legs(leg.run(barrier, dist), world, dist, torch)
+        if args.validate:
+            res["n_bad"] = leg.opt.validate()[0]
+        results[kind], objs[kind] = res, leg
+        if not (rank == 0 and world == 1 and args.cpu_sample != 0):
+            leg.opt.close()
+            leg.opt = None
 
-    moves = c1["moves"] - c0["moves"]
-    acc = c1["accepted"] - c0["accepted"]
-    rp = c1["random_picks"] - c0["random_picks"]
-    stats = torch.tensor([dt, float(moves), float(acc), float(rp), kernel_ms], dtype=torch.float64)
-    if world > 1:
-        stats = stats.cuda()
-        tmax = stats[[0, 4]].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tot = stats[1:4].clone()
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dt, kernel_ms = float(tmax[0]), float(tmax[1])
-        moves, acc, rp = (float(x) for x in tot)
-    n_bad = None
-    if args.validate:
-        n_bad = opt.validate()[0]
+    devices = None
+    if world > 1:  # what RCCL saw: one entry per rank
+        props = torch.cuda.get_device_properties(local_rank)
+        me = dict(rank=rank, local_rank=local_rank, device=props.name, uuid=str(getattr(props, "uuid", "")),
+                  backend=dist.get_backend())
+        devices = [None] * world
+        dist.all_gather_object(devices, me)
 
     if rank == 0:
-        a = acc / max(moves, 1)
-        q = rp / max(moves, 1)
-        bmove = algorithmic_bytes_per_move(prob.W, a, q)
-        moves_per_launch_gpu = moves / world / max(launches, 1)
-        avg_launch_s = kernel_ms / 1e3 / max(launches, 1)
-        achieved = bmove * moves_per_launch_gpu / avg_launch_s / 1e9
-        traffic = None
-        pmc = ROOT / "profiles" / "pmc_traffic.json"
-        if pmc.exists():
-            try:
-                traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "SA move-evaluations/s (whole node) + best log10(flops) vs ref, 512-leaf TN",
-            "value": moves / dt,
-            "unit": "move-evals/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {
-                "workload": f"{n}-leaf random 3-regular TN (bond dim 2, {prob.n_inds} indices, "
-                            f"{prob.W} mask words), {R} replicas per GPU, "
-                            f"{sps} SA sweeps per step, beta linear 0->100 over {total_sweeps} sweeps, "
-                            "Metropolis-Hastings, float64 cost",
-                "replicas_total": R * world,
-                "sweeps_per_step": sps,
-                "moves_timed": moves,
-                "accept_rate": a,
-                "random_pick_rate": q,
-                "best_log10_flops": float(np.log10(best)),
-                "improvements_timed": c1["improved"] - c0["improved"],
-                "full_tree_copies_timed": c1["full_copies"] - c0["full_copies"],
-                "validated_bad_replicas": n_bad,
-            },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "kernel": "sa_run_kernel",
-                "algorithmic_bytes_per_move": bmove,
-                "avg_launch_ms": avg_launch_s * 1e3,
-                "launches": launches,
-            },
-        }
-        if args.cpu_sample != 0 and world == 1:
-            cores = usable_cores()
-            if args.cpu_sample > 0:
-                ns = min(args.cpu_sample, R)
-            else:  # auto: a probe sets the sample so that the timed run is ~15 s of CPU work
-                probe = min(256, R)
-                pv, pm, _pt, _ = cpu_baseline(prob, links, seeds, betas, probe, cores)
-                ns = int(min(R, max(probe, 15.0 * pv / (pm / probe))))
-            v, m, t, cpu_min = cpu_baseline(prob, links, seeds, betas, ns, cores)
-            gpu_min = opt.costs()[1][:ns]
-            out["config"]["cpu_sample_min_cost_bit_exact"] = bool(np.array_equal(cpu_min, gpu_min))
-            out["cpu_baseline"] = {
-                "value": v, "unit": "move-evals/s", "cores": cores, "kind": "port",
-                "sample": f"oracle/tnco_oracle.c (plain-C restatement), {ns} of the same replicas, full "
-                          f"{total_sweeps}-sweep schedule each, {cores} threads; {m} moves in {t:.1f} s",
+        R, sps, every = args.replicas, args.sweeps_per_step, args.fw_update_slices
+        key = f"{args.workload}/{args.leaves}/{R}/{sps}/{args.steps}/{args.warmup}/{args.fw_max_width}/{every}/{args.fw_depth}"
+        pmc, pmc_note = None, None
+        if args.pmc and world == 1:
+            for leg in objs.values():  # free the GPU memory of this process first
+                if leg.opt is not None and args.cpu_sample == 0:
+                    leg.opt.close()
+                    leg.opt = None
+            pmc, pmc_note = pmc_passes(args, lib_version)
+            if pmc is not None:
+                pmc["workload_key"] = key
+                if args.pmc_out:
+                    Path(args.pmc_out).write_text(json.dumps(pmc, indent=1) + "\n")
+        if pmc is None and world == 1:
+            pmc = pmc_from_file(lib_version, key)
+            if pmc is not None:
+                pmc_note = "profiles/pmc_traffic.json (same library and workload)"
+
+        def leg_object(kind):
+            res, leg = results[kind], objs[kind]
+            prob = leg.prob
+            moves = res["moves"]
+            a, q = res["accepted"] / max(moves, 1), res["random_picks"] / max(moves, 1)
+            kt = res["kt"]
+            moves_per_step_gpu = moves / world / args.steps
+            if kind == "im":
+                kernels = ("sa_run_kernel",)
+                bmove = algorithmic_bytes_per_move(prob.W, a, q)
+                alg_per_step = bmove * moves_per_step_gpu
+                extra = {"algorithmic_bytes_per_move": bmove}
+            else:
+                kernels = ("fw_move_kernel", "fw_reslice_kernel")
+                bmove = algorithmic_bytes_per_move_fw(prob.W, a, q)
+                bres = algorithmic_bytes_per_reslice(prob.n, prob.W)
+                n_res = FW_RESLICE_LAUNCHES(sps, every) * R
+                alg_per_step = bmove * moves_per_step_gpu + bres * n_res
+                extra = {"algorithmic_bytes_per_move": bmove, "algorithmic_bytes_per_reslice": bres,
+                         "reslices_per_step": n_res}
+            step_ms = sum(kt[k][0] for k in kernels) / args.steps  # device time of one step's kernels
+            achieved = alg_per_step / (step_ms / 1e3) / 1e9
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": max(kernels, key=lambda k: kt[k][0]), "avg_launch_ms": step_ms,
+                    "launches": args.steps, **extra,
+                    "note": "achieved/frac are the contract's ALGORITHMIC bytes (SURVEY 8(d), no caching credit) / "
+                            "device time; traffic_frac (PMC bytes) and request_rate_frac (fabric requests vs the "
+                            "47e9/s random-request ceiling, tools/hbm_random.hip) say what binds the kernel"}
+            roof["kernels"] = {k: {"ms_per_step": kt[k][0] / args.steps, "launches_per_step": kt[k][1] / args.steps}
+                               for k in kernels}
+            if pmc is not None:
+                tot = {}
+                for k in kernels:
+                    kc = pmc["kernels"].get(k)
+                    if not kc:
+                        continue
+                    f = traffic_fields(kc, moves_per_step_gpu, kt[k][0] / args.steps / 1e3)
+                    roof["kernels"][k].update(f)
+                    for c, v in kc.items():
+                        tot[c] = tot.get(c, 0.0) + v
+                roof.update(traffic_fields(tot, moves_per_step_gpu, step_ms / 1e3))
+                roof["traffic_source"] = pmc_note or f"rocprofv3 --pmc child passes of this run ({pmc.get('seconds', 0):.0f} s), {pmc['library']}"
+            else:
+                roof["traffic_source"] = pmc_note
+            obj = {
+                "value": moves / res["dt"], "unit": "move-evals/s", "ms_per_step": res["dt"] / args.steps * 1e3,
+                "config": {
+                    "workload": (f"{prob.n}-leaf random 3-regular TN (bond dim 2, {prob.n_inds} indices, {prob.W} mask words), "
+                                 f"{R} replicas per GPU, {sps} SA sweeps per step, beta linear 0->100 over "
+                                 f"{leg.total_sweeps} sweeps, Metropolis-Hastings, float64 cost") if kind == "im" else
+                                (f"Sycamore-53-style depth-{args.fw_depth} circuit TN ({prob.n} tensors, {prob.n_inds} indices, "
+                                 f"{prob.W} mask words), max_width {args.fw_max_width:g} (float32 width), re-slice every {every} "
+                                 f"sweeps, {R} replicas per GPU, {sps} sweeps per step, beta linear 0->100 over "
+                                 f"{leg.total_sweeps} sweeps, Metropolis-Hastings, float64 cost"),
+                    "replicas_total": R * world, "sweeps_per_step": sps, "moves_timed": moves, "accept_rate": a,
+                    "random_pick_rate": q, "best_log10_flops": float(np.log10(res["best"])),
+                    "improvements_timed": res["improved"], "full_tree_copies_timed": res["full_copies"],
+                    "validated_bad_replicas": res.get("n_bad"), "library": lib_version,
+                },
+                "roofline": roof,
             }
+            if world > 1:
+                obj["config"]["ranks"] = res["per_rank"]
+            if args.cpu_sample != 0 and world == 1:
+                cores = usable_cores()
+                if kind == "im":
+                    fn = lambda ns: cpu_baseline_im(prob, leg.links, leg.seeds, leg.betas, ns, cores)  # noqa: E731
+                    probe, budget = min(256, R), 15.0
+                else:
+                    fn = lambda ns: cpu_baseline_fw(prob, leg.links, leg.seeds, leg.betas, ns, cores,  # noqa: E731
+                                                    args.fw_max_width, every)
+                    probe, budget = min(4 * cores, R), 10.0
+                if args.cpu_sample > 0:
+                    ns = min(args.cpu_sample, R)
+                else:  # auto: a probe sets the sample so that the timed run is ~10-15 s of CPU work
+                    pv, pm, _pt, _ = fn(probe)
+                    ns = int(min(R, max(probe, budget * pv / (pm / probe))))
+                v, m, t, cpu_min = fn(ns)
+                gpu_min = leg.opt.costs()[1][:ns]
+                obj["config"]["cpu_sample_min_cost_bit_exact"] = bool(np.array_equal(cpu_min, gpu_min))
+                obj["cpu_baseline"] = {
+                    "value": v, "unit": "move-evals/s", "cores": cores, "kind": "port",
+                    "sample": f"oracle/tnco_oracle.c (plain-C restatement of the reference's "
+                              f"{'infinite-memory' if kind == 'im' else 'finite-width'} optimizer), {ns} of the same "
+                              f"replicas, full {leg.total_sweeps}-sweep schedule each, {cores} threads; {m} moves in {t:.1f} s",
+                }
+            return obj
+
+        head_kind = legs[0]
+        head = leg_object(head_kind)
+        out = {
+            "metric": METRIC, "value": head["value"], "unit": head["unit"], "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": head["config"],
+            "roofline": head["roofline"],
+        }
+        if "cpu_baseline" in head:
+            out["cpu_baseline"] = head["cpu_baseline"]
+        if devices is not None:
+            out["config"]["devices"] = devices
+        for kind in legs[1:]:
+            out[kind] = leg_object(kind)
         print(json.dumps(out), flush=True)
-    opt.close()
+    for leg in objs.values():
+        if leg.opt is not None:
+            leg.opt.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

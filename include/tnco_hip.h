@@ -85,7 +85,8 @@ typedef struct tnco_hip_desc {
    * finite_width/cost_model/simple.hpp:89-95): active when max_width is finite and >= 0; pass
    * NAN / INFINITY for the infinite-memory optimizer. */
   double max_width;
-  uint64_t max_number_new_slices; /* must be 0 (the only value the reference's app uses) */
+  uint64_t max_number_new_slices; /* finite_width/greedy/optimizer.hpp:226-321 (the reference's app
+                                     always passes 0; any value is implemented) */
   const uint64_t* skip_slices;    /* [W] or NULL */
   const uint64_t* slices;         /* [W] initial slices, or NULL = greedy initial slicing */
 } tnco_hip_desc;
@@ -99,8 +100,10 @@ int tnco_hip_create(const tnco_hip_desc* desc, tnco_hip_handle* out);
 /* Replaces the Python step loop `for beta in betas: prob.beta = beta;
  * opt.update(prob)` (tnco/app/infinite_memory/sa.py:199-209 over
  * Optimizer::update, infinite_memory/optimizer.hpp:90-221): n_steps sweeps on
- * every replica, sweep k using betas[k].  Asynchronous on the handle's stream;
- * any getter synchronises. */
+ * every replica, sweep k using betas[k].  The call first waits for the handle's
+ * previous launch (it re-uses the device copy of `betas`), then enqueues its own
+ * kernels on the handle's stream and returns without waiting for them; any
+ * getter synchronises. */
 int tnco_hip_run(tnco_hip_handle h, int prob_kind, const double* betas, int64_t n_steps);
 
 /* Finite-width twin: `opt.update(prob, update_slices=(n % update_slices_every == 0))` for
@@ -167,9 +170,14 @@ int tnco_hip_get_moves(tnco_hip_handle h, uint64_t* moves_per_replica);
  * handle the slots are [too-wide counts, post-order, get_slices, rebuild + commit, re-slices]. */
 int tnco_hip_get_stage_cycles(tnco_hip_handle h, uint64_t* out5);
 
-/* Device time of the sweep kernel accumulated by tnco_hip_run since the last
- * reset (HIP events on the handle's stream), and number of launches. */
+/* Device time of the kernels launched by tnco_hip_run / tnco_hip_run_fw since the last reset (HIP
+ * events on the handle's stream around every kernel launch), and the number of schedule chunks
+ * launched (one per call unless the schedule is very long). */
 int tnco_hip_kernel_time(tnco_hip_handle h, double* ms, int64_t* launches, int reset);
+/* The same time split by kernel: [0] sa_run_kernel (Optimizer::update, infinite memory),
+ * [1] fw_move_kernel (finite_width/greedy/optimizer.hpp:130-331), [2] fw_reslice_kernel
+ * (:359-389); launches3 = kernel launches of each.  Either array may be NULL. */
+int tnco_hip_kernel_times(tnco_hip_handle h, double* ms3, int64_t* launches3, int reset);
 
 /* Bytes of device memory held by the handle. */
 int64_t tnco_hip_device_bytes(tnco_hip_handle h);

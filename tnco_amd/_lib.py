@@ -49,7 +49,7 @@ EXPORTS = [
     "tnco_hip_create", "tnco_hip_run", "tnco_hip_run_fw", "tnco_hip_get_slices", "tnco_hip_sync", "tnco_hip_get_costs", "tnco_hip_get_tree",
     "tnco_hip_get_caches", "tnco_hip_validate", "tnco_hip_get_prng", "tnco_hip_set_prng",
     "tnco_hip_best", "tnco_hip_get_counters", "tnco_hip_get_moves", "tnco_hip_get_full_copies",
-    "tnco_hip_kernel_time", "tnco_hip_get_stage_cycles",
+    "tnco_hip_kernel_time", "tnco_hip_kernel_times", "tnco_hip_get_stage_cycles",
     "tnco_hip_device_bytes", "tnco_hip_set_stream", "tnco_hip_destroy", "tnco_hip_random_trees",
     "tnco_hip_device_count", "tnco_hip_last_error", "tnco_hip_version",
 ]
@@ -85,6 +85,7 @@ def load() -> C.CDLL:
     L.tnco_hip_get_stage_cycles.argtypes = [vp, vp]
     L.tnco_hip_get_full_copies.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.tnco_hip_kernel_time.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.c_int]
+    L.tnco_hip_kernel_times.argtypes = [vp, vp, vp, C.c_int]
     L.tnco_hip_device_bytes.argtypes = [vp]
     L.tnco_hip_device_bytes.restype = i64
     L.tnco_hip_set_stream.argtypes = [vp, vp]

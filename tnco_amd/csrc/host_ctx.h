@@ -12,7 +12,9 @@
 
 struct EventPair {
   hipEvent_t a, b;
+  int kind;  // TNCO_KIND_*
 };
+enum : int { TNCO_KIND_SWEEP = 0, TNCO_KIND_FW_MOVE = 1, TNCO_KIND_FW_RESLICE = 2, TNCO_KINDS = 3 };
 
 
 struct tnco_hip_ctx {
@@ -31,8 +33,10 @@ struct tnco_hip_ctx {
   double* d_betas = nullptr;
   int64_t betas_cap = 0;
   std::vector<EventPair> pending, free_events;
-  double kernel_ms = 0;
-  int64_t launches = 0;
+  double kernel_ms = 0;   // all kernels of the run calls since the last reset
+  int64_t launches = 0;   // chunks of the schedule launched (one per tnco_hip_run[_fw] call unless very long)
+  double kind_ms[TNCO_KINDS] = {0, 0, 0};     // the same time, per kernel (HIP events around every launch)
+  int64_t kind_launches[TNCO_KINDS] = {0, 0, 0};
 
   template <typename T>
   hipError_t alloc(T** p, int64_t count) {
@@ -46,11 +50,44 @@ struct tnco_hip_ctx {
     }
     return e;
   }
+  // HIP events on the handle's stream around one kernel launch
+  template <typename F>
+  hipError_t timed(int kind, F&& launch) {
+    EventPair ev;
+    if (!free_events.empty()) {
+      ev = free_events.back();
+      free_events.pop_back();
+    } else {
+      hipError_t e = hipEventCreate(&ev.a);
+      if (e != hipSuccess) return e;
+      e = hipEventCreate(&ev.b);
+      if (e != hipSuccess) return e;
+    }
+    ev.kind = kind;
+    hipError_t e = hipEventRecord(ev.a, stream);
+    if (e != hipSuccess) return e;
+    launch();
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = hipEventRecord(ev.b, stream);
+    if (e != hipSuccess) return e;
+    pending.push_back(ev);
+    if (pending.size() > 1024) resolve_events();
+    return hipSuccess;
+  }
+  void reset_times() {
+    kernel_ms = 0;
+    launches = 0;
+    for (int k = 0; k < TNCO_KINDS; ++k) { kind_ms[k] = 0; kind_launches[k] = 0; }
+  }
   void resolve_events() {
     for (auto& ev : pending) {
       float ms = 0;
-      if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess)
+      if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
         kernel_ms += ms;
+        kind_ms[ev.kind] += ms;
+        kind_launches[ev.kind]++;
+      }
       free_events.push_back(ev);
     }
     pending.clear();

@@ -109,8 +109,8 @@ void launch_fw_init(tnco_hip_ctx* h, const FwInitArgs& a) {
 
 // n_steps sweeps of the finite-width optimizer: [moves up to and including the next re-slicing
 // sweep][re-slice] ... [the remaining moves]  (sweep k re-slices when (off + k) % every == 0)
-void launch_fw_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, int64_t off,
-                   int64_t every) {
+hipError_t launch_fw_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, int64_t off,
+                         int64_t every) {
   int64_t cur = 0;
   while (cur < n_steps) {
     int64_t next = n_steps;  // first re-slicing sweep >= cur
@@ -121,16 +121,23 @@ void launch_fw_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int pr
     const bool reslice = next < n_steps;
     const int64_t cnt = (reslice ? next + 1 : n_steps) - cur;
     const int tail_last = reslice ? 0 : 1;
+    hipError_t e = h->timed(TNCO_KIND_FW_MOVE, [&]() {
 #define CALL_FWM(LL, KK) launch_fw_move_lk<LL, KK>(h, betas + cur, cnt, prob_kind, tail_last)
-    DISPATCH_LK(h, CALL_FWM)
+      DISPATCH_LK(h, CALL_FWM)
 #undef CALL_FWM
+    });
+    if (e != hipSuccess) return e;
     if (reslice) {
+      e = h->timed(TNCO_KIND_FW_RESLICE, [&]() {
 #define CALL_FWS(LL, KK) launch_fw_reslice_lk<LL, KK>(h)
-      DISPATCH_LK(h, CALL_FWS)
+        DISPATCH_LK(h, CALL_FWS)
 #undef CALL_FWS
+      });
+      if (e != hipSuccess) return e;
     }
     cur += cnt;
   }
+  return hipSuccess;
 }
 
 // checkpoint := current tree, replica state := fresh
@@ -662,19 +669,7 @@ int tnco_hip_run(tnco_hip_handle h, int prob_kind, const double* betas, int64_t 
   const int64_t max_steps = std::max<int64_t>(1, (int64_t)0xF0000000u / std::max(1, h->P.n));
   for (int64_t s0 = 0; s0 < n_steps; s0 += max_steps) {
     const int64_t cnt = std::min(max_steps, n_steps - s0);
-    EventPair ev;
-    if (!h->free_events.empty()) {
-      ev = h->free_events.back();
-      h->free_events.pop_back();
-    } else {
-      HIP_TRY(hipEventCreate(&ev.a));
-      HIP_TRY(hipEventCreate(&ev.b));
-    }
-    HIP_TRY(hipEventRecord(ev.a, h->stream));
-    launch_run(h, h->d_betas + s0, cnt, prob_kind);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ev.b, h->stream));
-    h->pending.push_back(ev);
+    HIP_TRY(h->timed(TNCO_KIND_SWEEP, [&]() { launch_run(h, h->d_betas + s0, cnt, prob_kind); }));
     h->launches++;
   }
   if (h->pending.size() > 256) h->resolve_events();
@@ -701,19 +696,7 @@ int tnco_hip_run_fw(tnco_hip_handle h, int prob_kind, const double* betas, int64
   const int64_t max_steps = std::max<int64_t>(1, (int64_t)0xF0000000u / std::max(1, h->P.n));
   for (int64_t s0 = 0; s0 < n_steps; s0 += max_steps) {
     const int64_t cnt = std::min(max_steps, n_steps - s0);
-    EventPair ev;
-    if (!h->free_events.empty()) {
-      ev = h->free_events.back();
-      h->free_events.pop_back();
-    } else {
-      HIP_TRY(hipEventCreate(&ev.a));
-      HIP_TRY(hipEventCreate(&ev.b));
-    }
-    HIP_TRY(hipEventRecord(ev.a, h->stream));
-    launch_fw_run(h, h->d_betas + s0, cnt, prob_kind, step_offset + s0, update_slices_every);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ev.b, h->stream));
-    h->pending.push_back(ev);
+    HIP_TRY(launch_fw_run(h, h->d_betas + s0, cnt, prob_kind, step_offset + s0, update_slices_every));
     h->launches++;
   }
   if (h->pending.size() > 256) h->resolve_events();
@@ -741,10 +724,20 @@ int tnco_hip_kernel_time(tnco_hip_handle h, double* ms, int64_t* launches, int r
   h->resolve_events();
   if (ms) *ms = h->kernel_ms;
   if (launches) *launches = h->launches;
-  if (reset) {
-    h->kernel_ms = 0;
-    h->launches = 0;
+  if (reset) h->reset_times();
+  return TNCO_HIP_OK;
+}
+
+int tnco_hip_kernel_times(tnco_hip_handle h, double* ms3, int64_t* launches3, int reset) {
+  if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->resolve_events();
+  for (int k = 0; k < TNCO_KINDS; ++k) {
+    if (ms3) ms3[k] = h->kind_ms[k];
+    if (launches3) launches3[k] = h->kind_launches[k];
   }
+  if (reset) h->reset_times();
   return TNCO_HIP_OK;
 }
 

@@ -11,7 +11,8 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["random_regular_tn", "random_hyper_tn", "chain_tn", "sycamore53_tn"]
+__all__ = ["random_regular_tn", "random_hyper_tn", "chain_tn", "sycamore53_tn", "Problem",
+           "regular_problem", "sycamore_problem", "replica_seeds", "linear_betas"]
 
 
 def _connected(n: int, edges: np.ndarray) -> bool:
@@ -153,3 +154,60 @@ def random_hyper_tn(n: int, n_inds: int, k: int = 3, n_output: int = 0, seed: in
     output = sorted(int(x) for x in rng.choice(n_inds, size=min(n_output, n_inds), replace=False)) if n_output else []
     dims = [int(dims_choices[int(rng.randint(0, len(dims_choices)))]) for _ in range(n_inds)]
     return ts_inds, dims, tuple(output)
+
+
+class Problem:
+    """A synthetic tensor network flattened to bit positions (what `tnco_hip_create` takes)."""
+
+    def __init__(self, ts_inds, dims, output_inds=(), sparse_inds=(), n_inds=None):
+        from . import ctree as ct
+        self.ts_inds = [list(x) for x in ts_inds]
+        self.n = len(self.ts_inds)
+        self.n_inds = (max((max(x) for x in self.ts_inds if x), default=-1) + 1) if n_inds is None else n_inds
+        self.W = ct.n_words(self.n_inds)
+        self.dims = dims
+        self.leaf_masks = ct.pack_masks(self.ts_inds, self.n_inds)
+        self.output_mask = ct.pack_masks([list(output_inds)], self.n_inds)[0]
+        self.sparse_mask = ct.pack_masks([list(sparse_inds)], self.n_inds)[0] if len(sparse_inds) else None
+        self.holders = [[] for _ in range(self.n_inds)]
+        for t, xs in enumerate(self.ts_inds):
+            for i in xs:
+                self.holders[i].append(t)
+
+    def tree(self, seed):
+        """Python spec of the native initial-tree generator (random Kruskal order)."""
+        from . import ctree as ct
+        con = ct.random_contraction(self.holders, self.n, seed=int(seed) & 0xFFFFFFFF)
+        return ct.tree_from_contraction(con, self.n)
+
+    def links(self, seeds):
+        out = np.empty((len(seeds), 3, 2 * self.n - 1), np.int32)
+        for k, s in enumerate(seeds):
+            out[k, 0], out[k, 1], out[k, 2] = self.tree(s)
+        return out
+
+    def node_masks(self, left, right):
+        from . import ctree as ct
+        return ct.derive_inds(left, right, self.leaf_masks, self.output_mask)
+
+
+def regular_problem(n, graph_seed, degree=3):
+    ts, d, out = random_regular_tn(n, degree, graph_seed)
+    return Problem(ts, d, out)
+
+
+def sycamore_problem(depth=20):
+    ts, d, out = sycamore53_tn(depth)
+    return Problem(ts, d, out)
+
+
+def replica_seeds(R, S=0):
+    """seeds = Random(S).choices(range(2**32), k=R) -- tnco/app/infinite_memory/sa.py:237."""
+    import random
+    return random.Random(S).choices(range(2**32), k=R)
+
+
+def linear_betas(b0, b1, n_steps):
+    """more_itertools.numeric_range(b0, b1, (b1-b0)/n_steps): b0 + k*step (sa.py:155)."""
+    step = (b1 - b0) / n_steps
+    return np.array([b0 + k * step for k in range(n_steps)], np.float64)
