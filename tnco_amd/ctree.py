@@ -221,6 +221,163 @@ def random_contraction(holders: Sequence[Sequence[int]], n_tensors: int, seed: i
     return out
 
 
+def ssa_greedy(inputs: Sequence[frozenset], output: frozenset) -> list[tuple[int, int]]:
+    """opt_einsum's greedy path finder on index sets of dimension 2, SSA form.
+
+    The reference gets its initial path from `oe.contract_path(subscripts, *shapes, shapes=True,
+    optimize='greedy')` with every shape (2,) * rank (tnco/utils/tn.py:197-216).  opt_einsum is a
+    third-party dependency that is NOT pinned by the reference (pyproject.toml:55) and is absent
+    from this image, so this is a restatement of its published algorithm (opt_einsum 3.3/3.4
+    `paths.ssa_greedy_optimize` with `choose_fn=_simple_chooser`, `cost_fn='memory-removed'`):
+    **parity unpinned** -- it cannot be checked against opt_einsum here.
+
+    1. dims common to all inputs join the output; inputs with identical index sets are multiplied
+       eagerly (keys of `remaining` are the index SETS);
+    2. candidates (cost, k1, k2, k12) with cost = (size(k12) - size(k1) - size(k2), id2, id1),
+       id1 < id2 the ssa ids at push time; k12 = (either & output) | (two & dims held by >= 3
+       keys) | (one & dims held by >= 2 keys); per new tensor only the cheapest candidate among its
+       neighbours is pushed; a popped candidate is obsolete when one of its keys is gone;
+    3. what is left is combined by outer products, smallest output size first.
+    The native batched twin is csrc/host_trees.cpp (mode TNCO_HIP_TREES_GREEDY), tested equal.
+    """
+    import heapq
+    import itertools
+    if len(inputs) == 1:
+        return []
+    fs_inputs = [frozenset(x) for x in inputs]
+    output = frozenset(output) | frozenset.intersection(*fs_inputs)
+    size = lambda key: 1 << len(key)  # noqa: E731  (every dimension is 2)
+
+    remaining: dict[frozenset, int] = {}
+    ssa_ids = itertools.count(len(fs_inputs))
+    ssa_path = []
+    for ssa_id, key in enumerate(fs_inputs):
+        if key in remaining:
+            ssa_path.append((remaining[key], ssa_id))
+            remaining[key] = next(ssa_ids)
+        else:
+            remaining[key] = ssa_id
+
+    dim_to_keys: dict[Any, set] = {}
+    for key in remaining:
+        for dim in key - output:
+            dim_to_keys.setdefault(dim, set()).add(key)
+    ref = {c: set(d for d, keys in dim_to_keys.items() if len(keys) >= c) - output for c in (2, 3)}
+    footprints = {key: size(key) for key in remaining}
+
+    def candidate(k1, k2):
+        either, two = k1 | k2, k1 & k2
+        one = either - two
+        k12 = (either & output) | (two & ref[3]) | (one & ref[2])
+        cost = size(k12) - footprints[k1] - footprints[k2]
+        id1, id2 = remaining[k1], remaining[k2]
+        if id1 > id2:
+            k1, id1, k2, id2 = k2, id2, k1, id1
+        return (cost, id2, id1), k1, k2, k12
+
+    def push(k1, k2s, queue):
+        # (min over the cost triples: they are distinct, so no index set is ever compared)
+        heapq.heappush(queue, _Cand(min((candidate(k1, k2) for k2 in k2s), key=lambda c: c[0])))
+
+    queue: list = []
+    for dim, dim_keys in dim_to_keys.items():
+        lst = sorted(dim_keys, key=remaining.__getitem__)
+        for i, k1 in enumerate(lst[:-1]):
+            push(k1, lst[1 + i:], queue)
+
+    while queue:
+        _cost, k1, k2, k12 = heapq.heappop(queue).c
+        if k1 not in remaining or k2 not in remaining:
+            continue
+        id1, id2 = remaining.pop(k1), remaining.pop(k2)
+        for dim in k1 - output:
+            dim_to_keys[dim].remove(k1)
+        for dim in k2 - output:
+            dim_to_keys[dim].remove(k2)
+        ssa_path.append((id1, id2))
+        if k12 in remaining:
+            ssa_path.append((remaining[k12], next(ssa_ids)))
+        else:
+            for dim in k12 - output:
+                dim_to_keys.setdefault(dim, set()).add(k12)
+        remaining[k12] = next(ssa_ids)
+        for dim in k1 | k2 - output:  # (sic: k1 | (k2 - output), as published)
+            count = len(dim_to_keys.get(dim, ()))
+            if count <= 1:
+                ref[2].discard(dim)
+                ref[3].discard(dim)
+            elif count == 2:
+                ref[2].add(dim)
+                ref[3].discard(dim)
+            else:
+                ref[2].add(dim)
+                ref[3].add(dim)
+        footprints[k12] = size(k12)
+        k2s = set(k2 for dim in k12 - output for k2 in dim_to_keys[dim])
+        k2s.discard(k12)
+        if k2s:
+            push(k12, k2s, queue)
+
+    heap = [(size(key & output), ssa_id, key) for key, ssa_id in remaining.items()]
+    heap = [_Cand(x) for x in heap]
+    heapq.heapify(heap)
+    _, id1, k1 = heapq.heappop(heap).c
+    while heap:
+        _, id2, k2 = heapq.heappop(heap).c
+        ssa_path.append((min(id1, id2), max(id1, id2)))
+        k12 = (k1 | k2) & output
+        _, id1, k1 = heapq.heappushpop(heap, _Cand((size(k12), next(ssa_ids), k12))).c
+    return ssa_path
+
+
+class _Cand:
+    """Heap entry ordered by its leading fields only: opt_einsum compares whole tuples, whose
+    leading (cost, id2, id1) / (size, ssa id) fields are distinct for distinct contractions; equal
+    ones are the same contraction pushed twice, and then the order does not matter."""
+    __slots__ = ("c",)
+
+    def __init__(self, c):
+        self.c = c
+
+    def __lt__(self, other):
+        a, b = self.c, other.c
+        return (a[0], a[1]) < (b[0], b[1]) if not isinstance(a[0], tuple) else a[0] < b[0]
+
+
+def greedy_contraction(leaf_positions: Sequence[Sequence[int]], output_positions: Iterable[int], seed: int,
+                       rng=None):
+    """Initial contraction of one connected component as the reference draws it
+    (tnco/utils/tn.py:189-230): `Random(seed).shuffle` of the component's tensors, opt_einsum's
+    greedy on the shuffled list with every dimension 2, back to tensor ids.
+
+    Args:
+        leaf_positions: index positions of the component's tensors, in ascending tensor order.
+        output_positions: output indices that survive the reference's filter (held by at most one
+            tensor, tn.py:175-178); the others are contractible edges.
+        seed: the run's seed (also the optimizer's, sa.py:176,193).
+        rng: a `random.Random` already advanced by the components before this one (the reference
+            shares ONE generator over the components, tn.py:163,192); default `Random(seed)`.
+    Returns:
+        SSA triples (child0, child1, new) with child0 < child1, leaves 0..n-1.
+    """
+    from random import Random
+    n = len(leaf_positions)
+    if rng is None:
+        rng = Random(seed)
+    order = list(range(n))
+    rng.shuffle(order)
+    inputs = [frozenset(leaf_positions[t]) for t in order]
+    out = frozenset(output_positions) & frozenset().union(*inputs) if inputs else frozenset()
+    if n == 2 or (n > 2 and frozenset().union(*inputs) == out):
+        ssa = [(0, 1)] if n == 2 else None  # contract_path short-cuts (<= 2 operands / nothing to sum)
+        if ssa is None:
+            raise NotImplementedError("all indices are output indices: a single n-ary contraction in opt_einsum.")
+    else:
+        ssa = ssa_greedy(inputs, out)
+    node = lambda x: order[x] if x < n else x  # noqa: E731
+    return [(min(node(a), node(b)), max(node(a), node(b)), n + s) for s, (a, b) in enumerate(ssa)]
+
+
 class ContractionTree:
     """Flattened contraction tree (host mirror of tnco.ctree.ContractionTree).
 
