@@ -116,6 +116,10 @@ int tnco_hip_run_fw(tnco_hip_handle h, int prob_kind, const double* betas, int64
  * words each; either may be NULL. */
 int tnco_hip_get_slices(tnco_hip_handle h, int64_t replica, uint64_t* slices, uint64_t* min_slices);
 
+/* The same for k replicas at once: slices / min_slices [k][W] (either may be NULL). */
+int tnco_hip_get_slices_many(tnco_hip_handle h, int64_t k, const int64_t* replicas, uint64_t* slices,
+                             uint64_t* min_slices);
+
 int tnco_hip_sync(tnco_hip_handle h);
 
 /* total_cost / min_total_cost properties (optimizer.hpp:253-257) of every
@@ -148,8 +152,25 @@ int tnco_hip_set_prng(tnco_hip_handle h, int64_t replica, const uint32_t* state6
 
 /* The k replicas of lowest min_total_cost, ascending, ties by replica id
  * (replaces `sorted(results)` of tnco/app/infinite_memory/sa.py:257 for the
- * head of the list). */
+ * head of the list).  k <= 2048: selected on the device (per-block bitonic sort + merge passes),
+ * only the k pairs are copied back; longer heads sort the replica records on the host. */
 int tnco_hip_best(tnco_hip_handle h, int64_t k, double* costs, int64_t* replicas);
+/* min over the replicas of min_total_cost, reduced on the device into *device_dst_f64 (device
+ * memory, e.g. a torch tensor's storage): the operand of the RCCL all-reduce(min) that replaces
+ * the `sorted(results)[0]` of sa.py:257 across GPUs -- no host round trip. */
+int tnco_hip_min_cost_device(tnco_hip_handle h, void* device_dst_f64);
+/* ctree / min_ctree (optimize/optimizer.hpp:207-208) of k replicas in ONE buffer, and
+ * get_contraction (include/tnco/utils.hpp:53-71) of each, computed on the device:
+ * links [k][3][N] (left, right, parent); contraction [k][n_leaves-1][3] = (child0, child1, node)
+ * per internal node in the post-order of utils.hpp:34-51, or NULL. */
+int tnco_hip_get_trees(tnco_hip_handle h, int64_t k, const int64_t* replicas, int which, int32_t* links,
+                       int32_t* contraction);
+/* ContractionTree.path() (tnco/ctree.py:350-388) for k contractions of one component (host code):
+ * tensors_pos[nc] = ascending positions of the component's tensors among all n_tensors
+ * (`_tensors_pos`, ctree.py:128-132); contraction as tnco_hip_get_trees returns it; paths
+ * [k][nc-1][2] linear (einsum) format, operand positions in the order (child0, child1). */
+int tnco_hip_linear_paths(int32_t n_tensors, int32_t nc, const int32_t* tensors_pos, int64_t k,
+                          const int32_t* contraction, int32_t* paths, int32_t n_threads);
 
 /* Work counters summed over replicas: move evaluations (iterations of the
  * while loop at optimizer.hpp:117-192), accepted moves, best-tree updates, and
@@ -199,6 +220,19 @@ void tnco_hip_destroy(tnco_hip_handle h);
 int tnco_hip_random_trees(int32_t n_leaves, int32_t n_inds, const int32_t* holders_off,
                           const int32_t* holders, int64_t n_replicas, const uint32_t* seeds,
                           int32_t* links_out, int32_t n_threads);
+
+/* The same batch as the REFERENCE draws it (tnco/utils/tn.py:189-230): CPython's
+ * Random(seed).shuffle of the component's tensors, then opt_einsum's greedy path finder with every
+ * dimension 2 (restated: opt_einsum is not pinned by the reference and absent here -- "parity
+ * unpinned"; spec in tnco_amd/ctree.py greedy_contraction).  output_mask ([W] or NULL): the output
+ * indices held by at most one tensor (tn.py:175-178 drops the others).  draws ([n_replicas] or
+ * NULL): in = 32-bit outputs of Random(seed) already consumed by earlier components of the same run
+ * (the reference shares one generator over the components, tn.py:163), out = consumed after this
+ * one. */
+int tnco_hip_greedy_trees(int32_t n_leaves, int32_t n_inds, const int32_t* holders_off,
+                          const int32_t* holders, const uint64_t* output_mask, int64_t n_replicas,
+                          const uint32_t* seeds, uint64_t* draws, int32_t* links_out,
+                          int32_t n_threads);
 
 int tnco_hip_device_count(void);
 const char* tnco_hip_last_error(void);

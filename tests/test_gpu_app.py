@@ -56,12 +56,14 @@ def test_readme_chain_config1():
     assert res[0].cost == Decimal(10)
 
 
-def test_results_match_oracle_run_by_run(oracle_lib):
+@pytest.mark.parametrize("initial_trees", ["greedy", "kruskal"])
+def test_results_match_oracle_run_by_run(oracle_lib, initial_trees):
     ts, dims, out = __import__("tnco_amd.synthetic", fromlist=["x"]).random_regular_tn(24, 3, 5)
     spec = [(2, *[f"t{t}" for t in range(len(ts)) if k in ts[t]]) for k in range(36)]
     opt = Optimizer(method="sa", seed=11)
     n_runs, n_steps = 12, 150
-    tn, res = opt.optimize(spec, betas=(0, 50), n_steps=n_steps, n_runs=n_runs, fuse=None)
+    tn, res = opt.optimize(spec, betas=(0, 50), n_steps=n_steps, n_runs=n_runs, fuse=None,
+                           initial_trees=initial_trees)
     seeds = random.Random(11).choices(range(2**32), k=n_runs)
     betas = expand_betas((0, 50), n_steps)
     # bit position of an index = order of first appearance over the tensors (tnco/ctree.py:232,
@@ -70,7 +72,10 @@ def test_results_match_oracle_run_by_run(oracle_lib):
     prob = H.Problem([[imap[i] for i in xs] for xs in tn.ts_inds], 2)
     want = []
     for s in seeds:
-        l, r, p = prob.tree(s)
+        if initial_trees == "greedy":  # the reference's recipe (tnco/utils/tn.py:189-230), Python spec
+            l, r, p = ct.tree_from_contraction(ct.greedy_contraction(prob.ts_inds, (), s), prob.n)
+        else:
+            l, r, p = prob.tree(s)
         o = H.make_oracle(oracle_lib, prob, (l, r, p), s)
         o.run(oracle_lib.PROB_MH, betas)
         ml, mr, _mp, _ = o.tree(which_min=True)
@@ -82,6 +87,30 @@ def test_results_match_oracle_run_by_run(oracle_lib):
     for r in res:  # one component: the merged path is the component's path with sorted pairs
         assert [tuple(p) for p in r.path] == [tuple(sorted(p)) for p in r.disconnected_paths[0]]
     assert float(res[0].cost) <= float(tn.tags["best_raw_cost"]) * (1 + 1e-5)
+
+
+def test_full_head_of_1024_runs_matches_the_oracle(oracle_lib):
+    """`optimize(n_runs=1024)` returns all 1024 runs (top_k defaults to min(n_runs, 1024)): costs and
+    paths of the whole list, assembled from the device-side extraction, against 1024 oracle runs."""
+    ts, dims, out = __import__("tnco_amd.synthetic", fromlist=["x"]).random_regular_tn(14, 3, 2)
+    spec = [(2, *[f"t{t}" for t in range(len(ts)) if k in ts[t]]) for k in range(21)]
+    n_runs, n_steps = 1024, 40
+    tn, res = Optimizer(method="sa", seed=5).optimize(spec, betas=(0, 20), n_steps=n_steps, n_runs=n_runs, fuse=None)
+    assert len(res) == n_runs
+    seeds = random.Random(5).choices(range(2**32), k=n_runs)
+    betas = expand_betas((0, 20), n_steps)
+    imap = {x: k for k, x in enumerate(dict.fromkeys(i for xs in tn.ts_inds for i in xs))}
+    prob = H.Problem([[imap[i] for i in xs] for xs in tn.ts_inds], 2)
+    want = []
+    for gid, s in enumerate(seeds):
+        l, r, p = ct.tree_from_contraction(ct.greedy_contraction(prob.ts_inds, (), s), prob.n)
+        o = H.make_oracle(oracle_lib, prob, (l, r, p), s)
+        o.run(oracle_lib.PROB_MH, betas)
+        ml, mr, _mp, _ = o.tree(which_min=True)
+        want.append((Decimal("%g" % o.min_total_cost), gid, ct.ssa_to_linear(ct.get_contraction(ml, mr), len(ts))))
+    want.sort(key=lambda t: (t[0], t[1]))  # sorted(results) is stable over the run order (sa.py:257)
+    assert [r.cost for r in res] == [w[0] for w in want]
+    assert [[tuple(p) for p in r.disconnected_paths[0]] for r in res] == [[tuple(p) for p in w[2]] for w in want]
 
 
 def test_disconnected_components_and_json():

@@ -46,11 +46,11 @@ class Desc(C.Structure):
 
 
 EXPORTS = [
-    "tnco_hip_create", "tnco_hip_run", "tnco_hip_run_fw", "tnco_hip_get_slices", "tnco_hip_sync", "tnco_hip_get_costs", "tnco_hip_get_tree",
+    "tnco_hip_create", "tnco_hip_run", "tnco_hip_run_fw", "tnco_hip_get_slices", "tnco_hip_get_slices_many", "tnco_hip_sync", "tnco_hip_get_costs", "tnco_hip_get_tree",
     "tnco_hip_get_caches", "tnco_hip_validate", "tnco_hip_get_prng", "tnco_hip_set_prng",
-    "tnco_hip_best", "tnco_hip_get_counters", "tnco_hip_get_moves", "tnco_hip_get_full_copies",
+    "tnco_hip_best", "tnco_hip_min_cost_device", "tnco_hip_get_trees", "tnco_hip_linear_paths", "tnco_hip_get_counters", "tnco_hip_get_moves", "tnco_hip_get_full_copies",
     "tnco_hip_kernel_time", "tnco_hip_kernel_times", "tnco_hip_get_stage_cycles",
-    "tnco_hip_device_bytes", "tnco_hip_set_stream", "tnco_hip_destroy", "tnco_hip_random_trees",
+    "tnco_hip_device_bytes", "tnco_hip_set_stream", "tnco_hip_destroy", "tnco_hip_random_trees", "tnco_hip_greedy_trees",
     "tnco_hip_device_count", "tnco_hip_last_error", "tnco_hip_version",
 ]
 
@@ -72,6 +72,7 @@ def load() -> C.CDLL:
     L.tnco_hip_run.argtypes = [vp, C.c_int, vp, i64]
     L.tnco_hip_run_fw.argtypes = [vp, C.c_int, vp, i64, i64, i64]
     L.tnco_hip_get_slices.argtypes = [vp, i64, vp, vp]
+    L.tnco_hip_get_slices_many.argtypes = [vp, i64, vp, vp, vp]
     L.tnco_hip_sync.argtypes = [vp]
     L.tnco_hip_get_costs.argtypes = [vp, vp, vp]
     L.tnco_hip_get_tree.argtypes = [vp, i64, C.c_int, vp, vp, vp, vp]
@@ -80,6 +81,9 @@ def load() -> C.CDLL:
     L.tnco_hip_get_prng.argtypes = [vp, i64, vp]
     L.tnco_hip_set_prng.argtypes = [vp, i64, vp]
     L.tnco_hip_best.argtypes = [vp, i64, vp, vp]
+    L.tnco_hip_min_cost_device.argtypes = [vp, vp]
+    L.tnco_hip_get_trees.argtypes = [vp, i64, vp, C.c_int, vp, vp]
+    L.tnco_hip_linear_paths.argtypes = [i32, i32, vp, i64, vp, vp, i32]
     L.tnco_hip_get_counters.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4
     L.tnco_hip_get_moves.argtypes = [vp, vp]
     L.tnco_hip_get_stage_cycles.argtypes = [vp, vp]
@@ -92,6 +96,7 @@ def load() -> C.CDLL:
     L.tnco_hip_destroy.argtypes = [vp]
     L.tnco_hip_destroy.restype = None
     L.tnco_hip_random_trees.argtypes = [i32, i32, vp, vp, i64, vp, vp, i32]
+    L.tnco_hip_greedy_trees.argtypes = [i32, i32, vp, vp, vp, i64, vp, vp, vp, i32]
     L.tnco_hip_device_count.restype = C.c_int
     L.tnco_hip_last_error.restype = C.c_char_p
     L.tnco_hip_version.restype = C.c_char_p

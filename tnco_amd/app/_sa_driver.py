@@ -109,10 +109,12 @@ class _Component:
 
 
 def run_sa(opt, tn, betas, n_steps, n_runs, n_projs, timeout, *, top_k, sweeps_per_launch, prob, device,
-           update_slices: int | None):
+           update_slices: int | None, initial_trees: str = "greedy"):
     """Returns (tn, merged) with merged = [(cost, global run id, per-component costs, per-component
     paths, per-component slices | None)] sorted, the `top_k` best runs over all ranks."""
     finite = update_slices is not None
+    if initial_trees not in ("greedy", "kruskal"):
+        raise ValueError("'initial_trees' must be 'greedy' or 'kruskal'.")
     betas = expand_betas(betas, n_steps)
     n_runs = int(n_runs)
     if n_runs <= 0:
@@ -134,11 +136,24 @@ def run_sa(opt, tn, betas, n_steps, n_runs, n_projs, timeout, *, top_k, sweeps_p
     handles = []
     t0 = perf_counter()
     timed_out = False
+    # outputs of Random(seed) consumed so far by every run: the reference shares one generator over
+    # the components of a run (tnco/utils/tn.py:163,192)
+    draws = np.zeros(n_local, np.uint64)
+    n_holders = {}
+    for xs in tn.ts_inds:
+        for i in xs:
+            n_holders[i] = n_holders.get(i, 0) + 1
     for ci, comp in enumerate(comps):
         if len(comp.tensors) <= 1 or n_local == 0:  # `if not path`, sa.py:179-183
             handles.append(None)
             continue
-        links = core.random_trees(comp.leaf_positions, comp.n_inds, my_seeds)
+        if initial_trees == "greedy":
+            # tn.py:175-178: an output index held by two or more tensors is a contractible edge
+            keep = [k for k, x in enumerate(comp.inds_order) if x in tn.output_inds and n_holders.get(x, 0) <= 1]
+            links = core.greedy_trees(comp.leaf_positions, comp.n_inds, my_seeds,
+                                      output_mask=pack_masks([keep], comp.n_inds)[0], draws=draws)
+        else:
+            links = core.random_trees(comp.leaf_positions, comp.n_inds, my_seeds)
         kw = dict(max_width=opt.max_width, width_type=opt.width_type) if finite else {}
         h = core.BatchedOptimizer(comp.leaf_masks, links, my_seeds, n_inds=comp.n_inds, dims=comp.dims,
                                   output_mask=comp.output_mask, sparse_mask=comp.sparse_mask,
@@ -154,24 +169,42 @@ def run_sa(opt, tn, betas, n_steps, n_runs, n_projs, timeout, *, top_k, sweeps_p
         handles.append(h)
     runtime = perf_counter() - t0
 
-    # cost of a run = sum of the per-component Decimals (sa.py:215-218)
-    dec = [[cost_to_decimal(raw_cost[r, ci]) if handles[ci] is not None else 0 for ci in range(len(comps))]
-           for r in range(n_local)]
-    totals = [sum(d) for d in dec]
-    order = sorted(range(n_local), key=lambda r: (totals[r], lo + r))[:top_k]
+    # cost of a run = sum of the per-component Decimals (sa.py:215-218), which carry 6 significant
+    # digits: the head of `sorted(results)` (sa.py:257) by (Decimal total, run id) can only hold runs
+    # whose raw total is within 2e-5 of the top_k-th smallest raw total, so only those few are
+    # turned into Decimals and sorted exactly
+    live = [ci for ci, h in enumerate(handles) if h is not None]
+    raw_total = raw_cost.sum(axis=1)
+    if n_local > top_k:
+        kth = np.partition(raw_total, top_k - 1)[top_k - 1]
+        cand = np.nonzero(raw_total <= kth * (1 + 2e-5))[0]
+    else:
+        cand = np.arange(n_local)
+    dec = {int(r): [cost_to_decimal(raw_cost[r, ci]) if handles[ci] is not None else 0 for ci in range(len(comps))]
+           for r in cand}
+    totals = {r: sum(d) for r, d in dec.items()}
+    order = sorted(dec, key=lambda r: (totals[r], lo + r))[:top_k]
+    # best trees of the head: one device pass + one copy back per component (materialised from the
+    # checkpoint + rotation log, post-order get_contraction on the device), then path() natively
+    paths_by_comp, slices_by_comp = {}, {}
+    for ci in live:
+        comp, h = comps[ci], handles[ci]
+        _links, con = h.trees(order, which_min=True)
+        paths_by_comp[ci] = core.linear_paths(con, comp.tensors, len(tn)).tolist()
+        if finite:
+            slices_by_comp[ci] = h.slices_many(order)[1]
     local = []
-    for r in order:
+    for j, r in enumerate(order):
         paths, slices = [], []
         for ci, comp in enumerate(comps):
             if handles[ci] is None:
                 paths.append([])
                 slices.append(frozenset())
             else:
-                l, rr, _p, _m = handles[ci].tree(r, which_min=True, with_masks=False)
-                paths.append(comp.path(l, rr, len(tn)))
-                slices.append(comp.names(handles[ci].slices(r)[1]) if finite else frozenset())
+                paths.append([tuple(p) for p in paths_by_comp[ci][j]])
+                slices.append(comp.names(slices_by_comp[ci][j]) if finite else frozenset())
         local.append((totals[r], lo + r, dec[r], paths, slices))
-    best_raw = float(raw_cost.sum(axis=1).min()) if n_local else float("inf")
+    best_raw = float(raw_total.min()) if n_local else float("inf")
     for h in handles:
         if h is not None:
             h.close()

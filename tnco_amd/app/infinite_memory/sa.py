@@ -2,8 +2,10 @@
 
 Host mirror of /root/reference/tnco/app/infinite_memory/sa.py:63-257; the driver itself is
 tnco_amd/app/_sa_driver.py.  Differences a caller can observe:
-  * the initial tree of a run comes from this build's generator, not opt_einsum's greedy
-    (third-party, unpinned in the reference);
+  * the initial tree of a run is drawn as the reference draws it (Random(seed).shuffle of the tensors +
+    opt_einsum's greedy, restated in csrc/host_greedy.cpp: opt_einsum is third-party and unpinned in
+    the reference, so this stays "parity unpinned"); `initial_trees='kruskal'` selects the build's own
+    random-Kruskal generator instead;
   * `load_tn` takes index lists only (no circuits, no arrays); pre-fusing (`fuse`, default 4) is this
     build's restatement of tnco/utils/tn.py:598-824;
   * only the `top_k` best runs (default min(n_runs, 1024)) are materialised as results.
@@ -43,11 +45,11 @@ class Optimizer(BaseOptimizer):
     def optimize(self, tn: Any, betas, n_steps: int | None = None, n_runs: int = 1,
                  n_projs: int | None = None, timeout: float | None = None, *, top_k: int | None = None,
                  sweeps_per_launch: int = 100, prob: str = "mh", device: int | None = None,
-                 **load_tn_options) -> Any:
+                 initial_trees: str = "greedy", **load_tn_options) -> Any:
         tn = self._load_tn(tn, **load_tn_options)
         merged, runtime = run_sa(self, tn, betas, n_steps, n_runs, n_projs, timeout, top_k=top_k,
                                  sweeps_per_launch=sweeps_per_launch, prob=prob, device=device,
-                                 update_slices=None)
+                                 update_slices=None, initial_trees=initial_trees)
         results = [ContractionResults(cost=c, runtime_s=runtime, path=merge_contraction_paths(len(tn), paths),
                                       disconnected_costs=list(dc), disconnected_paths=paths)
                    for c, _gid, dc, paths, _sl in merged]

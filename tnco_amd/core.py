@@ -13,7 +13,7 @@ import numpy as np
 from . import _lib
 from .ctree import n_words
 
-__all__ = ["BatchedOptimizer", "random_trees", "PROB_BASE", "PROB_GREEDY", "PROB_MH"]
+__all__ = ["BatchedOptimizer", "random_trees", "greedy_trees", "linear_paths", "PROB_BASE", "PROB_GREEDY", "PROB_MH"]
 
 PROB_BASE, PROB_GREEDY, PROB_MH = _lib.PROB_BASE, _lib.PROB_GREEDY, _lib.PROB_MH
 _PROB = {"base": PROB_BASE, "greedy": PROB_GREEDY, "mh": PROB_MH,
@@ -53,6 +53,41 @@ def random_trees(leaf_positions, n_inds: int, seeds, n_threads: int = 0) -> np.n
     rc = L.tnco_hip_random_trees(n, n_inds, _ptr(off), _ptr(hold), len(seeds), _ptr(seeds), _ptr(out), n_threads)
     if rc:
         raise ValueError("tensor network component is not connected.")
+    return out
+
+
+def greedy_trees(leaf_positions, n_inds: int, seeds, output_mask=None, draws=None, n_threads: int = 0) -> np.ndarray:
+    """Initial trees as the reference draws them (Random(seed).shuffle + opt_einsum's greedy,
+    tnco/utils/tn.py:189-230) for one connected component: links[R, 3, N].
+
+    Native batched twin of ctree.greedy_contraction (csrc/host_greedy.cpp).  `draws` (uint64[R],
+    updated in place): outputs of Random(seed) consumed by the components before this one."""
+    L = _lib.load()
+    n = len(leaf_positions)
+    off, hold = holders_csr(leaf_positions, n_inds)
+    seeds = np.ascontiguousarray(np.asarray(seeds, np.uint64) & np.uint64(0xFFFFFFFF), np.uint32)
+    om = None if output_mask is None else np.ascontiguousarray(output_mask, np.uint64)
+    if draws is not None and (draws.dtype != np.uint64 or draws.shape != (len(seeds),) or not draws.flags.c_contiguous):
+        raise ValueError("'draws' must be a contiguous uint64 array with one entry per seed.")
+    out = np.empty((len(seeds), 3, 2 * n - 1), np.int32)
+    rc = L.tnco_hip_greedy_trees(n, n_inds, _ptr(off), _ptr(hold), _ptr(om), len(seeds), _ptr(seeds),
+                                 _ptr(draws), _ptr(out), n_threads)
+    if rc:
+        raise ValueError("greedy initial contraction failed (component not connected?).")
+    return out
+
+
+def linear_paths(contraction, tensors_pos, n_tensors: int, n_threads: int = 0) -> np.ndarray:
+    """ContractionTree.path() (tnco/ctree.py:350-388) of k contractions [k, nc-1, 3] -> [k, nc-1, 2]."""
+    L = _lib.load()
+    con = np.ascontiguousarray(contraction, np.int32)
+    tp = np.ascontiguousarray(tensors_pos, np.int32)
+    k, steps, _ = con.shape
+    if steps != len(tp) - 1:
+        raise ValueError("'contraction' does not match 'tensors_pos'.")
+    out = np.empty((k, steps, 2), np.int32)
+    if L.tnco_hip_linear_paths(int(n_tensors), len(tp), _ptr(tp), k, _ptr(con), _ptr(out), n_threads):
+        raise ValueError("'contraction' is not valid.")
     return out
 
 
@@ -195,6 +230,14 @@ class BatchedOptimizer:
         _lib.check(self._L.tnco_hip_get_slices(self._h, int(replica), _ptr(a), _ptr(b)))
         return a, b
 
+    def slices_many(self, replicas):
+        """(slices, min_slices) masks [k, W] of k replicas (finite width), one copy back."""
+        ids = np.ascontiguousarray(replicas, np.int64)
+        a = np.zeros((len(ids), self.n_words), np.uint64)
+        b = np.zeros((len(ids), self.n_words), np.uint64)
+        _lib.check(self._L.tnco_hip_get_slices_many(self._h, len(ids), _ptr(ids), _ptr(a), _ptr(b)))
+        return a, b
+
     def update(self, beta: float = 0.0, prob="mh") -> None:
         self.run([beta], prob)
 
@@ -266,6 +309,20 @@ class BatchedOptimizer:
         ids = np.empty(k, np.int64)
         _lib.check(self._L.tnco_hip_best(self._h, k, _ptr(c), _ptr(ids)))
         return c, ids
+
+    def trees(self, replicas, which_min: bool = True, contraction: bool = True):
+        """links [k, 3, N] (and get_contraction triples [k, n-1, 3], include/tnco/utils.hpp:53-71) of
+        k replicas: one device pass, one copy back."""
+        ids = np.ascontiguousarray(replicas, np.int64)
+        k = len(ids)
+        links = np.empty((k, 3, self.n_nodes), np.int32)
+        con = np.empty((k, self.n_leaves - 1, 3), np.int32) if contraction else None
+        _lib.check(self._L.tnco_hip_get_trees(self._h, k, _ptr(ids), int(which_min), _ptr(links), _ptr(con)))
+        return links, con
+
+    def min_cost_to_device(self, device_ptr: int) -> None:
+        """min over replicas of min_total_cost, written by the device into device memory."""
+        _lib.check(self._L.tnco_hip_min_cost_device(self._h, C.c_void_p(int(device_ptr))))
 
     def counters(self) -> dict:
         a, b, c, q = (C.c_uint64(0) for _ in range(4))

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "host_ctx.h"
+#include "extract_kernels.h"
 
 using namespace tnco;
 
@@ -745,19 +746,46 @@ int64_t tnco_hip_device_bytes(tnco_hip_handle h) { return h ? h->bytes : 0; }
 
 int tnco_hip_get_costs(tnco_hip_handle h, double* total_cost, double* min_total_cost) {
   if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
+  if (!total_cost && !min_total_cost) return TNCO_HIP_OK;
   const int64_t R = h->P.R;
-  if (min_total_cost) {
-    std::vector<ReplicaState> rs;
-    if (int rc = fetch_rs(h, rs)) return rc;
-    for (int64_t r = 0; r < R; ++r) min_total_cost[r] = rs[r].min_cost;
-  }
-  if (total_cost) {
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    // partial cost in the header of the root block of every replica (strided gather)
-    const uint8_t* src = h->P.blocks + (int64_t)(h->P.n - 2) * h->P.BS + offsetof(NodeRec, partial);
-    HIP_TRY(hipMemcpy2D(total_cost, 8, src, (size_t)h->block_bytes(), 8, (size_t)R, hipMemcpyDeviceToHost));
-  }
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (int rc = fw_runtime_status(h)) return rc;
+  TempBufs tmp;
+  double *dt = nullptr, *dm = nullptr;
+  if (total_cost) HIP_TRY(tmp.alloc(&dt, R));
+  if (min_total_cost) HIP_TRY(tmp.alloc(&dm, R));
+  hipLaunchKernelGGL(gather_costs_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, h->stream, h->P, dt, dm);
+  HIP_TRY(hipGetLastError());
+  if (total_cost) HIP_TRY(hipMemcpyAsync(total_cost, dt, (size_t)R * 8, hipMemcpyDeviceToHost, h->stream));
+  if (min_total_cost) HIP_TRY(hipMemcpyAsync(min_total_cost, dm, (size_t)R * 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return TNCO_HIP_OK;
+}
+
+int tnco_hip_get_slices_many(tnco_hip_handle h, int64_t k, const int64_t* ids, uint64_t* slices, uint64_t* min_slices) {
+  if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
+  if (!h->fw) return fail(TNCO_HIP_EINVAL, "handle was created without 'max_width'.");
+  if (k < 0 || (k > 0 && !ids)) return fail(TNCO_HIP_EINVAL, "null argument.");
+  for (int64_t i = 0; i < k; ++i)
+    if (ids[i] < 0 || ids[i] >= h->P.R) return fail(TNCO_HIP_EINVAL, "'replica' out of range.");
+  if (k == 0 || (!slices && !min_slices)) return TNCO_HIP_OK;
+  const int LK = h->L * h->K, W = h->P.W;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  TempBufs tmp;
+  int64_t* dids = nullptr;
+  uint64_t *dc = nullptr, *dm = nullptr;
+  HIP_TRY(tmp.alloc(&dids, k));
+  if (slices) HIP_TRY(tmp.alloc(&dc, k * W));
+  if (min_slices) HIP_TRY(tmp.alloc(&dm, k * W));
+  HIP_TRY(hipMemcpyAsync(dids, ids, (size_t)k * 8, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(gather_slices_kernel, dim3((unsigned)((k * W + 255) / 256)), dim3(256), 0, h->stream, h->F.slices, LK, W,
+                     dids, k, dc, dm);
+  HIP_TRY(hipGetLastError());
+  if (slices) HIP_TRY(hipMemcpyAsync(slices, dc, (size_t)k * W * 8, hipMemcpyDeviceToHost, h->stream));
+  if (min_slices) HIP_TRY(hipMemcpyAsync(min_slices, dm, (size_t)k * W * 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   return TNCO_HIP_OK;
 }
 
@@ -933,17 +961,110 @@ int tnco_hip_set_prng(tnco_hip_handle h, int64_t r, const uint32_t* in) {
 int tnco_hip_best(tnco_hip_handle h, int64_t k, double* costs, int64_t* replicas) {
   if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
   if (k < 0 || k > h->P.R) return fail(TNCO_HIP_EINVAL, "'k' out of range.");
-  std::vector<ReplicaState> rs;
-  if (int rc = fetch_rs(h, rs)) return rc;
-  std::vector<int64_t> idx((size_t)h->P.R);
-  std::iota(idx.begin(), idx.end(), (int64_t)0);
-  auto less = [&](int64_t a, int64_t b) {
-    return rs[a].min_cost < rs[b].min_cost || (rs[a].min_cost == rs[b].min_cost && a < b);
-  };
-  std::partial_sort(idx.begin(), idx.begin() + k, idx.end(), less);
+  if (k == 0) return TNCO_HIP_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  if (k > TOPK_CHUNK / 2 || h->P.R >= ((int64_t)1 << 32)) {
+    // a long head of the list: the replica records on the host (k of the order of R is a full sort anyway)
+    std::vector<ReplicaState> rs;
+    if (int rc = fetch_rs(h, rs)) return rc;
+    std::vector<int64_t> idx((size_t)h->P.R);
+    std::iota(idx.begin(), idx.end(), (int64_t)0);
+    auto less = [&](int64_t a, int64_t b) {
+      return rs[a].min_cost < rs[b].min_cost || (rs[a].min_cost == rs[b].min_cost && a < b);
+    };
+    std::partial_sort(idx.begin(), idx.begin() + k, idx.end(), less);
+    for (int64_t i = 0; i < k; ++i) {
+      if (costs) costs[i] = rs[idx[i]].min_cost;
+      if (replicas) replicas[i] = idx[i];
+    }
+    return TNCO_HIP_OK;
+  }
+  // k-select on the device: only k (cost, replica) pairs cross PCIe
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (int rc = fw_runtime_status(h)) return rc;
+  const int keep = (int)std::min<int64_t>(k, TOPK_CHUNK / 2);
+  int64_t count = h->P.R;
+  int64_t blocks = (count + TOPK_CHUNK - 1) / TOPK_CHUNK;
+  TempBufs tmp;
+  unsigned long long* bc[2];
+  uint32_t* bi[2];
+  for (int j = 0; j < 2; ++j) {
+    HIP_TRY(tmp.alloc(&bc[j], blocks * keep));
+    HIP_TRY(tmp.alloc(&bi[j], blocks * keep));
+  }
+  int cur = 0;
+  hipLaunchKernelGGL(topk_pass_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, h->P.rs, nullptr, nullptr, count,
+                     keep, bc[0], bi[0]);
+  count = blocks * keep;
+  while (blocks > 1) {
+    blocks = (count + TOPK_CHUNK - 1) / TOPK_CHUNK;
+    hipLaunchKernelGGL(topk_pass_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, nullptr, bc[cur], bi[cur], count,
+                       keep, bc[1 - cur], bi[1 - cur]);
+    cur = 1 - cur;
+    count = blocks * keep;
+  }
+  HIP_TRY(hipGetLastError());
+  std::vector<unsigned long long> hc((size_t)k);
+  std::vector<uint32_t> hi((size_t)k);
+  HIP_TRY(hipMemcpyAsync(hc.data(), bc[cur], (size_t)k * 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(hi.data(), bi[cur], (size_t)k * 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   for (int64_t i = 0; i < k; ++i) {
-    if (costs) costs[i] = rs[idx[i]].min_cost;
-    if (replicas) replicas[i] = idx[i];
+    double c;
+    std::memcpy(&c, &hc[i], 8);
+    if (costs) costs[i] = c;
+    if (replicas) replicas[i] = (int64_t)hi[i];
+  }
+  return TNCO_HIP_OK;
+}
+
+int tnco_hip_min_cost_device(tnco_hip_handle h, void* device_dst_f64) {
+  if (!h || !device_dst_f64) return fail(TNCO_HIP_EINVAL, "null argument.");
+  HIP_TRY(hipSetDevice(h->device));
+  hipLaunchKernelGGL(min_cost_kernel, dim3(1), dim3(1024), 0, h->stream, h->P.rs, h->P.R, (double*)device_dst_f64);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));  // (the caller's collective runs on another stream)
+  return fw_runtime_status(h);
+}
+
+int tnco_hip_get_trees(tnco_hip_handle h, int64_t k, const int64_t* ids, int which, int32_t* links,
+                       int32_t* contraction) {
+  if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
+  if (k < 0 || (k > 0 && (!ids || !links))) return fail(TNCO_HIP_EINVAL, "null argument.");
+  if (which != 0 && which != 1) return fail(TNCO_HIP_EINVAL, "'which' is not valid.");
+  for (int64_t i = 0; i < k; ++i)
+    if (ids[i] < 0 || ids[i] >= h->P.R) return fail(TNCO_HIP_EINVAL, "'replica' out of range.");
+  if (k == 0) return TNCO_HIP_OK;
+  const int n = h->P.n, N = h->P.N;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (int rc = fw_runtime_status(h)) return rc;
+  // in chunks, so that the device-side staging stays small whatever k
+  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(k, ((int64_t)256 << 20) / ((int64_t)N * 40)));
+  const size_t lds_bytes = (size_t)5 * N * 4;
+  const bool in_lds = lds_bytes <= 60 * 1024;
+  TempBufs tmp;
+  int64_t* dids = nullptr;
+  int32_t *dlinks = nullptr, *dcon = nullptr, *dscr = nullptr;
+  HIP_TRY(tmp.alloc(&dids, chunk));
+  HIP_TRY(tmp.alloc(&dlinks, chunk * 3 * N));
+  if (contraction) HIP_TRY(tmp.alloc(&dcon, chunk * 3 * (n - 1)));
+  if (!in_lds) HIP_TRY(tmp.alloc(&dscr, chunk * 5 * N));
+  for (int64_t k0 = 0; k0 < k; k0 += chunk) {
+    const int64_t cnt = std::min(chunk, k - k0);
+    HIP_TRY(hipMemcpyAsync(dids, ids + k0, (size_t)cnt * 8, hipMemcpyHostToDevice, h->stream));
+    if (in_lds)
+      hipLaunchKernelGGL((gather_trees_kernel<true>), dim3((unsigned)cnt), dim3(64), lds_bytes, h->stream, h->P, dids, which,
+                         dlinks, dcon, nullptr);
+    else
+      hipLaunchKernelGGL((gather_trees_kernel<false>), dim3((unsigned)cnt), dim3(64), 0, h->stream, h->P, dids, which,
+                         dlinks, dcon, dscr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(links + k0 * 3 * N, dlinks, (size_t)cnt * 3 * N * 4, hipMemcpyDeviceToHost, h->stream));
+    if (contraction)
+      HIP_TRY(hipMemcpyAsync(contraction + k0 * 3 * (n - 1), dcon, (size_t)cnt * 3 * (n - 1) * 4, hipMemcpyDeviceToHost,
+                             h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
   }
   return TNCO_HIP_OK;
 }
