@@ -133,6 +133,9 @@ struct CandGreater {  // for a min-heap on (cost, id2, id1)
 struct Scratch {
   std::vector<uint64_t> keys;     // [slot][W] index sets; a slot is an index SET, alive or not
   std::vector<int32_t> ssa, fp;   // per slot: current ssa id, |key|
+  std::vector<int32_t> nz_off;    // per slot: its nonzero words are nz[nz_off[s] .. nz_off[s + 1])
+  std::vector<uint8_t> nz;
+  std::vector<int32_t> keepcnt;   // scratch of push_best: per word, legs of k1 that survive a contraction
   std::vector<uint8_t> alive;
   std::vector<std::vector<int32_t>> dim_keys;  // per non-output dim: live slots holding it
   std::vector<uint64_t> arena;    // k12 of the queued candidates
@@ -168,6 +171,7 @@ void ssa_greedy(const Work& w, const uint64_t* inputs, Scratch& S) {
     for (int x = 0; x < W; ++x) output[x] |= all[x];
   }
   S.keys.clear(); S.ssa.clear(); S.fp.clear(); S.alive.clear(); S.arena.clear();
+  S.nz.clear(); S.nz_off.assign(1, 0); S.keepcnt.assign((size_t)W, 0);
   size_t tsize = 64;
   while (tsize < 8 * (size_t)n) tsize <<= 1;  // at most 2n - 1 + (outer products) index sets
   S.table.assign(tsize, -1);
@@ -187,6 +191,9 @@ void ssa_greedy(const Work& w, const uint64_t* inputs, Scratch& S) {
     S.ssa.push_back(-1);
     S.fp.push_back(popc(m, W));
     S.alive.push_back(0);
+    for (int x = 0; x < W; ++x)
+      if (m[x]) S.nz.push_back((uint8_t)x);
+    S.nz_off.push_back((int32_t)S.nz.size());
     size_t h = hash_mask(m, W) & (tsize - 1);
     while (S.table[h] >= 0) h = (h + 1) & (tsize - 1);
     S.table[h] = s;
@@ -204,13 +211,6 @@ void ssa_greedy(const Work& w, const uint64_t* inputs, Scratch& S) {
   };
   auto add_key = [&](int32_t s) {
     for_dims(&S.keys[(size_t)s * W], true, [&](int d) { S.dim_keys[d].push_back(s); });
-  };
-  auto remove_key = [&](int32_t s) {
-    for_dims(&S.keys[(size_t)s * W], true, [&](int d) {
-      auto& v = S.dim_keys[d];
-      for (size_t i = 0; i < v.size(); ++i)
-        if (v[i] == s) { v[i] = v.back(); v.pop_back(); break; }
-    });
   };
   // eager Hadamard products of equal index sets
   for (int t = 0; t < n; ++t) {
@@ -237,32 +237,47 @@ void ssa_greedy(const Work& w, const uint64_t* inputs, Scratch& S) {
   for (int d = 0; d < w.I; ++d) refresh_ref(d);
 
   std::priority_queue<Cand, std::vector<Cand>, CandGreater> queue;
-  auto candidate = [&](int32_t s1, int32_t s2, Cand& c, uint64_t* out12) {
+  auto result_mask = [&](int32_t s1, int32_t s2, uint64_t* out12) {
     const uint64_t *a = &S.keys[(size_t)s1 * W], *b = &S.keys[(size_t)s2 * W];
     for (int x = 0; x < W; ++x) {
       const uint64_t either = a[x] | b[x], two = a[x] & b[x], one = either & ~two;
       out12[x] = (either & output[x]) | (two & ref3[x]) | (one & ref2[x]);
     }
-    c.cost = Cost{popc(out12, W), S.fp[s1], S.fp[s2]};
-    int32_t id1 = S.ssa[s1], id2 = S.ssa[s2];
-    if (id1 > id2) { std::swap(id1, id2); std::swap(s1, s2); }
-    c.id1 = id1; c.id2 = id2; c.s1 = s1; c.s2 = s2;
   };
-  std::vector<uint64_t> best12((size_t)W);
+  // The candidates of one push share k1 and the reference counts: where k2 has no legs (most words
+  // of most neighbours) the result keeps k1 & (output | ref2), counted once per push; only k2's
+  // nonzero words are evaluated per candidate, and the result's index set only for the winner.
   auto push_best = [&](int32_t s1, const int32_t* k2s, int cnt) {
+    const uint64_t* a = &S.keys[(size_t)s1 * W];
+    int32_t keep_total = 0;
+    for (int x = 0; x < W; ++x) {
+      S.keepcnt[x] = __builtin_popcountll(a[x] & (output[x] | ref2[x]));
+      keep_total += S.keepcnt[x];
+    }
     Cand best{};
     bool have = false;
     for (int i = 0; i < cnt; ++i) {
+      const int32_t s2 = k2s[i];
+      const uint64_t* b = &S.keys[(size_t)s2 * W];
+      int32_t size12 = keep_total;
+      for (int32_t j = S.nz_off[s2]; j < S.nz_off[s2 + 1]; ++j) {
+        const int x = S.nz[j];
+        const uint64_t either = a[x] | b[x], two = a[x] & b[x], one = either & ~two;
+        size12 += __builtin_popcountll((either & output[x]) | (two & ref3[x]) | (one & ref2[x])) - S.keepcnt[x];
+      }
       Cand c;
-      candidate(s1, k2s[i], c, k12.data());
+      c.cost = Cost{size12, S.fp[s1], S.fp[s2]};
+      int32_t id1 = S.ssa[s1], id2 = S.ssa[s2], t1 = s1, t2 = s2;
+      if (id1 > id2) { std::swap(id1, id2); std::swap(t1, t2); }
+      c.id1 = id1; c.id2 = id2; c.s1 = t1; c.s2 = t2;
       if (!have || CandGreater()(best, c)) {
         best = c;
-        best12 = k12;
         have = true;
       }
     }
+    result_mask(best.s1, best.s2, k12.data());
     best.k12 = (int32_t)(S.arena.size() / W);
-    S.arena.insert(S.arena.end(), best12.begin(), best12.end());
+    S.arena.insert(S.arena.end(), k12.begin(), k12.end());
     queue.push(best);
   };
   // initial candidates: per dim, keys sorted by ssa id, each against the later ones
@@ -286,22 +301,31 @@ void ssa_greedy(const Work& w, const uint64_t* inputs, Scratch& S) {
     const int32_t id1 = S.ssa[c.s1], id2 = S.ssa[c.s2];
     S.alive[c.s1] = 0;
     S.alive[c.s2] = 0;
-    remove_key(c.s1);
-    remove_key(c.s2);
     S.path.emplace_back(id1, id2);
     std::memcpy(k12.data(), &S.arena[(size_t)c.k12 * W], (size_t)W * 8);
     int32_t s12 = find_slot(k12.data());
-    if (s12 >= 0 && S.alive[s12]) {
+    const bool merged = s12 >= 0 && S.alive[s12];  // an equal index set is live: Hadamard product with it
+    if (merged) {
       S.path.emplace_back(S.ssa[s12], next_ssa++);
     } else {
       if (s12 < 0) s12 = new_slot(k12.data());
       S.alive[s12] = 1;
-      add_key(s12);
     }
     S.ssa[s12] = next_ssa++;
-    // _update_ref_counts over k1 | (k2 - output); output dims never enter ref2 / ref3
+    // dim_to_keys: k1 and k2 leave, k12 enters (unless it was there already), and _update_ref_counts
+    // over k1 | (k2 - output) -- one pass over the dims of k1 | k2; a dim's reference class changes
+    // only when its number of holders does
     for (int x = 0; x < W; ++x) uni[x] = S.keys[(size_t)c.s1 * W + x] | S.keys[(size_t)c.s2 * W + x];
-    for_dims(uni.data(), true, [&](int d) { refresh_ref(d); });
+    for_dims(uni.data(), true, [&](int d) {
+      auto& v = S.dim_keys[d];
+      const size_t before = v.size();
+      size_t j = 0;
+      for (size_t i = 0; i < before; ++i)
+        if (v[i] != c.s1 && v[i] != c.s2) v[j++] = v[i];
+      v.resize(j);
+      if (!merged && ((k12[d >> 6] >> (d & 63)) & 1ull)) v.push_back(s12);
+      if (v.size() != before) refresh_ref(d);
+    });
     // neighbours of the new tensor
     if ((size_t)s12 >= S.stamp.size()) S.stamp.resize((size_t)s12 * 2 + 8, -1);
     ++stamp_id;
