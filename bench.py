@@ -51,6 +51,7 @@ RANDOM_REQ_PEAK = 47e9
 METRIC = "SA move-evaluations/s (whole node) + best log10(flops) vs ref, 512-leaf TN"
 PMC_GROUPS = (("FETCH_SIZE",), ("WRITE_SIZE",), ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum"),
               ("TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"))
+KERNELS = ("sa_run_kernel", "fw_move_kernel", "fw_reslice_kernel", "fw_walk_kernel")
 FW_MOVE_LAUNCHES = lambda sps, every: (sps + every - 1) // every + 1  # noqa: E731
 FW_RESLICE_LAUNCHES = lambda sps, every: (sps + every - 1) // every   # noqa: E731
 
@@ -190,7 +191,7 @@ class Leg:
 def reduce_legs(res, world, dist, torch):
     """max over ranks of the times, sum of the work; plus what every rank did (all-gather), so that
     the line itself shows how many ranks took part."""
-    names = ("sa_run_kernel", "fw_move_kernel", "fw_reslice_kernel")
+    names = KERNELS
     mine = [res["dt"], float(res["moves"]), float(res["accepted"]), float(res["random_picks"]),
             float(res["improved"]), float(res["full_copies"])] + [res["kt"][k][0] for k in names]
     per_rank = [mine]
@@ -205,7 +206,7 @@ def reduce_legs(res, world, dist, torch):
     for j, k in enumerate(("moves", "accepted", "random_picks", "improved", "full_copies")):
         out[k] = float(arr[:, 1 + j].sum())
     out["kt"] = {k: (float(arr[:, 6 + j].max()), res["kt"][k][1]) for j, k in enumerate(names)}
-    out["per_rank"] = [dict(rank=i, wall_s=v[0], moves=v[1], kernel_ms=sum(v[6:9])) for i, v in enumerate(per_rank)]
+    out["per_rank"] = [dict(rank=i, wall_s=v[0], moves=v[1], kernel_ms=sum(v[6:])) for i, v in enumerate(per_rank)]
     return out
 
 
@@ -245,13 +246,14 @@ def pmc_passes(args, lib_version):
         rows.sort(key=lambda r: int(r["Dispatch_Id"]))
         for r in rows:
             name = r["Kernel_Name"]
-            for short in ("sa_run_kernel", "fw_move_kernel", "fw_reslice_kernel"):
+            for short in KERNELS:
                 if short in name:
                     vals.setdefault((short, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
     shutil.rmtree(tmp, ignore_errors=True)
     every = args.fw_update_slices
     per_step = {"sa_run_kernel": 1, "fw_move_kernel": FW_MOVE_LAUNCHES(args.sweeps_per_step, every),
-                "fw_reslice_kernel": FW_RESLICE_LAUNCHES(args.sweeps_per_step, every)}
+                "fw_reslice_kernel": FW_RESLICE_LAUNCHES(args.sweeps_per_step, every),
+                "fw_walk_kernel": FW_RESLICE_LAUNCHES(args.sweeps_per_step, every)}
     res = {"library": lib_version, "seconds": None, "kernels": {}}
     for (short, ctr), v in vals.items():
         n = per_step[short]
@@ -396,7 +398,7 @@ def main() -> None:
                 alg_per_step = bmove * moves_per_step_gpu
                 extra = {"algorithmic_bytes_per_move": bmove}
             else:
-                kernels = ("fw_move_kernel", "fw_reslice_kernel")
+                kernels = tuple(k for k in ("fw_move_kernel", "fw_reslice_kernel", "fw_walk_kernel") if kt[k][1] > 0)
                 bmove = algorithmic_bytes_per_move_fw(prob.W, a, q)
                 bres = algorithmic_bytes_per_reslice(prob.n, prob.W)
                 n_res = FW_RESLICE_LAUNCHES(sps, every) * R

@@ -197,8 +197,9 @@ int tnco_hip_get_stage_cycles(tnco_hip_handle h, uint64_t* out5);
 int tnco_hip_kernel_time(tnco_hip_handle h, double* ms, int64_t* launches, int reset);
 /* The same time split by kernel: [0] sa_run_kernel (Optimizer::update, infinite memory),
  * [1] fw_move_kernel (finite_width/greedy/optimizer.hpp:130-331), [2] fw_reslice_kernel
- * (:359-389); launches3 = kernel launches of each.  Either array may be NULL. */
-int tnco_hip_kernel_times(tnco_hip_handle h, double* ms3, int64_t* launches3, int reset);
+ * (:359-389), [3] fw_walk_kernel (the traverse of get_slices, greedy/utils.hpp:62); launches4 =
+ * kernel launches of each.  Either array ([4]) may be NULL. */
+int tnco_hip_kernel_times(tnco_hip_handle h, double* ms4, int64_t* launches4, int reset);
 
 /* Bytes of device memory held by the handle. */
 int64_t tnco_hip_device_bytes(tnco_hip_handle h);

@@ -344,10 +344,10 @@ class BatchedOptimizer:
 
     def kernel_times_ms(self, reset: bool = False) -> dict:
         """{kernel: (ms, launches)} since the last reset, from HIP events around every launch."""
-        ms = np.zeros(3, np.float64)
-        n = np.zeros(3, np.int64)
+        ms = np.zeros(4, np.float64)
+        n = np.zeros(4, np.int64)
         _lib.check(self._L.tnco_hip_kernel_times(self._h, _ptr(ms), _ptr(n), int(reset)))
-        names = ("sa_run_kernel", "fw_move_kernel", "fw_reslice_kernel")
+        names = ("sa_run_kernel", "fw_move_kernel", "fw_reslice_kernel", "fw_walk_kernel")
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
     @property

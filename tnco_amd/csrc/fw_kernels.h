@@ -42,6 +42,7 @@ struct FwParams {
   int32_t* scratch_i;       // [R][fw_scratch_ints]  see FwScratch
   double* scratch_d;        // [R][2N]        see FwScratch
   double* width64;          // [R][N] widths of the internal nodes when width_type is float64
+  int32_t* nwide;           // [R] fw_walk_kernel -> fw_reslice_kernel: too-wide tensors listed (-1: no slices, nothing to do)
   int32_t* status;          // [R] runtime problems (1: candidate legs beyond the scratch; cannot happen
                             //     since the scratch holds every index)
 };
@@ -376,10 +377,12 @@ __device__ __forceinline__ int fw_traverse(const Params& P, const FwParams& F, c
 // child is the node just before its parent and its sum still in a register (`part`); an internal
 // left child's sum is the top of the stack of finished subtrees; a node with two leaf children
 // pushes (pstk[]: consecutive doubles, the same few lines again and again).
+typedef TNCO_LDS volatile double lds_vdouble;
+
 template <int LOG2L, int K, bool HYPER, int B = 4>
 __device__ __forceinline__ double fw_rebuild(const Params& P, const View<LOG2L, K, HYPER>& v, const uint64_t* rec,
                                              const Mask<K>& slices, double2* cp, double* pstk, bool lane0,
-                                             int gbase, double* sum) {
+                                             int gbase, double* sum, lds_vdouble* lstk = nullptr, int lcap = 0) {
   const int n = P.n, ni = P.N - P.n;
   double s = 0.0, part = 0.0;
   if (ni <= 0) {
@@ -387,17 +390,32 @@ __device__ __forceinline__ double fw_rebuild(const Params& P, const View<LOG2L, 
     return 0.0;
   }
   auto ld_rec = [&](int j) -> uint64_t { return rec[j < ni ? j : ni - 1]; };
+  // Without hyper-indices the legs of an internal node are left ^ right (tnco/ctree.py:163-189), and
+  // in post-order an internal RIGHT child is the node just before its parent: its legs are still in
+  // registers (`prev`), so only leaves (the shared leaf table, L2) and internal LEFT children are
+  // read -- half of the random reads of node blocks.  (A skipped child reads leaf 0 instead: one
+  // unconditional load per slot, "a loaded value has one definition".)
+  auto right_src = [&](uint64_t r) -> int {
+    const int rr = fw_rec_right(r);
+    return (!HYPER && rr >= n) ? 0 : rr;
+  };
   uint64_t rc[B];
 #pragma unroll
   for (int i = 0; i < B; ++i) rc[i] = ld_rec(i);
+  Mask<K> prev = mzero<K>();
   int sp = 0;  // finished subtrees not yet consumed: the newest in `part`, the others in pstk[0 .. sp - 2]
+  // (the stack of partial sums: its first lcap entries in LDS, deeper ones in global scratch)
+  auto stk_get = [&](int i) -> double { return i < lcap ? lstk[i] : pstk[i]; };
+  auto stk_put = [&](int i, double x) {
+    if (i < lcap) lstk[i] = x; else pstk[i] = x;
+  };
   for (int j0 = 0; j0 < ni; j0 += B) {
     Mask<K> ml[B], mr[B];
     uint64_t rn[B];
 #pragma unroll
     for (int i = 0; i < B; ++i) {
       ml[i] = v.mask(fw_rec_left(rc[i]));
-      mr[i] = v.mask(fw_rec_right(rc[i]));
+      mr[i] = v.mask(right_src(rc[i]));
     }
 #pragma unroll
     for (int i = 0; i < B; ++i) rn[i] = ld_rec(j0 + B + i);
@@ -405,21 +423,23 @@ __device__ __forceinline__ double fw_rebuild(const Params& P, const View<LOG2L, 
     for (int i = 0; i < B; ++i) {
       if (j0 + i < ni) {
         const int l = fw_rec_left(rc[i]), rr = fw_rec_right(rc[i]);
-        const Mask<K> u = mor<K>(mor<K>(ml[i], mr[i]), slices);
+        const bool li = l >= n, ri = rr >= n;
+        const Mask<K> mright = (!HYPER && ri) ? prev : mr[i];
+        const Mask<K> u = mor<K>(mor<K>(ml[i], mright), slices);
+        if constexpr (!HYPER) prev = mxor<K>(ml[i], mright);
         const double c = generic_cost<LOG2L, K>(P, u, v.lig, gbase);
         s = rnd_cost(s + c, P.f32);
-        const bool li = l >= n, ri = rr >= n;
         if (lane0) {
           double pl = 0.0, pr = 0.0;
           if (li && ri) {
             pr = part;
-            pl = pstk[sp - 2];  // (lane 0's own store: an L2 hit)
+            pl = stk_get(sp - 2);
           } else if (ri) {
             pr = part;
           } else if (li) {
             pl = part;
           } else if (sp >= 1) {
-            pstk[sp - 1] = part;
+            stk_put(sp - 1, part);
           }
           part = rnd_cost(rnd_cost(c + pl, P.f32) + pr, P.f32);
           cp[j0 + i] = make_double2(c, part);
@@ -620,8 +640,10 @@ __device__ __forceinline__ void fw_slice_wide(const Params& P, const FwParams& F
 template <int LOG2L, int K, bool HYPER>
 __device__ __forceinline__ int fw_gs_mark(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
                                           const double* w64, const FwScratch& sc, FwStack st, bool lane0, int gbase,
-                                          unsigned long long* prof = nullptr) {
-  const int nw = fw_traverse<LOG2L, K, HYPER>(P, F, v, w64, sc.rec, sc.wlist, lane0, gbase, st, sc.gstk);
+                                          unsigned long long* prof = nullptr, int nw_pre = -1) {
+  // (nw_pre >= 0: fw_walk_kernel has left sc.rec / sc.wlist and this count)
+  const int nw = nw_pre >= 0 ? nw_pre
+                             : fw_traverse<LOG2L, K, HYPER>(P, F, v, w64, sc.rec, sc.wlist, lane0, gbase, st, sc.gstk);
 #ifdef TNCO_PROFILE
   if (prof) prof[0] = __builtin_amdgcn_s_memtime();
 #endif
@@ -759,8 +781,8 @@ __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams
                                                  const double* w64, Rng<LOG2L>& rng, const FwScratch& sc, FwStack st,
                                                  lds_vi32* lpos, bool lane0, int gbase, int32_t* status,
                                                  unsigned long long* prof = nullptr,
-                                                 unsigned long long* cnt = nullptr) {
-  const int nw = fw_gs_mark<LOG2L, K, HYPER>(P, F, v, w64, sc, st, lane0, gbase, prof);
+                                                 unsigned long long* cnt = nullptr, int nw_pre = -1) {
+  const int nw = fw_gs_mark<LOG2L, K, HYPER>(P, F, v, w64, sc, st, lane0, gbase, prof, nw_pre);
   return fw_gs_pick<LOG2L, K, HYPER>(P, F, v, rng, sc, nw, lpos, lane0, gbase, status, cnt);
 }
 
@@ -780,6 +802,103 @@ __global__ __launch_bounds__(256) void fw_leaf_bits_kernel(const Params P, const
       *any = 1;
     }
   }
+}
+
+// The walk of the re-slice as a kernel of its own, ONE LANE per replica (fw_reslice_kernel then
+// starts from the lists).  The walk is scalar work per replica -- links and cached widths, no leg
+// masks -- and a chain of dependent header reads: with four lanes per replica it ran 16 chains per
+// wavefront and every lane of a group repeated the same instructions.  Here a wavefront runs 64
+// chains, so the same number of resident wavefronts keeps four times as many header reads in
+// flight (the chip retires ~47 G random reads/s, tools/hbm_random.hip; the 4-lane walk reached 25 G/s)
+// at a quarter of the instructions.  Same step structure as fw_traverse: one fetch per iteration, an
+// up-step before and after it; stack entries lane-interleaved in LDS (no bank conflicts whatever
+// the depths), the deep end in global scratch.  Trees of at most 8192 nodes (13-bit stack fields).
+#ifndef TNCO_FW_WALK_CAP
+#define TNCO_FW_WALK_CAP 40
+#endif
+constexpr int FW_WALK_CAP = TNCO_FW_WALK_CAP;
+
+static __global__ __launch_bounds__(256) void fw_walk_kernel(const Params P, const FwParams F) {
+  __shared__ int32_t se[FW_WALK_CAP * 256];
+  __shared__ uint16_t sl[FW_WALK_CAP * 256];
+  const int tid = threadIdx.x;
+  const int64_t r = (int64_t)blockIdx.x * 256 + tid;
+  if (r >= P.R) return;
+  const int n = P.n, N = P.N, LK = F.I64 / 64;
+  {  // greedy/optimizer.hpp:359: nothing to do without slices
+    const uint64_t* sl0 = F.slices + r * 2 * (int64_t)LK;
+    uint64_t any = 0;
+    for (int w = 0; w < P.W; ++w) any |= sl0[w];
+    if (!any) {
+      F.nwide[r] = -1;
+      return;
+    }
+  }
+  const FwScratch sc(F, r, N);
+  const uint8_t* blk = P.blocks + r * (int64_t)(n - 1) * P.BS;
+  const double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
+  uint64_t* rec = sc.rec;
+  int32_t* wlist = sc.wlist;
+  volatile int32_t* gstk = sc.gstk;
+  TNCO_LDS volatile int32_t* e_ = (TNCO_LDS volatile int32_t*)se + tid;
+  TNCO_LDS volatile uint16_t* l_ = (TNCO_LDS volatile uint16_t*)sl + tid;
+  const int gh = (N + 1) / 2;
+  int ni = 0, nw = 0;
+  auto emit_leaf = [&](int x) {
+    if (F.leaf_wide && ((F.leaf_bits[x >> 5] >> (x & 31)) & 1u)) wlist[nw++] = x;
+  };
+  int sp = 0, x = N - 1;
+  bool done = false;
+  if (x < n) {
+    emit_leaf(x);
+    done = true;
+  }
+  auto up = [&]() {
+    int e, l;
+    if (sp <= FW_WALK_CAP) {
+      e = e_[(sp - 1) * 256];
+      l = l_[(sp - 1) * 256];
+    } else {
+      e = gstk[sp - 1 - FW_WALK_CAP];
+      l = gstk[gh + sp - 1 - FW_WALK_CAP];
+    }
+    const int node = e & 0x1FFF, rr = (e >> 13) & 0x1FFF;
+    const bool fresh = ((e >> 26) & 1) == 0;
+    if (fresh && rr >= n) {  // into the right subtree
+      if (sp <= FW_WALK_CAP) e_[(sp - 1) * 256] = e | (1 << 26); else gstk[sp - 1 - FW_WALK_CAP] = e | (1 << 26);
+      x = rr;
+    } else {
+      if (fresh) emit_leaf(rr);
+      --sp;
+      rec[ni++] = fw_rec(node, l, rr);
+      if ((e >> 27) & 1) wlist[nw++] = node;
+      if (sp == 0) done = true;
+    }
+  };
+  while (!done) {
+    if (x < 0) up();
+    if (x >= n) {  // down: the only read of this node's header (links + cached width, one line)
+      const int4 h = *reinterpret_cast<const int4*>(blk + (int64_t)(x - n) * P.BS);
+      const double w = F.width_f32 ? (double)__int_as_float(h.w) : w64[x];
+      const bool wide = w > F.max_width;
+      ++sp;
+      const int e = x | (h.y << 13) | (wide ? (1 << 27) : 0);
+      if (sp <= FW_WALK_CAP) {
+        e_[(sp - 1) * 256] = e;
+        l_[(sp - 1) * 256] = (uint16_t)h.x;
+      } else {
+        gstk[sp - 1 - FW_WALK_CAP] = e;
+        gstk[gh + sp - 1 - FW_WALK_CAP] = h.x;
+      }
+      x = h.x;
+      if (x < n) {
+        emit_leaf(x);
+        x = -1;
+      }
+    }
+    if (!done && x < 0) up();
+  }
+  F.nwide[r] = nw;
 }
 
 struct FwInitArgs {
@@ -1025,7 +1144,6 @@ __global__ __launch_bounds__(256, MAXNEW ? TNCO_FW_MAXNEW_WAVES : TNCO_FW_MOVE_W
       } else {
         pick0 = inter0;
       }
-      const int D = pick0 ? hb.left : hb.right;
       int E = pick0 ? hb.right : hb.left;
       const M mD = msel<K>(pick0, m0, m1), mE = msel<K>(pick0, m1, m0);
       const double pD = pick0 ? p0 : p1, pE = pick0 ? p1 : p0;
@@ -1208,14 +1326,14 @@ __device__ __forceinline__ void fw_sweep_tail(const Params& P, const View<LOG2L,
 // current tree (get_slices), the cost cache rebuilt with them, kept if the total improves; then the
 // best-so-far bookkeeping of the sweep (:385-389).
 template <int LOG2L, int K, bool HYPER>
-__global__ __launch_bounds__(256, 2) void fw_reslice_kernel(const Params P, const FwParams F) {
+__global__ __launch_bounds__(256, 2) void fw_reslice_kernel(const Params P, const FwParams F, const int prewalked) {
   constexpr int L = 1 << LOG2L;
   constexpr int GPB = 256 >> LOG2L;
   constexpr int LK = L * K;
   using M = Mask<K>;
   using R = Rng<LOG2L>;
   __shared__ uint32_t rngbuf[GPB * R::RING];
-  __shared__ int32_t posbuf[GPB * FW_LDSPOS];   // candidate legs of a tensor / traversal stack
+  __shared__ __attribute__((aligned(8))) int32_t posbuf[GPB * FW_LDSPOS];  // candidate legs / traversal stack / partial sums
   __shared__ uint16_t leftbuf[GPB * FW_LDSPOS];  // traversal stack: left children
   const int tid = threadIdx.x;
   const int lig = tid & (L - 1);
@@ -1236,26 +1354,28 @@ __global__ __launch_bounds__(256, 2) void fw_reslice_kernel(const Params P, cons
   M slices;
 #pragma unroll
   for (int k = 0; k < K; ++k) slices.w[k] = sl[v.widx(k)];
+  const int nw_pre = prewalked ? F.nwide[r] : -1;
   FW_PROF_DECL;
   FW_PROF_T(1);
   if (gany<LOG2L>(mnonzero<K>(slices))) {
     R rng;
     rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
 #if defined(TNCO_PROFILE) && TNCO_PROFILE == 3  // event counts instead of cycles
-    const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, sc, st, lpos, lane0, gbase, F.status + r, nullptr, fc_);
+    const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, sc, st, lpos, lane0, gbase, F.status + r, nullptr, fc_, nw_pre);
 #elif defined(TNCO_PROFILE)
     unsigned long long fp_[2] = {0, 0};  // end of the walk, end of the counts
-    const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, sc, st, lpos, lane0, gbase, F.status + r, fp_);
+    const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, sc, st, lpos, lane0, gbase, F.status + r, fp_, nullptr, nw_pre);
     ft_[2] = fp_[0];
     ft_[0] = ft_[1];                  // slot 0: the walk (from the start of the re-slice)
     ft_[1] = ft_[2];                  // slot 1: too-wide counts
     ft_[2] = fp_[1];                  // slot 2: the greedy pass (up to T(3))
 #else
-    const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, sc, st, lpos, lane0, gbase, F.status + r);
+    const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, sc, st, lpos, lane0, gbase, F.status + r, nullptr, nullptr, nw_pre);
 #endif
     FW_PROF_T(3);
     double sum;
-    const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, sc.rec, ns, sc.cp, sc.pstk, lane0, gbase, &sum);
+    const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, sc.rec, ns, sc.cp, sc.pstk, lane0, gbase, &sum,
+                                                   (lds_vdouble*)lpos, FW_LDSPOS / 2);
     if (tot < v.hdr(N - 1)->partial) {
       slices = ns;
       fw_commit<LOG2L, K, HYPER>(P, v, sc.rec, sc.cp);

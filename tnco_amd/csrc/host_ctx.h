@@ -14,7 +14,7 @@ struct EventPair {
   hipEvent_t a, b;
   int kind;  // TNCO_KIND_*
 };
-enum : int { TNCO_KIND_SWEEP = 0, TNCO_KIND_FW_MOVE = 1, TNCO_KIND_FW_RESLICE = 2, TNCO_KINDS = 3 };
+enum : int { TNCO_KIND_SWEEP = 0, TNCO_KIND_FW_MOVE = 1, TNCO_KIND_FW_RESLICE = 2, TNCO_KIND_FW_WALK = 3, TNCO_KINDS = 4 };
 
 
 struct tnco_hip_ctx {
@@ -35,8 +35,8 @@ struct tnco_hip_ctx {
   std::vector<EventPair> pending, free_events;
   double kernel_ms = 0;   // all kernels of the run calls since the last reset
   int64_t launches = 0;   // chunks of the schedule launched (one per tnco_hip_run[_fw] call unless very long)
-  double kind_ms[TNCO_KINDS] = {0, 0, 0};     // the same time, per kernel (HIP events around every launch)
-  int64_t kind_launches[TNCO_KINDS] = {0, 0, 0};
+  double kind_ms[TNCO_KINDS] = {0, 0, 0, 0};     // the same time, per kernel (HIP events around every launch)
+  int64_t kind_launches[TNCO_KINDS] = {0, 0, 0, 0};
 
   template <typename T>
   hipError_t alloc(T** p, int64_t count) {
@@ -125,4 +125,4 @@ void launch_fw_check_lk(tnco_hip_ctx* h, const tnco::BuildArgs& a, int which_min
 template <int LOG2L, int K>
 void launch_fw_move_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, int tail_last);
 template <int LOG2L, int K>
-void launch_fw_reslice_lk(tnco_hip_ctx* h);
+void launch_fw_reslice_lk(tnco_hip_ctx* h, int prewalked);

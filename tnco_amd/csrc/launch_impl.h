@@ -84,13 +84,13 @@ void launch_fw_move_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, in
 #undef TNCO_FW_MOVE
 }
 template <int LOG2L, int K>
-void launch_fw_reslice_lk(tnco_hip_ctx* h) {
+void launch_fw_reslice_lk(tnco_hip_ctx* h, int prewalked) {
   const int gpb = 256 >> LOG2L;
   dim3 grid((unsigned)((h->P.R + gpb - 1) / gpb));
   if (h->hyper)
-    hipLaunchKernelGGL((fw_reslice_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, h->F);
+    hipLaunchKernelGGL((fw_reslice_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, h->F, prewalked);
   else
-    hipLaunchKernelGGL((fw_reslice_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F);
+    hipLaunchKernelGGL((fw_reslice_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, prewalked);
 }
 
 template void launch_run_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const double*, int64_t, int);
@@ -100,4 +100,4 @@ template void launch_fw_leaf_bits_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, ui
 template void launch_fw_init_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const FwInitArgs&);
 template void launch_fw_check_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const BuildArgs&, int, double, int32_t*);
 template void launch_fw_move_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const double*, int64_t, int, int);
-template void launch_fw_reslice_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*);
+template void launch_fw_reslice_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, int);

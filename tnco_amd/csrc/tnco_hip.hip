@@ -108,6 +108,11 @@ void launch_fw_init(tnco_hip_ctx* h, const FwInitArgs& a) {
 #undef CALL_FWI
 }
 
+// (one lane per replica: the same kernel whatever the lane layout of the handle)
+void launch_fw_walk(tnco_hip_ctx* h) {
+  hipLaunchKernelGGL(fw_walk_kernel, dim3((unsigned)((h->P.R + 255) / 256)), dim3(256), 0, h->stream, h->P, h->F);
+}
+
 // n_steps sweeps of the finite-width optimizer: [moves up to and including the next re-slicing
 // sweep][re-slice] ... [the remaining moves]  (sweep k re-slices when (off + k) % every == 0)
 hipError_t launch_fw_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, int64_t off,
@@ -129,8 +134,15 @@ hipError_t launch_fw_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, 
     });
     if (e != hipSuccess) return e;
     if (reslice) {
+      // the walk over the tree as a kernel of its own (one lane per replica), unless the tree is too
+      // large for its stack fields or the test knob TNCO_HIP_FW_STACK=0 asks for the link-walking path
+      const int prewalked = (h->P.N <= 8192 && h->F.stack_cap > 0 && h->F.nwide != nullptr) ? 1 : 0;
+      if (prewalked) {
+        e = h->timed(TNCO_KIND_FW_WALK, [&]() { launch_fw_walk(h); });
+        if (e != hipSuccess) return e;
+      }
       e = h->timed(TNCO_KIND_FW_RESLICE, [&]() {
-#define CALL_FWS(LL, KK) launch_fw_reslice_lk<LL, KK>(h)
+#define CALL_FWS(LL, KK) launch_fw_reslice_lk<LL, KK>(h, prewalked)
         DISPATCH_LK(h, CALL_FWS)
 #undef CALL_FWS
       });
@@ -576,6 +588,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     HIP_TRY(h->alloc(&F.scratch_i, R * fw_scratch_ints(N, F.I64)));
     HIP_TRY(h->alloc(&F.scratch_d, R * 2 * (int64_t)N));
     HIP_TRY(h->alloc(&F.status, R));
+    if (!std::getenv("TNCO_HIP_FW_NO_WALK_KERNEL")) HIP_TRY(h->alloc(&F.nwide, R));
     HIP_TRY(hipMemset(F.status, 0, (size_t)R * 4));
     F.stack_cap = FW_LDSPOS;
     if (const char* e = std::getenv("TNCO_HIP_FW_STACK")) F.stack_cap = std::max(0, std::min(FW_LDSPOS, std::atoi(e)));
@@ -729,14 +742,14 @@ int tnco_hip_kernel_time(tnco_hip_handle h, double* ms, int64_t* launches, int r
   return TNCO_HIP_OK;
 }
 
-int tnco_hip_kernel_times(tnco_hip_handle h, double* ms3, int64_t* launches3, int reset) {
+int tnco_hip_kernel_times(tnco_hip_handle h, double* ms4, int64_t* launches4, int reset) {
   if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->resolve_events();
   for (int k = 0; k < TNCO_KINDS; ++k) {
-    if (ms3) ms3[k] = h->kind_ms[k];
-    if (launches3) launches3[k] = h->kind_launches[k];
+    if (ms4) ms4[k] = h->kind_ms[k];
+    if (launches4) launches4[k] = h->kind_launches[k];
   }
   if (reset) h->reset_times();
   return TNCO_HIP_OK;
