@@ -3,6 +3,8 @@
 #pragma once
 #include "host_ctx.h"
 
+#include <cstdlib>
+
 using namespace tnco;
 
 template <int LOG2L, int K>
@@ -13,14 +15,14 @@ void launch_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int pr
   dim3 grid((unsigned)((P.R + gpb - 1) / gpb));
   if (h->hyper) {
     if (h->generic)
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, true>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, true, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1);
     else
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, false, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1);
   } else {
     if (h->generic)
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, true>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, true, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1);
     else
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind);
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, false, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1);
   }
 }
 
@@ -73,6 +75,18 @@ void launch_fw_move_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, in
   const int gpb = 256 >> LOG2L;
   dim3 grid((unsigned)((h->P.R + gpb - 1) / gpb));
   const bool maxnew = h->F.max_new_slices > 0;
+  if (!maxnew && !std::getenv("TNCO_HIP_FW_UNSTAGED")) {  // the staged state machine (sa_sweep.h, FW = true)
+#define TNCO_FW_STAGED(HY, GE)                                                                                          \
+  hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, HY, GE, true>), grid, dim3(256), 0, h->stream, h->P, betas, n_steps, \
+                     prob_kind, h->F, tail_last)
+    if (h->hyper) {
+      if (h->generic) TNCO_FW_STAGED(true, true); else TNCO_FW_STAGED(true, false);
+    } else {
+      if (h->generic) TNCO_FW_STAGED(false, true); else TNCO_FW_STAGED(false, false);
+    }
+#undef TNCO_FW_STAGED
+    return;
+  }
 #define TNCO_FW_MOVE(HY, MN)                                                                                        \
   hipLaunchKernelGGL((fw_move_kernel<LOG2L, K, HY, MN>), grid, dim3(256), 0, h->stream, h->P, h->F, betas, n_steps, \
                      prob_kind, tail_last)

@@ -31,8 +31,17 @@
 // and waits -- right after the load: leaf / internal-node legs select the address, not the value.
 // The mt19937 stream is produced the same way: a 16-word block (4 words per lane) is requested
 // with the other loads and twisted + tempered into an LDS ring at the top of a later iteration.
+//
+// FW = true: the same state machine runs the moves of the memory-constrained optimizer
+// (finite_width/greedy/optimizer.hpp:117-331 without the max_number_new_slices branch, which keeps
+// the unstaged fw_move_kernel): the sliced-index mask is carried in registers and OR-ed into both
+// contraction costs (:191-193), the cached width of a node travels with its header (the spare
+// word), a move whose new B is wider than max_width once sliced draws no uniform and is not
+// accepted (:188-201), an accepted one stores B's new width (:216).  The re-slice at the end of a
+// sweep is fw_walk_kernel + fw_reslice_kernel: the host launches [moves][walk][re-slice]...
 #pragma once
 #include "sa_kernels.h"
+#include "fw_params.h"
 
 namespace tnco {
 
@@ -271,9 +280,13 @@ typedef TNCO_LDS volatile ColdState lds_cold;
 #define TNCO_PROF_OUT(rs)
 #endif
 
-template <int LOG2L, int K, bool HYPER, bool GENERIC>
-__global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : TNCO_WAVES_PER_SIMD)) void sa_run_kernel(
-    const Params P, const double* __restrict__ betas, const int64_t n_steps, const int prob_kind) {
+#ifndef TNCO_FW_STAGED_WAVES
+#define TNCO_FW_STAGED_WAVES 2
+#endif
+template <int LOG2L, int K, bool HYPER, bool GENERIC, bool FW = false>
+__global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES : TNCO_WAVES_PER_SIMD))) void sa_run_kernel(
+    const Params P, const double* __restrict__ betas, const int64_t n_steps, const int prob_kind,
+    const FwParams F, const int tail_last) {
   constexpr int L = 1 << LOG2L;
   constexpr int GPB = 256 >> LOG2L;  // groups (replicas) per block
   using M = Mask<K>;
@@ -336,6 +349,14 @@ __global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : TNCO_WAVES_PER_SIMD)) void s
       jb(4 * q + 0) = t.x; jb(4 * q + 1) = t.y; jb(4 * q + 2) = t.z; jb(4 * q + 3) = t.w;
     }
   }
+  // finite width: the sliced indices (constant during this kernel), this lane's words
+  M sl = mzero<K>();
+  [[maybe_unused]] bool impr_any = false;
+  if constexpr (FW) {
+    const uint64_t* s0 = F.slices + r * 2 * (int64_t)(L * K);
+#pragma unroll
+    for (int k = 0; k < K; ++k) sl.w[k] = s0[v.widx(k)];
+  }
   const int f32 = GENERIC ? P.f32 : 0;
   const int log2d = P.log2d;
   const bool disable_shared = P.disable_shared != 0;
@@ -343,6 +364,7 @@ __global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : TNCO_WAVES_PER_SIMD)) void s
 
   // ---- carried state: B and what is known about its two children ----------
   int B = 0, bl = 0, br = 0, A = -1;
+  [[maybe_unused]] int wB = 0, raW = 0, rnW = 0;  // finite width: the spare header word (cached width) of B, A, parent(A)
   double ccB = 0, partB = 0, total = 0, beta = 0;
   M m0 = mzero<K>(), m1 = mzero<K>(), iB = mzero<K>(), hB = mzero<K>();
   double p0 = 0, p1 = 0;
@@ -369,6 +391,8 @@ __global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : TNCO_WAVES_PER_SIMD)) void s
     // what the store phase needs
     bool acc = false, did_move = false, did_end = false, improved = false, b_is_left_of_a = false;
     int stB = 0, stA = -1, stC = 0, stE = 0, stL = 0, stR = 0;
+    [[maybe_unused]] int stW = 0;
+    [[maybe_unused]] double stW64 = 0;
     double stCC = 0, stPart = 0;
     M stH = mzero<K>();
     int x_al = 0, x_ar = 0, x_aP = -1;
@@ -378,8 +402,12 @@ __global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : TNCO_WAVES_PER_SIMD)) void s
       // ---- B is the root: end of sweep (optimizer.hpp:194-201) ------------
       did_end = true;
       stB = B; stA = -1; stL = bl; stR = br; stCC = ccB; stPart = partB;
+      if constexpr (FW) stW = wB;
       if constexpr (HYPER) stH = hB;
-      if (partB < cold.min_cost) {
+      // (finite width, a launch that ends in a re-slicing sweep: fw_reslice_kernel closes that sweep)
+      const bool close_sweep = !FW || tail_last != 0 || step != nsteps32 - 1;
+      if (close_sweep && partB < cold.min_cost) {
+        if constexpr (FW) impr_any = true;  // min_slices := slices, once, at the end of the kernel
         if (lane0) {
           cold.min_cost = partB;
           cold.n_impr = cold.n_impr + 1;
@@ -446,10 +474,12 @@ __global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : TNCO_WAVES_PER_SIMD)) void s
     // ======================= requests (staging registers) ====================
     // Nothing below reads these registers before the landing fence.
     int gL = -1, gR = -1, gP = -1;
+    [[maybe_unused]] int gW = 0;
     double gC = 0;
     if (hN >= 0) {
       const NodeRec* q = v.hdr(hN);
       gL = q->left; gR = q->right; gP = q->parent; gC = q->ccost;
+      if constexpr (FW) gW = q->pad;
     }
     M gM = mzero<K>();
     double gMp = 0;
@@ -488,10 +518,12 @@ __global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : TNCO_WAVES_PER_SIMD)) void s
       bool inter0, inter1;
       int pcA0 = 0, pcB0 = 0, pcA1 = 0, pcB1 = 0;
       if constexpr (!GENERIC) {
-        uint32_t w0 = mpopc<K>(mor<K>(mor<K>(mxor<K>(m0, mC), hy), m1)) | (mpopc<K>(mor<K>(m0, mC)) << 13) |
-                      ((mnonzero<K>(mand<K>(m0, mC)) ? 1u : 0u) << 26);
-        uint32_t w1 = mpopc<K>(mor<K>(mor<K>(mxor<K>(m1, mC), hy), m0)) | (mpopc<K>(mor<K>(m1, mC)) << 13) |
-                      ((mnonzero<K>(mand<K>(m1, mC)) ? 1u : 0u) << 26);
+        // (finite width: both costs are over in1 | in2 | slices, finite_width/cost_model/simple.hpp:139-144;
+        // sl is zero otherwise)
+        uint32_t w0 = mpopc<K>(mor<K>(mor<K>(mor<K>(mxor<K>(m0, mC), hy), m1), sl)) |
+                      (mpopc<K>(mor<K>(mor<K>(m0, mC), sl)) << 13) | ((mnonzero<K>(mand<K>(m0, mC)) ? 1u : 0u) << 26);
+        uint32_t w1 = mpopc<K>(mor<K>(mor<K>(mor<K>(mxor<K>(m1, mC), hy), m0), sl)) |
+                      (mpopc<K>(mor<K>(mor<K>(m1, mC), sl)) << 13) | ((mnonzero<K>(mand<K>(m1, mC)) ? 1u : 0u) << 26);
         w0 = gsum<LOG2L>(w0);
         w1 = gsum<LOG2L>(w1);
         inter0 = (w0 >> 26) != 0;
@@ -516,25 +548,49 @@ __global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : TNCO_WAVES_PER_SIMD)) void s
       const double pD = pick0 ? p0 : p1, pE = pick0 ? p1 : p0;
       const int E = pick0 ? br : bl;
 
+      // finite width (greedy/optimizer.hpp:174-190): the width of the new B (cached on accept) and
+      // its width without the sliced indices, which gates the move
+      [[maybe_unused]] double new_width_B = 0;
+      bool fits = true;
+      if constexpr (FW) {
+        double sliced_width;
+        if (!GENERIC || (F.log2dims == nullptr && P.sparse == nullptr)) {  // log2(d) * count (simple.hpp:43-47)
+          const uint32_t x = gsum<LOG2L>(mpopc<K>(newB) | (mpopc<K>(mandn<K>(newB, sl)) << 16));
+          new_width_B = fw_wr(F, F.log2d * (double)(x & 0xffffu));
+          sliced_width = fw_wr(F, F.log2d * (double)(x >> 16));
+        } else {
+          new_width_B = fw_width<LOG2L, K>(P, F, newB, lig, gbase);
+          sliced_width = fw_width<LOG2L, K>(P, F, mandn<K>(newB, sl), lig, gbase);
+        }
+        fits = sliced_width <= F.max_width;
+      }
       double nA, nB;  // optimizer.hpp:152-155
       if constexpr (!GENERIC) {
         nA = pow2_cost(log2d * (pick0 ? pcA0 : pcA1), 0);
         nB = pow2_cost(log2d * (pick0 ? pcB0 : pcB1), 0);
       } else {
-        nA = generic_cost<LOG2L, K>(P, mor<K>(newB, mE), lig, gbase, sdims);
-        nB = generic_cost<LOG2L, K>(P, mor<K>(mD, mC), lig, gbase, sdims);
+        nA = generic_cost<LOG2L, K>(P, mor<K>(mor<K>(newB, mE), sl), lig, gbase, sdims);
+        nB = generic_cost<LOG2L, K>(P, mor<K>(mor<K>(mD, mC), sl), lig, gbase, sdims);
       }
       const double delta = rnd_cost(rnd_cost(nB - ccB, f32) + rnd_cost(nA - ccA, f32), f32);  // :158
       ++n_moves;
 
-      const double u = rng.uniform01();  // :162 (always drawn)
-      acc = accept_move(prob_kind, beta, delta, total, u, f32);
+      // :162 (always drawn; finite width: only for a move that fits, greedy/optimizer.hpp:188-201)
+      if (fits) {
+        const double u = rng.uniform01();
+        acc = accept_move(prob_kind, beta, delta, total, u, f32);
+      }
 
       double pEcur = pE, pCcur = pC;  // partials of B's / A's other child after the move
       M mBnow, mX;                     // legs of B / of A's other child after the move
       stB = B; stA = A; stC = C; stE = E;
+      if constexpr (FW) stW = wB;
       if (acc) {
         ++n_acc;
+        if constexpr (FW) {  // :216  width_B = new_width_B
+          if (F.width_f32) stW = __float_as_int((float)new_width_B);
+          stW64 = new_width_B;
+        }
         // Tree::swap_with_nn(E): include/tnco/tree.hpp:176-184
         if (pick0) br = C; else bl = C;
         if (c_is_right) ar = E; else al = E;
@@ -571,6 +627,7 @@ __global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : TNCO_WAVES_PER_SIMD)) void s
     // Everything requested above is needed before the first store below: vmcnt is in order, so
     // waiting for these loads later would also wait for the stores.
     TNCO_LANDED(gL); TNCO_LANDED(gR); TNCO_LANDED(gP); TNCO_LANDED(gC);
+    if constexpr (FW) TNCO_LANDED(gW);
     TNCO_LANDED(gMp); TNCO_LANDED(gXlo); TNCO_LANDED(gXhi);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -606,8 +663,11 @@ __global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : TNCO_WAVES_PER_SIMD)) void s
     if (did_move || did_end) {
       if (lane0) {
         NodeRec o;
-        o.left = stL; o.right = stR; o.parent = stA; o.pad = 0; o.ccost = stCC; o.partial = stPart;
+        o.left = stL; o.right = stR; o.parent = stA; o.pad = FW ? stW : 0; o.ccost = stCC; o.partial = stPart;
         *v.hdr(stB) = o;
+        if constexpr (FW) {
+          if (did_move && acc && !F.width_f32) F.width64[(int64_t)rng.r32 * N + stB] = stW64;
+        }
       }
       // Experiment (off): HBM writes whole 64-byte pieces and a shorter write is a read-modify-write
       // there (tools/hbm_random.hip), so complete the 32-byte header with legs 0..3, unchanged.
@@ -634,6 +694,7 @@ __global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : TNCO_WAVES_PER_SIMD)) void s
       A = x_aP;
       raL = rnL; raR = rnR; raP = rnP; raC = rnC;
       rnL = gL; rnR = gR; rnP = gP; rnC = gC;
+      if constexpr (FW) { wB = raW; raW = rnW; rnW = gW; }
       mC = gM;
       pC = gMp;
       state = (A < 0) ? S_END : S_MOVE;
@@ -642,18 +703,21 @@ __global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : TNCO_WAVES_PER_SIMD)) void s
       state = S_GOT_B;
     } else if (state == S_GOT_B) {
       bl = gL; br = gR; A = gP; ccB = gC;
+      if constexpr (FW) wB = gW;
       partB = __hiloint2double((int)gXhi, (int)gXlo);
       state = S_GOT_HB;
     } else if (state == S_GOT_HB) {
       m0 = gM; p0 = gMp;
       total = __hiloint2double((int)gXhi, (int)gXlo);
       raL = gL; raR = gR; raP = gP; raC = gC;
+      if constexpr (FW) raW = gW;
       if constexpr (HYPER) { iB = gI; hB = gH; }
       state = S_GOT_B1;
     } else if (state == S_GOT_B1) {
       m1 = gM; p1 = gMp;
       beta = __hiloint2double((int)gXhi, (int)gXlo);
       rnL = gL; rnR = gR; rnP = gP; rnC = gC;
+      if constexpr (FW) rnW = gW;
       if constexpr (HYPER) { iA = gI; hA = gH; }
       state = (A < 0) ? S_END : S_GOT_HA;
     } else if (state == S_GOT_HA) {
@@ -666,6 +730,13 @@ __global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : TNCO_WAVES_PER_SIMD)) void s
     for (int q = lig; q < 4; q += L)
       *reinterpret_cast<int4*>(jlog() + (jtail & ~15u) + 4 * q) =
           make_int4(jb(4 * q + 0), jb(4 * q + 1), jb(4 * q + 2), jb(4 * q + 3));
+  }
+  if constexpr (FW) {
+    if (impr_any) {  // :385-389  min_slices = slices (the slices did not change during these sweeps)
+      uint64_t* s1 = F.slices + r * 2 * (int64_t)(L * K) + L * K;
+#pragma unroll
+      for (int k = 0; k < K; ++k) s1[v.widx(k)] = sl.w[k];
+    }
   }
   int mti, mtw;
   rng.finish(mti, mtw);
