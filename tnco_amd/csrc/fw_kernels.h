@@ -67,8 +67,8 @@ __device__ __forceinline__ double fw_log2dim(const FwParams& F, int pos) {
 }
 
 // /usr/include/c++/11/bits/uniform_int_dist.h:246-321, 32-bit generator, range < 2^32
-template <int LOG2L>
-__device__ __forceinline__ uint32_t fw_uniform_int(Rng<LOG2L>& rng, uint32_t hi) {
+template <int LOG2L, typename RNG>
+__device__ __forceinline__ uint32_t fw_uniform_int(RNG& rng, uint32_t hi) {
   const uint32_t uerange = hi + 1u;
   uint64_t product = (uint64_t)rng.next_sync() * (uint64_t)uerange;
   uint32_t low = (uint32_t)product;
@@ -84,8 +84,8 @@ __device__ __forceinline__ uint32_t fw_uniform_int(Rng<LOG2L>& rng, uint32_t hi)
 
 // std::shuffle of /usr/include/c++/11/bits/stl_algo.h:3706-3792 on a scratch array (n < 65536: two
 // swap positions per variate).  Executed redundantly by every lane of the group; lane 0 writes.
-template <int LOG2L, typename A>
-__device__ __forceinline__ void fw_shuffle(Rng<LOG2L>& rng, A a, int n, bool lane0) {
+template <int LOG2L, typename RNG, typename A>
+__device__ __forceinline__ void fw_shuffle(RNG& rng, A a, int n, bool lane0) {
   if (n <= 1) return;
   int i = 1;
   auto swp = [&](int x, int y) {
@@ -105,6 +105,69 @@ __device__ __forceinline__ void fw_shuffle(Rng<LOG2L>& rng, A a, int n, bool lan
     ++i;
     swp(i, (int)p1);
     ++i;
+  }
+}
+
+// uniform_int_distribution on a raw output already drawn (the rare re-draws come from the ring)
+template <int LOG2L, typename RNG>
+__device__ __forceinline__ uint32_t fw_uniform_int_from(RNG& rng, uint32_t raw, uint32_t hi) {
+  const uint32_t uerange = hi + 1u;
+  uint64_t product = (uint64_t)raw * (uint64_t)uerange;
+  uint32_t low = (uint32_t)product;
+  if (low < uerange) {
+    const uint32_t threshold = (0u - uerange) % uerange;
+    while (low < threshold) {
+      product = (uint64_t)rng.next_sync() * (uint64_t)uerange;
+      low = (uint32_t)product;
+    }
+  }
+  return (uint32_t)(product >> 32);
+}
+
+// The same std::shuffle on an LDS array, arranged for latency: the loads of the generator's next
+// block are issued as soon as there is room for it; the raw output of the NEXT pair of swaps is
+// read from the ring before this pair's LDS traffic; the four array reads of a pair (a[i], a[i + 1]
+// early, a[p0], a[p1] together once the variate is known) are independent, and the four writes in
+// program order give exactly the two swaps (the second swap sees the first through the selects).
+template <int LOG2L, typename RNG>
+__device__ __forceinline__ void fw_shuffle_lds(RNG& rng, lds_vi32* a, int n, bool lane0) {
+  if (n <= 1) return;
+  // The generator: the sixteen replicas of a wavefront are at sixteen different phases of their
+  // 16-word blocks, so "refill when there is room" makes the wavefront run the (long) request and
+  // produce code at nearly every draw.  Instead every replica fills its ring now and, the draws
+  // being one per iteration for all of them, all request a block at the same iterations (every
+  // 16th) and produce it eight iterations later, its loads long landed.  (next_sync() still fetches
+  // on demand should a ring run dry: re-draws of uniform_int, rings smaller than 64.)
+  while (rng.room()) {
+    rng.request();
+    rng.produce();
+  }
+  int i = 1;
+  if ((n % 2) == 0) {
+    const uint32_t j = fw_uniform_int_from<LOG2L>(rng, rng.next_sync(), 1u);
+    const int a1 = a[1], aj = a[j];
+    if (lane0) { a[1] = aj; a[j] = a1; }
+    i = 2;
+  }
+  if (i == n) return;
+  uint32_t raw = rng.next_sync();
+  for (int it = 0; i != n; ++it) {
+    const int ai = a[i], ai1 = a[i + 1];
+    const uint32_t sr = (uint32_t)i + 1u;
+    const uint32_t x = fw_uniform_int_from<LOG2L>(rng, raw, sr * (sr + 1u) - 1u);
+    const uint32_t p0 = x / (sr + 1u), p1 = x - p0 * (sr + 1u);
+    if ((it & 15) == 15) rng.prefetch();
+    if ((it & 15) == 7 && rng.pend) rng.produce();
+    if (i + 2 != n) raw = rng.next_sync();  // (only if another pair follows: no draw may be consumed in vain)
+    const int ap0 = a[p0], ap1 = a[p1];
+    const int v1 = (p1 == (uint32_t)i) ? ap0 : ((p1 == p0) ? ai : ((p1 == (uint32_t)i + 1u) ? ai1 : ap1));
+    if (lane0) {
+      a[i] = ap0;
+      a[p0] = ai;
+      a[i + 1] = v1;
+      a[p1] = ai1;
+    }
+    i += 2;
   }
 }
 
@@ -446,55 +509,75 @@ __device__ __forceinline__ uint32_t fw_positions(const View<LOG2L, K, HYPER>& v,
 #endif
 constexpr int FW_LDSPOS = TNCO_FW_LDSPOS;  // candidate legs per tensor that fit the LDS fast path
 
+#if defined(TNCO_PROFILE) && TNCO_PROFILE == 4  // cycles inside the greedy pass: [scan, positions, shuffle, keys + picks]
+#define FW_GP_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define FW_GP_ADD(i, a, b) do { if (cnt) cnt[i] += (b) - (a); } while (0)
+#define FW_GP_COUNT(i, x)
+#else
+#define FW_GP_T(var)
+#define FW_GP_ADD(i, a, b)
+#define FW_GP_COUNT(i, x) do { if (cnt) cnt[i] += (x); } while (0)
+#endif
+
 // A tensor that is still too wide after the slices chosen so far (sliced_xs = its legs - slices, of
 // width sliced_width): shuffle its candidate legs and slice them in the order of `greater` until it
 // fits (finite_width/greedy/utils.hpp:72-101).
-template <int LOG2L, int K, bool HYPER>
+template <int LOG2L, int K, bool HYPER, typename RNG>
 __device__ __forceinline__ void fw_slice_wide(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
-                                              Rng<LOG2L>& rng, const int32_t* n_big, volatile int16_t* pos,
+                                              RNG& rng, const int32_t* n_big, volatile int16_t* pos,
                                               lds_vi32* lpos, bool lane0, int gbase, int32_t* status,
                                               const Mask<K>& skip, Mask<K> sliced_xs, double sliced_width,
                                               Mask<K>& slices, unsigned long long* cnt) {
   constexpr int L = 1 << LOG2L;
   const int lig = v.lig;
-  if (cnt) cnt[1] += 1;  // ... still too wide after the slices so far: shuffled and picked from
+  FW_GP_COUNT(1, 1);  // ... still too wide after the slices so far: shuffled and picked from
   // candidate positions, ascending
   const Mask<K> cand = mandn<K>(sliced_xs, skip);
   if (F.log2dims == nullptr && fw_count<LOG2L, K>(cand) <= (uint32_t)FW_LDSPOS) {
     // Fast path (uniform dims, the usual number of candidates): the candidate list lives in LDS.
-    // Same draws, same order: shuffle, then the keys are attached ((n_big << 16) | position) and
-    // every pick is a scan shared by the lanes of the group + one DPP max; a taken entry keeps
-    // key 0 (a candidate's key is >= 1: the tensor itself is too wide).
+    // Same draws, same order: shuffle, then the keys are attached and every pick is a scan shared
+    // by the lanes of the group + one DPP max (a candidate's key is >= 1: the tensor itself is too
+    // wide, so 0 can stand for "taken").
+    FW_GP_T(t0_);
+    rng.prefetch();  // (the generator's next block travels while the positions are listed)
     const uint32_t np = fw_positions<LOG2L, K, HYPER>(v, cand, lpos, (uint32_t)FW_LDSPOS, gbase, lane0, status);
-    fw_shuffle<LOG2L>(rng, lpos, (int)np, lane0);
-    if (cnt) cnt[2] += np;  // candidate legs
-    for (uint32_t q0 = (uint32_t)lig; q0 < np; q0 += 4 * L) {  // (four gathers in flight per lane)
-      int xp[4], kb[4];
+    FW_GP_T(t1_);
+    fw_shuffle_lds<LOG2L>(rng, lpos, (int)np, lane0);
+    FW_GP_T(t2_);
+    FW_GP_ADD(1, t0_, t1_);
+    FW_GP_ADD(2, t1_, t2_);
+    FW_GP_COUNT(2, np);  // candidate legs
+    // Keys ((too-wide count << 16) | 0xFFFF - shuffled rank: the stable order of :83) stay in
+    // registers, FW_LDSPOS / L per lane, gathered in one flight; a pick is a register scan + one DPP
+    // max over the group, a taken candidate's key becomes 0.  LDS keeps the shuffled positions.
+    constexpr int G = FW_LDSPOS / L;
+    uint32_t ck[G];
+    {
+      int xp[G];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xp[i] = q0 + i * L < np ? (int)lpos[q0 + i * L] : 0;
+      for (int i = 0; i < G; ++i) xp[i] = (uint32_t)(lig + i * L) < np ? (int)lpos[lig + i * L] : 0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) kb[i] = n_big[xp[i]];
+      for (int i = 0; i < G; ++i) ck[i] = ((uint32_t)(lig + i * L) < np) ? (uint32_t)n_big[xp[i]] : 0u;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (q0 + i * L < np) lpos[q0 + i * L] = (kb[i] << 16) | xp[i];
+      for (int i = 0; i < G; ++i) ck[i] = ck[i] ? ((ck[i] << 16) | (0xFFFFu - (uint32_t)(lig + i * L))) : 0u;
     }
     for (uint32_t taken = 0; taken < np; ++taken) {
       uint32_t best = 0;
-      for (uint32_t q = (uint32_t)lig; q < np; q += L) {
-        const uint32_t key = (uint32_t)lpos[q] >> 16;
-        const uint32_t c = (key << 16) | (0xFFFFu - q);
-        if (key != 0u && c > best) best = c;
-      }
+#pragma unroll
+      for (int i = 0; i < G; ++i) best = ck[i] > best ? ck[i] : best;
       best = gmax<LOG2L>(best);
+#pragma unroll
+      for (int i = 0; i < G; ++i) ck[i] = (ck[i] == best) ? 0u : ck[i];
       const uint32_t qb = 0xFFFFu - (best & 0xFFFFu);
-      const int xpos = lpos[qb] & 0xFFFF;
-      if (lane0) lpos[qb] = xpos;
+      const int xpos = lpos[qb];
       fw_flip<LOG2L, K, HYPER>(v, slices, xpos);
       sliced_width = fw_wr(F, sliced_width + fw_delta_width<LOG2L, K, HYPER>(P, F, v, sliced_xs, xpos, gbase));
       fw_flip<LOG2L, K, HYPER>(v, sliced_xs, xpos);
-      if (cnt) cnt[3] += 1;  // picks
+      FW_GP_COUNT(3, 1);  // picks
       if (sliced_width <= F.max_width) break;
     }
+    FW_GP_T(t3_);
+    FW_GP_ADD(3, t2_, t3_);
     return;
   }
   uint32_t np = fw_positions<LOG2L, K, HYPER>(v, cand, pos, (uint32_t)F.I64, gbase, lane0, status);
@@ -627,9 +710,9 @@ __device__ __forceinline__ int fw_gs_mark(const Params& P, const FwParams& F, co
 }
 
 // Part 2, :62-101: the greedy pass over the nw too-wide tensors in post-order; returns the new slices.
-template <int LOG2L, int K, bool HYPER>
+template <int LOG2L, int K, bool HYPER, typename RNG>
 __device__ __forceinline__ Mask<K> fw_gs_pick(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
-                                              Rng<LOG2L>& rng, const FwScratch& sc, int nw, lds_vi32* lpos,
+                                              RNG& rng, const FwScratch& sc, int nw, lds_vi32* lpos,
                                               bool lane0, int gbase, int32_t* status,
                                               unsigned long long* cnt = nullptr) {
   const int lig = v.lig;
@@ -656,13 +739,14 @@ __device__ __forceinline__ Mask<K> fw_gs_pick(const Params& P, const FwParams& F
       bool have = false;
       Mask<K> sx = mzero<K>();
       double sw = 0.0;
+      FW_GP_T(ts0_);
       while (j < nw) {
         const Mask<K> m = ma;
         ta = tb;
         ++j;
         ma = v.mask(ta);  // (past the end of the list: any tensor)
         tb = wlist[j + 1 < nw ? j + 1 : nw - 1];
-        if (cnt) cnt[0] += 1;  // too-wide tensors
+        FW_GP_COUNT(0, 1);  // too-wide tensors
         sx = mandn<K>(m, slices);
         sw = fw_width<LOG2L, K>(P, F, sx, lig, gbase);
         if (sw > F.max_width) {
@@ -670,6 +754,8 @@ __device__ __forceinline__ Mask<K> fw_gs_pick(const Params& P, const FwParams& F
           break;
         }
       }
+      FW_GP_T(ts1_);
+      FW_GP_ADD(0, ts0_, ts1_);
       if (!have) break;
       fw_slice_wide<LOG2L, K, HYPER>(P, F, v, rng, n_big, pos, lpos, lane0, gbase, status, skip, sx, sw, slices, cnt);
     }
@@ -677,9 +763,9 @@ __device__ __forceinline__ Mask<K> fw_gs_pick(const Params& P, const FwParams& F
   return slices;
 }
 
-template <int LOG2L, int K, bool HYPER>
+template <int LOG2L, int K, bool HYPER, typename RNG>
 __device__ __forceinline__ Mask<K> fw_get_slices(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
-                                                 const double* w64, Rng<LOG2L>& rng, const FwScratch& sc, FwStack st,
+                                                 const double* w64, RNG& rng, const FwScratch& sc, FwStack st,
                                                  lds_vi32* lpos, bool lane0, int gbase, int32_t* status,
                                                  unsigned long long* prof = nullptr,
                                                  unsigned long long* cnt = nullptr, int nw_pre = -1) {
@@ -717,13 +803,22 @@ __global__ __launch_bounds__(256) void fw_leaf_bits_kernel(const Params P, const
 #ifndef TNCO_FW_WALK_CAP
 #define TNCO_FW_WALK_CAP 40
 #endif
+#ifndef TNCO_FW_WALK_LANES
+#define TNCO_FW_WALK_LANES 32
+#endif
 constexpr int FW_WALK_CAP = TNCO_FW_WALK_CAP;
+// Only FW_WALK_LANES lanes of a wavefront carry a replica: with all 64 busy, 65536 replicas are one
+// wavefront per SIMD, and nothing overlaps that wavefront's LDS / ALU latency with its memory waits;
+// half-empty wavefronts give every SIMD two.
+constexpr int FW_WALK_LANES = TNCO_FW_WALK_LANES;
+constexpr int FW_WALK_PER_BLOCK = 4 * FW_WALK_LANES;  // replicas per 256-thread block
 
 static __global__ __launch_bounds__(256) void fw_walk_kernel(const Params P, const FwParams F) {
   __shared__ int32_t se[FW_WALK_CAP * 256];
   __shared__ uint16_t sl[FW_WALK_CAP * 256];
   const int tid = threadIdx.x;
-  const int64_t r = (int64_t)blockIdx.x * 256 + tid;
+  if ((tid & 63) >= FW_WALK_LANES) return;
+  const int64_t r = (int64_t)blockIdx.x * FW_WALK_PER_BLOCK + (tid >> 6) * FW_WALK_LANES + (tid & 63);
   if (r >= P.R) return;
   const int n = P.n, N = P.N, LK = F.I64 / 64;
   {  // greedy/optimizer.hpp:359: nothing to do without slices
@@ -882,7 +977,7 @@ __global__ __launch_bounds__(256, 2) void fw_init_kernel(const Params P, const F
     fa_[2] += ft_[3] - ft_[2]; fa_[3] += ft_[4] - ft_[3];        \
     fa_[4] += 1;                                                 \
   } while (0)
-#if TNCO_PROFILE == 3
+#if TNCO_PROFILE == 3 || TNCO_PROFILE == 4
 #define FW_PROF_OUT(rs)                                          \
   for (int k_ = 0; k_ < 4; ++k_) (rs)->pad1[k_] += fc_[k_];      \
   (rs)->pad1[4] += fa_[4]
@@ -1232,10 +1327,9 @@ __global__ __launch_bounds__(256, 2) void fw_reslice_kernel(const Params P, cons
   constexpr int GPB = 256 >> LOG2L;
   constexpr int LK = L * K;
   using M = Mask<K>;
-  using R = Rng<LOG2L>;
+  using R = Rng<LOG2L, 64>;  // (a ring of 64 outputs: the lock-step refills of fw_shuffle_lds)
   __shared__ uint32_t rngbuf[GPB * R::RING];
-  __shared__ __attribute__((aligned(8))) int32_t posbuf[GPB * FW_LDSPOS];  // candidate legs / traversal stack / partial sums
-  __shared__ uint16_t leftbuf[GPB * FW_LDSPOS];  // traversal stack: left children
+  __shared__ __attribute__((aligned(8))) int32_t posbuf[GPB * FW_LDSPOS];  // candidate legs / partial sums
   const int tid = threadIdx.x;
   const int lig = tid & (L - 1);
   const int gib = tid >> LOG2L;
@@ -1243,7 +1337,9 @@ __global__ __launch_bounds__(256, 2) void fw_reslice_kernel(const Params P, cons
   const int64_t r = (int64_t)blockIdx.x * GPB + gib;
   if (r >= P.R) return;
   lds_vi32* lpos = (lds_vi32*)posbuf + gib * FW_LDSPOS;
-  const FwStack st{F.stack_cap > 0 ? lpos : nullptr, (lds_vu16*)leftbuf + gib * FW_LDSPOS, F.stack_cap};
+  // (the walk is fw_walk_kernel's; without it -- trees of more than 8192 nodes, test knobs -- the
+  // links are walked in place, no LDS stack)
+  const FwStack st{nullptr, nullptr, 0};
   const bool lane0 = lig == 0;
   const int n = P.n, N = P.N;
   View<LOG2L, K, HYPER> v;
@@ -1261,7 +1357,7 @@ __global__ __launch_bounds__(256, 2) void fw_reslice_kernel(const Params P, cons
   if (gany<LOG2L>(mnonzero<K>(slices))) {
     R rng;
     rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
-#if defined(TNCO_PROFILE) && TNCO_PROFILE == 3  // event counts instead of cycles
+#if defined(TNCO_PROFILE) && (TNCO_PROFILE == 3 || TNCO_PROFILE == 4)  // event counts / greedy-pass cycles instead
     const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, sc, st, lpos, lane0, gbase, F.status + r, nullptr, fc_, nw_pre);
 #elif defined(TNCO_PROFILE)
     unsigned long long fp_[2] = {0, 0};  // end of the walk, end of the counts

@@ -32,7 +32,7 @@ struct FwParams {
 // the candidate legs of one tensor (int16, for the shuffle when they do not fit the LDS fast path)
 // [I64: every index can be one], the post-order records of the internal nodes (fw_rec, 8 bytes)
 // [n - 1], the too-wide tensors in post-order [N], the deep part of the traversal stack [N].
-__host__ __device__ inline int64_t fw_np(int N) { return (N + 3) & ~3; }
+__host__ __device__ inline int64_t fw_np(int N) { return (N + 15) & ~15; }  // (64-byte pieces: fw_walk_kernel)
 __host__ __device__ inline int64_t fw_scratch_ints(int N, int I64) { return I64 + I64 / 2 + 3 * fw_np(N); }
 struct FwScratch {
   int32_t* n_big;

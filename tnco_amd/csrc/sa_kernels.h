@@ -68,7 +68,7 @@ struct Params {
   uint8_t* blocks;           // [R][n-1][BS]
   int32_t* lpar;             // [R][n][LPS]   parent of every leaf (one 64-byte record per leaf)
   uint32_t* mt;              // [R][624]
-  uint32_t* mtshadow;        // [R][32]       generation-g words overwritten ahead of consumption
+  uint32_t* mtshadow;        // [R][MT_SHADOW = 64]      generation-g words overwritten ahead of consumption
   ReplicaState* rs;          // [R]
   Links* minlinks;           // [R][N]        best-tree checkpoint (links only; legs re-derived on read)
   int32_t* jlog;             // [R][jcap]     node E of every accepted rotation since the checkpoint

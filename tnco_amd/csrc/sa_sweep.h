@@ -69,22 +69,25 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t z) {
 // outputs ahead of consumption; when that crosses into the next generation the overwritten
 // words are kept in a shadow so that the exported state is exactly libstdc++'s at `cons`.
 // ---------------------------------------------------------------------------
-template <int LOG2L>
+constexpr int MT_SHADOW = 64;  // words of P.mtshadow per replica: the largest ring any kernel uses
+
+template <int LOG2L, int RINGX = 0>
 struct Rng {
   static constexpr int L = 1 << LOG2L;
   static constexpr int NL = L < 4 ? L : 4;         // lanes of the group that work on a block
   static constexpr int SB = 4 * NL;                // words per block: 4 per lane (one dwordx4); 624 % 16 == 0
-  static constexpr int RING = (2 * SB > 16) ? 2 * SB : 16;
+  static constexpr int RING = RINGX ? RINGX : ((2 * SB > 16) ? 2 * SB : 16);
+  static_assert(RING <= MT_SHADOW && (RING & (RING - 1)) == 0 && RING >= 2 * SB, "ring size");
 
   struct __attribute__((packed, aligned(4))) U4 { uint32_t x[4]; };  // 4 words at any word address
 
   uint32_t* mt_base;       // P.mt      (uniform; the replica's words start at 624 * r)
-  uint32_t* sh_base;       // P.mtshadow (uniform; 32 * r)
+  uint32_t* sh_base;       // P.mtshadow (uniform; MT_SHADOW * r)
   uint32_t r32;            // replica index
   lds_vu32* ring;          // group's LDS ring
   int lig;
   __device__ __forceinline__ uint32_t* st() const { return mt_base + (uint64_t)r32 * 624u; }
-  __device__ __forceinline__ uint32_t* shadow() const { return sh_base + (uint64_t)r32 * 32u; }
+  __device__ __forceinline__ uint32_t* shadow() const { return sh_base + (uint64_t)r32 * (uint32_t)MT_SHADOW; }
   uint32_t cons, prod, tw;
   bool pend, ptw;          // a block's inputs are in flight (for virtual position prod); it needs a twist
   // this lane's inputs: mt[k..k+3], mt[k+4], mt[k+397..k+400] (indices mod 624); written ONLY by
@@ -139,7 +142,7 @@ struct Rng {
         const int sidx = (int)(prod % 624u) + 4 * lig;
         *reinterpret_cast<uint4*>(st() + sidx) = make_uint4(v[0], v[1], v[2], v[3]);
         // a block of the generation after the one being consumed: keep the old words (sidx < RING
-        // <= 32: production runs at most RING words ahead of consumption)
+        // <= MT_SHADOW: production runs at most RING words ahead of consumption)
         if ((prod / 624u) > gen_of_cons())
           *reinterpret_cast<uint4*>(shadow() + sidx) = make_uint4(pa[0], pa[1], pa[2], pa[3]);
       }
@@ -179,6 +182,12 @@ struct Rng {
     }
     return next();
   }
+  // issue the loads of the next block if there is room for one (its latency then overlaps whatever
+  // comes before the draw that needs it)
+  __device__ __forceinline__ void prefetch() {
+    if (room()) request();
+  }
+  __device__ __forceinline__ uint32_t avail() const { return prod - cons; }
   // std::uniform_real_distribution<double>{} == generate_canonical<double,53>
   // (random.tcc:3348-3380): low word first, one rounding, scale by 2^-64.
   __device__ __forceinline__ double uniform01() {
@@ -752,7 +761,7 @@ __global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
     rs->n_randpick += cold.n_rpick;
     rs->mti = mti;
     rs->mtw = mtw;
-    TNCO_PROF_OUT(rs);
+    if constexpr (!FW) { TNCO_PROF_OUT(rs); }
   }
 }
 

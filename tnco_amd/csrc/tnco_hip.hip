@@ -110,7 +110,8 @@ void launch_fw_init(tnco_hip_ctx* h, const FwInitArgs& a) {
 
 // (one lane per replica: the same kernel whatever the lane layout of the handle)
 void launch_fw_walk(tnco_hip_ctx* h) {
-  hipLaunchKernelGGL(fw_walk_kernel, dim3((unsigned)((h->P.R + 255) / 256)), dim3(256), 0, h->stream, h->P, h->F);
+  hipLaunchKernelGGL(fw_walk_kernel, dim3((unsigned)((h->P.R + FW_WALK_PER_BLOCK - 1) / FW_WALK_PER_BLOCK)), dim3(256), 0, h->stream,
+                     h->P, h->F);
 }
 
 // n_steps sweeps of the finite-width optimizer: [moves up to and including the next re-slicing
@@ -449,7 +450,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   HIP_TRY(h->alloc(&P.blocks, R * h->block_bytes()));
   HIP_TRY(h->alloc(&P.lpar, R * n * LPS + 16));  // the sweep kernel reads 8 bytes at a leaf's record
   HIP_TRY(h->alloc(&P.mt, R * 624));
-  HIP_TRY(h->alloc(&P.mtshadow, R * 32));
+  HIP_TRY(h->alloc(&P.mtshadow, R * MT_SHADOW));
   HIP_TRY(h->alloc(&P.rs, R));
   HIP_TRY(h->alloc(&P.minlinks, R * N));
   HIP_TRY(h->alloc(&P.jlog, R * (int64_t)P.jcap));

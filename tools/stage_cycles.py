@@ -69,6 +69,8 @@ def fw(a):
     L.tnco_hip_get_stage_cycles(opt._h, cyc.ctypes.data_as(C.c_void_p))
     cyc = (cyc - base).astype(np.float64)
     names = ["walk (post-order, widths)", "get_slices: too-wide counts", "get_slices: greedy pass", "rebuild + commit"]
+    if a.fine:  # library built with -DTNCO_PROFILE=4: cycles inside the greedy pass
+        names = ["scan for the next tensor that does not fit", "candidate positions", "shuffle", "keys + picks"]
     print(f"re-slices {cyc[4]:.3e} over {a.replicas} replicas (re-slicing sweeps only)")
     for k in range(4):
         print(f"  {names[k]:28s} {cyc[k] / cyc[4]:12.0f} cycles per re-slicing sweep  {100 * cyc[k] / cyc[:4].sum():5.1f} %")
