@@ -342,11 +342,15 @@ __device__ __forceinline__ int fw_traverse(const Params& P, const FwParams& F, c
 // left child's sum is the top of the stack of finished subtrees; a node with two leaf children
 // pushes (pstk[]: consecutive doubles, the same few lines again and again).
 typedef TNCO_LDS volatile double lds_vdouble;
+typedef TNCO_LDS volatile uint64_t lds_vu64;
 
 template <int LOG2L, int K, bool HYPER, int B = 4>
 __device__ __forceinline__ double fw_rebuild(const Params& P, const View<LOG2L, K, HYPER>& v, const uint64_t* rec,
                                              const Mask<K>& slices, double2* cp, double* pstk, bool lane0,
-                                             int gbase, double* sum, lds_vdouble* lstk = nullptr, int lcap = 0) {
+                                             int gbase, double* sum, lds_vdouble* lstk = nullptr, int lcap = 0,
+                                             lds_vu64* lmask = nullptr, int mcap = 0) {
+  constexpr int L = 1 << LOG2L;
+  constexpr int LK = L * K;
   const int n = P.n, ni = P.N - P.n;
   double s = 0.0, part = 0.0;
   if (ni <= 0) {
@@ -354,21 +358,22 @@ __device__ __forceinline__ double fw_rebuild(const Params& P, const View<LOG2L, 
     return 0.0;
   }
   auto ld_rec = [&](int j) -> uint64_t { return rec[j < ni ? j : ni - 1]; };
-  // Without hyper-indices the legs of an internal node are left ^ right (tnco/ctree.py:163-189), and
-  // in post-order an internal RIGHT child is the node just before its parent: its legs are still in
-  // registers (`prev`), so only leaves (the shared leaf table, L2) and internal LEFT children are
-  // read -- half of the random reads of node blocks.  (A skipped child reads leaf 0 instead: one
-  // unconditional load per slot, "a loaded value has one definition".)
-  auto right_src = [&](uint64_t r) -> int {
-    const int rr = fw_rec_right(r);
-    return (!HYPER && rr >= n) ? 0 : rr;
-  };
+  // Without hyper-indices the legs of an internal node are left ^ right (tnco/ctree.py:163-189), so
+  // the rebuild needs no leg mask of an internal node from memory.  In post-order the subtree
+  // finished last is in registers (`prev`: the legs of its root, `part`: its partial sum): it is the
+  // right child of the next node if that one's right child is internal, else its left child if that
+  // is internal.  A node with two internal children takes its left child from the stack of finished
+  // subtrees, where a subtree goes when the next node starts a new one (two leaf children).  The
+  // stack's first entries are in LDS (partial sums: lcap, legs: mcap); deeper partial sums go to
+  // global scratch, deeper legs are not kept and read from the node block when needed (that read is
+  // predicted when the batch's loads are issued: the stack depth follows from the records alone).
+  // Only leaf legs (the shared table, L2) are read otherwise.  (A skipped read fetches leaf 0
+  // instead: one unconditional load per slot, "a loaded value has one definition".)
   uint64_t rc[B];
 #pragma unroll
   for (int i = 0; i < B; ++i) rc[i] = ld_rec(i);
   Mask<K> prev = mzero<K>();
-  int sp = 0;  // finished subtrees not yet consumed: the newest in `part`, the others in pstk[0 .. sp - 2]
-  // (the stack of partial sums: its first lcap entries in LDS, deeper ones in global scratch)
+  int sp = 0;  // finished subtrees not yet consumed: the newest in registers, the others on the stack [0, sp - 1)
   auto stk_get = [&](int i) -> double { return i < lcap ? lstk[i] : pstk[i]; };
   auto stk_put = [&](int i, double x) {
     if (i < lcap) lstk[i] = x; else pstk[i] = x;
@@ -376,10 +381,21 @@ __device__ __forceinline__ double fw_rebuild(const Params& P, const View<LOG2L, 
   for (int j0 = 0; j0 < ni; j0 += B) {
     Mask<K> ml[B], mr[B];
     uint64_t rn[B];
+    {
+      int spp = sp;  // the stack depth when each record of the batch is reached
 #pragma unroll
-    for (int i = 0; i < B; ++i) {
-      ml[i] = v.mask(fw_rec_left(rc[i]));
-      mr[i] = v.mask(right_src(rc[i]));
+      for (int i = 0; i < B; ++i) {
+        const int l = fw_rec_left(rc[i]), rr = fw_rec_right(rc[i]);
+        const bool li = l >= n, ri = rr >= n;
+        int lsrc = l, rsrc = rr;
+        if constexpr (!HYPER) {
+          if (ri) rsrc = 0;                                   // right child: the subtree finished last
+          if (li && (!ri || spp - 2 < mcap)) lsrc = 0;        // left child: the subtree finished last / an LDS entry
+        }
+        ml[i] = v.mask(lsrc);
+        mr[i] = v.mask(rsrc);
+        spp += (li && ri) ? -1 : ((!li && !ri) ? 1 : 0);
+      }
     }
 #pragma unroll
     for (int i = 0; i < B; ++i) rn[i] = ld_rec(j0 + B + i);
@@ -388,9 +404,21 @@ __device__ __forceinline__ double fw_rebuild(const Params& P, const View<LOG2L, 
       if (j0 + i < ni) {
         const int l = fw_rec_left(rc[i]), rr = fw_rec_right(rc[i]);
         const bool li = l >= n, ri = rr >= n;
-        const Mask<K> mright = (!HYPER && ri) ? prev : mr[i];
-        const Mask<K> u = mor<K>(mor<K>(ml[i], mright), slices);
-        if constexpr (!HYPER) prev = mxor<K>(ml[i], mright);
+        Mask<K> mleft = ml[i], mright = mr[i];
+        if constexpr (!HYPER) {
+          if (ri) mright = prev;
+          if (li && !ri) mleft = prev;
+          if (li && ri && sp - 2 < mcap) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) mleft.w[k] = lmask[(sp - 2) * LK + k * L + v.lig];
+          }
+          if (!li && !ri && sp >= 1 && sp - 1 < mcap) {  // a new subtree starts: the finished one waits on the stack
+#pragma unroll
+            for (int k = 0; k < K; ++k) lmask[(sp - 1) * LK + k * L + v.lig] = prev.w[k];
+          }
+        }
+        const Mask<K> u = mor<K>(mor<K>(mleft, mright), slices);
+        if constexpr (!HYPER) prev = mxor<K>(mleft, mright);
         const double c = generic_cost<LOG2L, K>(P, u, v.lig, gbase);
         s = rnd_cost(s + c, P.f32);
         if (lane0) {
@@ -509,6 +537,17 @@ __device__ __forceinline__ uint32_t fw_positions(const View<LOG2L, K, HYPER>& v,
 #endif
 constexpr int FW_LDSPOS = TNCO_FW_LDSPOS;  // candidate legs per tensor that fit the LDS fast path
 
+// too-wide counts per index (sc.n_big): bytes when one flush of the bit-sliced counters holds them
+template <int K>
+constexpr int FW_NBIG_PLANES = K <= 4 ? 8 : 5;
+template <int K>
+__device__ __forceinline__ bool fw_nbig8(int nw) {
+  return FW_NBIG_PLANES<K> == 8 && nw <= 255;
+}
+__device__ __forceinline__ int fw_nbig_at(const int32_t* n_big, bool nb8, int x) {
+  return nb8 ? (int)reinterpret_cast<const uint8_t*>(n_big)[x] : n_big[x];
+}
+
 #if defined(TNCO_PROFILE) && TNCO_PROFILE == 4  // cycles inside the greedy pass: [scan, positions, shuffle, keys + picks]
 #define FW_GP_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define FW_GP_ADD(i, a, b) do { if (cnt) cnt[i] += (b) - (a); } while (0)
@@ -524,7 +563,7 @@ constexpr int FW_LDSPOS = TNCO_FW_LDSPOS;  // candidate legs per tensor that fit
 // fits (finite_width/greedy/utils.hpp:72-101).
 template <int LOG2L, int K, bool HYPER, typename RNG>
 __device__ __forceinline__ void fw_slice_wide(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
-                                              RNG& rng, const int32_t* n_big, volatile int16_t* pos,
+                                              RNG& rng, const int32_t* n_big, const bool nb8, volatile int16_t* pos,
                                               lds_vi32* lpos, bool lane0, int gbase, int32_t* status,
                                               const Mask<K>& skip, Mask<K> sliced_xs, double sliced_width,
                                               Mask<K>& slices, unsigned long long* cnt) {
@@ -557,7 +596,7 @@ __device__ __forceinline__ void fw_slice_wide(const Params& P, const FwParams& F
 #pragma unroll
       for (int i = 0; i < G; ++i) xp[i] = (uint32_t)(lig + i * L) < np ? (int)lpos[lig + i * L] : 0;
 #pragma unroll
-      for (int i = 0; i < G; ++i) ck[i] = ((uint32_t)(lig + i * L) < np) ? (uint32_t)n_big[xp[i]] : 0u;
+      for (int i = 0; i < G; ++i) ck[i] = ((uint32_t)(lig + i * L) < np) ? (uint32_t)fw_nbig_at(n_big, nb8, xp[i]) : 0u;
 #pragma unroll
       for (int i = 0; i < G; ++i) ck[i] = ck[i] ? ((ck[i] << 16) | (0xFFFFu - (uint32_t)(lig + i * L))) : 0u;
     }
@@ -592,7 +631,7 @@ __device__ __forceinline__ void fw_slice_wide(const Params& P, const FwParams& F
     for (uint32_t q = 0; q < np; ++q) {
       const int xp = pos[q];
       if (xp < 0) continue;
-      const int key = n_big[xp];
+      const int key = fw_nbig_at(n_big, nb8, xp);
       if (F.log2dims == nullptr) {
         if (key > best_key) { best_key = key; best = (int)q; }
       } else {
@@ -637,8 +676,12 @@ __device__ __forceinline__ int fw_gs_mark(const Params& P, const FwParams& F, co
   // traffic at all; the first version issued one atomic per leg: 5 000 per replica on config 5,
   // bound by the L2's atomic rate).  The planes are written out as int32 counts once per
   // 2^NP - 1 tensors.
+  // Up to 255 too-wide tensors (the usual case: one flush) the counts are written as BYTES: the
+  // greedy pass gathers them one candidate leg at a time, and a replica's counts then span a
+  // quarter of the lines (fw_nbig8 / fw_nbig_at).
   int32_t* n_big = sc.n_big;
-  constexpr int NP = K <= 4 ? 8 : 5;  // (registers: 2 * K * NP)
+  constexpr int NP = FW_NBIG_PLANES<K>;  // (registers: 2 * K * NP)
+  const bool nb8 = fw_nbig8<K>(nw);
   Mask<K> pl[NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p) pl[p] = mzero<K>();
@@ -651,6 +694,20 @@ __device__ __forceinline__ int fw_gs_mark(const Params& P, const FwParams& F, co
         uint32_t w[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) w[p] = (uint32_t)(pl[p].w[k] >> (32 * h));
+        if (nb8) {  // 32 counters -> 32 bytes; a nibble of plane bits is spread over the bytes of a word
+          uint32_t o[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            uint32_t c = 0;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) c |= ((((w[p] >> (4 * j)) & 0xFu) * 0x00204081u) & 0x01010101u) << p;
+            o[j] = c;
+          }
+          uint4* d8 = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(n_big) + v.widx(k) * 64 + 32 * h);
+          d8[0] = make_uint4(o[0], o[1], o[2], o[3]);
+          d8[1] = make_uint4(o[4], o[5], o[6], o[7]);
+          continue;
+        }
         int4* dst = reinterpret_cast<int4*>(n_big + v.widx(k) * 64 + 32 * h);
         for (int j = 0; j < 8; ++j) {
           int4 c = {0, 0, 0, 0};
@@ -757,7 +814,8 @@ __device__ __forceinline__ Mask<K> fw_gs_pick(const Params& P, const FwParams& F
       FW_GP_T(ts1_);
       FW_GP_ADD(0, ts0_, ts1_);
       if (!have) break;
-      fw_slice_wide<LOG2L, K, HYPER>(P, F, v, rng, n_big, pos, lpos, lane0, gbase, status, skip, sx, sw, slices, cnt);
+      fw_slice_wide<LOG2L, K, HYPER>(P, F, v, rng, n_big, fw_nbig8<K>(nw), pos, lpos, lane0, gbase, status, skip, sx, sw,
+                                     slices, cnt);
     }
   }
   return slices;
@@ -803,6 +861,9 @@ __global__ __launch_bounds__(256) void fw_leaf_bits_kernel(const Params P, const
 #ifndef TNCO_FW_WALK_CAP
 #define TNCO_FW_WALK_CAP 40
 #endif
+#ifndef TNCO_FW_WALK_POPS
+#define TNCO_FW_WALK_POPS 1
+#endif
 #ifndef TNCO_FW_WALK_LANES
 #define TNCO_FW_WALK_LANES 32
 #endif
@@ -814,11 +875,19 @@ constexpr int FW_WALK_LANES = TNCO_FW_WALK_LANES;
 constexpr int FW_WALK_PER_BLOCK = 4 * FW_WALK_LANES;  // replicas per 256-thread block
 
 static __global__ __launch_bounds__(256) void fw_walk_kernel(const Params P, const FwParams F) {
-  __shared__ int32_t se[FW_WALK_CAP * 256];
-  __shared__ uint16_t sl[FW_WALK_CAP * 256];
+  constexpr int NT = FW_WALK_PER_BLOCK;  // replicas (busy lanes) per block: the stride of the LDS arrays
+  __shared__ int32_t se[FW_WALK_CAP * NT];
+  __shared__ uint16_t sl[FW_WALK_CAP * NT];
+  // The lists leave through LDS, eight entries at a time: a lane's 8-byte stores to its own list
+  // reached the memory one by one, as partial writes (rocprofv3: 660 write requests per replica, 83 %
+  // of them 32-byte ones -- the header reads turn the L2 over long before a line of records is full);
+  // eight records are four back-to-back 16-byte stores of one 64-byte piece.
+  __shared__ uint32_t rbuf[16 * NT];  // 8 records (low, high words) per replica
+  __shared__ int32_t wbuf[8 * NT];    // 8 too-wide tensors per replica
   const int tid = threadIdx.x;
   if ((tid & 63) >= FW_WALK_LANES) return;
-  const int64_t r = (int64_t)blockIdx.x * FW_WALK_PER_BLOCK + (tid >> 6) * FW_WALK_LANES + (tid & 63);
+  const int slot = (tid >> 6) * FW_WALK_LANES + (tid & 63);
+  const int64_t r = (int64_t)blockIdx.x * FW_WALK_PER_BLOCK + slot;
   if (r >= P.R) return;
   const int n = P.n, N = P.N, LK = F.I64 / 64;
   {  // greedy/optimizer.hpp:359: nothing to do without slices
@@ -833,15 +902,37 @@ static __global__ __launch_bounds__(256) void fw_walk_kernel(const Params P, con
   const FwScratch sc(F, r, N);
   const uint8_t* blk = P.blocks + r * (int64_t)(n - 1) * P.BS;
   const double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
-  uint64_t* rec = sc.rec;
+  uint64_t* rec = sc.rec;  // (64-byte aligned: fw_np, fw_scratch_ints)
   int32_t* wlist = sc.wlist;
   volatile int32_t* gstk = sc.gstk;
-  TNCO_LDS volatile int32_t* e_ = (TNCO_LDS volatile int32_t*)se + tid;
-  TNCO_LDS volatile uint16_t* l_ = (TNCO_LDS volatile uint16_t*)sl + tid;
+  TNCO_LDS volatile int32_t* e_ = (TNCO_LDS volatile int32_t*)se + slot;
+  TNCO_LDS volatile uint16_t* l_ = (TNCO_LDS volatile uint16_t*)sl + slot;
+  TNCO_LDS volatile uint32_t* rb = (TNCO_LDS volatile uint32_t*)rbuf + slot;
+  TNCO_LDS volatile int32_t* wb = (TNCO_LDS volatile int32_t*)wbuf + slot;
   const int gh = (N + 1) / 2;
   int ni = 0, nw = 0;
+  auto put_wide = [&](int x) {
+    wb[(nw & 7) * NT] = x;
+    ++nw;
+    if ((nw & 7) == 0) {
+      int4* d = reinterpret_cast<int4*>(wlist + nw - 8);
+      d[0] = make_int4(wb[0], wb[NT], wb[2 * NT], wb[3 * NT]);
+      d[1] = make_int4(wb[4 * NT], wb[5 * NT], wb[6 * NT], wb[7 * NT]);
+    }
+  };
+  auto put_rec = [&](uint64_t x) {
+    rb[(2 * (ni & 7)) * NT] = (uint32_t)x;
+    rb[(2 * (ni & 7) + 1) * NT] = (uint32_t)(x >> 32);
+    ++ni;
+    if ((ni & 7) == 0) {
+      uint4* d = reinterpret_cast<uint4*>(rec + ni - 8);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        d[q] = make_uint4(rb[(4 * q) * NT], rb[(4 * q + 1) * NT], rb[(4 * q + 2) * NT], rb[(4 * q + 3) * NT]);
+    }
+  };
   auto emit_leaf = [&](int x) {
-    if (F.leaf_wide && ((F.leaf_bits[x >> 5] >> (x & 31)) & 1u)) wlist[nw++] = x;
+    if (F.leaf_wide && ((F.leaf_bits[x >> 5] >> (x & 31)) & 1u)) put_wide(x);
   };
   int sp = 0, x = N - 1;
   bool done = false;
@@ -852,8 +943,8 @@ static __global__ __launch_bounds__(256) void fw_walk_kernel(const Params P, con
   auto up = [&]() {
     int e, l;
     if (sp <= FW_WALK_CAP) {
-      e = e_[(sp - 1) * 256];
-      l = l_[(sp - 1) * 256];
+      e = e_[(sp - 1) * NT];
+      l = l_[(sp - 1) * NT];
     } else {
       e = gstk[sp - 1 - FW_WALK_CAP];
       l = gstk[gh + sp - 1 - FW_WALK_CAP];
@@ -861,13 +952,13 @@ static __global__ __launch_bounds__(256) void fw_walk_kernel(const Params P, con
     const int node = e & 0x1FFF, rr = (e >> 13) & 0x1FFF;
     const bool fresh = ((e >> 26) & 1) == 0;
     if (fresh && rr >= n) {  // into the right subtree
-      if (sp <= FW_WALK_CAP) e_[(sp - 1) * 256] = e | (1 << 26); else gstk[sp - 1 - FW_WALK_CAP] = e | (1 << 26);
+      if (sp <= FW_WALK_CAP) e_[(sp - 1) * NT] = e | (1 << 26); else gstk[sp - 1 - FW_WALK_CAP] = e | (1 << 26);
       x = rr;
     } else {
       if (fresh) emit_leaf(rr);
       --sp;
-      rec[ni++] = fw_rec(node, l, rr);
-      if ((e >> 27) & 1) wlist[nw++] = node;
+      put_rec(fw_rec(node, l, rr));
+      if ((e >> 27) & 1) put_wide(node);
       if (sp == 0) done = true;
     }
   };
@@ -880,8 +971,8 @@ static __global__ __launch_bounds__(256) void fw_walk_kernel(const Params P, con
       ++sp;
       const int e = x | (h.y << 13) | (wide ? (1 << 27) : 0);
       if (sp <= FW_WALK_CAP) {
-        e_[(sp - 1) * 256] = e;
-        l_[(sp - 1) * 256] = (uint16_t)h.x;
+        e_[(sp - 1) * NT] = e;
+        l_[(sp - 1) * NT] = (uint16_t)h.x;
       } else {
         gstk[sp - 1 - FW_WALK_CAP] = e;
         gstk[gh + sp - 1 - FW_WALK_CAP] = h.x;
@@ -892,8 +983,15 @@ static __global__ __launch_bounds__(256) void fw_walk_kernel(const Params P, con
         x = -1;
       }
     }
-    if (!done && x < 0) up();
+    // (up-steps are LDS only: a few per iteration, so that nearly every iteration of the wavefront --
+    // one memory latency each -- fetches a header for every lane)
+#pragma unroll 1
+    for (int q = 0; q < TNCO_FW_WALK_POPS && !done && x < 0; ++q) up();
   }
+  // the unfinished pieces of the lists
+  for (int k = ni & ~7; k < ni; ++k)
+    rec[k] = (uint64_t)rb[(2 * (k & 7)) * NT] | ((uint64_t)rb[(2 * (k & 7) + 1) * NT] << 32);
+  for (int k = nw & ~7; k < nw; ++k) wlist[k] = wb[(k & 7) * NT];
   F.nwide[r] = nw;
 }
 
@@ -1371,8 +1469,10 @@ __global__ __launch_bounds__(256, 2) void fw_reslice_kernel(const Params P, cons
 #endif
     FW_PROF_T(3);
     double sum;
+    // (LDS of the candidate list, free now: 16 partial sums + as many leg masks as fit behind them)
+    constexpr int PCAP = 16, MCAP = (FW_LDSPOS / 2 - PCAP) / LK;
     const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, sc.rec, ns, sc.cp, sc.pstk, lane0, gbase, &sum,
-                                                   (lds_vdouble*)lpos, FW_LDSPOS / 2);
+                                                   (lds_vdouble*)lpos, PCAP, (lds_vu64*)lpos + PCAP, MCAP);
     if (tot < v.hdr(N - 1)->partial) {
       slices = ns;
       fw_commit<LOG2L, K, HYPER>(P, v, sc.rec, sc.cp);
