@@ -9,6 +9,7 @@
 #include "sa_kernels.h"
 #include "sa_sweep.h"
 #include "fw_kernels.h"
+#include "sa_small.h"
 
 struct EventPair {
   hipEvent_t a, b;
@@ -25,6 +26,7 @@ struct tnco_hip_ctx {
   int log2l = 2, K = 1, L = 4;  // lanes per replica = L, mask words per lane = K
   bool hyper = false, generic = false;
   bool fw = false;  // finite-width optimizer
+  bool small_tree = false;  // infinite memory, fast cost path, <= 2 mask words, <= 128 leaves: LDS-resident sweeps
   tnco::FwParams F{};
   std::vector<void*> allocs;
   int64_t bytes = 0;

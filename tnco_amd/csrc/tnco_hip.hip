@@ -412,6 +412,13 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   const bool f32 = d->cost_dtype == TNCO_HIP_F32;
   const bool pow2u = uniform && (dim_u & (dim_u - 1)) == 0;
   h->generic = !(pow2u && !d->sparse_mask && !f32);
+  // small trees: every replica's whole tree in LDS during a launch (sa_small.h).  Opt-in
+  // (TNCO_HIP_SMALL=1): measured on BASELINE config 2 (64 leaves, 65536 replicas) it runs 6.8e9
+  // move-evals/s against 7.4e9 of the staged kernel -- LDS capacity (2.4 KB per replica) leaves one
+  // wavefront per SIMD, and 64 replicas per CU at ~0.5 us per move are no more moves per second than
+  // 192 replicas per CU at ~2 us (profiles/r02_small_trees.md).
+  h->small_tree = !fw && !h->hyper && !h->generic && W <= 2 && n - 1 <= SMALL_MAX_INTERNAL && LPS == 1 &&
+                  std::getenv("TNCO_HIP_SMALL") != nullptr && std::atoi(std::getenv("TNCO_HIP_SMALL")) != 0;
 
   Params& P = h->P;
   P.n = n; P.N = N; P.I = I; P.W = W; P.R = R;
