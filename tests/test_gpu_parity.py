@@ -156,6 +156,31 @@ def test_vector_dims(core, oracle_lib):
     _run_both(core, oracle_lib, prob, seeds, H.linear_betas(0, 30, 200))
 
 
+def test_vector_dims_one_odd_part(core, oracle_lib):
+    """Per-index dims 2^a * m with ONE odd part m for all of them ({2, 3, 4, 6, 12}; also a large power
+    of two times 3): the sequential product of simple.hpp:51-53 is a table of the number of odd factors
+    times an exact power of two -- same bits as the oracle's loop, float64 and float32 cost, with
+    sparse legs, and with the table switched off (the factor-by-factor chain over the odd parts)."""
+    from tnco_amd import synthetic as syn
+    ts, dims, out = syn.random_hyper_tn(26, 64, k=3, n_output=2, seed=9, dims_choices=(2, 3, 4, 6, 12, 3))
+    dims = list(dims)
+    dims[5] = 3 * 2**21
+    prob = H.Problem(ts, np.array(dims, np.uint64), out)
+    seeds = H.replica_seeds(20, S=6)
+    _run_both(core, oracle_lib, prob, seeds, H.linear_betas(0, 30, 200))
+    _run_both(core, oracle_lib, prob, seeds, H.linear_betas(0, 30, 100), cost_type="float32")
+    probs = H.Problem(ts, np.array(dims, np.uint64), out, sparse_inds=[1, 4, 11, 30, 31, 60])
+    _run_both(core, oracle_lib, probs, seeds, H.linear_betas(0, 30, 100), n_projs=7)
+
+
+def test_vector_dims_chain_without_the_table(core, oracle_lib, monkeypatch):
+    monkeypatch.setenv("TNCO_HIP_NO_ODD_TABLE", "1")
+    from tnco_amd import synthetic as syn
+    ts, dims, out = syn.random_hyper_tn(26, 64, k=3, n_output=2, seed=9, dims_choices=(2, 3, 4, 6, 12, 3))
+    prob = H.Problem(ts, np.array(dims, np.uint64), out)
+    _run_both(core, oracle_lib, prob, H.replica_seeds(12, S=6), H.linear_betas(0, 30, 120))
+
+
 def test_sparse_inds(core, oracle_lib):
     from tnco_amd import synthetic as syn
     ts, dims, out = syn.random_hyper_tn(24, 60, k=3, n_output=4, seed=6)

@@ -32,7 +32,7 @@ def _expected_validate(verdicts):
 
 def _problem(seed, n, k, dims_kind, n_sparse):
     ts, dims, out = syn.random_hyper_tn(n, int(2.2 * n), k=k, n_output=seed % 4, seed=seed,
-                                        dims_choices=(2, 3, 4) if dims_kind == "vector" else (2,))
+                                        dims_choices=((2, 3, 4) if seed % 2 else (2, 3, 5, 6, 8)) if dims_kind == "vector" else (2,))
     n_inds = 1 + max(i for xs in ts for i in xs)
     d = {"two": 2, "three": 3, "four": 4, "vector": np.array(dims[:n_inds], np.uint64)}[dims_kind]
     rng = np.random.RandomState(seed)

@@ -11,7 +11,7 @@
 // small groups (L = 4) keep that redundancy low and put 16 replicas in one wavefront.
 //
 // HBM layout, replica-major (everything of one replica is contiguous):
-//   node block of internal node p (BS bytes, BS = 32 + 8*W [*2 with hyper legs], rounded to 32):
+//   node block of internal node p (BS bytes, BS = 32 + 8*W [*2 with hyper legs, at P.hoff], rounded to 32):
 //       [ left right parent pad | ccost | partial | legs: W words | hyper legs: W words ]
 //     so one move touches ONE line per node it reads or writes (512-leaf TN: W = 12, BS = 128 B
 //     = exactly one 128-B line).  HBM here is bound by the number of random line activations,
@@ -63,6 +63,7 @@ static_assert(sizeof(ReplicaState) == 128, "ReplicaState");
 struct Params {
   int32_t n, N, I, W;
   int32_t BS;                // bytes per node block
+  int32_t hoff;              // byte offset of the hyper legs inside a block (networks with hyper-indices)
   int32_t jcap;              // rotation-log entries per replica
   int64_t R;
   uint8_t* blocks;           // [R][n-1][BS]
@@ -74,11 +75,15 @@ struct Params {
   int32_t* jlog;             // [R][jcap]     node E of every accepted rotation since the checkpoint
   const uint64_t* leafmask;  // [n][L*K]
   const uint64_t* outmask;   // [L*K]
-  int32_t cost_mode;         // 0: uniform dims = 2^log2d; 1: uniform dims table; 2: per-index dims;
-                             // 3: per-index dims that are all powers of two
+  int32_t cost_mode;         // 0: uniform dims = 2^log2d; 1: uniform dims table; 2: per-index dims
+                             // (dims[p] = 2^a[p] * odd[p]: exponent classes + a sequential product over
+                             // the odd parts); 3: per-index dims that are all powers of two
   int32_t log2d;
   const double* ctab;        // [64*W+1]  d^k in cost_type (mode 1)
-  const double* dimsd;       // [L*K*64] dims in cost_type (mode 2)
+  const double* dimsd;       // [L*K*64] ODD PARTS of the dims in cost_type (mode 2)
+  const uint64_t* oddmask;   // [L*K] positions whose dimension is not a power of two (mode 2)
+  int32_t odd_single;        // mode 2: every such dimension has the SAME odd part m; ctab[t] = the product of
+                             // t factors m as the reference's loop rounds it
   const uint64_t* sparse;    // [L*K] or NULL
   double n_projs;            // (cost_type)n_projs
   int32_t f32;               // cost_type float32
@@ -145,10 +150,13 @@ struct View {
   uint8_t* blk;
   int32_t* lpar;
   const uint64_t* leafmask;
-  int n, BS, W, lig;
+  int n, BS, W, lig, hoff;
 
   __device__ __forceinline__ void init(const Params& P, uint8_t* blk_, int32_t* lpar_, int lig_) {
-    blk = blk_; lpar = lpar_; leafmask = P.leafmask; n = P.n; BS = P.BS; W = P.W; lig = lig_;
+    blk = blk_; lpar = lpar_; leafmask = P.leafmask; n = P.n; BS = P.BS; W = P.W; lig = lig_; hoff = P.hoff;
+  }
+  __device__ __forceinline__ uint64_t* hwords(int p) const {
+    return reinterpret_cast<uint64_t*>(blk + (int64_t)(p - n) * BS + hoff);
   }
   __device__ __forceinline__ NodeRec* hdr(int p) const {
     return reinterpret_cast<NodeRec*>(blk + (int64_t)(p - n) * BS);
@@ -204,7 +212,7 @@ struct View {
   __device__ __forceinline__ Mask<K> hyper(int p) const {
     Mask<K> r = mzero<K>();
     if constexpr (HYPER) {
-      const uint64_t* s = words(p) + W;
+      const uint64_t* s = hwords(p);
 #pragma unroll
       for (int k = 0; k < K; ++k)
         if (widx(k) < W) r.w[k] = s[widx(k)];  // (a predicated load, not a select on the loaded value)
@@ -213,7 +221,7 @@ struct View {
   }
   __device__ __forceinline__ void set_hyper(int p, const Mask<K>& v) const {
     if constexpr (HYPER) {
-      uint64_t* s = words(p) + W;
+      uint64_t* s = hwords(p);
 #pragma unroll
       for (int k = 0; k < K; ++k)
         if (widx(k) < W) s[widx(k)] = v.w[k];
@@ -309,20 +317,68 @@ __device__ __forceinline__ double pow2_cost(int e, int f32) {
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) const double lds_cdouble;
 
+// Broadcast of lane j's 64-bit value to its group: DPP inside a quad (groups of <= 4 lanes), a
+// permute through LDS hardware otherwise.
+template <int LOG2L>
+__device__ __forceinline__ uint64_t group_bcast(uint64_t x, int j, int gbase) {
+  uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+  if constexpr (LOG2L <= 2) {
+    uint32_t l2, h2;
+    switch (j) {
+      case 0: l2 = dpp<0x00>(lo); h2 = dpp<0x00>(hi); break;  // quad_perm [0,0,0,0]
+      case 1: l2 = dpp<0x55>(lo); h2 = dpp<0x55>(hi); break;
+      case 2: l2 = dpp<0xAA>(lo); h2 = dpp<0xAA>(hi); break;
+      default: l2 = dpp<0xFF>(lo); h2 = dpp<0xFF>(hi); break;
+    }
+    // (groups of 2 lanes: two groups share a quad -- lanes j and j + 2)
+    if constexpr (LOG2L == 1) {
+      const uint32_t l3 = j == 0 ? dpp<0xAA>(lo) : dpp<0xFF>(lo), h3 = j == 0 ? dpp<0xAA>(hi) : dpp<0xFF>(hi);
+      const bool upper = (__lane_id() & 2) != 0;
+      l2 = upper ? l3 : l2;
+      h2 = upper ? h3 : h2;
+    }
+    lo = l2; hi = h2;
+  } else {
+    lo = (uint32_t)__shfl((int)lo, gbase + j);
+    hi = (uint32_t)__shfl((int)hi, gbase + j);
+  }
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// simple.hpp:51-53: the running product in cost_type over ascending set bits (Bitset::visit order;
+// word k*L + j is slot k of lane j).  A dimension 2^a * m (m odd) multiplies the running product by m
+// -- rounded -- and by 2^a -- exact: scaling by a power of two commutes with every rounding, and an
+// overflow is reached by the scaled chain exactly when the reference's reaches it (the chain only
+// grows).  So only the ODD parts are multiplied sequentially (dims that are powers of two drop out
+// of the chain) and the powers of two are one masked popcount per exponent class, applied at the end.
 template <int LOG2L, int K>
-__device__ __forceinline__ double seq_product(const Params& P, const Mask<K>& u, int gbase,
+__device__ __forceinline__ double seq_product(const Params& P, const Mask<K>& u, int lig, int gbase,
                                               lds_cdouble* sdims = nullptr) {
-  // running product in cost_type over ascending set bits (Bitset::visit order): word k*L + j is
-  // slot k of lane j
   constexpr int L = 1 << LOG2L;
+  if (P.odd_single) {
+    // one odd part m for all of them (dims like {2, 3, 4, 6, 12}): the chain is m * m * ... rounded
+    // after every factor, a function of the NUMBER of factors alone -- a table built on the host
+    uint32_t et = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) et += (uint32_t)__popcll(u.w[k] & P.oddmask[k * L + lig]) << 18;
+    for (int j = 0; j < P.n_dimclass; ++j) {
+      const uint64_t* m = P.dimclass + (int64_t)j * (L * K);
+      uint32_t cnt = 0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) cnt += (uint32_t)__popcll(u.w[k] & m[k * L + lig]);
+      et += (uint32_t)(j + 1) * cnt;
+    }
+    et = gsum<LOG2L>(et);
+    return rnd_cost(ldexp(P.ctab[et >> 18], (int)(et & 0x3ffffu)), P.f32);
+  }
   double c = 1.0;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
+    const uint64_t mine = u.w[k] & P.oddmask[k * L + lig];
     for (int j = 0; j < L; ++j) {
-      const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)u.w[k], gbase + j);
-      const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(u.w[k] >> 32), gbase + j);
-      uint64_t x = ((uint64_t)hi << 32) | lo;
       const int w = k * L + j;
+      if (P.oddmask[w] == 0ull) continue;  // (uniform: no such dimension in this word)
+      uint64_t x = group_bcast<LOG2L>(mine, j, gbase);
       while (x) {
         const int b = __ffsll((unsigned long long)x) - 1;
         // (one dependent table look-up per leg: from LDS when the caller staged the table there)
@@ -331,7 +387,15 @@ __device__ __forceinline__ double seq_product(const Params& P, const Mask<K>& u,
       }
     }
   }
-  return c;
+  uint32_t e = 0;
+  for (int j = 0; j < P.n_dimclass; ++j) {
+    const uint64_t* m = P.dimclass + (int64_t)j * (L * K);
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) cnt += (uint32_t)__popcll(u.w[k] & m[k * L + lig]);
+    e += (uint32_t)(j + 1) * cnt;
+  }
+  return rnd_cost(ldexp(c, (int)gsum<LOG2L>(e)), P.f32);
 }
 
 // Per-index dims that are all powers of two: every partial product of simple.hpp:51-53 is an exact
@@ -354,7 +418,7 @@ __device__ __forceinline__ double pow2_product(const Params& P, const Mask<K>& u
 template <int LOG2L, int K>
 __device__ __forceinline__ double product_cost(const Params& P, const Mask<K>& u, int lig, int gbase,
                                                lds_cdouble* sdims = nullptr) {
-  return P.cost_mode == 3 ? pow2_product<LOG2L, K>(P, u, lig) : seq_product<LOG2L, K>(P, u, gbase, sdims);
+  return P.cost_mode == 3 ? pow2_product<LOG2L, K>(P, u, lig) : seq_product<LOG2L, K>(P, u, lig, gbase, sdims);
 }
 
 __device__ __forceinline__ double uniform_cost(const Params& P, int pc) {

@@ -41,9 +41,7 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
   constexpr int LOG2L = 2, K = 1, L = 4, GPB = TPB / 4;
   using M = Mask<K>;
   using R = Rng<LOG2L, 64>;
-  typedef TNCO_LDS volatile uint32_t lvu32;
   typedef TNCO_LDS volatile uint64_t lvu64;
-  typedef TNCO_LDS volatile double lvf64;
   typedef TNCO_LDS volatile uint8_t lvu8;
   __shared__ SmallRec recbuf[GPB * NI];
   __shared__ uint8_t lparbuf[GPB * (NI + 1)];

@@ -293,7 +293,11 @@ typedef TNCO_LDS volatile ColdState lds_cold;
 #define TNCO_FW_STAGED_WAVES 2
 #endif
 template <int LOG2L, int K, bool HYPER, bool GENERIC, bool FW = false>
-__global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES : TNCO_WAVES_PER_SIMD))) void sa_run_kernel(
+// (hyper-indices: six more masks are carried -- at 3 wavefronts per SIMD the K = 3 kernel spilled 51 VGPRs)
+#ifndef TNCO_HYPER_WAVES
+#define TNCO_HYPER_WAVES 2
+#endif
+__global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES : (HYPER ? TNCO_HYPER_WAVES : TNCO_WAVES_PER_SIMD)))) void sa_run_kernel(
     const Params P, const double* __restrict__ betas, const int64_t n_steps, const int prob_kind,
     const FwParams F, const int tail_last) {
   constexpr int L = 1 << LOG2L;

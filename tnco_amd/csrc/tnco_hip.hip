@@ -422,18 +422,26 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
 
   Params& P = h->P;
   P.n = n; P.N = N; P.I = I; P.W = W; P.R = R;
-  P.BS = (32 + 8 * W * (h->hyper ? 2 : 1) + 31) / 32 * 32;
+  P.BS = (32 + 8 * W + 31) / 32 * 32;
+  P.hoff = 0;
+  if (h->hyper) {  // the hyper legs follow the legs
+    P.hoff = 32 + 8 * W;
+    P.BS = (32 + 16 * W + 31) / 32 * 32;
+    if (std::getenv("TNCO_HIP_HYPER_ALIGNED")) {
+      // experiment: header + legs | hyper legs, each part in whole 128-byte lines of its own.  Measured
+      // on the 512-tensor hyper-index network: 4.16e9 against 4.15e9 move-evals/s -- no gain for 14 %
+      // more memory (what did help was two wavefronts per SIMD: no spills, 2.5e9 -> 4.2e9).
+      P.hoff = (32 + 8 * W + 127) / 128 * 128;
+      P.BS = P.hoff + (8 * W + 127) / 128 * 128;
+    }
+  }
   P.f32 = f32; P.disable_shared = d->disable_shared_inds ? 1 : 0;
   P.cost_mode = uniform ? (pow2u ? 0 : 1) : 2;
-  int max_log2 = 0;  // per-index dims, all powers of two (<= 2^16): exponent classes instead of the leg loop
-  if (!uniform) {
+  if (!uniform) {  // per-index dims, all powers of two: exponent classes only, no leg loop
     bool allp2 = true;
     for (int i = 0; i < I && allp2; ++i) {
       const uint64_t x = d->dims[i];
-      allp2 = (x & (x - 1)) == 0 && x <= 65536;
-      int e = 0;
-      while ((1ull << e) < x) ++e;
-      max_log2 = std::max(max_log2, e);
+      allp2 = (x & (x - 1)) == 0;
     }
     if (allp2 && !std::getenv("TNCO_HIP_NO_POW2_CLASSES")) P.cost_mode = 3;
   }
@@ -490,25 +498,64 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       HIP_TRY(h->alloc(&dt, (int64_t)tab.size()));
       HIP_TRY(hipMemcpy(dt, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
       P.ctab = dt;
-    } else if (P.cost_mode == 3) {
-      std::vector<uint64_t> cls((size_t)std::max(max_log2, 1) * L, 0);
+    } else if (P.cost_mode == 3 || P.cost_mode == 2) {
+      // dims[p] = 2^a * odd: exponent classes (a = 1 .. max) for both modes; mode 2 also the odd parts
+      // (as cost_type) and the mask of the positions that have one (simple.hpp:51-53; sa_kernels.h seq_product)
+      int max_a = 0;
+      std::vector<int> av((size_t)I, 0);
+      std::vector<uint64_t> odd((size_t)I, 1);
       for (int i = 0; i < I; ++i) {
-        int e = 0;
-        while ((1ull << e) < d->dims[i]) ++e;
-        if (e > 0) cls[(size_t)(e - 1) * L + (i >> 6)] |= 1ull << (i & 63);
+        uint64_t x = d->dims[i];
+        while ((x & 1ull) == 0) { x >>= 1; ++av[i]; }
+        odd[i] = x;
+        max_a = std::max(max_a, av[i]);
       }
+      std::vector<uint64_t> cls((size_t)std::max(max_a, 1) * L, 0);
+      for (int i = 0; i < I; ++i)
+        if (av[i] > 0) cls[(size_t)(av[i] - 1) * L + (i >> 6)] |= 1ull << (i & 63);
       uint64_t* dc;
       HIP_TRY(h->alloc(&dc, (int64_t)cls.size()));
       HIP_TRY(hipMemcpy(dc, cls.data(), cls.size() * 8, hipMemcpyHostToDevice));
       P.dimclass = dc;
-      P.n_dimclass = max_log2;
-    } else if (P.cost_mode == 2) {
-      std::vector<double> dd((size_t)L * 64, 1.0);
-      for (int i = 0; i < I; ++i) dd[i] = rc((double)d->dims[i]);
-      double* dt;
-      HIP_TRY(h->alloc(&dt, (int64_t)dd.size()));
-      HIP_TRY(hipMemcpy(dt, dd.data(), dd.size() * 8, hipMemcpyHostToDevice));
-      P.dimsd = dt;
+      P.n_dimclass = max_a;
+      if (P.cost_mode == 2) {
+        std::vector<double> dd((size_t)L * 64, 1.0);
+        std::vector<uint64_t> om((size_t)L, 0);
+        for (int i = 0; i < I; ++i) {
+          dd[i] = rc((double)odd[i]);
+          if (odd[i] != 1) om[i >> 6] |= 1ull << (i & 63);
+        }
+        double* dt;
+        uint64_t* dom2;
+        HIP_TRY(h->alloc(&dt, (int64_t)dd.size()));
+        HIP_TRY(hipMemcpy(dt, dd.data(), dd.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY(h->alloc(&dom2, (int64_t)om.size()));
+        HIP_TRY(hipMemcpy(dom2, om.data(), om.size() * 8, hipMemcpyHostToDevice));
+        P.dimsd = dt;
+        P.oddmask = dom2;
+        // a single odd part m (and exponents that fit the packed sum): chain of t factors as a table
+        uint64_t m1 = 0;
+        bool single = true;
+        for (int i = 0; i < I; ++i)
+          if (odd[i] != 1) {
+            if (m1 == 0) m1 = odd[i];
+            single &= odd[i] == m1;
+          }
+        if (single && m1 != 0 && (int64_t)max_a * W * 64 < (1 << 18) && !std::getenv("TNCO_HIP_NO_ODD_TABLE")) {
+          std::vector<double> tab((size_t)W * 64 + 1);
+          double c = 1.0;
+          const double md = rc((double)m1);
+          for (size_t t = 0; t < tab.size(); ++t) {
+            tab[t] = c;
+            c = rc(c * md);
+          }
+          double* dtab;
+          HIP_TRY(h->alloc(&dtab, (int64_t)tab.size()));
+          HIP_TRY(hipMemcpy(dtab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+          P.ctab = dtab;
+          P.odd_single = 1;
+        }
+      }
     }
   }
 
@@ -871,7 +918,7 @@ int tnco_hip_get_caches(tnco_hip_handle h, int64_t r, double* ccost, double* par
     if (ccost) ccost[i] = i < n ? 0.0 : hd.ccost;
     if (partial) partial[i] = i < n ? 0.0 : hd.partial;
     if (hyper && h->hyper && i >= n)
-      std::memcpy(hyper + (size_t)i * W, blk.data() + (size_t)(i - n) * BS + 32 + (size_t)W * 8, (size_t)W * 8);
+      std::memcpy(hyper + (size_t)i * W, blk.data() + (size_t)(i - n) * BS + h->P.hoff, (size_t)W * 8);
   }
   return TNCO_HIP_OK;
 }
