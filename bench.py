@@ -196,7 +196,8 @@ def reduce_legs(res, world, dist, torch):
             float(res["improved"]), float(res["full_copies"])] + [res["kt"][k][0] for k in names]
     per_rank = [mine]
     if world > 1:
-        t = torch.tensor(mine, dtype=torch.float64).cuda()
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor(mine, dtype=torch.float64, device=dev)
         allv = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(allv, t)
         per_rank = [[float(x) for x in v] for v in allv]

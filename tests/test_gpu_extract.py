@@ -33,6 +33,21 @@ def test_best_k_select_matches_host_sort(core, R):
             assert np.array_equal(ids, order[:k]) and np.array_equal(c, mn[order[:k]])
 
 
+def test_min_cost_reduced_on_the_device(core):
+    """tnco_hip_min_cost_device: the operand of the RCCL all-reduce(min) is written by the device into
+    a torch tensor's storage (no host round trip), here read back and compared."""
+    import torch
+    prob = H.regular_problem(24, graph_seed=2)
+    seeds = H.replica_seeds(3000, S=5)
+    links = core.random_trees(prob.ts_inds, prob.n_inds, seeds)
+    with core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds) as gpu:
+        gpu.run(H.linear_betas(0, 20, 10))
+        t = torch.full((1,), -1.0, dtype=torch.float64, device="cuda")
+        gpu.min_cost_to_device(t.data_ptr())
+        torch.cuda.synchronize()
+        assert float(t[0]) == gpu.costs()[1].min() == gpu.best(1)[0][0]
+
+
 def test_batched_trees_match_single_reads(core, oracle_lib):
     prob = H.regular_problem(96, graph_seed=21)
     seeds = H.replica_seeds(300, S=3)
