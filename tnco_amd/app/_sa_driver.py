@@ -20,7 +20,7 @@ from ..ctree import get_contraction, pack_masks, ssa_to_linear, unpack_mask
 from .app import cost_to_decimal
 from .tn import get_connected_components
 
-__all__ = ["run_sa", "merge_contraction_paths", "expand_betas"]
+__all__ = ["run_sa", "merge_contraction_paths", "split_contraction_path", "expand_betas"]
 
 
 def merge_contraction_paths(n_tensors: int, paths: Iterable[list], *, autocomplete: bool = True) -> list:
@@ -45,6 +45,41 @@ def merge_contraction_paths(n_tensors: int, paths: Iterable[list], *, autocomple
     if autocomplete:
         merged_path += [(0, 1)] * (len(merged_pos) - 1)
     return merged_path
+
+
+def split_contraction_path(n_tensors: int, path: Iterable[tuple[int, int]]) -> list:
+    """tnco/utils/tn.py:404-517 (default options): a linear path over all tensors -> one path per
+    connected component (the inverse of merge_contraction_paths), each still indexed over all tensors."""
+    path = [tuple(sorted(p)) for p in path]
+    tensors = list(range(n_tensors))
+    comp = list(range(n_tensors + len(path)))  # union-find over tensor ids (intermediates: n_tensors + step)
+
+    def find(a):
+        while comp[a] != a:
+            comp[a] = comp[comp[a]]
+            a = comp[a]
+        return a
+
+    ids = []
+    for i, (x, y) in enumerate(path):
+        ty, tx = tensors.pop(y), tensors.pop(x)
+        z = n_tensors + i
+        tensors.append(z)
+        ids.append((tx, ty, z))
+        for t in (tx, ty):
+            ra, rb = find(t), find(z)
+            comp[max(ra, rb)] = min(ra, rb)
+    order = list(dict.fromkeys(find(t) for t in range(n_tensors) if any(find(t) == find(z) for _x, _y, z in ids)))
+    paths = {c: [] for c in order}
+    pos = {c: list(range(n_tensors)) for c in order}
+    for tx, ty, z in ids:
+        c = find(z)
+        x, y = sorted((pos[c].index(tx), pos[c].index(ty)))
+        paths[c].append((x, y))
+        pos[c].pop(y)
+        pos[c].pop(x)
+        pos[c].append(z)
+    return [paths[c] for c in order if paths[c]]
 
 
 def expand_betas(betas, n_steps):
