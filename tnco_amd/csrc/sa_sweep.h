@@ -223,8 +223,21 @@ __device__ __attribute__((noinline)) bool accept_exact(double x, double beta, do
 // `uniform <= prob(delta, total)` (optimizer.hpp:162) for the rules of
 // include/tnco/optimize/prob/{base,greedy,mh}.hpp.  Metropolis: p = pow(1 + delta/total, -beta)
 // (mh.hpp:52-58).  The comparison is first decided in the log2 domain with single-precision
-// hardware logs and a rigorous error margin; only when u falls inside the margin is the
-// double-precision pow evaluated, so the decision is always the one `u <= pow(...)` gives.
+// hardware logs and an error margin; only when u falls inside the margin is the double-precision pow
+// evaluated, so the decision is the one `u <= pow(...)` gives.
+//
+// Margin (beta >= 0, x = 1 + delta/total >= 1, 0 < u < 1; outside these the exact path is taken):
+//   lu = log2f((float)u), lx = log2f((float)x), lp = -beta * lx.
+//   * rounding u, x to float: relative 2^-24 each -> |d lu|, |d lx| <= 1.4427 * 6.0e-8 = 8.6e-8
+//     absolute (|d log2 t| = |dt / t| * log2 e), hence up to 8.6e-8 * beta on lp;
+//   * v_log_f32: assumed |err| <= 2e-7 + 1.2e-7 * |result| (1 ulp of the result plus an absolute
+//     floor near 1) -- an assumption about the instruction, not a documented bound;
+//   * (float)beta and the product -beta * lx: relative 2^-24 each.
+//   Sum: |lp_true - lp| + |lu_true - lu| <= (|lp| + |lu|) * 2.4e-7 + beta * 2.9e-7 + 2e-7, bounded
+//   by the margin (|lp| + |lu|) * 2e-6 + beta * 3e-7 + 1e-5 used below.
+// Cross-check: a build with -DTNCO_CHECK_ACCEPT evaluates the exact rule next to every filtered
+// decision and traps on a difference (tools/fuzz_gpu.py and the parity tests run clean with it:
+// profiles/r02_accept_check.txt).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ bool accept_move(int kind, double beta, double delta, double total, double u,
                                             int f32) {
@@ -238,8 +251,16 @@ __device__ __forceinline__ bool accept_move(int kind, double beta, double delta,
   const float lp = -bf * lx;
   const float margin = (fabsf(lp) + fabsf(lu)) * 2e-6f + fabsf(bf) * 3e-7f + 1e-5f;
   if (uf > 1e-30f && xf < 1e30f && fabsf(lp) < 1e30f && beta >= 0.0) {
+#ifdef TNCO_CHECK_ACCEPT
+    if (lu < lp - margin || lu > lp + margin) {
+      const bool fast = lu < lp - margin;
+      if (fast != accept_exact(x, beta, u, f32)) __builtin_trap();
+      return fast;
+    }
+#else
     if (lu < lp - margin) return true;
     if (lu > lp + margin) return false;
+#endif
   }
   return accept_exact(x, beta, u, f32);
 }

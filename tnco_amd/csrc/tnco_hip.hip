@@ -348,6 +348,8 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   // finite width?  (tnco/app/app.py:866-870: finite max_width selects the finite_width optimizer)
   const bool fw = std::isfinite(d->max_width);
   if (fw) {
+    // (the greedy re-slice packs a too-wide count and a shuffled rank into 16 bits each, fw_kernels.h)
+    if (N > 65535) return fail(TNCO_HIP_ENOTIMPL, "finite width: more than 32768 tensors are not supported.");
     if (d->max_width < 0) return fail(TNCO_HIP_ERUNTIME, "'max_width' must be a non-negative number.");
     if (d->width_dtype != TNCO_HIP_F32 && d->width_dtype != TNCO_HIP_F64)
       return fail(TNCO_HIP_ENOTIMPL, "finite width: width_type must be float32 or float64.");
