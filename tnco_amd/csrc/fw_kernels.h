@@ -858,6 +858,11 @@ __global__ __launch_bounds__(256) void fw_leaf_bits_kernel(const Params P, const
 // at a quarter of the instructions.  Same step structure as fw_traverse: one fetch per iteration, an
 // up-step before and after it; stack entries lane-interleaved in LDS (no bank conflicts whatever
 // the depths), the deep end in global scratch.  Trees of at most 8192 nodes (13-bit stack fields).
+// Measured and rejected (config 5, 65536 replicas, ms per walk): this loop 1.41; up to 3 or 4 up-steps
+// per iteration 1.65 / 1.68; both children's headers requested together, the right one's kept in
+// the stack entry until its subtree is entered (half the dependent reads, six actions per
+// iteration) 3.85 -- the loop is bound by its instructions under 32- / 64-way divergence, not by
+// the reads; 64 busy lanes per wavefront instead of 32: 1.44.
 #ifndef TNCO_FW_WALK_CAP
 #define TNCO_FW_WALK_CAP 40
 #endif
@@ -874,7 +879,7 @@ constexpr int FW_WALK_CAP = TNCO_FW_WALK_CAP;
 constexpr int FW_WALK_LANES = TNCO_FW_WALK_LANES;
 constexpr int FW_WALK_PER_BLOCK = 4 * FW_WALK_LANES;  // replicas per 256-thread block
 
-static __global__ __launch_bounds__(256) void fw_walk_kernel_v1(const Params P, const FwParams F) {
+static __global__ __launch_bounds__(256) void fw_walk_kernel(const Params P, const FwParams F) {
   constexpr int NT = FW_WALK_PER_BLOCK;  // replicas (busy lanes) per block: the stride of the LDS arrays
   __shared__ int32_t se[FW_WALK_CAP * NT];
   __shared__ uint16_t sl[FW_WALK_CAP * NT];
@@ -989,190 +994,6 @@ static __global__ __launch_bounds__(256) void fw_walk_kernel_v1(const Params P, 
     for (int q = 0; q < TNCO_FW_WALK_POPS && !done && x < 0; ++q) up();
   }
   // the unfinished pieces of the lists
-  for (int k = ni & ~7; k < ni; ++k)
-    rec[k] = (uint64_t)rb[(2 * (k & 7)) * NT] | ((uint64_t)rb[(2 * (k & 7) + 1) * NT] << 32);
-  for (int k = nw & ~7; k < nw; ++k) wlist[k] = wb[(k & 7) * NT];
-  F.nwide[r] = nw;
-}
-
-// The same walk with both children's headers in flight.  The chain of dependent header reads is what
-// a walk costs (every iteration of a wavefront is one memory latency), and in the walk above every
-// internal node is one link of that chain.  Here, when a node's header lands, the header of its
-// LEFT child (needed next) and of its RIGHT child (needed after the whole left subtree) are
-// requested together; the right child's lands with the left one's and waits in the node's stack
-// entry, so entering a right subtree costs no wait: only the nodes reached through a left edge
-// remain links of the chain -- about half of them.  A lane acts until it needs a header that is
-// not there yet (bounded per iteration), one fetch and one prefetch per iteration at most.
-// Stack entry: node | right << 13 | right-entered << 26 | too-wide << 27, left child (u16), and the
-// right child's header as (left, right) u16 + a word with its too-wide bit and a valid bit.
-#ifndef TNCO_FW_WALK_ACTIONS
-#define TNCO_FW_WALK_ACTIONS 6
-#endif
-static __global__ __launch_bounds__(256) void fw_walk_kernel(const Params P, const FwParams F) {
-  constexpr int NT = FW_WALK_PER_BLOCK;
-  constexpr int CAP = FW_WALK_CAP;
-  __shared__ int32_t se[CAP * NT];
-  __shared__ uint16_t sl[CAP * NT];
-  __shared__ uint32_t sr[CAP * NT];   // prefetched header of the right child: left | right << 16
-  __shared__ uint8_t sf[CAP * NT];    // ... 1: valid, 2: too wide
-  __shared__ uint32_t rbuf[16 * NT];  // 8 records (low, high words) per replica
-  __shared__ int32_t wbuf[8 * NT];    // 8 too-wide tensors per replica
-  const int tid = threadIdx.x;
-  if ((tid & 63) >= FW_WALK_LANES) return;
-  const int slot = (tid >> 6) * FW_WALK_LANES + (tid & 63);
-  const int64_t r = (int64_t)blockIdx.x * FW_WALK_PER_BLOCK + slot;
-  if (r >= P.R) return;
-  const int n = P.n, N = P.N, LK = F.I64 / 64;
-  {  // greedy/optimizer.hpp:359: nothing to do without slices
-    const uint64_t* sl0 = F.slices + r * 2 * (int64_t)LK;
-    uint64_t any = 0;
-    for (int w = 0; w < P.W; ++w) any |= sl0[w];
-    if (!any) {
-      F.nwide[r] = -1;
-      return;
-    }
-  }
-  const FwScratch sc(F, r, N);
-  const uint8_t* blk = P.blocks + r * (int64_t)(n - 1) * P.BS;
-  const double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
-  uint64_t* rec = sc.rec;
-  int32_t* wlist = sc.wlist;
-  volatile int32_t* gstk = sc.gstk;  // entries beyond CAP: [0, gh) e, [gh, 2 gh) left child; no prefetch kept there
-  TNCO_LDS volatile int32_t* e_ = (TNCO_LDS volatile int32_t*)se + slot;
-  TNCO_LDS volatile uint16_t* l_ = (TNCO_LDS volatile uint16_t*)sl + slot;
-  TNCO_LDS volatile uint32_t* r_ = (TNCO_LDS volatile uint32_t*)sr + slot;
-  TNCO_LDS volatile uint8_t* f_ = (TNCO_LDS volatile uint8_t*)sf + slot;
-  TNCO_LDS volatile uint32_t* rb = (TNCO_LDS volatile uint32_t*)rbuf + slot;
-  TNCO_LDS volatile int32_t* wb = (TNCO_LDS volatile int32_t*)wbuf + slot;
-  const int gh = (N + 1) / 2;
-  int ni = 0, nw = 0;
-  auto put_wide = [&](int x) {
-    wb[(nw & 7) * NT] = x;
-    ++nw;
-    if ((nw & 7) == 0) {
-      int4* d = reinterpret_cast<int4*>(wlist + nw - 8);
-      d[0] = make_int4(wb[0], wb[NT], wb[2 * NT], wb[3 * NT]);
-      d[1] = make_int4(wb[4 * NT], wb[5 * NT], wb[6 * NT], wb[7 * NT]);
-    }
-  };
-  auto put_rec = [&](uint64_t x) {
-    rb[(2 * (ni & 7)) * NT] = (uint32_t)x;
-    rb[(2 * (ni & 7) + 1) * NT] = (uint32_t)(x >> 32);
-    ++ni;
-    if ((ni & 7) == 0) {
-      uint4* d = reinterpret_cast<uint4*>(rec + ni - 8);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        d[q] = make_uint4(rb[(4 * q) * NT], rb[(4 * q + 1) * NT], rb[(4 * q + 2) * NT], rb[(4 * q + 3) * NT]);
-    }
-  };
-  auto emit_leaf = [&](int x) {
-    if (F.leaf_wide && ((F.leaf_bits[x >> 5] >> (x & 31)) & 1u)) put_wide(x);
-  };
-  auto is_wide = [&](int x, int pad) -> bool {
-    const double w = F.width_f32 ? (double)__int_as_float(pad) : w64[x];
-    return w > F.max_width;
-  };
-  auto hdr_of = [&](int x) -> int4 { return *reinterpret_cast<const int4*>(blk + (int64_t)(x - n) * P.BS); };
-
-  int sp = 0;
-  bool done = false;
-  // what is in flight: the header of `pendL` (to be entered as soon as it lands) and the header of
-  // the right child of the stack entry at depth `pendR` (to be stashed there)
-  int pendL = -1, pendR = -1, pendRnode = 0;
-  int4 hL = make_int4(0, 0, 0, 0), hR = make_int4(0, 0, 0, 0);
-  int cur = -1, cl = 0, cr = 0;  // a node to enter (its header known), kept over an iteration boundary
-  bool cw = false;               // when the actions of an iteration run out
-  if (N - 1 < n) {
-    emit_leaf(N - 1);
-    done = true;
-  } else {
-    pendL = N - 1;
-    hL = hdr_of(pendL);
-  }
-  while (!done) {
-    // ---- what was requested in the previous iteration has landed -------------------------------
-    if (pendL >= 0) {
-      cur = pendL; cl = hL.x; cr = hL.y;
-      cw = is_wide(pendL, hL.w);
-    }
-    if (pendR >= 0) {
-      if (pendR < CAP) {
-        r_[pendR * NT] = (uint32_t)hR.x | ((uint32_t)hR.y << 16);
-        f_[pendR * NT] = (uint8_t)(1 | (is_wide(pendRnode, hR.w) ? 2 : 0));
-      }
-      pendR = -1;
-    }
-    pendL = -1;
-    // ---- act until a header is needed that is not there ------------------------------------------
-#pragma unroll 1
-    for (int act = 0; act < TNCO_FW_WALK_ACTIONS && !done; ++act) {
-      if (cur >= 0) {  // down into `cur`, whose header is (cl, cr, cw)
-        ++sp;
-        const int e = cur | (cr << 13) | (cw ? (1 << 27) : 0);
-        if (sp <= CAP) {
-          e_[(sp - 1) * NT] = e;
-          l_[(sp - 1) * NT] = (uint16_t)cl;
-          f_[(sp - 1) * NT] = 0;
-        } else {
-          gstk[sp - 1 - CAP] = e;
-          gstk[gh + sp - 1 - CAP] = cl;
-        }
-        if (cr >= n && pendR < 0 && sp <= CAP) {  // the right child's header, for later
-          pendR = sp - 1;
-          pendRnode = cr;
-          hR = hdr_of(cr);
-        }
-        if (cl >= n) {  // the left child's header: needed now
-          pendL = cl;
-          hL = hdr_of(cl);
-          cur = -1;
-          break;
-        }
-        emit_leaf(cl);
-        cur = -1;
-        continue;
-      }
-      // up: the top of the stack
-      int e, l;
-      if (sp <= CAP) {
-        e = e_[(sp - 1) * NT];
-        l = l_[(sp - 1) * NT];
-      } else {
-        e = gstk[sp - 1 - CAP];
-        l = gstk[gh + sp - 1 - CAP];
-      }
-      const int node = e & 0x1FFF, rr = (e >> 13) & 0x1FFF;
-      const bool entered = ((e >> 26) & 1) != 0;
-      if (!entered) {
-        if (rr < n) {
-          emit_leaf(rr);
-          if (sp <= CAP) e_[(sp - 1) * NT] = e | (1 << 26); else gstk[sp - 1 - CAP] = e | (1 << 26);
-          continue;
-        }
-        const int fl = sp <= CAP ? (int)f_[(sp - 1) * NT] : 0;
-        if (fl & 1) {  // its header waits here: enter it in the next action
-          const uint32_t hx = r_[(sp - 1) * NT];
-          if (sp <= CAP) e_[(sp - 1) * NT] = e | (1 << 26); else gstk[sp - 1 - CAP] = e | (1 << 26);
-          cur = rr;
-          cl = (int)(hx & 0xFFFFu);
-          cr = (int)(hx >> 16);
-          cw = (fl & 2) != 0;
-          continue;
-        }
-        if (pendR == sp - 1) break;  // ... still in flight: it lands with the next iteration
-        // not prefetched (deep stack, or the prefetch slot was taken): fetch it now
-        if (sp <= CAP) e_[(sp - 1) * NT] = e | (1 << 26); else gstk[sp - 1 - CAP] = e | (1 << 26);
-        pendL = rr;
-        hL = hdr_of(rr);
-        break;
-      }
-      --sp;
-      put_rec(fw_rec(node, l, rr));
-      if ((e >> 27) & 1) put_wide(node);
-      if (sp == 0) done = true;
-    }
-  }
   for (int k = ni & ~7; k < ni; ++k)
     rec[k] = (uint64_t)rb[(2 * (k & 7)) * NT] | ((uint64_t)rb[(2 * (k & 7) + 1) * NT] << 32);
   for (int k = nw & ~7; k < nw; ++k) wlist[k] = wb[(k & 7) * NT];
