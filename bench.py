@@ -56,6 +56,18 @@ FW_MOVE_LAUNCHES = lambda sps, every: (sps + every - 1) // every + 1  # noqa: E7
 FW_RESLICE_LAUNCHES = lambda sps, every: (sps + every - 1) // every   # noqa: E731
 
 
+def kernel_of(name: str):
+    """Kernel name of a rocprofv3 row -> the names used here.  The staged sweep kernel also runs the
+    moves of the finite-width optimizer: sa_run_kernel<LOG2L, K, HYPER, GENERIC, FW = true>."""
+    if "sa_run_kernel<" in name:
+        targs = name.split("sa_run_kernel<", 1)[1].split(">", 1)[0].split(",")
+        return "fw_move_kernel" if len(targs) >= 5 and targs[4].strip() == "true" else "sa_run_kernel"
+    for short in ("fw_move_kernel", "fw_reslice_kernel", "fw_walk_kernel"):
+        if short in name:
+            return short
+    return None
+
+
 def algorithmic_bytes_per_move(W: int, a: float, q: float) -> float:
     """B_move = 56W + 80 + a(24W + 64) + 8(2 + q)."""
     return 56 * W + 80 + a * (24 * W + 64) + 8 * (2 + q)
@@ -246,10 +258,9 @@ def pmc_passes(args, lib_version):
                 rows += list(csv.DictReader(fh))
         rows.sort(key=lambda r: int(r["Dispatch_Id"]))
         for r in rows:
-            name = r["Kernel_Name"]
-            for short in KERNELS:
-                if short in name:
-                    vals.setdefault((short, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+            short = kernel_of(r["Kernel_Name"])
+            if short:
+                vals.setdefault((short, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
     shutil.rmtree(tmp, ignore_errors=True)
     every = args.fw_update_slices
     per_step = {"sa_run_kernel": 1, "fw_move_kernel": FW_MOVE_LAUNCHES(args.sweeps_per_step, every),
@@ -334,8 +345,15 @@ def main() -> None:
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("TNCO_BENCH_SHARE_GPU"):
+            # test knob (tests/test_gpu_two_ranks.py): N ranks on ONE GPU over gloo -- the N > 1 code of this
+            # file on a 1-GPU box; RCCL needs a GPU per rank and is what the driver's scaling run uses
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from tnco_amd import _lib
     lib_version = _lib.load().tnco_hip_version().decode()

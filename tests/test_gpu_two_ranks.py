@@ -70,3 +70,30 @@ def test_two_ranks_equal_one_process(max_width):
     want = _run(max_width)  # (after the children: this process touches the GPU only now)
     assert len(want) == 12
     assert out[0] == want and out[1] == want
+
+
+@pytest.mark.timeout(600)
+def test_bench_line_of_a_two_rank_launch():
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank), here
+    with both ranks on the one GPU of the box over gloo (TNCO_BENCH_SHARE_GPU): the N > 1 code path
+    -- sharded seeds, barriers, all-gathers, the per-rank record -- produces one valid line whose
+    totals are the sums over the ranks."""
+    import json
+    import subprocess
+    env = dict(os.environ, TNCO_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--replicas", "2048", "--sweeps-per-step", "20", "--pmc", "0", "--cpu-sample", "0"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=540, env=env, cwd=str(ROOT))
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["vs_baseline"] is None
+    for obj in (j, j["fw"]):
+        ranks = obj["config"]["ranks"]
+        assert [r["rank"] for r in ranks] == [0, 1] and all(r["moves"] > 0 for r in ranks)
+        assert sum(r["moves"] for r in ranks) == obj["config"]["moves_timed"]
+        assert obj["config"]["replicas_total"] == 4096
+        assert obj["value"] > 0 and obj["roofline"]["frac"] > 0
+    assert len(j["config"]["devices"]) == 2

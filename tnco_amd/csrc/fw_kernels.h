@@ -1424,8 +1424,11 @@ __device__ __forceinline__ void fw_sweep_tail(const Params& P, const View<LOG2L,
 // The end of a re-slicing sweep, finite_width/greedy/optimizer.hpp:360-389: new slices for the
 // current tree (get_slices), the cost cache rebuilt with them, kept if the total improves; then the
 // best-so-far bookkeeping of the sweep (:385-389).
+#ifndef TNCO_FW_RESLICE_WAVES
+#define TNCO_FW_RESLICE_WAVES 2
+#endif
 template <int LOG2L, int K, bool HYPER>
-__global__ __launch_bounds__(256, 2) void fw_reslice_kernel(const Params P, const FwParams F, const int prewalked) {
+__global__ __launch_bounds__(256, TNCO_FW_RESLICE_WAVES) void fw_reslice_kernel(const Params P, const FwParams F, const int prewalked) {
   constexpr int L = 1 << LOG2L;
   constexpr int GPB = 256 >> LOG2L;
   constexpr int LK = L * K;
