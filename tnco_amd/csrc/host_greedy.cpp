@@ -103,9 +103,10 @@ inline int norm3(int32_t e[3]) {  // descending distinct exponents of 2^e0 + 2^e
   return m;
 }
 inline int cmp_cost(const Cost& x, const Cost& y) {
-  if (x.a < 61 && x.b < 61 && x.c < 61 && y.a < 61 && y.b < 61 && y.c < 61) {
-    const int64_t vx = ((int64_t)1 << x.a) - ((int64_t)1 << x.b) - ((int64_t)1 << x.c);
-    const int64_t vy = ((int64_t)1 << y.a) - ((int64_t)1 << y.b) - ((int64_t)1 << y.c);
+  if (x.a < 125 && x.b < 125 && x.c < 125 && y.a < 125 && y.b < 125 && y.c < 125) {
+    typedef __int128 i128;
+    const i128 vx = ((i128)1 << x.a) - ((i128)1 << x.b) - ((i128)1 << x.c);
+    const i128 vy = ((i128)1 << y.a) - ((i128)1 << y.b) - ((i128)1 << y.c);
     return vx < vy ? -1 : (vx > vy ? 1 : 0);
   }
   int32_t l[3] = {x.a, y.b, y.c}, r[3] = {y.a, x.b, x.c};
@@ -137,9 +138,11 @@ struct Scratch {
   std::vector<uint8_t> nz;
   std::vector<int32_t> keepcnt;   // scratch of push_best: per word, legs of k1 that survive a contraction
   std::vector<uint8_t> alive;
-  std::vector<std::vector<int32_t>> dim_keys;  // per non-output dim: live slots holding it
+  std::vector<std::vector<int32_t>> dim_keys;  // per non-output dim: the INPUT keys holding it (set-up only)
+  std::vector<int32_t> cnt;       // per non-output dim: live keys holding it
+  std::vector<uint64_t> nbr;      // [slot][NW] live keys that share a non-output dim with the slot's key
   std::vector<uint64_t> arena;    // k12 of the queued candidates
-  std::vector<int32_t> stamp, k2s, order;
+  std::vector<int32_t> k2s, order;
   std::vector<int32_t> table;     // open addressing: hash of the set -> slot (-1: free)
   std::vector<std::pair<int32_t, int32_t>> path;
 };
@@ -209,9 +212,21 @@ void ssa_greedy(const Work& w, const uint64_t* inputs, Scratch& S) {
       }
     }
   };
-  auto add_key = [&](int32_t s) {
-    for_dims(&S.keys[(size_t)s * W], true, [&](int d) { S.dim_keys[d].push_back(s); });
-  };
+  // Bookkeeping of the published algorithm (dim -> keys holding it; the keys that share a dim with
+  // the new tensor) in a form whose upkeep costs O(shared dims + neighbours) per contraction instead
+  // of O(legs of both tensors): per dim only the NUMBER of live holders (that is all `_get_candidate`
+  // reads: held by >= 2, by >= 3), per key the SET of its neighbours as a bitset over the slots.  When
+  // k1 and k2 become k12, a dim held by one of them and kept keeps its number of holders, and every
+  // neighbour of k1 or k2 is a neighbour of k12: it shares a dim held by >= 2 (or >= 3 if both hold
+  // it) keys, which the result keeps.  (A queued candidate's stored result stays consistent with the
+  // counts while both its keys are alive: a count only changes when two holders merge.)
+  const int SMAX = 2 * n + 8;  // slots: inputs, one result per contraction (outer products keep no slot)
+  const int NW = (SMAX + 63) / 64;
+  S.cnt.assign((size_t)w.I, 0);
+  S.nbr.assign((size_t)SMAX * NW, 0);
+  auto nb = [&](int32_t s) { return &S.nbr[(size_t)s * NW]; };
+  auto nb_set = [&](int32_t s, int32_t x) { nb(s)[x >> 6] |= 1ull << (x & 63); };
+  auto nb_clr = [&](int32_t s, int32_t x) { nb(s)[x >> 6] &= ~(1ull << (x & 63)); };
   // eager Hadamard products of equal index sets
   for (int t = 0; t < n; ++t) {
     const uint64_t* m = inputs + (size_t)t * W;
@@ -226,15 +241,25 @@ void ssa_greedy(const Work& w, const uint64_t* inputs, Scratch& S) {
     }
   }
   const int32_t n_init = (int32_t)S.ssa.size();
-  for (int32_t s = 0; s < n_init; ++s) add_key(s);
+  for (int32_t s = 0; s < n_init; ++s)
+    for_dims(&S.keys[(size_t)s * W], true, [&](int d) { S.dim_keys[d].push_back(s); });
   std::vector<uint64_t> ref2((size_t)W), ref3((size_t)W), k12((size_t)W);
   auto refresh_ref = [&](int d) {  // dims held by >= 2 / >= 3 live keys (never output dims)
-    const size_t c = S.dim_keys[d].size();
+    const int32_t c = S.cnt[d];
     const uint64_t bit = 1ull << (d & 63);
     if (c >= 2) ref2[d >> 6] |= bit; else ref2[d >> 6] &= ~bit;
     if (c >= 3) ref3[d >> 6] |= bit; else ref3[d >> 6] &= ~bit;
   };
-  for (int d = 0; d < w.I; ++d) refresh_ref(d);
+  for (int d = 0; d < w.I; ++d) {
+    const auto& v = S.dim_keys[d];
+    S.cnt[d] = (int32_t)v.size();
+    refresh_ref(d);
+    for (size_t i = 0; i < v.size(); ++i)
+      for (size_t j = i + 1; j < v.size(); ++j) {
+        nb_set(v[i], v[j]);
+        nb_set(v[j], v[i]);
+      }
+  }
 
   std::priority_queue<Cand, std::vector<Cand>, CandGreater> queue;
   auto result_mask = [&](int32_t s1, int32_t s2, uint64_t* out12) {
@@ -289,18 +314,15 @@ void ssa_greedy(const Work& w, const uint64_t* inputs, Scratch& S) {
     for (size_t i = 0; i + 1 < S.order.size(); ++i)
       push_best(S.order[i], S.order.data() + i + 1, (int)(S.order.size() - i - 1));
   }
-  int32_t n_alive = 0;
-  for (int32_t s = 0; s < n_init; ++s) n_alive += S.alive[s];
-  S.stamp.assign(S.ssa.size() + 2 * (size_t)n + 8, -1);
-  int32_t stamp_id = 0;
-  std::vector<uint64_t> uni((size_t)W);
+  std::vector<uint64_t> uni((size_t)W), un((size_t)NW);
   while (!queue.empty()) {
     const Cand c = queue.top();
     queue.pop();
     if (!S.alive[c.s1] || !S.alive[c.s2]) continue;  // obsolete
-    const int32_t id1 = S.ssa[c.s1], id2 = S.ssa[c.s2];
-    S.alive[c.s1] = 0;
-    S.alive[c.s2] = 0;
+    const int32_t s1 = c.s1, s2 = c.s2;
+    const int32_t id1 = S.ssa[s1], id2 = S.ssa[s2];
+    S.alive[s1] = 0;
+    S.alive[s2] = 0;
     S.path.emplace_back(id1, id2);
     std::memcpy(k12.data(), &S.arena[(size_t)c.k12 * W], (size_t)W * 8);
     int32_t s12 = find_slot(k12.data());
@@ -309,35 +331,51 @@ void ssa_greedy(const Work& w, const uint64_t* inputs, Scratch& S) {
       S.path.emplace_back(S.ssa[s12], next_ssa++);
     } else {
       if (s12 < 0) s12 = new_slot(k12.data());
+      if (s12 >= SMAX) { S.path.clear(); return; }  // (cannot happen: at most 2n - 1 distinct live / dead sets)
       S.alive[s12] = 1;
     }
     S.ssa[s12] = next_ssa++;
-    // dim_to_keys: k1 and k2 leave, k12 enters (unless it was there already), and _update_ref_counts
-    // over k1 | (k2 - output) -- one pass over the dims of k1 | k2; a dim's reference class changes
-    // only when its number of holders does
-    for (int x = 0; x < W; ++x) uni[x] = S.keys[(size_t)c.s1 * W + x] | S.keys[(size_t)c.s2 * W + x];
-    for_dims(uni.data(), true, [&](int d) {
-      auto& v = S.dim_keys[d];
-      const size_t before = v.size();
-      size_t j = 0;
-      for (size_t i = 0; i < before; ++i)
-        if (v[i] != c.s1 && v[i] != c.s2) v[j++] = v[i];
-      v.resize(j);
-      if (!merged && ((k12[d >> 6] >> (d & 63)) & 1ull)) v.push_back(s12);
-      if (v.size() != before) refresh_ref(d);
-    });
-    // neighbours of the new tensor
-    if ((size_t)s12 >= S.stamp.size()) S.stamp.resize((size_t)s12 * 2 + 8, -1);
-    ++stamp_id;
+    const uint64_t *a = &S.keys[(size_t)s1 * W], *b = &S.keys[(size_t)s2 * W];
+    // holders per dim (dim_to_keys / _update_ref_counts of the published code)
+    if (merged) {  // k1 and k2 leave, nothing enters
+      for (int x = 0; x < W; ++x) uni[x] = a[x] | b[x];
+      for_dims(uni.data(), true, [&](int d) {
+        S.cnt[d] -= (int32_t)((a[d >> 6] >> (d & 63)) & 1ull) + (int32_t)((b[d >> 6] >> (d & 63)) & 1ull);
+        refresh_ref(d);
+      });
+    } else {  // only shared dims (two holders become one or none) and dropped dims change their number
+      for (int x = 0; x < W; ++x) uni[x] = (a[x] & b[x]) | ((a[x] ^ b[x]) & ~k12[x]);
+      for_dims(uni.data(), true, [&](int d) {
+        const int in12 = (int)((k12[d >> 6] >> (d & 63)) & 1ull);
+        S.cnt[d] -= (int32_t)((a[d >> 6] >> (d & 63)) & 1ull) + (int32_t)((b[d >> 6] >> (d & 63)) & 1ull) - in12;
+        refresh_ref(d);
+      });
+    }
+    // neighbours: those of k1 and of k2 (every one of them shares a dim the result keeps)
+    uint64_t* n12 = nb(s12);
+    const uint64_t *n1 = nb(s1), *n2 = nb(s2);
+    for (int x = 0; x < NW; ++x) un[x] = n1[x] | n2[x];
+    un[s1 >> 6] &= ~(1ull << (s1 & 63));
+    un[s2 >> 6] &= ~(1ull << (s2 & 63));
+    un[s12 >> 6] &= ~(1ull << (s12 & 63));
+    if (merged) { for (int x = 0; x < NW; ++x) n12[x] |= un[x]; }
+    else { for (int x = 0; x < NW; ++x) n12[x] = un[x]; }
     S.k2s.clear();
-    S.stamp[s12] = stamp_id;
-    for_dims(&S.keys[(size_t)s12 * W], true, [&](int d) {
-      for (int32_t s : S.dim_keys[d])
-        if (S.stamp[s] != stamp_id) {
-          S.stamp[s] = stamp_id;
-          S.k2s.push_back(s);
-        }
-    });
+    for (int x = 0; x < NW; ++x) {
+      uint64_t v = un[x];
+      while (v) {
+        const int32_t y = x * 64 + __builtin_ctzll(v);
+        v &= v - 1;
+        nb_clr(y, s1);
+        nb_clr(y, s2);
+        nb_set(y, s12);
+      }
+      v = n12[x];
+      while (v) {
+        S.k2s.push_back(x * 64 + __builtin_ctzll(v));
+        v &= v - 1;
+      }
+    }
     if (!S.k2s.empty()) push_best(s12, S.k2s.data(), (int)S.k2s.size());
   }
   // outer products of what is left, smallest output size first
@@ -351,7 +389,6 @@ void ssa_greedy(const Work& w, const uint64_t* inputs, Scratch& S) {
   };
   for (int32_t s = 0; s < (int32_t)S.ssa.size(); ++s)
     if (S.alive[s]) rest.push(Rest{out_size(&S.keys[(size_t)s * W]), S.ssa[s], s});
-  (void)n_alive;
   if (rest.empty()) return;
   Rest cur = rest.top();
   rest.pop();

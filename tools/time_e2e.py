@@ -36,3 +36,33 @@ timed("README chain, default fuse", "2 a b\n2 b c\n2 c d", n_steps=100, n_runs=8
 timed("64 leaves, 4096 runs x 1000 steps, fuse=None", spec_of(64, 7), n_steps=1000, n_runs=4096, fuse=None)
 timed("512 leaves, 65536 runs x 1000 steps, fuse=None", spec_of(512, 11), n_steps=1000, n_runs=65536, top_k=16, fuse=None)
 timed("512 leaves, 65536 runs x 1000 steps, fuse=4", spec_of(512, 11), n_steps=1000, n_runs=65536, top_k=16)
+timed("  same, fuse=None, initial_trees='kruskal'", spec_of(512, 11), n_steps=1000, n_runs=65536, top_k=16, fuse=None,
+      initial_trees="kruskal")
+timed("  same, fuse=None, top_k=1024 (default)", spec_of(512, 11), n_steps=1000, n_runs=65536, fuse=None)
+
+
+def phases(n=512, R=65536, k=1024, sweeps=1000):
+    """The pieces of such a call through the C ABI: initial trees, create, sweeps, read-back of the k best."""
+    from tnco_amd import core
+    prob = syn.regular_problem(n, 11)
+    seeds = syn.replica_seeds(R)
+    t = [time.perf_counter()]
+    links = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds); t.append(time.perf_counter())
+    opt = core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds); opt.sync(); t.append(time.perf_counter())
+    betas = syn.linear_betas(0, 100, sweeps)
+    for s in range(0, sweeps, 100):
+        opt.run(betas[s:s + 100])
+    opt.sync(); t.append(time.perf_counter())
+    mn = opt.costs()[1]; t.append(time.perf_counter())
+    c, ids = opt.best(k); t.append(time.perf_counter())
+    lk, con = opt.trees(ids, which_min=True); t.append(time.perf_counter())
+    paths = core.linear_paths(con, np.arange(n, dtype=np.int32), n); t.append(time.perf_counter())
+    old = [opt.tree(int(r), which_min=True, with_masks=False) for r in ids[:64]]; t.append(time.perf_counter())
+    d = np.diff(t)
+    print(f"phases, {n} leaves x {R} runs x {sweeps} sweeps, head of {k}: greedy trees {d[0]:.2f} s, create {d[1]:.2f} s, "
+          f"sweeps {d[2]:.2f} s | read-back: all min costs {1e3 * d[3]:.1f} ms, k-select {1e3 * d[4]:.1f} ms, "
+          f"{k} best trees + contractions {1e3 * d[5]:.1f} ms, {k} linear paths {1e3 * d[6]:.1f} ms "
+          f"(round 1: one tree at a time {1e3 * d[7] / 64:.2f} ms each)")
+
+
+phases()
