@@ -171,6 +171,11 @@ int tnco_hip_get_trees(tnco_hip_handle h, int64_t k, const int64_t* replicas, in
  * [k][nc-1][2] linear (einsum) format, operand positions in the order (child0, child1). */
 int tnco_hip_linear_paths(int32_t n_tensors, int32_t nc, const int32_t* tensors_pos, int64_t k,
                           const int32_t* contraction, int32_t* paths, int32_t n_threads);
+/* merge_contraction_paths (tnco/utils/tn.py:334-401) for k results (host code): triples [k][steps][3]
+ * = the components' contractions concatenated, in SSA form over all tensors (leaves 0..n_tensors-1,
+ * step s creates id n_tensors + s); paths [k][steps][2], each pair sorted. */
+int tnco_hip_linear_paths_ssa(int32_t n_tensors, int32_t steps, int64_t k, const int32_t* triples,
+                              int32_t* paths, int32_t n_threads);
 
 /* Work counters summed over replicas: move evaluations (iterations of the
  * while loop at optimizer.hpp:117-192), accepted moves, best-tree updates, and

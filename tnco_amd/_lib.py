@@ -48,7 +48,7 @@ class Desc(C.Structure):
 EXPORTS = [
     "tnco_hip_create", "tnco_hip_run", "tnco_hip_run_fw", "tnco_hip_get_slices", "tnco_hip_get_slices_many", "tnco_hip_sync", "tnco_hip_get_costs", "tnco_hip_get_tree",
     "tnco_hip_get_caches", "tnco_hip_validate", "tnco_hip_get_prng", "tnco_hip_set_prng",
-    "tnco_hip_best", "tnco_hip_min_cost_device", "tnco_hip_get_trees", "tnco_hip_linear_paths", "tnco_hip_get_counters", "tnco_hip_get_moves", "tnco_hip_get_full_copies",
+    "tnco_hip_best", "tnco_hip_min_cost_device", "tnco_hip_get_trees", "tnco_hip_linear_paths", "tnco_hip_linear_paths_ssa", "tnco_hip_get_counters", "tnco_hip_get_moves", "tnco_hip_get_full_copies",
     "tnco_hip_kernel_time", "tnco_hip_kernel_times", "tnco_hip_get_stage_cycles",
     "tnco_hip_device_bytes", "tnco_hip_set_stream", "tnco_hip_destroy", "tnco_hip_random_trees", "tnco_hip_greedy_trees",
     "tnco_hip_device_count", "tnco_hip_last_error", "tnco_hip_version",
@@ -84,6 +84,7 @@ def load() -> C.CDLL:
     L.tnco_hip_min_cost_device.argtypes = [vp, vp]
     L.tnco_hip_get_trees.argtypes = [vp, i64, vp, C.c_int, vp, vp]
     L.tnco_hip_linear_paths.argtypes = [i32, i32, vp, i64, vp, vp, i32]
+    L.tnco_hip_linear_paths_ssa.argtypes = [i32, i32, i64, vp, vp, i32]
     L.tnco_hip_get_counters.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4
     L.tnco_hip_get_moves.argtypes = [vp, vp]
     L.tnco_hip_get_stage_cycles.argtypes = [vp, vp]

@@ -145,8 +145,8 @@ class _Component:
 
 def run_sa(opt, tn, betas, n_steps, n_runs, n_projs, timeout, *, top_k, sweeps_per_launch, prob, device,
            update_slices: int | None, initial_trees: str = "greedy"):
-    """Returns (tn, merged) with merged = [(cost, global run id, per-component costs, per-component
-    paths, per-component slices | None)] sorted, the `top_k` best runs over all ranks."""
+    """Returns (merged, runtime) with merged = [(cost, global run id, per-component costs, per-component
+    paths, per-component slices | None, merged path)] sorted, the `top_k` best runs over all ranks."""
     finite = update_slices is not None
     if initial_trees not in ("greedy", "kruskal"):
         raise ValueError("'initial_trees' must be 'greedy' or 'kruskal'.")
@@ -221,13 +221,19 @@ def run_sa(opt, tn, betas, n_steps, n_runs, n_projs, timeout, *, top_k, sweeps_p
     order = sorted(dec, key=lambda r: (totals[r], lo + r))[:top_k]
     # best trees of the head: one device pass + one copy back per component (materialised from the
     # checkpoint + rotation log, post-order get_contraction on the device), then path() natively
-    paths_by_comp, slices_by_comp = {}, {}
+    paths_by_comp, slices_by_comp, cons = {}, {}, []
     for ci in live:
         comp, h = comps[ci], handles[ci]
         _links, con = h.trees(order, which_min=True)
+        cons.append(con)
         paths_by_comp[ci] = core.linear_paths(con, comp.tensors, len(tn)).tolist()
         if finite:
             slices_by_comp[ci] = h.slices_many(order)[1]
+    # merge_contraction_paths (tn.py:334-401) of every result, natively and for all of them at once
+    if live and order:
+        merged_all = core.merged_paths(cons, [comps[ci].tensors for ci in live], len(tn)).tolist()
+    else:
+        merged_all = [merge_contraction_paths(len(tn), [[] for _ in comps])] * len(order)
     local = []
     for j, r in enumerate(order):
         paths, slices = [], []
@@ -238,7 +244,7 @@ def run_sa(opt, tn, betas, n_steps, n_runs, n_projs, timeout, *, top_k, sweeps_p
             else:
                 paths.append([tuple(p) for p in paths_by_comp[ci][j]])
                 slices.append(comp.names(slices_by_comp[ci][j]) if finite else frozenset())
-        local.append((totals[r], lo + r, dec[r], paths, slices))
+        local.append((totals[r], lo + r, dec[r], paths, slices, [tuple(p) for p in merged_all[j]]))
     best_raw = float(raw_total.min()) if n_local else float("inf")
     for h in handles:
         if h is not None:

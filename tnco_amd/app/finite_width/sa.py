@@ -52,9 +52,9 @@ class Optimizer(BaseOptimizer):
         merged, runtime = run_sa(self, tn, betas, n_steps, n_runs, n_projs, timeout, top_k=top_k,
                                  sweeps_per_launch=sweeps_per_launch, prob=prob, device=device,
                                  update_slices=int(update_slices), initial_trees=initial_trees)
-        results = [ContractionResults(cost=c, runtime_s=runtime, path=merge_contraction_paths(len(tn), paths),
+        results = [ContractionResults(cost=c, runtime_s=runtime, path=mp,
                                       disconnected_costs=list(dc), disconnected_paths=paths,
                                       disconnected_slices=list(sl),
                                       slices=reduce(frozenset.union, sl, frozenset()))
-                   for c, _gid, dc, paths, sl in merged]
+                   for c, _gid, dc, paths, sl, mp in merged]
         return self._dump_results(tn, results)

@@ -13,7 +13,7 @@ import numpy as np
 from . import _lib
 from .ctree import n_words
 
-__all__ = ["BatchedOptimizer", "random_trees", "greedy_trees", "linear_paths", "PROB_BASE", "PROB_GREEDY", "PROB_MH"]
+__all__ = ["BatchedOptimizer", "random_trees", "greedy_trees", "linear_paths", "merged_paths", "PROB_BASE", "PROB_GREEDY", "PROB_MH"]
 
 PROB_BASE, PROB_GREEDY, PROB_MH = _lib.PROB_BASE, _lib.PROB_GREEDY, _lib.PROB_MH
 _PROB = {"base": PROB_BASE, "greedy": PROB_GREEDY, "mh": PROB_MH,
@@ -88,6 +88,44 @@ def linear_paths(contraction, tensors_pos, n_tensors: int, n_threads: int = 0) -
     out = np.empty((k, steps, 2), np.int32)
     if L.tnco_hip_linear_paths(int(n_tensors), len(tp), _ptr(tp), k, _ptr(con), _ptr(out), n_threads):
         raise ValueError("'contraction' is not valid.")
+    return out
+
+
+def merged_paths(contractions, tensors_pos, n_tensors: int, *, autocomplete: bool = True, n_threads: int = 0):
+    """merge_contraction_paths (tnco/utils/tn.py:334-401) for k results at once.
+
+    contractions: one array [k, nc_i - 1, 3] per connected component (get_contraction triples with
+    component-local node ids, as BatchedOptimizer.trees returns them); tensors_pos: per component the
+    ascending positions of its tensors among all n_tensors.  Returns [k, steps, 2] with steps =
+    sum(nc_i - 1) (+ the pairs (0, 1) that join the components when `autocomplete`)."""
+    L = _lib.load()
+    k = len(contractions[0]) if contractions else 0
+    parts, off = [], 0
+    for con, tp in zip(contractions, tensors_pos):
+        con = np.asarray(con, np.int64)
+        tp = np.asarray(tp, np.int64)
+        nc = len(tp)
+        steps = nc - 1
+        inv = np.empty((k, steps), np.int64)  # node id - nc -> step at which it is created
+        np.put_along_axis(inv, con[:, :, 2] - nc, np.broadcast_to(np.arange(steps), (k, steps)), axis=1)
+        g = np.empty((k, steps, 3), np.int64)
+        for j in range(2):
+            x = con[:, :, j]
+            leaf = x < nc
+            g[:, :, j] = np.where(leaf, tp[np.where(leaf, x, 0)],
+                                  n_tensors + off + np.take_along_axis(inv, np.where(leaf, 0, x - nc), axis=1))
+        g[:, :, 2] = n_tensors + off + np.arange(steps)
+        parts.append(g)
+        off += steps
+    tri = np.ascontiguousarray(np.concatenate(parts, axis=1) if parts else np.zeros((k, 0, 3)), np.int32)
+    out = np.empty((k, off, 2), np.int32)
+    if L.tnco_hip_linear_paths_ssa(int(n_tensors), off, k, _ptr(tri), _ptr(out), n_threads):
+        raise ValueError("'paths' are not valid or not disconnected.")
+    if autocomplete:
+        extra = n_tensors - off - 1
+        if extra > 0:
+            tail = np.broadcast_to(np.array([0, 1], np.int32), (k, extra, 2))
+            out = np.concatenate([out, tail], axis=1)
     return out
 
 

@@ -89,3 +89,52 @@ extern "C" int tnco_hip_linear_paths(int32_t n_tensors, int32_t nc, const int32_
     if (!v) return TNCO_HIP_EINVAL;
   return TNCO_HIP_OK;
 }
+
+// The same linearisation for contractions already in SSA form over ALL tensors: triples (x, y, z)
+// with leaves 0 .. n_tensors-1 and the s-th step creating id n_tensors + s.  This is what
+// merge_contraction_paths (tnco/utils/tn.py:334-401) computes for the concatenation of the
+// components' paths: every step names the positions of its operands in one global list, sorted.
+extern "C" int tnco_hip_linear_paths_ssa(int32_t n_tensors, int32_t steps, int64_t k, const int32_t* triples,
+                                         int32_t* paths, int32_t n_threads) {
+  if (n_tensors < 1 || steps < 0 || k < 0 || (k > 0 && steps > 0 && (!triples || !paths))) return TNCO_HIP_EINVAL;
+  int nth = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+  nth = (int)std::max<int64_t>(1, std::min<int64_t>(nth, k / 16 + 1));
+  std::vector<int> ok((size_t)nth, 1);
+  std::vector<std::thread> th;
+  for (int t = 0; t < nth; ++t)
+    th.emplace_back([&, t]() {
+      Fenwick leaves, inter;
+      for (int64_t q = t; q < k; q += nth) {
+        const int32_t* con = triples + q * 3 * steps;
+        int32_t* out = paths + q * 2 * steps;
+        leaves.reset(n_tensors, n_tensors);
+        inter.reset(steps + 1, 0);
+        int32_t live_leaves = n_tensors;
+        for (int32_t s = 0; s < steps; ++s) {
+          int32_t pos[2];
+          for (int j = 0; j < 2; ++j) {
+            const int32_t x = con[3 * s + j];
+            if (x < 0 || x >= n_tensors + s) { ok[t] = 0; return; }
+            pos[j] = x < n_tensors ? leaves.prefix(x) : live_leaves + inter.prefix(x - n_tensors);
+          }
+          out[2 * s] = std::min(pos[0], pos[1]);
+          out[2 * s + 1] = std::max(pos[0], pos[1]);
+          for (int j = 0; j < 2; ++j) {
+            const int32_t x = con[3 * s + j];
+            if (x < n_tensors) {
+              leaves.add(x, -1);
+              --live_leaves;
+            } else {
+              inter.add(x - n_tensors, -1);
+            }
+          }
+          if (con[3 * s + 2] != n_tensors + s) { ok[t] = 0; return; }
+          inter.add(s, 1);
+        }
+      }
+    });
+  for (auto& x : th) x.join();
+  for (int v : ok)
+    if (!v) return TNCO_HIP_EINVAL;
+  return TNCO_HIP_OK;
+}
