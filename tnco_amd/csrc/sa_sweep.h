@@ -455,11 +455,26 @@ __global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
             *v.hdr(B) = o;
           }
           v.lpar = lpar();
+          // (the sixteen replicas of the wavefront wait for this copy: four nodes per lane in flight)
           Links* __restrict__ ml = P.minlinks + r * (int64_t)N;
-          for (int i = lig; i < N; i += L) {
-            Links o;
-            o.left = v.left(i); o.right = v.right(i); o.parent = v.parent(i); o.pad = 0;
-            ml[i] = o;
+          for (int i0 = lig; i0 < N; i0 += 4 * L) {
+            int4 h4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int i = i0 + q * L;
+              h4[q] = make_int4(-1, -1, -1, 0);
+              if (i < n) h4[q].z = v.lpar[(int64_t)i * LPS];
+              else if (i < N) h4[q] = *reinterpret_cast<const int4*>(v.hdr(i));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int i = i0 + q * L;
+              if (i < N) {
+                Links o;
+                o.left = h4[q].x; o.right = h4[q].y; o.parent = h4[q].z; o.pad = 0;
+                ml[i] = o;
+              }
+            }
           }
           jtail = 0;
           jinvalid = false;

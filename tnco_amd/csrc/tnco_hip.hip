@@ -454,14 +454,15 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
 
   // Rotation log: one int32 per accepted move since the last re-base of the checkpoint.  When it is
   // full, the next improvement re-bases the checkpoint on the current tree (a 16 N-byte copy) and the
-  // log starts again, so its size only sets how often that happens: 16 Ki entries (64 KB per replica)
-  // are one re-base per ~1000 sweeps of the 512-leaf benchmark.  (Round 1 gave the log an eighth of
+  // log starts again, so its size only sets how often that happens: 32 Ki entries (128 KB per replica)
+  // are one re-base per ~2000 sweeps of the 512-leaf benchmark (a re-base stalls its wavefront: with
+  // 16 Ki entries every replica took one in the 1200-sweep bench run, -3 %).  (Round 1 gave the log an eighth of
   // the free HBM -- 34 GB at 65536 replicas -- and hipMalloc of it took 1.4 s of every create().)
   {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     int64_t cap = (int64_t)(free_b / 8) / (R * 4);
-    cap = std::max<int64_t>(1024, std::min<int64_t>(cap, (int64_t)1 << 14));
+    cap = std::max<int64_t>(1024, std::min<int64_t>(cap, (int64_t)1 << 15));
     if (const char* e = std::getenv("TNCO_HIP_JLOG_CAP")) cap = std::max<int64_t>(1, std::atoll(e));  // test knob
     cap = (cap + 15) & ~(int64_t)15;  // the sweep kernel appends in whole 16-entry (64-byte) pieces
     P.jcap = (int32_t)cap;
