@@ -309,7 +309,7 @@ int fetch_rs(tnco_hip_handle h, std::vector<ReplicaState>& rs) {
 extern "C" {
 
 const char* tnco_hip_last_error(void) { return g_err.c_str(); }
-const char* tnco_hip_version(void) { return "tnco_hip 0.2 (gfx950)"; }
+const char* tnco_hip_version(void) { return "tnco_hip 0.3 (gfx950), round 2"; }
 
 int tnco_hip_device_count(void) {
   int n = 0;
