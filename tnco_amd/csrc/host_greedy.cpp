@@ -181,27 +181,35 @@ void ssa_greedy(const Work& w, const uint64_t* inputs, Scratch& S) {
   if (S.dim_keys.size() != (size_t)w.I) S.dim_keys.assign((size_t)w.I, {});
   for (auto& v : S.dim_keys) v.clear();
   int32_t next_ssa = n;
+  size_t last_probe = 0;  // where find_slot stopped: the free cell a following new_slot takes
   auto find_slot = [&](const uint64_t* m) -> int32_t {
     for (size_t h = hash_mask(m, W) & (tsize - 1);; h = (h + 1) & (tsize - 1)) {
       const int32_t s = S.table[h];
-      if (s < 0) return -1;
+      if (s < 0) {
+        last_probe = h;
+        return -1;
+      }
       if (!std::memcmp(&S.keys[(size_t)s * W], m, (size_t)W * 8)) return s;
     }
   };
-  auto new_slot = [&](const uint64_t* m) -> int32_t {
+  auto new_slot = [&](const uint64_t* m) -> int32_t {  // (right after a find_slot(m) that returned -1)
     const int32_t s = (int32_t)S.ssa.size();
     S.keys.insert(S.keys.end(), m, m + W);
     S.ssa.push_back(-1);
-    S.fp.push_back(popc(m, W));
-    S.alive.push_back(0);
+    int fp = 0;
     for (int x = 0; x < W; ++x)
-      if (m[x]) S.nz.push_back((uint8_t)x);
+      if (m[x]) {
+        fp += __builtin_popcountll(m[x]);
+        S.nz.push_back((uint8_t)x);
+      }
+    S.fp.push_back(fp);
+    S.alive.push_back(0);
     S.nz_off.push_back((int32_t)S.nz.size());
-    size_t h = hash_mask(m, W) & (tsize - 1);
-    while (S.table[h] >= 0) h = (h + 1) & (tsize - 1);
-    S.table[h] = s;
+    S.table[last_probe] = s;
     return s;
   };
+  S.keys.reserve((size_t)(2 * n + 8) * W);
+  S.nz.reserve((size_t)(2 * n + 8) * W);
   auto for_dims = [&](const uint64_t* m, bool minus_output, auto&& f) {
     for (int x = 0; x < W; ++x) {
       uint64_t v = m[x] & (minus_output ? ~output[x] : ~0ull);
