@@ -66,6 +66,18 @@ def load() -> C.CDLL:
             f"{_PATH} is missing: build it with `make -C tnco_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
             "tnco_amd has no CPU fallback.")
+    # PyTorch-ROCm bundles its own HIP / HSA runtime (torch/lib/libamdhip64.so, no soname) next to the
+    # system one this library links (/opt/rocm/lib/libamdhip64.so.7): both end up in a process that
+    # uses torch (torch.distributed over RCCL, the device-side reduction operand).  They coexist when
+    # torch's runtime initialises FIRST; the other way round torch reports "No HIP GPUs are available".
+    # So if torch can be imported, its runtime is initialised here, before the library touches the GPU.
+    if not os.environ.get("TNCO_HIP_NO_TORCH_FIRST"):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:  # no torch / no GPU: nothing to order
+            pass
     L = C.CDLL(str(_PATH))
     vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
     L.tnco_hip_create.argtypes = [C.POINTER(Desc), C.POINTER(vp)]
