@@ -2,6 +2,10 @@
 -DTNCO_PROFILE (make -C tnco_amd/csrc profile -> build_variants/lib_profile.so):
 
     TNCO_HIP_LIB=$PWD/build_variants/lib_profile.so python tools/stage_cycles.py
+    tools/build_variant.sh profile4 -DTNCO_PROFILE=4   # cycles inside the greedy pass of the re-slice
+    TNCO_HIP_LIB=$PWD/build_variants/lib_profile4.so python tools/stage_cycles.py --fw --fine
+(-DTNCO_PROFILE=3: event counts of the re-slice instead of cycles: too-wide tensors scanned, tensors
+shuffled and picked from, candidate legs, picks.)
 """
 import argparse
 import ctypes as C
