@@ -318,7 +318,9 @@ template <int LOG2L, int K, bool HYPER, bool GENERIC, bool FW = false>
 #ifndef TNCO_HYPER_WAVES
 #define TNCO_HYPER_WAVES 2
 #endif
-__global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES : (HYPER ? TNCO_HYPER_WAVES : TNCO_WAVES_PER_SIMD)))) void sa_run_kernel(
+// (four mask words per lane: at three wavefronts per SIMD the kernel spills; at two, 1360 leaves
+// (8 lanes x 4 words) run 3.25 -> 3.6e9 move-evals/s, 680 leaves the same within the +-3 % of the boxes)
+__global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES : ((HYPER || K >= 4) ? TNCO_HYPER_WAVES : TNCO_WAVES_PER_SIMD)))) void sa_run_kernel(
     const Params P, const double* __restrict__ betas, const int64_t n_steps, const int prob_kind,
     const FwParams F, const int tail_last) {
   constexpr int L = 1 << LOG2L;
