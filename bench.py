@@ -168,7 +168,8 @@ class Leg:
             kw = dict(max_width=args.fw_max_width)
         all_seeds = synthetic.replica_seeds(R * world, S=0)
         self.seeds = all_seeds[rank * R:(rank + 1) * R]
-        self.links = core.random_trees(self.prob.ts_inds, self.prob.n_inds, self.seeds)
+        gen = core.greedy_trees if args.init == "greedy" else core.random_trees
+        self.links = gen(self.prob.ts_inds, self.prob.n_inds, self.seeds)
         self.sps = args.sweeps_per_step
         self.total_sweeps = (args.warmup + args.steps) * self.sps
         self.betas = synthetic.linear_betas(0.0, 100.0, self.total_sweeps)
@@ -234,7 +235,7 @@ def pmc_passes(args, lib_version):
     env = dict(os.environ, TMPDIR="/tmp")
     cmd_tail = [sys.executable, str(ROOT / "bench.py"), "--steps", str(args.steps), "--warmup", str(args.warmup),
                 "--sweeps-per-step", str(args.sweeps_per_step), "--leaves", str(args.leaves),
-                "--replicas", str(args.replicas), "--graph-seed", str(args.graph_seed),
+                "--replicas", str(args.replicas), "--graph-seed", str(args.graph_seed), "--init", args.init,
                 "--workload", args.workload, "--fw-max-width", str(args.fw_max_width),
                 "--fw-update-slices", str(args.fw_update_slices), "--fw-depth", str(args.fw_depth),
                 "--cpu-sample", "0", "--pmc", "0"]
@@ -319,6 +320,9 @@ def main() -> None:
     ap.add_argument("--leaves", type=int, default=512)
     ap.add_argument("--replicas", type=int, default=65536, help="replicas per GPU")
     ap.add_argument("--graph-seed", type=int, default=11)
+    ap.add_argument("--init", choices=("kruskal", "greedy"), default="kruskal",
+                    help="initial trees: the build's random-Kruskal generator (round 1's line) or the reference's recipe "
+                         "(shuffle + opt_einsum greedy, restated)")
     ap.add_argument("--workload", choices=("both", "im", "fw"), default="both",
                     help="im: the headline leg only; fw: the finite-width leg as the headline; both: im + 'fw' object")
     ap.add_argument("--fw-max-width", type=float, default=40.0)
@@ -387,7 +391,8 @@ def main() -> None:
 
     if rank == 0:
         R, sps, every = args.replicas, args.sweeps_per_step, args.fw_update_slices
-        key = f"{args.workload}/{args.leaves}/{R}/{sps}/{args.steps}/{args.warmup}/{args.fw_max_width}/{every}/{args.fw_depth}"
+        key = (f"{args.workload}/{args.leaves}/{R}/{sps}/{args.steps}/{args.warmup}/{args.fw_max_width}/{every}/"
+               f"{args.fw_depth}" + ("" if args.init == "kruskal" else "/" + args.init))
         pmc, pmc_note = None, None
         if args.pmc and world == 1:
             for leg in objs.values():  # free the GPU memory of this process first
@@ -463,6 +468,8 @@ def main() -> None:
                     "random_pick_rate": q, "best_log10_flops": float(np.log10(res["best"])),
                     "improvements_timed": res["improved"], "full_tree_copies_timed": res["full_copies"],
                     "validated_bad_replicas": res.get("n_bad"), "library": lib_version,
+                    "initial_trees": "random Kruskal (tnco_hip_random_trees)" if args.init == "kruskal" else
+                                     "Random(seed).shuffle + opt_einsum greedy restated (tnco_hip_greedy_trees)",
                 },
                 "roofline": roof,
             }
