@@ -156,9 +156,10 @@ def cpu_baseline_fw(prob, links, seeds, betas, n_sample, cores, max_width, every
 # one timed leg on this rank's GPU
 # ------------------------------------------------------------------------------------------------
 class Leg:
-    def __init__(self, kind, args, rank, world, local_rank):
+    def __init__(self, kind, args, rank, world, local_rank, grouped=None):
         from tnco_amd import core, synthetic
         self.kind, self.args, self.rank, self.world, self.local_rank = kind, args, rank, world, local_rank
+        self.grouped = world > 1 if grouped is None else grouped
         R = args.replicas
         if kind == "im":
             self.prob = synthetic.regular_problem(args.leaves, graph_seed=args.graph_seed)
@@ -192,7 +193,7 @@ class Leg:
         t0 = time.perf_counter()
         for s in range(a.warmup, a.warmup + a.steps):
             self.step(s)
-        best = parallel.global_best(opt, rank=self.rank, world=self.world, device=self.local_rank)
+        best = parallel.global_best(opt, rank=self.rank, world=self.world, device=self.local_rank, grouped=self.grouped)
         barrier(opt)
         dt = time.perf_counter() - t0
         c1 = opt.counters()
@@ -201,14 +202,14 @@ class Leg:
         return dict(dt=dt, best=best, kt=kt, **d)
 
 
-def reduce_legs(res, world, dist, torch):
+def reduce_legs(res, world, dist, torch, grouped=None):
     """max over ranks of the times, sum of the work; plus what every rank did (all-gather), so that
     the line itself shows how many ranks took part."""
     names = KERNELS
     mine = [res["dt"], float(res["moves"]), float(res["accepted"]), float(res["random_picks"]),
             float(res["improved"]), float(res["full_copies"])] + [res["kt"][k][0] for k in names]
     per_rank = [mine]
-    if world > 1:
+    if world > 1 if grouped is None else grouped:
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
         t = torch.tensor(mine, dtype=torch.float64, device=dev)
         allv = [torch.empty_like(t) for _ in range(world)]
@@ -346,8 +347,14 @@ def main() -> None:
 
     import torch
     import torch.distributed as dist
-    if world > 1:
+    # test knob (tests/test_gpu_two_ranks.py): a launch of ONE rank goes through the process group too -- RCCL
+    # initialised next to the library, the reduction fed from device memory, the all-gathers -- on a 1-GPU box
+    grouped = world > 1 or bool(os.environ.get("TNCO_BENCH_FORCE_GROUP"))
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if os.environ.get("TNCO_BENCH_SHARE_GPU"):
             # test knob (tests/test_gpu_two_ranks.py): N ranks on ONE GPU over gloo -- the N > 1 code of this
@@ -365,15 +372,15 @@ def main() -> None:
     def barrier(opt):
         opt.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
             torch.cuda.synchronize()
 
     legs = {"both": ("im", "fw"), "im": ("im",), "fw": ("fw",)}[args.workload]
     results, objs = {}, {}
     for kind in legs:
-        leg = Leg(kind, args, rank, world, local_rank)
-        res = reduce_legs(leg.run(barrier, dist), world, dist, torch)
+        leg = Leg(kind, args, rank, world, local_rank, grouped)
+        res = reduce_legs(leg.run(barrier, dist), world, dist, torch, grouped)
         if args.validate:
             res["n_bad"] = leg.opt.validate()[0]
         results[kind], objs[kind] = res, leg
@@ -382,7 +389,7 @@ def main() -> None:
             leg.opt = None
 
     devices = None
-    if world > 1:  # what RCCL saw: one entry per rank
+    if grouped:  # what RCCL saw: one entry per rank
         props = torch.cuda.get_device_properties(local_rank)
         me = dict(rank=rank, local_rank=local_rank, device=props.name, uuid=str(getattr(props, "uuid", "")),
                   backend=dist.get_backend())
@@ -473,7 +480,7 @@ def main() -> None:
                 },
                 "roofline": roof,
             }
-            if world > 1:
+            if grouped:
                 obj["config"]["ranks"] = res["per_rank"]
             if args.cpu_sample != 0 and world == 1:
                 cores = usable_cores()
@@ -518,7 +525,7 @@ def main() -> None:
     for leg in objs.values():
         if leg.opt is not None:
             leg.opt.close()
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

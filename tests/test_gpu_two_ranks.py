@@ -2,8 +2,8 @@
 end to end: the run list is sharded, every rank gets the same merged results, and they are the
 results of the single-process call -- results do not depend on the number of ranks
 (tnco_amd/parallel.py; the reference fans runs out to processes and sorts, tnco/parallel.py:111-368,
-tnco/app/infinite_memory/sa.py:243-257).  RCCL itself needs one GPU per rank and is exercised by
-bench.py under the driver."""
+tnco/app/infinite_memory/sa.py:243-257).  RCCL needs one GPU per rank: on this 1-GPU box it runs as a
+group of ONE rank (the last test), N > 1 over RCCL is bench.py under the driver."""
 import os
 import socket
 import sys
@@ -97,3 +97,31 @@ def test_bench_line_of_a_two_rank_launch():
         assert obj["config"]["replicas_total"] == 4096
         assert obj["value"] > 0 and obj["roofline"]["frac"] > 0
     assert len(j["config"]["devices"]) == 2
+
+
+@pytest.mark.timeout(600)
+def test_bench_line_through_rccl_group_of_one():
+    """The RCCL side of bench.py on a 1-GPU box: a launch of one rank that still goes through the process
+    group (TNCO_BENCH_FORCE_GROUP) -- RCCL initialised on the device before the library loads, the best
+    cost reduced on the device into the tensor the all-reduce runs on, barriers and all-gathers on
+    device tensors -- gives the line of the plain launch."""
+    import json
+    import subprocess
+    tail = [str(ROOT / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--replicas", "2048",
+            "--sweeps-per-step", "20", "--pmc", "0", "--cpu-sample", "0"]
+    lines = []
+    for extra in ({"TNCO_BENCH_FORCE_GROUP": "1", "MASTER_PORT": str(_free_port())}, {}):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+        p = subprocess.run([sys.executable, *tail], capture_output=True, text=True, timeout=280, env=env, cwd=str(ROOT))
+        assert p.returncode == 0, p.stderr[-2000:]
+        out = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(out) == 1
+        lines.append(json.loads(out[0]))
+    grp, plain = lines
+    assert grp["n_gpus"] == 1 and len(grp["config"]["devices"]) == 1
+    assert grp["config"]["devices"][0]["backend"] == "nccl" and grp["config"]["devices"][0]["rank"] == 0
+    assert "devices" not in plain["config"]
+    for a, b in ((grp, plain), (grp["fw"], plain["fw"])):
+        assert [r["rank"] for r in a["config"]["ranks"]] == [0]
+        assert a["config"]["ranks"][0]["moves"] == a["config"]["moves_timed"] == b["config"]["moves_timed"]
+        assert a["config"]["best_log10_flops"] == b["config"]["best_log10_flops"]

@@ -66,14 +66,16 @@ def _tensor_device(dist, device):
     return torch.device("cpu")
 
 
-def global_best(opt_or_cost, rank: int = 0, world: int = 1, device: int = 0) -> float:
+def global_best(opt_or_cost, rank: int = 0, world: int = 1, device: int = 0, grouped: bool | None = None) -> float:
     """min over all ranks of the local best min_total_cost.
 
     Given an optimizer handle and an RCCL group, the local minimum is reduced on the device
     (tnco_hip_min_cost_device) straight into the tensor the all-reduce(min) runs on: 8 bytes over
-    xGMI, no host round trip before the collective."""
+    xGMI, no host round trip before the collective.  `grouped` (default: world > 1) = go through the
+    process group; a group of ONE rank takes the same code path (tests/test_gpu_two_ranks.py runs
+    RCCL that way on a 1-GPU box)."""
     is_opt = hasattr(opt_or_cost, "best")
-    if world == 1:
+    if not (world > 1 if grouped is None else grouped):
         return float(opt_or_cost.best(1)[0][0]) if is_opt else float(opt_or_cost)
     torch, dist = _dist()
     dev = _tensor_device(dist, device)
