@@ -240,6 +240,19 @@ int tnco_hip_greedy_trees(int32_t n_leaves, int32_t n_inds, const int32_t* holde
                           const uint32_t* seeds, uint64_t* draws, int32_t* links_out,
                           int32_t n_threads);
 
+/* The same trees drawn ON THE DEVICE (csrc/greedy_device.hip: CPython's generator one lane per tree,
+ * the greedy path finder one wavefront per tree); the trees come back in links_out (host memory).
+ * Networks outside the kernel's limits (tnco_hip_greedy_device_supported == 0: more than 2040
+ * indices or 2000 tensors, an index held by more than 6 tensors) and single trees that end in outer
+ * products are done by tnco_hip_greedy_trees on n_threads host threads: same result either way. */
+int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, int32_t n_inds, const int32_t* holders_off,
+                                 const int32_t* holders, const uint64_t* output_mask, int64_t n_replicas,
+                                 const uint32_t* seeds, uint64_t* draws, int32_t* links_out,
+                                 int32_t n_threads);
+int tnco_hip_greedy_device_supported(int32_t n_leaves, int32_t n_inds, const int32_t* holders_off);
+/* diagnostics: trees of the last device call that the host version did (-1: the whole batch) */
+int64_t tnco_hip_greedy_device_redone(void);
+
 int tnco_hip_device_count(void);
 const char* tnco_hip_last_error(void);
 const char* tnco_hip_version(void);

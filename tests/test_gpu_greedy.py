@@ -1,0 +1,82 @@
+"""The device-side generator of the reference's initial trees (csrc/greedy_device.hip:
+Random(seed).shuffle + opt_einsum's greedy, tnco/utils/tn.py:189-230) against the host generator
+(csrc/host_greedy.cpp, itself tested equal to the Python spec in tests/test_host.py): the same trees,
+tree for tree, whatever the network -- plain graphs, hyper-indices, output legs, equal index sets,
+several components sharing one generator, networks outside the kernel's limits."""
+import numpy as np
+import pytest
+
+from tnco_amd import core, ctree as ct, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(ts, n_inds, seeds, out_keep=(), draws=None, on_device=True):
+    """host == device; `on_device`: the kernel did every tree itself (none handed back to the host)."""
+    from tnco_amd import _lib
+    om = ct.pack_masks([list(out_keep)], n_inds)[0]
+    d_host = None if draws is None else draws.copy()
+    d_dev = None if draws is None else draws.copy()
+    host = core.greedy_trees(ts, n_inds, seeds, output_mask=om, draws=d_host)
+    dev = core.greedy_trees(ts, n_inds, seeds, output_mask=om, draws=d_dev, device=0)
+    redone = _lib.load().tnco_hip_greedy_device_redone()
+    assert (redone == 0) if on_device else (redone != 0), redone
+    bad = [k for k in range(len(seeds)) if not np.array_equal(host[k], dev[k])]
+    assert not bad, (len(ts), bad[:8])
+    if draws is not None:
+        assert np.array_equal(d_host, d_dev)
+        draws[:] = d_host
+    return host
+
+
+def _supported(ts, n_inds):
+    from tnco_amd import _lib
+    off, _hold = core.holders_csr(ts, n_inds)
+    return bool(_lib.load().tnco_hip_greedy_device_supported(len(ts), n_inds, off.ctypes.data))
+
+
+@pytest.mark.parametrize("n,gs", [(4, 1), (8, 1), (64, 7), (200, 3), (512, 11)])
+def test_regular_graphs(n, gs):
+    prob = syn.regular_problem(n, graph_seed=gs, degree=3 if n > 4 else 2)
+    assert _supported(prob.ts_inds, prob.n_inds)
+    seeds = np.concatenate([[0, 1, 42, 2**32 - 1, 123456789, 77], syn.replica_seeds(250)])
+    links = _both(prob.ts_inds, prob.n_inds, seeds)
+    for k in (0, 5, 100):  # every contraction shares an index (check_shared_inds, sa.py:186-190)
+        ct.derive_inds(links[k, 0], links[k, 1], prob.leaf_masks, prob.output_mask, check_shared_inds=True)
+
+
+def test_hyper_indices_outputs_equal_sets():
+    seeds = syn.replica_seeds(40)
+    for seed in range(8):
+        ts, _d, out = syn.random_hyper_tn(20, 37, k=3, n_output=4, seed=seed)
+        n_inds = 1 + max(i for xs in ts for i in xs)
+        cnt = [sum(i in xs for xs in ts) for i in range(n_inds)]
+        assert _supported(ts, n_inds)
+        _both(ts, n_inds, seeds, out_keep=[i for i in out if cnt[i] <= 1])
+    _both([[0, 1], [0, 1], [1, 2], [2, 3], [1, 2], [3, 0]], 4, seeds)          # equal index sets
+    _both([[0, 1, 9], [1, 2, 9], [2, 3, 9], [3, 4, 9], [4, 0, 9]], 10, seeds)  # an index common to all
+    _both([[0, 1], [1, 2], [2, 3]], 4, seeds, out_keep=[0, 3])                  # the reference's docstring example
+
+
+def test_config5_topology_and_many_seeds():
+    p = syn.sycamore_problem(20)
+    assert _supported(p.ts_inds, p.n_inds)
+    _both(p.ts_inds, p.n_inds, syn.replica_seeds(600))
+
+
+def test_components_share_one_generator():
+    a, b = syn.regular_problem(10, graph_seed=2), syn.regular_problem(16, graph_seed=4)
+    seeds = np.array([3, 99, 2**31 + 5, 7, 8, 9])
+    draws = np.zeros(len(seeds), np.uint64)
+    _both(a.ts_inds, a.n_inds, seeds, draws=draws)
+    assert np.all(draws >= 9)
+    _both(b.ts_inds, b.n_inds, seeds, draws=draws)
+
+
+def test_networks_outside_the_kernel_limits_take_the_host_path():
+    # an index held by seven tensors: not the kernel's, same result through the same entry point
+    ts = [[0, i + 1, (i + 1) % 7 + 1] for i in range(7)]
+    assert not _supported(ts, 8)
+    _both(ts, 8, syn.replica_seeds(5), on_device=False)
+    # two tensors / one tensor: contract_path does not call the optimizer
+    _both([[0, 1], [1, 2]], 3, [1, 2, 3], on_device=False)

@@ -56,12 +56,16 @@ def random_trees(leaf_positions, n_inds: int, seeds, n_threads: int = 0) -> np.n
     return out
 
 
-def greedy_trees(leaf_positions, n_inds: int, seeds, output_mask=None, draws=None, n_threads: int = 0) -> np.ndarray:
+def greedy_trees(leaf_positions, n_inds: int, seeds, output_mask=None, draws=None, n_threads: int = 0,
+                 device: int | None = None) -> np.ndarray:
     """Initial trees as the reference draws them (Random(seed).shuffle + opt_einsum's greedy,
     tnco/utils/tn.py:189-230) for one connected component: links[R, 3, N].
 
-    Native batched twin of ctree.greedy_contraction (csrc/host_greedy.cpp).  `draws` (uint64[R],
-    updated in place): outputs of Random(seed) consumed by the components before this one."""
+    Native batched twin of ctree.greedy_contraction: on host threads (csrc/host_greedy.cpp) or, with
+    `device` = a GPU ordinal, on that GPU (csrc/greedy_device.hip: one wavefront per tree; networks
+    outside the kernel's limits go to the host version inside the call) -- the same trees either way.
+    `draws` (uint64[R], updated in place): outputs of Random(seed) consumed by the components before
+    this one."""
     L = _lib.load()
     n = len(leaf_positions)
     off, hold = holders_csr(leaf_positions, n_inds)
@@ -70,8 +74,12 @@ def greedy_trees(leaf_positions, n_inds: int, seeds, output_mask=None, draws=Non
     if draws is not None and (draws.dtype != np.uint64 or draws.shape != (len(seeds),) or not draws.flags.c_contiguous):
         raise ValueError("'draws' must be a contiguous uint64 array with one entry per seed.")
     out = np.empty((len(seeds), 3, 2 * n - 1), np.int32)
-    rc = L.tnco_hip_greedy_trees(n, n_inds, _ptr(off), _ptr(hold), _ptr(om), len(seeds), _ptr(seeds),
-                                 _ptr(draws), _ptr(out), n_threads)
+    if device is None:
+        rc = L.tnco_hip_greedy_trees(n, n_inds, _ptr(off), _ptr(hold), _ptr(om), len(seeds), _ptr(seeds),
+                                     _ptr(draws), _ptr(out), n_threads)
+    else:
+        rc = L.tnco_hip_greedy_trees_device(int(device), n, n_inds, _ptr(off), _ptr(hold), _ptr(om), len(seeds),
+                                            _ptr(seeds), _ptr(draws), _ptr(out), n_threads)
     if rc:
         raise ValueError("greedy initial contraction failed (component not connected?).")
     return out

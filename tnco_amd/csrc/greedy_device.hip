@@ -1,0 +1,776 @@
+// greedy_device.hip -- the reference's initial contraction trees drawn ON THE DEVICE: the batched
+// twin of host_greedy.cpp (same trees, tree for tree; tests/test_gpu_greedy.py).
+//
+//   tnco/utils/tn.py:189-230: Random(seed).shuffle of the component's tensors (CPython's MT19937,
+//   init_by_array, _randbelow), then opt_einsum's greedy path finder with every dimension 2
+//   (paths.ssa_greedy_optimize, _simple_chooser, 'memory-removed'; restated, "parity unpinned" like
+//   the host version: opt_einsum is not pinned by the reference and absent here).
+//
+// Why a kernel: for 65 536 runs of a 512-tensor network the host version takes 3 s on the GPU box's 16
+// threads -- seven times the 1 000 SA sweeps that follow.
+//
+// Two kernels.  py_shuffle_kernel: ONE LANE per tree (seeding and shuffling are a serial chain per
+// tree, 2 500 dependent steps; the generator's state is a column of a [624][R] array, so the lanes of
+// a wavefront read and write whole lines).  greedy_kernel: ONE WAVEFRONT per tree, a persistent grid:
+//   * an index set = W 64-bit words, word x in lane x (W <= 64); |set| = a wave reduction;
+//   * opt_einsum's candidate queue ordered by (cost, id2, id1) with cost = 2^|k12| - 2^|k1| - 2^|k2|
+//     becomes ONE 64-bit key per candidate (greedy_key.h: the cost in non-adjacent form, exact), the
+//     queue a flat array in LDS, cell c owned by lane c % 64: every lane keeps the minimum of its
+//     cells, a pop is a wave-min over the lanes + a rescan of the winner's cells, a push one LDS
+//     store -- no sift-down chains;
+//   * the neighbours of the tensor just made (the keys sharing a contractible dim with it) are a
+//     bitset over the slots, word x in lane x; the candidates of one push are evaluated one per lane;
+//   * index sets are content-addressed slots (a stale queue entry revives when an equal set
+//     reappears, as with the frozenset keys of the published code): an open-addressing table in LDS.
+// Limits of this path (the host version takes the rest): n_inds <= 2040, n_leaves <= 2000, every
+// index held by at most GREEDY_MAXH tensors, LDS need <= 64 KB.  A tree that ends with more than one
+// tensor (outer products left) is flagged and redone on the host.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/tnco_hip.h"
+#include "greedy_key.h"
+
+namespace tnco {
+namespace {
+
+constexpr int GREEDY_MAXH = 6;
+constexpr uint32_t DEAD = 0xFFFFu;
+constexpr uint64_t KMAX = ~0ull;
+
+// ---------------------------------------------------------------------------------------------
+// CPython's generator, one lane per tree
+// ---------------------------------------------------------------------------------------------
+struct ShuffleParams {
+  int32_t n;
+  int64_t R;
+  const uint32_t* seeds;
+  uint64_t* draws;      // [R] or NULL (in: outputs to skip, out: outputs consumed)
+  const uint32_t* mt0;  // [624] init_genrand(19650218)
+  uint32_t* mt;         // [624][R]
+  uint16_t* perm;       // [R][n]
+};
+
+__global__ __launch_bounds__(64) void py_shuffle_kernel(const ShuffleParams p) {
+  const int64_t r = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (r >= p.R) return;
+  const int64_t S = p.R;
+  uint32_t* mt = p.mt + r;
+  const uint32_t seed = p.seeds[r];
+  // Modules/_randommodule.c init_by_array(key = {seed})
+  for (int i = 0; i < 624; ++i) mt[i * S] = p.mt0[i];
+  uint32_t prev = p.mt0[0];
+  int i = 1;
+  for (int k = 624; k; --k) {
+    const uint32_t cur = (mt[i * S] ^ ((prev ^ (prev >> 30)) * 1664525u)) + seed;  // + key[0] + 0
+    mt[i * S] = cur;
+    prev = cur;
+    if (++i >= 624) {
+      mt[0] = cur;
+      i = 1;
+    }
+  }
+  for (int k = 623; k; --k) {
+    const uint32_t cur = (mt[i * S] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
+    mt[i * S] = cur;
+    prev = cur;
+    if (++i >= 624) {
+      mt[0] = cur;
+      i = 1;
+    }
+  }
+  mt[0] = 0x80000000u;
+  int idx = 624;
+  uint64_t used = 0;
+  auto next = [&]() -> uint32_t {
+    if (idx >= 624) {  // genrand_uint32: the whole state at once
+      uint32_t cur = mt[0];
+      for (int k = 0; k < 624; ++k) {
+        const uint32_t nx = mt[((k + 1) % 624) * S];
+        const uint32_t y = (cur & 0x80000000u) | (nx & 0x7fffffffu);
+        mt[k * S] = mt[((k + 397) % 624) * S] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        cur = nx;
+      }
+      idx = 0;
+    }
+    uint32_t y = mt[(idx++) * S];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    ++used;
+    return y;
+  };
+  if (p.draws)
+    for (uint64_t k = p.draws[r]; k; --k) (void)next();
+  // Lib/random.py shuffle: for i in reversed(range(1, n)): j = _randbelow(i + 1)
+  uint16_t* perm = p.perm + r * (int64_t)p.n;
+  for (int t = 0; t < p.n; ++t) perm[t] = (uint16_t)t;
+  for (int t = p.n - 1; t >= 1; --t) {
+    const uint32_t bound = (uint32_t)t + 1u;
+    const int k = 32 - __clz(bound);  // bound.bit_length()
+    uint32_t j = next() >> (32 - k);
+    while (j >= bound) j = next() >> (32 - k);
+    const uint16_t a = perm[t], b = perm[j];
+    perm[t] = b;
+    perm[j] = a;
+  }
+  if (p.draws) p.draws[r] = used;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the greedy path finder, one wavefront per tree
+// ---------------------------------------------------------------------------------------------
+struct GreedyParams {
+  int32_t n, I, W, NW, SMAX, Q, TS;  // TS: table size (a power of two)
+  int64_t R;
+  const uint64_t* leaf;     // [n][W] index sets of the tensors, original order
+  const uint64_t* output;   // [W]
+  const int32_t* hoff;      // CSR: index -> tensors holding it
+  const int32_t* holders;
+  const uint16_t* perm;     // [R][n]
+  // scratch, one set per resident wavefront (G = gridDim.x)
+  uint64_t* keys;           // [G][SMAX][W]   slot -> index set
+  uint64_t* nbr;            // [G][SMAX][NW]  slot -> live slots sharing a contractible dim
+  uint64_t* arena;          // [G][Q][W + 1]  queued candidate -> its result set, then s1 | s2 << 16
+  int32_t* path;            // [G][n][2]      ssa path
+  uint16_t* slot_of_leaf;   // [G][n]
+  int32_t* links;           // [R][3][2n - 1] out
+  int32_t* status;          // [R] out: 0 = done, else redo on the host
+};
+
+__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int o) {
+  const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int lane) {
+  const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, lane), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), lane);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t wsum(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+  return v;
+}
+__device__ __forceinline__ uint64_t wmin64(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) {
+    const uint64_t t = shfl_xor64(v, o);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+__device__ __forceinline__ uint64_t wxor64(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) v ^= shfl_xor64(v, o);
+  return v;
+}
+__device__ __forceinline__ uint64_t wand64(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) v &= shfl_xor64(v, o);
+  return v;
+}
+// exclusive prefix sum over the lanes
+__device__ __forceinline__ uint32_t wscan_excl(uint32_t v, int lane) {
+  uint32_t s = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)s, o);
+    if (lane >= o) s += t;
+  }
+  return s - v;
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+typedef __attribute__((address_space(3))) volatile uint64_t* lds_u64;
+typedef __attribute__((address_space(3))) volatile uint16_t* lds_u16;
+typedef __attribute__((address_space(3))) volatile int16_t* lds_i16;
+
+__global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
+  extern __shared__ uint64_t lds_raw[];
+  const int lane = threadIdx.x;
+  const int n = p.n, I = p.I, W = p.W, NW = p.NW, SMAX = p.SMAX, Q = p.Q, TS = p.TS;
+  const int QC = (Q + 63) & ~63;  // queue cells (a multiple of 64)
+  // LDS: queue keys [QC] | broadcast rows a, output, ref2, ref3 [4 W] | ssa [SMAX] | fp [SMAX] |
+  //      holders per dim [I] | neighbour list [SMAX] | table [TS]
+  lds_u64 hk = (lds_u64)lds_raw;
+  lds_u64 bc = hk + QC;
+  lds_u16 ssa = (lds_u16)(bc + 4 * W);
+  lds_u16 fp = ssa + SMAX;
+  lds_u16 cnt = fp + SMAX;
+  lds_u16 lst = cnt + I;
+  lds_i16 table = (lds_i16)(lst + SMAX);
+
+  const int g = blockIdx.x;
+  uint64_t* keys = p.keys + (size_t)g * SMAX * W;
+  uint64_t* nbr = p.nbr + (size_t)g * SMAX * NW;
+  uint64_t* arena = p.arena + (size_t)g * Q * (W + 1);
+  int32_t* path = p.path + (size_t)g * n * 2;
+  uint16_t* slot_of_leaf = p.slot_of_leaf + (size_t)g * n;
+  const bool inw = lane < W;
+
+  for (int64_t r = g; r < p.R; r += gridDim.x) {
+    const uint16_t* perm = p.perm + r * (int64_t)n;
+    int status = 0;
+    // ---- clear ----
+    for (int c = lane; c < QC; c += 64) hk[c] = KMAX;
+    for (int c = lane; c < TS; c += 64) table[c] = -1;
+    for (int c = lane; c < I; c += 64) cnt[c] = 0;
+    for (int c = lane; c < SMAX; c += 64) ssa[c] = DEAD;
+    for (size_t c = lane; c < (size_t)SMAX * NW; c += 64) nbr[c] = 0;
+    uint64_t out = inw ? p.output[lane] : 0;
+    {  // dims common to all inputs join the output
+      uint64_t all = inw ? ~0ull : 0;
+      for (int t = 0; t < n; ++t) all &= inw ? p.leaf[(size_t)t * W + lane] : 0;
+      out |= all;
+    }
+    __syncthreads();
+    int next_ssa = n, nslots = 0, step = 0, n_alive = 0;
+    // content-addressed slot of an index set (word x in lane x): >= 0 found, else -1 and *cell = the free cell
+    auto hash_of = [&](uint64_t m) -> uint32_t {
+      uint64_t h = inw ? (m + 0x9E3779B97F4A7C15ull * (uint64_t)(lane + 1)) * 0xff51afd7ed558ccdull : 0;
+      h ^= h >> 29;
+      h = wxor64(h);
+      h *= 0xc4ceb9fe1a85ec53ull;
+      h ^= h >> 32;
+      return (uint32_t)h;
+    };
+    auto find_slot = [&](uint64_t m, int& cell) -> int {
+      for (uint32_t h = hash_of(m) & (uint32_t)(TS - 1);; h = (h + 1) & (uint32_t)(TS - 1)) {
+        const int s = uni((int)table[h]);
+        if (s < 0) {
+          cell = (int)h;
+          return -1;
+        }
+        const uint64_t ks = inw ? keys[(size_t)s * W + lane] : 0;
+        if (__all(ks == m)) return s;
+      }
+    };
+    auto new_slot = [&](uint64_t m, int cell) -> int {
+      const int s = nslots++;
+      if (s >= SMAX) {
+        status = 4;
+        return 0;
+      }
+      if (inw) keys[(size_t)s * W + lane] = m;
+      const uint32_t f = wsum(inw ? (uint32_t)__popcll(m) : 0u);
+      if (lane == 0) {
+        fp[s] = (uint16_t)f;
+        table[cell] = (int16_t)s;
+      }
+      return s;
+    };
+    // ---- the inputs in shuffled order; equal index sets are multiplied at once ----
+    for (int t = 0; t < n; ++t) {
+      const int lf = perm[t];
+      const uint64_t m = inw ? p.leaf[(size_t)lf * W + lane] : 0;
+      int cell = 0;
+      int s = find_slot(m, cell);
+      const bool alive = s >= 0 && ssa[s] != DEAD;
+      if (alive) {
+        if (lane == 0) {
+          path[2 * step] = ssa[s];
+          path[2 * step + 1] = t;
+          ssa[s] = (uint16_t)next_ssa;
+        }
+        ++step;
+        ++next_ssa;
+      } else {
+        if (s < 0) s = new_slot(m, cell);
+        if (lane == 0) ssa[s] = (uint16_t)t;
+        ++n_alive;
+      }
+      if (lane == 0) slot_of_leaf[lf] = (uint16_t)s;
+      __syncthreads();
+    }
+    // ---- per contractible dim: its holders (slots, by ssa id), the counts, the neighbour sets ----
+    if (inw) {
+      bc[W + lane] = out;
+      bc[2 * W + lane] = 0;
+      bc[3 * W + lane] = 0;
+    }
+    __syncthreads();
+    // the (deduplicated, ssa-ordered) slots holding dim d; returns their number
+    auto dim_slots = [&](int d, int (&sl)[GREEDY_MAXH], int (&id)[GREEDY_MAXH]) -> int {
+      const int h0 = p.hoff[d], m = p.hoff[d + 1] - h0;
+      int cntu = 0;
+#pragma unroll
+      for (int i = 0; i < GREEDY_MAXH; ++i) {
+        sl[i] = -1;
+        id[i] = 0x7FFFFFFF;
+        if (i < m) {
+          const int s = slot_of_leaf[p.holders[h0 + i]];
+          bool dup = false;
+#pragma unroll
+          for (int j = 0; j < GREEDY_MAXH; ++j)
+            if (j < i && sl[j] == s) dup = true;
+          if (!dup) {
+            sl[i] = s;
+            id[i] = ssa[s];
+            ++cntu;
+          }
+        }
+      }
+      // order by ssa id (absent entries last): odd-even transposition over GREEDY_MAXH
+#pragma unroll
+      for (int pass = 0; pass < GREEDY_MAXH; ++pass) {
+#pragma unroll
+        for (int i = pass & 1; i + 1 < GREEDY_MAXH; i += 2) {
+          if (id[i] > id[i + 1]) {
+            const int ti = id[i], ts = sl[i];
+            id[i] = id[i + 1]; sl[i] = sl[i + 1];
+            id[i + 1] = ti; sl[i + 1] = ts;
+          }
+        }
+      }
+      return cntu;
+    };
+    for (int d0 = 0; d0 < I; d0 += 64) {
+      const int d = d0 + lane;
+      if (d < I && !((bc[W + (d >> 6)] >> (d & 63)) & 1ull)) {
+        int sl[GREEDY_MAXH], id[GREEDY_MAXH];
+        const int m = dim_slots(d, sl, id);
+        cnt[d] = (uint16_t)m;
+        if (m >= 2) atomicOr((unsigned long long*)(uint64_t*)(bc + 2 * W + (d >> 6)), 1ull << (d & 63));
+        if (m >= 3) atomicOr((unsigned long long*)(uint64_t*)(bc + 3 * W + (d >> 6)), 1ull << (d & 63));
+#pragma unroll
+        for (int i = 0; i < GREEDY_MAXH; ++i)
+#pragma unroll
+          for (int j = 0; j < GREEDY_MAXH; ++j)
+            if (i < m && j < m && i != j)
+              atomicOr((unsigned long long*)&nbr[(size_t)sl[i] * NW + (sl[j] >> 6)], 1ull << (sl[j] & 63));
+      }
+    }
+    __threadfence();
+    __syncthreads();
+    uint64_t ref2 = inw ? bc[2 * W + lane] : 0, ref3 = inw ? bc[3 * W + lane] : 0;
+    // |result| of contracting slots s1, s2 under the current counts (this lane alone: W words)
+    auto size12_of = [&](int s1, int s2) -> int {
+      int c = 0;
+      for (int x = 0; x < W; ++x) {
+        const uint64_t a = keys[(size_t)s1 * W + x], b = keys[(size_t)s2 * W + x];
+        const uint64_t either = a | b, two = a & b, one = either & ~two;
+        c += __popcll((either & bc[W + x]) | (two & bc[3 * W + x]) | (one & bc[2 * W + x]));
+      }
+      return c;
+    };
+    // ---- initial candidates: per dim, each holder against the later ones, the cheapest pushed ----
+    int count = 0;  // queue cells used
+    for (int d0 = 0; d0 < I; d0 += 64) {
+      const int d = d0 + lane;
+      int sl[GREEDY_MAXH], id[GREEDY_MAXH];
+      int m = 0;
+      if (d < I && !((bc[W + (d >> 6)] >> (d & 63)) & 1ull)) m = dim_slots(d, sl, id);
+      const int mine = m >= 2 ? m - 1 : 0;
+      const int base = count + (int)wscan_excl((uint32_t)mine, lane);
+      count += (int)wsum((uint32_t)mine);
+      if (count > Q) {
+        status = 5;
+        break;
+      }
+#pragma unroll
+      for (int i = 0; i + 1 < GREEDY_MAXH; ++i) {
+        if (i + 1 < m) {
+          uint64_t bestk = KMAX;
+          int bj = i + 1;
+#pragma unroll
+          for (int j = 1; j < GREEDY_MAXH; ++j) {
+            if (j > i && j < m) {
+              const int s12 = size12_of(sl[i], sl[j]);
+              const uint64_t k = greedy_cand_key(s12, fp[sl[i]], fp[sl[j]], id[j], id[i]);
+              if (k < bestk) {
+                bestk = k;
+                bj = j;
+              }
+            }
+          }
+          int sj = sl[1];
+#pragma unroll
+          for (int j = 1; j < GREEDY_MAXH; ++j)
+            if (j == bj) sj = sl[j];
+          const int seq = base + i;
+          uint64_t* row = arena + (size_t)seq * (W + 1);
+          for (int x = 0; x < W; ++x) {
+            const uint64_t a = keys[(size_t)sl[i] * W + x], b = keys[(size_t)sj * W + x];
+            const uint64_t either = a | b, two = a & b, one = either & ~two;
+            row[x] = (either & bc[W + x]) | (two & bc[3 * W + x]) | (one & bc[2 * W + x]);
+          }
+          row[W] = (uint64_t)sl[i] | ((uint64_t)sj << 16);  // (ids ascend along the list: id1 = id[i])
+          hk[seq] = bestk;
+        }
+      }
+    }
+    __syncthreads();
+    // every lane: the minimum of its cells
+    uint64_t lkey = KMAX;
+    int lrow = 0;
+    auto rescan = [&]() {
+      lkey = KMAX;
+      lrow = 0;
+      for (int c = lane, row = 0; c < count; c += 64, ++row) {
+        const uint64_t k = hk[c];
+        if (k < lkey) {
+          lkey = k;
+          lrow = row;
+        }
+      }
+    };
+    rescan();
+    // ---- the greedy loop ----
+    while (status == 0) {
+      const uint64_t best = wmin64(lkey);
+      if (best == KMAX) break;
+      const int wl = __ffsll((unsigned long long)__ballot(lkey == best)) - 1;
+      const int seq = uni(__shfl(lrow, wl)) * 64 + wl;
+      if (lane == wl) {
+        hk[seq] = KMAX;
+        rescan();
+      }
+      const uint64_t* row = arena + (size_t)seq * (W + 1);
+      const uint64_t sw = row[W];
+      const int s1 = uni((int)(sw & 0xFFFFu)), s2 = uni((int)((sw >> 16) & 0xFFFFu));
+      const int id1 = ssa[s1], id2 = ssa[s2];
+      if (id1 == (int)DEAD || id2 == (int)DEAD) continue;  // obsolete
+      const uint64_t k12 = inw ? row[lane] : 0;
+      if (lane == 0) {
+        ssa[s1] = DEAD;
+        ssa[s2] = DEAD;
+        path[2 * step] = id1;
+        path[2 * step + 1] = id2;
+      }
+      ++step;
+      __syncthreads();
+      int cell = 0;
+      int s12 = find_slot(k12, cell);
+      const bool merged = s12 >= 0 && ssa[s12] != DEAD;  // an equal index set is live: multiplied with it
+      if (merged) {
+        if (lane == 0) {
+          path[2 * step] = ssa[s12];
+          path[2 * step + 1] = next_ssa;
+        }
+        ++step;
+        ++next_ssa;
+        n_alive -= 2;
+      } else {
+        if (s12 < 0) s12 = new_slot(k12, cell);
+        if (status) break;
+        n_alive -= 1;
+      }
+      const int id12 = next_ssa++;
+      if (lane == 0) ssa[s12] = (uint16_t)id12;
+      // holders per dim: only shared dims and dropped dims change their number
+      const uint64_t a = inw ? keys[(size_t)s1 * W + lane] : 0, b = inw ? keys[(size_t)s2 * W + lane] : 0;
+      {
+        uint64_t u = (merged ? (a | b) : ((a & b) | ((a ^ b) & ~k12))) & ~out;
+        while (u) {
+          const int bit = __ffsll((unsigned long long)u) - 1;
+          u &= u - 1;
+          const int d = lane * 64 + bit;
+          const int dec = (int)((a >> bit) & 1ull) + (int)((b >> bit) & 1ull) - (merged ? 0 : (int)((k12 >> bit) & 1ull));
+          const int c = (int)cnt[d] - dec;
+          cnt[d] = (uint16_t)c;
+          const uint64_t m1 = 1ull << bit;
+          ref2 = c >= 2 ? (ref2 | m1) : (ref2 & ~m1);
+          ref3 = c >= 3 ? (ref3 | m1) : (ref3 & ~m1);
+        }
+      }
+      // neighbours: those of k1 and of k2 (every one of them shares a dim the result keeps)
+      const bool innw = lane < NW;
+      uint64_t un = innw ? (nbr[(size_t)s1 * NW + lane] | nbr[(size_t)s2 * NW + lane]) : 0;
+      if (lane == (s1 >> 6)) un &= ~(1ull << (s1 & 63));
+      if (lane == (s2 >> 6)) un &= ~(1ull << (s2 & 63));
+      if (lane == (s12 >> 6)) un &= ~(1ull << (s12 & 63));
+      uint64_t n12 = un;
+      if (merged && innw) n12 |= nbr[(size_t)s12 * NW + lane];
+      if (innw) nbr[(size_t)s12 * NW + lane] = n12;
+      {
+        const int w1 = s1 >> 6, w2 = s2 >> 6, w12 = s12 >> 6;
+        const uint64_t m1 = 1ull << (s1 & 63), m2 = 1ull << (s2 & 63), m12 = 1ull << (s12 & 63);
+        uint64_t u = un;
+        while (u) {
+          const int y = lane * 64 + __ffsll((unsigned long long)u) - 1;
+          u &= u - 1;
+          uint64_t* ry = nbr + (size_t)y * NW;
+          uint64_t v = ry[w1];
+          v &= ~m1;
+          if (w2 == w1) v &= ~m2;
+          if (w12 == w1) v |= m12;
+          ry[w1] = v;
+          if (w2 != w1) {
+            v = ry[w2];
+            v &= ~m2;
+            if (w12 == w2) v |= m12;
+            ry[w2] = v;
+          }
+          if (w12 != w1 && w12 != w2) ry[w12] |= m12;
+        }
+      }
+      // push the cheapest (k12, neighbour)
+      const uint32_t pc = (uint32_t)__popcll(n12);
+      const int total = (int)wsum(pc);
+      if (total > 0) {
+        {
+          int at = (int)wscan_excl(pc, lane);
+          uint64_t u = n12;
+          while (u) {
+            lst[at++] = (uint16_t)(lane * 64 + __ffsll((unsigned long long)u) - 1);
+            u &= u - 1;
+          }
+        }
+        if (inw) {
+          bc[lane] = k12;
+          bc[2 * W + lane] = ref2;
+          bc[3 * W + lane] = ref3;
+        }
+        __syncthreads();
+        const int f12 = fp[s12];
+        uint64_t bestk = KMAX;
+        int bests = 0;
+        for (int j0 = 0; j0 < total; j0 += 64) {
+          const int j = j0 + lane;
+          if (j < total) {
+            const int s = lst[j];
+            int c = 0;
+            for (int x = 0; x < W; ++x) {
+              const uint64_t ax = bc[x], bx = keys[(size_t)s * W + x];
+              const uint64_t either = ax | bx, two = ax & bx, one = either & ~two;
+              c += __popcll((either & bc[W + x]) | (two & bc[3 * W + x]) | (one & bc[2 * W + x]));
+            }
+            const int ids = ssa[s];
+            const uint64_t k = greedy_cand_key(c, f12, fp[s], ids > id12 ? ids : id12, ids > id12 ? id12 : ids);
+            if (k < bestk) {
+              bestk = k;
+              bests = s;
+            }
+          }
+        }
+        // (keys of distinct neighbours differ in an id: exactly one lane holds the minimum)
+        const uint64_t wk = wmin64(bestk);
+        const int sbest = uni(__shfl(bests, __ffsll((unsigned long long)__ballot(bestk == wk)) - 1));
+        const int idb = ssa[sbest];
+        const uint64_t bb = inw ? keys[(size_t)sbest * W + lane] : 0;
+        const uint64_t either = k12 | bb, two = k12 & bb, one = either & ~two;
+        const uint64_t res = (either & out) | (two & ref3) | (one & ref2);
+        if (count >= Q) {
+          status = 5;
+          break;
+        }
+        const int cs = count++;
+        uint64_t* nrow = arena + (size_t)cs * (W + 1);
+        if (inw) nrow[lane] = res;
+        if (lane == 0) nrow[W] = id12 < idb ? ((uint64_t)s12 | ((uint64_t)sbest << 16)) : ((uint64_t)sbest | ((uint64_t)s12 << 16));
+        if (lane == (cs & 63)) {
+          hk[cs] = wk;
+          if (wk < lkey) {
+            lkey = wk;
+            lrow = cs >> 6;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (status == 0 && (n_alive != 1 || step != n - 1)) status = 3;  // outer products left: the host's
+    // ---- ssa path -> links ----
+    const int N = 2 * n - 1;
+    int32_t* lk = p.links + r * 3 * (int64_t)N;
+    for (int c = lane; c < 3 * N; c += 64) lk[c] = -1;
+    __threadfence();
+    __syncthreads();
+    if (status == 0) {
+      int bad = 0;
+      for (int s = lane; s < n - 1; s += 64) {
+        int x = path[2 * s], y = path[2 * s + 1];
+        x = x < n ? (int)perm[x] : x;
+        y = y < n ? (int)perm[y] : y;
+        const int z = n + s;
+        if (x < 0 || y < 0 || x >= z || y >= z || x == y) {
+          bad = 1;
+          continue;
+        }
+        lk[z] = x < y ? x : y;
+        lk[N + z] = x < y ? y : x;
+        if (atomicExch(&lk[2 * N + x], z) != -1) bad = 1;
+        if (atomicExch(&lk[2 * N + y], z) != -1) bad = 1;
+      }
+      if (__any(bad)) status = 6;
+    }
+    if (lane == 0) p.status[r] = status;
+    __threadfence();
+    __syncthreads();
+  }
+}
+
+struct DevBufs {
+  std::vector<void*> ptrs;
+  ~DevBufs() {
+    for (void* q : ptrs) (void)hipFree(q);
+  }
+  template <typename T>
+  hipError_t alloc(T** p, size_t count) {
+    void* q = nullptr;
+    const hipError_t e = hipMalloc(&q, std::max<size_t>(count * sizeof(T), 16));
+    if (e == hipSuccess) ptrs.push_back(q);
+    *p = static_cast<T*>(q);
+    return e;
+  }
+};
+
+void py_init_genrand(uint32_t* mt, uint32_t s) {
+  mt[0] = s;
+  for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+}
+
+size_t lds_bytes(int W, int SMAX, int I, int QC, int TS) {
+  return (size_t)QC * 8 + (size_t)4 * W * 8 + (size_t)SMAX * 2 * 3 + (size_t)I * 2 + (size_t)TS * 2 + 16;
+}
+
+}  // namespace
+}  // namespace tnco
+
+using namespace tnco;
+
+#define G_TRY(expr)                      \
+  do {                                   \
+    const hipError_t e_ = (expr);        \
+    if (e_ != hipSuccess) return TNCO_HIP_ERUNTIME; \
+  } while (0)
+
+static int64_t g_last_redone = -1;
+// trees of the last tnco_hip_greedy_trees_device call that the host version did (-1: the whole batch)
+extern "C" int64_t tnco_hip_greedy_device_redone(void) { return g_last_redone; }
+
+// 1 when tnco_hip_greedy_trees_device takes this network itself (else it hands the batch to the host version)
+extern "C" int tnco_hip_greedy_device_supported(int32_t n_leaves, int32_t n_inds, const int32_t* holders_off) {
+  if (n_leaves < 3 || n_leaves > 2000 || n_inds < 1 || n_inds > GREEDY_KEY_MAX_EXP || !holders_off) return 0;
+  int64_t q = n_leaves;
+  for (int32_t i = 0; i < n_inds; ++i) {
+    const int32_t m = holders_off[i + 1] - holders_off[i];
+    if (m > GREEDY_MAXH) return 0;
+    q += m > 1 ? m - 1 : 0;
+  }
+  const int W = (n_inds + 63) / 64, SMAX = 2 * n_leaves + 8;
+  int TS = 64;
+  while (TS < 2 * SMAX) TS <<= 1;
+  const int QC = (int)((q + 63) & ~63ll);
+  return lds_bytes(W, SMAX, n_inds, QC, TS) <= 64 * 1024 ? 1 : 0;
+}
+
+extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, int32_t n_inds, const int32_t* holders_off,
+                                            const int32_t* holders, const uint64_t* output_mask, int64_t n_replicas,
+                                            const uint32_t* seeds, uint64_t* draws, int32_t* links_out,
+                                            int32_t n_threads) {
+  if (n_leaves < 1 || n_inds < 0 || !holders_off || !holders || !seeds || !links_out || n_replicas < 0)
+    return TNCO_HIP_EINVAL;
+  if (n_replicas == 0) return TNCO_HIP_OK;
+  g_last_redone = -1;
+  if (!tnco_hip_greedy_device_supported(n_leaves, n_inds, holders_off))
+    return tnco_hip_greedy_trees(n_leaves, n_inds, holders_off, holders, output_mask, n_replicas, seeds, draws,
+                                 links_out, n_threads);
+  G_TRY(hipSetDevice(device));
+  const int n = n_leaves, I = n_inds, W = (I + 63) / 64, SMAX = 2 * n + 8, NW = (SMAX + 63) / 64;
+  const int64_t R = n_replicas, N = 2 * (int64_t)n - 1;
+  int64_t q = n;
+  for (int i = 0; i < I; ++i) q += std::max(0, holders_off[i + 1] - holders_off[i] - 1);
+  const int Q = (int)q, QC = (Q + 63) & ~63;
+  int TS = 64;
+  while (TS < 2 * SMAX) TS <<= 1;
+  std::vector<uint64_t> leaf((size_t)n * W, 0), outm((size_t)W, 0);
+  for (int i = 0; i < I; ++i)
+    for (int k = holders_off[i]; k < holders_off[i + 1]; ++k) {
+      const int t = holders[k];
+      if (t < 0 || t >= n) return TNCO_HIP_EINVAL;
+      leaf[(size_t)t * W + (i >> 6)] |= 1ull << (i & 63);
+    }
+  if (output_mask)
+    for (int x = 0; x < W; ++x) outm[x] = output_mask[x];
+  uint32_t mt0[624];
+  py_init_genrand(mt0, 19650218u);
+
+  int cus = 256;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  }
+  const size_t lds = lds_bytes(W, SMAX, I, QC, TS);
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / lds));
+  const int G = (int)std::min<int64_t>(R, (int64_t)cus * per_cu);
+
+  DevBufs db;
+  ShuffleParams sp{};
+  GreedyParams gp{};
+  uint32_t *d_seeds, *d_mt0, *d_mt;
+  uint64_t *d_draws = nullptr, *d_leaf, *d_out;
+  int32_t *d_hoff, *d_hold;
+  uint16_t* d_perm;
+  G_TRY(db.alloc(&d_seeds, (size_t)R));
+  G_TRY(db.alloc(&d_mt0, 624));
+  G_TRY(db.alloc(&d_mt, (size_t)624 * R));
+  G_TRY(db.alloc(&d_perm, (size_t)R * n));
+  if (draws) G_TRY(db.alloc(&d_draws, (size_t)R));
+  G_TRY(db.alloc(&d_leaf, leaf.size()));
+  G_TRY(db.alloc(&d_out, outm.size()));
+  G_TRY(db.alloc(&d_hoff, (size_t)I + 1));
+  G_TRY(db.alloc(&d_hold, (size_t)std::max(1, holders_off[I])));
+  G_TRY(db.alloc(&gp.keys, (size_t)G * SMAX * W));
+  G_TRY(db.alloc(&gp.nbr, (size_t)G * SMAX * NW));
+  G_TRY(db.alloc(&gp.arena, (size_t)G * Q * (W + 1)));
+  G_TRY(db.alloc(&gp.path, (size_t)G * n * 2));
+  G_TRY(db.alloc(&gp.slot_of_leaf, (size_t)G * n));
+  G_TRY(db.alloc(&gp.links, (size_t)R * 3 * N));
+  G_TRY(db.alloc(&gp.status, (size_t)R));
+  G_TRY(hipMemcpy(d_seeds, seeds, (size_t)R * 4, hipMemcpyHostToDevice));
+  G_TRY(hipMemcpy(d_mt0, mt0, sizeof(mt0), hipMemcpyHostToDevice));
+  if (draws) G_TRY(hipMemcpy(d_draws, draws, (size_t)R * 8, hipMemcpyHostToDevice));
+  G_TRY(hipMemcpy(d_leaf, leaf.data(), leaf.size() * 8, hipMemcpyHostToDevice));
+  G_TRY(hipMemcpy(d_out, outm.data(), outm.size() * 8, hipMemcpyHostToDevice));
+  G_TRY(hipMemcpy(d_hoff, holders_off, ((size_t)I + 1) * 4, hipMemcpyHostToDevice));
+  if (holders_off[I] > 0) G_TRY(hipMemcpy(d_hold, holders, (size_t)holders_off[I] * 4, hipMemcpyHostToDevice));
+
+  sp.n = n; sp.R = R; sp.seeds = d_seeds; sp.draws = d_draws; sp.mt0 = d_mt0; sp.mt = d_mt; sp.perm = d_perm;
+  hipLaunchKernelGGL(py_shuffle_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, 0, sp);
+  G_TRY(hipGetLastError());
+  gp.n = n; gp.I = I; gp.W = W; gp.NW = NW; gp.SMAX = SMAX; gp.Q = Q; gp.TS = TS; gp.R = R;
+  gp.leaf = d_leaf; gp.output = d_out; gp.hoff = d_hoff; gp.holders = d_hold; gp.perm = d_perm;
+  hipLaunchKernelGGL(greedy_kernel, dim3((unsigned)G), dim3(64), lds, 0, gp);
+  G_TRY(hipGetLastError());
+  G_TRY(hipDeviceSynchronize());
+  G_TRY(hipMemcpy(links_out, gp.links, (size_t)R * 3 * N * 4, hipMemcpyDeviceToHost));
+  std::vector<int32_t> status((size_t)R);
+  G_TRY(hipMemcpy(status.data(), gp.status, (size_t)R * 4, hipMemcpyDeviceToHost));
+  std::vector<uint64_t> draws_in;
+  if (draws) {
+    draws_in.assign(draws, draws + R);
+    G_TRY(hipMemcpy(draws, d_draws, (size_t)R * 8, hipMemcpyDeviceToHost));
+  }
+  // the trees the kernel left to the host (outer products at the end, limits)
+  std::vector<int64_t> redo;
+  for (int64_t r = 0; r < R; ++r)
+    if (status[r] != 0) redo.push_back(r);
+  g_last_redone = (int64_t)redo.size();
+  if (!redo.empty()) {
+    if (std::getenv("TNCO_HIP_GREEDY_DEBUG"))
+      for (size_t k = 0; k < std::min<size_t>(redo.size(), 8); ++k)
+        std::fprintf(stderr, "greedy_device: tree %lld status %d\n", (long long)redo[k], status[redo[k]]);
+    std::vector<uint32_t> s2(redo.size());
+    std::vector<uint64_t> d2(redo.size());
+    std::vector<int32_t> l2(redo.size() * 3 * (size_t)N);
+    for (size_t k = 0; k < redo.size(); ++k) {
+      s2[k] = seeds[redo[k]];
+      if (draws) d2[k] = draws_in[redo[k]];
+    }
+    const int rc = tnco_hip_greedy_trees(n_leaves, n_inds, holders_off, holders, output_mask, (int64_t)redo.size(),
+                                         s2.data(), draws ? d2.data() : nullptr, l2.data(), n_threads);
+    if (rc) return rc;
+    for (size_t k = 0; k < redo.size(); ++k) {
+      std::memcpy(links_out + redo[k] * 3 * N, l2.data() + k * 3 * (size_t)N, (size_t)3 * N * 4);
+      if (draws) draws[redo[k]] = d2[k];
+    }
+  }
+  return TNCO_HIP_OK;
+}
