@@ -10,6 +10,7 @@ one all-gather of the heads.
 """
 from __future__ import annotations
 
+import os
 from time import perf_counter
 from typing import Iterable
 
@@ -185,8 +186,13 @@ def run_sa(opt, tn, betas, n_steps, n_runs, n_projs, timeout, *, top_k, sweeps_p
         if initial_trees == "greedy":
             # tn.py:175-178: an output index held by two or more tensors is a contractible edge
             keep = [k for k, x in enumerate(comp.inds_order) if x in tn.output_inds and n_holders.get(x, 0) <= 1]
+            # large batches are drawn on the GPU (csrc/greedy_device.hip: the same trees, tests/test_gpu_greedy.py);
+            # TNCO_HIP_GREEDY=host|device overrides the size rule
+            where = os.environ.get("TNCO_HIP_GREEDY", "auto")
+            on_gpu = where == "device" or (where == "auto" and n_local * len(comp.tensors) >= 1_000_000)
             links = core.greedy_trees(comp.leaf_positions, comp.n_inds, my_seeds,
-                                      output_mask=pack_masks([keep], comp.n_inds)[0], draws=draws)
+                                      output_mask=pack_masks([keep], comp.n_inds)[0], draws=draws,
+                                      device=device if on_gpu else None)
         else:
             links = core.random_trees(comp.leaf_positions, comp.n_inds, my_seeds)
         kw = dict(max_width=opt.max_width, width_type=opt.width_type) if finite else {}

@@ -41,6 +41,13 @@ namespace tnco {
 namespace {
 
 constexpr int GREEDY_MAXH = 6;
+
+// -DTNCO_GREEDY_PROF: shader-clock ticks per section of greedy_kernel, summed per wavefront (diagnostic build)
+#ifdef TNCO_GREEDY_PROF
+#define GP_T(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_[i] += t_ - pt_; pt_ = t_; } while (0)
+#else
+#define GP_T(i)
+#endif
 constexpr uint32_t DEAD = 0xFFFFu;
 constexpr uint64_t KMAX = ~0ull;
 
@@ -138,11 +145,12 @@ struct GreedyParams {
   // scratch, one set per resident wavefront (G = gridDim.x)
   uint64_t* keys;           // [G][SMAX][W]   slot -> index set
   uint64_t* nbr;            // [G][SMAX][NW]  slot -> live slots sharing a contractible dim
-  uint64_t* arena;          // [G][Q][W + 1]  queued candidate -> its result set, then s1 | s2 << 16
+  uint64_t* arena;          // [G][Q][W]      queued candidate -> its result set
   int32_t* path;            // [G][n][2]      ssa path
   uint16_t* slot_of_leaf;   // [G][n]
   int32_t* links;           // [R][3][2n - 1] out
   int32_t* status;          // [R] out: 0 = done, else redo on the host
+  unsigned long long* prof; // [G][16] (TNCO_GREEDY_PROF)
 };
 
 __device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int o) {
@@ -153,28 +161,49 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int lane) {
   const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, lane), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), lane);
   return ((uint64_t)hi << 32) | lo;
 }
+// wave reductions: four DPP steps inside each row of 16 lanes (xor 1, xor 2, half mirror, mirror), then
+// the four row results through readlane -- no LDS crossbar round trips
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp64(uint64_t v) {
+  return ((uint64_t)dpp<CTRL>((uint32_t)(v >> 32)) << 32) | dpp<CTRL>((uint32_t)v);
+}
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+__device__ __forceinline__ uint64_t rdlane64(uint64_t v, int lane) {
+  return ((uint64_t)rdlane((uint32_t)(v >> 32), lane) << 32) | rdlane((uint32_t)v, lane);
+}
+// (every DPP read is evaluated ONCE, with all lanes active: a read from a lane that a branch has switched
+//  off returns nothing)
+template <int CTRL>
+__device__ __forceinline__ uint64_t min_step(uint64_t v) {
+  const uint64_t t = dpp64<CTRL>(v);
+  return t < v ? t : v;
+}
 __device__ __forceinline__ uint32_t wsum(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
-  return v;
+  v += dpp<0xB1>(v);
+  v += dpp<0x4E>(v);
+  v += dpp<0x141>(v);
+  v += dpp<0x140>(v);
+  return rdlane(v, 0) + rdlane(v, 16) + rdlane(v, 32) + rdlane(v, 48);
 }
 __device__ __forceinline__ uint64_t wmin64(uint64_t v) {
-#pragma unroll
-  for (int o = 32; o; o >>= 1) {
-    const uint64_t t = shfl_xor64(v, o);
-    v = t < v ? t : v;
-  }
-  return v;
+  v = min_step<0xB1>(v);
+  v = min_step<0x4E>(v);
+  v = min_step<0x141>(v);
+  v = min_step<0x140>(v);
+  const uint64_t a = rdlane64(v, 0), b = rdlane64(v, 16), c = rdlane64(v, 32), d = rdlane64(v, 48);
+  const uint64_t ab = b < a ? b : a, cd = d < c ? d : c;
+  return cd < ab ? cd : ab;
 }
 __device__ __forceinline__ uint64_t wxor64(uint64_t v) {
-#pragma unroll
-  for (int o = 32; o; o >>= 1) v ^= shfl_xor64(v, o);
-  return v;
-}
-__device__ __forceinline__ uint64_t wand64(uint64_t v) {
-#pragma unroll
-  for (int o = 32; o; o >>= 1) v &= shfl_xor64(v, o);
-  return v;
+  v ^= dpp64<0xB1>(v);
+  v ^= dpp64<0x4E>(v);
+  v ^= dpp64<0x141>(v);
+  v ^= dpp64<0x140>(v);
+  return rdlane64(v, 0) ^ rdlane64(v, 16) ^ rdlane64(v, 32) ^ rdlane64(v, 48);
 }
 // exclusive prefix sum over the lanes
 __device__ __forceinline__ uint32_t wscan_excl(uint32_t v, int lane) {
@@ -198,23 +227,27 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
   const int n = p.n, I = p.I, W = p.W, NW = p.NW, SMAX = p.SMAX, Q = p.Q, TS = p.TS;
   const int QC = (Q + 63) & ~63;  // queue cells (a multiple of 64)
   // LDS: queue keys [QC] | broadcast rows a, output, ref2, ref3 [4 W] | ssa [SMAX] | fp [SMAX] |
-  //      holders per dim [I] | neighbour list [SMAX] | table [TS]
+  //      holders per dim [I] | neighbour list [SMAX] | slot of an ssa id [2n] | table [TS]
   lds_u64 hk = (lds_u64)lds_raw;
   lds_u64 bc = hk + QC;
   lds_u16 ssa = (lds_u16)(bc + 4 * W);
   lds_u16 fp = ssa + SMAX;
   lds_u16 cnt = fp + SMAX;
   lds_u16 lst = cnt + I;
-  lds_i16 table = (lds_i16)(lst + SMAX);
+  lds_u16 sid = lst + SMAX;  // ssa id -> slot [2n]
+  lds_i16 table = (lds_i16)(sid + 2 * n);
 
   const int g = blockIdx.x;
   uint64_t* keys = p.keys + (size_t)g * SMAX * W;
   uint64_t* nbr = p.nbr + (size_t)g * SMAX * NW;
-  uint64_t* arena = p.arena + (size_t)g * Q * (W + 1);
+  uint64_t* arena = p.arena + (size_t)g * Q * W;
   int32_t* path = p.path + (size_t)g * n * 2;
   uint16_t* slot_of_leaf = p.slot_of_leaf + (size_t)g * n;
   const bool inw = lane < W;
 
+#ifdef TNCO_GREEDY_PROF
+  unsigned long long prof_[16] = {0}, pt_ = __builtin_amdgcn_s_memtime();
+#endif
   for (int64_t r = g; r < p.R; r += gridDim.x) {
     const uint16_t* perm = p.perm + r * (int64_t)n;
     int status = 0;
@@ -231,6 +264,7 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
       out |= all;
     }
     __syncthreads();
+    GP_T(0);
     int next_ssa = n, nslots = 0, step = 0, n_alive = 0;
     // content-addressed slot of an index set (word x in lane x): >= 0 found, else -1 and *cell = the free cell
     auto hash_of = [&](uint64_t m) -> uint32_t {
@@ -267,28 +301,42 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
       return s;
     };
     // ---- the inputs in shuffled order; equal index sets are multiplied at once ----
-    for (int t = 0; t < n; ++t) {
-      const int lf = perm[t];
-      const uint64_t m = inw ? p.leaf[(size_t)lf * W + lane] : 0;
-      int cell = 0;
-      int s = find_slot(m, cell);
-      const bool alive = s >= 0 && ssa[s] != DEAD;
-      if (alive) {
-        if (lane == 0) {
-          path[2 * step] = ssa[s];
-          path[2 * step + 1] = t;
-          ssa[s] = (uint16_t)next_ssa;
+    for (int t0 = 0; t0 < n; t0 += 64) {
+      const int pv = t0 + lane < n ? (int)perm[t0 + lane] : 0;  // (64 positions per read; the next index set travels
+      const int nt = n - t0 < 64 ? n - t0 : 64;                  //  while this one is looked up)
+      const int lf0 = uni(__shfl(pv, 0));  // (all lanes take part in the shuffles)
+      uint64_t m_next = inw ? p.leaf[(size_t)lf0 * W + lane] : 0;
+      for (int i = 0; i < nt; ++i) {
+        const int t = t0 + i;
+        const int lf = uni(__shfl(pv, i));
+        const uint64_t m = m_next;
+        const int lf1 = uni(__shfl(pv, i + 1 < nt ? i + 1 : i));
+        if (i + 1 < nt) m_next = inw ? p.leaf[(size_t)lf1 * W + lane] : 0;
+        int cell = 0;
+        int s = find_slot(m, cell);
+        const bool alive = s >= 0 && ssa[s] != DEAD;
+        if (alive) {
+          if (lane == 0) {
+            path[2 * step] = ssa[s];
+            path[2 * step + 1] = t;
+            ssa[s] = (uint16_t)next_ssa;
+            sid[next_ssa] = (uint16_t)s;
+          }
+          ++step;
+          ++next_ssa;
+        } else {
+          if (s < 0) s = new_slot(m, cell);
+          if (lane == 0) {
+            ssa[s] = (uint16_t)t;
+            sid[t] = (uint16_t)s;
+          }
+          ++n_alive;
         }
-        ++step;
-        ++next_ssa;
-      } else {
-        if (s < 0) s = new_slot(m, cell);
-        if (lane == 0) ssa[s] = (uint16_t)t;
-        ++n_alive;
+        if (lane == 0) slot_of_leaf[lf] = (uint16_t)s;
+        __syncthreads();
       }
-      if (lane == 0) slot_of_leaf[lf] = (uint16_t)s;
-      __syncthreads();
     }
+    GP_T(1);
     // ---- per contractible dim: its holders (slots, by ssa id), the counts, the neighbour sets ----
     if (inw) {
       bc[W + lane] = out;
@@ -349,6 +397,7 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
     }
     __threadfence();
     __syncthreads();
+    GP_T(2);
     uint64_t ref2 = inw ? bc[2 * W + lane] : 0, ref3 = inw ? bc[3 * W + lane] : 0;
     // |result| of contracting slots s1, s2 under the current counts (this lane alone: W words)
     auto size12_of = [&](int s1, int s2) -> int {
@@ -395,24 +444,24 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
           for (int j = 1; j < GREEDY_MAXH; ++j)
             if (j == bj) sj = sl[j];
           const int seq = base + i;
-          uint64_t* row = arena + (size_t)seq * (W + 1);
+          uint64_t* row = arena + (size_t)seq * W;
           for (int x = 0; x < W; ++x) {
             const uint64_t a = keys[(size_t)sl[i] * W + x], b = keys[(size_t)sj * W + x];
             const uint64_t either = a | b, two = a & b, one = either & ~two;
             row[x] = (either & bc[W + x]) | (two & bc[3 * W + x]) | (one & bc[2 * W + x]);
           }
-          row[W] = (uint64_t)sl[i] | ((uint64_t)sj << 16);  // (ids ascend along the list: id1 = id[i])
           hk[seq] = bestk;
         }
       }
     }
     __syncthreads();
-    // every lane: the minimum of its cells
+    // every lane: the minimum of its cells (four reads in flight)
     uint64_t lkey = KMAX;
     int lrow = 0;
     auto rescan = [&]() {
       lkey = KMAX;
       lrow = 0;
+#ifdef TG1
       for (int c = lane, row = 0; c < count; c += 64, ++row) {
         const uint64_t k = hk[c];
         if (k < lkey) {
@@ -420,9 +469,26 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
           lrow = row;
         }
       }
+      return;
+#endif
+      const __attribute__((address_space(3))) uint64_t* cells = (const __attribute__((address_space(3))) uint64_t*)hk + lane;
+      const int rows = (count + 63) >> 6;
+      for (int row = 0; row < rows; row += 4) {
+        uint64_t k[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) k[q] = row + q < rows ? cells[(row + q) * 64] : KMAX;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (k[q] < lkey) {
+            lkey = k[q];
+            lrow = row + q;
+          }
+      }
     };
     rescan();
+    GP_T(3);
     // ---- the greedy loop ----
+    const bool innw = lane < NW;
     while (status == 0) {
       const uint64_t best = wmin64(lkey);
       if (best == KMAX) break;
@@ -432,12 +498,15 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
         hk[seq] = KMAX;
         rescan();
       }
-      const uint64_t* row = arena + (size_t)seq * (W + 1);
-      const uint64_t sw = row[W];
-      const int s1 = uni((int)(sw & 0xFFFFu)), s2 = uni((int)((sw >> 16) & 0xFFFFu));
+      // (the key carries the ssa ids at push time; an id belongs to one slot for good)
+      const int s1 = uni((int)sid[(int)(best & 0x3FFFu)]), s2 = uni((int)sid[(int)((best >> 14) & 0x3FFFu)]);
       const int id1 = ssa[s1], id2 = ssa[s2];
+      GP_T(4);
       if (id1 == (int)DEAD || id2 == (int)DEAD) continue;  // obsolete
-      const uint64_t k12 = inw ? row[lane] : 0;
+      // everything this contraction reads from memory, requested together
+      const uint64_t k12 = inw ? arena[(size_t)seq * W + lane] : 0;
+      const uint64_t a = inw ? keys[(size_t)s1 * W + lane] : 0, b = inw ? keys[(size_t)s2 * W + lane] : 0;
+      uint64_t un = innw ? (nbr[(size_t)s1 * NW + lane] | nbr[(size_t)s2 * NW + lane]) : 0;
       if (lane == 0) {
         ssa[s1] = DEAD;
         ssa[s2] = DEAD;
@@ -463,9 +532,13 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
         n_alive -= 1;
       }
       const int id12 = next_ssa++;
-      if (lane == 0) ssa[s12] = (uint16_t)id12;
+      if (lane == 0) {
+        ssa[s12] = (uint16_t)id12;
+        sid[id12] = (uint16_t)s12;
+      }
+      GP_T(5);
+      uint64_t n12m = (merged && innw) ? nbr[(size_t)s12 * NW + lane] : 0;
       // holders per dim: only shared dims and dropped dims change their number
-      const uint64_t a = inw ? keys[(size_t)s1 * W + lane] : 0, b = inw ? keys[(size_t)s2 * W + lane] : 0;
       {
         uint64_t u = (merged ? (a | b) : ((a & b) | ((a ^ b) & ~k12))) & ~out;
         while (u) {
@@ -480,14 +553,12 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
           ref3 = c >= 3 ? (ref3 | m1) : (ref3 & ~m1);
         }
       }
+      GP_T(6);
       // neighbours: those of k1 and of k2 (every one of them shares a dim the result keeps)
-      const bool innw = lane < NW;
-      uint64_t un = innw ? (nbr[(size_t)s1 * NW + lane] | nbr[(size_t)s2 * NW + lane]) : 0;
       if (lane == (s1 >> 6)) un &= ~(1ull << (s1 & 63));
       if (lane == (s2 >> 6)) un &= ~(1ull << (s2 & 63));
       if (lane == (s12 >> 6)) un &= ~(1ull << (s12 & 63));
-      uint64_t n12 = un;
-      if (merged && innw) n12 |= nbr[(size_t)s12 * NW + lane];
+      const uint64_t n12 = un | n12m;
       if (innw) nbr[(size_t)s12 * NW + lane] = n12;
       {
         const int w1 = s1 >> 6, w2 = s2 >> 6, w12 = s12 >> 6;
@@ -497,20 +568,37 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
           const int y = lane * 64 + __ffsll((unsigned long long)u) - 1;
           u &= u - 1;
           uint64_t* ry = nbr + (size_t)y * NW;
-          uint64_t v = ry[w1];
-          v &= ~m1;
-          if (w2 == w1) v &= ~m2;
-          if (w12 == w1) v |= m12;
-          ry[w1] = v;
-          if (w2 != w1) {
-            v = ry[w2];
-            v &= ~m2;
-            if (w12 == w2) v |= m12;
-            ry[w2] = v;
+#ifdef TG4
+          {
+            uint64_t v = ry[w1];
+            v &= ~m1;
+            if (w2 == w1) v &= ~m2;
+            if (w12 == w1) v |= m12;
+            ry[w1] = v;
+            if (w2 != w1) {
+              v = ry[w2];
+              v &= ~m2;
+              if (w12 == w2) v |= m12;
+              ry[w2] = v;
+            }
+            if (w12 != w1 && w12 != w2) ry[w12] |= m12;
+            continue;
           }
-          if (w12 != w1 && w12 != w2) ry[w12] |= m12;
+#endif
+          uint64_t v1 = ry[w1], v2 = ry[w2], v12 = ry[w12];  // (three reads in flight; equal words: equal values)
+          v1 &= ~m1;
+          if (w2 == w1) v1 &= ~m2;
+          if (w12 == w1) v1 |= m12;
+          ry[w1] = v1;
+          if (w2 != w1) {
+            v2 &= ~m2;
+            if (w12 == w2) v2 |= m12;
+            ry[w2] = v2;
+          }
+          if (w12 != w1 && w12 != w2) ry[w12] = v12 | m12;
         }
       }
+      GP_T(7);
       // push the cheapest (k12, neighbour)
       const uint32_t pc = (uint32_t)__popcll(n12);
       const int total = (int)wsum(pc);
@@ -523,37 +611,43 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
             u &= u - 1;
           }
         }
-        if (inw) {
-          bc[lane] = k12;
-          bc[2 * W + lane] = ref2;
-          bc[3 * W + lane] = ref3;
-        }
         __syncthreads();
+        GP_T(8);
+        // one neighbour per lane; the words of k12 / output / ref2 / ref3 come from their lanes by readlane
         const int f12 = fp[s12];
         uint64_t bestk = KMAX;
         int bests = 0;
         for (int j0 = 0; j0 < total; j0 += 64) {
           const int j = j0 + lane;
-          if (j < total) {
-            const int s = lst[j];
-            int c = 0;
-            for (int x = 0; x < W; ++x) {
-              const uint64_t ax = bc[x], bx = keys[(size_t)s * W + x];
-              const uint64_t either = ax | bx, two = ax & bx, one = either & ~two;
-              c += __popcll((either & bc[W + x]) | (two & bc[3 * W + x]) | (one & bc[2 * W + x]));
-            }
-            const int ids = ssa[s];
-            const uint64_t k = greedy_cand_key(c, f12, fp[s], ids > id12 ? ids : id12, ids > id12 ? id12 : ids);
-            if (k < bestk) {
-              bestk = k;
-              bests = s;
+          const bool valid = j < total;
+          const int s = lst[valid ? j : 0];
+          const uint64_t* ks = keys + (size_t)s * W;
+          int c = 0;
+          for (int x0 = 0; x0 < W; x0 += 16) {  // (sixteen words requested together: one memory latency per neighbour)
+            uint64_t bx[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) bx[q] = x0 + q < W ? ks[x0 + q] : 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              if (x0 + q < W) {
+                const int x = x0 + q;
+                const uint64_t ax = rdlane64(k12, x);
+                const uint64_t either = ax | bx[q], two = ax & bx[q], one = either & ~two;
+                c += __popcll((either & rdlane64(out, x)) | (two & rdlane64(ref3, x)) | (one & rdlane64(ref2, x)));
+              }
             }
           }
+          const int ids = ssa[s];
+          const uint64_t k = greedy_cand_key(c, f12, fp[s], ids > id12 ? ids : id12, ids > id12 ? id12 : ids);
+          if (valid && k < bestk) {
+            bestk = k;
+            bests = s;
+          }
         }
+        GP_T(9);
         // (keys of distinct neighbours differ in an id: exactly one lane holds the minimum)
         const uint64_t wk = wmin64(bestk);
         const int sbest = uni(__shfl(bests, __ffsll((unsigned long long)__ballot(bestk == wk)) - 1));
-        const int idb = ssa[sbest];
         const uint64_t bb = inw ? keys[(size_t)sbest * W + lane] : 0;
         const uint64_t either = k12 | bb, two = k12 & bb, one = either & ~two;
         const uint64_t res = (either & out) | (two & ref3) | (one & ref2);
@@ -562,9 +656,7 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
           break;
         }
         const int cs = count++;
-        uint64_t* nrow = arena + (size_t)cs * (W + 1);
-        if (inw) nrow[lane] = res;
-        if (lane == 0) nrow[W] = id12 < idb ? ((uint64_t)s12 | ((uint64_t)sbest << 16)) : ((uint64_t)sbest | ((uint64_t)s12 << 16));
+        if (inw) arena[(size_t)cs * W + lane] = res;
         if (lane == (cs & 63)) {
           hk[cs] = wk;
           if (wk < lkey) {
@@ -574,6 +666,7 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
         }
       }
       __syncthreads();
+      GP_T(10);
     }
     if (status == 0 && (n_alive != 1 || step != n - 1)) status = 3;  // outer products left: the host's
     // ---- ssa path -> links ----
@@ -603,7 +696,12 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
     if (lane == 0) p.status[r] = status;
     __threadfence();
     __syncthreads();
+    GP_T(11);
   }
+#ifdef TNCO_GREEDY_PROF
+  if (lane == 0)
+    for (int i = 0; i < 16; ++i) p.prof[(size_t)g * 16 + i] = prof_[i];
+#endif
 }
 
 struct DevBufs {
@@ -627,7 +725,7 @@ void py_init_genrand(uint32_t* mt, uint32_t s) {
 }
 
 size_t lds_bytes(int W, int SMAX, int I, int QC, int TS) {
-  return (size_t)QC * 8 + (size_t)4 * W * 8 + (size_t)SMAX * 2 * 3 + (size_t)I * 2 + (size_t)TS * 2 + 16;
+  return (size_t)QC * 8 + (size_t)4 * W * 8 + (size_t)SMAX * 2 * 3 + (size_t)(SMAX - 8) * 2 + (size_t)I * 2 + (size_t)TS * 2 + 16;
 }
 
 }  // namespace
@@ -656,7 +754,7 @@ extern "C" int tnco_hip_greedy_device_supported(int32_t n_leaves, int32_t n_inds
   }
   const int W = (n_inds + 63) / 64, SMAX = 2 * n_leaves + 8;
   int TS = 64;
-  while (TS < 2 * SMAX) TS <<= 1;
+  while (4 * TS < 5 * SMAX) TS <<= 1;
   const int QC = (int)((q + 63) & ~63ll);
   return lds_bytes(W, SMAX, n_inds, QC, TS) <= 64 * 1024 ? 1 : 0;
 }
@@ -679,7 +777,7 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
   for (int i = 0; i < I; ++i) q += std::max(0, holders_off[i + 1] - holders_off[i] - 1);
   const int Q = (int)q, QC = (Q + 63) & ~63;
   int TS = 64;
-  while (TS < 2 * SMAX) TS <<= 1;
+  while (4 * TS < 5 * SMAX) TS <<= 1;
   std::vector<uint64_t> leaf((size_t)n * W, 0), outm((size_t)W, 0);
   for (int i = 0; i < I; ++i)
     for (int k = holders_off[i]; k < holders_off[i + 1]; ++k) {
@@ -719,11 +817,12 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
   G_TRY(db.alloc(&d_hold, (size_t)std::max(1, holders_off[I])));
   G_TRY(db.alloc(&gp.keys, (size_t)G * SMAX * W));
   G_TRY(db.alloc(&gp.nbr, (size_t)G * SMAX * NW));
-  G_TRY(db.alloc(&gp.arena, (size_t)G * Q * (W + 1)));
+  G_TRY(db.alloc(&gp.arena, (size_t)G * Q * W));
   G_TRY(db.alloc(&gp.path, (size_t)G * n * 2));
   G_TRY(db.alloc(&gp.slot_of_leaf, (size_t)G * n));
   G_TRY(db.alloc(&gp.links, (size_t)R * 3 * N));
   G_TRY(db.alloc(&gp.status, (size_t)R));
+  G_TRY(db.alloc(&gp.prof, (size_t)G * 16));
   G_TRY(hipMemcpy(d_seeds, seeds, (size_t)R * 4, hipMemcpyHostToDevice));
   G_TRY(hipMemcpy(d_mt0, mt0, sizeof(mt0), hipMemcpyHostToDevice));
   if (draws) G_TRY(hipMemcpy(d_draws, draws, (size_t)R * 8, hipMemcpyHostToDevice));
@@ -732,15 +831,46 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
   G_TRY(hipMemcpy(d_hoff, holders_off, ((size_t)I + 1) * 4, hipMemcpyHostToDevice));
   if (holders_off[I] > 0) G_TRY(hipMemcpy(d_hold, holders, (size_t)holders_off[I] * 4, hipMemcpyHostToDevice));
 
+  const bool dbg = std::getenv("TNCO_HIP_GREEDY_DEBUG") != nullptr;
+  hipEvent_t ev[4];
+  if (dbg) {
+    for (auto& e : ev) G_TRY(hipEventCreate(&e));
+    G_TRY(hipEventRecord(ev[0], 0));
+  }
   sp.n = n; sp.R = R; sp.seeds = d_seeds; sp.draws = d_draws; sp.mt0 = d_mt0; sp.mt = d_mt; sp.perm = d_perm;
   hipLaunchKernelGGL(py_shuffle_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, 0, sp);
   G_TRY(hipGetLastError());
+  if (dbg) G_TRY(hipEventRecord(ev[1], 0));
   gp.n = n; gp.I = I; gp.W = W; gp.NW = NW; gp.SMAX = SMAX; gp.Q = Q; gp.TS = TS; gp.R = R;
   gp.leaf = d_leaf; gp.output = d_out; gp.hoff = d_hoff; gp.holders = d_hold; gp.perm = d_perm;
   hipLaunchKernelGGL(greedy_kernel, dim3((unsigned)G), dim3(64), lds, 0, gp);
   G_TRY(hipGetLastError());
+  if (dbg) G_TRY(hipEventRecord(ev[2], 0));
   G_TRY(hipDeviceSynchronize());
   G_TRY(hipMemcpy(links_out, gp.links, (size_t)R * 3 * N * 4, hipMemcpyDeviceToHost));
+  if (dbg) {
+    G_TRY(hipEventRecord(ev[3], 0));
+    G_TRY(hipEventSynchronize(ev[3]));
+    float a = 0, b = 0, c = 0;
+    (void)hipEventElapsedTime(&a, ev[0], ev[1]);
+    (void)hipEventElapsedTime(&b, ev[1], ev[2]);
+    (void)hipEventElapsedTime(&c, ev[2], ev[3]);
+    std::fprintf(stderr, "greedy_device: shuffle kernel %.1f ms, greedy kernel %.1f ms (%d wavefronts, %zu B LDS each), "
+                 "links to the host %.1f ms\n", a, b, G, lds, c);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+#ifdef TNCO_GREEDY_PROF
+    std::vector<unsigned long long> pr((size_t)G * 16);
+    G_TRY(hipMemcpy(pr.data(), gp.prof, pr.size() * 8, hipMemcpyDeviceToHost));
+    const char* nm[12] = {"clear", "inputs", "dims: counts, neighbours", "dims: candidates", "pop", "slot of the result", "holders per dim", "neighbour rows", "list + broadcast", "evaluate", "winner + push", "links"};
+    double tot = 0;
+    for (size_t i = 0; i < pr.size(); ++i) tot += (double)pr[i];
+    for (int i = 0; i < 12; ++i) {
+      double v = 0;
+      for (int g2 = 0; g2 < G; ++g2) v += (double)pr[(size_t)g2 * 16 + i];
+      std::fprintf(stderr, "  %-26s %5.1f %%  %9.0f ticks per tree\n", nm[i], 100 * v / tot, v / (double)R);
+    }
+#endif
+  }
   std::vector<int32_t> status((size_t)R);
   G_TRY(hipMemcpy(status.data(), gp.status, (size_t)R * 4, hipMemcpyDeviceToHost));
   std::vector<uint64_t> draws_in;

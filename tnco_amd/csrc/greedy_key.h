@@ -20,53 +20,42 @@ namespace tnco {
 
 constexpr int GREEDY_KEY_MAX_EXP = 2040;
 
-// 36-bit key, larger key <=> larger v
+// 36-bit key, larger key <=> larger v.  (Three digits in named variables, no indexed arrays: on the
+// device an indexed array is scratch memory, and this runs once per candidate in every lane.)
 TNCO_HD inline uint64_t greedy_cost_key(int a, int b, int c) {
-  // digits as (position, sign), at most 3; normalise to non-adjacent form
-  int p[3] = {a, b, c};
-  int s[3] = {1, -1, -1};
-  int m = 3;
+  constexpr int GONE = -(1 << 20);  // position of an absent digit (sorts last, never equal / adjacent to a live one)
+  int p0 = a, p1 = b, p2 = c;
+  int s0 = 1, s1 = -1, s2 = -1;
+#define TNCO_GK_CX(pa, sa, pb, sb) \
+  if (pa < pb) {                   \
+    const int tp_ = pa, ts_ = sa;  \
+    pa = pb; sa = sb;              \
+    pb = tp_; sb = ts_;            \
+  }
+  // (pa, sa), (pb, sb) with pa == pb or pa == pb + 1, both live -> their sum in non-adjacent form
+#define TNCO_GK_JOIN(pa, sa, pb, sb)                                             \
+  if (pa == pb) {                                                                \
+    if (sa == sb) { pa += 1; } else { pa = GONE; sa = 0; }                       \
+    pb = GONE; sb = 0;                                                           \
+  } else {                                                                       \
+    if (sa == sb) { pa += 1; sb = -sb; } else { pa = pb; pb = GONE; sb = 0; }    \
+  }
   for (;;) {
-    // order by position, descending (m <= 3)
-    for (int i = 0; i + 1 < m; ++i)
-      for (int j = 0; j + 1 < m - i; ++j)
-        if (p[j] < p[j + 1]) {
-          const int tp = p[j], ts = s[j];
-          p[j] = p[j + 1]; s[j] = s[j + 1];
-          p[j + 1] = tp; s[j + 1] = ts;
-        }
-    bool changed = false;
-    for (int i = 0; i + 1 < m && !changed; ++i) {
-      if (p[i] == p[i + 1]) {
-        if (s[i] == s[i + 1]) {  // 2^p + 2^p = 2^(p+1)
-          p[i] += 1;
-          for (int j = i + 1; j + 1 < m; ++j) { p[j] = p[j + 1]; s[j] = s[j + 1]; }
-          m -= 1;
-        } else {                 // 2^p - 2^p = 0
-          for (int j = i; j + 2 < m; ++j) { p[j] = p[j + 2]; s[j] = s[j + 2]; }
-          m -= 2;
-        }
-        changed = true;
-      } else if (p[i] == p[i + 1] + 1) {
-        if (s[i] == s[i + 1]) {  // 2^(p+1) + 2^p = 2^(p+2) - 2^p
-          p[i] += 1;
-          s[i + 1] = -s[i + 1];
-        } else {                 // 2^(p+1) - 2^p = 2^p
-          p[i] = p[i + 1];
-          for (int j = i + 1; j + 1 < m; ++j) { p[j] = p[j + 1]; s[j] = s[j + 1]; }
-          m -= 1;
-        }
-        changed = true;
-      }
+    TNCO_GK_CX(p0, s0, p1, s1)
+    TNCO_GK_CX(p1, s1, p2, s2)
+    TNCO_GK_CX(p0, s0, p1, s1)
+    if (s1 != 0 && p0 - p1 <= 1) {
+      TNCO_GK_JOIN(p0, s0, p1, s1)
+    } else if (s2 != 0 && p1 - p2 <= 1) {
+      TNCO_GK_JOIN(p1, s1, p2, s2)
+    } else {
+      break;
     }
-    if (!changed) break;
   }
-  uint64_t key = 0;
-  for (int k = 0; k < 3; ++k) {
-    const int d = k < m ? s[k] * (p[k] + 1) : 0;
-    key = (key << 12) | (uint64_t)(d + 2048);
-  }
-  return key;
+#undef TNCO_GK_CX
+#undef TNCO_GK_JOIN
+  const int d0 = s0 * (p0 + 1), d1 = s1 * (p1 + 1), d2 = s2 * (p2 + 1);  // (absent: s = 0)
+  return ((uint64_t)(d0 + 2048) << 24) | ((uint64_t)(d1 + 2048) << 12) | (uint64_t)(d2 + 2048);
 }
 
 // (cost, id2, id1) of a candidate as one integer: 36 + 14 + 14 bits
