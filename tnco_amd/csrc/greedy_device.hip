@@ -17,7 +17,7 @@
 //     becomes ONE 64-bit key per candidate (greedy_key.h: the cost in non-adjacent form, exact), the
 //     queue a flat array in LDS, cell c owned by lane c % 64: every lane keeps the minimum of its
 //     cells, a pop is a wave-min over the lanes + a rescan of the winner's cells, a push one LDS
-//     store -- no sift-down chains;
+//     store into the cell just popped -- no sift-down chains, never more cells than initial candidates;
 //   * the neighbours of the tensor just made (the keys sharing a contractible dim with it) are a
 //     bitset over the slots, word x in lane x; the candidates of one push are evaluated one per lane;
 //   * index sets are content-addressed slots (a stale queue entry revives when an equal set
@@ -41,6 +41,7 @@ namespace tnco {
 namespace {
 
 constexpr int GREEDY_MAXH = 6;
+constexpr int GREEDY_LCAP = 256;  // neighbours of one tensor the kernel handles (more: the tree goes to the host)
 
 // -DTNCO_GREEDY_PROF: shader-clock ticks per section of greedy_kernel, summed per wavefront (diagnostic build)
 #ifdef TNCO_GREEDY_PROF
@@ -226,15 +227,14 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
   const int lane = threadIdx.x;
   const int n = p.n, I = p.I, W = p.W, NW = p.NW, SMAX = p.SMAX, Q = p.Q, TS = p.TS;
   const int QC = (Q + 63) & ~63;  // queue cells (a multiple of 64)
-  // LDS: queue keys [QC] | broadcast rows a, output, ref2, ref3 [4 W] | ssa [SMAX] | fp [SMAX] |
-  //      holders per dim [I] | neighbour list [SMAX] | slot of an ssa id [2n] | table [TS]
+  // LDS: queue keys [QC] | broadcast rows a, output, ref2, ref3 [4 W] | ssa [SMAX] | holders per dim [I] |
+  //      neighbour list [GREEDY_LCAP] | slot of an ssa id [2n] | table [TS]
   lds_u64 hk = (lds_u64)lds_raw;
   lds_u64 bc = hk + QC;
   lds_u16 ssa = (lds_u16)(bc + 4 * W);
-  lds_u16 fp = ssa + SMAX;
-  lds_u16 cnt = fp + SMAX;
+  lds_u16 cnt = ssa + SMAX;
   lds_u16 lst = cnt + I;
-  lds_u16 sid = lst + SMAX;  // ssa id -> slot [2n]
+  lds_u16 sid = lst + GREEDY_LCAP;  // ssa id -> slot [2n]
   lds_i16 table = (lds_i16)(sid + 2 * n);
 
   const int g = blockIdx.x;
@@ -293,11 +293,7 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
         return 0;
       }
       if (inw) keys[(size_t)s * W + lane] = m;
-      const uint32_t f = wsum(inw ? (uint32_t)__popcll(m) : 0u);
-      if (lane == 0) {
-        fp[s] = (uint16_t)f;
-        table[cell] = (int16_t)s;
-      }
+      if (lane == 0) table[cell] = (int16_t)s;
       return s;
     };
     // ---- the inputs in shuffled order; equal index sets are multiplied at once ----
@@ -400,12 +396,17 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
     GP_T(2);
     uint64_t ref2 = inw ? bc[2 * W + lane] : 0, ref3 = inw ? bc[3 * W + lane] : 0;
     // |result| of contracting slots s1, s2 under the current counts (this lane alone: W words)
-    auto size12_of = [&](int s1, int s2) -> int {
+    // (|k1|, |k2| are counted along: no table of sizes)
+    auto size12_of = [&](int s1, int s2, int& f1, int& f2) -> int {
       int c = 0;
+      f1 = 0;
+      f2 = 0;
       for (int x = 0; x < W; ++x) {
         const uint64_t a = keys[(size_t)s1 * W + x], b = keys[(size_t)s2 * W + x];
         const uint64_t either = a | b, two = a & b, one = either & ~two;
         c += __popcll((either & bc[W + x]) | (two & bc[3 * W + x]) | (one & bc[2 * W + x]));
+        f1 += __popcll(a);
+        f2 += __popcll(b);
       }
       return c;
     };
@@ -431,8 +432,9 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
 #pragma unroll
           for (int j = 1; j < GREEDY_MAXH; ++j) {
             if (j > i && j < m) {
-              const int s12 = size12_of(sl[i], sl[j]);
-              const uint64_t k = greedy_cand_key(s12, fp[sl[i]], fp[sl[j]], id[j], id[i]);
+              int f1, f2;
+              const int s12 = size12_of(sl[i], sl[j], f1, f2);
+              const uint64_t k = greedy_cand_key(s12, f1, f2, id[j], id[i]);
               if (k < bestk) {
                 bestk = k;
                 bj = j;
@@ -461,16 +463,6 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
     auto rescan = [&]() {
       lkey = KMAX;
       lrow = 0;
-#ifdef TG1
-      for (int c = lane, row = 0; c < count; c += 64, ++row) {
-        const uint64_t k = hk[c];
-        if (k < lkey) {
-          lkey = k;
-          lrow = row;
-        }
-      }
-      return;
-#endif
       const __attribute__((address_space(3))) uint64_t* cells = (const __attribute__((address_space(3))) uint64_t*)hk + lane;
       const int rows = (count + 63) >> 6;
       for (int row = 0; row < rows; row += 4) {
@@ -568,23 +560,6 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
           const int y = lane * 64 + __ffsll((unsigned long long)u) - 1;
           u &= u - 1;
           uint64_t* ry = nbr + (size_t)y * NW;
-#ifdef TG4
-          {
-            uint64_t v = ry[w1];
-            v &= ~m1;
-            if (w2 == w1) v &= ~m2;
-            if (w12 == w1) v |= m12;
-            ry[w1] = v;
-            if (w2 != w1) {
-              v = ry[w2];
-              v &= ~m2;
-              if (w12 == w2) v |= m12;
-              ry[w2] = v;
-            }
-            if (w12 != w1 && w12 != w2) ry[w12] |= m12;
-            continue;
-          }
-#endif
           uint64_t v1 = ry[w1], v2 = ry[w2], v12 = ry[w12];  // (three reads in flight; equal words: equal values)
           v1 &= ~m1;
           if (w2 == w1) v1 &= ~m2;
@@ -602,6 +577,10 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
       // push the cheapest (k12, neighbour)
       const uint32_t pc = (uint32_t)__popcll(n12);
       const int total = (int)wsum(pc);
+      if (total > GREEDY_LCAP) {
+        status = 7;
+        break;
+      }
       if (total > 0) {
         {
           int at = (int)wscan_excl(pc, lane);
@@ -614,7 +593,7 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
         __syncthreads();
         GP_T(8);
         // one neighbour per lane; the words of k12 / output / ref2 / ref3 come from their lanes by readlane
-        const int f12 = fp[s12];
+        const int f12 = (int)wsum(inw ? (uint32_t)__popcll(k12) : 0u);
         uint64_t bestk = KMAX;
         int bests = 0;
         for (int j0 = 0; j0 < total; j0 += 64) {
@@ -622,7 +601,7 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
           const bool valid = j < total;
           const int s = lst[valid ? j : 0];
           const uint64_t* ks = keys + (size_t)s * W;
-          int c = 0;
+          int c = 0, fs = 0;
           for (int x0 = 0; x0 < W; x0 += 16) {  // (sixteen words requested together: one memory latency per neighbour)
             uint64_t bx[16];
 #pragma unroll
@@ -634,11 +613,12 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
                 const uint64_t ax = rdlane64(k12, x);
                 const uint64_t either = ax | bx[q], two = ax & bx[q], one = either & ~two;
                 c += __popcll((either & rdlane64(out, x)) | (two & rdlane64(ref3, x)) | (one & rdlane64(ref2, x)));
+                fs += __popcll(bx[q]);
               }
             }
           }
           const int ids = ssa[s];
-          const uint64_t k = greedy_cand_key(c, f12, fp[s], ids > id12 ? ids : id12, ids > id12 ? id12 : ids);
+          const uint64_t k = greedy_cand_key(c, f12, fs, ids > id12 ? ids : id12, ids > id12 ? id12 : ids);
           if (valid && k < bestk) {
             bestk = k;
             bests = s;
@@ -651,17 +631,14 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
         const uint64_t bb = inw ? keys[(size_t)sbest * W + lane] : 0;
         const uint64_t either = k12 | bb, two = k12 & bb, one = either & ~two;
         const uint64_t res = (either & out) | (two & ref3) | (one & ref2);
-        if (count >= Q) {
-          status = 5;
-          break;
-        }
-        const int cs = count++;
-        if (inw) arena[(size_t)cs * W + lane] = res;
-        if (lane == (cs & 63)) {
-          hk[cs] = wk;
+        // into the cell (and the arena row) of the candidate popped in this iteration: the queue never
+        // holds more than the initial candidates
+        if (inw) arena[(size_t)seq * W + lane] = res;
+        if (lane == wl) {
+          hk[seq] = wk;
           if (wk < lkey) {
             lkey = wk;
-            lrow = cs >> 6;
+            lrow = seq >> 6;
           }
         }
       }
@@ -725,7 +702,7 @@ void py_init_genrand(uint32_t* mt, uint32_t s) {
 }
 
 size_t lds_bytes(int W, int SMAX, int I, int QC, int TS) {
-  return (size_t)QC * 8 + (size_t)4 * W * 8 + (size_t)SMAX * 2 * 3 + (size_t)(SMAX - 8) * 2 + (size_t)I * 2 + (size_t)TS * 2 + 16;
+  return (size_t)QC * 8 + (size_t)4 * W * 8 + (size_t)SMAX * 2 + (size_t)GREEDY_LCAP * 2 + (size_t)(SMAX - 8) * 2 + (size_t)I * 2 + (size_t)TS * 2 + 16;
 }
 
 }  // namespace
@@ -746,7 +723,7 @@ extern "C" int64_t tnco_hip_greedy_device_redone(void) { return g_last_redone; }
 // 1 when tnco_hip_greedy_trees_device takes this network itself (else it hands the batch to the host version)
 extern "C" int tnco_hip_greedy_device_supported(int32_t n_leaves, int32_t n_inds, const int32_t* holders_off) {
   if (n_leaves < 3 || n_leaves > 2000 || n_inds < 1 || n_inds > GREEDY_KEY_MAX_EXP || !holders_off) return 0;
-  int64_t q = n_leaves;
+  int64_t q = 0;  // candidates queued at most: the initial ones (a push takes the cell of the pop before it)
   for (int32_t i = 0; i < n_inds; ++i) {
     const int32_t m = holders_off[i + 1] - holders_off[i];
     if (m > GREEDY_MAXH) return 0;
@@ -773,7 +750,7 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
   G_TRY(hipSetDevice(device));
   const int n = n_leaves, I = n_inds, W = (I + 63) / 64, SMAX = 2 * n + 8, NW = (SMAX + 63) / 64;
   const int64_t R = n_replicas, N = 2 * (int64_t)n - 1;
-  int64_t q = n;
+  int64_t q = 0;
   for (int i = 0; i < I; ++i) q += std::max(0, holders_off[i + 1] - holders_off[i] - 1);
   const int Q = (int)q, QC = (Q + 63) & ~63;
   int TS = 64;
@@ -796,7 +773,7 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
   }
   const size_t lds = lds_bytes(W, SMAX, I, QC, TS);
-  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / lds));
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (size_t)(160 * 1024) / lds));
   const int G = (int)std::min<int64_t>(R, (int64_t)cus * per_cu);
 
   DevBufs db;

@@ -47,7 +47,7 @@ def phases(n=512, R=65536, k=1024, sweeps=1000):
     prob = syn.regular_problem(n, 11)
     seeds = syn.replica_seeds(R)
     t = [time.perf_counter()]
-    links = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds); t.append(time.perf_counter())
+    links = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds, device=0); t.append(time.perf_counter())
     opt = core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds); opt.sync(); t.append(time.perf_counter())
     betas = syn.linear_betas(0, 100, sweeps)
     for s in range(0, sweeps, 100):
@@ -59,7 +59,7 @@ def phases(n=512, R=65536, k=1024, sweeps=1000):
     paths = core.linear_paths(con, np.arange(n, dtype=np.int32), n); t.append(time.perf_counter())
     old = [opt.tree(int(r), which_min=True, with_masks=False) for r in ids[:64]]; t.append(time.perf_counter())
     d = np.diff(t)
-    print(f"phases, {n} leaves x {R} runs x {sweeps} sweeps, head of {k}: greedy trees {d[0]:.2f} s, create {d[1]:.2f} s, "
+    print(f"phases, {n} leaves x {R} runs x {sweeps} sweeps, head of {k}: greedy trees (device) {d[0]:.2f} s, create {d[1]:.2f} s, "
           f"sweeps {d[2]:.2f} s | read-back: all min costs {1e3 * d[3]:.1f} ms, k-select {1e3 * d[4]:.1f} ms, "
           f"{k} best trees + contractions {1e3 * d[5]:.1f} ms, {k} linear paths {1e3 * d[6]:.1f} ms "
           f"(round 1: one tree at a time {1e3 * d[7] / 64:.2f} ms each)")
