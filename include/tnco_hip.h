@@ -66,7 +66,8 @@ typedef struct tnco_hip_desc {
   int64_t n_replicas;
   const uint64_t* leaf_masks;  /* [n_leaves][W]; identical for every replica */
   const uint64_t* output_mask; /* [W] legs of the result tensor, or NULL (none) */
-  const int32_t* links;        /* per replica [3][N]: left[N], right[N], parent[N]; null = -1 */
+  const int32_t* links;        /* per replica [3][N]: left[N], right[N], parent[N]; null = -1.  Host memory,
+                                  or device memory of `device` (tnco_hip_greedy_trees_device) */
   int64_t links_stride;        /* int32 elements between replicas; 0 = one tree shared by all */
   const uint64_t* node_masks;  /* optional per replica [N][W] legs of EVERY node (the reference
                                   passes them in); NULL = derive them on the device from the
@@ -244,12 +245,21 @@ int tnco_hip_greedy_trees(int32_t n_leaves, int32_t n_inds, const int32_t* holde
  * the greedy path finder one wavefront per tree); the trees come back in links_out (host memory).
  * Networks outside the kernel's limits (tnco_hip_greedy_device_supported == 0: more than 2040
  * indices or 2000 tensors, an index held by more than 6 tensors) and single trees that end in outer
- * products are done by tnco_hip_greedy_trees on n_threads host threads: same result either way. */
+ * products are done by tnco_hip_greedy_trees on n_threads host threads: same result either way.
+ * links_out (host, may be NULL) receives the trees; links_device (may be NULL) receives a pointer to
+ * the same [n_replicas][3][N] array in DEVICE memory, which tnco_hip_create takes as tnco_hip_desc.links
+ * without a copy or a host-side check (it validates the trees on the device).  That memory belongs
+ * to the library: it stays valid until the next tnco_hip_greedy_trees_device call or
+ * tnco_hip_greedy_device_release(). */
 int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, int32_t n_inds, const int32_t* holders_off,
                                  const int32_t* holders, const uint64_t* output_mask, int64_t n_replicas,
                                  const uint32_t* seeds, uint64_t* draws, int32_t* links_out,
-                                 int32_t n_threads);
+                                 int32_t** links_device, int32_t n_threads);
+/* device -> host copy of such a buffer */
+int tnco_hip_copy_to_host(void* dst, const void* device_src, uint64_t bytes);
 int tnco_hip_greedy_device_supported(int32_t n_leaves, int32_t n_inds, const int32_t* holders_off);
+/* the device memory tnco_hip_greedy_trees_device keeps between calls (one block, re-used) is freed */
+void tnco_hip_greedy_device_release(void);
 /* diagnostics: trees of the last device call that the host version did (-1: the whole batch) */
 int64_t tnco_hip_greedy_device_redone(void);
 

@@ -80,3 +80,49 @@ def test_networks_outside_the_kernel_limits_take_the_host_path():
     _both(ts, 8, syn.replica_seeds(5), on_device=False)
     # two tensors / one tensor: contract_path does not call the optimizer
     _both([[0, 1], [1, 2]], 3, [1, 2, 3], on_device=False)
+
+
+def test_trees_stay_on_the_device_for_the_optimizer():
+    """greedy_trees(keep_on_device=True) -> BatchedOptimizer without a trip through the host: the same
+    optimizer state as from the host array; tnco_hip_create checks such trees on the device."""
+    prob = syn.regular_problem(64, graph_seed=7)
+    seeds = syn.replica_seeds(300)
+    host = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds)
+    dl = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds, device=0, keep_on_device=True)
+    assert isinstance(dl, core.DeviceLinks) and dl.shape == host.shape
+    assert np.array_equal(dl.numpy(), host)
+    a = core.BatchedOptimizer(prob.leaf_masks, dl, seeds, n_inds=prob.n_inds)
+    b = core.BatchedOptimizer(prob.leaf_masks, host, seeds, n_inds=prob.n_inds)
+    betas = syn.linear_betas(0, 50, 40)
+    a.run(betas)
+    b.run(betas)
+    assert np.array_equal(a.costs()[0], b.costs()[0]) and np.array_equal(a.costs()[1], b.costs()[1])
+    for r in (0, 17, 299):
+        assert all(np.array_equal(x, y) for x, y in zip(a.tree(r), b.tree(r)))
+    # a network outside the kernel's limits: the host version's trees, uploaded
+    ts = [[0, i + 1, (i + 1) % 7 + 1] for i in range(7)]
+    dl2 = core.greedy_trees(ts, 8, seeds[:5], device=0, keep_on_device=True)
+    assert np.array_equal(dl2.numpy(), core.greedy_trees(ts, 8, seeds[:5]))
+
+
+def test_create_rejects_bad_trees_in_device_memory():
+    """The device-side twin of the host check (Node::is_valid / Tree::is_valid, node.hpp:72-107,
+    tree.hpp:58-139): same messages."""
+    prob = syn.regular_problem(16, graph_seed=3)
+    seeds = syn.replica_seeds(4)
+    dl = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds, device=0, keep_on_device=True)
+    good = dl.numpy()
+    import torch
+    cases = [(2, 2, 30, 5), (1, 0, 20, 3), (3, 0, 2, 1), (0, 2, 4, 4), (2, 1, 25, -1), (1, 2, 7, 29)]
+    seen = set()
+    for r, row, col, val in cases:
+        bad = good.copy()
+        bad[r, row, col] = val
+        t = torch.from_numpy(bad).cuda()
+        with pytest.raises(ValueError) as on_host:
+            core.BatchedOptimizer(prob.leaf_masks, bad, seeds, n_inds=prob.n_inds)
+        with pytest.raises(ValueError) as on_device:
+            core.BatchedOptimizer(prob.leaf_masks, core.DeviceLinks(t.data_ptr(), bad.shape, 0), seeds, n_inds=prob.n_inds)
+        assert str(on_device.value) == str(on_host.value)
+        seen.add(str(on_host.value))
+    assert len(seen) >= 3  # several of the checks were exercised

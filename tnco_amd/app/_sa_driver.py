@@ -192,7 +192,7 @@ def run_sa(opt, tn, betas, n_steps, n_runs, n_projs, timeout, *, top_k, sweeps_p
             on_gpu = where == "device" or (where == "auto" and n_local * len(comp.tensors) >= 1_000_000)
             links = core.greedy_trees(comp.leaf_positions, comp.n_inds, my_seeds,
                                       output_mask=pack_masks([keep], comp.n_inds)[0], draws=draws,
-                                      device=device if on_gpu else None)
+                                      device=device if on_gpu else None, keep_on_device=on_gpu)
         else:
             links = core.random_trees(comp.leaf_positions, comp.n_inds, my_seeds)
         kw = dict(max_width=opt.max_width, width_type=opt.width_type) if finite else {}

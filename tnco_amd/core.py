@@ -13,7 +13,7 @@ import numpy as np
 from . import _lib
 from .ctree import n_words
 
-__all__ = ["BatchedOptimizer", "random_trees", "greedy_trees", "linear_paths", "merged_paths", "PROB_BASE", "PROB_GREEDY", "PROB_MH"]
+__all__ = ["BatchedOptimizer", "DeviceLinks", "random_trees", "greedy_trees", "linear_paths", "merged_paths", "PROB_BASE", "PROB_GREEDY", "PROB_MH"]
 
 PROB_BASE, PROB_GREEDY, PROB_MH = _lib.PROB_BASE, _lib.PROB_GREEDY, _lib.PROB_MH
 _PROB = {"base": PROB_BASE, "greedy": PROB_GREEDY, "mh": PROB_MH,
@@ -56,8 +56,22 @@ def random_trees(leaf_positions, n_inds: int, seeds, n_threads: int = 0) -> np.n
     return out
 
 
+class DeviceLinks:
+    """Initial trees [R, 3, N] left in the memory of GPU `device` by greedy_trees(..., keep_on_device=True):
+    BatchedOptimizer takes them as `links` without a trip through the host.  The memory belongs to the
+    library and is re-used by the next greedy_trees call on a device: build the optimizer first."""
+
+    def __init__(self, ptr: int, shape, device: int):
+        self.ptr, self.shape, self.device = int(ptr), tuple(shape), int(device)
+
+    def numpy(self) -> np.ndarray:
+        out = np.empty(self.shape, np.int32)
+        _lib.check(_lib.load().tnco_hip_copy_to_host(_ptr(out), C.c_void_p(self.ptr), out.nbytes))
+        return out
+
+
 def greedy_trees(leaf_positions, n_inds: int, seeds, output_mask=None, draws=None, n_threads: int = 0,
-                 device: int | None = None) -> np.ndarray:
+                 device: int | None = None, keep_on_device: bool = False):
     """Initial trees as the reference draws them (Random(seed).shuffle + opt_einsum's greedy,
     tnco/utils/tn.py:189-230) for one connected component: links[R, 3, N].
 
@@ -65,7 +79,7 @@ def greedy_trees(leaf_positions, n_inds: int, seeds, output_mask=None, draws=Non
     `device` = a GPU ordinal, on that GPU (csrc/greedy_device.hip: one wavefront per tree; networks
     outside the kernel's limits go to the host version inside the call) -- the same trees either way.
     `draws` (uint64[R], updated in place): outputs of Random(seed) consumed by the components before
-    this one."""
+    this one.  `keep_on_device` (with `device`): return a DeviceLinks instead of an array."""
     L = _lib.load()
     n = len(leaf_positions)
     off, hold = holders_csr(leaf_positions, n_inds)
@@ -73,16 +87,21 @@ def greedy_trees(leaf_positions, n_inds: int, seeds, output_mask=None, draws=Non
     om = None if output_mask is None else np.ascontiguousarray(output_mask, np.uint64)
     if draws is not None and (draws.dtype != np.uint64 or draws.shape != (len(seeds),) or not draws.flags.c_contiguous):
         raise ValueError("'draws' must be a contiguous uint64 array with one entry per seed.")
-    out = np.empty((len(seeds), 3, 2 * n - 1), np.int32)
+    shape = (len(seeds), 3, 2 * n - 1)
+    if keep_on_device and device is None:
+        raise ValueError("'keep_on_device' needs a 'device'.")
+    out = None if keep_on_device else np.empty(shape, np.int32)
+    dptr = C.c_void_p()
     if device is None:
         rc = L.tnco_hip_greedy_trees(n, n_inds, _ptr(off), _ptr(hold), _ptr(om), len(seeds), _ptr(seeds),
                                      _ptr(draws), _ptr(out), n_threads)
     else:
         rc = L.tnco_hip_greedy_trees_device(int(device), n, n_inds, _ptr(off), _ptr(hold), _ptr(om), len(seeds),
-                                            _ptr(seeds), _ptr(draws), _ptr(out), n_threads)
+                                            _ptr(seeds), _ptr(draws), _ptr(out),
+                                            C.byref(dptr) if keep_on_device else None, n_threads)
     if rc:
         raise ValueError("greedy initial contraction failed (component not connected?).")
-    return out
+    return DeviceLinks(dptr.value, shape, device) if keep_on_device else out
 
 
 def linear_paths(contraction, tensors_pos, n_tensors: int, n_threads: int = 0) -> np.ndarray:
@@ -169,7 +188,11 @@ class BatchedOptimizer:
         if leaf_masks.shape != (n, W):
             raise ValueError("'leaf_masks' has the wrong shape.")
         N = 2 * n - 1
-        links = np.ascontiguousarray(links, np.int32)
+        on_device = isinstance(links, DeviceLinks)
+        if on_device and links.device != int(device):
+            raise ValueError("'links' are in the memory of another device.")
+        if not on_device:
+            links = np.ascontiguousarray(links, np.int32)
         seeds = np.ascontiguousarray(np.asarray(seeds, np.uint64) & np.uint64(0xFFFFFFFF), np.uint32)
         R = len(seeds)
         if links.shape == (3, N):
@@ -183,7 +206,7 @@ class BatchedOptimizer:
         d.leaf_masks = _ptr(leaf_masks)
         om = None if output_mask is None else np.ascontiguousarray(output_mask, np.uint64)
         d.output_mask = _ptr(om)
-        d.links, d.links_stride = _ptr(links), stride
+        d.links, d.links_stride = (C.c_void_p(links.ptr) if on_device else _ptr(links)), stride
         nm = None
         if node_masks is not None:
             nm = np.ascontiguousarray(node_masks, np.uint64)

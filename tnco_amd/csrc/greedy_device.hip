@@ -31,7 +31,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/tnco_hip.h"
@@ -681,18 +683,46 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
 #endif
 }
 
+// Device memory of a call: ONE block, kept between calls (hipFree of the ~2.5 GB a 65 536-tree batch uses
+// took 0.1 s -- as long as half of the kernel).  tnco_hip_greedy_device_release() gives it back.
+struct Pool {
+  void* base = nullptr;
+  size_t bytes = 0;
+  int device = -1;
+  std::mutex mu;
+};
+Pool g_pool;
+
 struct DevBufs {
-  std::vector<void*> ptrs;
-  ~DevBufs() {
-    for (void* q : ptrs) (void)hipFree(q);
-  }
+  bool dry = true;   // first pass: only add up the sizes
+  size_t off = 0;
+  char* base = nullptr;
   template <typename T>
   hipError_t alloc(T** p, size_t count) {
-    void* q = nullptr;
-    const hipError_t e = hipMalloc(&q, std::max<size_t>(count * sizeof(T), 16));
-    if (e == hipSuccess) ptrs.push_back(q);
-    *p = static_cast<T*>(q);
-    return e;
+    const size_t nb = (std::max<size_t>(count * sizeof(T), 16) + 255) & ~(size_t)255;
+    *p = dry ? nullptr : reinterpret_cast<T*>(base + off);
+    off += nb;
+    return hipSuccess;
+  }
+  // second pass: the block (from the pool if it is large enough and on this device)
+  hipError_t commit(int device) {
+    const size_t need = off;
+    if (g_pool.base == nullptr || g_pool.bytes < need || g_pool.device != device) {
+      if (g_pool.base) (void)hipFree(g_pool.base);
+      g_pool.base = nullptr;
+      g_pool.bytes = 0;
+      const hipError_t e = hipMalloc(&g_pool.base, need);
+      if (e != hipSuccess) {
+        g_pool.base = nullptr;
+        return e;
+      }
+      g_pool.bytes = need;
+      g_pool.device = device;
+    }
+    base = static_cast<char*>(g_pool.base);
+    off = 0;
+    dry = false;
+    return hipSuccess;
   }
 };
 
@@ -715,6 +745,18 @@ using namespace tnco;
     const hipError_t e_ = (expr);        \
     if (e_ != hipSuccess) return TNCO_HIP_ERUNTIME; \
   } while (0)
+
+// gives the device memory kept between calls back to the driver
+extern "C" void tnco_hip_greedy_device_release(void) {
+  std::lock_guard<std::mutex> lock(g_pool.mu);
+  if (g_pool.base) {
+    (void)hipSetDevice(g_pool.device);
+    (void)hipFree(g_pool.base);
+  }
+  g_pool.base = nullptr;
+  g_pool.bytes = 0;
+  g_pool.device = -1;
+}
 
 static int64_t g_last_redone = -1;
 // trees of the last tnco_hip_greedy_trees_device call that the host version did (-1: the whole batch)
@@ -739,14 +781,34 @@ extern "C" int tnco_hip_greedy_device_supported(int32_t n_leaves, int32_t n_inds
 extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, int32_t n_inds, const int32_t* holders_off,
                                             const int32_t* holders, const uint64_t* output_mask, int64_t n_replicas,
                                             const uint32_t* seeds, uint64_t* draws, int32_t* links_out,
-                                            int32_t n_threads) {
-  if (n_leaves < 1 || n_inds < 0 || !holders_off || !holders || !seeds || !links_out || n_replicas < 0)
+                                            int32_t** links_device, int32_t n_threads) {
+  if (n_leaves < 1 || n_inds < 0 || !holders_off || !holders || !seeds || (!links_out && !links_device) || n_replicas < 0)
     return TNCO_HIP_EINVAL;
+  if (links_device) *links_device = nullptr;
   if (n_replicas == 0) return TNCO_HIP_OK;
   g_last_redone = -1;
-  if (!tnco_hip_greedy_device_supported(n_leaves, n_inds, holders_off))
-    return tnco_hip_greedy_trees(n_leaves, n_inds, holders_off, holders, output_mask, n_replicas, seeds, draws,
-                                 links_out, n_threads);
+  if (!tnco_hip_greedy_device_supported(n_leaves, n_inds, holders_off)) {
+    // the host version; the trees go to the device afterwards if the caller wants them there
+    const size_t cnt = (size_t)n_replicas * 3 * (2 * (size_t)n_leaves - 1);
+    std::vector<int32_t> tmp;
+    if (!links_out) tmp.resize(cnt);
+    int32_t* host = links_out ? links_out : tmp.data();
+    const int rc = tnco_hip_greedy_trees(n_leaves, n_inds, holders_off, holders, output_mask, n_replicas, seeds, draws,
+                                         host, n_threads);
+    if (rc || !links_device) return rc;
+    G_TRY(hipSetDevice(device));
+    std::lock_guard<std::mutex> pool_lock(g_pool.mu);
+    DevBufs db;
+    int32_t* dl = nullptr;
+    for (int pass = 0; pass < 2; ++pass) {
+      G_TRY(db.alloc(&dl, cnt));
+      if (pass == 0) G_TRY(db.commit(device));
+    }
+    G_TRY(hipMemcpy(dl, host, cnt * 4, hipMemcpyHostToDevice));
+    *links_device = dl;
+    return TNCO_HIP_OK;
+  }
+  const auto t_start = std::chrono::steady_clock::now();
   G_TRY(hipSetDevice(device));
   const int n = n_leaves, I = n_inds, W = (I + 63) / 64, SMAX = 2 * n + 8, NW = (SMAX + 63) / 64;
   const int64_t R = n_replicas, N = 2 * (int64_t)n - 1;
@@ -776,6 +838,7 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (size_t)(160 * 1024) / lds));
   const int G = (int)std::min<int64_t>(R, (int64_t)cus * per_cu);
 
+  std::lock_guard<std::mutex> pool_lock(g_pool.mu);
   DevBufs db;
   ShuffleParams sp{};
   GreedyParams gp{};
@@ -783,23 +846,26 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
   uint64_t *d_draws = nullptr, *d_leaf, *d_out;
   int32_t *d_hoff, *d_hold;
   uint16_t* d_perm;
-  G_TRY(db.alloc(&d_seeds, (size_t)R));
-  G_TRY(db.alloc(&d_mt0, 624));
-  G_TRY(db.alloc(&d_mt, (size_t)624 * R));
-  G_TRY(db.alloc(&d_perm, (size_t)R * n));
-  if (draws) G_TRY(db.alloc(&d_draws, (size_t)R));
-  G_TRY(db.alloc(&d_leaf, leaf.size()));
-  G_TRY(db.alloc(&d_out, outm.size()));
-  G_TRY(db.alloc(&d_hoff, (size_t)I + 1));
-  G_TRY(db.alloc(&d_hold, (size_t)std::max(1, holders_off[I])));
-  G_TRY(db.alloc(&gp.keys, (size_t)G * SMAX * W));
-  G_TRY(db.alloc(&gp.nbr, (size_t)G * SMAX * NW));
-  G_TRY(db.alloc(&gp.arena, (size_t)G * Q * W));
-  G_TRY(db.alloc(&gp.path, (size_t)G * n * 2));
-  G_TRY(db.alloc(&gp.slot_of_leaf, (size_t)G * n));
-  G_TRY(db.alloc(&gp.links, (size_t)R * 3 * N));
-  G_TRY(db.alloc(&gp.status, (size_t)R));
-  G_TRY(db.alloc(&gp.prof, (size_t)G * 16));
+  for (int pass = 0; pass < 2; ++pass) {
+    G_TRY(db.alloc(&d_seeds, (size_t)R));
+    G_TRY(db.alloc(&d_mt0, 624));
+    G_TRY(db.alloc(&d_mt, (size_t)624 * R));
+    G_TRY(db.alloc(&d_perm, (size_t)R * n));
+    if (draws) G_TRY(db.alloc(&d_draws, (size_t)R));
+    G_TRY(db.alloc(&d_leaf, leaf.size()));
+    G_TRY(db.alloc(&d_out, outm.size()));
+    G_TRY(db.alloc(&d_hoff, (size_t)I + 1));
+    G_TRY(db.alloc(&d_hold, (size_t)std::max(1, holders_off[I])));
+    G_TRY(db.alloc(&gp.keys, (size_t)G * SMAX * W));
+    G_TRY(db.alloc(&gp.nbr, (size_t)G * SMAX * NW));
+    G_TRY(db.alloc(&gp.arena, (size_t)G * Q * W));
+    G_TRY(db.alloc(&gp.path, (size_t)G * n * 2));
+    G_TRY(db.alloc(&gp.slot_of_leaf, (size_t)G * n));
+    G_TRY(db.alloc(&gp.links, (size_t)R * 3 * N));
+    G_TRY(db.alloc(&gp.status, (size_t)R));
+    G_TRY(db.alloc(&gp.prof, (size_t)G * 16));
+    if (pass == 0) G_TRY(db.commit(device));
+  }
   G_TRY(hipMemcpy(d_seeds, seeds, (size_t)R * 4, hipMemcpyHostToDevice));
   G_TRY(hipMemcpy(d_mt0, mt0, sizeof(mt0), hipMemcpyHostToDevice));
   if (draws) G_TRY(hipMemcpy(d_draws, draws, (size_t)R * 8, hipMemcpyHostToDevice));
@@ -809,6 +875,11 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
   if (holders_off[I] > 0) G_TRY(hipMemcpy(d_hold, holders, (size_t)holders_off[I] * 4, hipMemcpyHostToDevice));
 
   const bool dbg = std::getenv("TNCO_HIP_GREEDY_DEBUG") != nullptr;
+  if (dbg) {
+    G_TRY(hipDeviceSynchronize());
+    std::fprintf(stderr, "greedy_device: set-up (allocations, inputs to the device) %.1f ms\n",
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+  }
   hipEvent_t ev[4];
   if (dbg) {
     for (auto& e : ev) G_TRY(hipEventCreate(&e));
@@ -824,7 +895,7 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
   G_TRY(hipGetLastError());
   if (dbg) G_TRY(hipEventRecord(ev[2], 0));
   G_TRY(hipDeviceSynchronize());
-  G_TRY(hipMemcpy(links_out, gp.links, (size_t)R * 3 * N * 4, hipMemcpyDeviceToHost));
+  if (links_out) G_TRY(hipMemcpy(links_out, gp.links, (size_t)R * 3 * N * 4, hipMemcpyDeviceToHost));
   if (dbg) {
     G_TRY(hipEventRecord(ev[3], 0));
     G_TRY(hipEventSynchronize(ev[3]));
@@ -875,9 +946,21 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
                                          s2.data(), draws ? d2.data() : nullptr, l2.data(), n_threads);
     if (rc) return rc;
     for (size_t k = 0; k < redo.size(); ++k) {
-      std::memcpy(links_out + redo[k] * 3 * N, l2.data() + k * 3 * (size_t)N, (size_t)3 * N * 4);
+      if (links_out) std::memcpy(links_out + redo[k] * 3 * N, l2.data() + k * 3 * (size_t)N, (size_t)3 * N * 4);
+      G_TRY(hipMemcpy(gp.links + redo[k] * 3 * N, l2.data() + k * 3 * (size_t)N, (size_t)3 * N * 4, hipMemcpyHostToDevice));
       if (draws) draws[redo[k]] = d2[k];
     }
   }
+  if (dbg)
+    std::fprintf(stderr, "greedy_device: %.1f ms from entry to the return (before the buffers are freed)\n",
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+  if (links_device) *links_device = gp.links;
+  return TNCO_HIP_OK;
+}
+
+// device -> host copy of a buffer this library handed out (the trees of tnco_hip_greedy_trees_device)
+extern "C" int tnco_hip_copy_to_host(void* dst, const void* device_src, uint64_t bytes) {
+  if (!dst || !device_src) return TNCO_HIP_EINVAL;
+  G_TRY(hipMemcpy(dst, device_src, (size_t)bytes, hipMemcpyDeviceToHost));
   return TNCO_HIP_OK;
 }

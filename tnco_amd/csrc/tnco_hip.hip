@@ -217,6 +217,60 @@ const char* tree_check(int32_t N, const int32_t* left, const int32_t* right, con
   return nullptr;
 }
 
+// The same checks for trees that are already in device memory (tnco_hip_greedy_trees_device leaves
+// them there), one wavefront per tree.  The host version's two counters (how often a node is named as
+// a parent / as a child) follow from the rest: with one root, n leaves, every child link answered by the
+// child's parent pointer and left != right, the 2(n - 1) child links name 2(n - 1) different nodes
+// other than the root -- each exactly once -- and the N - 1 parent pointers are those links.
+// Status: 0 ok, else the number of the first check of tree_check that fails.
+__global__ __launch_bounds__(64) void tree_check_kernel(int32_t N, const int32_t* links, int64_t stride, int64_t ntrees,
+                                                        int32_t* out_status) {
+  const int64_t r = blockIdx.x;
+  if (r >= ntrees) return;
+  const int32_t* left = links + r * stride;
+  const int32_t* right = left + N;
+  const int32_t* parent = left + 2 * (int64_t)N;
+  const int32_t n = (N + 1) / 2;
+  const int lane = threadIdx.x;
+  int bad_node = 0, roots = 0, leaves = 0, leaf_late = 0, bad_tree = 0;
+  for (int32_t i = lane; i < N; i += 64) {
+    const int32_t p = parent[i], l = left[i], rr = right[i];
+    const int32_t xs[3] = {p, l, rr};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (!(xs[k] == -1 || (xs[k] >= 0 && xs[k] < N))) bad_node = 1;
+    if ((l < 0) != (rr < 0)) bad_node = 1;
+    if (l >= 0 && l == rr) bad_node = 1;
+    if (l >= 0 && p >= 0 && (p == l || p == rr)) bad_node = 1;
+    roots += p < 0;
+    leaves += l < 0;
+    if (i < n && l >= 0) leaf_late = 1;
+    if (!bad_node && l >= 0 && rr >= 0 && (parent[l] != i || parent[rr] != i)) bad_tree = 1;
+  }
+  for (int o = 32; o; o >>= 1) {
+    roots += __shfl_xor(roots, o);
+    leaves += __shfl_xor(leaves, o);
+  }
+  int st = 0;
+  if (__any(bad_node)) st = 1;
+  else if (parent[N - 1] != -1) st = 2;
+  else if (roots != 1) st = 3;
+  else if (__any(leaf_late)) st = 4;
+  else if (leaves != n) st = 5;
+  else if (__any(bad_tree)) st = 6;
+  if (lane == 0) out_status[r] = st;
+}
+const char* tree_check_message(int st) {
+  switch (st) {
+    case 1: return "Nodes are not valid";
+    case 2: return "Last node should be root.";
+    case 3: return "There should be only one root.";
+    case 4: return "All leaves should be first.";
+    case 5: return "Number of nodes is not constenst with the number of leaves.";
+    default: return "Tree is not valid.";
+  }
+}
+
 // Post-order of include/tnco/utils.hpp:34-51.
 void host_traverse(int32_t N, const int32_t* left, const int32_t* right, std::vector<int32_t>& order) {
   std::vector<int32_t> stack;
@@ -355,8 +409,21 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       return fail(TNCO_HIP_ENOTIMPL, "finite width: width_type must be float32 or float64.");
   }
 
-  // host-side structural validation of every tree
+  // links already in device memory (tnco_hip_greedy_trees_device): validated there, never copied
+  bool links_on_device = false;
   {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, d->links) == hipSuccess) {
+      if (at.type == hipMemoryTypeDevice) {
+        if (at.device != d->device) return fail(TNCO_HIP_EINVAL, "'links' are in the memory of another device.");
+        links_on_device = true;
+      }
+    } else {
+      (void)hipGetLastError();  // (plain host memory: not an error)
+    }
+  }
+  // host-side structural validation of every tree
+  if (!links_on_device) {
     const int64_t ntrees = d->links_stride == 0 ? 1 : R;
     const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ntrees / 64 + 1, 16), std::thread::hardware_concurrency()));
     std::vector<const char*> errs((size_t)nth, nullptr);
@@ -584,11 +651,27 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     int32_t* dstatus = nullptr;
     std::vector<double> total((size_t)R), sum((size_t)R);
     std::vector<int32_t> status((size_t)R);
-    HIP_TRY(tmp.alloc(&dlinks, ntrees * 3 * N));
-    if (d->links_stride == 0 || d->links_stride == 3 * (int64_t)N)
-      HIP_TRY(hipMemcpy(dlinks, d->links, (size_t)ntrees * 3 * N * 4, hipMemcpyHostToDevice));
-    else
-      HIP_TRY(hipMemcpy2D(dlinks, (size_t)3 * N * 4, d->links, (size_t)d->links_stride * 4, (size_t)3 * N * 4, (size_t)ntrees, hipMemcpyHostToDevice));
+    if (links_on_device && (d->links_stride == 0 || d->links_stride == 3 * (int64_t)N)) {
+      dlinks = const_cast<int32_t*>(d->links);  // (read only)
+    } else {
+      HIP_TRY(tmp.alloc(&dlinks, ntrees * 3 * N));
+      const hipMemcpyKind kind = links_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+      if (d->links_stride == 0 || d->links_stride == 3 * (int64_t)N)
+        HIP_TRY(hipMemcpy(dlinks, d->links, (size_t)ntrees * 3 * N * 4, kind));
+      else
+        HIP_TRY(hipMemcpy2D(dlinks, (size_t)3 * N * 4, d->links, (size_t)d->links_stride * 4, (size_t)3 * N * 4, (size_t)ntrees, kind));
+    }
+    if (links_on_device) {
+      int32_t* dcheck = nullptr;
+      HIP_TRY(tmp.alloc(&dcheck, ntrees));
+      hipLaunchKernelGGL(tree_check_kernel, dim3((unsigned)ntrees), dim3(64), 0, h->stream, (int32_t)N, dlinks, 3 * (int64_t)N, ntrees, dcheck);
+      HIP_TRY(hipGetLastError());
+      std::vector<int32_t> chk((size_t)ntrees);
+      HIP_TRY(hipMemcpyAsync(chk.data(), dcheck, (size_t)ntrees * 4, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      for (int64_t r = 0; r < ntrees; ++r)
+        if (chk[r]) return fail(TNCO_HIP_EINVAL, tree_check_message(chk[r]));
+    }
     const int64_t nmasks = d->node_masks ? (d->node_masks_stride == 0 ? 1 : R) : 0;
     if (nmasks) {
       HIP_TRY(tmp.alloc(&dmasks, nmasks * N * W));
