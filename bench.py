@@ -169,8 +169,10 @@ class Leg:
             kw = dict(max_width=args.fw_max_width)
         all_seeds = synthetic.replica_seeds(R * world, S=0)
         self.seeds = all_seeds[rank * R:(rank + 1) * R]
-        gen = core.greedy_trees if args.init == "greedy" else core.random_trees
-        self.links = gen(self.prob.ts_inds, self.prob.n_inds, self.seeds)
+        if args.init == "greedy":  # as the reference starts every run (tnco/utils/tn.py:189-230), drawn on this rank's GPU
+            self.links = core.greedy_trees(self.prob.ts_inds, self.prob.n_inds, self.seeds, device=local_rank)
+        else:
+            self.links = core.random_trees(self.prob.ts_inds, self.prob.n_inds, self.seeds)
         self.sps = args.sweeps_per_step
         self.total_sweeps = (args.warmup + args.steps) * self.sps
         self.betas = synthetic.linear_betas(0.0, 100.0, self.total_sweeps)
@@ -321,9 +323,9 @@ def main() -> None:
     ap.add_argument("--leaves", type=int, default=512)
     ap.add_argument("--replicas", type=int, default=65536, help="replicas per GPU")
     ap.add_argument("--graph-seed", type=int, default=11)
-    ap.add_argument("--init", choices=("kruskal", "greedy"), default="kruskal",
-                    help="initial trees: the build's random-Kruskal generator (round 1's line) or the reference's recipe "
-                         "(shuffle + opt_einsum greedy, restated)")
+    ap.add_argument("--init", choices=("kruskal", "greedy"), default="greedy",
+                    help="initial trees: the reference's recipe (Random(seed).shuffle + opt_einsum greedy, restated, drawn "
+                         "on the GPU) or the build's random-Kruskal generator (the line of round 1)")
     ap.add_argument("--workload", choices=("both", "im", "fw"), default="both",
                     help="im: the headline leg only; fw: the finite-width leg as the headline; both: im + 'fw' object")
     ap.add_argument("--fw-max-width", type=float, default=40.0)
@@ -399,7 +401,7 @@ def main() -> None:
     if rank == 0:
         R, sps, every = args.replicas, args.sweeps_per_step, args.fw_update_slices
         key = (f"{args.workload}/{args.leaves}/{R}/{sps}/{args.steps}/{args.warmup}/{args.fw_max_width}/{every}/"
-               f"{args.fw_depth}" + ("" if args.init == "kruskal" else "/" + args.init))
+               f"{args.fw_depth}/{args.init}")
         pmc, pmc_note = None, None
         if args.pmc and world == 1:
             for leg in objs.values():  # free the GPU memory of this process first
@@ -476,7 +478,7 @@ def main() -> None:
                     "improvements_timed": res["improved"], "full_tree_copies_timed": res["full_copies"],
                     "validated_bad_replicas": res.get("n_bad"), "library": lib_version,
                     "initial_trees": "random Kruskal (tnco_hip_random_trees)" if args.init == "kruskal" else
-                                     "Random(seed).shuffle + opt_einsum greedy restated (tnco_hip_greedy_trees)",
+                                     "Random(seed).shuffle + opt_einsum greedy restated (tnco_hip_greedy_trees_device)",
                 },
                 "roofline": roof,
             }
