@@ -23,8 +23,8 @@ def _initial_max_width(prob, links_r):
     return max(len(ct.unpack_mask(m)) for m in inds)
 
 
-def _check(core, orc, prob, seeds, betas, max_width, chunks, every=10, **kw):
-    links = prob.links(seeds)
+def _check(core, orc, prob, seeds, betas, max_width, chunks, every=10, links=None, **kw):
+    links = prob.links(seeds) if links is None else links
     gpu = core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, dims=prob.dims,
                                 output_mask=prob.output_mask, sparse_mask=prob.sparse_mask, max_width=max_width, **kw)
     lo = 0
@@ -192,3 +192,45 @@ def test_fw_traversal_fallbacks(core, oracle_lib, monkeypatch, stack):
     _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 60, 60), max(2, int(0.4 * w0)), chunks=[25, 35], every=5)
     prob = H.regular_problem(36, graph_seed=12)
     _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 50, 40), 5, chunks=[40], max_number_new_slices=2)
+
+
+def _spine_with_cherries(n, left_deep):
+    """Pairs of leaves ('cherries') hanging off one long spine: the spine is the RIGHT child everywhere
+    (left_deep=False: the backward walker of fw_walk2_kernel has a left child waiting at every level)
+    or the LEFT child everywhere (the forward walker's stack is as deep as the spine)."""
+    m = n // 2
+    con, nxt = [], n
+    cher = []
+    for k in range(m):
+        con.append((2 * k, 2 * k + 1, nxt)); cher.append(nxt); nxt += 1
+    top = cher[-1]
+    for k in reversed(range(m - 1)):
+        con.append((top, cher[k], nxt) if left_deep else (cher[k], top, nxt)); top = nxt; nxt += 1
+    return np.stack(ct.tree_from_contraction(con, n))
+
+
+@pytest.mark.parametrize("left_deep", [False, True])
+def test_fw_walk_from_both_ends_on_deep_trees(core, oracle_lib, left_deep):
+    """fw_walk2_kernel beyond its LDS stacks: 64 levels of spine with a subtree waiting at every level --
+    the backward walker's 40 entries overflow (it stops, the forward walker lists the rest) or the
+    forward walker's stack spills to global memory; re-slicing every sweep, so the first walks see
+    these trees nearly unchanged.  Bit for bit against the oracle."""
+    n = 128
+    m = n // 2
+    # a ladder (rungs inside the cherries, rails between neighbouring cherries) + long-range bonds
+    ts = [[] for _ in range(n)]
+    nxt = 0
+    for k in range(m):
+        ts[2 * k].append(nxt); ts[2 * k + 1].append(nxt); nxt += 1              # rung
+        if k + 1 < m:
+            for side in (0, 1):
+                ts[2 * k + side].append(nxt); ts[2 * (k + 1) + side].append(nxt); nxt += 1   # rails
+        far = (k + 7) % m
+        ts[2 * k].append(nxt); ts[2 * far + 1].append(nxt); nxt += 1            # long-range bond
+    from tnco_amd.synthetic import Problem
+    prob = Problem(ts, 2)
+    seeds = H.replica_seeds(5, S=3)
+    tree = _spine_with_cherries(n, left_deep)
+    links = np.repeat(tree[None], len(seeds), axis=0)
+    w0 = _initial_max_width(prob, tree)
+    _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 40, 12), max(3, w0 // 2), chunks=[12], every=1, links=links)

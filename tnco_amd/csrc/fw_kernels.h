@@ -733,14 +733,14 @@ __device__ __forceinline__ int fw_gs_mark(const Params& P, const FwParams& F, co
   };
   if (nw > 0) {
     int inchunk = 0;
-    int ta = sc.wlist[0], tb = nw > 1 ? sc.wlist[1] : 0;
+    int ta = sc.wl(0, nw), tb = nw > 1 ? sc.wl(1, nw) : 0;
     Mask<K> m0 = v.mask(ta);
     for (int j = 0; j < nw; ++j) {
       // (the next mask is on its way while this one is added; past the end of the list: any tensor --
       // unconditional loads, one definition each)
       ta = tb;
       const Mask<K> m1 = v.mask(ta);
-      tb = sc.wlist[j + 2 < nw ? j + 2 : nw - 1];
+      tb = sc.wl(j + 2 < nw ? j + 2 : nw - 1, nw);
       Mask<K> carry = m0;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
@@ -773,7 +773,6 @@ __device__ __forceinline__ Mask<K> fw_gs_pick(const Params& P, const FwParams& F
                                               bool lane0, int gbase, int32_t* status,
                                               unsigned long long* cnt = nullptr) {
   const int lig = v.lig;
-  const int32_t* wlist = sc.wlist;
   const int32_t* n_big = sc.n_big;
   volatile int16_t* pos = sc.pos;
   Mask<K> slices = mzero<K>();
@@ -789,7 +788,7 @@ __device__ __forceinline__ Mask<K> fw_gs_pick(const Params& P, const FwParams& F
   // the replicas of the wavefront do the long part together.
   {
     int j = 0;
-    int ta = nw > 0 ? wlist[0] : 0, tb = nw > 1 ? wlist[1] : 0;
+    int ta = nw > 0 ? sc.wl(0, nw) : 0, tb = nw > 1 ? sc.wl(1, nw) : 0;
     Mask<K> ma = mzero<K>();
     if (nw > 0) ma = v.mask(ta);
     for (;;) {
@@ -802,7 +801,7 @@ __device__ __forceinline__ Mask<K> fw_gs_pick(const Params& P, const FwParams& F
         ta = tb;
         ++j;
         ma = v.mask(ta);  // (past the end of the list: any tensor)
-        tb = wlist[j + 1 < nw ? j + 1 : nw - 1];
+        tb = sc.wl(j + 1 < nw ? j + 1 : nw - 1, nw);
         FW_GP_COUNT(0, 1);  // too-wide tensors
         sx = mandn<K>(m, slices);
         sw = fw_width<LOG2L, K>(P, F, sx, lig, gbase);
@@ -998,6 +997,204 @@ static __global__ __launch_bounds__(256) void fw_walk_kernel(const Params P, con
     rec[k] = (uint64_t)rb[(2 * (k & 7)) * NT] | ((uint64_t)rb[(2 * (k & 7) + 1) * NT] << 32);
   for (int k = nw & ~7; k < nw; ++k) wlist[k] = wb[(k & 7) * NT];
   F.nwide[r] = nw;
+}
+
+// The same walk from BOTH ends of the post-order, two lanes per replica (lanes 0-31 of a wavefront walk
+// forward, lane 32 + i walks backward for the replica of lane i).  The one-ended walk keeps one header
+// read in flight per replica and sits at half of the chip's request rate; the reverse of a post-order
+// is the pre-order that takes the RIGHT child first, so a second walker can emit the list from its end:
+// node x at the moment its header arrives (position n - 2 - b for the b-th node), right subtree next,
+// the left child waiting on a small stack.  Both fill the same rec[]; the too-wide tensors of the
+// backward walker go to the END of wlist (FwScratch::wl).  The two lanes run in lock-step and exchange
+// their counts every iteration: with `left` = nodes not yet listed, the backward walker lists one more
+// only while left >= 2, the forward walker gets the rest -- every node exactly once.  A backward
+// walker whose stack outgrows its LDS entries stops for good (the forward walker finishes alone).
+// Not for trees with too-wide LEAVES (F.leaf_wide: their place in the list is the forward walker's
+// business): the host launches fw_walk_kernel for those.
+constexpr int FW_WALK2_CAPB = 40;
+static __global__ __launch_bounds__(256) void fw_walk2_kernel(const Params P, const FwParams F) {
+  constexpr int NT = 128;  // replicas per block: the stride of the LDS arrays
+  __shared__ int32_t se[FW_WALK_CAP * NT];
+  __shared__ uint16_t sl[FW_WALK_CAP * NT];
+  __shared__ uint16_t sb[FW_WALK2_CAPB * NT];  // backward walker: left children waiting
+  __shared__ uint32_t rbuf[2 * 16 * NT];       // 8 records per walker
+  __shared__ int32_t wbuf[2 * 8 * NT];         // 8 too-wide tensors per walker
+  const int tid = threadIdx.x;
+  const bool fwd = (tid & 32) == 0;
+  const int slot = (tid >> 6) * 32 + (tid & 31);
+  const int64_t r = (int64_t)blockIdx.x * NT + slot;
+  const int n = P.n, N = P.N, LK = F.I64 / 64, ni_all = N - n;
+  bool active = r < P.R;
+  if (active) {  // greedy/optimizer.hpp:359: nothing to do without slices
+    const uint64_t* sl0 = F.slices + r * 2 * (int64_t)LK;
+    uint64_t any = 0;
+    for (int w = 0; w < P.W; ++w) any |= sl0[w];
+    if (!any) {
+      if (fwd) F.nwide[r] = -1;
+      active = false;
+    }
+  }
+  const int64_t rr_ = active ? r : 0;
+  const FwScratch sc(F, rr_, N);
+  const uint8_t* blk = P.blocks + rr_ * (int64_t)(n - 1) * P.BS;
+  const double* w64 = F.width64 ? F.width64 + rr_ * (int64_t)N : nullptr;
+  uint64_t* rec = sc.rec;
+  int32_t* wlist = sc.wlist;
+  volatile int32_t* gstk = sc.gstk;
+  const int wcap = sc.wcap;
+  TNCO_LDS volatile int32_t* e_ = (TNCO_LDS volatile int32_t*)se + slot;
+  TNCO_LDS volatile uint16_t* l_ = (TNCO_LDS volatile uint16_t*)sl + slot;
+  TNCO_LDS volatile uint16_t* b_ = (TNCO_LDS volatile uint16_t*)sb + slot;
+  TNCO_LDS volatile uint32_t* rb = (TNCO_LDS volatile uint32_t*)rbuf + (fwd ? 0 : 16 * NT) + slot;
+  TNCO_LDS volatile int32_t* wb = (TNCO_LDS volatile int32_t*)wbuf + (fwd ? 0 : 8 * NT) + slot;
+  const int gh = (N + 1) / 2;
+  int cnt = 0, nw = 0;  // nodes / too-wide tensors this walker has listed
+  // ---- forward walker (as fw_walk_kernel) ----
+  int sp = 0, x = N - 1;
+  auto f_put_wide = [&](int t) {
+    wb[(nw & 7) * NT] = t;
+    ++nw;
+    if ((nw & 7) == 0) {
+      int4* d = reinterpret_cast<int4*>(wlist + nw - 8);
+      d[0] = make_int4(wb[0], wb[NT], wb[2 * NT], wb[3 * NT]);
+      d[1] = make_int4(wb[4 * NT], wb[5 * NT], wb[6 * NT], wb[7 * NT]);
+    }
+  };
+  auto f_put_rec = [&](uint64_t v) {
+    rb[(2 * (cnt & 7)) * NT] = (uint32_t)v;
+    rb[(2 * (cnt & 7) + 1) * NT] = (uint32_t)(v >> 32);
+    ++cnt;
+    if ((cnt & 7) == 0) {
+      uint4* d = reinterpret_cast<uint4*>(rec + cnt - 8);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        d[q] = make_uint4(rb[(4 * q) * NT], rb[(4 * q + 1) * NT], rb[(4 * q + 2) * NT], rb[(4 * q + 3) * NT]);
+    }
+  };
+  // one step up; lists a node only if `may` (returns 1 if it did)
+  auto f_up = [&](bool may) -> int {
+    int e, l;
+    if (sp <= FW_WALK_CAP) {
+      e = e_[(sp - 1) * NT];
+      l = l_[(sp - 1) * NT];
+    } else {
+      e = gstk[sp - 1 - FW_WALK_CAP];
+      l = gstk[gh + sp - 1 - FW_WALK_CAP];
+    }
+    const int node = e & 0x1FFF, rr = (e >> 13) & 0x1FFF;
+    const bool fresh = ((e >> 26) & 1) == 0;
+    if (fresh && rr >= n) {  // into the right subtree
+      if (sp <= FW_WALK_CAP) e_[(sp - 1) * NT] = e | (1 << 26); else gstk[sp - 1 - FW_WALK_CAP] = e | (1 << 26);
+      x = rr;
+      return 0;
+    }
+    if (!may) return 0;
+    --sp;
+    f_put_rec(fw_rec(node, l, rr));
+    if ((e >> 27) & 1) f_put_wide(node);
+    return 1;
+  };
+  // ---- backward walker ----
+  int bx = N - 1, bsp = 0;
+  bool balive = true;  // (false: stack overflow, this walker has stopped)
+  auto b_put_wide = [&](int t) {  // the k-th goes to wlist[wcap - 1 - k]
+    const int pos = wcap - 1 - nw;
+    wb[(pos & 7) * NT] = t;
+    ++nw;
+    if ((pos & 7) == 0) {
+      int4* d = reinterpret_cast<int4*>(wlist + pos);
+      d[0] = make_int4(wb[0], wb[NT], wb[2 * NT], wb[3 * NT]);
+      d[1] = make_int4(wb[4 * NT], wb[5 * NT], wb[6 * NT], wb[7 * NT]);
+    }
+  };
+  auto b_put_rec = [&](uint64_t v) {  // the k-th goes to rec[ni_all - 1 - k]
+    const int pos = ni_all - 1 - cnt;
+    rb[(2 * (pos & 7)) * NT] = (uint32_t)v;
+    rb[(2 * (pos & 7) + 1) * NT] = (uint32_t)(v >> 32);
+    ++cnt;
+    if ((pos & 7) == 0) {
+      if (pos + 8 <= ni_all) {  // a whole 8-record piece of this walker's
+        uint4* d = reinterpret_cast<uint4*>(rec + pos);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          d[q] = make_uint4(rb[(4 * q) * NT], rb[(4 * q + 1) * NT], rb[(4 * q + 2) * NT], rb[(4 * q + 3) * NT]);
+      } else {  // the piece holding the last record of the list, cut by its end
+        for (int k = pos; k < ni_all; ++k)
+          rec[k] = (uint64_t)rb[(2 * (k & 7)) * NT] | ((uint64_t)rb[(2 * (k & 7) + 1) * NT] << 32);
+      }
+    }
+  };
+  if (N - 1 < n) active = false;  // (a single tensor: no internal node)
+  for (;;) {
+    // counts of the pair, and whether the backward walker is still going
+    const int word = active ? (cnt | ((fwd || balive) ? (1 << 20) : 0)) : (1 << 21);
+    const int oth = __shfl_xor(word, 32);
+    const bool pair_off = !active || ((oth >> 21) & 1);
+    const int left = pair_off ? 0 : ni_all - cnt - (oth & 0xFFFFF);
+    if (!__any(left > 0)) break;
+    if (left <= 0) continue;
+    if (fwd) {
+      const bool b_on = ((oth >> 20) & 1) != 0;
+      int may = left - ((b_on && left >= 2) ? 1 : 0);
+      if (x < 0 && sp > 0) may -= f_up(may > 0);
+      if (x >= n) {  // down: the only read of this node's header (links + cached width, one line)
+        const int4 h = *reinterpret_cast<const int4*>(blk + (int64_t)(x - n) * P.BS);
+        const double w = F.width_f32 ? (double)__int_as_float(h.w) : w64[x];
+        const bool wide = w > F.max_width;
+        ++sp;
+        const int e = x | (h.y << 13) | (wide ? (1 << 27) : 0);
+        if (sp <= FW_WALK_CAP) {
+          e_[(sp - 1) * NT] = e;
+          l_[(sp - 1) * NT] = (uint16_t)h.x;
+        } else {
+          gstk[sp - 1 - FW_WALK_CAP] = e;
+          gstk[gh + sp - 1 - FW_WALK_CAP] = h.x;
+        }
+        x = h.x;
+        if (x < n) x = -1;
+      }
+      if (x < 0 && sp > 0) may -= f_up(may > 0);
+    } else if (balive && left >= 2 && bx >= n) {
+      const int4 h = *reinterpret_cast<const int4*>(blk + (int64_t)(bx - n) * P.BS);
+      const double w = F.width_f32 ? (double)__int_as_float(h.w) : w64[bx];
+      b_put_rec(fw_rec(bx, h.x, h.y));
+      if (w > F.max_width) b_put_wide(bx);
+      const bool li = h.x >= n, ri = h.y >= n;
+      if (ri) {
+        if (li) {
+          if (bsp < FW_WALK2_CAPB) b_[(bsp++) * NT] = (uint16_t)h.x; else balive = false;
+        }
+        bx = h.y;
+      } else if (li) {
+        bx = h.x;
+      } else if (bsp > 0) {
+        bx = b_[(--bsp) * NT];
+      } else {
+        bx = -1;  // (only after the root's last descendant: nothing is left then)
+      }
+    }
+  }
+  if (!active) return;
+  // the unfinished pieces of the lists, the counts
+  if (fwd) {
+    for (int k = cnt & ~7; k < cnt; ++k)
+      rec[k] = (uint64_t)rb[(2 * (k & 7)) * NT] | ((uint64_t)rb[(2 * (k & 7) + 1) * NT] << 32);
+    for (int k = nw & ~7; k < nw; ++k) wlist[k] = wb[(k & 7) * NT];
+  } else {
+    // records [ni_all - cnt, ni_all): pieces went out when the walker reached their first record; the
+    // piece cut by the lowest record is left
+    const int lo = ni_all - cnt;
+    for (int k = lo; k < ni_all && (k & ~7) < lo; ++k)
+      rec[k] = (uint64_t)rb[(2 * (k & 7)) * NT] | ((uint64_t)rb[(2 * (k & 7) + 1) * NT] << 32);
+    const int wlo = wcap - nw;
+    for (int k = wlo; k < wcap; ++k)
+      if ((k & ~7) < wlo) wlist[k] = wb[(k & 7) * NT];
+  }
+  const int onw = __shfl_xor(nw, 32);
+  if (fwd) {
+    F.nwide[r] = nw + onw;
+    F.nwfront[r] = nw;
+  }
 }
 
 struct FwInitArgs {
@@ -1451,7 +1648,8 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_WAVES) void fw_reslice_kernel(
   View<LOG2L, K, HYPER> v;
   v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n * LPS, lig);
   ReplicaState* rs = P.rs + r;
-  const FwScratch sc(F, r, N);
+  FwScratch sc(F, r, N);
+  if (prewalked == 2) sc.nwf = F.nwfront[r];  // (fw_walk2_kernel: the list in two parts)
   double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
   uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
   M slices;

@@ -24,6 +24,7 @@ struct FwParams {
   double* scratch_d;        // [R][2N]        see FwScratch
   double* width64;          // [R][N] widths of the internal nodes when width_type is float64
   int32_t* nwide;           // [R] fw_walk_kernel -> fw_reslice_kernel: too-wide tensors listed (-1: no slices, nothing to do)
+  int32_t* nwfront;         // [R] ... how many of them at the front of the list (fw_walk2_kernel: the rest at its end)
   int32_t* status;          // [R] runtime problems (1: candidate legs beyond the scratch; cannot happen
                             //     since the scratch holds every index)
 };
@@ -42,6 +43,10 @@ struct FwScratch {
   int32_t* gstk;
   double2* cp;   // FwParams::scratch_d: rebuilt (cost, partial sum) by post-order number [n - 1]
   double* pstk;  // ... and the stack of partial sums [N]
+  int32_t wcap;  // entries of wlist
+  int32_t nwf;   // too-wide tensors at the front of wlist; the others are its last entries (fw_walk2_kernel)
+  // the j-th of nw too-wide tensors, in post-order
+  __device__ __forceinline__ int32_t wl(int j, int nw) const { return wlist[j < nwf ? j : wcap - nw + j]; }
   __device__ __forceinline__ FwScratch(const FwParams& F, int64_t r, int N) {
     int32_t* si = F.scratch_i + r * fw_scratch_ints(N, F.I64);
     n_big = si;
@@ -49,6 +54,8 @@ struct FwScratch {
     rec = reinterpret_cast<uint64_t*>(si + F.I64 + F.I64 / 2);
     wlist = si + F.I64 + F.I64 / 2 + fw_np(N);
     gstk = wlist + fw_np(N);
+    wcap = (int32_t)fw_np(N);
+    nwf = 0x7FFFFFFF;
     double* sd = F.scratch_d + r * 2 * (int64_t)N;
     cp = reinterpret_cast<double2*>(sd);
     pstk = sd + N;

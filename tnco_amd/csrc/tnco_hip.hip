@@ -109,7 +109,11 @@ void launch_fw_init(tnco_hip_ctx* h, const FwInitArgs& a) {
 }
 
 // (one lane per replica: the same kernel whatever the lane layout of the handle)
-void launch_fw_walk(tnco_hip_ctx* h) {
+void launch_fw_walk(tnco_hip_ctx* h, int two_ended) {
+  if (two_ended) {  // two lanes per replica, from both ends of the post-order
+    hipLaunchKernelGGL(fw_walk2_kernel, dim3((unsigned)((h->P.R + 127) / 128)), dim3(256), 0, h->stream, h->P, h->F);
+    return;
+  }
   hipLaunchKernelGGL(fw_walk_kernel, dim3((unsigned)((h->P.R + FW_WALK_PER_BLOCK - 1) / FW_WALK_PER_BLOCK)), dim3(256), 0, h->stream,
                      h->P, h->F);
 }
@@ -137,9 +141,10 @@ hipError_t launch_fw_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, 
     if (reslice) {
       // the walk over the tree as a kernel of its own (one lane per replica), unless the tree is too
       // large for its stack fields or the test knob TNCO_HIP_FW_STACK=0 asks for the link-walking path
-      const int prewalked = (h->P.N <= 8192 && h->F.stack_cap > 0 && h->F.nwide != nullptr) ? 1 : 0;
+      int prewalked = (h->P.N <= 8192 && h->F.stack_cap > 0 && h->F.nwide != nullptr) ? 1 : 0;
+      if (prewalked && h->F.nwfront != nullptr && !h->F.leaf_wide) prewalked = 2;
       if (prewalked) {
-        e = h->timed(TNCO_KIND_FW_WALK, [&]() { launch_fw_walk(h); });
+        e = h->timed(TNCO_KIND_FW_WALK, [&]() { launch_fw_walk(h, prewalked == 2); });
         if (e != hipSuccess) return e;
       }
       e = h->timed(TNCO_KIND_FW_RESLICE, [&]() {
@@ -732,7 +737,10 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     HIP_TRY(h->alloc(&F.scratch_i, R * fw_scratch_ints(N, F.I64)));
     HIP_TRY(h->alloc(&F.scratch_d, R * 2 * (int64_t)N));
     HIP_TRY(h->alloc(&F.status, R));
-    if (!std::getenv("TNCO_HIP_FW_NO_WALK_KERNEL")) HIP_TRY(h->alloc(&F.nwide, R));
+    if (!std::getenv("TNCO_HIP_FW_NO_WALK_KERNEL")) {
+      HIP_TRY(h->alloc(&F.nwide, R));
+      if (!std::getenv("TNCO_HIP_FW_ONE_ENDED_WALK")) HIP_TRY(h->alloc(&F.nwfront, R));  // (test knob: fw_walk_kernel)
+    }
     HIP_TRY(hipMemset(F.status, 0, (size_t)R * 4));
     F.stack_cap = FW_LDSPOS;
     if (const char* e = std::getenv("TNCO_HIP_FW_STACK")) F.stack_cap = std::max(0, std::min(FW_LDSPOS, std::atoi(e)));
