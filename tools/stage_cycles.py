@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--sweeps", type=int, default=100)
     ap.add_argument("--fine", action="store_true")
     ap.add_argument("--fw", action="store_true", help="finite-width kernels on the config-5 topology")
+    ap.add_argument("--kruskal", action="store_true", help="--fw: random-Kruskal initial trees")
     a = ap.parse_args()
     if a.fw:
         return fw(a)
@@ -62,7 +63,8 @@ def fw(a):
     n_inds = 1 + max(i for xs in ts for i in xs)
     lm = ctree.pack_masks(ts, n_inds)
     seeds = np.arange(1, a.replicas + 1, dtype=np.uint32)
-    links = core.random_trees(ts, n_inds, seeds)
+    # (the reference's greedy starts, as bench.py; --kruskal: the random starts of round 1's line)
+    links = core.random_trees(ts, n_inds, seeds) if a.kruskal else core.greedy_trees(ts, n_inds, seeds, device=0)
     opt = core.BatchedOptimizer(lm, links, seeds, n_inds=n_inds, max_width=40)
     L = _lib.load()
     base = np.zeros(5, np.uint64)
