@@ -277,25 +277,32 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
       h ^= h >> 32;
       return (uint32_t)h;
     };
+    // a table cell: slot (12 bits: SMAX <= 4008) | 4 bits of the hash << 12; 0xFFFF = free.  A set is only
+    // compared with the stored one (a read from memory) when those four bits agree.
+    int tag = 0;
     auto find_slot = [&](uint64_t m, int& cell) -> int {
-      for (uint32_t h = hash_of(m) & (uint32_t)(TS - 1);; h = (h + 1) & (uint32_t)(TS - 1)) {
-        const int s = uni((int)table[h]);
-        if (s < 0) {
+      const uint32_t hh = hash_of(m);
+      tag = (int)(hh >> 28);
+      for (uint32_t h = hh & (uint32_t)(TS - 1);; h = (h + 1) & (uint32_t)(TS - 1)) {
+        const int e = uni((int)(uint16_t)table[h]);
+        if (e == 0xFFFF) {
           cell = (int)h;
           return -1;
         }
+        if ((e >> 12) != tag) continue;
+        const int s = e & 0xFFF;
         const uint64_t ks = inw ? keys[(size_t)s * W + lane] : 0;
         if (__all(ks == m)) return s;
       }
     };
-    auto new_slot = [&](uint64_t m, int cell) -> int {
+    auto new_slot = [&](uint64_t m, int cell) -> int {  // (right after the find_slot(m) that found `cell` free)
       const int s = nslots++;
       if (s >= SMAX) {
         status = 4;
         return 0;
       }
       if (inw) keys[(size_t)s * W + lane] = m;
-      if (lane == 0) table[cell] = (int16_t)s;
+      if (lane == 0) table[cell] = (int16_t)(uint16_t)(s | (tag << 12));
       return s;
     };
     // ---- the inputs in shuffled order; equal index sets are multiplied at once ----
@@ -594,7 +601,10 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
         }
         __syncthreads();
         GP_T(8);
-        // one neighbour per lane; the words of k12 / output / ref2 / ref3 come from their lanes by readlane
+        // one neighbour per lane.  Per word the result keeps, of the legs the neighbour b does NOT hold,
+        // P = k12 & (output | ref2), and of those it holds Q = output | (k12 & ref3) | (~k12 & ref2):
+        // |k12'| = popcount(b ? Q : P), two masks per push; their words come from their lanes by readlane
+        const uint64_t pmask = k12 & (out | ref2), qmask = out | (k12 & ref3) | (~k12 & ref2);
         const int f12 = (int)wsum(inw ? (uint32_t)__popcll(k12) : 0u);
         uint64_t bestk = KMAX;
         int bests = 0;
@@ -612,9 +622,7 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
             for (int q = 0; q < 16; ++q) {
               if (x0 + q < W) {
                 const int x = x0 + q;
-                const uint64_t ax = rdlane64(k12, x);
-                const uint64_t either = ax | bx[q], two = ax & bx[q], one = either & ~two;
-                c += __popcll((either & rdlane64(out, x)) | (two & rdlane64(ref3, x)) | (one & rdlane64(ref2, x)));
+                c += __popcll((bx[q] & rdlane64(qmask, x)) | (~bx[q] & rdlane64(pmask, x)));
                 fs += __popcll(bx[q]);
               }
             }
@@ -631,8 +639,7 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
         const uint64_t wk = wmin64(bestk);
         const int sbest = uni(__shfl(bests, __ffsll((unsigned long long)__ballot(bestk == wk)) - 1));
         const uint64_t bb = inw ? keys[(size_t)sbest * W + lane] : 0;
-        const uint64_t either = k12 | bb, two = k12 & bb, one = either & ~two;
-        const uint64_t res = (either & out) | (two & ref3) | (one & ref2);
+        const uint64_t res = (bb & qmask) | (~bb & pmask);
         // into the cell (and the arena row) of the candidate popped in this iteration: the queue never
         // holds more than the initial candidates
         if (inw) arena[(size_t)seq * W + lane] = res;
