@@ -258,6 +258,9 @@ int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, int32_t n_ind
 /* device -> host copy of such a buffer */
 int tnco_hip_copy_to_host(void* dst, const void* device_src, uint64_t bytes);
 int tnco_hip_greedy_device_supported(int32_t n_leaves, int32_t n_inds, const int32_t* holders_off);
+/* diagnostics: the 36-bit key of the cost 2^a - 2^b - 2^c by which the device generator orders its
+ * candidates (larger cost <=> larger key; a, b, c <= 2040) */
+uint64_t tnco_hip_greedy_cost_key(int32_t a, int32_t b, int32_t c);
 /* the device memory tnco_hip_greedy_trees_device keeps between calls (one block, re-used) is freed */
 void tnco_hip_greedy_device_release(void);
 /* diagnostics: trees of the last device call that the host version did (-1: the whole batch) */

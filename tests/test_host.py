@@ -259,3 +259,19 @@ def test_dump_results_formats_and_files(tmp_path):
     with pytest.raises(TypeError):
         dump_results(tn, res, nope=1)
     assert res[0] < ContractionResults(cost=Decimal("9"), runtime_s=0, path=[], disconnected_costs=[], disconnected_paths=[])
+
+
+def test_greedy_cost_key_orders_like_the_exact_cost():
+    """csrc/greedy_key.h: the 36-bit key the device generator of the initial trees sorts opt_einsum's
+    candidates by must order 2^a - 2^b - 2^c exactly like the integers do (ties included): every
+    (a, b, c) up to 22, and exponents far apart / at the upper limit."""
+    from tnco_amd import _lib
+    L = _lib.load()
+    def check(triples):
+        vals = sorted(((1 << a) - (1 << b) - (1 << c), L.tnco_hip_greedy_cost_key(a, b, c)) for a, b, c in triples)
+        for (v0, k0), (v1, k1) in zip(vals, vals[1:]):
+            assert (k0 < k1) if v0 < v1 else (k0 == k1), (v0, v1, k0, k1)
+    rng = range(23)
+    check([(a, b, c) for a in rng for b in rng for c in rng])
+    far = [0, 1, 2, 3, 5, 60, 61, 62, 63, 64, 65, 100, 101, 102, 103, 1000, 1001, 2038, 2039, 2040]
+    check([(a, b, c) for a in far for b in far for c in far])

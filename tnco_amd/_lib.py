@@ -51,7 +51,7 @@ EXPORTS = [
     "tnco_hip_best", "tnco_hip_min_cost_device", "tnco_hip_get_trees", "tnco_hip_linear_paths", "tnco_hip_linear_paths_ssa", "tnco_hip_get_counters", "tnco_hip_get_moves", "tnco_hip_get_full_copies",
     "tnco_hip_kernel_time", "tnco_hip_kernel_times", "tnco_hip_get_stage_cycles",
     "tnco_hip_device_bytes", "tnco_hip_set_stream", "tnco_hip_destroy", "tnco_hip_random_trees", "tnco_hip_greedy_trees",
-    "tnco_hip_greedy_trees_device", "tnco_hip_greedy_device_supported", "tnco_hip_greedy_device_redone", "tnco_hip_greedy_device_release", "tnco_hip_copy_to_host",
+    "tnco_hip_greedy_trees_device", "tnco_hip_greedy_device_supported", "tnco_hip_greedy_device_redone", "tnco_hip_greedy_device_release", "tnco_hip_copy_to_host", "tnco_hip_greedy_cost_key",
     "tnco_hip_device_count", "tnco_hip_last_error", "tnco_hip_version",
 ]
 
@@ -113,6 +113,8 @@ def load() -> C.CDLL:
     L.tnco_hip_greedy_trees.argtypes = [i32, i32, vp, vp, vp, i64, vp, vp, vp, i32]
     L.tnco_hip_greedy_trees_device.argtypes = [i32, i32, i32, vp, vp, vp, i64, vp, vp, vp, vp, i32]
     L.tnco_hip_copy_to_host.argtypes = [vp, vp, C.c_uint64]
+    L.tnco_hip_greedy_cost_key.argtypes = [i32, i32, i32]
+    L.tnco_hip_greedy_cost_key.restype = C.c_uint64
     L.tnco_hip_greedy_device_supported.argtypes = [i32, i32, vp]
     L.tnco_hip_greedy_device_release.argtypes = []
     L.tnco_hip_greedy_device_release.restype = None

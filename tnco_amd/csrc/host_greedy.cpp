@@ -11,6 +11,7 @@
 // genrand_uint32, getrandbits; Lib/random.py: _randbelow_with_getrandbits, shuffle) is checked
 // against the interpreter of this image by the test.
 #include "../../include/tnco_hip.h"
+#include "greedy_key.h"
 
 #include <algorithm>
 #include <cstdint>
@@ -496,3 +497,7 @@ extern "C" int tnco_hip_greedy_trees(int32_t n_leaves, int32_t n_inds, const int
     if (!v) return TNCO_HIP_EINVAL;
   return TNCO_HIP_OK;
 }
+
+// the order-preserving key of 2^a - 2^b - 2^c the device generator sorts its candidates by (greedy_key.h),
+// for the test that checks it against exact integers
+extern "C" uint64_t tnco_hip_greedy_cost_key(int32_t a, int32_t b, int32_t c) { return tnco::greedy_cost_key(a, b, c); }
