@@ -65,6 +65,8 @@ def kernel_of(name: str):
     for short in ("fw_move_kernel", "fw_reslice_kernel", "fw_walk_kernel"):
         if short in name:
             return short
+    if "fw_walk2_kernel" in name:  # (the walk from both ends of the post-order: the default walk kernel)
+        return "fw_walk_kernel"
     return None
 
 
