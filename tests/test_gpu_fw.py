@@ -51,8 +51,14 @@ def _check(core, orc, prob, seeds, betas, max_width, chunks, every=10, links=Non
     return gpu
 
 
+@pytest.mark.parametrize("delta", [True, False])
 @pytest.mark.parametrize("n,frac", [(24, 0.5), (48, 0.6), (64, 0.4)])
-def test_fw_regular(core, oracle_lib, n, frac):
+def test_fw_regular(core, oracle_lib, monkeypatch, n, frac, delta):
+    """Both forms of the re-slice's cache rebuild: the re-pricing of the old costs (fw_delta_kernel: uniform
+    power-of-two dims, the default here) and the full rebuild from the legs (TNCO_HIP_FW_NO_DELTA=1; what
+    hyper-indices, per-index dims, sparse legs and float32 costs always get)."""
+    if not delta:
+        monkeypatch.setenv("TNCO_HIP_FW_NO_DELTA", "1")
     prob = H.regular_problem(n, graph_seed=n + 1)
     seeds = H.replica_seeds(24, S=n)
     w0 = _initial_max_width(prob, prob.tree(seeds[0]))

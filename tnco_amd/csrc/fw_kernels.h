@@ -173,13 +173,18 @@ __device__ __forceinline__ void fw_shuffle_lds(RNG& rng, lds_vi32* a, int n, boo
 
 typedef TNCO_LDS volatile uint16_t lds_vu16;
 
-// One internal node of the post-order list: node | left << 21 | right << 42.
-__device__ __forceinline__ uint64_t fw_rec(int node, int l, int rr) {
-  return (uint64_t)(uint32_t)node | ((uint64_t)(uint32_t)l << 21) | ((uint64_t)(uint32_t)rr << 42);
+// One internal node of the post-order list: node | left << 16 | right << 32 | e << 48 (finite width: at
+// most 65 535 nodes).  e = the exponent field of the node's cached contraction cost (the walk kernels
+// read it with the links: fw_delta_kernel re-prices the node from it), 0 where nobody recorded it.
+__device__ __forceinline__ uint64_t fw_rec(int node, int l, int rr, int e = 0) {
+  return (uint64_t)(uint32_t)node | ((uint64_t)(uint32_t)l << 16) | ((uint64_t)(uint32_t)rr << 32) | ((uint64_t)(uint32_t)e << 48);
 }
-__device__ __forceinline__ int fw_rec_node(uint64_t x) { return (int)(x & 0x1FFFFFu); }
-__device__ __forceinline__ int fw_rec_left(uint64_t x) { return (int)((x >> 21) & 0x1FFFFFu); }
-__device__ __forceinline__ int fw_rec_right(uint64_t x) { return (int)(x >> 42); }
+__device__ __forceinline__ int fw_rec_node(uint64_t x) { return (int)(x & 0xFFFFu); }
+__device__ __forceinline__ int fw_rec_left(uint64_t x) { return (int)((x >> 16) & 0xFFFFu); }
+__device__ __forceinline__ int fw_rec_right(uint64_t x) { return (int)((x >> 32) & 0xFFFFu); }
+__device__ __forceinline__ int fw_rec_exp(uint64_t x) { return (int)(x >> 48); }
+// the exponent field of a double
+__device__ __forceinline__ int fw_exp_field(double c) { return (int)((__double_as_longlong(c) >> 52) & 0x7FF); }
 
 // LDS of one replica for the traversal: `cap` stack entries (int32) + their left children (uint16)
 struct FwStack {
@@ -1011,14 +1016,14 @@ static __global__ __launch_bounds__(256) void fw_walk_kernel(const Params P, con
 // walker whose stack outgrows its LDS entries stops for good (the forward walker finishes alone).
 // Not for trees with too-wide LEAVES (F.leaf_wide: their place in the list is the forward walker's
 // business): the host launches fw_walk_kernel for those.
-constexpr int FW_WALK2_CAPB = 40;
+constexpr int FW_WALK2_CAPB = 32;
 static __global__ __launch_bounds__(256) void fw_walk2_kernel(const Params P, const FwParams F) {
   constexpr int NT = 128;  // replicas per block: the stride of the LDS arrays
   __shared__ int32_t se[FW_WALK_CAP * NT];
-  __shared__ uint16_t sl[FW_WALK_CAP * NT];
+  __shared__ uint32_t sl[FW_WALK_CAP * NT];    // left child | exponent field of the cached cost << 16
   __shared__ uint16_t sb[FW_WALK2_CAPB * NT];  // backward walker: left children waiting
   __shared__ uint32_t rbuf[2 * 16 * NT];       // 8 records per walker
-  __shared__ int32_t wbuf[2 * 8 * NT];         // 8 too-wide tensors per walker
+  // (the too-wide tensors go to their list one by one: a handful per replica)
   const int tid = threadIdx.x;
   const bool fwd = (tid & 32) == 0;
   const int slot = (tid >> 6) * 32 + (tid & 31);
@@ -1043,23 +1048,14 @@ static __global__ __launch_bounds__(256) void fw_walk2_kernel(const Params P, co
   volatile int32_t* gstk = sc.gstk;
   const int wcap = sc.wcap;
   TNCO_LDS volatile int32_t* e_ = (TNCO_LDS volatile int32_t*)se + slot;
-  TNCO_LDS volatile uint16_t* l_ = (TNCO_LDS volatile uint16_t*)sl + slot;
+  TNCO_LDS volatile uint32_t* l_ = (TNCO_LDS volatile uint32_t*)sl + slot;
   TNCO_LDS volatile uint16_t* b_ = (TNCO_LDS volatile uint16_t*)sb + slot;
   TNCO_LDS volatile uint32_t* rb = (TNCO_LDS volatile uint32_t*)rbuf + (fwd ? 0 : 16 * NT) + slot;
-  TNCO_LDS volatile int32_t* wb = (TNCO_LDS volatile int32_t*)wbuf + (fwd ? 0 : 8 * NT) + slot;
   const int gh = (N + 1) / 2;
   int cnt = 0, nw = 0;  // nodes / too-wide tensors this walker has listed
   // ---- forward walker (as fw_walk_kernel) ----
   int sp = 0, x = N - 1;
-  auto f_put_wide = [&](int t) {
-    wb[(nw & 7) * NT] = t;
-    ++nw;
-    if ((nw & 7) == 0) {
-      int4* d = reinterpret_cast<int4*>(wlist + nw - 8);
-      d[0] = make_int4(wb[0], wb[NT], wb[2 * NT], wb[3 * NT]);
-      d[1] = make_int4(wb[4 * NT], wb[5 * NT], wb[6 * NT], wb[7 * NT]);
-    }
-  };
+  auto f_put_wide = [&](int t) { wlist[nw++] = t; };
   auto f_put_rec = [&](uint64_t v) {
     rb[(2 * (cnt & 7)) * NT] = (uint32_t)v;
     rb[(2 * (cnt & 7) + 1) * NT] = (uint32_t)(v >> 32);
@@ -1090,23 +1086,14 @@ static __global__ __launch_bounds__(256) void fw_walk2_kernel(const Params P, co
     }
     if (!may) return 0;
     --sp;
-    f_put_rec(fw_rec(node, l, rr));
+    f_put_rec(fw_rec(node, l & 0xFFFF, rr, (int)((uint32_t)l >> 16)));
     if ((e >> 27) & 1) f_put_wide(node);
     return 1;
   };
   // ---- backward walker ----
   int bx = N - 1, bsp = 0;
   bool balive = true;  // (false: stack overflow, this walker has stopped)
-  auto b_put_wide = [&](int t) {  // the k-th goes to wlist[wcap - 1 - k]
-    const int pos = wcap - 1 - nw;
-    wb[(pos & 7) * NT] = t;
-    ++nw;
-    if ((pos & 7) == 0) {
-      int4* d = reinterpret_cast<int4*>(wlist + pos);
-      d[0] = make_int4(wb[0], wb[NT], wb[2 * NT], wb[3 * NT]);
-      d[1] = make_int4(wb[4 * NT], wb[5 * NT], wb[6 * NT], wb[7 * NT]);
-    }
-  };
+  auto b_put_wide = [&](int t) { wlist[wcap - 1 - (nw++)] = t; };  // the k-th goes to wlist[wcap - 1 - k]
   auto b_put_rec = [&](uint64_t v) {  // the k-th goes to rec[ni_all - 1 - k]
     const int pos = ni_all - 1 - cnt;
     rb[(2 * (pos & 7)) * NT] = (uint32_t)v;
@@ -1139,16 +1126,18 @@ static __global__ __launch_bounds__(256) void fw_walk2_kernel(const Params P, co
       if (x < 0 && sp > 0) may -= f_up(may > 0);
       if (x >= n) {  // down: the only read of this node's header (links + cached width, one line)
         const int4 h = *reinterpret_cast<const int4*>(blk + (int64_t)(x - n) * P.BS);
+        const int ce = fw_exp_field(*reinterpret_cast<const double*>(blk + (int64_t)(x - n) * P.BS + 16));  // (same sector)
         const double w = F.width_f32 ? (double)__int_as_float(h.w) : w64[x];
         const bool wide = w > F.max_width;
         ++sp;
         const int e = x | (h.y << 13) | (wide ? (1 << 27) : 0);
+        const uint32_t le = (uint32_t)h.x | ((uint32_t)ce << 16);
         if (sp <= FW_WALK_CAP) {
           e_[(sp - 1) * NT] = e;
-          l_[(sp - 1) * NT] = (uint16_t)h.x;
+          l_[(sp - 1) * NT] = le;
         } else {
           gstk[sp - 1 - FW_WALK_CAP] = e;
-          gstk[gh + sp - 1 - FW_WALK_CAP] = h.x;
+          gstk[gh + sp - 1 - FW_WALK_CAP] = (int32_t)le;
         }
         x = h.x;
         if (x < n) x = -1;
@@ -1156,8 +1145,9 @@ static __global__ __launch_bounds__(256) void fw_walk2_kernel(const Params P, co
       if (x < 0 && sp > 0) may -= f_up(may > 0);
     } else if (balive && left >= 2 && bx >= n) {
       const int4 h = *reinterpret_cast<const int4*>(blk + (int64_t)(bx - n) * P.BS);
+      const int ce = fw_exp_field(*reinterpret_cast<const double*>(blk + (int64_t)(bx - n) * P.BS + 16));
       const double w = F.width_f32 ? (double)__int_as_float(h.w) : w64[bx];
-      b_put_rec(fw_rec(bx, h.x, h.y));
+      b_put_rec(fw_rec(bx, h.x, h.y, ce));
       if (w > F.max_width) b_put_wide(bx);
       const bool li = h.x >= n, ri = h.y >= n;
       if (ri) {
@@ -1179,16 +1169,12 @@ static __global__ __launch_bounds__(256) void fw_walk2_kernel(const Params P, co
   if (fwd) {
     for (int k = cnt & ~7; k < cnt; ++k)
       rec[k] = (uint64_t)rb[(2 * (k & 7)) * NT] | ((uint64_t)rb[(2 * (k & 7) + 1) * NT] << 32);
-    for (int k = nw & ~7; k < nw; ++k) wlist[k] = wb[(k & 7) * NT];
   } else {
     // records [ni_all - cnt, ni_all): pieces went out when the walker reached their first record; the
     // piece cut by the lowest record is left
     const int lo = ni_all - cnt;
     for (int k = lo; k < ni_all && (k & ~7) < lo; ++k)
       rec[k] = (uint64_t)rb[(2 * (k & 7)) * NT] | ((uint64_t)rb[(2 * (k & 7) + 1) * NT] << 32);
-    const int wlo = wcap - nw;
-    for (int k = wlo; k < wcap; ++k)
-      if ((k & ~7) < wlo) wlist[k] = wb[(k & 7) * NT];
   }
   const int onw = __shfl_xor(nw, 32);
   if (fwd) {
@@ -1698,6 +1684,300 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_WAVES) void fw_reslice_kernel(
   if (lane0) {
     FW_PROF_OUT(rs);
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The re-slice as three kernels when the costs are powers of two (uniform dims 2^k, no sparse legs, no
+// hyper-indices, float64): get_slices (phase A, four lanes per replica as before) | the cache rebuild
+// as a RE-PRICING of the old costs, one lane per replica (fw_delta_kernel) | the end of the sweep (phase
+// B, which also does the full rebuild of the few replicas the re-pricing has left).
+//
+// Why: from the reference's greedy starts four fifths of a re-slice were the rebuild -- the legs of
+// all n - 1 nodes re-derived (16 words each) only to count |legs(left) | legs(right) | slices| again,
+// although the new slices S' differ from the old S in a handful of indices.  A node's contraction cost
+// is 2^(k |u | S|), u = legs(left) | legs(right), and |u | S'| - |u | S| = sum over the changed
+// indices d of (+1 if d joined, -1 if d left) * [d not in u].  An index held by two tensors is a leg
+// of a subtree exactly when the subtree holds ONE of them, so per subtree a count vector suffices
+// (two bits per changed index: holders inside), added up the post-order like the partial sums.  The
+// walk kernels record the exponent field of every node's old cost next to its links (the same 32-byte
+// header): the new cost is that exponent moved, a double built from bits -- exact, like the power of
+// two the full rebuild computes.  No leg masks, no leaf table, no reductions: a stack machine of
+// scalars, 64 replicas per wavefront; the total first, and only if it improves a second pass that
+// writes (cost, partial sum) straight into the node headers (no scratch list, no scatter pass).
+// ---------------------------------------------------------------------------------------------
+constexpr int FWD_MAXD = 32;   // changed indices per re-slice handled here (more: the full rebuild)
+#ifdef TNCO_FW_DELTA_STATS  // (diagnostic build: how many indices change, why replicas take the full rebuild)
+__device__ unsigned long long g_fwd_stats[80];
+#define FWD_STAT(i) atomicAdd(&g_fwd_stats[i], 1ull)
+#else
+#define FWD_STAT(i)
+#endif
+constexpr int FWD_STK = 24;    // stack entries in LDS per replica (deeper: global scratch)
+constexpr int FWD_BITW = 32;   // words of the per-replica leaf bitmap: <= 1024 tensors
+#ifndef TNCO_FWD_LANES
+#define TNCO_FWD_LANES 32
+#endif
+constexpr int FWD_LANES = TNCO_FWD_LANES;  // replicas (busy lanes) per wavefront of fw_delta_kernel
+
+template <int LOG2L, int K, bool HYPER>
+__global__ __launch_bounds__(256, TNCO_FW_RESLICE_WAVES) void fw_reslice_a_kernel(const Params P, const FwParams F, const int prewalked) {
+  constexpr int L = 1 << LOG2L;
+  constexpr int GPB = 256 >> LOG2L;
+  constexpr int LK = L * K;
+  using M = Mask<K>;
+  using R = Rng<LOG2L, 64>;
+  __shared__ uint32_t rngbuf[GPB * R::RING];
+  __shared__ __attribute__((aligned(8))) int32_t posbuf[GPB * FW_LDSPOS];
+  const int tid = threadIdx.x;
+  const int lig = tid & (L - 1);
+  const int gib = tid >> LOG2L;
+  const int gbase = (tid & 63) & ~(L - 1);
+  const int64_t r = (int64_t)blockIdx.x * GPB + gib;
+  if (r >= P.R) return;
+  lds_vi32* lpos = (lds_vi32*)posbuf + gib * FW_LDSPOS;
+  const FwStack st{nullptr, nullptr, 0};
+  const bool lane0 = lig == 0;
+  const int n = P.n, N = P.N;
+  View<LOG2L, K, HYPER> v;
+  v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n * LPS, lig);
+  ReplicaState* rs = P.rs + r;
+  FwScratch sc(F, r, N);
+  if (prewalked == 2) sc.nwf = F.nwfront[r];
+  double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
+  const uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
+  M slices;
+#pragma unroll
+  for (int k = 0; k < K; ++k) slices.w[k] = sl[v.widx(k)];
+  if (!gany<LOG2L>(mnonzero<K>(slices))) return;  // greedy/optimizer.hpp:359
+  R rng;
+  rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
+  const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, sc, st, lpos, lane0, gbase, F.status + r, nullptr, nullptr,
+                                              prewalked ? F.nwide[r] : -1);
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last reads of the position scratch)
+  // the proposed slices travel in the candidate-position scratch, free now
+  uint64_t* prop = reinterpret_cast<uint64_t*>(const_cast<int16_t*>(sc.pos));
+#pragma unroll
+  for (int k = 0; k < K; ++k) prop[v.widx(k)] = ns.w[k];
+  int mti, mtw;
+  rng.finish(mti, mtw);
+  if (lane0) {
+    rs->mti = mti;
+    rs->mtw = mtw;
+  }
+}
+
+static __global__ __launch_bounds__(64) void fw_delta_kernel(const Params P, const FwParams F) {
+  // FWD_LANES busy lanes per wavefront: the work of a replica is a chain (LDS stack, record loads), so
+  // more, emptier wavefronts hide more of its latency (as in fw_walk_kernel)
+  constexpr int NL = FWD_LANES;
+  __shared__ double sstk[FWD_STK * NL];
+  __shared__ uint64_t scv[FWD_STK * NL];
+  __shared__ uint32_t sbm[FWD_BITW * NL];
+  __shared__ uint16_t sh[2 * FWD_MAXD * NL];
+  const int lane = threadIdx.x;
+  if (lane >= NL) return;
+  const int64_t r = (int64_t)blockIdx.x * NL + lane;
+  if (r >= P.R) return;
+  const int n = P.n, N = P.N, LK = F.I64 / 64, ni = N - n;
+  F.fastflag[r] = 0;
+  const FwScratch sc(F, r, N);
+  uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
+  const uint64_t* prop = reinterpret_cast<const uint64_t*>(const_cast<const int16_t*>(sc.pos));
+  {
+    uint64_t any = 0;
+    for (int w = 0; w < P.W; ++w) any |= sl[w];
+    if (!any) return;  // (nothing was proposed)
+  }
+  TNCO_LDS volatile double* stk = (TNCO_LDS volatile double*)sstk + lane;
+  TNCO_LDS volatile uint64_t* cvs = (TNCO_LDS volatile uint64_t*)scv + lane;
+  TNCO_LDS volatile uint32_t* bm = (TNCO_LDS volatile uint32_t*)sbm + lane;
+  TNCO_LDS volatile uint16_t* hl = (TNCO_LDS volatile uint16_t*)sh + lane;
+  // the changed indices, their holders, which way they changed
+  for (int w = 0; w < FWD_BITW; ++w) bm[w * NL] = 0;
+  int nd = 0, base = 0;
+  uint64_t plus = 0, minus = 0;
+  bool slow = false;
+  for (int w = 0; w < P.W && !slow; ++w) {
+    const uint64_t o = sl[w], q = prop[w];
+    uint64_t ch = o ^ q;
+    while (ch) {
+      const int bit = __ffsll((unsigned long long)ch) - 1;
+      ch &= ch - 1;
+      const int d = w * 64 + bit;
+      const int t1 = F.holder2[2 * d], t2 = F.holder2[2 * d + 1];
+      if (nd >= FWD_MAXD || t1 < 0) {
+        slow = true;
+        FWD_STAT(t1 < 0 ? 70 : 71);
+        break;
+      }
+      hl[(2 * nd) * NL] = (uint16_t)t1;
+      hl[(2 * nd + 1) * NL] = (uint16_t)(t2 < 0 ? 0xFFFF : t2);
+      bm[(t1 >> 5) * NL] |= 1u << (t1 & 31);
+      if (t2 >= 0) bm[(t2 >> 5) * NL] |= 1u << (t2 & 31);
+      if ((q >> bit) & 1ull) {
+        plus |= 1ull << (2 * nd);
+        base += 1;
+      } else {
+        minus |= 1ull << (2 * nd);
+        base -= 1;
+      }
+      ++nd;
+    }
+  }
+  if (slow) return;  // (phase B rebuilds this replica in full)
+  FWD_STAT(nd < 40 ? nd : 40);
+  if (nd == 0) {     // the slices it has: nothing can improve
+    F.fastflag[r] = 1;
+    return;
+  }
+  // holders of changed indices inside a leaf: two bits per index
+  auto leafcv = [&](int t) -> uint64_t {
+    if (!((bm[(t >> 5) * NL] >> (t & 31)) & 1u)) return 0ull;
+    uint64_t cv = 0;
+    for (int k = 0; k < nd; ++k)
+      if (hl[(2 * k) * NL] == t || hl[(2 * k + 1) * NL] == t) cv += 1ull << (2 * k);
+    return cv;
+  };
+  const uint8_t* blk = P.blocks + r * (int64_t)(n - 1) * P.BS;
+  const int log2d = P.log2d;
+  bool bad = false;
+  const uint4* rec4 = reinterpret_cast<const uint4*>(sc.rec);  // (64-byte aligned; 8 records per 64 bytes)
+  // ONE pass: the new (cost, partial sum) of every node go to the sequential scratch list (whole lines);
+  // only a replica whose total improves scatters them into its node headers afterwards.  (Recomputing
+  // in a second, storing pass cost as much as the first for EVERY wavefront: one improving replica
+  // among its lanes is enough.)  Straight-line code with selects -- the lanes of a wavefront are at
+  // different (left internal?, right internal?) cases at every node.
+  double part = 0.0;
+  uint64_t cvp = 0;
+  int sp = 0;
+  {
+    uint4 nb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) nb[q] = rec4[q];
+    for (int j0 = 0; j0 < ni; j0 += 8) {
+      uint64_t rc[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        rc[2 * q] = (uint64_t)nb[q].x | ((uint64_t)nb[q].y << 32);
+        rc[2 * q + 1] = (uint64_t)nb[q].z | ((uint64_t)nb[q].w << 32);
+      }
+      const int jn = j0 + 8 < ni ? j0 + 8 : j0;  // (past the end: the same piece again)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) nb[q] = rec4[(jn >> 1) + q];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (j0 + i < ni) {
+          const uint64_t cur = rc[i];
+          const int l = fw_rec_left(cur), rr = fw_rec_right(cur), e = fw_rec_exp(cur);
+          const bool li = l >= n, ri = rr >= n, both = li && ri, none = !li && !ri;
+          // the entry below the newest finished subtree (read whether needed or not)
+          const int k2 = sp - 2 < 0 ? 0 : sp - 2;
+          double top;
+          uint64_t topcv;
+          if (k2 < FWD_STK) {
+            top = stk[k2 * NL];
+            topcv = cvs[k2 * NL];
+          } else {
+            top = sc.pstk[k2];
+            topcv = reinterpret_cast<const uint64_t*>(sc.gstk)[k2];
+          }
+          if (none && sp >= 1) {  // a new subtree starts: the finished one waits on the stack
+            const int k1 = sp - 1;
+            if (k1 < FWD_STK) {
+              stk[k1 * NL] = part;
+              cvs[k1 * NL] = cvp;
+            } else {
+              sc.pstk[k1] = part;
+              reinterpret_cast<uint64_t*>(sc.gstk)[k1] = cvp;
+            }
+          }
+          const uint64_t lcl = li ? 0ull : leafcv(l), lcr = ri ? 0ull : leafcv(rr);
+          const double pl = both ? top : (li ? part : 0.0);
+          const double pr = ri ? part : 0.0;
+          const uint64_t cvl = both ? topcv : (li ? cvp : lcl);
+          const uint64_t cvr = ri ? cvp : lcr;
+          // a changed index is among the legs of a child that holds exactly one of its tensors
+          const uint64_t in_u = ((cvl & ~(cvl >> 1)) | (cvr & ~(cvr >> 1))) & 0x5555555555555555ull;
+          const int ne = e + log2d * (base - __popcll(in_u & plus) + __popcll(in_u & minus));
+          bad = bad || e <= 0 || e >= 2047 || ne <= 0 || ne >= 2047;
+          const double c = __longlong_as_double((long long)((uint64_t)(uint32_t)ne << 52));
+          part = (c + pl) + pr;  // (the association order of finite_width/utils.hpp:36-47)
+          cvp = cvl + cvr;
+          sc.cp[j0 + i] = make_double2(c, part);
+          sp += both ? -1 : (none ? 1 : 0);
+        }
+      }
+    }
+  }
+  if (bad) {
+    FWD_STAT(72);
+    return;  // (a cost outside the powers of two of a double: the full rebuild decides)
+  }
+  const double cur = reinterpret_cast<const NodeRec*>(blk + (int64_t)(N - 1 - n) * P.BS)->partial;
+  if (part < cur) {  // greedy/optimizer.hpp:371-374
+#ifndef TNCO_FWD_NO_STORE  // (measurement builds only)
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int j0 = 0; j0 < ni; j0 += 4) {
+      uint64_t x[4];
+      double2 c[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = j0 + i < ni ? j0 + i : ni - 1;
+        x[i] = sc.rec[j];
+        c[i] = sc.cp[j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (j0 + i < ni)
+          *reinterpret_cast<double2*>(const_cast<uint8_t*>(blk) + (int64_t)(fw_rec_node(x[i]) - n) * P.BS + 16) = c[i];
+    }
+#endif
+    for (int w = 0; w < LK; ++w) sl[w] = prop[w];
+  }
+  F.fastflag[r] = 1;
+}
+
+template <int LOG2L, int K, bool HYPER>
+__global__ __launch_bounds__(256, TNCO_FW_RESLICE_WAVES) void fw_reslice_b_kernel(const Params P, const FwParams F) {
+  constexpr int L = 1 << LOG2L;
+  constexpr int GPB = 256 >> LOG2L;
+  constexpr int LK = L * K;
+  using M = Mask<K>;
+  __shared__ __attribute__((aligned(8))) int32_t posbuf[GPB * FW_LDSPOS];
+  const int tid = threadIdx.x;
+  const int lig = tid & (L - 1);
+  const int gib = tid >> LOG2L;
+  const int gbase = (tid & 63) & ~(L - 1);
+  const int64_t r = (int64_t)blockIdx.x * GPB + gib;
+  if (r >= P.R) return;
+  lds_vi32* lpos = (lds_vi32*)posbuf + gib * FW_LDSPOS;
+  const bool lane0 = lig == 0;
+  const int n = P.n, N = P.N;
+  View<LOG2L, K, HYPER> v;
+  v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n * LPS, lig);
+  ReplicaState* rs = P.rs + r;
+  const FwScratch sc(F, r, N);
+  uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
+  M slices;
+#pragma unroll
+  for (int k = 0; k < K; ++k) slices.w[k] = sl[v.widx(k)];
+  if (F.fastflag[r] == 0 && gany<LOG2L>(mnonzero<K>(slices))) {  // (not re-priced: rebuilt in full)
+    const uint64_t* prop = reinterpret_cast<const uint64_t*>(const_cast<const int16_t*>(sc.pos));
+    M ns;
+#pragma unroll
+    for (int k = 0; k < K; ++k) ns.w[k] = prop[v.widx(k)];
+    double sum;
+    constexpr int PCAP = 16, MCAP = (FW_LDSPOS / 2 - PCAP) / LK;
+    const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, sc.rec, ns, sc.cp, sc.pstk, lane0, gbase, &sum,
+                                                   (lds_vdouble*)lpos, PCAP, (lds_vu64*)lpos + PCAP, MCAP);
+    if (tot < v.hdr(N - 1)->partial) {
+      slices = ns;
+      fw_commit<LOG2L, K, HYPER>(P, v, sc.rec, sc.cp);
+#pragma unroll
+      for (int k = 0; k < K; ++k) sl[v.widx(k)] = slices.w[k];
+    }
+  }
+  fw_sweep_tail<LOG2L, K, HYPER>(P, v, rs, r, sl, slices, lane0);
 }
 
 // is_valid of the finite-width optimizer, the part on top of the infinite-memory checks

@@ -25,6 +25,10 @@ struct FwParams {
   double* width64;          // [R][N] widths of the internal nodes when width_type is float64
   int32_t* nwide;           // [R] fw_walk_kernel -> fw_reslice_kernel: too-wide tensors listed (-1: no slices, nothing to do)
   int32_t* nwfront;         // [R] ... how many of them at the front of the list (fw_walk2_kernel: the rest at its end)
+  // the re-slice re-priced from the OLD costs (fw_delta_kernel): usable when fast_ok
+  int32_t fast_ok;          // uniform power-of-two dims, float64 cost, no sparse legs, no hyper-indices, <= 1024 tensors
+  const int32_t* holder2;   // [I64][2] the (one or two) tensors holding an index, -1: none / index not supported
+  int32_t* fastflag;        // [R] 1: fw_delta_kernel has done this replica's rebuild (+ commit)
   int32_t* status;          // [R] runtime problems (1: candidate legs beyond the scratch; cannot happen
                             //     since the scratch holds every index)
 };

@@ -113,6 +113,26 @@ template <int LOG2L, int K>
 void launch_fw_reslice_lk(tnco_hip_ctx* h, int prewalked) {
   const int gpb = 256 >> LOG2L;
   dim3 grid((unsigned)((h->P.R + gpb - 1) / gpb));
+#ifndef TNCO_PROFILE
+  if (h->F.fast_ok && prewalked == 2 && !h->hyper) {  // get_slices | re-pricing of the old costs | end of the sweep
+    hipLaunchKernelGGL((fw_reslice_a_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, prewalked);
+    hipLaunchKernelGGL(fw_delta_kernel, dim3((unsigned)((h->P.R + FWD_LANES - 1) / FWD_LANES)), dim3(64), 0, h->stream, h->P, h->F);
+    hipLaunchKernelGGL((fw_reslice_b_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F);
+#ifdef TNCO_FW_DELTA_STATS  // (diagnostic build: the counters of this translation unit, every 40 re-slices)
+    static int calls = 0;
+    if (++calls % 40 == 0) {
+      unsigned long long st[80];
+      (void)hipStreamSynchronize(h->stream);
+      if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_fwd_stats), sizeof(st)) == hipSuccess) {
+        std::fprintf(stderr, "fw_delta after %d re-slices: changed indices:", calls);
+        for (int i = 0; i <= 40; ++i) std::fprintf(stderr, " %d:%llu", i, st[i]);
+        std::fprintf(stderr, " | full rebuild: unsupported index %llu, > %d changed %llu, cost not 2^k %llu\n", st[70], FWD_MAXD, st[71], st[72]);
+      }
+    }
+#endif
+    return;
+  }
+#endif
   if (h->hyper)
     hipLaunchKernelGGL((fw_reslice_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, h->F, prewalked);
   else

@@ -742,6 +742,29 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       if (!std::getenv("TNCO_HIP_FW_ONE_ENDED_WALK")) HIP_TRY(h->alloc(&F.nwfront, R));  // (test knob: fw_walk_kernel)
     }
     HIP_TRY(hipMemset(F.status, 0, (size_t)R * 4));
+    // the re-slice by re-pricing (fw_delta_kernel): costs must be powers of two and a leg of a subtree
+    // decidable from the holders it contains
+    if (F.nwfront != nullptr && P.cost_mode == 0 && !P.f32 && d->sparse_mask == nullptr && !h->hyper && n <= 32 * FWD_BITW &&
+        !std::getenv("TNCO_HIP_FW_NO_DELTA")) {
+      std::vector<int32_t> hold((size_t)F.I64 * 2, -1);
+      std::vector<int32_t> cnt((size_t)I, 0);
+      for (int t = 0; t < n; ++t)
+        for (int i = 0; i < I; ++i)
+          if ((d->leaf_masks[(size_t)t * W + (i >> 6)] >> (i & 63)) & 1ull) {
+            if (cnt[i] < 2) hold[(size_t)2 * i + cnt[i]] = t;
+            cnt[i] += 1;
+          }
+      for (int i = 0; i < I; ++i) {
+        const bool is_out = d->output_mask && ((d->output_mask[i >> 6] >> (i & 63)) & 1ull);
+        if (cnt[i] == 0 || cnt[i] > 2 || (cnt[i] == 2 && is_out)) hold[(size_t)2 * i] = hold[(size_t)2 * i + 1] = -1;
+      }
+      int32_t* dh;
+      HIP_TRY(h->alloc(&dh, (int64_t)hold.size()));
+      HIP_TRY(hipMemcpy(dh, hold.data(), hold.size() * 4, hipMemcpyHostToDevice));
+      F.holder2 = dh;
+      HIP_TRY(h->alloc(&F.fastflag, R));
+      F.fast_ok = 1;
+    }
     F.stack_cap = FW_LDSPOS;
     if (const char* e = std::getenv("TNCO_HIP_FW_STACK")) F.stack_cap = std::max(0, std::min(FW_LDSPOS, std::atoi(e)));
     auto upload_mask = [&](const uint64_t* src, const uint64_t** dst) -> int {
