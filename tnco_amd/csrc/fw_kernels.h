@@ -1705,7 +1705,8 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_WAVES) void fw_reslice_kernel(
 // scalars, 64 replicas per wavefront; the total first, and only if it improves a second pass that
 // writes (cost, partial sum) straight into the node headers (no scratch list, no scatter pass).
 // ---------------------------------------------------------------------------------------------
-constexpr int FWD_MAXD = 32;   // changed indices per re-slice handled here (more: the full rebuild)
+constexpr int FWD_MAXD = 64;   // changed indices per re-slice handled here (more: the full rebuild); beyond 32 a
+                               // second count-vector word joins in (early in a schedule, one re-slice in 2 000)
 #ifdef TNCO_FW_DELTA_STATS  // (diagnostic build: how many indices change, why replicas take the full rebuild)
 __device__ unsigned long long g_fwd_stats[80];
 #define FWD_STAT(i) atomicAdd(&g_fwd_stats[i], 1ull)
@@ -1773,7 +1774,7 @@ static __global__ __launch_bounds__(64) void fw_delta_kernel(const Params P, con
   __shared__ double sstk[FWD_STK * NL];
   __shared__ uint64_t scv[FWD_STK * NL];
   __shared__ uint32_t sbm[FWD_BITW * NL];
-  __shared__ uint16_t sh[2 * FWD_MAXD * NL];
+  __shared__ uint16_t sh[2 * 32 * NL];  // holders of the first 32 changed indices (the others: memory)
   const int lane = threadIdx.x;
   if (lane >= NL) return;
   const int64_t r = (int64_t)blockIdx.x * NL + lane;
@@ -1792,10 +1793,13 @@ static __global__ __launch_bounds__(64) void fw_delta_kernel(const Params P, con
   TNCO_LDS volatile uint64_t* cvs = (TNCO_LDS volatile uint64_t*)scv + lane;
   TNCO_LDS volatile uint32_t* bm = (TNCO_LDS volatile uint32_t*)sbm + lane;
   TNCO_LDS volatile uint16_t* hl = (TNCO_LDS volatile uint16_t*)sh + lane;
+  // (rarely touched: in memory -- 20 KB of LDS per 32 replicas keep all 65 536 of a launch resident)
+  volatile uint16_t* hl2 = reinterpret_cast<volatile uint16_t*>(F.delta_scr + r * 64);  // holders of the indices 32..63
+  volatile uint64_t* cvs2 = F.delta_scr + r * 64 + 32;                                  // second words of the stack
   // the changed indices, their holders, which way they changed
   for (int w = 0; w < FWD_BITW; ++w) bm[w * NL] = 0;
   int nd = 0, base = 0;
-  uint64_t plus = 0, minus = 0;
+  uint64_t plus = 0, minus = 0, plus2 = 0, minus2 = 0;
   bool slow = false;
   for (int w = 0; w < P.W && !slow; ++w) {
     const uint64_t o = sl[w], q = prop[w];
@@ -1810,15 +1814,22 @@ static __global__ __launch_bounds__(64) void fw_delta_kernel(const Params P, con
         FWD_STAT(t1 < 0 ? 70 : 71);
         break;
       }
-      hl[(2 * nd) * NL] = (uint16_t)t1;
-      hl[(2 * nd + 1) * NL] = (uint16_t)(t2 < 0 ? 0xFFFF : t2);
+      const uint16_t u1 = (uint16_t)t1, u2 = (uint16_t)(t2 < 0 ? 0xFFFF : t2);
+      if (nd < 32) {
+        hl[(2 * nd) * NL] = u1;
+        hl[(2 * nd + 1) * NL] = u2;
+      } else {
+        hl2[2 * (nd - 32)] = u1;
+        hl2[2 * (nd - 32) + 1] = u2;
+      }
       bm[(t1 >> 5) * NL] |= 1u << (t1 & 31);
       if (t2 >= 0) bm[(t2 >> 5) * NL] |= 1u << (t2 & 31);
+      const uint64_t fld = 1ull << (2 * (nd & 31));
       if ((q >> bit) & 1ull) {
-        plus |= 1ull << (2 * nd);
+        if (nd < 32) plus |= fld; else plus2 |= fld;
         base += 1;
       } else {
-        minus |= 1ull << (2 * nd);
+        if (nd < 32) minus |= fld; else minus2 |= fld;
         base -= 1;
       }
       ++nd;
@@ -1826,16 +1837,20 @@ static __global__ __launch_bounds__(64) void fw_delta_kernel(const Params P, con
   }
   if (slow) return;  // (phase B rebuilds this replica in full)
   FWD_STAT(nd < 40 ? nd : 40);
-  if (nd == 0) {     // the slices it has: nothing can improve
-    F.fastflag[r] = 1;
-    return;
-  }
+  // (nd == 0, the slices the replica has: the rebuild still runs -- its partial sums are those of
+  //  finite_width/utils.hpp:36-47, (cost + left) + right at every node, which the moves' incremental
+  //  updates do not always reproduce to the last bit: the reference compares and may commit)
   // holders of changed indices inside a leaf: two bits per index
-  auto leafcv = [&](int t) -> uint64_t {
+  const bool wide = nd > 32;
+  auto leafcv = [&](int t, uint64_t& hi) -> uint64_t {
+    hi = 0;
     if (!((bm[(t >> 5) * NL] >> (t & 31)) & 1u)) return 0ull;
     uint64_t cv = 0;
-    for (int k = 0; k < nd; ++k)
+    const int n1 = nd < 32 ? nd : 32;
+    for (int k = 0; k < n1; ++k)
       if (hl[(2 * k) * NL] == t || hl[(2 * k + 1) * NL] == t) cv += 1ull << (2 * k);
+    for (int k = 32; k < nd; ++k)
+      if (hl2[2 * (k - 32)] == t || hl2[2 * (k - 32) + 1] == t) hi += 1ull << (2 * (k - 32));
     return cv;
   };
   const uint8_t* blk = P.blocks + r * (int64_t)(n - 1) * P.BS;
@@ -1848,7 +1863,7 @@ static __global__ __launch_bounds__(64) void fw_delta_kernel(const Params P, con
   // among its lanes is enough.)  Straight-line code with selects -- the lanes of a wavefront are at
   // different (left internal?, right internal?) cases at every node.
   double part = 0.0;
-  uint64_t cvp = 0;
+  uint64_t cvp = 0, cvp2 = 0;
   int sp = 0;
   {
     uint4 nb[4];
@@ -1873,32 +1888,43 @@ static __global__ __launch_bounds__(64) void fw_delta_kernel(const Params P, con
           // the entry below the newest finished subtree (read whether needed or not)
           const int k2 = sp - 2 < 0 ? 0 : sp - 2;
           double top;
-          uint64_t topcv;
+          uint64_t topcv, topcv2 = 0;
           if (k2 < FWD_STK) {
             top = stk[k2 * NL];
             topcv = cvs[k2 * NL];
+            if (wide) topcv2 = cvs2[k2];
           } else {
             top = sc.pstk[k2];
             topcv = reinterpret_cast<const uint64_t*>(sc.gstk)[k2];
+            if (wide) bad = true;  // (both at once never seen: the full rebuild takes it)
           }
           if (none && sp >= 1) {  // a new subtree starts: the finished one waits on the stack
             const int k1 = sp - 1;
             if (k1 < FWD_STK) {
               stk[k1 * NL] = part;
               cvs[k1 * NL] = cvp;
+              if (wide) cvs2[k1] = cvp2;
             } else {
               sc.pstk[k1] = part;
               reinterpret_cast<uint64_t*>(sc.gstk)[k1] = cvp;
             }
           }
-          const uint64_t lcl = li ? 0ull : leafcv(l), lcr = ri ? 0ull : leafcv(rr);
+          uint64_t lcl2 = 0, lcr2 = 0;
+          const uint64_t lcl = li ? 0ull : leafcv(l, lcl2), lcr = ri ? 0ull : leafcv(rr, lcr2);
           const double pl = both ? top : (li ? part : 0.0);
           const double pr = ri ? part : 0.0;
           const uint64_t cvl = both ? topcv : (li ? cvp : lcl);
           const uint64_t cvr = ri ? cvp : lcr;
           // a changed index is among the legs of a child that holds exactly one of its tensors
           const uint64_t in_u = ((cvl & ~(cvl >> 1)) | (cvr & ~(cvr >> 1))) & 0x5555555555555555ull;
-          const int ne = e + log2d * (base - __popcll(in_u & plus) + __popcll(in_u & minus));
+          int dex = base - __popcll(in_u & plus) + __popcll(in_u & minus);
+          if (wide) {  // (indices 32..63 of the list)
+            const uint64_t cvl2 = both ? topcv2 : (li ? cvp2 : lcl2), cvr2 = ri ? cvp2 : lcr2;
+            const uint64_t in_u2 = ((cvl2 & ~(cvl2 >> 1)) | (cvr2 & ~(cvr2 >> 1))) & 0x5555555555555555ull;
+            dex += __popcll(in_u2 & minus2) - __popcll(in_u2 & plus2);
+            cvp2 = cvl2 + cvr2;
+          }
+          const int ne = e + log2d * dex;
           bad = bad || e <= 0 || e >= 2047 || ne <= 0 || ne >= 2047;
           const double c = __longlong_as_double((long long)((uint64_t)(uint32_t)ne << 52));
           part = (c + pl) + pr;  // (the association order of finite_width/utils.hpp:36-47)

@@ -763,6 +763,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       HIP_TRY(hipMemcpy(dh, hold.data(), hold.size() * 4, hipMemcpyHostToDevice));
       F.holder2 = dh;
       HIP_TRY(h->alloc(&F.fastflag, R));
+      HIP_TRY(h->alloc(&F.delta_scr, R * 64));
       F.fast_ok = 1;
     }
     F.stack_cap = FW_LDSPOS;
