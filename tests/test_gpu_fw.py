@@ -240,3 +240,30 @@ def test_fw_walk_from_both_ends_on_deep_trees(core, oracle_lib, left_deep):
     links = np.repeat(tree[None], len(seeds), axis=0)
     w0 = _initial_max_width(prob, tree)
     _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 40, 12), max(3, w0 // 2), chunks=[12], every=1, links=links)
+
+
+def test_fw_repricing_equals_the_full_rebuild_at_scale(core, monkeypatch):
+    """The two forms of the re-slice's rebuild on the config-5 topology, 32 768 replicas x 30 sweeps from the
+    reference's greedy starts: totals, best totals, slices and best slices identical.  (What the small
+    cases above cannot show: events of one replica in ten thousand -- a re-slice that proposes the
+    slices a replica already has must still re-associate the partial sums and may commit, as the
+    reference's CostCache rebuild does; more than 32 changed indices early in a schedule.)"""
+    from tnco_amd import synthetic as syn
+    R = 32768
+    p = syn.sycamore_problem(20)
+    seeds = np.asarray(syn.replica_seeds(R))
+    links = core.greedy_trees(p.ts_inds, p.n_inds, seeds, device=0)
+    betas = H.linear_betas(0, 100, 1200)[:30]
+    monkeypatch.delenv("TNCO_HIP_FW_NO_DELTA", raising=False)
+    a = core.BatchedOptimizer(p.leaf_masks, links, seeds, n_inds=p.n_inds, max_width=40)
+    monkeypatch.setenv("TNCO_HIP_FW_NO_DELTA", "1")
+    b = core.BatchedOptimizer(p.leaf_masks, links, seeds, n_inds=p.n_inds, max_width=40)
+    for c in range(0, 30, 10):
+        a.run(betas[c:c + 10], update_slices_every=10)
+        b.run(betas[c:c + 10], update_slices_every=10)
+        (ta, ma), (tb, mb) = a.costs(), b.costs()
+        assert np.array_equal(ta, tb) and np.array_equal(ma, mb), c
+    ids = np.arange(R)
+    sa, sb = a.slices_many(ids), b.slices_many(ids)
+    assert np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1])
+    assert a.validate() == (0, -1)
