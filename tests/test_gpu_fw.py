@@ -59,6 +59,8 @@ def test_fw_regular(core, oracle_lib, monkeypatch, n, frac, delta):
     hyper-indices, per-index dims, sparse legs and float32 costs always get)."""
     if not delta:
         monkeypatch.setenv("TNCO_HIP_FW_NO_DELTA", "1")
+    else:
+        monkeypatch.setenv("TNCO_HIP_FW_DELTA", "1")  # (pinned: the library would leave the mode when many replicas fall back)
     prob = H.regular_problem(n, graph_seed=n + 1)
     seeds = H.replica_seeds(24, S=n)
     w0 = _initial_max_width(prob, prob.tree(seeds[0]))
@@ -255,6 +257,7 @@ def test_fw_repricing_equals_the_full_rebuild_at_scale(core, monkeypatch):
     links = core.greedy_trees(p.ts_inds, p.n_inds, seeds, device=0)
     betas = H.linear_betas(0, 100, 1200)[:30]
     monkeypatch.delenv("TNCO_HIP_FW_NO_DELTA", raising=False)
+    monkeypatch.setenv("TNCO_HIP_FW_DELTA", "1")
     a = core.BatchedOptimizer(p.leaf_masks, links, seeds, n_inds=p.n_inds, max_width=40)
     monkeypatch.setenv("TNCO_HIP_FW_NO_DELTA", "1")
     b = core.BatchedOptimizer(p.leaf_masks, links, seeds, n_inds=p.n_inds, max_width=40)

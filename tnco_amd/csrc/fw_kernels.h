@@ -1835,7 +1835,10 @@ static __global__ __launch_bounds__(64) void fw_delta_kernel(const Params P, con
       ++nd;
     }
   }
-  if (slow) return;  // (phase B rebuilds this replica in full)
+  if (slow) {  // (phase B rebuilds this replica in full; the host watches how often: tnco_hip_run_fw)
+    atomicAdd(F.slowstat, 1ull);
+    return;
+  }
   FWD_STAT(nd < 40 ? nd : 40);
   // (nd == 0, the slices the replica has: the rebuild still runs -- its partial sums are those of
   //  finite_width/utils.hpp:36-47, (cost + left) + right at every node, which the moves' incremental
@@ -1937,6 +1940,7 @@ static __global__ __launch_bounds__(64) void fw_delta_kernel(const Params P, con
   }
   if (bad) {
     FWD_STAT(72);
+    atomicAdd(F.slowstat, 1ull);
     return;  // (a cost outside the powers of two of a double: the full rebuild decides)
   }
   const double cur = reinterpret_cast<const NodeRec*>(blk + (int64_t)(N - 1 - n) * P.BS)->partial;

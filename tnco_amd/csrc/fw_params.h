@@ -29,6 +29,7 @@ struct FwParams {
   int32_t fast_ok;          // uniform power-of-two dims, float64 cost, no sparse legs, no hyper-indices, <= 1024 tensors
   const int32_t* holder2;   // [I64][2] the (one or two) tensors holding an index, -1: none / index not supported
   int32_t* fastflag;        // [R] 1: fw_delta_kernel has done this replica's rebuild (+ commit)
+  unsigned long long* slowstat;  // [1] replicas fw_delta_kernel has left to the full rebuild since the host last looked
   uint64_t* delta_scr;      // [R][64] fw_delta_kernel: holders of the changed indices (u16[128]), second count-vector words
   int32_t* status;          // [R] runtime problems (1: candidate legs beyond the scratch; cannot happen
                             //     since the scratch holds every index)

@@ -26,6 +26,12 @@ struct tnco_hip_ctx {
   int log2l = 2, K = 1, L = 4;  // lanes per replica = L, mask words per lane = K
   bool hyper = false, generic = false;
   bool fw = false;  // finite-width optimizer
+  // the re-slice by re-pricing (fw_delta_kernel) pays while few replicas fall back to the full rebuild: the
+  // mode of a tnco_hip_run_fw call follows the fall-backs counted during the previous one
+  bool fw_delta_capable = false, fw_delta_on = false;
+  int64_t fw_delta_reslices = 0;  // re-slices launched in that mode since the count was read
+  int fw_single_calls = 0;        // calls in the other mode since the last probe
+  int fw_probe_wait = 4;          // ... before the next probe (doubles after a probe that failed)
   bool small_tree = false;  // infinite memory, fast cost path, <= 2 mask words, <= 128 leaves: LDS-resident sweeps
   tnco::FwParams F{};
   std::vector<void*> allocs;

@@ -147,6 +147,7 @@ hipError_t launch_fw_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, 
         e = h->timed(TNCO_KIND_FW_WALK, [&]() { launch_fw_walk(h, prewalked == 2); });
         if (e != hipSuccess) return e;
       }
+      if (h->F.fast_ok && prewalked == 2 && !h->hyper) h->fw_delta_reslices += 1;
       e = h->timed(TNCO_KIND_FW_RESLICE, [&]() {
 #define CALL_FWS(LL, KK) launch_fw_reslice_lk<LL, KK>(h, prewalked)
         DISPATCH_LK(h, CALL_FWS)
@@ -764,7 +765,10 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       F.holder2 = dh;
       HIP_TRY(h->alloc(&F.fastflag, R));
       HIP_TRY(h->alloc(&F.delta_scr, R * 64));
+      HIP_TRY(h->alloc(&F.slowstat, 1));
+      HIP_TRY(hipMemset(F.slowstat, 0, 8));
       F.fast_ok = 1;
+      h->fw_delta_capable = h->fw_delta_on = true;
     }
     F.stack_cap = FW_LDSPOS;
     if (const char* e = std::getenv("TNCO_HIP_FW_STACK")) F.stack_cap = std::max(0, std::min(FW_LDSPOS, std::atoi(e)));
@@ -875,6 +879,27 @@ int tnco_hip_run_fw(tnco_hip_handle h, int prob_kind, const double* betas, int64
   if (n_steps == 0) return TNCO_HIP_OK;
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->fw_delta_capable) {
+    // Re-pricing or the single re-slice kernel for this call?  Re-pricing (three kernels) wins while
+    // fewer than ~3 % of the replicas fall back to the full rebuild (more than 64 changed indices: random
+    // initial trees early in a schedule) -- a fall-back costs its whole wavefront the rebuild.  The
+    // previous call's kernels are complete here: its fall-backs are counted, or, after 4, 8, 16 ... calls in
+    // the other mode, this call probes again.
+    if (h->fw_delta_reslices > 0) {
+      unsigned long long slow = 0;
+      HIP_TRY(hipMemcpy(&slow, h->F.slowstat, 8, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemsetAsync(h->F.slowstat, 0, 8, h->stream));
+      const bool was_on = h->fw_delta_on;
+      h->fw_delta_on = (double)slow < 0.02 * (double)h->fw_delta_reslices * (double)h->P.R;
+      h->fw_probe_wait = h->fw_delta_on ? 4 : (was_on && h->fw_single_calls == 0 ? std::min(64, 2 * h->fw_probe_wait) : h->fw_probe_wait);
+      h->fw_delta_reslices = 0;
+      h->fw_single_calls = 0;
+    } else if (!h->fw_delta_on && ++h->fw_single_calls >= h->fw_probe_wait) {
+      h->fw_delta_on = true;
+    }
+    if (const char* e = std::getenv("TNCO_HIP_FW_DELTA")) h->fw_delta_on = std::atoi(e) != 0;  // (test knob: pin the mode)
+    h->F.fast_ok = h->fw_delta_on ? 1 : 0;
+  }
   if (n_steps > h->betas_cap) {
     if (h->d_betas) (void)hipFree(h->d_betas);
     h->d_betas = nullptr;
