@@ -270,3 +270,30 @@ def test_fw_repricing_equals_the_full_rebuild_at_scale(core, monkeypatch):
     sa, sb = a.slices_many(ids), b.slices_many(ids)
     assert np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1])
     assert a.validate() == (0, -1)
+
+
+def test_fw_form_of_the_reslice_chosen_per_call(core, monkeypatch):
+    """tnco_hip_run_fw switches between the two forms of the re-slice by the fall-backs of the previous call
+    (random starts: many changed indices early -> the single kernel, later probes of the re-pricing):
+    whatever it picks, the results are those of either form pinned."""
+    from tnco_amd import synthetic as syn
+    R = 4096
+    p = syn.sycamore_problem(20)
+    seeds = np.asarray(syn.replica_seeds(R))
+    links = core.random_trees(p.ts_inds, p.n_inds, seeds)
+    betas = H.linear_betas(0, 100, 1200)[:240]
+    out = []
+    for pin in (None, "0", "1"):
+        if pin is None:
+            monkeypatch.delenv("TNCO_HIP_FW_DELTA", raising=False)
+        else:
+            monkeypatch.setenv("TNCO_HIP_FW_DELTA", pin)
+        o = core.BatchedOptimizer(p.leaf_masks, links, seeds, n_inds=p.n_inds, max_width=40)
+        for c in range(0, 240, 20):  # twelve calls: the adaptive run changes form in between
+            o.run(betas[c:c + 20], update_slices_every=10)
+        out.append((o.costs(), o.slices_many(np.arange(R))))
+        assert o.validate() == (0, -1)
+        o.close()
+    for (ca, sa) in out[1:]:
+        assert np.array_equal(out[0][0][0], ca[0]) and np.array_equal(out[0][0][1], ca[1])
+        assert np.array_equal(out[0][1][0], sa[0]) and np.array_equal(out[0][1][1], sa[1])
