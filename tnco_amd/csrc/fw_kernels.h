@@ -1865,6 +1865,10 @@ static __global__ __launch_bounds__(64) void fw_delta_kernel(const Params P, con
   // in a second, storing pass cost as much as the first for EVERY wavefront: one improving replica
   // among its lanes is enough.)  Straight-line code with selects -- the lanes of a wavefront are at
   // different (left internal?, right internal?) cases at every node.
+  // the new partial sums (8 B) and cost exponents (2 B) of the nodes, by post-order number: whole 64-byte
+  // pieces per eight nodes (a (cost, partial) pair per node was 135 lines per replica instead of 85)
+  double* plist = reinterpret_cast<double*>(sc.cp);
+  uint16_t* elist = reinterpret_cast<uint16_t*>(plist + ((ni + 9) & ~1));
   double part = 0.0;
   uint64_t cvp = 0, cvp2 = 0;
   int sp = 0;
@@ -1882,8 +1886,12 @@ static __global__ __launch_bounds__(64) void fw_delta_kernel(const Params P, con
       const int jn = j0 + 8 < ni ? j0 + 8 : j0;  // (past the end: the same piece again)
 #pragma unroll
       for (int q = 0; q < 4; ++q) nb[q] = rec4[(jn >> 1) + q];
+      double pv[8];
+      uint32_t ev[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
+        pv[i] = 0.0;
+        ev[i] = 0;
         if (j0 + i < ni) {
           const uint64_t cur = rc[i];
           const int l = fw_rec_left(cur), rr = fw_rec_right(cur), e = fw_rec_exp(cur);
@@ -1932,10 +1940,16 @@ static __global__ __launch_bounds__(64) void fw_delta_kernel(const Params P, con
           const double c = __longlong_as_double((long long)((uint64_t)(uint32_t)ne << 52));
           part = (c + pl) + pr;  // (the association order of finite_width/utils.hpp:36-47)
           cvp = cvl + cvr;
-          sc.cp[j0 + i] = make_double2(c, part);
+          pv[i] = part;
+          ev[i] = (uint32_t)ne & 0xFFFFu;
           sp += both ? -1 : (none ? 1 : 0);
         }
       }
+      // (the lists are padded by eight entries: whole pieces also at the end)
+      double2* pd = reinterpret_cast<double2*>(plist + j0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pd[q] = make_double2(pv[2 * q], pv[2 * q + 1]);
+      *reinterpret_cast<uint4*>(elist + j0) = make_uint4(ev[0] | (ev[1] << 16), ev[2] | (ev[3] << 16), ev[4] | (ev[5] << 16), ev[6] | (ev[7] << 16));
     }
   }
   if (bad) {
@@ -1949,17 +1963,20 @@ static __global__ __launch_bounds__(64) void fw_delta_kernel(const Params P, con
     __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int j0 = 0; j0 < ni; j0 += 4) {
       uint64_t x[4];
-      double2 c[4];
+      double pp[4];
+      uint32_t ee[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int j = j0 + i < ni ? j0 + i : ni - 1;
         x[i] = sc.rec[j];
-        c[i] = sc.cp[j];
+        pp[i] = plist[j];
+        ee[i] = elist[j];
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (j0 + i < ni)
-          *reinterpret_cast<double2*>(const_cast<uint8_t*>(blk) + (int64_t)(fw_rec_node(x[i]) - n) * P.BS + 16) = c[i];
+          *reinterpret_cast<double2*>(const_cast<uint8_t*>(blk) + (int64_t)(fw_rec_node(x[i]) - n) * P.BS + 16) =
+              make_double2(__longlong_as_double((long long)((uint64_t)ee[i] << 52)), pp[i]);
     }
 #endif
     for (int w = 0; w < LK; ++w) sl[w] = prop[w];

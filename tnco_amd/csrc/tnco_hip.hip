@@ -745,7 +745,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     HIP_TRY(hipMemset(F.status, 0, (size_t)R * 4));
     // the re-slice by re-pricing (fw_delta_kernel): costs must be powers of two and a leg of a subtree
     // decidable from the holders it contains
-    if (F.nwfront != nullptr && P.cost_mode == 0 && !P.f32 && d->sparse_mask == nullptr && !h->hyper && n <= 32 * FWD_BITW &&
+    if (F.nwfront != nullptr && P.cost_mode == 0 && !P.f32 && d->sparse_mask == nullptr && !h->hyper && n >= 16 && n <= 32 * FWD_BITW &&
         !std::getenv("TNCO_HIP_FW_NO_DELTA")) {
       std::vector<int32_t> hold((size_t)F.I64 * 2, -1);
       std::vector<int32_t> cnt((size_t)I, 0);
