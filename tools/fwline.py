@@ -1,3 +1,5 @@
+"""One line per bench.py JSON line on stdin: value, ms per step, per-kernel ms per step (experiments):
+    python bench.py --workload fw --pmc 0 --cpu-sample 0 | python tools/fwline.py"""
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
