@@ -58,6 +58,22 @@ def test_hyper_indices_outputs_equal_sets():
     _both([[0, 1], [1, 2], [2, 3]], 4, seeds, out_keep=[0, 3])                  # the reference's docstring example
 
 
+def test_fuzz_on_small_hyper_networks_against_the_python_spec():
+    """The networks of tests/test_host.py's fuzz (equal index sets reappearing DURING the contraction:
+    the case the round-2 advisor found wrong in both native generators), device == host == Python spec.
+    Trees that end in outer products go to the host version inside the call: not asserted either way."""
+    from tests.test_host import _small_hyper_networks
+    seeds = np.array([0, 1, 2, 3, 5, 8, 13, 21])
+    for ts, n_inds, out_keep in _small_hyper_networks(300):
+        if not _supported(ts, n_inds):
+            continue
+        om = ct.pack_masks([list(out_keep)], n_inds)[0]
+        dev = core.greedy_trees(ts, n_inds, seeds, output_mask=om, device=0)
+        for k, sd in enumerate(seeds):
+            con = ct.greedy_contraction(ts, out_keep, int(sd))
+            assert np.array_equal(dev[k], np.stack(ct.tree_from_contraction(con, len(ts)))), (len(ts), int(sd))
+
+
 def test_config5_topology_and_many_seeds():
     p = syn.sycamore_problem(20)
     assert _supported(p.ts_inds, p.n_inds)

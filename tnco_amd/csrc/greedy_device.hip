@@ -539,6 +539,9 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
       }
       GP_T(5);
       uint64_t n12m = (merged && innw) ? nbr[(size_t)s12 * NW + lane] : 0;
+      // (the live equal set keeps its neighbours, minus the two tensors that just left)
+      if (lane == (s1 >> 6)) n12m &= ~(1ull << (s1 & 63));
+      if (lane == (s2 >> 6)) n12m &= ~(1ull << (s2 & 63));
       // holders per dim: only shared dims and dropped dims change their number
       {
         uint64_t u = (merged ? (a | b) : ((a & b) | ((a ^ b) & ~k12))) & ~out;

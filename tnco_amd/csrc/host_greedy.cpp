@@ -367,7 +367,11 @@ void ssa_greedy(const Work& w, const uint64_t* inputs, Scratch& S) {
     un[s1 >> 6] &= ~(1ull << (s1 & 63));
     un[s2 >> 6] &= ~(1ull << (s2 & 63));
     un[s12 >> 6] &= ~(1ull << (s12 & 63));
-    if (merged) { for (int x = 0; x < NW; ++x) n12[x] |= un[x]; }
+    if (merged) {  // (the live equal set keeps its neighbours, minus the two tensors that just left)
+      for (int x = 0; x < NW; ++x) n12[x] |= un[x];
+      n12[s1 >> 6] &= ~(1ull << (s1 & 63));
+      n12[s2 >> 6] &= ~(1ull << (s2 & 63));
+    }
     else { for (int x = 0; x < NW; ++x) n12[x] = un[x]; }
     S.k2s.clear();
     for (int x = 0; x < NW; ++x) {
