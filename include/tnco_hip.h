@@ -89,7 +89,21 @@ typedef struct tnco_hip_desc {
   uint64_t max_number_new_slices; /* finite_width/greedy/optimizer.hpp:226-321 (the reference's app
                                      always passes 0; any value is implemented) */
   const uint64_t* skip_slices;    /* [W] or NULL */
-  const uint64_t* slices;         /* [W] initial slices, or NULL = greedy initial slicing */
+  const uint64_t* slices;         /* [W] per row: the `slices` constructor argument (no initial slicing, no
+                                     PRNG draw), or NULL = greedy initial slicing (draws from the PRNG) */
+  /* Restoring a batch -- the remaining constructor arguments, which Optimizer.__reduce__ round-trips
+   * (tnco/optimize/infinite_memory/optimizer.py:243-245, finite_width/optimizer.py:343-346;
+   * include/tnco/optimize/optimizer.hpp:57-77, infinite_memory/optimizer.hpp:61-88,
+   * finite_width/greedy/optimizer.hpp:72-115).  As in the reference the caches are rebuilt from the
+   * trees and min_total_cost = get_cost(min_ctree[, min_slices]).  All optional (zero / NULL). */
+  const int32_t* min_links;       /* per replica [3][N] like `links`: min_ctree.  NULL = the current tree.  Host memory */
+  int64_t min_links_stride;       /* int32 elements between replicas; 0 = one tree shared by all */
+  const uint64_t* min_slices;     /* [W] per row: min_slices.  NULL = slices */
+  int64_t slices_stride;          /* uint64 elements between the replicas' rows of `slices` and of `min_slices`;
+                                     0 = one row shared by all */
+  const uint32_t* prng_states;    /* [n_replicas][625]: prng_state of every replica (624 words + position, the
+                                     numbers of the reference's string seed, optimize/optimizer.hpp:68-71);
+                                     replaces `seeds`, which may then be NULL */
 } tnco_hip_desc;
 
 /* Replaces the Optimizer_<cost> constructor for a batch: copies inputs, builds
@@ -101,10 +115,12 @@ int tnco_hip_create(const tnco_hip_desc* desc, tnco_hip_handle* out);
 /* Replaces the Python step loop `for beta in betas: prob.beta = beta;
  * opt.update(prob)` (tnco/app/infinite_memory/sa.py:199-209 over
  * Optimizer::update, infinite_memory/optimizer.hpp:90-221): n_steps sweeps on
- * every replica, sweep k using betas[k].  The call first waits for the handle's
- * previous launch (it re-uses the device copy of `betas`), then enqueues its own
- * kernels on the handle's stream and returns without waiting for them; any
- * getter synchronises. */
+ * every replica, sweep k using betas[k].  The call copies `betas`, enqueues its
+ * kernels and returns without waiting -- neither for them nor for the previous
+ * call's (calls queue up on the device); any getter synchronises.  A handle whose
+ * replicas do not fill whole rounds of resident workgroups runs every step as two
+ * concurrent launches over half of the replicas each (streams of its own, forked
+ * from / joined into the handle's stream): same results, no idle tail. */
 int tnco_hip_run(tnco_hip_handle h, int prob_kind, const double* betas, int64_t n_steps);
 
 /* Finite-width twin: `opt.update(prob, update_slices=(n % update_slices_every == 0))` for
@@ -150,6 +166,9 @@ int tnco_hip_validate(tnco_hip_handle h, double atol, int64_t* n_bad, int64_t* f
  * `oss << std::mt19937` prints. */
 int tnco_hip_get_prng(tnco_hip_handle h, int64_t replica, uint32_t* state625);
 int tnco_hip_set_prng(tnco_hip_handle h, int64_t replica, const uint32_t* state625);
+/* The same for k replicas in one call: states [k][625]; replicas == NULL means replicas 0 .. k-1. */
+int tnco_hip_get_prng_many(tnco_hip_handle h, int64_t k, const int64_t* replicas, uint32_t* states625);
+int tnco_hip_set_prng_many(tnco_hip_handle h, int64_t k, const int64_t* replicas, const uint32_t* states625);
 
 /* The k replicas of lowest min_total_cost, ascending, ties by replica id
  * (replaces `sorted(results)` of tnco/app/infinite_memory/sa.py:257 for the

@@ -76,6 +76,8 @@ def lib():
                           C.c_void_p, C.c_double, C.c_int, C.c_uint64, C.c_void_p,
                           C.c_void_p, C.POINTER(C.c_int)]
             getattr(L, pf + "destroy").argtypes = [C.c_void_p]
+            getattr(L, pf + "set_min").argtypes = [C.c_void_p, _i32p, _i32p, _i32p, _u64p, C.c_void_p]
+            getattr(L, pf + "set_min").restype = C.c_int
             getattr(L, pf + "update").argtypes = [C.c_void_p, C.c_int, C.c_double]
             getattr(L, pf + "update_fw").argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int]
             getattr(L, pf + "run").argtypes = [C.c_void_p, C.c_int, _f64p, C.c_int64]
@@ -174,7 +176,7 @@ class Oracle:
     def __init__(self, left, right, parent, inds, *, n_inds, dims=2, sparse=None,
                  n_projs=0, disable_shared_inds=False, seed=0, mt_state=None,
                  cost_type="float64", max_width=None, width_type="float32",
-                 max_number_new_slices=0, skip_slices=None, slices=None):
+                 max_number_new_slices=0, skip_slices=None, slices=None, min_tree=None, min_slices=None):
         self._pf = {"float64": "orc_f64_", "float32": "orc_f32_"}[cost_type]
         L = lib()
         left = np.ascontiguousarray(left, np.int32)
@@ -210,6 +212,11 @@ class Oracle:
                 int(seed), _opt_ptr(mt), float(max_width), int(width_type == "float32"),
                 int(max_number_new_slices), _opt_ptr(sk), _opt_ptr(sl), C.byref(st))
         self.status = st.value
+        if not self.status and min_tree is not None:
+            # `_min_ctree` / `_min_slices` of the reference's constructors (what __reduce__ round-trips)
+            ml, mr, mp, mi = (np.ascontiguousarray(x, t) for x, t in zip(min_tree, (np.int32,) * 3 + (np.uint64,)))
+            msl = None if min_slices is None else np.ascontiguousarray(min_slices, np.uint64)
+            self.status = int(self._f("set_min")(self._h, ml, mr, mp, mi.reshape(-1), _opt_ptr(msl)))
         if self.status:
             self.close()
             if self.status == 20:

@@ -871,6 +871,30 @@ PFX(state_t)* PFX(create_fw)(int32_t n_leaves, int32_t n_inds, const int32_t* le
   return o;
 }
 
+/* The `min_ctree` (and, finite width, `min_slices`) constructor arguments, applied to a state
+ * constructed without them -- nothing else of the constructors reads these members:
+ * optimize/optimizer.hpp:57-65 (min_ctree{min_ctree.has_value() ? *min_ctree : ctree}),
+ * infinite_memory/optimizer.hpp:61-88 and finite_width/greedy/optimizer.hpp:72-115
+ * (min_slices{min_slices.has_value() ? *min_slices : slices}; min_total_cost =
+ * get_cost(min_ctree[, min_slices]); "Precision is too low." on log2 of it; is_valid of the
+ * tree).  These are what Optimizer.__reduce__ round-trips
+ * (tnco/optimize/infinite_memory/optimizer.py:243-245, finite_width/optimizer.py:343-346).
+ * min_slices == NULL: unchanged.  Return: 0 ok; 1..11 invalid tree; 20 precision. */
+int PFX(set_min)(PFX(state_t)* o, const int32_t* min_left, const int32_t* min_right,
+                 const int32_t* min_parent, const uint64_t* min_inds, const uint64_t* min_slices) {
+  const size_t nb = sizeof(int32_t) * (size_t)o->N, mb = sizeof(uint64_t) * (size_t)o->N * o->W;
+  int rc = orc_ctree_is_valid(o->N, o->W, min_left, min_right, min_parent, min_inds,
+                              !o->disable_shared_inds);
+  if (rc) return rc;
+  memcpy(o->min_left, min_left, nb); memcpy(o->min_right, min_right, nb); memcpy(o->min_parent, min_parent, nb);
+  memcpy(o->min_inds, min_inds, mb);
+  if (o->fw && min_slices) memcpy(o->min_slices, min_slices, sizeof(uint64_t) * (size_t)o->W);
+  o->min_total_cost = PFX(tree_cost)(o, o->min_left, o->min_right, o->min_inds, o->fw ? o->min_slices : NULL);
+  const double l2 = log2((double)o->min_total_cost);
+  if (isinf(l2) || isnan(l2)) return 20;
+  return 0;
+}
+
 /* finite_width/greedy/optimizer.hpp:117-390 update(prob, update_slices). */
 void PFX(update_fw)(PFX(state_t)* o, int prob_kind, double beta, int update_slices) {
   const int W = o->W;

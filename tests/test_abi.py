@@ -31,7 +31,7 @@ def test_desc_struct_matches_header():
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = [re.findall(r"(\w+)\s*;", ln)[0] for ln in body.split("\n") if ";" in ln]
     assert fields == [f[0] for f in _lib.Desc._fields_]
-    assert ctypes.sizeof(_lib.Desc) == 152
+    assert ctypes.sizeof(_lib.Desc) == 192
 
 
 def test_integration_stub_matches_header():

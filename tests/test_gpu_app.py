@@ -187,3 +187,29 @@ def test_timeout_and_top_k():
     tn, res = Optimizer(method="sa", seed=1).optimize(spec, betas=(0, 100), n_steps=20000, n_runs=64,
                                                       timeout=0.2, top_k=5, sweeps_per_launch=50, fuse=None)
     assert len(res) == 5 and tn.tags["timed_out"] and tn.tags["n_runs"] == 64
+
+
+def test_progress_series_is_non_increasing_and_ends_at_the_best_result(capsys):
+    """`verbose` / `progress`: best min_total_cost so far per launch chunk (replaces the reference's `status` /
+    `log2_total_cost` buffers, tnco/parallel.py:229-317, tnco/app/infinite_memory/sa.py:208-209)."""
+    ts, dims, out = __import__("tnco_amd.synthetic", fromlist=["x"]).random_regular_tn(64, 3, 7)
+    spec = [(2, *[f"t{t}" for t in range(64) if k in ts[t]]) for k in range(96)]
+    seen = []
+    tn, res = Optimizer(method="sa", seed=3, verbose=True).optimize(
+        spec, betas=(0, 100), n_steps=600, n_runs=256, sweeps_per_launch=25, fuse=None,
+        progress=lambda comp, done, total, best: seen.append((comp, done, total, best)))
+    series = tn.tags["progress"]
+    assert len(series) == len(seen) >= 10 and series[-1]["sweeps"] == series[-1]["of"] == 600
+    costs = [p["best_cost"] for p in series]
+    assert all(a >= b for a, b in zip(costs, costs[1:])) and costs[0] > costs[-1]
+    assert [s[3] for s in seen] == costs
+    assert Decimal("%g" % costs[-1]) == res[0].cost and costs[-1] == tn.tags["best_raw_cost"]
+    err = capsys.readouterr().err
+    assert err.count("log2(min_total_cost)") == len(series)
+    # the finite-width driver reports the same way
+    tn, res = Optimizer(method="sa", seed=3, max_width=8).optimize(
+        spec, betas=(0, 50), n_steps=100, n_runs=64, sweeps_per_launch=20, fuse=None,
+        progress=lambda *a: seen.append(a))
+    costs = [p["best_cost"] for p in tn.tags["progress"]]
+    assert len(costs) == 5 and all(a >= b for a, b in zip(costs, costs[1:]))
+    assert Decimal("%g" % costs[-1]) == res[0].cost

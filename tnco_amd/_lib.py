@@ -7,9 +7,10 @@ import fails loudly.
 from __future__ import annotations
 
 import ctypes as C
-from pathlib import Path
-
 import os
+import sys
+import warnings
+from pathlib import Path
 
 _PATH = Path(os.environ.get("TNCO_HIP_LIB", Path(__file__).resolve().parent / "libtnco_hip.so"))
 
@@ -42,12 +43,17 @@ class Desc(C.Structure):
         ("max_number_new_slices", C.c_uint64),
         ("skip_slices", C.c_void_p),
         ("slices", C.c_void_p),
+        ("min_links", C.c_void_p),
+        ("min_links_stride", C.c_int64),
+        ("min_slices", C.c_void_p),
+        ("slices_stride", C.c_int64),
+        ("prng_states", C.c_void_p),
     ]
 
 
 EXPORTS = [
     "tnco_hip_create", "tnco_hip_run", "tnco_hip_run_fw", "tnco_hip_get_slices", "tnco_hip_get_slices_many", "tnco_hip_sync", "tnco_hip_get_costs", "tnco_hip_get_tree",
-    "tnco_hip_get_caches", "tnco_hip_validate", "tnco_hip_get_prng", "tnco_hip_set_prng",
+    "tnco_hip_get_caches", "tnco_hip_validate", "tnco_hip_get_prng", "tnco_hip_set_prng", "tnco_hip_get_prng_many", "tnco_hip_set_prng_many",
     "tnco_hip_best", "tnco_hip_min_cost_device", "tnco_hip_get_trees", "tnco_hip_linear_paths", "tnco_hip_linear_paths_ssa", "tnco_hip_get_counters", "tnco_hip_get_moves", "tnco_hip_get_full_copies",
     "tnco_hip_kernel_time", "tnco_hip_kernel_times", "tnco_hip_get_stage_cycles",
     "tnco_hip_device_bytes", "tnco_hip_set_stream", "tnco_hip_destroy", "tnco_hip_random_trees", "tnco_hip_greedy_trees",
@@ -72,13 +78,16 @@ def load() -> C.CDLL:
     # uses torch (torch.distributed over RCCL, the device-side reduction operand).  They coexist when
     # torch's runtime initialises FIRST; the other way round torch reports "No HIP GPUs are available".
     # So if torch can be imported, its runtime is initialised here, before the library touches the GPU.
-    if not os.environ.get("TNCO_HIP_NO_TORCH_FIRST"):
+    # Only a process that uses torch pays for this: torch already imported, or a torch.distributed launch
+    # (tnco_amd.parallel imports torch before it creates a process group).
+    if not os.environ.get("TNCO_HIP_NO_TORCH_FIRST") and ("torch" in sys.modules or "WORLD_SIZE" in os.environ):
         try:
             import torch
             if torch.cuda.is_available():
                 torch.cuda.init()
-        except Exception:  # no torch / no GPU: nothing to order
-            pass
+        except Exception as e:  # noqa: BLE001 -- reported, not swallowed: the ordering problem would come back silently
+            warnings.warn(f"tnco_amd: could not initialise torch's HIP runtime before libtnco_hip.so ({e!r}); "
+                          "torch may report 'No HIP GPUs are available' later in this process.")
     L = C.CDLL(str(_PATH))
     vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
     L.tnco_hip_create.argtypes = [C.POINTER(Desc), C.POINTER(vp)]
@@ -93,6 +102,8 @@ def load() -> C.CDLL:
     L.tnco_hip_validate.argtypes = [vp, dbl, C.POINTER(i64), C.POINTER(i64)]
     L.tnco_hip_get_prng.argtypes = [vp, i64, vp]
     L.tnco_hip_set_prng.argtypes = [vp, i64, vp]
+    L.tnco_hip_get_prng_many.argtypes = [vp, i64, vp, vp]
+    L.tnco_hip_set_prng_many.argtypes = [vp, i64, vp, vp]
     L.tnco_hip_best.argtypes = [vp, i64, vp, vp]
     L.tnco_hip_min_cost_device.argtypes = [vp, vp]
     L.tnco_hip_get_trees.argtypes = [vp, i64, vp, C.c_int, vp, vp]

@@ -11,6 +11,7 @@ one all-gather of the heads.
 from __future__ import annotations
 
 import os
+import sys
 from time import perf_counter
 from typing import Iterable
 
@@ -153,10 +154,23 @@ class _Component:
         return frozenset(self.inds_order[p] for p in unpack_mask(mask))
 
 
+# cost_to_decimal prints 6 significant digits ('%g'): two raw totals whose Decimals tie or swap differ by at
+# most this relative amount (half a unit of the 6th digit per component, doubled for safety)
+DECIMAL_TIE_MARGIN = 2e-5
+PROGRESS_POINTS = 20  # best-cost reports per component and schedule when `verbose` / `progress` ask for them
+
+
 def run_sa(opt, tn, betas, n_steps, n_runs, n_projs, timeout, *, top_k, sweeps_per_launch, prob, device,
-           update_slices: int | None, initial_trees: str = "greedy"):
+           update_slices: int | None, initial_trees: str = "greedy", progress=None):
     """Returns (merged, runtime) with merged = [(cost, global run id, per-component costs, per-component
-    paths, per-component slices | None, merged path)] sorted, the `top_k` best runs over all ranks."""
+    paths, per-component slices | None, merged path)] sorted, the `top_k` best runs over all ranks.
+
+    Progress (replaces the `status` / `log2_total_cost` shared-memory buffers the reference's worker
+    processes write every step and its rich progress bar renders, tnco/parallel.py:229-317,
+    tnco/app/infinite_memory/sa.py:208-209): with `opt.verbose` or a `progress` callable, the best
+    min_total_cost over this rank's runs is read back (k-select of one on the device) about
+    PROGRESS_POINTS times per component and schedule -- printed to stderr when verbose, passed as
+    progress(component, sweeps_done, sweeps_total, best_cost), and kept in tn.tags['progress']."""
     finite = update_slices is not None
     if initial_trees not in ("greedy", "kruskal"):
         raise ValueError("'initial_trees' must be 'greedy' or 'kruskal'.")
@@ -184,6 +198,7 @@ def run_sa(opt, tn, betas, n_steps, n_runs, n_projs, timeout, *, top_k, sweeps_p
     # outputs of Random(seed) consumed so far by every run: the reference shares one generator over
     # the components of a run (tnco/utils/tn.py:163,192)
     draws = np.zeros(n_local, np.uint64)
+    series = []
     n_holders = {}
     for xs in tn.ts_inds:
         for i in xs:
@@ -208,28 +223,43 @@ def run_sa(opt, tn, betas, n_steps, n_runs, n_projs, timeout, *, top_k, sweeps_p
         h = core.BatchedOptimizer(comp.leaf_masks, links, my_seeds, n_inds=comp.n_inds, dims=comp.dims,
                                   output_mask=comp.output_mask, sparse_mask=comp.sparse_mask,
                                   n_projs=n_projs, cost_type=opt.cost_type, device=device, **kw)
-        for s in range(0, len(betas), max(1, int(sweeps_per_launch))):
+        if ci == len(comps) - 1 or all(len(c.tensors) <= 1 for c in comps[ci + 1:]):
+            core.greedy_release()  # the last batch of device-drawn trees has been consumed: return its memory
+        spl = max(1, int(sweeps_per_launch))
+        starts = list(range(0, len(betas), spl))
+        report_every = max(1, -(-len(starts) // PROGRESS_POINTS)) if (opt.verbose or progress is not None) else 0
+        for k, s in enumerate(starts):
             if timeout is not None and perf_counter() - t0 > timeout:
                 timed_out = True
                 break
-            h.run(betas[s:s + sweeps_per_launch], prob, update_slices_every=update_slices or 0)
+            h.run(betas[s:s + spl], prob, update_slices_every=update_slices or 0)
             if timeout is not None:
                 h.sync()
+            if report_every and ((k + 1) % report_every == 0 or k == len(starts) - 1):
+                done = min(len(betas), s + spl)
+                best_now = float(h.best(1)[0][0])
+                series.append(dict(component=ci, sweeps=done, of=len(betas), best_cost=best_now))
+                if progress is not None:
+                    progress(ci, done, len(betas), best_now)
+                if opt.verbose:
+                    print(f"[tnco_amd] rank {rank} component {ci + 1}/{len(comps)}: {done}/{len(betas)} sweeps, "
+                          f"{n_local} runs, log2(min_total_cost) = {np.log2(best_now):.4f}", file=sys.stderr, flush=True)
         raw_cost[:, ci] = h.costs()[1]
         handles.append(h)
     runtime = perf_counter() - t0
 
     # cost of a run = sum of the per-component Decimals (sa.py:215-218), which carry 6 significant
     # digits: the head of `sorted(results)` (sa.py:257) by (Decimal total, run id) can only hold runs
-    # whose raw total is within 2e-5 of the top_k-th smallest raw total, so only those few are
+    # whose raw total is within DECIMAL_TIE_MARGIN of the top_k-th smallest raw total, so only those few are
     # turned into Decimals and sorted exactly
     live = [ci for ci, h in enumerate(handles) if h is not None]
     raw_total = raw_cost.sum(axis=1)
-    if n_local > top_k:
+    cand = np.arange(n_local)
+    if n_local > top_k and np.all(np.isfinite(raw_total)):
         kth = np.partition(raw_total, top_k - 1)[top_k - 1]
-        cand = np.nonzero(raw_total <= kth * (1 + 2e-5))[0]
-    else:
-        cand = np.arange(n_local)
+        few = np.nonzero(raw_total <= kth * (1 + DECIMAL_TIE_MARGIN))[0]
+        if len(few) >= top_k:  # (else, e.g. non-positive costs: sort them all, like the reference's sorted(results))
+            cand = few
     dec = {int(r): [cost_to_decimal(raw_cost[r, ci]) if handles[ci] is not None else 0 for ci in range(len(comps))]
            for r in cand}
     totals = {r: sum(d) for r, d in dec.items()}
@@ -269,4 +299,6 @@ def run_sa(opt, tn, betas, n_steps, n_runs, n_projs, timeout, *, top_k, sweeps_p
     tn.tags["best_raw_cost"] = parallel.global_best(best_raw, rank, world, device)
     tn.tags["n_runs"] = n_runs
     tn.tags["timed_out"] = timed_out
+    if series:
+        tn.tags["progress"] = series
     return merged, runtime

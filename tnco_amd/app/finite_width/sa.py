@@ -45,13 +45,13 @@ class Optimizer(BaseOptimizer):
     def optimize(self, tn: Any, betas, n_steps: int | None = None, n_runs: int = 1,
                  n_projs: int | None = None, timeout: float | None = None, update_slices: int = 10, *,
                  top_k: int | None = None, sweeps_per_launch: int = 100, prob: str = "mh",
-                 device: int | None = None, initial_trees: str = "greedy", **load_tn_options) -> Any:
+                 device: int | None = None, initial_trees: str = "greedy", progress=None, **load_tn_options) -> Any:
         tn = self._load_tn(tn, **load_tn_options)
         if int(update_slices) != update_slices or update_slices <= 0:
             raise ValueError("'update_slices' must be a positive number.")
         merged, runtime = run_sa(self, tn, betas, n_steps, n_runs, n_projs, timeout, top_k=top_k,
                                  sweeps_per_launch=sweeps_per_launch, prob=prob, device=device,
-                                 update_slices=int(update_slices), initial_trees=initial_trees)
+                                 update_slices=int(update_slices), initial_trees=initial_trees, progress=progress)
         results = [ContractionResults(cost=c, runtime_s=runtime, path=mp,
                                       disconnected_costs=list(dc), disconnected_paths=paths,
                                       disconnected_slices=list(sl),

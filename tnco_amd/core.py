@@ -104,6 +104,12 @@ def greedy_trees(leaf_positions, n_inds: int, seeds, output_mask=None, draws=Non
     return DeviceLinks(dptr.value, shape, device) if keep_on_device else out
 
 
+def greedy_release() -> None:
+    """Frees the device memory greedy_trees(..., device=) keeps between calls (one block per process,
+    ~2.5 GB after 65536 x 512-leaf trees); a DeviceLinks handed out earlier is invalid afterwards."""
+    _lib.load().tnco_hip_greedy_device_release()
+
+
 def linear_paths(contraction, tensors_pos, n_tensors: int, n_threads: int = 0) -> np.ndarray:
     """ContractionTree.path() (tnco/ctree.py:350-388) of k contractions [k, nc-1, 3] -> [k, nc-1, 2]."""
     L = _lib.load()
@@ -173,10 +179,18 @@ class BatchedOptimizer:
                  sparse_mask=None, n_projs: int | None = None, cost_type: str = "float64",
                  disable_shared_inds: bool = False, node_masks=None, device: int = 0,
                  max_width: float | None = None, width_type: str = "float32",
-                 max_number_new_slices: int = 0, skip_slices=None, slices=None):
+                 max_number_new_slices: int = 0, skip_slices=None, slices=None, min_links=None,
+                 min_slices=None, prng_states=None, steps_done: int = 0):
         """Finite width (max_width finite): the batched counterpart of
         finite_width.greedy.Optimizer_<cost>_<width>
-        (include/tnco/optimize/finite_width/greedy/optimizer.hpp:462-518)."""
+        (include/tnco/optimize/finite_width/greedy/optimizer.hpp:462-518).
+
+        Restoring a batch (what Optimizer.__reduce__ round-trips in the reference,
+        tnco/optimize/infinite_memory/optimizer.py:243-245, finite_width/optimizer.py:343-346):
+        `links` = the current trees, `min_links` [R, 3, N] or [3, N] = min_ctree, `slices` /
+        `min_slices` [R, W] or [W], `prng_states` [R, 625] = prng_state of every replica (then
+        `seeds` may be None), `steps_done` = sweeps already run (the n of `n % update_slices`).
+        As in the reference the caches are rebuilt and min_total_cost = get_cost(min_ctree)."""
         self._h = None
         L = _lib.load()
         if cost_type not in ("float64", "float32"):
@@ -193,6 +207,15 @@ class BatchedOptimizer:
             raise ValueError("'links' are in the memory of another device.")
         if not on_device:
             links = np.ascontiguousarray(links, np.int32)
+        ps = None
+        if prng_states is not None:
+            ps = np.ascontiguousarray(prng_states, np.uint32)
+            if ps.ndim != 2 or ps.shape[1] != 625 or (seeds is not None and len(seeds) != len(ps)):
+                raise ValueError("'prng_states' must be [n_replicas, 625].")
+        if seeds is None:
+            if ps is None:
+                raise ValueError("'seeds' or 'prng_states' is needed.")
+            seeds = np.zeros(len(ps), np.uint32)
         seeds = np.ascontiguousarray(np.asarray(seeds, np.uint64) & np.uint64(0xFFFFFFFF), np.uint32)
         R = len(seeds)
         if links.shape == (3, N):
@@ -247,8 +270,27 @@ class BatchedOptimizer:
         d.max_number_new_slices = int(max_number_new_slices)
         sk = None if skip_slices is None else np.ascontiguousarray(skip_slices, np.uint64)
         sl = None if slices is None else np.ascontiguousarray(slices, np.uint64)
-        d.skip_slices, d.slices = _ptr(sk), _ptr(sl)
-        self._steps_done = 0
+        msl = None if min_slices is None else np.ascontiguousarray(min_slices, np.uint64)
+        for x in (sl, msl):
+            if x is not None and x.shape not in ((W,), (R, W)):
+                raise ValueError("'slices' / 'min_slices' must be [W] or [n_replicas, W].")
+        if sl is not None and msl is not None and sl.shape != msl.shape:
+            raise ValueError("'slices' and 'min_slices' must have the same shape.")
+        per_replica = any(x is not None and x.ndim == 2 for x in (sl, msl))
+        d.skip_slices, d.slices, d.min_slices = _ptr(sk), _ptr(sl), _ptr(msl)
+        d.slices_stride = W if per_replica else 0
+        ml = None
+        if min_links is not None:
+            ml = np.ascontiguousarray(min_links, np.int32)
+            if ml.shape == (3, N):
+                d.min_links_stride = 0
+            elif ml.shape == (R, 3, N):
+                d.min_links_stride = 3 * N
+            else:
+                raise ValueError("'min_links' has the wrong shape.")
+            d.min_links = _ptr(ml)
+        d.prng_states = _ptr(ps)
+        self._steps_done = int(steps_done)
         h = C.c_void_p()
         _lib.check(L.tnco_hip_create(C.byref(d), C.byref(h)))
         self._h = h
@@ -371,6 +413,46 @@ class BatchedOptimizer:
         if st.shape != (625,):
             raise ValueError("prng state must hold 625 words.")
         _lib.check(self._L.tnco_hip_set_prng(self._h, int(replica), _ptr(st)))
+
+    def prng_states(self, replicas=None) -> np.ndarray:
+        """prng_state of k replicas (all when None) in one call: uint32 [k, 625]."""
+        if replicas is None:
+            out = np.empty((self.n_replicas, 625), np.uint32)
+            _lib.check(self._L.tnco_hip_get_prng_many(self._h, self.n_replicas, None, _ptr(out)))
+            return out
+        ids = np.ascontiguousarray(replicas, np.int64)
+        out = np.empty((len(ids), 625), np.uint32)
+        _lib.check(self._L.tnco_hip_get_prng_many(self._h, len(ids), _ptr(ids), _ptr(out)))
+        return out
+
+    def set_prng_states(self, states, replicas=None) -> None:
+        st = np.ascontiguousarray(states, np.uint32)
+        ids = None if replicas is None else np.ascontiguousarray(replicas, np.int64)
+        k = len(st)
+        if st.ndim != 2 or st.shape[1] != 625 or (ids is not None and len(ids) != k) or (ids is None and k > self.n_replicas):
+            raise ValueError("prng states must be [k, 625].")
+        _lib.check(self._L.tnco_hip_set_prng_many(self._h, k, _ptr(ids), _ptr(st)))
+
+    def snapshot(self) -> dict:
+        """Everything Optimizer.__reduce__ round-trips in the reference, for all replicas at once
+        (tnco/optimize/infinite_memory/optimizer.py:243-245, finite_width/optimizer.py:343-346): current
+        trees, best trees, PRNG states [, slices, min_slices] + the number of sweeps run.  Feed it to
+        BatchedOptimizer.restore()."""
+        ids = np.arange(self.n_replicas, dtype=np.int64)
+        snap = dict(links=self.trees(ids, which_min=False, contraction=False)[0],
+                    min_links=self.trees(ids, which_min=True, contraction=False)[0],
+                    prng_states=self.prng_states(), steps_done=self._steps_done)
+        if self.finite_width:
+            snap["slices"], snap["min_slices"] = self.slices_many(ids)
+        return snap
+
+    @classmethod
+    def restore(cls, snap: dict, leaf_masks, **kw):
+        """A new batch from snapshot() + the problem description (leaf_masks and the keyword arguments of the
+        constructor).  Like the reference's unpickling it rebuilds the caches from the trees and takes
+        min_total_cost = get_cost(min_ctree[, min_slices]) (infinite_memory/optimizer.hpp:61-88)."""
+        return cls(leaf_masks, snap["links"], None, min_links=snap["min_links"], prng_states=snap["prng_states"],
+                   slices=snap.get("slices"), min_slices=snap.get("min_slices"), steps_done=snap["steps_done"], **kw)
 
     def best(self, k: int = 1):
         k = int(k)

@@ -1184,7 +1184,8 @@ static __global__ __launch_bounds__(256) void fw_walk2_kernel(const Params P, co
 }
 
 struct FwInitArgs {
-  const uint64_t* slices_in;  // [LK] or NULL: use instead of the initial get_slices
+  const uint64_t* slices_in;  // [LK] per row or NULL: use instead of the initial get_slices
+  int64_t slices_in_stride;   // uint64 elements between the replicas' rows; 0: one row for all
   double* out_total;          // [R]
   double* out_sum;            // [R]
 };
@@ -1225,7 +1226,7 @@ __global__ __launch_bounds__(256, 2) void fw_init_kernel(const Params P, const F
   if (a.slices_in) {
     fw_traverse<LOG2L, K, HYPER>(P, F, v, w64, sc.rec, nullptr, lane0, gbase, st, sc.gstk);
 #pragma unroll
-    for (int k = 0; k < K; ++k) slices.w[k] = a.slices_in[v.widx(k)];
+    for (int k = 0; k < K; ++k) slices.w[k] = a.slices_in[r * a.slices_in_stride + v.widx(k)];
   } else {
     slices = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, sc, st, lpos, lane0, gbase, F.status + r);
   }

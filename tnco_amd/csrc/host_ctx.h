@@ -40,6 +40,26 @@ struct tnco_hip_ctx {
   std::vector<uint64_t> outmask_w;   // [W]
   double* d_betas = nullptr;
   int64_t betas_cap = 0;
+  // Infinite memory: tnco_hip_run enqueues without waiting for the previous call.  The betas of a call go
+  // through a pinned host ring into a device ring (a region is re-used only after a wrap, which waits).
+  double *beta_pin = nullptr, *beta_ring = nullptr;
+  int64_t ring_cap = 0, ring_pos = 0;
+  // ... and a handle whose replicas do not fill whole rounds of resident blocks (65536 replicas at 512
+  // leaves: 1024 blocks for 768 slots) splits every step over n_groups streams, half of the blocks each:
+  // a block that ends then frees its slot for the OTHER stream's pending launch, and the chip stays full
+  // from step to step instead of running the last third of every launch on a third of its CUs
+  // (tools/overlap_probe.py: +10 %).  Group kernels are ordered after the main stream's work at the fork
+  // (event), every other entry point joins them back first (join_groups).
+  static constexpr int MAX_GROUPS = 4;
+  int n_groups = 1;
+  int run_slots = 0;  // resident blocks of the sweep kernel on this device
+  hipStream_t gstream[MAX_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t gfork = nullptr, gjoin[MAX_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
+  bool groups_dirty = false;
+  // device time of grouped steps: from the fork of the first call after a reset to the join that reads it
+  hipEvent_t region_a = nullptr, region_b = nullptr;
+  bool region_open = false, region_b_set = false;
+  int64_t region_calls = 0;
   std::vector<EventPair> pending, free_events;
   double kernel_ms = 0;   // all kernels of the run calls since the last reset
   int64_t launches = 0;   // chunks of the schedule launched (one per tnco_hip_run[_fw] call unless very long)
@@ -83,7 +103,46 @@ struct tnco_hip_ctx {
     if (pending.size() > 1024) resolve_events();
     return hipSuccess;
   }
+  // Everything the group streams hold becomes work the main stream waits for.
+  hipError_t join_groups() {
+    if (!groups_dirty) return hipSuccess;
+    for (int q = 0; q < n_groups; ++q) {
+      hipError_t e = hipEventRecord(gjoin[q], gstream[q]);
+      if (e != hipSuccess) return e;
+      e = hipStreamWaitEvent(stream, gjoin[q], 0);
+      if (e != hipSuccess) return e;
+    }
+    groups_dirty = false;
+    if (region_open) {  // the device time of the grouped steps ends here
+      hipError_t e = hipEventRecord(region_b, stream);
+      if (e != hipSuccess) return e;
+      region_b_set = true;
+    }
+    return hipSuccess;
+  }
+  hipError_t sync_all() {
+    hipError_t e = join_groups();
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(stream);
+  }
+  // closes the timing region of grouped steps (called with the groups joined and the stream idle)
+  void close_region() {
+    if (!region_open) return;
+    float ms = 0;
+    if ((region_b_set || hipEventRecord(region_b, stream) == hipSuccess) && hipEventSynchronize(region_b) == hipSuccess &&
+        hipEventElapsedTime(&ms, region_a, region_b) == hipSuccess) {
+      kernel_ms += ms;
+      kind_ms[TNCO_KIND_SWEEP] += ms;
+      kind_launches[TNCO_KIND_SWEEP] += region_calls;
+    }
+    region_open = false;
+    region_b_set = false;
+    region_calls = 0;
+  }
   void reset_times() {
+    region_open = false;
+    region_b_set = false;
+    region_calls = 0;
     kernel_ms = 0;
     launches = 0;
     for (int k = 0; k < TNCO_KINDS; ++k) { kind_ms[k] = 0; kind_launches[k] = 0; }
@@ -102,8 +161,19 @@ struct tnco_hip_ctx {
   }
   ~tnco_hip_ctx() {
     (void)hipSetDevice(device);
+    for (int q = 0; q < MAX_GROUPS; ++q)
+      if (gstream[q]) (void)hipStreamSynchronize(gstream[q]);
     if (stream) (void)hipStreamSynchronize(stream);
     resolve_events();
+    for (int q = 0; q < MAX_GROUPS; ++q) {
+      if (gstream[q]) (void)hipStreamDestroy(gstream[q]);
+      if (gjoin[q]) (void)hipEventDestroy(gjoin[q]);
+    }
+    if (gfork) (void)hipEventDestroy(gfork);
+    if (region_a) (void)hipEventDestroy(region_a);
+    if (region_b) (void)hipEventDestroy(region_b);
+    if (beta_pin) (void)hipHostFree(beta_pin);
+    if (beta_ring) (void)hipFree(beta_ring);
     for (auto& ev : free_events) {
       (void)hipEventDestroy(ev.a);
       (void)hipEventDestroy(ev.b);
@@ -119,7 +189,9 @@ struct tnco_hip_ctx {
 // Launchers of the kernels of one (LOG2L, K) pair; defined in launch_impl.h, instantiated once per
 // pair in inst_<LOG2L>_<K>.hip so that the pairs compile in parallel.
 template <int LOG2L, int K>
-void launch_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind);
+void launch_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, hipStream_t s, int block0, int nblocks);
+template <int LOG2L, int K>
+int run_blocks_per_cu_lk(tnco_hip_ctx* h);
 template <int LOG2L, int K>
 void launch_build_lk(tnco_hip_ctx* h, const tnco::BuildArgs& a);
 template <int LOG2L, int K>

@@ -7,10 +7,33 @@
 
 using namespace tnco;
 
+// The sweep kernel this handle runs (infinite memory), or nullptr for the LDS-resident small-tree kernel.
 template <int LOG2L, int K>
-void launch_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind) {
+static const void* run_kernel_ptr(const tnco_hip_ctx* h) {
+  if (h->hyper)
+    return h->generic ? (const void*)sa_run_kernel<LOG2L, K, true, true, false> : (const void*)sa_run_kernel<LOG2L, K, true, false, false>;
+  return h->generic ? (const void*)sa_run_kernel<LOG2L, K, false, true, false> : (const void*)sa_run_kernel<LOG2L, K, false, false, false>;
+}
+
+// Blocks of that kernel one CU holds at a time (its register budget decides: 3 at 512 leaves).
+template <int LOG2L, int K>
+int run_blocks_per_cu_lk(tnco_hip_ctx* h) {
+  if constexpr (LOG2L == 2 && K == 1) {
+    if (h->small_tree) return 0;
+  }
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, run_kernel_ptr<LOG2L, K>(h), 256, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return nb;
+}
+
+// n_steps sweeps of the replicas of blocks [block0, block0 + nblocks) on stream s (nblocks < 0: all of them).
+template <int LOG2L, int K>
+void launch_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, hipStream_t s, int block0,
+                   int nblocks) {
   const Params& P = h->P;
-  hipStream_t s = h->stream;
   if constexpr (LOG2L == 2 && K == 1) {
     // small trees (BASELINE config 2): the replica's whole tree in LDS for the launch (sa_small.h)
     if (h->small_tree) {
@@ -24,17 +47,17 @@ void launch_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int pr
     }
   }
   const int gpb = 256 >> LOG2L;
-  dim3 grid((unsigned)((P.R + gpb - 1) / gpb));
+  dim3 grid((unsigned)(nblocks >= 0 ? nblocks : (P.R + gpb - 1) / gpb));
   if (h->hyper) {
     if (h->generic)
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, true, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1);
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, true, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1, block0);
     else
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, false, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1);
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, false, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1, block0);
   } else {
     if (h->generic)
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, true, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1);
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, true, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1, block0);
     else
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, false, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1);
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, false, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1, block0);
   }
 }
 
@@ -90,7 +113,7 @@ void launch_fw_move_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, in
   if (!maxnew && !std::getenv("TNCO_HIP_FW_UNSTAGED")) {  // the staged state machine (sa_sweep.h, FW = true)
 #define TNCO_FW_STAGED(HY, GE)                                                                                          \
   hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, HY, GE, true>), grid, dim3(256), 0, h->stream, h->P, betas, n_steps, \
-                     prob_kind, h->F, tail_last)
+                     prob_kind, h->F, tail_last, 0)
     if (h->hyper) {
       if (h->generic) TNCO_FW_STAGED(true, true); else TNCO_FW_STAGED(true, false);
     } else {
@@ -139,7 +162,8 @@ void launch_fw_reslice_lk(tnco_hip_ctx* h, int prewalked) {
     hipLaunchKernelGGL((fw_reslice_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, prewalked);
 }
 
-template void launch_run_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const double*, int64_t, int);
+template void launch_run_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const double*, int64_t, int, hipStream_t, int, int);
+template int run_blocks_per_cu_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*);
 template void launch_build_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const BuildArgs&);
 template void launch_compare_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const BuildArgs&, double, int32_t*);
 template void launch_fw_leaf_bits_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, uint32_t*, int32_t*);

@@ -322,7 +322,7 @@ template <int LOG2L, int K, bool HYPER, bool GENERIC, bool FW = false>
 // (8 lanes x 4 words) run 3.25 -> 3.6e9 move-evals/s, 680 leaves the same within the +-3 % of the boxes)
 __global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES : ((HYPER || K >= 4) ? TNCO_HYPER_WAVES : TNCO_WAVES_PER_SIMD)))) void sa_run_kernel(
     const Params P, const double* __restrict__ betas, const int64_t n_steps, const int prob_kind,
-    const FwParams F, const int tail_last) {
+    const FwParams F, const int tail_last, const int block0) {
   constexpr int L = 1 << LOG2L;
   constexpr int GPB = 256 >> LOG2L;  // groups (replicas) per block
   using M = Mask<K>;
@@ -345,7 +345,9 @@ __global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
   const int lig = tid & (L - 1);
   const int gib = tid >> LOG2L;
   const int gbase = (tid & 63) & ~(L - 1);  // first lane of the group inside the wave
-  const int64_t r = (int64_t)blockIdx.x * GPB + gib;
+  // (block0: the launch covers the replicas of blocks block0 .. block0 + gridDim.x - 1 -- a handle may split a
+  // step over several streams, launch_run_lk)
+  const int64_t r = ((int64_t)blockIdx.x + block0) * GPB + gib;
   if (r >= P.R || n_steps <= 0) return;
   const bool lane0 = (lig == 0);
 

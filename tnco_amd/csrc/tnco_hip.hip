@@ -80,10 +80,18 @@ void choose_lanes(int W, int* log2l, int* K) {
     default: CALL(4, 4); break;                               \
   }
 
-void launch_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind) {
-#define CALL_RUN(LL, KK) launch_run_lk<LL, KK>(h, betas, n_steps, prob_kind)
+void launch_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, hipStream_t s, int block0 = 0,
+                int nblocks = -1) {
+#define CALL_RUN(LL, KK) launch_run_lk<LL, KK>(h, betas, n_steps, prob_kind, s, block0, nblocks)
   DISPATCH_LK(h, CALL_RUN)
 #undef CALL_RUN
+}
+int run_blocks_per_cu(tnco_hip_ctx* h) {
+  int nb = 0;
+#define CALL_OCC(LL, KK) nb = run_blocks_per_cu_lk<LL, KK>(h)
+  DISPATCH_LK(h, CALL_OCC)
+#undef CALL_OCC
+  return nb;
 }
 void launch_build(tnco_hip_ctx* h, const BuildArgs& a) {
 #define CALL_BUILD(LL, KK) launch_build_lk<LL, KK>(h, a)
@@ -185,6 +193,36 @@ __global__ void finish_init_kernel(Params P, const double* sum, const double* to
     rs->n_moves = 0; rs->n_accepted = 0; rs->n_improved = 0; rs->n_randpick = 0; rs->n_fullcopy = 0;
     rs->status = 0; rs->jinvalid = 0; rs->jmin = 0; rs->jtail = 0; rs->pad0 = 0; rs->pad2 = 0;
   }
+}
+
+// the position field of a prng_state (the words are copied straight into P.mt): nothing is left to twist
+__global__ void mt_pos_kernel(ReplicaState* rs, const uint32_t* pos, const int64_t* ids, int64_t k) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  ReplicaState* x = rs + (ids ? ids[i] : i);
+  x->mti = (int32_t)pos[i];
+  x->mtw = 624;
+}
+
+// the `min_ctree` constructor argument: checkpoint := these links, no rotation logged
+__global__ void set_minlinks_kernel(Params P, const int32_t* in, int64_t stride) {
+  const int64_t r = blockIdx.x;
+  const int32_t* lk = in + r * stride;
+  Links* ml = P.minlinks + r * (int64_t)P.N;
+  for (int i = threadIdx.x; i < P.N; i += blockDim.x) {
+    Links o;
+    o.left = lk[i]; o.right = lk[P.N + i]; o.parent = lk[2 * (int64_t)P.N + i]; o.pad = 0;
+    ml[i] = o;
+  }
+}
+// ... min_total_cost := get_cost(min_ctree[, min_slices]); the log restarts with the next improvement,
+// which takes a whole copy (the current tree is not the checkpoint's)
+__global__ void restore_min_kernel(ReplicaState* rs, int64_t r0, int64_t count, const double* sum) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= count) return;
+  ReplicaState* x = rs + r0 + q;
+  x->min_cost = sum[q];
+  x->jmin = 0; x->jtail = 0; x->jinvalid = 1;
 }
 
 // ---- host-side tree checks: Node::is_valid (include/tnco/node.hpp:72-107) +
@@ -357,7 +395,7 @@ int fw_runtime_status(tnco_hip_handle h) {
 
 int fetch_rs(tnco_hip_handle h, std::vector<ReplicaState>& rs) {
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(h->sync_all());
   if (int rc = fw_runtime_status(h)) return rc;
   rs.resize((size_t)h->P.R);
   HIP_TRY(hipMemcpy(rs.data(), h->P.rs, (size_t)h->P.R * sizeof(ReplicaState), hipMemcpyDeviceToHost));
@@ -384,7 +422,10 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   *out = nullptr;
   if (d->n_leaves < 2) return fail(TNCO_HIP_EINVAL, "Precision is too low.");  // total cost 0 -> log2 = -inf (optimizer.hpp:77-80)
   if (d->n_inds < 0 || d->n_replicas <= 0) return fail(TNCO_HIP_EINVAL, "'n_inds' / 'n_replicas' are not valid.");
-  if (!d->leaf_masks || !d->links || !d->seeds) return fail(TNCO_HIP_EINVAL, "null input array.");
+  if (!d->leaf_masks || !d->links || (!d->seeds && !d->prng_states)) return fail(TNCO_HIP_EINVAL, "null input array.");
+  if (d->prng_states)
+    for (int64_t r = 0; r < d->n_replicas; ++r)
+      if (d->prng_states[r * 625 + 624] > 624) return fail(TNCO_HIP_EINVAL, "prng position out of range.");
   if (d->cost_dtype != TNCO_HIP_F64 && d->cost_dtype != TNCO_HIP_F32)
     return fail(TNCO_HIP_ENOTIMPL, "cost_type must be float64 or float32.");
   const int n = d->n_leaves, N = 2 * n - 1, I = d->n_inds;
@@ -640,12 +681,21 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
 
   TempBufs tmp;
   // seeds -> MT state
-  {
+  if (d->prng_states) {  // the string-seed form of the constructor (optimize/optimizer.hpp:68-71): whole states
+    HIP_TRY(hipMemcpy2D(P.mt, (size_t)624 * 4, d->prng_states, (size_t)625 * 4, (size_t)624 * 4, (size_t)R, hipMemcpyHostToDevice));
+    std::vector<uint32_t> pos((size_t)R);
+    for (int64_t r = 0; r < R; ++r) pos[(size_t)r] = d->prng_states[r * 625 + 624];
+    uint32_t* dpos = nullptr;
+    HIP_TRY(tmp.alloc(&dpos, R));
+    HIP_TRY(hipMemcpy(dpos, pos.data(), (size_t)R * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(mt_pos_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, h->stream, P.rs, dpos, (const int64_t*)nullptr, R);
+    HIP_TRY(h->sync_all());
+  } else {
     uint32_t* dseeds = nullptr;
     HIP_TRY(tmp.alloc(&dseeds, R));
     HIP_TRY(hipMemcpy(dseeds, d->seeds, (size_t)R * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(mt_seed_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, h->stream, P.mt, P.rs, dseeds, R);
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(h->sync_all());
   }
 
   // links (+ optional explicit legs) -> node blocks and caches
@@ -674,7 +724,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       HIP_TRY(hipGetLastError());
       std::vector<int32_t> chk((size_t)ntrees);
       HIP_TRY(hipMemcpyAsync(chk.data(), dcheck, (size_t)ntrees * 4, hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(hipStreamSynchronize(h->stream));
+      HIP_TRY(h->sync_all());
       for (int64_t r = 0; r < ntrees; ++r)
         if (chk[r]) return fail(TNCO_HIP_EINVAL, tree_check_message(chk[r]));
     }
@@ -700,12 +750,12 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     a.r0 = 0; a.count = R;
     launch_build(h, a);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(h->sync_all());
     HIP_TRY(hipMemcpy(total.data(), dtotal, (size_t)R * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(sum.data(), dsum, (size_t)R * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(status.data(), dstatus, (size_t)R * 4, hipMemcpyDeviceToHost));
     hipLaunchKernelGGL(finish_init_kernel, dim3((unsigned)R), dim3(64), 0, h->stream, P, dsum, dtotal);
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(h->sync_all());
     for (int64_t r = 0; r < R; ++r)
       if (status[r]) return fail(TNCO_HIP_EINVAL, status_message(status[r]));
     if (!fw)
@@ -798,19 +848,34 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       HIP_TRY(hipGetLastError());
       int32_t a1 = 0;
       HIP_TRY(hipMemcpyAsync(&a1, any, 4, hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(hipStreamSynchronize(h->stream));
+      HIP_TRY(h->sync_all());
       F.leaf_wide = a1 ? 1 : 0;
     }
+    // rows of W words (one shared, or one per replica) -> rows of L words on the device, zero-padded
+    auto upload_rows = [&](const uint64_t* src, uint64_t** dst) -> int {
+      const int64_t rows = d->slices_stride == 0 ? 1 : R;
+      uint64_t* dm;
+      HIP_TRY(tmp.alloc(&dm, rows * L));
+      HIP_TRY(hipMemset(dm, 0, (size_t)rows * L * 8));
+      HIP_TRY(hipMemcpy2D(dm, (size_t)L * 8, src, (size_t)std::max<int64_t>(d->slices_stride, W) * 8, (size_t)W * 8, (size_t)rows, hipMemcpyHostToDevice));
+      *dst = dm;
+      return TNCO_HIP_OK;
+    };
+    if (d->slices_stride != 0 && d->slices_stride < W) return fail(TNCO_HIP_EINVAL, "'slices_stride' is not valid.");
     FwInitArgs a{};
-    if (d->slices)
-      if (int rc = upload_mask(d->slices, &a.slices_in)) return rc;
+    if (d->slices) {
+      uint64_t* ds = nullptr;
+      if (int rc = upload_rows(d->slices, &ds)) return rc;
+      a.slices_in = ds;
+      a.slices_in_stride = d->slices_stride == 0 ? 0 : L;
+    }
     double *dtotal = nullptr, *dsum = nullptr;
     HIP_TRY(tmp.alloc(&dtotal, R));
     HIP_TRY(tmp.alloc(&dsum, R));
     a.out_total = dtotal; a.out_sum = dsum;
     launch_fw_init(h, a);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(h->sync_all());
     std::vector<double> total((size_t)R), sum((size_t)R);
     std::vector<int32_t> st((size_t)R);
     HIP_TRY(hipMemcpy(total.data(), dtotal, (size_t)R * 8, hipMemcpyDeviceToHost));
@@ -822,6 +887,103 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     }
   }
 
+  // The `min_ctree` / `min_slices` constructor arguments (optimize/optimizer.hpp:57-65,
+  // infinite_memory/optimizer.hpp:61-88, finite_width/greedy/optimizer.hpp:72-115): the best tree so far
+  // and its slices, min_total_cost = get_cost(min_ctree[, min_slices]), the checks of is_valid on them.
+  if (d->min_links || (fw && d->min_slices)) {
+    const int64_t LKw = L;
+    if (d->min_links) {
+      const int64_t ntrees = d->min_links_stride == 0 ? 1 : R;
+      if (d->min_links_stride != 0 && d->min_links_stride < 3 * (int64_t)N) return fail(TNCO_HIP_EINVAL, "'min_links_stride' is not valid.");
+      {
+        std::vector<int32_t> cp((size_t)N), cc((size_t)N);
+        for (int64_t r = 0; r < ntrees; ++r) {
+          const int32_t* lk = d->min_links + r * d->min_links_stride;
+          if (const char* e = tree_check(N, lk, lk + N, lk + 2 * (int64_t)N, cp, cc)) return fail(TNCO_HIP_EINVAL, e);
+        }
+      }
+      int32_t* dmin = nullptr;
+      HIP_TRY(tmp.alloc(&dmin, ntrees * 3 * N));
+      if (d->min_links_stride == 0 || d->min_links_stride == 3 * (int64_t)N)
+        HIP_TRY(hipMemcpy(dmin, d->min_links, (size_t)ntrees * 3 * N * 4, hipMemcpyHostToDevice));
+      else
+        HIP_TRY(hipMemcpy2D(dmin, (size_t)3 * N * 4, d->min_links, (size_t)d->min_links_stride * 4, (size_t)3 * N * 4, (size_t)ntrees, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(set_minlinks_kernel, dim3((unsigned)R), dim3(64), 0, h->stream, P, dmin, d->min_links_stride == 0 ? (int64_t)0 : 3 * (int64_t)N);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(h->sync_all());
+      h->small_tree = false;  // (the LDS-resident kernel assumes the log starts at the checkpoint)
+    }
+    if (fw && d->min_slices) {  // row 1 of every replica's [2][L] slices record
+      std::vector<uint64_t> rows((size_t)R * LKw, 0);
+      for (int64_t r = 0; r < R; ++r)
+        for (int w = 0; w < W; ++w) rows[(size_t)r * LKw + w] = d->min_slices[r * d->slices_stride + w];
+      HIP_TRY(hipMemcpy2D(h->F.slices + LKw, (size_t)2 * LKw * 8, rows.data(), (size_t)LKw * 8, (size_t)LKw * 8, (size_t)R, hipMemcpyHostToDevice));
+    }
+    const int64_t per = h->block_bytes() + (int64_t)n * 4 + (int64_t)N * 16 + 64;
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(R, ((int64_t)1 << 30) / per));
+    uint8_t* tblk = nullptr; int32_t *tlpar = nullptr, *tscr = nullptr, *tstat = nullptr, *tbad = nullptr;
+    double *ttot = nullptr, *tsum = nullptr;
+    HIP_TRY(tmp.alloc(&tblk, chunk * h->block_bytes()));
+    HIP_TRY(tmp.alloc(&tlpar, chunk * n * LPS));
+    HIP_TRY(tmp.alloc(&tscr, chunk * 4 * N));
+    HIP_TRY(tmp.alloc(&tstat, chunk));
+    HIP_TRY(tmp.alloc(&tbad, chunk));
+    HIP_TRY(tmp.alloc(&ttot, chunk));
+    HIP_TRY(tmp.alloc(&tsum, chunk));
+    std::vector<int32_t> hs((size_t)chunk), hb((size_t)chunk);
+    std::vector<double> hsum((size_t)chunk);
+    for (int64_t r0 = 0; r0 < R; r0 += chunk) {
+      const int64_t cnt = std::min(chunk, R - r0);
+      BuildArgs a{};
+      a.out_blocks = tblk; a.out_lpar = tlpar; a.scratch = tscr;
+      a.out_total = ttot; a.out_sum = tsum; a.out_status = tstat; a.r0 = r0; a.count = cnt;
+      a.src_live = 0;
+      a.src_links = P.minlinks + r0 * (int64_t)N;
+      if (fw) { a.cost_slices = h->F.slices + LKw; a.cost_slices_stride = 2 * LKw; }
+      launch_build(h, a);
+      HIP_TRY(hipMemsetAsync(tbad, 0, (size_t)cnt * 4, h->stream));
+      if (fw) launch_fw_check(h, a, 1, 1e-5, tbad);
+      hipLaunchKernelGGL(restore_min_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, P.rs, r0, cnt, tsum);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(h->sync_all());
+      HIP_TRY(hipMemcpy(hs.data(), tstat, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(hb.data(), tbad, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(hsum.data(), tsum, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+      for (int64_t q = 0; q < cnt; ++q) {
+        if (hs[q]) return fail(TNCO_HIP_EINVAL, status_message(hs[q]));
+        if (hb[q]) return fail(TNCO_HIP_EINVAL, "Width of the sliced minimum contraction is larger than 'max_width'.");
+        if (bad_log2(hsum[q])) return fail(TNCO_HIP_EINVAL, "Precision is too low.");
+      }
+    }
+  }
+
+  // Infinite memory: do the replicas fill whole rounds of resident blocks?  If the last round would be
+  // partial (65536 replicas at 512 leaves: 1024 blocks, 768 resident), every step is split over two streams
+  // (host_ctx.h, tnco_hip_run).  TNCO_HIP_GROUPS=1..4 overrides.
+  if (!fw) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, d->device));
+    h->run_slots = run_blocks_per_cu(h) * prop.multiProcessorCount;
+    const int64_t nblocks = (R + (256 / h->L) - 1) / (256 / h->L);
+    int G = 1;
+    if (h->run_slots > 0 && nblocks > h->run_slots) {
+      const double rounds = (double)nblocks / (double)h->run_slots, part = rounds - std::floor(rounds);
+      if (part > 0.02 && part < 0.85) G = 2;
+    }
+    if (const char* e = std::getenv("TNCO_HIP_GROUPS")) G = std::max(1, std::min((int)tnco_hip_ctx::MAX_GROUPS, std::atoi(e)));
+    if (h->small_tree || nblocks < 2 * G) G = 1;
+    if (G > 1) {
+      for (int q = 0; q < G; ++q) {
+        HIP_TRY(hipStreamCreateWithFlags(&h->gstream[q], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&h->gjoin[q], hipEventDisableTiming));
+      }
+      HIP_TRY(hipEventCreateWithFlags(&h->gfork, hipEventDisableTiming));
+      HIP_TRY(hipEventCreate(&h->region_a));
+      HIP_TRY(hipEventCreate(&h->region_b));
+      h->n_groups = G;
+    }
+  }
+
   guard.h = nullptr;
   *out = h;
   return TNCO_HIP_OK;
@@ -830,15 +992,16 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
 int tnco_hip_set_stream(tnco_hip_handle h, void* s) {
   if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  h->stream = s ? (hipStream_t)s : h->own_stream;
+  HIP_TRY(h->sync_all());
+  h->close_region();
+  h->stream = s ? (hipStream_t)s : h->own_stream;  // (a grouped handle forks from / joins into this stream)
   return TNCO_HIP_OK;
 }
 
 int tnco_hip_sync(tnco_hip_handle h) {
   if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(h->sync_all());
   return fw_runtime_status(h);
 }
 
@@ -849,24 +1012,64 @@ int tnco_hip_run(tnco_hip_handle h, int prob_kind, const double* betas, int64_t 
   if (n_steps == 0) return TNCO_HIP_OK;
   if (h->fw) return fail(TNCO_HIP_EINVAL, "handle was created with 'max_width': use tnco_hip_run_fw.");
   HIP_TRY(hipSetDevice(h->device));
-  // the previous launch may still be reading d_betas
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  if (n_steps > h->betas_cap) {
-    if (h->d_betas) (void)hipFree(h->d_betas);
-    h->d_betas = nullptr;
-    h->betas_cap = 0;
-    HIP_TRY(hipMalloc((void**)&h->d_betas, (size_t)n_steps * 8));
-    h->betas_cap = n_steps;
+  // betas: pinned host ring -> device ring, no wait for the previous call (a region of the rings is
+  // re-used only after a wrap, and a wrap waits for everything enqueued)
+  if (n_steps > h->ring_cap / 4) {
+    HIP_TRY(h->sync_all());
+    if (h->beta_pin) (void)hipHostFree(h->beta_pin);
+    if (h->beta_ring) (void)hipFree(h->beta_ring);
+    h->beta_pin = h->beta_ring = nullptr;
+    h->ring_cap = h->ring_pos = 0;
+    const int64_t cap = std::max<int64_t>((int64_t)1 << 16, 4 * n_steps);
+    HIP_TRY(hipHostMalloc((void**)&h->beta_pin, (size_t)cap * 8, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&h->beta_ring, (size_t)cap * 8));
+    h->ring_cap = cap;
   }
-  HIP_TRY(hipMemcpyAsync(h->d_betas, betas, (size_t)n_steps * 8, hipMemcpyHostToDevice, h->stream));
+  if (h->ring_pos + n_steps > h->ring_cap) {
+    HIP_TRY(h->sync_all());
+    h->ring_pos = 0;
+  }
+  double* dbetas = h->beta_ring + h->ring_pos;
+  std::memcpy(h->beta_pin + h->ring_pos, betas, (size_t)n_steps * 8);
+  HIP_TRY(hipMemcpyAsync(dbetas, h->beta_pin + h->ring_pos, (size_t)n_steps * 8, hipMemcpyHostToDevice, h->stream));
+  h->ring_pos += n_steps;
   // per-launch work counters are 32-bit: at most (n_leaves - 1) moves per sweep
   const int64_t max_steps = std::max<int64_t>(1, (int64_t)0xF0000000u / std::max(1, h->P.n));
-  for (int64_t s0 = 0; s0 < n_steps; s0 += max_steps) {
-    const int64_t cnt = std::min(max_steps, n_steps - s0);
-    HIP_TRY(h->timed(TNCO_KIND_SWEEP, [&]() { launch_run(h, h->d_betas + s0, cnt, prob_kind); }));
-    h->launches++;
+  if (h->n_groups <= 1) {
+    for (int64_t s0 = 0; s0 < n_steps; s0 += max_steps) {
+      const int64_t cnt = std::min(max_steps, n_steps - s0);
+      HIP_TRY(h->timed(TNCO_KIND_SWEEP, [&]() { launch_run(h, dbetas + s0, cnt, prob_kind, h->stream); }));
+      h->launches++;
+    }
+    if (h->pending.size() > 256) h->resolve_events();
+    return TNCO_HIP_OK;
   }
-  if (h->pending.size() > 256) h->resolve_events();
+  // Grouped: group q runs its blocks on its own stream, after this call's betas (fork event on the main
+  // stream) and -- stream order -- after its own previous launch, NOT after the other groups'.  A long call
+  // is cut into slices of ~100 sweeps so that the streams interleave inside one call as they do from call
+  // to call (a replica's sweeps stay in order: one stream per group).
+  if (h->region_open && h->region_b_set) h->close_region();  // (a join since the last call: that stretch is complete)
+  if (!h->region_open) {
+    HIP_TRY(hipEventRecord(h->region_a, h->stream));
+    h->region_open = true;
+  }
+  HIP_TRY(hipEventRecord(h->gfork, h->stream));
+  const int gpb = 256 / h->L;
+  const int nblocks = (int)((h->P.R + gpb - 1) / gpb);
+  const int64_t n_slices = std::max<int64_t>(1, std::max<int64_t>((n_steps + max_steps - 1) / max_steps, (n_steps + 50) / 100));
+  for (int q = 0; q < h->n_groups; ++q) HIP_TRY(hipStreamWaitEvent(h->gstream[q], h->gfork, 0));
+  for (int64_t i = 0; i < n_slices; ++i) {
+    const int64_t s0 = n_steps * i / n_slices, s1 = n_steps * (i + 1) / n_slices;
+    if (s1 == s0) continue;
+    for (int q = 0; q < h->n_groups; ++q) {
+      const int b0 = (int)((int64_t)nblocks * q / h->n_groups), b1 = (int)((int64_t)nblocks * (q + 1) / h->n_groups);
+      if (b1 > b0) launch_run(h, dbetas + s0, s1 - s0, prob_kind, h->gstream[q], b0, b1 - b0);
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  h->groups_dirty = true;
+  h->region_calls++;
+  h->launches++;
   return TNCO_HIP_OK;
 }
 
@@ -878,7 +1081,7 @@ int tnco_hip_run_fw(tnco_hip_handle h, int prob_kind, const double* betas, int64
   if (n_steps < 0 || (n_steps > 0 && !betas) || step_offset < 0) return fail(TNCO_HIP_EINVAL, "'betas' is not valid.");
   if (n_steps == 0) return TNCO_HIP_OK;
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(h->sync_all());
   if (h->fw_delta_capable) {
     // Re-pricing or the single re-slice kernel for this call?  Re-pricing (three kernels) wins while
     // fewer than ~3 % of the replicas fall back to the full rebuild (more than 64 changed indices: random
@@ -924,7 +1127,7 @@ int tnco_hip_get_slices(tnco_hip_handle h, int64_t r, uint64_t* slices, uint64_t
   if (r < 0 || r >= h->P.R) return fail(TNCO_HIP_EINVAL, "'replica' out of range.");
   const int LK = h->L * h->K, W = h->P.W;
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(h->sync_all());
   std::vector<uint64_t> s((size_t)2 * LK);
   HIP_TRY(hipMemcpy(s.data(), h->F.slices + r * 2 * (int64_t)LK, s.size() * 8, hipMemcpyDeviceToHost));
   if (slices) std::memcpy(slices, s.data(), (size_t)W * 8);
@@ -935,7 +1138,8 @@ int tnco_hip_get_slices(tnco_hip_handle h, int64_t r, uint64_t* slices, uint64_t
 int tnco_hip_kernel_time(tnco_hip_handle h, double* ms, int64_t* launches, int reset) {
   if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(h->sync_all());
+  h->close_region();
   h->resolve_events();
   if (ms) *ms = h->kernel_ms;
   if (launches) *launches = h->launches;
@@ -946,7 +1150,8 @@ int tnco_hip_kernel_time(tnco_hip_handle h, double* ms, int64_t* launches, int r
 int tnco_hip_kernel_times(tnco_hip_handle h, double* ms4, int64_t* launches4, int reset) {
   if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(h->sync_all());
+  h->close_region();
   h->resolve_events();
   for (int k = 0; k < TNCO_KINDS; ++k) {
     if (ms4) ms4[k] = h->kind_ms[k];
@@ -963,7 +1168,7 @@ int tnco_hip_get_costs(tnco_hip_handle h, double* total_cost, double* min_total_
   if (!total_cost && !min_total_cost) return TNCO_HIP_OK;
   const int64_t R = h->P.R;
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(h->sync_all());
   if (int rc = fw_runtime_status(h)) return rc;
   TempBufs tmp;
   double *dt = nullptr, *dm = nullptr;
@@ -973,7 +1178,7 @@ int tnco_hip_get_costs(tnco_hip_handle h, double* total_cost, double* min_total_
   HIP_TRY(hipGetLastError());
   if (total_cost) HIP_TRY(hipMemcpyAsync(total_cost, dt, (size_t)R * 8, hipMemcpyDeviceToHost, h->stream));
   if (min_total_cost) HIP_TRY(hipMemcpyAsync(min_total_cost, dm, (size_t)R * 8, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(h->sync_all());
   return TNCO_HIP_OK;
 }
 
@@ -986,7 +1191,7 @@ int tnco_hip_get_slices_many(tnco_hip_handle h, int64_t k, const int64_t* ids, u
   if (k == 0 || (!slices && !min_slices)) return TNCO_HIP_OK;
   const int LK = h->L * h->K, W = h->P.W;
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(h->sync_all());
   TempBufs tmp;
   int64_t* dids = nullptr;
   uint64_t *dc = nullptr, *dm = nullptr;
@@ -999,7 +1204,7 @@ int tnco_hip_get_slices_many(tnco_hip_handle h, int64_t k, const int64_t* ids, u
   HIP_TRY(hipGetLastError());
   if (slices) HIP_TRY(hipMemcpyAsync(slices, dc, (size_t)k * W * 8, hipMemcpyDeviceToHost, h->stream));
   if (min_slices) HIP_TRY(hipMemcpyAsync(min_slices, dm, (size_t)k * W * 8, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(h->sync_all());
   return TNCO_HIP_OK;
 }
 
@@ -1010,7 +1215,7 @@ int tnco_hip_get_tree(tnco_hip_handle h, int64_t r, int which, int32_t* left, in
   if (!left || !right || !parent) return fail(TNCO_HIP_EINVAL, "null output array.");
   const int n = h->P.n, N = h->P.N, W = h->P.W, BS = h->P.BS;
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(h->sync_all());
   if (which == 0) {
     std::vector<uint8_t> blk((size_t)h->block_bytes());
     HIP_TRY(hipMemcpy(blk.data(), h->P.blocks + r * h->block_bytes(), blk.size(), hipMemcpyDeviceToHost));
@@ -1054,7 +1259,7 @@ int tnco_hip_get_caches(tnco_hip_handle h, int64_t r, double* ccost, double* par
   if (r < 0 || r >= h->P.R) return fail(TNCO_HIP_EINVAL, "'replica' out of range.");
   const int n = h->P.n, N = h->P.N, W = h->P.W, BS = h->P.BS;
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(h->sync_all());
   std::vector<uint8_t> blk((size_t)h->block_bytes());
   HIP_TRY(hipMemcpy(blk.data(), h->P.blocks + r * h->block_bytes(), blk.size(), hipMemcpyDeviceToHost));
   if (hyper) std::memset(hyper, 0, (size_t)N * W * 8);
@@ -1076,7 +1281,7 @@ int tnco_hip_validate(tnco_hip_handle h, double atol, int64_t* n_bad, int64_t* f
   const int n = P.n, N = P.N;
   const int64_t R = P.R;
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(h->sync_all());
   const int64_t per = h->block_bytes() + (int64_t)n * 4 + (int64_t)N * 32 + 64;
   const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(R, ((int64_t)1 << 30) / per));
   TempBufs tmp;
@@ -1107,7 +1312,7 @@ int tnco_hip_validate(tnco_hip_handle h, double atol, int64_t* n_bad, int64_t* f
     launch_build(h, a);
     launch_compare(h, a, atol, tbad);
     if (h->fw) launch_fw_check(h, a, 0, atol, tbad);
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(h->sync_all());
     HIP_TRY(hipMemcpy(hb.data(), tbad, (size_t)cnt * 4, hipMemcpyDeviceToHost));
     // (2) best tree (checkpoint + rotation log): its cost must match min_total_cost
     hipLaunchKernelGGL(materialize_min_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, h->stream, P, tlinks, r0, cnt);
@@ -1118,13 +1323,13 @@ int tnco_hip_validate(tnco_hip_handle h, double atol, int64_t* n_bad, int64_t* f
     if (h->fw) {  // the widths of the best tree, against min_slices
       HIP_TRY(hipMemsetAsync(tbad, 0, (size_t)cnt * 4, h->stream));
       launch_fw_check(h, a, 1, atol, tbad);
-      HIP_TRY(hipStreamSynchronize(h->stream));
+      HIP_TRY(h->sync_all());
       std::vector<int32_t> hb2((size_t)cnt);
       HIP_TRY(hipMemcpy(hb2.data(), tbad, (size_t)cnt * 4, hipMemcpyDeviceToHost));
       for (int64_t q = 0; q < cnt; ++q)
         if (hb2[q]) hb[q] = hb[q] ? hb[q] : hb2[q];
     }
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(h->sync_all());
     HIP_TRY(hipMemcpy(hs.data(), tstat, (size_t)cnt * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(hsum.data(), tsum, (size_t)cnt * 8, hipMemcpyDeviceToHost));
     for (int64_t q = 0; q < cnt; ++q) {
@@ -1141,7 +1346,7 @@ int tnco_hip_get_prng(tnco_hip_handle h, int64_t r, uint32_t* out) {
   if (!h || !out) return fail(TNCO_HIP_EINVAL, "null argument.");
   if (r < 0 || r >= h->P.R) return fail(TNCO_HIP_EINVAL, "'replica' out of range.");
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(h->sync_all());
   ReplicaState rs;
   HIP_TRY(hipMemcpy(&rs, h->P.rs + r, sizeof(rs), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(out, h->P.mt + r * 624, 624 * 4, hipMemcpyDeviceToHost));
@@ -1162,13 +1367,82 @@ int tnco_hip_set_prng(tnco_hip_handle h, int64_t r, const uint32_t* in) {
   if (r < 0 || r >= h->P.R) return fail(TNCO_HIP_EINVAL, "'replica' out of range.");
   if (in[624] > 624) return fail(TNCO_HIP_EINVAL, "prng position out of range.");
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(h->sync_all());
   ReplicaState rs;
   HIP_TRY(hipMemcpy(&rs, h->P.rs + r, sizeof(rs), hipMemcpyDeviceToHost));
   rs.mti = (int32_t)in[624];
   rs.mtw = 624;
   HIP_TRY(hipMemcpy(h->P.mt + r * 624, in, 624 * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->P.rs + r, &rs, sizeof(rs), hipMemcpyHostToDevice));
+  return TNCO_HIP_OK;
+}
+
+int tnco_hip_get_prng_many(tnco_hip_handle h, int64_t k, const int64_t* ids, uint32_t* out) {
+  if (!h || (k > 0 && !out)) return fail(TNCO_HIP_EINVAL, "null argument.");
+  if (k < 0 || (!ids && k > h->P.R)) return fail(TNCO_HIP_EINVAL, "'k' is not valid.");
+  for (int64_t i = 0; ids && i < k; ++i)
+    if (ids[i] < 0 || ids[i] >= h->P.R) return fail(TNCO_HIP_EINVAL, "'replica' out of range.");
+  if (k == 0) return TNCO_HIP_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(h->sync_all());
+  std::vector<ReplicaState> rs;
+  if (int rc = fetch_rs(h, rs)) return rc;
+  if (!ids) {  // replicas 0 .. k-1: one strided copy
+    HIP_TRY(hipMemcpy2D(out, (size_t)625 * 4, h->P.mt, (size_t)624 * 4, (size_t)624 * 4, (size_t)k, hipMemcpyDeviceToHost));
+  } else {
+    for (int64_t i = 0; i < k; ++i)
+      HIP_TRY(hipMemcpyAsync(out + i * 625, h->P.mt + ids[i] * 624, 624 * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h->sync_all());
+  }
+  // finish the lazily generated block sequence so the 624 words are what libstdc++ holds after
+  // _M_gen_rand() (random.tcc:396-430)
+  const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(k / 256 + 1, std::min<unsigned>(16, std::thread::hardware_concurrency())));
+  std::vector<std::thread> th;
+  for (int t = 0; t < nth; ++t)
+    th.emplace_back([&, t]() {
+      for (int64_t i = t; i < k; i += nth) {
+        const ReplicaState& x = rs[(size_t)(ids ? ids[i] : i)];
+        uint32_t* o = out + i * 625;
+        if (x.mti < 624)
+          for (int j = x.mtw; j < 624; ++j) {
+            const uint32_t y = (o[j] & 0x80000000u) | (o[(j + 1) % 624] & 0x7fffffffu);
+            o[j] = o[(j + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+          }
+        o[624] = (uint32_t)x.mti;
+      }
+    });
+  for (auto& x : th) x.join();
+  return TNCO_HIP_OK;
+}
+
+int tnco_hip_set_prng_many(tnco_hip_handle h, int64_t k, const int64_t* ids, const uint32_t* in) {
+  if (!h || (k > 0 && !in)) return fail(TNCO_HIP_EINVAL, "null argument.");
+  if (k < 0 || (!ids && k > h->P.R)) return fail(TNCO_HIP_EINVAL, "'k' is not valid.");
+  for (int64_t i = 0; i < k; ++i) {
+    if (ids && (ids[i] < 0 || ids[i] >= h->P.R)) return fail(TNCO_HIP_EINVAL, "'replica' out of range.");
+    if (in[i * 625 + 624] > 624) return fail(TNCO_HIP_EINVAL, "prng position out of range.");
+  }
+  if (k == 0) return TNCO_HIP_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(h->sync_all());
+  TempBufs tmp;
+  uint32_t* dpos = nullptr;
+  int64_t* dids = nullptr;
+  std::vector<uint32_t> pos((size_t)k);
+  for (int64_t i = 0; i < k; ++i) pos[(size_t)i] = in[i * 625 + 624];
+  HIP_TRY(tmp.alloc(&dpos, k));
+  HIP_TRY(hipMemcpy(dpos, pos.data(), (size_t)k * 4, hipMemcpyHostToDevice));
+  if (!ids) {
+    HIP_TRY(hipMemcpy2D(h->P.mt, (size_t)624 * 4, in, (size_t)625 * 4, (size_t)624 * 4, (size_t)k, hipMemcpyHostToDevice));
+  } else {
+    HIP_TRY(tmp.alloc(&dids, k));
+    HIP_TRY(hipMemcpy(dids, ids, (size_t)k * 8, hipMemcpyHostToDevice));
+    for (int64_t i = 0; i < k; ++i)
+      HIP_TRY(hipMemcpyAsync(h->P.mt + ids[i] * 624, in + i * 625, 624 * 4, hipMemcpyHostToDevice, h->stream));
+  }
+  hipLaunchKernelGGL(mt_pos_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, h->stream, h->P.rs, dpos, dids, k);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(h->sync_all());
   return TNCO_HIP_OK;
 }
 
@@ -1194,7 +1468,7 @@ int tnco_hip_best(tnco_hip_handle h, int64_t k, double* costs, int64_t* replicas
     return TNCO_HIP_OK;
   }
   // k-select on the device: only k (cost, replica) pairs cross PCIe
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(h->sync_all());
   if (int rc = fw_runtime_status(h)) return rc;
   const int keep = (int)std::min<int64_t>(k, TOPK_CHUNK / 2);
   int64_t count = h->P.R;
@@ -1222,7 +1496,7 @@ int tnco_hip_best(tnco_hip_handle h, int64_t k, double* costs, int64_t* replicas
   std::vector<uint32_t> hi((size_t)k);
   HIP_TRY(hipMemcpyAsync(hc.data(), bc[cur], (size_t)k * 8, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemcpyAsync(hi.data(), bi[cur], (size_t)k * 4, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(h->sync_all());
   for (int64_t i = 0; i < k; ++i) {
     double c;
     std::memcpy(&c, &hc[i], 8);
@@ -1235,9 +1509,10 @@ int tnco_hip_best(tnco_hip_handle h, int64_t k, double* costs, int64_t* replicas
 int tnco_hip_min_cost_device(tnco_hip_handle h, void* device_dst_f64) {
   if (!h || !device_dst_f64) return fail(TNCO_HIP_EINVAL, "null argument.");
   HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(h->join_groups());
   hipLaunchKernelGGL(min_cost_kernel, dim3(1), dim3(1024), 0, h->stream, h->P.rs, h->P.R, (double*)device_dst_f64);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(h->stream));  // (the caller's collective runs on another stream)
+  HIP_TRY(h->sync_all());  // (the caller's collective runs on another stream)
   return fw_runtime_status(h);
 }
 
@@ -1251,7 +1526,7 @@ int tnco_hip_get_trees(tnco_hip_handle h, int64_t k, const int64_t* ids, int whi
   if (k == 0) return TNCO_HIP_OK;
   const int n = h->P.n, N = h->P.N;
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(h->sync_all());
   if (int rc = fw_runtime_status(h)) return rc;
   // in chunks, so that the device-side staging stays small whatever k
   const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(k, ((int64_t)256 << 20) / ((int64_t)N * 40)));
@@ -1278,7 +1553,7 @@ int tnco_hip_get_trees(tnco_hip_handle h, int64_t k, const int64_t* ids, int whi
     if (contraction)
       HIP_TRY(hipMemcpyAsync(contraction + k0 * 3 * (n - 1), dcon, (size_t)cnt * 3 * (n - 1) * 4, hipMemcpyDeviceToHost,
                              h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(h->sync_all());
   }
   return TNCO_HIP_OK;
 }

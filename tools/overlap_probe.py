@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
-"""overlap_probe.py -- does splitting the replicas of the infinite-memory leg over G handles (G streams)
-remove the launch tail of `sa_run_kernel`?  65536 replicas are 1024 blocks for 768 resident ones: the last
-256 blocks of every launch run on a third of the chip.  With G handles of R / G replicas, each on a stream of
-its own and stepped round-robin, a block that ends frees its slot for a block of ANOTHER handle's pending
-launch, so the chip stays full over the whole schedule (experiment of round 3; the library does this
-inside one handle when it pays).
+"""overlap_probe.py -- the launch tail of `sa_run_kernel` and the streams that remove it.
 
-    python tools/overlap_probe.py [--groups 1,2,4,8] [--steps 20] [--sweeps 100]
+65536 replicas at 512 leaves are 1024 blocks for 768 resident ones: the last 256 blocks of every launch
+run on a third of the chip.  A handle therefore splits every step over G streams (`TNCO_HIP_GROUPS`,
+default 2 when the last round of blocks would be partial; csrc/host_ctx.h, tnco_hip_run): a block that
+ends frees its slot for a block of the OTHER stream's pending launch, so the chip stays full from step to
+step.  This tool times the bench's headline loop for G = 1, 2, 3, 4 (and checks that the best cost does
+not depend on G: a replica's sweeps stay in order).
+
+    python tools/overlap_probe.py [--groups 1,2,3,4] [--steps 20] [--sweeps 100]
 """
 import argparse
 import sys
@@ -21,7 +23,7 @@ from tnco_amd import core, synthetic  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--groups", default="1,2,4,8")
+    ap.add_argument("--groups", default="1,2,3,4")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--sweeps", type=int, default=100)
@@ -32,29 +34,26 @@ def main():
     seeds = synthetic.replica_seeds(a.replicas, S=0)
     links = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds, device=0)
     betas = synthetic.linear_betas(0.0, 100.0, (a.warmup + a.steps) * a.sweeps)
+    import os
     for G in [int(x) for x in a.groups.split(",")]:
-        per = a.replicas // G
-        opts = [core.BatchedOptimizer(prob.leaf_masks, links[g * per:(g + 1) * per], seeds[g * per:(g + 1) * per],
-                                      n_inds=prob.n_inds, dims=2, device=0) for g in range(G)]
+        os.environ["TNCO_HIP_GROUPS"] = str(G)  # (read by tnco_hip_create)
+        opt = core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, dims=2, device=0)
         for s in range(a.warmup):
-            for o in opts:
-                o.run(betas[s * a.sweeps:(s + 1) * a.sweeps])
-        for o in opts:
-            o.sync()
-        m0 = sum(o.counters()["moves"] for o in opts)
+            opt.run(betas[s * a.sweeps:(s + 1) * a.sweeps])
+        opt.sync()
+        m0 = opt.counters()["moves"]
+        opt.kernel_times_ms(reset=True)
         t0 = time.perf_counter()
         for s in range(a.warmup, a.warmup + a.steps):
-            for o in opts:
-                o.run(betas[s * a.sweeps:(s + 1) * a.sweeps])
-        for o in opts:
-            o.sync()
+            opt.run(betas[s * a.sweeps:(s + 1) * a.sweeps])
+        opt.sync()
         dt = time.perf_counter() - t0
-        m1 = sum(o.counters()["moves"] for o in opts)
-        best = min(float(o.costs()[1].min()) for o in opts)
-        print(f"groups {G}: {(m1 - m0) / dt / 1e9:.3f}e9 move-evals/s, {dt / a.steps * 1e3:.2f} ms per step, "
-              f"best log10 {np.log10(best):.4f}", flush=True)
-        for o in opts:
-            o.close()
+        kt = opt.kernel_times_ms()
+        m1 = opt.counters()["moves"]
+        best = float(opt.costs()[1].min())
+        print(f"groups {G}: {(m1 - m0) / dt / 1e9:.3f}e9 move-evals/s, {dt / a.steps * 1e3:.2f} ms per step (device "
+              f"{kt['sa_run_kernel'][0] / a.steps:.2f}), best log10 {np.log10(best):.4f}", flush=True)
+        opt.close()
 
 
 if __name__ == "__main__":
