@@ -111,11 +111,11 @@ def test_finite_width_batch_survives_destroy_and_restore(core, oracle_lib):
             o2 = orc.Oracle(l, rr, p, m, n_inds=prob.n_inds, dims=2, mt_state=o.prng_state(), max_width=6,
                             slices=sl, min_tree=o.tree(True), min_slices=msl)
             assert o2.min_total_cost == mid["mn"][r] and o2.total_cost == mid["tot"][r]
-            o.run(orc.PROB_MH, betas[47:], update_slices_every=10)
-            # (the restored oracle's sweep counter restarts at 0: drive it sweep by sweep with the true n)
-            for n in range(47, len(betas)):
-                o2.update(orc.PROB_MH, betas[n], update_slices=(n % 10 == 0))
             for oo in (o, o2):
+                # (Oracle.run counts its sweeps from 0 in every call: drive both sweep by sweep with the true n,
+                #  as tnco/app/finite_width/sa.py:228 does)
+                for n in range(47, len(betas)):
+                    oo.update(orc.PROB_MH, betas[n], update_slices=(n % 10 == 0))
                 H.assert_replica_equal(b, r, oo)
                 assert oo.min_total_cost == want["mn"][r]
                 assert all(np.array_equal(x, y) for x, y in zip(b.slices(r), oo.slices()))
