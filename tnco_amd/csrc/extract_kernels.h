@@ -90,7 +90,7 @@ static __global__ __launch_bounds__(256) void gather_costs_kernel(const Params P
   if (r >= P.R) return;
   if (mn) mn[r] = P.rs[r].min_cost;
   if (total)
-    total[r] = reinterpret_cast<const NodeRec*>(P.blocks + (r * (int64_t)(P.n - 1) + (P.n - 2)) * P.BS)->partial;
+    total[r] = reinterpret_cast<const NodeRec*>(P.blocks + r * P.RB + (int64_t)(P.n - 2) * P.BS)->partial;
 }
 
 // slices / min_slices of k replicas: out[q][0..W) <- src[ids[q]][which][0..W)
@@ -151,7 +151,7 @@ static __global__ __launch_bounds__(64) void gather_trees_kernel(const Params P,
       __syncthreads();
     }
   } else {
-    const uint8_t* blk = P.blocks + r * (int64_t)(n - 1) * P.BS;
+    const uint8_t* blk = P.blocks + r * P.RB;
     const int32_t* lp = P.lpar + r * (int64_t)n * LPS;
     for (int i = lane; i < N; i += 64) {
       if (i < n) {

@@ -909,7 +909,7 @@ static __global__ __launch_bounds__(256) void fw_walk_kernel(const Params P, con
     }
   }
   const FwScratch sc(F, r, N);
-  const uint8_t* blk = P.blocks + r * (int64_t)(n - 1) * P.BS;
+  const uint8_t* blk = P.blocks + r * P.RB;
   const double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
   uint64_t* rec = sc.rec;  // (64-byte aligned: fw_np, fw_scratch_ints)
   int32_t* wlist = sc.wlist;
@@ -1041,7 +1041,7 @@ static __global__ __launch_bounds__(256) void fw_walk2_kernel(const Params P, co
   }
   const int64_t rr_ = active ? r : 0;
   const FwScratch sc(F, rr_, N);
-  const uint8_t* blk = P.blocks + rr_ * (int64_t)(n - 1) * P.BS;
+  const uint8_t* blk = P.blocks + rr_ * P.RB;
   const double* w64 = F.width64 ? F.width64 + rr_ * (int64_t)N : nullptr;
   uint64_t* rec = sc.rec;
   int32_t* wlist = sc.wlist;
@@ -1212,7 +1212,7 @@ __global__ __launch_bounds__(256, 2) void fw_init_kernel(const Params P, const F
   const bool lane0 = lig == 0;
   const int n = P.n, N = P.N;
   View<LOG2L, K, HYPER> v;
-  v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n * LPS, lig);
+  v.init(P, P.blocks + r * P.RB, P.lpar + r * (int64_t)n * LPS, lig);
   ReplicaState* rs = P.rs + r;
   R rng;
   rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
@@ -1318,7 +1318,7 @@ __global__ __launch_bounds__(256, MAXNEW ? TNCO_FW_MAXNEW_WAVES : TNCO_FW_MOVE_W
   const int n = P.n, N = P.N;
   const int f32 = P.f32;
   View<LOG2L, K, HYPER> v;
-  v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n * LPS, lig);
+  v.init(P, P.blocks + r * P.RB, P.lpar + r * (int64_t)n * LPS, lig);
   ReplicaState* rs = P.rs + r;
   R rng;
   rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
@@ -1633,7 +1633,7 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_WAVES) void fw_reslice_kernel(
   const bool lane0 = lig == 0;
   const int n = P.n, N = P.N;
   View<LOG2L, K, HYPER> v;
-  v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n * LPS, lig);
+  v.init(P, P.blocks + r * P.RB, P.lpar + r * (int64_t)n * LPS, lig);
   ReplicaState* rs = P.rs + r;
   FwScratch sc(F, r, N);
   if (prewalked == 2) sc.nwf = F.nwfront[r];  // (fw_walk2_kernel: the list in two parts)
@@ -1706,6 +1706,7 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_WAVES) void fw_reslice_kernel(
 // scalars, 64 replicas per wavefront; the total first, and only if it improves a second pass that
 // writes (cost, partial sum) straight into the node headers (no scratch list, no scatter pass).
 // ---------------------------------------------------------------------------------------------
+constexpr int FWT_MAXD = 64;   // changed indices handled by fw_tree_kernel (below), 32 per pass over the paths (more: the full rebuild)
 constexpr int FWD_MAXD = 64;   // changed indices per re-slice handled here (more: the full rebuild); beyond 32 a
                                // second count-vector word joins in (early in a schedule, one re-slice in 2 000)
 #ifdef TNCO_FW_DELTA_STATS  // (diagnostic build: how many indices change, why replicas take the full rebuild)
@@ -1741,10 +1742,12 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_WAVES) void fw_reslice_a_kerne
   const bool lane0 = lig == 0;
   const int n = P.n, N = P.N;
   View<LOG2L, K, HYPER> v;
-  v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n * LPS, lig);
+  v.init(P, P.blocks + r * P.RB, P.lpar + r * (int64_t)n * LPS, lig);
   ReplicaState* rs = P.rs + r;
   FwScratch sc(F, r, N);
-  if (prewalked == 2) sc.nwf = F.nwfront[r];
+  // (-2: fw_order_kernel has left this replica's too-wide tensors to the traverse in here)
+  const int nw_pre = prewalked ? (F.nwide[r] == -2 ? -1 : F.nwide[r]) : -1;
+  if (prewalked == 2 && nw_pre >= 0) sc.nwf = F.nwfront[r];
   double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
   const uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
   M slices;
@@ -1754,12 +1757,56 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_WAVES) void fw_reslice_a_kerne
   R rng;
   rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
   const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, sc, st, lpos, lane0, gbase, F.status + r, nullptr, nullptr,
-                                              prewalked ? F.nwide[r] : -1);
+                                              nw_pre);
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last reads of the position scratch)
   // the proposed slices travel in the candidate-position scratch, free now
   uint64_t* prop = reinterpret_cast<uint64_t*>(const_cast<int16_t*>(sc.pos));
 #pragma unroll
   for (int k = 0; k < K; ++k) prop[v.widx(k)] = ns.w[k];
+  if (F.tree_ok) {
+    // ... and for fw_tree_kernel the indices that changed, each with the parents of the (one or two) leaves
+    // holding it -- where its two paths to the root start: F.delta_scr, as 32-bit words
+    //   [0] how many (0xFFFFFFFF: more than FWT_MAXD, or an index held otherwise: the full rebuild)
+    //   [4..5] [6..7] which of them join / leave the slices (64 bits each)
+    //   [8 + k] first start | second start << 16 (0xFFFF: none)
+    uint32_t* chg = reinterpret_cast<uint32_t*>(F.delta_scr + r * 64);
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) mine += __popcll(ns.w[k] ^ slices.w[k]);
+    int off = 0, total = 0;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      const int c = __shfl(mine, gbase + j);
+      off += j < lig ? c : 0;
+      total += c;
+    }
+    bool unsup = total > FWT_MAXD;
+    uint64_t plus = 0, minus = 0;
+    if (!unsup) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        uint64_t ch = ns.w[k] ^ slices.w[k];
+        while (ch) {
+          const int bit = __ffsll((unsigned long long)ch) - 1;
+          ch &= ch - 1;
+          const int2 t12 = *reinterpret_cast<const int2*>(F.holder2 + 2 * (v.widx(k) * 64 + bit));
+          if (t12.x < 0) { unsup = true; break; }
+          const int s1 = v.lpar[(int64_t)t12.x * LPS], s2 = t12.y < 0 ? 0xFFFF : v.lpar[(int64_t)t12.y * LPS];
+          chg[8 + off] = (uint32_t)s1 | ((uint32_t)s2 << 16);
+          if ((ns.w[k] >> bit) & 1ull) plus |= 1ull << off; else minus |= 1ull << off;
+          ++off;
+        }
+      }
+    }
+    unsup = gany<LOG2L>(unsup);
+    // (disjoint bits: the sum over the group is the union)
+    const uint32_t p0 = gsum<LOG2L>((uint32_t)plus), p1 = gsum<LOG2L>((uint32_t)(plus >> 32));
+    const uint32_t m0 = gsum<LOG2L>((uint32_t)minus), m1 = gsum<LOG2L>((uint32_t)(minus >> 32));
+    if (lane0) {
+      chg[0] = unsup ? 0xFFFFFFFFu : (uint32_t)total;
+      *reinterpret_cast<uint4*>(chg + 4) = make_uint4(p0, p1, m0, m1);
+    }
+  }
   int mti, mtw;
   rng.finish(mti, mtw);
   if (lane0) {
@@ -1857,7 +1904,7 @@ static __global__ __launch_bounds__(64) void fw_delta_kernel(const Params P, con
       if (hl2[2 * (k - 32)] == t || hl2[2 * (k - 32) + 1] == t) hi += 1ull << (2 * (k - 32));
     return cv;
   };
-  const uint8_t* blk = P.blocks + r * (int64_t)(n - 1) * P.BS;
+  const uint8_t* blk = P.blocks + r * P.RB;
   const int log2d = P.log2d;
   bool bad = false;
   const uint4* rec4 = reinterpret_cast<const uint4*>(sc.rec);  // (64-byte aligned; 8 records per 64 bytes)
@@ -1985,8 +2032,331 @@ static __global__ __launch_bounds__(64) void fw_delta_kernel(const Params P, con
   F.fastflag[r] = 1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 3: the re-slice WITHOUT a walk over the tree (split layout, re-pricing form).
+//
+// fw_walk2_kernel + fw_delta_kernel were n - 1 dependent, random header reads per replica and re-slice
+// (at the chip's random-request ceiling: 0.9 ms), 8-byte records written and read again, and -- for the
+// replicas that keep their new slices -- n - 1 scattered 16-byte stores.  Neither needs a traversal:
+//   * get_slices wants the TOO-WIDE tensors in post-order -- a handful.  fw_order_kernel reads the replica's
+//     header array (one contiguous piece in the split layout), lists the too-wide nodes and gives each the
+//     key of its root path (one bit per level, 0 = left; padded with ones; deeper first on ties):
+//     ascending keys ARE the post-order of include/tnco/utils.hpp:34-51.
+//   * the re-priced CostCache (finite_width/utils.hpp:36-47) only needs children before parents.
+//     fw_tree_kernel: one wavefront per replica, the node table in LDS (16 bytes per node).  The new cost
+//     of a node is its old one times 2^(k * (joined - left)) over the changed indices that are NOT among
+//     its children's legs -- and those that are sit on the paths from the indices' holders up to where the
+//     two paths meet: one lane per (index, holder) marks its path, then every node prices itself.  The
+//     partial sums follow: every lane starts at its nodes with two leaf children, and the LAST of two
+//     children to arrive at a parent (an LDS counter) goes on with the parent.  partial = (cost + left)
+//     + right whatever the order of evaluation, so the sums are the reference's bit for bit.  A replica
+//     that keeps the new slices rewrites its header array as whole lines.
+// ---------------------------------------------------------------------------------------------
+constexpr int FWO_MAXW = 256;   // too-wide tensors fw_order_kernel orders (more: the traverse inside fw_reslice_a_kernel)
+constexpr int FWT_JMAX = 16;    // internal nodes per lane of fw_tree_kernel at most: n - 1 <= 1024
+__host__ __device__ inline size_t fwo_lds_bytes(int n) {  // per replica (wavefront)
+  const size_t ni = (size_t)((n - 1 + 63) & ~63);
+  return (ni * 4 + ni * 2 + (size_t)FWO_MAXW * (8 + 2 + 2) + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t fwt_lds_bytes(int n) {
+  const size_t ni = (size_t)((n - 1 + 63) & ~63), nl = (size_t)((n + 31) / 32);
+  (void)nl;
+  return (ni * (8 + 4 + 4) + 32 + 15) & ~(size_t)15;
+}
+
+static __global__ __launch_bounds__(256) void fw_order_kernel(const Params P, const FwParams F) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t fwo_smem[];
+  const int n = P.n, N = P.N, ni = N - n, LK = F.I64 / 64;
+  const int nip = (ni + 63) & ~63;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wv;
+  if (r >= P.R) return;
+  uint8_t* base = fwo_smem + (size_t)wv * fwo_lds_bytes(n);
+  TNCO_LDS volatile uint64_t* key = (TNCO_LDS volatile uint64_t*)base;                 // [FWO_MAXW]
+  TNCO_LDS volatile uint32_t* lr = (TNCO_LDS volatile uint32_t*)(key + FWO_MAXW);       // [nip] left | right << 16
+  TNCO_LDS volatile uint16_t* par = (TNCO_LDS volatile uint16_t*)(lr + nip);            // [nip]
+  TNCO_LDS volatile uint16_t* wnode = par + nip;                                        // [FWO_MAXW]
+  TNCO_LDS volatile uint16_t* dep = wnode + FWO_MAXW;                                   // [FWO_MAXW]
+  {  // greedy/optimizer.hpp:359: nothing to do without slices
+    const uint64_t* sl0 = F.slices + r * 2 * (int64_t)LK;
+    uint64_t any = 0;
+    for (int w = lane; w < P.W; w += 64) any |= sl0[w];
+    if (!__any(any != 0)) {
+      if (lane == 0) F.nwide[r] = -1;
+      return;
+    }
+  }
+  const uint8_t* hb = P.blocks + r * P.RB;
+  const double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
+  const FwScratch sc(F, r, N);
+  uint2* img = reinterpret_cast<uint2*>(sc.rec);
+  int32_t* imgw = sc.gstk;  // [n - 1] (the deep end of the traversal stacks: unused without a walk)
+  int nw = 0;
+  for (int j0 = 0; j0 < ni; j0 += 64) {
+    const int i = j0 + lane;
+    bool wide = false;
+    if (i < ni) {
+      const int4 h = *reinterpret_cast<const int4*>(hb + (int64_t)i * P.BS);
+      const uint32_t ce = *reinterpret_cast<const uint32_t*>(hb + (int64_t)i * P.BS + 20);  // high word of the cached cost
+      lr[i] = (uint32_t)h.x | ((uint32_t)h.y << 16);
+      par[i] = (uint16_t)h.z;  // (the root: 0xFFFF)
+      const double w = F.width_f32 ? (double)__int_as_float(h.w) : w64[n + i];
+      wide = w > F.max_width;
+      // the node table of fw_tree_kernel, 8 bytes per node, in the (otherwise unused) record scratch:
+      // left | right << 16;  parent | cost exponent << 16 | internal children << 27
+      const uint32_t c = (h.x >= n ? 1u : 0u) + (h.y >= n ? 1u : 0u);
+      img[i] = make_uint2((uint32_t)h.x | ((uint32_t)h.y << 16), ((uint32_t)h.z & 0xFFFFu) | (((ce >> 20) & 0x7FFu) << 16) | (c << 27));
+      imgw[i] = h.w;  // (the spare header word -- the cached float32 width: a kept re-slice rewrites whole headers)
+    }
+    const unsigned long long b = __ballot(wide);
+    if (wide) {
+      const int k = nw + __popcll(b & ((1ull << lane) - 1ull));
+      if (k < FWO_MAXW) wnode[k] = (uint16_t)(n + i);
+    }
+    nw += __popcll(b);
+  }
+  if (nw > FWO_MAXW) {  // (fw_reslice_a_kernel traverses this replica itself)
+    if (lane == 0) F.nwide[r] = -2;
+    return;
+  }
+  // root-path keys
+  bool deep = false;
+  for (int k0 = 0; k0 < nw; k0 += 64) {
+    const int k = k0 + lane;
+    if (k < nw) {
+      int x = wnode[k], d = 0;
+      uint64_t rev = 0;
+      while (x != N - 1 && d <= 64) {
+        const int p = par[x - n];
+        rev = (rev << 1) | (uint64_t)((int)(lr[p - n] >> 16) == x);
+        x = p;
+        ++d;
+      }
+      if (d > 64) deep = true;
+      uint64_t ky = d ? (__brevll((unsigned long long)rev)) : 0ull;  // level 0 (below the root) in bit 63
+      if (d < 64) ky |= ~0ull >> d;
+      key[k] = ky;
+      dep[k] = (uint16_t)d;
+    }
+  }
+  if (__any(deep)) {
+    if (lane == 0) F.nwide[r] = -2;
+    return;
+  }
+  // ranks: ascending key, deeper first on equal keys (a node and its all-right ancestors)
+  for (int k0 = 0; k0 < nw; k0 += 64) {
+    const int k = k0 + lane;
+    if (k < nw) {
+      const uint64_t ky = key[k];
+      const int d = dep[k];
+      int rank = 0;
+      for (int m = 0; m < nw; ++m) {
+        const uint64_t km = key[m];
+        const int dm = dep[m];
+        rank += (km < ky || (km == ky && dm > d)) ? 1 : 0;
+      }
+      sc.wlist[rank] = wnode[k];
+    }
+  }
+  if (lane == 0) {
+    F.nwide[r] = nw;
+    F.nwfront[r] = nw;
+  }
+}
+
+#ifdef TNCO_FWT_PROF  // (diagnostic build: shader cycles of [setup, header load, the loop, commit], loop iterations, replicas, commits)
+static __device__ unsigned long long g_fwt_prof[8];
+#define FWT_T(i) const unsigned long long tt##i = __builtin_amdgcn_s_memtime()
+#else
+#define FWT_T(i)
+#endif
+template <int J>  // nodes per lane: n - 1 <= 64 J
+static __global__ __launch_bounds__(256, (J <= 9 ? 4 : 2)) void fw_tree_kernel(const Params P, const FwParams F) {
+  FWT_T(0);
+  extern __shared__ __attribute__((aligned(16))) uint8_t fwt_smem[];
+  const int n = P.n, N = P.N, ni = N - n, LK = F.I64 / 64;
+  const int nip = (ni + 63) & ~63;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wv;
+  if (r >= P.R) return;
+  uint8_t* base = fwt_smem + (size_t)wv * fwt_lds_bytes(n);
+  // node i of the table: lo = left | right << 16; hi = parent | cost exponent << 16 | children still to arrive << 27;
+  // Pn = the new partial sum -- before that the two path masks of the node (see below)
+  TNCO_LDS volatile double* Pn = (TNCO_LDS volatile double*)base;                        // [nip]
+  TNCO_LDS uint32_t* on = (TNCO_LDS uint32_t*)base;                                      // [nip][2] (the same memory)
+  TNCO_LDS volatile uint32_t* onv = (TNCO_LDS volatile uint32_t*)base;
+  TNCO_LDS volatile uint32_t* lo = (TNCO_LDS volatile uint32_t*)(Pn + nip);              // [nip]
+  TNCO_LDS uint32_t* hi = (TNCO_LDS uint32_t*)(lo + nip);                                // [nip] (atomic arrivals)
+  TNCO_LDS volatile uint32_t* hiv = (TNCO_LDS volatile uint32_t*)hi;                     // (plain accesses)
+  TNCO_LDS volatile uint32_t* misc = (TNCO_LDS volatile uint32_t*)(hi + nip);            // [8]
+  if (lane == 0) F.fastflag[r] = 0;
+  uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
+  const FwScratch sc(F, r, N);
+  // ---- everything this replica needs, in flight at once: the node table fw_order_kernel has left (8 bytes per
+  // node, one contiguous piece), the changed indices with the starts of their paths (fw_reslice_a_kernel), the
+  // current total, the old slices
+  uint8_t* hb = P.blocks + r * P.RB;
+  const uint32_t* chg = reinterpret_cast<const uint32_t*>(F.delta_scr + r * 64);
+  const uint2 c0 = *reinterpret_cast<const uint2*>(chg);
+  const uint4 c1 = *reinterpret_cast<const uint4*>(chg + 4);
+  const uint32_t myent = chg[8 + lane];  // (FWT_MAXD = 64 entries: one per lane)
+  uint64_t myold = 0;
+  if (lane < P.W) myold = sl[lane];
+  const double cur = reinterpret_cast<const NodeRec*>(hb + (int64_t)(ni - 1) * P.BS)->partial;
+  const int nwide_r = F.nwide[r];
+  const uint2* img = reinterpret_cast<const uint2*>(sc.rec);
+  const int32_t* imgw = sc.gstk;  // (the spare header words: a kept re-slice rewrites whole headers)
+  uint2 im[J];  // (only until the table is in LDS: the kernel must stay below 128 registers, four wavefronts per SIMD)
+  int32_t iw[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int i = j * 64 + lane;
+    im[j] = make_uint2(0, 0);
+    iw[j] = 0;
+    if (i < ni) {
+      im[j] = img[i];
+      iw[j] = imgw[i];
+    }
+  }
+  if (!__any(myold != 0)) return;  // (nothing was proposed: greedy/optimizer.hpp:359)
+  // (-2: fw_reslice_a_kernel has traversed this replica itself -- over the node table; no list: the full rebuild)
+  if (nwide_r == -2 || c0.x == 0xFFFFFFFFu) {
+    if (lane == 0) atomicAdd(F.slowstat, 1ull);
+    return;
+  }
+  const int nd = (int)c0.x;
+  // bit k of the pair: changed index number k joins / leaves the slices
+  const int dbase = __popc(c1.x) + __popc(c1.y) - __popc(c1.z) - __popc(c1.w);
+  FWT_T(1);
+  // ---- the node table (links, old exponents, arrival counters), path masks cleared ------------------
+  uint32_t startmask = 0;
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int i = j * 64 + lane;
+    if (i < ni) {
+      const int e = (int)((im[j].y >> 16) & 0x7FFu);
+      bad = bad || e <= 0 || e >= 2047;
+      lo[i] = im[j].x;
+      hiv[i] = im[j].y;
+      onv[2 * i] = 0;
+      onv[2 * i + 1] = 0;
+      if ((im[j].y >> 27) == 0u) startmask |= 1u << j;
+    }
+  }
+  // ---- which nodes see a changed index among the legs of their children ------------------------------
+  // An index held by two tensors is a leg of a subtree exactly when the subtree holds ONE of them: of the
+  // nodes above the first holder (mask 0) and above the second (mask 1), those below their meeting point have
+  // it among their children's legs, the meeting point too, the nodes above it not.  One lane per (index,
+  // holder) walks its path to the root; 32 indices per pass (a second pass: one re-slice in some hundreds).
+  const int log2d = P.log2d;
+  for (int pass = 0; pass * 32 < nd || pass == 0; ++pass) {
+    const uint32_t plus = pass ? c1.y : c1.x, minus = pass ? c1.w : c1.z;
+    if (pass) {
+      for (int i = lane; i < ni; i += 64) { onv[2 * i] = 0; onv[2 * i + 1] = 0; }
+    }
+    {
+      const int k = lane >> 1, which = lane & 1;
+      const uint32_t e = (uint32_t)__shfl((int)myent, 32 * pass + k);
+      const int st = which ? (int)(e >> 16) : (int)(e & 0xFFFFu);
+      int x = (32 * pass + k < nd && st != 0xFFFF) ? st : -1;  // the path of a holder starts at its parent
+      for (int guard = 0; __any(x >= 0); ++guard) {
+        if (guard > ni) { bad = true; break; }  // (cannot happen in a tree: never spin on corrupt links)
+        if (x >= 0) {
+          __hip_atomic_fetch_or(&on[2 * (x - n) + which], 1u << k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const int pp = (int)(hiv[x - n] & 0xFFFFu);
+          x = pp == 0xFFFF ? -1 : pp;
+        }
+      }
+    }
+    for (int i = lane; i < ni; i += 64) {
+      const uint32_t w = lo[i], h = hiv[i];
+      const int l = (int)(w & 0xFFFFu), rr = (int)(w >> 16);
+      const uint32_t a = onv[2 * i], b = onv[2 * i + 1];
+      const int il = l >= n ? l - n : i, ir = rr >= n ? rr - n : i;
+      const uint32_t bl = onv[2 * il] & onv[2 * il + 1], br = onv[2 * ir] & onv[2 * ir + 1];
+      const uint32_t both_below = (l >= n ? bl : 0u) | (rr >= n ? br : 0u);
+      const uint32_t in_u = (a ^ b) | (a & b & ~both_below);
+      const int dex = (pass ? 0 : dbase) - __popc(in_u & plus) + __popc(in_u & minus);
+      const int ne = (int)((h >> 16) & 0x7FFu) + log2d * dex;
+      bad = bad || ne <= 0 || ne >= 2047;  // (also between the passes: the full rebuild decides then)
+      hiv[i] = (h & 0xF800FFFFu) | ((uint32_t)(ne & 0x7FF) << 16);  // (nobody reads another node's exponent in this pass)
+    }
+  }
+  FWT_T(2);
+  [[maybe_unused]] unsigned long long iters_ = 0;
+  // ---- children before parents: every lane starts at its nodes with two leaf children; the second child to
+  // arrive at a parent goes on with it (the arrival returns the parent's record)
+  int p = -1;
+  uint32_t phi = 0, plo = 0;
+  for (int guard = 0;; ++guard) {
+    if (guard > 2 * ni + 64) { bad = true; break; }  // (cannot happen in a tree)
+    if (p < 0 && startmask) {
+      const int j = __ffs(startmask) - 1;
+      startmask &= startmask - 1;
+      p = j * 64 + lane;
+      phi = hiv[p];
+      plo = lo[p];
+    }
+    if (!__any(p >= 0)) break;
+#ifdef TNCO_FWT_PROF
+    ++iters_;
+#endif
+    if (p >= 0) {
+      const uint32_t w = plo;
+      const int l = (int)(w & 0xFFFFu), rr = (int)(w >> 16);
+      const bool li = l >= n, ri = rr >= n;
+      const double pl0 = Pn[li ? l - n : p], pr0 = Pn[ri ? rr - n : p];
+      const double pl = li ? pl0 : 0.0, pr = ri ? pr0 : 0.0;
+      const double c = __longlong_as_double((long long)((uint64_t)((phi >> 16) & 0x7FFu) << 52));
+      Pn[p] = (c + pl) + pr;  // (the association order of finite_width/utils.hpp:36-47)
+      if (p == ni - 1) {
+        p = -1;  // the root
+      } else {
+        const int q = (int)(phi & 0xFFFFu) - n;
+        const uint32_t old = __hip_atomic_fetch_add(&hi[q], 0u - (1u << 27), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t qlo = lo[q];  // (with the arrival: the parent's children, in case this lane goes on with it)
+        if ((old >> 27) == 1u) { p = q; phi = old; plo = qlo; } else { p = -1; }
+      }
+    }
+  }
+  FWT_T(3);
+  if (__any(bad)) {  // (a cost outside the powers of two of a double: the full rebuild decides)
+    if (lane == 0) atomicAdd(F.slowstat, 1ull);
+    return;
+  }
+  if (lane == ((ni - 1) & 63)) misc[0] = (Pn[ni - 1] < cur) ? 1u : 0u;  // greedy/optimizer.hpp:371-374
+  if (misc[0]) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int i = j * 64 + lane;
+      if (i < ni) {
+        // the whole header, links and width as they were: two 16-byte stores per node that leave the L2 as whole
+        // lines (the second halves alone, 16 of every 32 bytes, were read-modify-writes in the memory: 2.5 x the time)
+        const uint32_t w = lo[i], h = hiv[i];
+        const double c = __longlong_as_double((long long)((uint64_t)((h >> 16) & 0x7FFu) << 52)), pp = Pn[i];
+        const int par = (int)(h & 0xFFFFu);
+        int4* d = reinterpret_cast<int4*>(hb + (int64_t)i * P.BS);
+        d[0] = make_int4((int)(w & 0xFFFFu), (int)(w >> 16), par == 0xFFFF ? -1 : par, iw[j]);
+        d[1] = make_int4(__double2loint(c), __double2hiint(c), __double2loint(pp), __double2hiint(pp));
+      }
+    }
+    const uint64_t* prop = reinterpret_cast<const uint64_t*>(const_cast<const int16_t*>(sc.pos));
+    if (lane < LK) sl[lane] = lane < P.W ? prop[lane] : 0ull;
+  }
+  if (lane == 0) F.fastflag[r] = 1;
+#ifdef TNCO_FWT_PROF
+  if (lane == 0) {
+    const unsigned long long tt4 = __builtin_amdgcn_s_memtime();
+    atomicAdd(&g_fwt_prof[0], tt1 - tt0); atomicAdd(&g_fwt_prof[1], tt2 - tt1); atomicAdd(&g_fwt_prof[2], tt3 - tt2);
+    atomicAdd(&g_fwt_prof[3], tt4 - tt3); atomicAdd(&g_fwt_prof[4], iters_); atomicAdd(&g_fwt_prof[5], 1ull);
+    atomicAdd(&g_fwt_prof[6], misc[0] ? 1ull : 0ull); atomicAdd(&g_fwt_prof[7], (unsigned long long)nd);
+  }
+#endif
+}
+
 template <int LOG2L, int K, bool HYPER>
-__global__ __launch_bounds__(256, TNCO_FW_RESLICE_WAVES) void fw_reslice_b_kernel(const Params P, const FwParams F) {
+__global__ __launch_bounds__(256, TNCO_FW_RESLICE_WAVES) void fw_reslice_b_kernel(const Params P, const FwParams F, const int need_rec) {
   constexpr int L = 1 << LOG2L;
   constexpr int GPB = 256 >> LOG2L;
   constexpr int LK = L * K;
@@ -2002,7 +2372,7 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_WAVES) void fw_reslice_b_kerne
   const bool lane0 = lig == 0;
   const int n = P.n, N = P.N;
   View<LOG2L, K, HYPER> v;
-  v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n * LPS, lig);
+  v.init(P, P.blocks + r * P.RB, P.lpar + r * (int64_t)n * LPS, lig);
   ReplicaState* rs = P.rs + r;
   const FwScratch sc(F, r, N);
   uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
@@ -2014,6 +2384,12 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_WAVES) void fw_reslice_b_kerne
     M ns;
 #pragma unroll
     for (int k = 0; k < K; ++k) ns.w[k] = prop[v.widx(k)];
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (need_rec) {  // (no walk kernel ran -- fw_order_kernel / fw_tree_kernel: the post-order of this replica, here)
+      const FwStack st{nullptr, nullptr, 0};
+      fw_traverse<LOG2L, K, HYPER>(P, F, v, F.width64 ? F.width64 + r * (int64_t)N : nullptr, sc.rec, nullptr, lane0, gbase,
+                                   st, sc.gstk);
+    }
     double sum;
     constexpr int PCAP = 16, MCAP = (FW_LDSPOS / 2 - PCAP) / LK;
     const double tot = fw_rebuild<LOG2L, K, HYPER>(P, v, sc.rec, ns, sc.cp, sc.pstk, lane0, gbase, &sum,
@@ -2046,8 +2422,8 @@ __global__ __launch_bounds__(256) void fw_check_kernel(const Params P, const FwP
   const int64_t r = a.r0 + q;
   const int n = P.n, N = P.N;
   View<LOG2L, K, HYPER> ref, cur;
-  ref.init(P, a.out_blocks + q * (int64_t)(n - 1) * P.BS, a.out_lpar + q * (int64_t)n * LPS, lig);
-  cur.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n * LPS, lig);
+  ref.init(P, a.out_blocks + q * P.RB, a.out_lpar + q * (int64_t)n * LPS, lig);
+  cur.init(P, P.blocks + r * P.RB, P.lpar + r * (int64_t)n * LPS, lig);
   const double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
   Mask<K> sl;
 #pragma unroll

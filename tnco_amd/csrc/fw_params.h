@@ -27,6 +27,7 @@ struct FwParams {
   int32_t* nwfront;         // [R] ... how many of them at the front of the list (fw_walk2_kernel: the rest at its end)
   // the re-slice re-priced from the OLD costs (fw_delta_kernel): usable when fast_ok
   int32_t fast_ok;          // uniform power-of-two dims, float64 cost, no sparse legs, no hyper-indices, <= 1024 tensors
+  int32_t tree_ok;          // ... and no too-wide leaf, split layout: the re-slice without a walk (fw_order_kernel, fw_tree_kernel)
   const int32_t* holder2;   // [I64][2] the (one or two) tensors holding an index, -1: none / index not supported
   int32_t* fastflag;        // [R] 1: fw_delta_kernel has done this replica's rebuild (+ commit)
   unsigned long long* slowstat;  // [1] replicas fw_delta_kernel has left to the full rebuild since the host last looked

@@ -182,7 +182,7 @@ struct tnco_hip_ctx {
     if (d_betas) (void)hipFree(d_betas);
     if (own_stream) (void)hipStreamDestroy(own_stream);
   }
-  int64_t block_bytes() const { return (int64_t)(P.n - 1) * P.BS; }
+  int64_t block_bytes() const { return P.RB; }
 };
 
 
@@ -206,3 +206,7 @@ template <int LOG2L, int K>
 void launch_fw_move_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, int tail_last);
 template <int LOG2L, int K>
 void launch_fw_reslice_lk(tnco_hip_ctx* h, int prewalked);
+template <int LOG2L, int K>
+bool fw_tree_prepare_lk(tnco_hip_ctx* h);
+template <int LOG2L, int K>
+void launch_fw_order_lk(tnco_hip_ctx* h);

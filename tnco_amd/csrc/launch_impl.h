@@ -3,6 +3,7 @@
 #pragma once
 #include "host_ctx.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 using namespace tnco;
@@ -132,15 +133,57 @@ void launch_fw_move_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, in
   }
 #undef TNCO_FW_MOVE
 }
+// (every translation unit has its own copy of the static kernels: the attribute is set where they are launched)
+template <int LOG2L, int K>
+bool fw_tree_prepare_lk(tnco_hip_ctx* h) {
+  bool ok = hipFuncSetAttribute((const void*)fw_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess;
+#define TNCO_FWT(JJ) ok = ok && hipFuncSetAttribute((const void*)fw_tree_kernel<JJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess
+  TNCO_FWT(2); TNCO_FWT(4); TNCO_FWT(6); TNCO_FWT(9); TNCO_FWT(12); TNCO_FWT(16);
+#undef TNCO_FWT
+  if (!ok) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return 4 * fwt_lds_bytes(h->P.n) <= 160 * 1024 - 256 && 4 * fwo_lds_bytes(h->P.n) <= 160 * 1024 - 256;
+}
+template <int LOG2L, int K>
+void launch_fw_order_lk(tnco_hip_ctx* h) {
+  hipLaunchKernelGGL(fw_order_kernel, dim3((unsigned)((h->P.R + 3) / 4)), dim3(256), 4 * fwo_lds_bytes(h->P.n), h->stream, h->P, h->F);
+}
 template <int LOG2L, int K>
 void launch_fw_reslice_lk(tnco_hip_ctx* h, int prewalked) {
   const int gpb = 256 >> LOG2L;
   dim3 grid((unsigned)((h->P.R + gpb - 1) / gpb));
 #ifndef TNCO_PROFILE
+  if (h->F.fast_ok && prewalked == 3 && !h->hyper) {  // no walk: get_slices from fw_order_kernel's list | fw_tree_kernel | end of the sweep
+    hipLaunchKernelGGL((fw_reslice_a_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, 2);
+    {
+      const dim3 tg((unsigned)((h->P.R + 3) / 4));
+      const size_t tb = 4 * fwt_lds_bytes(h->P.n);
+      const int need = (h->P.n - 1 + 63) / 64;
+#define TNCO_FWT(JJ) hipLaunchKernelGGL(fw_tree_kernel<JJ>, tg, dim3(256), tb, h->stream, h->P, h->F)
+      if (need <= 2) TNCO_FWT(2); else if (need <= 4) TNCO_FWT(4); else if (need <= 6) TNCO_FWT(6);
+      else if (need <= 9) TNCO_FWT(9); else if (need <= 12) TNCO_FWT(12); else TNCO_FWT(16);
+#undef TNCO_FWT
+    }
+    hipLaunchKernelGGL((fw_reslice_b_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, 1);
+#ifdef TNCO_FWT_PROF
+    static int calls = 0;
+    if (++calls % 40 == 0) {
+      unsigned long long st[8];
+      (void)hipStreamSynchronize(h->stream);
+      if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_fwt_prof), sizeof(st)) == hipSuccess && st[5])
+        std::fprintf(stderr, "fw_tree after %d re-slices: per replica cycles setup %.0f load %.0f loop %.0f commit %.0f; %.1f iterations, "
+                     "%.2f kept, %.1f changed indices\n", calls, (double)st[0] / st[5], (double)st[1] / st[5], (double)st[2] / st[5],
+                     (double)st[3] / st[5], (double)st[4] / st[5], (double)st[6] / st[5], (double)st[7] / st[5]);
+    }
+#endif
+    return;
+  }
   if (h->F.fast_ok && prewalked == 2 && !h->hyper) {  // get_slices | re-pricing of the old costs | end of the sweep
     hipLaunchKernelGGL((fw_reslice_a_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, prewalked);
     hipLaunchKernelGGL(fw_delta_kernel, dim3((unsigned)((h->P.R + FWD_LANES - 1) / FWD_LANES)), dim3(64), 0, h->stream, h->P, h->F);
-    hipLaunchKernelGGL((fw_reslice_b_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F);
+    hipLaunchKernelGGL((fw_reslice_b_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, 0);
 #ifdef TNCO_FW_DELTA_STATS  // (diagnostic build: the counters of this translation unit, every 40 re-slices)
     static int calls = 0;
     if (++calls % 40 == 0) {
@@ -171,3 +214,5 @@ template void launch_fw_init_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const F
 template void launch_fw_check_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const BuildArgs&, int, double, int32_t*);
 template void launch_fw_move_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const double*, int64_t, int, int);
 template void launch_fw_reslice_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, int);
+template bool fw_tree_prepare_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*);
+template void launch_fw_order_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*);

@@ -62,11 +62,21 @@ static_assert(sizeof(ReplicaState) == 128, "ReplicaState");
 
 struct Params {
   int32_t n, N, I, W;
-  int32_t BS;                // bytes per node block
+  int32_t BS;                // bytes between the HEADERS of consecutive nodes (unified layout: the node block)
+  // Two layouts of a replica's region (RB bytes, at blocks + r * RB):
+  //   unified  [ header | legs (| hyper legs) ] per node, BS bytes: WOFF = 32, WS = BS -- one line per node
+  //            at <= 12 mask words (the infinite-memory benchmark);
+  //   split    [ all headers, 32 B each ][ all legs, WS bytes each, 128-byte aligned ]: BS = 32 -- the
+  //            finite-width optimizer: its node blocks (15 words: 160 B) straddled lines anyway, the walk of
+  //            the re-slice reads the header array as ONE coalesced 17-KB piece instead of n - 1 random
+  //            32-byte reads, and a kept re-slice rewrites it the same way.
+  int32_t WS;                // bytes between the legs of consecutive nodes
+  int32_t WOFF;              // byte offset of node n's legs from the replica's base
+  int64_t RB;                // bytes per replica
   int32_t hoff;              // byte offset of the hyper legs inside a block (networks with hyper-indices)
   int32_t jcap;              // rotation-log entries per replica
   int64_t R;
-  uint8_t* blocks;           // [R][n-1][BS]
+  uint8_t* blocks;           // [R][RB]
   int32_t* lpar;             // [R][n][LPS]   parent of every leaf (one 64-byte record per leaf)
   uint32_t* mt;              // [R][624]
   uint32_t* mtshadow;        // [R][MT_SHADOW = 64]      generation-g words overwritten ahead of consumption
@@ -142,20 +152,22 @@ __device__ __forceinline__ Mask<K> msel(bool c, const Mask<K>& a, const Mask<K>&
   return r;
 }
 
-// Per-replica view of the node blocks.
-template <int LOG2L, int K, bool HYPER>
+// Per-replica view of the node blocks.  UNI: the unified layout only (the infinite-memory sweep kernel:
+// one multiply per node, as before the split layout existed); else whatever Params says.
+template <int LOG2L, int K, bool HYPER, bool UNI = false>
 struct View {
   static constexpr int L = 1 << LOG2L;
   static constexpr int LK = L * K;
   uint8_t* blk;
   int32_t* lpar;
   const uint64_t* leafmask;
-  int n, BS, W, lig, hoff;
+  int n, BS, W, lig, hoff, WS, WOFF;
 
   __device__ __forceinline__ void init(const Params& P, uint8_t* blk_, int32_t* lpar_, int lig_) {
     blk = blk_; lpar = lpar_; leafmask = P.leafmask; n = P.n; BS = P.BS; W = P.W; lig = lig_; hoff = P.hoff;
+    WS = P.WS; WOFF = P.WOFF;
   }
-  __device__ __forceinline__ uint64_t* hwords(int p) const {
+  __device__ __forceinline__ uint64_t* hwords(int p) const {  // (networks with hyper-indices: unified layout)
     return reinterpret_cast<uint64_t*>(blk + (int64_t)(p - n) * BS + hoff);
   }
   __device__ __forceinline__ NodeRec* hdr(int p) const {
@@ -165,7 +177,8 @@ struct View {
   // L consecutive words (one contiguous 8L-byte piece of the line) per instruction
   __device__ __forceinline__ int widx(int k) const { return k * L + lig; }
   __device__ __forceinline__ uint64_t* words(int p) const {
-    return reinterpret_cast<uint64_t*>(blk + (int64_t)(p - n) * BS + 32);
+    if constexpr (UNI) return reinterpret_cast<uint64_t*>(blk + (int64_t)(p - n) * BS + 32);
+    return reinterpret_cast<uint64_t*>(blk + WOFF + (int64_t)(p - n) * WS);
   }
   // Legs of node x (this lane's words).  The ADDRESS is selected (leaf table / node block), not the
   // value: one load per word, one definition -- two loads in the arms of a branch merge where the
@@ -482,7 +495,7 @@ struct BuildArgs {
   int32_t src_live;            // read links from P.blocks / P.lpar
   const Links* src_links;      // [count][N] or NULL (indexed by q, not r)
   const uint64_t* in_masks; int64_t in_masks_stride;  // optional explicit legs [N][W]
-  uint8_t* out_blocks;         // [count][n-1][BS]
+  uint8_t* out_blocks;         // [count][RB]
   int32_t* out_lpar;           // [count][n][LPS]
   int32_t* scratch;            // [count][4N]
   double* out_total;           // [count] partial[root]
@@ -510,9 +523,9 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
   const int n = P.n, N = P.N;
 
   View<LOG2L, K, HYPER> v;
-  v.init(P, a.out_blocks + q * (int64_t)(n - 1) * P.BS, a.out_lpar + q * (int64_t)n * LPS, lig);
+  v.init(P, a.out_blocks + q * P.RB, a.out_lpar + q * (int64_t)n * LPS, lig);
   View<LOG2L, K, HYPER> live;
-  live.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n * LPS, lig);
+  live.init(P, P.blocks + r * P.RB, P.lpar + r * (int64_t)n * LPS, lig);
   int32_t* stack = a.scratch + q * 4 * (int64_t)N;
   int32_t* order = stack + N;
   int32_t* visited = order + N;
@@ -653,8 +666,8 @@ __global__ __launch_bounds__(256) void compare_kernel(const Params P, const Buil
   const int64_t r = a.r0 + q;
   const int n = P.n, N = P.N;
   View<LOG2L, K, HYPER> ref, cur;
-  ref.init(P, a.out_blocks + q * (int64_t)(n - 1) * P.BS, a.out_lpar + q * (int64_t)n * LPS, lig);
-  cur.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, P.lpar + r * (int64_t)n * LPS, lig);
+  ref.init(P, a.out_blocks + q * P.RB, a.out_lpar + q * (int64_t)n * LPS, lig);
+  cur.init(P, P.blocks + r * P.RB, P.lpar + r * (int64_t)n * LPS, lig);
   int bad = a.out_status[q];
   auto logclose = [&](double x, double y) -> bool {
     if (x < 0 || y < 0) return false;

@@ -352,8 +352,8 @@ __global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
   const bool lane0 = (lig == 0);
 
   const int n = P.n, N = P.N;
-  View<LOG2L, K, HYPER> v;
-  v.init(P, P.blocks + r * (int64_t)(n - 1) * P.BS, nullptr, lig);
+  View<LOG2L, K, HYPER, !FW> v;  // (finite width: the split layout unless the network has hyper-indices)
+  v.init(P, P.blocks + r * P.RB, nullptr, lig);
   auto lpar = [&]() -> int32_t* { return P.lpar + r * (int64_t)n * LPS; };
   lds_cold& cold = *((lds_cold*)coldbuf + gib);
 

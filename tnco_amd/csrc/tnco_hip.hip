@@ -151,11 +151,19 @@ hipError_t launch_fw_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, 
       // large for its stack fields or the test knob TNCO_HIP_FW_STACK=0 asks for the link-walking path
       int prewalked = (h->P.N <= 8192 && h->F.stack_cap > 0 && h->F.nwide != nullptr) ? 1 : 0;
       if (prewalked && h->F.nwfront != nullptr && !h->F.leaf_wide) prewalked = 2;
-      if (prewalked) {
+      if (prewalked == 2 && h->F.fast_ok && h->F.tree_ok && !h->hyper) prewalked = 3;  // no walk at all (fw_order_kernel, fw_tree_kernel)
+      if (prewalked == 3) {
+        e = h->timed(TNCO_KIND_FW_WALK, [&]() {
+#define CALL_FWO(LL, KK) launch_fw_order_lk<LL, KK>(h)
+          DISPATCH_LK(h, CALL_FWO)
+#undef CALL_FWO
+        });
+        if (e != hipSuccess) return e;
+      } else if (prewalked) {
         e = h->timed(TNCO_KIND_FW_WALK, [&]() { launch_fw_walk(h, prewalked == 2); });
         if (e != hipSuccess) return e;
       }
-      if (h->F.fast_ok && prewalked == 2 && !h->hyper) h->fw_delta_reslices += 1;
+      if (h->F.fast_ok && prewalked >= 2 && !h->hyper) h->fw_delta_reslices += 1;
       e = h->timed(TNCO_KIND_FW_RESLICE, [&]() {
 #define CALL_FWS(LL, KK) launch_fw_reslice_lk<LL, KK>(h, prewalked)
         DISPATCH_LK(h, CALL_FWS)
@@ -172,7 +180,7 @@ hipError_t launch_fw_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, 
 __global__ void finish_init_kernel(Params P, const double* sum, const double* total) {
   const int64_t r = blockIdx.x;
   const int n = P.n;
-  const uint8_t* blk = P.blocks + r * (int64_t)(n - 1) * P.BS;
+  const uint8_t* blk = P.blocks + r * P.RB;
   const int32_t* lp = P.lpar + r * (int64_t)n * LPS;
   Links* ml = P.minlinks + r * (int64_t)P.N;
   for (int i = threadIdx.x; i < P.N; i += blockDim.x) {
@@ -551,6 +559,13 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       P.BS = P.hoff + (8 * W + 127) / 128 * 128;
     }
   }
+  P.WS = P.BS; P.WOFF = 32; P.RB = (int64_t)(n - 1) * P.BS;
+  if (fw && !h->hyper && !std::getenv("TNCO_HIP_FW_UNIFIED")) {  // split layout (sa_kernels.h, Params)
+    P.BS = 32;
+    P.WS = (8 * W + 63) / 64 * 64;
+    P.WOFF = ((n - 1) * 32 + 127) / 128 * 128;
+    P.RB = ((int64_t)P.WOFF + (int64_t)(n - 1) * P.WS + 127) / 128 * 128;
+  }
   P.f32 = f32; P.disable_shared = d->disable_shared_inds ? 1 : 0;
   P.cost_mode = uniform ? (pow2u ? 0 : 1) : 2;
   if (!uniform) {  // per-index dims, all powers of two: exponent classes only, no leg loop
@@ -819,6 +834,12 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       HIP_TRY(hipMemset(F.slowstat, 0, 8));
       F.fast_ok = 1;
       h->fw_delta_capable = h->fw_delta_on = true;
+      // ... without any walk over the tree when the headers are one array per replica (split layout), no leaf is too
+      // wide (set below) and a lane of fw_tree_kernel can hold its share of the nodes
+      F.tree_ok = (P.BS == 32 && n - 1 <= 64 * FWT_JMAX && !std::getenv("TNCO_HIP_FW_NO_TREE")) ? 1 : 0;
+#ifdef TNCO_PROFILE  // (the stage counters live in the single re-slice kernel)
+      F.tree_ok = 0;
+#endif
     }
     F.stack_cap = FW_LDSPOS;
     if (const char* e = std::getenv("TNCO_HIP_FW_STACK")) F.stack_cap = std::max(0, std::min(FW_LDSPOS, std::atoi(e)));
@@ -850,6 +871,14 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       HIP_TRY(hipMemcpyAsync(&a1, any, 4, hipMemcpyDeviceToHost, h->stream));
       HIP_TRY(h->sync_all());
       F.leaf_wide = a1 ? 1 : 0;
+      if (F.leaf_wide) F.tree_ok = 0;
+      if (F.tree_ok) {
+        bool ok = false;
+#define CALL_FWP(LL, KK) ok = fw_tree_prepare_lk<LL, KK>(h)
+        DISPATCH_LK(h, CALL_FWP)
+#undef CALL_FWP
+        if (!ok) F.tree_ok = 0;
+      }
     }
     // rows of W words (one shared, or one per replica) -> rows of L words on the device, zero-padded
     auto upload_rows = [&](const uint64_t* src, uint64_t** dst) -> int {
@@ -1228,7 +1257,7 @@ int tnco_hip_get_tree(tnco_hip_handle h, int64_t r, int which, int32_t* left, in
       NodeRec hd;
       std::memcpy(&hd, b, sizeof(hd));
       left[p] = hd.left; right[p] = hd.right; parent[p] = hd.parent;
-      if (masks) std::memcpy(masks + (size_t)p * W, b + 32, (size_t)W * 8);
+      if (masks) std::memcpy(masks + (size_t)p * W, blk.data() + (size_t)h->P.WOFF + (size_t)(p - n) * h->P.WS, (size_t)W * 8);
     }
   } else {
     // best tree = checkpoint + rotations jlog[0, jmin): Tree::swap_with_nn replayed on the host
