@@ -137,6 +137,13 @@ int tnco_hip_get_slices(tnco_hip_handle h, int64_t replica, uint64_t* slices, ui
 int tnco_hip_get_slices_many(tnco_hip_handle h, int64_t k, const int64_t* replicas, uint64_t* slices,
                              uint64_t* min_slices);
 
+/* Diagnostics of the LAST re-slice of every replica (no reference counterpart; tests pick the replicas whose
+ * re-slice took a rare path and compare exactly those with the oracle): how[r] = 1 the cost cache was re-priced
+ * (fw_tree_kernel / fw_delta_kernel), 0 it was rebuilt in full (or the replica has no slices); n_changed[r] = indices
+ * by which the proposed slices differed from the current ones (-1: not recorded -- the single-kernel form, or more
+ * than the re-pricing handles).  Either may be NULL.  EINVAL for a handle without re-pricing. */
+int tnco_hip_get_reslice_info(tnco_hip_handle h, int32_t* how, int32_t* n_changed);
+
 int tnco_hip_sync(tnco_hip_handle h);
 
 /* total_cost / min_total_cost properties (optimizer.hpp:253-257) of every

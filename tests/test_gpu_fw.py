@@ -297,3 +297,75 @@ def test_fw_form_of_the_reslice_chosen_per_call(core, monkeypatch):
     for (ca, sa) in out[1:]:
         assert np.array_equal(out[0][0][0], ca[0]) and np.array_equal(out[0][0][1], ca[1])
         assert np.array_equal(out[0][1][0], sa[0]) and np.array_equal(out[0][1][1], sa[1])
+
+
+def test_config5_from_the_reference_starts_at_scale_against_the_oracle(core, oracle_lib, monkeypatch):
+    """What bench.py's finite-width leg runs -- the config-5 topology from DEVICE-drawn greedy starts, the
+    re-slice without a walk (fw_order_kernel | get_slices | fw_tree_kernel) -- against the oracle: 32 768
+    replicas x 40 sweeps (re-slices at sweeps 0, 10, 20, 30), then every replica whose re-slice took a rare
+    path at one of them (rebuilt in full although it has slices; more than 32 changed indices: the second
+    pass over the paths) and 64 others, compared in full: trees, best trees, caches, slices, PRNG."""
+    from tnco_amd import synthetic as syn
+    orc = oracle_lib
+    monkeypatch.delenv("TNCO_HIP_FW_DELTA", raising=False)
+    monkeypatch.delenv("TNCO_HIP_FW_NO_DELTA", raising=False)
+    monkeypatch.delenv("TNCO_HIP_FW_NO_TREE", raising=False)
+    R = 32768
+    p = syn.sycamore_problem(20)
+    seeds = np.asarray(syn.replica_seeds(R))
+    links = core.greedy_trees(p.ts_inds, p.n_inds, seeds, device=0)
+    betas = H.linear_betas(0, 100, 1200)[:40]
+    rare = set()
+    with core.BatchedOptimizer(p.leaf_masks, links, seeds, n_inds=p.n_inds, max_width=40) as gpu:
+        for c in (1, 10, 10, 10, 9):  # every chunk but the last ends right after a re-slicing sweep
+            lo = gpu._steps_done
+            gpu.run(betas[lo:lo + c], update_slices_every=10)
+            if lo + c < 40:
+                how, nch = gpu.reslice_info()
+                has = gpu.slices_many(np.arange(R))[0].any(axis=1)
+                rare |= set(np.nonzero((how == 0) & has)[0].tolist())
+                rare |= set(np.nonzero(nch > 32)[0].tolist())
+                assert (nch >= 0).any()  # (the change lists were recorded: the walk-free form ran)
+        assert gpu.validate() == (0, -1)
+        rng = np.random.RandomState(5)
+        ids = sorted(rare)[:96] + [int(x) for x in rng.choice(R, 64, replace=False)]
+        tot, mn = gpu.costs()
+        for r in ids:
+            o = H.make_oracle(orc, p, links[r], seeds[r], max_width=40)
+            o.run(orc.PROB_MH, betas, update_slices_every=10)
+            H.assert_replica_equal(gpu, r, o)
+            assert tot[r] == o.total_cost and mn[r] == o.min_total_cost
+            assert all(np.array_equal(a, b) for a, b in zip(gpu.slices(r), o.slices()))
+    print(f"rare-path replicas compared: {len(rare)} found, {min(len(rare), 96)} compared")
+
+
+def test_config5_many_changed_indices_from_random_starts(core, oracle_lib, monkeypatch):
+    """Random (Kruskal) starts change many indices per re-slice early on: with the re-pricing pinned, replicas
+    with 33..64 changed indices (two passes over the paths) and with more (the full rebuild inside
+    fw_reslice_b_kernel, its own traverse) are all there; each kind against the oracle."""
+    from tnco_amd import synthetic as syn
+    orc = oracle_lib
+    monkeypatch.setenv("TNCO_HIP_FW_DELTA", "1")
+    R = 2048
+    p = syn.sycamore_problem(20)
+    seeds = np.asarray(syn.replica_seeds(R, S=9))
+    links = core.random_trees(p.ts_inds, p.n_inds, seeds)
+    betas = H.linear_betas(0, 100, 1200)[:21]
+    kinds = {"<=32": set(), "33..64": set(), "rebuilt": set()}
+    with core.BatchedOptimizer(p.leaf_masks, links, seeds, n_inds=p.n_inds, max_width=40) as gpu:
+        for c in (1, 10, 10):
+            lo = gpu._steps_done
+            gpu.run(betas[lo:lo + c], update_slices_every=10)
+            how, nch = gpu.reslice_info()
+            kinds["<=32"] |= set(np.nonzero((how == 1) & (nch >= 0) & (nch <= 32))[0].tolist())
+            kinds["33..64"] |= set(np.nonzero((how == 1) & (nch > 32))[0].tolist())
+            kinds["rebuilt"] |= set(np.nonzero(how == 0)[0].tolist())
+        assert gpu.validate() == (0, -1)
+        assert all(kinds.values()), {k: len(v) for k, v in kinds.items()}
+        tot, mn = gpu.costs()
+        for r in [x for v in kinds.values() for x in sorted(v)[:12]]:
+            o = H.make_oracle(orc, p, links[r], seeds[r], max_width=40)
+            o.run(orc.PROB_MH, betas, update_slices_every=10)
+            H.assert_replica_equal(gpu, r, o)
+            assert tot[r] == o.total_cost and mn[r] == o.min_total_cost
+            assert all(np.array_equal(a, b) for a, b in zip(gpu.slices(r), o.slices()))

@@ -312,6 +312,32 @@ def test_c3_full_size_properties(core, oracle_lib):
     assert np.all(tot2 <= tot) and np.all(mn2 <= mn) and gpu.validate() == (0, -1)
 
 
+def test_c3_full_size_from_the_reference_starts(core, oracle_lib):
+    """BASELINE config 3 as bench.py runs it: 65 536 replicas from DEVICE-drawn greedy starts (the reference's
+    recipe, tnco/utils/tn.py:189-230), stepped in chunks through the handle's two streams (the split of every
+    step over two launches, tnco_hip_run): 64 replicas spread over both halves of the batch against the oracle,
+    bit for bit, the best costs of 4 096 more, every replica valid."""
+    prob = H.regular_problem(512, graph_seed=11)
+    R = 65536
+    seeds = H.replica_seeds(R)
+    links = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds, device=0)
+    betas = H.linear_betas(0, 100, 1200)[:150]
+    with core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds) as gpu:
+        for lo in range(0, 150, 50):
+            gpu.run(betas[lo:lo + 50])
+        assert gpu.validate() == (0, -1)
+        tot, mn = gpu.costs()
+        rng = np.random.RandomState(3)
+        for r in sorted(int(x) for x in rng.choice(R, 64, replace=False)) + [0, R // 2 - 1, R // 2, R - 1]:
+            o = H.make_oracle(oracle_lib, prob, links[r], seeds[r])
+            o.run(oracle_lib.PROB_MH, betas)
+            H.assert_replica_equal(gpu, r, o)
+            assert tot[r] == o.total_cost and mn[r] == o.min_total_cost
+        _dt, _t, omn, _mv = oracle_lib.run_batch(links[30000:34096], prob.leaf_masks, seeds[30000:34096], betas,
+                                                 n_inds=prob.n_inds, dims=2)
+        assert np.array_equal(omn, mn[30000:34096])
+
+
 def test_prng_state_string_is_libstdcxx_text(core):
     """`prng_state` (optimize/optimizer.hpp:191-195) is the text libstdc++ streams for the generator:
     compared with the strings the REAL std::mt19937 of the build image printed

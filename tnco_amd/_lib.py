@@ -52,7 +52,7 @@ class Desc(C.Structure):
 
 
 EXPORTS = [
-    "tnco_hip_create", "tnco_hip_run", "tnco_hip_run_fw", "tnco_hip_get_slices", "tnco_hip_get_slices_many", "tnco_hip_sync", "tnco_hip_get_costs", "tnco_hip_get_tree",
+    "tnco_hip_create", "tnco_hip_run", "tnco_hip_run_fw", "tnco_hip_get_slices", "tnco_hip_get_slices_many", "tnco_hip_get_reslice_info", "tnco_hip_sync", "tnco_hip_get_costs", "tnco_hip_get_tree",
     "tnco_hip_get_caches", "tnco_hip_validate", "tnco_hip_get_prng", "tnco_hip_set_prng", "tnco_hip_get_prng_many", "tnco_hip_set_prng_many",
     "tnco_hip_best", "tnco_hip_min_cost_device", "tnco_hip_get_trees", "tnco_hip_linear_paths", "tnco_hip_linear_paths_ssa", "tnco_hip_get_counters", "tnco_hip_get_moves", "tnco_hip_get_full_copies",
     "tnco_hip_kernel_time", "tnco_hip_kernel_times", "tnco_hip_get_stage_cycles",
@@ -95,6 +95,7 @@ def load() -> C.CDLL:
     L.tnco_hip_run_fw.argtypes = [vp, C.c_int, vp, i64, i64, i64]
     L.tnco_hip_get_slices.argtypes = [vp, i64, vp, vp]
     L.tnco_hip_get_slices_many.argtypes = [vp, i64, vp, vp, vp]
+    L.tnco_hip_get_reslice_info.argtypes = [vp, vp, vp]
     L.tnco_hip_sync.argtypes = [vp]
     L.tnco_hip_get_costs.argtypes = [vp, vp, vp]
     L.tnco_hip_get_tree.argtypes = [vp, i64, C.c_int, vp, vp, vp, vp]

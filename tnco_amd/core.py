@@ -349,6 +349,14 @@ class BatchedOptimizer:
         _lib.check(self._L.tnco_hip_get_slices_many(self._h, len(ids), _ptr(ids), _ptr(a), _ptr(b)))
         return a, b
 
+    def reslice_info(self):
+        """(how, n_changed) of every replica's LAST re-slice (diagnostics, tnco_hip_get_reslice_info): how = 1
+        re-priced, 0 rebuilt in full / no slices; n_changed = indices the proposal differed by (-1 unknown)."""
+        how = np.empty(self.n_replicas, np.int32)
+        nch = np.empty(self.n_replicas, np.int32)
+        _lib.check(self._L.tnco_hip_get_reslice_info(self._h, _ptr(how), _ptr(nch)))
+        return how, nch
+
     def update(self, beta: float = 0.0, prob="mh") -> None:
         self.run([beta], prob)
 

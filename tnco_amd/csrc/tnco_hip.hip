@@ -1164,6 +1164,22 @@ int tnco_hip_get_slices(tnco_hip_handle h, int64_t r, uint64_t* slices, uint64_t
   return TNCO_HIP_OK;
 }
 
+int tnco_hip_get_reslice_info(tnco_hip_handle h, int32_t* how, int32_t* n_changed) {
+  if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
+  if (!h->fw || !h->F.fastflag) return fail(TNCO_HIP_EINVAL, "handle has no re-pricing re-slice.");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(h->sync_all());
+  const int64_t R = h->P.R;
+  if (how) HIP_TRY(hipMemcpy(how, h->F.fastflag, (size_t)R * 4, hipMemcpyDeviceToHost));
+  if (n_changed) {  // word 0 of every replica's change list (fw_reslice_a_kernel), 512 bytes apart
+    if (h->F.tree_ok)
+      HIP_TRY(hipMemcpy2D(n_changed, 4, h->F.delta_scr, 512, 4, (size_t)R, hipMemcpyDeviceToHost));
+    else
+      for (int64_t r = 0; r < R; ++r) n_changed[r] = -1;
+  }
+  return TNCO_HIP_OK;
+}
+
 int tnco_hip_kernel_time(tnco_hip_handle h, double* ms, int64_t* launches, int reset) {
   if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
   HIP_TRY(hipSetDevice(h->device));
