@@ -65,10 +65,11 @@ def kernel_of(name: str):
     for short in ("fw_move_kernel", "fw_reslice_kernel", "fw_walk_kernel"):
         if short in name:
             return short
-    if "fw_walk2_kernel" in name:  # (the walk from both ends of the post-order: the default walk kernel)
+    if "fw_walk2_kernel" in name or "fw_order_kernel" in name:  # (what lists the too-wide tensors in post-order)
         return "fw_walk_kernel"
-    if "fw_reslice_a_kernel" in name or "fw_delta_kernel" in name or "fw_reslice_b_kernel" in name:
-        return "fw_reslice_kernel"  # (the re-slice by re-pricing: get_slices | fw_delta_kernel | end of the sweep)
+    if ("fw_reslice_a_kernel" in name or "fw_delta_kernel" in name or "fw_tree_kernel" in name
+            or "fw_reslice_b_kernel" in name):
+        return "fw_reslice_kernel"  # (the re-slice by re-pricing: get_slices | fw_tree_kernel | end of the sweep)
     return None
 
 
@@ -81,6 +82,15 @@ def algorithmic_bytes_per_move_fw(W: int, a: float, q: float) -> float:
     """The same move of the finite-width optimizer: + the slices mask read
     (8W, finite_width/greedy/optimizer.hpp:177,191-193) + the cached width written on accept (4a, :216)."""
     return algorithmic_bytes_per_move(W, a, q) + 8 * W + 4 * a
+
+
+def algorithmic_bytes_per_reslice_repriced(n: int) -> float:
+    """The re-slice in its re-priced form (no leg mask is read): the width cache (4N) and
+    node links (12 per internal node) read by get_slices' ordering, and per internal node the old cost (8) and
+    the two children's partial sums (16) read by the re-pricing.  The (cost, partial) pairs a KEPT re-slice
+    writes back (16 per node, 25-55 % of the re-slices) and the too-wide tensors' masks are left out."""
+    N = 2 * n - 1
+    return 4 * N + (n - 1) * (12 + 8 + 16)
 
 
 def algorithmic_bytes_per_reslice(n: int, W: int) -> float:
@@ -205,6 +215,13 @@ class Leg:
         c1 = opt.counters()
         kt = opt.kernel_times_ms()
         d = {k: c1[k] - c0[k] for k in c1}
+        self.groups = opt.launch_groups
+        self.repriced = False
+        if self.kind == "fw":
+            try:
+                self.repriced = bool((opt.reslice_info()[1] >= 0).any())
+            except ValueError:
+                pass
         return dict(dt=dt, best=best, kt=kt, **d)
 
 
@@ -215,7 +232,10 @@ def reduce_legs(res, world, dist, torch, grouped=None):
     mine = [res["dt"], float(res["moves"]), float(res["accepted"]), float(res["random_picks"]),
             float(res["improved"]), float(res["full_copies"])] + [res["kt"][k][0] for k in names]
     per_rank = [mine]
-    if world > 1 if grouped is None else grouped:
+    from tnco_amd import parallel
+    if (world > 1 if grouped is None else grouped) and parallel._native is not None:
+        per_rank = [[float(x) for x in v] for v in parallel._native.allgather_array(np.array(mine, np.float64))]
+    elif world > 1 if grouped is None else grouped:
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
         t = torch.tensor(mine, dtype=torch.float64, device=dev)
         allv = [torch.empty_like(t) for _ in range(world)]
@@ -277,8 +297,12 @@ def pmc_passes(args, lib_version):
     res = {"library": lib_version, "seconds": None, "kernels": {}}
     for (short, ctr), v in vals.items():
         n = per_step[short]
-        if len(v) == 3 * n * (args.warmup + args.steps):
-            n *= 3  # (the re-slice by re-pricing is three dispatches: get_slices | fw_delta_kernel | end of the sweep)
+        for mult in (1, 2, 3, 4):
+            # (a step of the headline leg is two concurrent dispatches when the handle splits it over two streams; the
+            #  re-slice by re-pricing is three: get_slices | fw_tree_kernel | end of the sweep)
+            if len(v) == mult * n * (args.warmup + args.steps):
+                n *= mult
+                break
         timed = v[args.warmup * n:(args.warmup + args.steps) * n]  # the timed steps' dispatches
         if len(timed) != args.steps * n:
             continue
@@ -353,34 +377,61 @@ def main() -> None:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
 
-    import torch
-    import torch.distributed as dist
-    # test knob (tests/test_gpu_two_ranks.py): a launch of ONE rank goes through the process group too -- RCCL
-    # initialised next to the library, the reduction fed from device memory, the all-gathers -- on a 1-GPU box
+    # N > 1 (or TNCO_BENCH_FORCE_GROUP, the test of a group of ONE rank on a 1-GPU box): the ranks talk through RCCL bound
+    # inside libtnco_hip.so (tnco_amd/parallel.py NativeComm: this process then holds ONE HIP runtime, torch is only the
+    # launcher); TNCO_BENCH_COMM=torch, or a failure to set that up, goes through torch.distributed ("nccl" = RCCL in
+    # PyTorch's bundled runtime) as rounds 1-2 did; TNCO_BENCH_SHARE_GPU (tests: N ranks on one GPU) through gloo.
+    from tnco_amd import parallel
     grouped = world > 1 or bool(os.environ.get("TNCO_BENCH_FORCE_GROUP"))
+    torch = dist = None
+    comm_kind, comm_note = None, None
     if grouped:
+        # RCCL prints a version banner on the C-level stdout, flushed when the process ends -- after the JSON line.  The
+        # line must be the only thing on stdout: everything written to file descriptor 1 from here on goes to stderr,
+        # Python's own sys.stdout keeps the real one.
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
+        sys.stdout = os.fdopen(real_stdout, "w")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if os.environ.get("TNCO_BENCH_SHARE_GPU"):
-            # test knob (tests/test_gpu_two_ranks.py): N ranks on ONE GPU over gloo -- the N > 1 code of this
-            # file on a 1-GPU box; RCCL needs a GPU per rank and is what the driver's scaling run uses
-            local_rank = 0
-            torch.cuda.set_device(0)
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        want = "gloo" if os.environ.get("TNCO_BENCH_SHARE_GPU") else os.environ.get("TNCO_BENCH_COMM", "native")
+        if want == "native":
+            try:
+                parallel.init_native(rank, world, local_rank)
+                comm_kind = "rccl (librccl.so bound inside libtnco_hip.so)"
+            except Exception as e:  # noqa: BLE001 -- reported in the line; the run goes on through torch.distributed
+                comm_note = f"native communicator failed ({e!r}): torch.distributed instead"
+                want = "torch"
+        if want != "native":
+            import torch
+            import torch.distributed as dist
+            if want == "gloo":
+                # test knob (tests/test_gpu_two_ranks.py): N ranks on ONE GPU over gloo -- the N > 1 code of this
+                # file on a 1-GPU box; RCCL needs a GPU per rank and is what the driver's scaling run uses
+                local_rank = 0
+                torch.cuda.set_device(0)
+                dist.init_process_group("gloo")
+            else:
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            comm_kind = f"torch.distributed {dist.get_backend()}"
+    else:
+        import torch  # (one rank: nothing to exchange; torch only for the contract's torch.cuda.synchronize())
 
     from tnco_amd import _lib
     lib_version = _lib.load().tnco_hip_version().decode()
 
     def barrier(opt):
         opt.sync()
-        torch.cuda.synchronize()
-        if grouped:
+        if torch is not None:
+            torch.cuda.synchronize()
+        if parallel._native is not None:
+            parallel._native.barrier()
+        elif grouped:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -397,12 +448,16 @@ def main() -> None:
             leg.opt = None
 
     devices = None
-    if grouped:  # what RCCL saw: one entry per rank
-        props = torch.cuda.get_device_properties(local_rank)
-        me = dict(rank=rank, local_rank=local_rank, device=props.name, uuid=str(getattr(props, "uuid", "")),
-                  backend=dist.get_backend())
-        devices = [None] * world
-        dist.all_gather_object(devices, me)
+    if grouped:  # what the communicator saw: one entry per rank
+        import ctypes
+        nm = ctypes.create_string_buffer(256)
+        _lib.load().tnco_hip_device_name(local_rank, nm, 256)
+        me = dict(rank=rank, local_rank=local_rank, device=nm.value.decode(), backend=comm_kind)
+        if parallel._native is not None:
+            devices = parallel._native.allgather_object(me)
+        else:
+            devices = [None] * world
+            dist.all_gather_object(devices, me)
 
     if rank == 0:
         R, sps, every = args.replicas, args.sweeps_per_step, args.fw_update_slices
@@ -439,11 +494,15 @@ def main() -> None:
             else:
                 kernels = tuple(k for k in ("fw_move_kernel", "fw_reslice_kernel", "fw_walk_kernel") if kt[k][1] > 0)
                 bmove = algorithmic_bytes_per_move_fw(prob.W, a, q)
-                bres = algorithmic_bytes_per_reslice(prob.n, prob.W)
+                # (the full CostCache rebuild is credited only when it is what ran: VERDICT r02)
+                bres = (algorithmic_bytes_per_reslice_repriced(prob.n) if leg.repriced
+                        else algorithmic_bytes_per_reslice(prob.n, prob.W))
                 n_res = FW_RESLICE_LAUNCHES(sps, every) * R
                 alg_per_step = bmove * moves_per_step_gpu + bres * n_res
                 extra = {"algorithmic_bytes_per_move": bmove, "algorithmic_bytes_per_reslice": bres,
-                         "reslices_per_step": n_res}
+                         "reslice_form": ("re-priced: fw_order_kernel | get_slices | fw_tree_kernel (no walk, no leg mask read)"
+                                          if leg.repriced else "full CostCache rebuild"),
+                         "reslices_per_step": n_res, "algorithmic_bytes_moves_only": bmove * moves_per_step_gpu}
             step_ms = sum(kt[k][0] for k in kernels) / args.steps  # device time of one step's kernels
             achieved = alg_per_step / (step_ms / 1e3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -453,6 +512,16 @@ def main() -> None:
                     "note": "achieved/frac are the contract's ALGORITHMIC bytes (SURVEY 8(d), no caching credit) / "
                             "device time; traffic_frac (PMC bytes) and request_rate_frac (fabric requests vs the "
                             "47e9/s random-request ceiling, tools/hbm_random.hip) say what binds the kernel"}
+            if kind == "fw":  # the moves' bytes alone over the leg's device time, and over the move kernel's
+                roof["frac_moves_only"] = extra["algorithmic_bytes_moves_only"] / (step_ms / 1e3) / 1e9 / HBM_PEAK_GBS
+                roof["frac_move_kernel"] = (extra["algorithmic_bytes_moves_only"] / (kt["fw_move_kernel"][0] / args.steps / 1e3)
+                                            / 1e9 / HBM_PEAK_GBS)
+            elif leg.groups > 1:
+                roof["sub_launches_per_step"] = leg.groups
+                roof["note_streams"] = (f"a step is {leg.groups} concurrent launches of sa_run_kernel over half of the replicas "
+                                        "each, on two streams (no idle tail: 1024 blocks for 768 resident ones); avg_launch_ms = "
+                                        "device time from the first launch of the timed region to the end of the last / steps -- "
+                                        "in a kernel trace every sub-launch lasts about that long, two at a time")
             roof["kernels"] = {k: {"ms_per_step": kt[k][0] / args.steps, "launches_per_step": kt[k][1] / args.steps}
                                for k in kernels}
             if pmc is not None:
@@ -527,13 +596,18 @@ def main() -> None:
             out["cpu_baseline"] = head["cpu_baseline"]
         if devices is not None:
             out["config"]["devices"] = devices
+            if comm_note:
+                out["config"]["comm_note"] = comm_note
         for kind in legs[1:]:
             out[kind] = leg_object(kind)
         print(json.dumps(out), flush=True)
     for leg in objs.values():
         if leg.opt is not None:
             leg.opt.close()
-    if grouped:
+    if parallel._native is not None:
+        parallel._native.barrier()
+        parallel.shutdown_native()
+    elif grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -224,14 +224,21 @@ int tnco_hip_get_moves(tnco_hip_handle h, uint64_t* moves_per_replica);
 int tnco_hip_get_stage_cycles(tnco_hip_handle h, uint64_t* out5);
 
 /* Device time of the kernels launched by tnco_hip_run / tnco_hip_run_fw since the last reset (HIP
- * events on the handle's stream around every kernel launch), and the number of schedule chunks
- * launched (one per call unless the schedule is very long). */
+ * events on the handle's streams), and the number of schedule chunks launched (one per call unless the
+ * schedule is very long).  A handle that splits its steps over two streams (tnco_hip_launch_groups() > 1)
+ * reports the time from the first launch after the reset to the end of the last one: its concurrent
+ * launches overlap, their durations do not add up. */
 int tnco_hip_kernel_time(tnco_hip_handle h, double* ms, int64_t* launches, int reset);
 /* The same time split by kernel: [0] sa_run_kernel (Optimizer::update, infinite memory),
- * [1] fw_move_kernel (finite_width/greedy/optimizer.hpp:130-331), [2] fw_reslice_kernel
- * (:359-389), [3] fw_walk_kernel (the traverse of get_slices, greedy/utils.hpp:62); launches4 =
- * kernel launches of each.  Either array ([4]) may be NULL. */
+ * [1] the moves of the finite-width optimizer (finite_width/greedy/optimizer.hpp:130-331), [2] its re-slice
+ * (:359-389: get_slices, the cost cache rebuilt or re-priced, the end of the sweep), [3] what orders the too-wide
+ * tensors for get_slices (greedy/utils.hpp:62: the walk kernels, or fw_order_kernel); launches4 = launches of
+ * each.  Either array ([4]) may be NULL. */
 int tnco_hip_kernel_times(tnco_hip_handle h, double* ms4, int64_t* launches4, int reset);
+
+/* Concurrent launches a step of tnco_hip_run is split into (1, or 2 when the replicas do not fill whole rounds of
+ * resident workgroups: see tnco_hip_run). */
+int tnco_hip_launch_groups(tnco_hip_handle h);
 
 /* Bytes of device memory held by the handle. */
 int64_t tnco_hip_device_bytes(tnco_hip_handle h);
@@ -292,6 +299,28 @@ void tnco_hip_greedy_device_release(void);
 /* diagnostics: trees of the last device call that the host version did (-1: the whole batch) */
 int64_t tnco_hip_greedy_device_redone(void);
 
+/*
+ * The exchange between the GPUs of one node -- replaces what little tnco/parallel.py:330-341 moves between its worker
+ * processes (the results; here: the best cost, the heads of the result lists).  One process per GPU; RCCL over xGMI,
+ * loaded with dlopen from the ROCm installation, i.e. on this library's own HIP runtime.  Rendezvous: rank 0 calls
+ * tnco_hip_comm_unique_id and hands the 128 bytes to the other ranks by any means (tnco_amd/parallel.py: a file named
+ * after the torchrun environment); then every rank calls tnco_hip_comm_init (collective).
+ */
+typedef struct tnco_hip_comm_s* tnco_hip_comm;
+int tnco_hip_comm_unique_id(uint8_t* id128);
+int tnco_hip_comm_init(int rank, int world, const uint8_t* id128, int device, tnco_hip_comm* out);
+void tnco_hip_comm_destroy(tnco_hip_comm c);
+/* min over the ranks of the best min_total_cost (replaces `sorted(results)[0]`, sa.py:257, across GPUs): the handle's
+ * replicas are reduced on the device straight into the operand of ncclAllReduce(ncclMin) -- 8 bytes over xGMI, no host
+ * round trip before the collective.  h == NULL: `local` is this rank's value instead. */
+int tnco_hip_comm_allreduce_min(tnco_hip_comm c, tnco_hip_handle h, double local, double* out_min);
+/* every rank's `bytes` bytes to every rank, in rank order: recv holds world * bytes */
+int tnco_hip_comm_allgather(tnco_hip_comm c, const void* send, void* recv, uint64_t bytes);
+int tnco_hip_comm_barrier(tnco_hip_comm c);
+const char* tnco_hip_comm_last_error(void);
+
+/* "name|pci ...|uuid ...|N CUs" of a device: what a multi-GPU bench line lists per rank */
+int tnco_hip_device_name(int device, char* buf, int cap);
 int tnco_hip_device_count(void);
 const char* tnco_hip_last_error(void);
 const char* tnco_hip_version(void);

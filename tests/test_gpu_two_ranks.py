@@ -101,27 +101,62 @@ def test_bench_line_of_a_two_rank_launch():
 
 @pytest.mark.timeout(600)
 def test_bench_line_through_rccl_group_of_one():
-    """The RCCL side of bench.py on a 1-GPU box: a launch of one rank that still goes through the process
-    group (TNCO_BENCH_FORCE_GROUP) -- RCCL initialised on the device before the library loads, the best
-    cost reduced on the device into the tensor the all-reduce runs on, barriers and all-gathers on
-    device tensors -- gives the line of the plain launch."""
+    """The RCCL side of bench.py on a 1-GPU box: a launch of one rank that still goes through the communicator
+    (TNCO_BENCH_FORCE_GROUP) -- natively (RCCL bound inside libtnco_hip.so: no torch in the process, the best cost
+    reduced on the device into the all-reduce's operand, barriers and all-gathers through the library) and, as
+    rounds 1-2 did, through torch.distributed's "nccl" -- gives the line of the plain launch either way."""
     import json
     import subprocess
     tail = [str(ROOT / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--replicas", "2048",
             "--sweeps-per-step", "20", "--pmc", "0", "--cpu-sample", "0"]
     lines = []
-    for extra in ({"TNCO_BENCH_FORCE_GROUP": "1", "MASTER_PORT": str(_free_port())}, {}):
+    for extra in ({"TNCO_BENCH_FORCE_GROUP": "1", "MASTER_PORT": str(_free_port())},
+                  {"TNCO_BENCH_FORCE_GROUP": "1", "MASTER_PORT": str(_free_port()), "TNCO_BENCH_COMM": "torch"}, {}):
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
         p = subprocess.run([sys.executable, *tail], capture_output=True, text=True, timeout=280, env=env, cwd=str(ROOT))
         assert p.returncode == 0, p.stderr[-2000:]
-        out = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-        assert len(out) == 1
-        lines.append(json.loads(out[0]))
-    grp, plain = lines
-    assert grp["n_gpus"] == 1 and len(grp["config"]["devices"]) == 1
-    assert grp["config"]["devices"][0]["backend"] == "nccl" and grp["config"]["devices"][0]["rank"] == 0
+        assert len(p.stdout.strip().splitlines()) == 1, p.stdout[-500:]  # ONE line on stdout, nothing else (RCCL's banner: stderr)
+        lines.append(json.loads(p.stdout))
+    grp, grp_torch, plain = lines
+    for g, backend in ((grp, "librccl.so bound inside libtnco_hip.so"), (grp_torch, "torch.distributed nccl")):
+        assert g["n_gpus"] == 1 and len(g["config"]["devices"]) == 1 and "comm_note" not in g["config"]
+        assert backend in g["config"]["devices"][0]["backend"] and g["config"]["devices"][0]["rank"] == 0
+        assert "CUs" in g["config"]["devices"][0]["device"]
     assert "devices" not in plain["config"]
-    for a, b in ((grp, plain), (grp["fw"], plain["fw"])):
+    for a, b in ((grp, plain), (grp["fw"], plain["fw"]), (grp_torch, plain), (grp_torch["fw"], plain["fw"])):
         assert [r["rank"] for r in a["config"]["ranks"]] == [0]
         assert a["config"]["ranks"][0]["moves"] == a["config"]["moves_timed"] == b["config"]["moves_timed"]
         assert a["config"]["best_log10_flops"] == b["config"]["best_log10_flops"]
+
+
+def test_native_communicator_of_one_rank():
+    """tnco_amd.parallel.NativeComm (csrc/host_comm.cpp) as a group of one: the collectives are RCCL's, on the library's
+    own HIP runtime -- min of a handle's replicas reduced on the device, array and object all-gathers, barrier.  Run in
+    a child process: it must work WITHOUT torch in the process."""
+    import subprocess
+    code = """
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from tnco_amd import core, parallel
+from tests import helpers as H
+assert 'torch' not in sys.modules
+c = parallel.NativeComm(0, 1, 0, port=%d)
+prob = H.regular_problem(32, graph_seed=2)
+seeds = H.replica_seeds(512)
+opt = core.BatchedOptimizer(prob.leaf_masks, prob.links(seeds), seeds, n_inds=prob.n_inds)
+opt.run(H.linear_betas(0, 50, 40))
+assert c.allreduce_min(opt) == opt.costs()[1].min() == opt.best(1)[0][0]
+assert c.allreduce_min(3.5) == 3.5
+a = np.arange(12, dtype=np.int32).reshape(3, 4)
+assert np.array_equal(c.allgather_array(a), a[None])
+assert c.allgather_object({'x': [1, 2, (3, 'y')]}) == [{'x': [1, 2, (3, 'y')]}]
+c.barrier()
+c.close()
+assert 'torch' not in sys.modules
+print('ok')
+""" % (str(ROOT), _free_port())
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=200,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=str(ROOT))
+    # (RCCL prints its version banner on stdout when the process ends)
+    assert p.returncode == 0 and "ok" in p.stdout.split(), p.stderr[-2000:]

@@ -56,9 +56,11 @@ EXPORTS = [
     "tnco_hip_get_caches", "tnco_hip_validate", "tnco_hip_get_prng", "tnco_hip_set_prng", "tnco_hip_get_prng_many", "tnco_hip_set_prng_many",
     "tnco_hip_best", "tnco_hip_min_cost_device", "tnco_hip_get_trees", "tnco_hip_linear_paths", "tnco_hip_linear_paths_ssa", "tnco_hip_get_counters", "tnco_hip_get_moves", "tnco_hip_get_full_copies",
     "tnco_hip_kernel_time", "tnco_hip_kernel_times", "tnco_hip_get_stage_cycles",
-    "tnco_hip_device_bytes", "tnco_hip_set_stream", "tnco_hip_destroy", "tnco_hip_random_trees", "tnco_hip_greedy_trees",
+    "tnco_hip_launch_groups", "tnco_hip_device_bytes", "tnco_hip_set_stream", "tnco_hip_destroy", "tnco_hip_random_trees", "tnco_hip_greedy_trees",
     "tnco_hip_greedy_trees_device", "tnco_hip_greedy_device_supported", "tnco_hip_greedy_device_redone", "tnco_hip_greedy_device_release", "tnco_hip_copy_to_host", "tnco_hip_greedy_cost_key",
-    "tnco_hip_device_count", "tnco_hip_last_error", "tnco_hip_version",
+    "tnco_hip_comm_unique_id", "tnco_hip_comm_init", "tnco_hip_comm_destroy", "tnco_hip_comm_allreduce_min", "tnco_hip_comm_allgather",
+    "tnco_hip_comm_barrier", "tnco_hip_comm_last_error",
+    "tnco_hip_device_name", "tnco_hip_device_count", "tnco_hip_last_error", "tnco_hip_version",
 ]
 
 _lib = None
@@ -116,6 +118,7 @@ def load() -> C.CDLL:
     L.tnco_hip_get_full_copies.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.tnco_hip_kernel_time.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.c_int]
     L.tnco_hip_kernel_times.argtypes = [vp, vp, vp, C.c_int]
+    L.tnco_hip_launch_groups.argtypes = [vp]
     L.tnco_hip_device_bytes.argtypes = [vp]
     L.tnco_hip_device_bytes.restype = i64
     L.tnco_hip_set_stream.argtypes = [vp, vp]
@@ -132,6 +135,15 @@ def load() -> C.CDLL:
     L.tnco_hip_greedy_device_release.restype = None
     L.tnco_hip_greedy_device_redone.argtypes = []
     L.tnco_hip_greedy_device_redone.restype = i64
+    L.tnco_hip_comm_unique_id.argtypes = [vp]
+    L.tnco_hip_comm_init.argtypes = [C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp)]
+    L.tnco_hip_comm_destroy.argtypes = [vp]
+    L.tnco_hip_comm_destroy.restype = None
+    L.tnco_hip_comm_allreduce_min.argtypes = [vp, vp, dbl, C.POINTER(dbl)]
+    L.tnco_hip_comm_allgather.argtypes = [vp, vp, vp, C.c_uint64]
+    L.tnco_hip_comm_barrier.argtypes = [vp]
+    L.tnco_hip_comm_last_error.restype = C.c_char_p
+    L.tnco_hip_device_name.argtypes = [C.c_int, vp, C.c_int]
     L.tnco_hip_device_count.restype = C.c_int
     L.tnco_hip_last_error.restype = C.c_char_p
     L.tnco_hip_version.restype = C.c_char_p

@@ -510,5 +510,11 @@ class BatchedOptimizer:
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
     @property
+    def launch_groups(self) -> int:
+        """Concurrent launches (streams) a step of run() is split into: 1, or 2 when the replicas do not fill
+        whole rounds of resident workgroups (tnco_hip_run)."""
+        return int(self._L.tnco_hip_launch_groups(self._h))
+
+    @property
     def device_bytes(self) -> int:
         return int(self._L.tnco_hip_device_bytes(self._h))

@@ -415,7 +415,7 @@ int fetch_rs(tnco_hip_handle h, std::vector<ReplicaState>& rs) {
 extern "C" {
 
 const char* tnco_hip_last_error(void) { return g_err.c_str(); }
-const char* tnco_hip_version(void) { return "tnco_hip 0.3 (gfx950), round 2"; }
+const char* tnco_hip_version(void) { return "tnco_hip 0.4 (gfx950), round 3"; }
 
 int tnco_hip_device_count(void) {
   int n = 0;
@@ -1205,6 +1205,8 @@ int tnco_hip_kernel_times(tnco_hip_handle h, double* ms4, int64_t* launches4, in
   if (reset) h->reset_times();
   return TNCO_HIP_OK;
 }
+
+int tnco_hip_launch_groups(tnco_hip_handle h) { return h ? h->n_groups : 0; }
 
 int64_t tnco_hip_device_bytes(tnco_hip_handle h) { return h ? h->bytes : 0; }
 

@@ -3,15 +3,141 @@
 Replaces tnco/parallel.py (joblib/loky process fan-out + SharedMemory buffers,
 /root/reference/tnco/parallel.py:111-368): replicas never interact, so rank k of
 `world` owns a contiguous block of the run list and the only exchange is the
-reduction of the best cost (RCCL all-reduce(min) over xGMI when the process
-group's backend is "nccl"; gloo in the CPU tests) plus a broadcast of the
-winning tree when a caller wants it.
+reduction of the best cost -- RCCL all-reduce(min) over xGMI -- plus the gather of
+the heads of the result lists.  Two transports behind the same functions: the
+NATIVE communicator (RCCL bound inside libtnco_hip.so, the default of a
+multi-process launch) and a torch.distributed process group (gloo in the CPU
+tests; nccl if a caller has initialised one).
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
+import pickle
+import socket
+import time
+
 import numpy as np
 
-__all__ = ["shard_bounds", "global_best", "global_winner"]
+__all__ = ["shard_bounds", "global_best", "global_winner", "NativeComm", "init_native", "shutdown_native"]
+
+
+class NativeComm:
+    """One rank of the node-wide communicator, on RCCL bound INSIDE libtnco_hip.so (csrc/host_comm.cpp:
+    dlopen of the ROCm installation's librccl.so, the HIP runtime the library itself links) -- nothing of
+    PyTorch in the process, no pointer between two HIP runtimes.  The 128-byte ncclUniqueId travels from
+    rank 0 to the others over a plain TCP socket on MASTER_ADDR : MASTER_PORT + 17 (`TNCO_COMM_PORT`
+    overrides), so a launch by `torch.distributed.run` needs torch for the launcher only."""
+
+    def __init__(self, rank: int, world: int, device: int, addr: str | None = None, port: int | None = None,
+                 timeout: float = 180.0):
+        from . import _lib
+        self._L = _lib.load()
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        self._h = None
+        addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(port or os.environ.get("TNCO_COMM_PORT") or int(os.environ.get("MASTER_PORT", "29533")) + 17)
+        uid = (C.c_uint8 * 128)()
+        if self.rank == 0:
+            self._check(self._L.tnco_hip_comm_unique_id(uid))
+            if self.world > 1:
+                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                srv.bind((addr, port))
+                srv.listen(self.world)
+                srv.settimeout(timeout)
+                try:
+                    for _ in range(self.world - 1):
+                        conn, _peer = srv.accept()
+                        with conn:
+                            conn.sendall(bytes(uid))
+                finally:
+                    srv.close()
+        else:
+            t0, data = time.monotonic(), b""
+            while len(data) < 128:
+                try:
+                    with socket.create_connection((addr, port), timeout=5.0) as c:
+                        data = b""
+                        while len(data) < 128:
+                            chunk = c.recv(128 - len(data))
+                            if not chunk:
+                                break
+                            data += chunk
+                except OSError:
+                    data = b""
+                if len(data) < 128:
+                    if time.monotonic() - t0 > timeout:
+                        raise RuntimeError(f"rank {self.rank}: no ncclUniqueId from rank 0 at {addr}:{port}")
+                    time.sleep(0.05)
+            C.memmove(uid, data, 128)
+        h = C.c_void_p()
+        self._check(self._L.tnco_hip_comm_init(self.rank, self.world, uid, self.device, C.byref(h)))
+        self._h = h
+
+    def _check(self, rc):
+        if rc:
+            raise RuntimeError(self._L.tnco_hip_comm_last_error().decode())
+
+    def close(self):
+        if self._h:
+            self._L.tnco_hip_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def barrier(self) -> None:
+        self._check(self._L.tnco_hip_comm_barrier(self._h))
+
+    def allreduce_min(self, opt_or_cost) -> float:
+        """min over the ranks; an optimizer handle is reduced on the device straight into the collective's operand."""
+        out = C.c_double(0.0)
+        if hasattr(opt_or_cost, "_h"):
+            self._check(self._L.tnco_hip_comm_allreduce_min(self._h, opt_or_cost._h, 0.0, C.byref(out)))
+        else:
+            self._check(self._L.tnco_hip_comm_allreduce_min(self._h, None, float(opt_or_cost), C.byref(out)))
+        return out.value
+
+    def allgather_array(self, a: np.ndarray) -> np.ndarray:
+        """[world, *a.shape]: equal shapes and dtypes on every rank."""
+        a = np.ascontiguousarray(a)
+        out = np.empty((self.world,) + a.shape, a.dtype)
+        self._check(self._L.tnco_hip_comm_allgather(self._h, a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                                    a.nbytes))
+        return out
+
+    def allgather_object(self, obj) -> list:
+        blob = np.frombuffer(pickle.dumps(obj), np.uint8)
+        sizes = self.allgather_array(np.array([len(blob)], np.int64))[:, 0]
+        pad = np.zeros(int(sizes.max()), np.uint8)
+        pad[:len(blob)] = blob
+        allb = self.allgather_array(pad)
+        return [pickle.loads(allb[k, :int(sizes[k])].tobytes()) for k in range(self.world)]
+
+
+_native: NativeComm | None = None
+
+
+def init_native(rank: int | None = None, world: int | None = None, device: int | None = None, **kw) -> NativeComm:
+    """The process-wide communicator (rank / world / device default to the torchrun environment)."""
+    global _native
+    if _native is None:
+        rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+        world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+        device = local_device() if device is None else device
+        _native = NativeComm(rank, world, device, **kw)
+    return _native
+
+
+def shutdown_native() -> None:
+    global _native
+    if _native is not None:
+        _native.close()
+        _native = None
 
 
 def shard_bounds(n_runs: int, world: int, rank: int) -> tuple[int, int]:
@@ -30,19 +156,24 @@ def _dist():
 
 
 def rank_world() -> tuple[int, int]:
-    """(rank, world) of the default process group, (0, 1) when torch.distributed is not in use."""
-    try:
+    """(rank, world): the native communicator's if there is one; else a torch.distributed group's (the gloo
+    tests, or a caller that initialised one); else, under a multi-process launch (WORLD_SIZE > 1 in the
+    environment), the native communicator is created; else (0, 1)."""
+    if _native is not None:
+        return _native.rank, _native.world
+    import sys
+    if "torch" in sys.modules:
         _torch, dist = _dist()
-    except ImportError:
-        return 0, 1
-    if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size()
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not os.environ.get("TNCO_COMM", "").startswith("torch"):
+        c = init_native()
+        return c.rank, c.world
     return 0, 1
 
 
 def local_device() -> int:
     """GPU ordinal of this rank: LOCAL_RANK under torchrun, else 0."""
-    import os
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
@@ -52,9 +183,12 @@ def merge_heads(local: list, k: int, rank: int, world: int) -> list:
     tnco/app/infinite_memory/sa.py:257)."""
     if world == 1:
         return sorted(local, key=lambda t: (t[0], t[1]))[:k]
-    _torch, dist = _dist()
-    gathered = [None] * world
-    dist.all_gather_object(gathered, local)
+    if _native is not None:
+        gathered = _native.allgather_object(local)
+    else:
+        _torch, dist = _dist()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, local)
     merged = [t for part in gathered for t in part]
     return sorted(merged, key=lambda t: (t[0], t[1]))[:k]
 
@@ -77,6 +211,8 @@ def global_best(opt_or_cost, rank: int = 0, world: int = 1, device: int = 0, gro
     is_opt = hasattr(opt_or_cost, "best")
     if not (world > 1 if grouped is None else grouped):
         return float(opt_or_cost.best(1)[0][0]) if is_opt else float(opt_or_cost)
+    if _native is not None:  # RCCL inside the library: the device-side minimum is the collective's operand
+        return _native.allreduce_min(opt_or_cost)
     torch, dist = _dist()
     dev = _tensor_device(dist, device)
     if is_opt and dev.type == "cuda" and hasattr(opt_or_cost, "min_cost_to_device"):
@@ -99,6 +235,12 @@ def global_winner(cost: float, global_id: int, payload: np.ndarray | None, rank:
     """
     if world == 1:
         return cost, global_id, payload
+    if _native is not None:
+        pairs = _native.allgather_array(np.array([cost, float(global_id)], np.float64))
+        best_cost, best_id, src = min((float(v[0]), int(v[1]), k) for k, v in enumerate(pairs))
+        if payload is not None:
+            payload = _native.allgather_array(np.ascontiguousarray(payload, np.int32))[src]
+        return best_cost, best_id, payload
     torch, dist = _dist()
     dev = _tensor_device(dist, device)
     mine = torch.tensor([cost, float(global_id)], dtype=torch.float64, device=dev)
