@@ -244,39 +244,6 @@ def test_invalid_inputs(core):
     core.BatchedOptimizer(lm, lk, [1], n_inds=3, disable_shared_inds=True).close()
 
 
-def test_lds_resident_small_tree_kernel(core, oracle_lib, monkeypatch):
-    """sa_small.h (opt-in, TNCO_HIP_SMALL=1): the whole tree of every replica in LDS for a launch --
-    same bits as the oracle on the config-2 topology, with launches of 1, 7 and 40 sweeps, and on a
-    100-leaf network (the 128-thread instantiation)."""
-    monkeypatch.setenv("TNCO_HIP_SMALL", "1")
-    for n, gs, R in ((64, 7, 96), (100, 3, 40), (10, 2, 70)):
-        prob = H.regular_problem(n, graph_seed=gs)
-        seeds = H.replica_seeds(R, S=n)
-        links = prob.links(seeds)
-        betas = H.linear_betas(0, 60, 48)
-        gpu = core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds)
-        gpu.run(betas[:1]); gpu.run(betas[1:8]); gpu.run(betas[8:])
-        tot, mn = gpu.costs()
-        for r in range(0, R, 3):
-            o = H.make_oracle(oracle_lib, prob, links[r], seeds[r])
-            o.run(oracle_lib.PROB_MH, betas)
-            H.assert_replica_equal(gpu, r, o)
-            assert tot[r] == o.total_cost and mn[r] == o.min_total_cost
-        assert gpu.validate() == (0, -1)
-
-
-def test_precision_too_low(core, oracle_lib):
-    """optimizer.hpp:77-84: a total cost whose log2 is not finite (here: float32 overflow on a
-    512-leaf random tree, costs ~2^150) is refused at construction, by the oracle and by the GPU path."""
-    prob = H.regular_problem(512, graph_seed=11)
-    seeds = H.replica_seeds(2)
-    links = prob.links(seeds)
-    with pytest.raises(ValueError, match="Precision is too low."):
-        H.make_oracle(oracle_lib, prob, links[0], seeds[0], cost_type="float32")
-    with pytest.raises(ValueError, match="Precision is too low."):
-        core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, cost_type="float32")
-
-
 def test_c3_full_size_properties(core, oracle_lib):
     """BASELINE config 3 at FULL size (512 leaves, 65 536 replicas): size-independent properties
     the reference's own tests assert (tests/test_utils.py:575-769) -- every replica is_valid() on the

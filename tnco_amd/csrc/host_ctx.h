@@ -9,7 +9,6 @@
 #include "sa_kernels.h"
 #include "sa_sweep.h"
 #include "fw_kernels.h"
-#include "sa_small.h"
 
 struct EventPair {
   hipEvent_t a, b;
@@ -32,7 +31,6 @@ struct tnco_hip_ctx {
   int64_t fw_delta_reslices = 0;  // re-slices launched in that mode since the count was read
   int fw_single_calls = 0;        // calls in the other mode since the last probe
   int fw_probe_wait = 4;          // ... before the next probe (doubles after a probe that failed)
-  bool small_tree = false;  // infinite memory, fast cost path, <= 2 mask words, <= 128 leaves: LDS-resident sweeps
   tnco::FwParams F{};
   std::vector<void*> allocs;
   int64_t bytes = 0;

@@ -19,9 +19,6 @@ static const void* run_kernel_ptr(const tnco_hip_ctx* h) {
 // Blocks of that kernel one CU holds at a time (its register budget decides: 3 at 512 leaves).
 template <int LOG2L, int K>
 int run_blocks_per_cu_lk(tnco_hip_ctx* h) {
-  if constexpr (LOG2L == 2 && K == 1) {
-    if (h->small_tree) return 0;
-  }
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, run_kernel_ptr<LOG2L, K>(h), 256, 0) != hipSuccess) {
     (void)hipGetLastError();
@@ -35,18 +32,6 @@ template <int LOG2L, int K>
 void launch_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, hipStream_t s, int block0,
                    int nblocks) {
   const Params& P = h->P;
-  if constexpr (LOG2L == 2 && K == 1) {
-    // small trees (BASELINE config 2): the replica's whole tree in LDS for the launch (sa_small.h)
-    if (h->small_tree) {
-      if (P.n - 1 <= 63)
-        hipLaunchKernelGGL((sa_small_kernel<63, 256>), dim3((unsigned)((P.R + 63) / 64)), dim3(256), 0, s, P, betas, n_steps,
-                           prob_kind);
-      else
-        hipLaunchKernelGGL((sa_small_kernel<127, 128>), dim3((unsigned)((P.R + 31) / 32)), dim3(128), 0, s, P, betas, n_steps,
-                           prob_kind);
-      return;
-    }
-  }
   const int gpb = 256 >> LOG2L;
   dim3 grid((unsigned)(nblocks >= 0 ? nblocks : (P.R + gpb - 1) / gpb));
   if (h->hyper) {

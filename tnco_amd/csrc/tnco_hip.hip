@@ -536,14 +536,6 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   const bool f32 = d->cost_dtype == TNCO_HIP_F32;
   const bool pow2u = uniform && (dim_u & (dim_u - 1)) == 0;
   h->generic = !(pow2u && !d->sparse_mask && !f32);
-  // small trees: every replica's whole tree in LDS during a launch (sa_small.h).  Opt-in
-  // (TNCO_HIP_SMALL=1): measured on BASELINE config 2 (64 leaves, 65536 replicas) it runs 6.8e9
-  // move-evals/s against 7.4e9 of the staged kernel -- LDS capacity (2.4 KB per replica) leaves one
-  // wavefront per SIMD, and 64 replicas per CU at ~0.5 us per move are no more moves per second than
-  // 192 replicas per CU at ~2 us (profiles/r02_small_trees.md).
-  h->small_tree = !fw && !h->hyper && !h->generic && W <= 2 && n - 1 <= SMALL_MAX_INTERNAL && LPS == 1 &&
-                  std::getenv("TNCO_HIP_SMALL") != nullptr && std::atoi(std::getenv("TNCO_HIP_SMALL")) != 0;
-
   Params& P = h->P;
   P.n = n; P.N = N; P.I = I; P.W = W; P.R = R;
   P.BS = (32 + 8 * W + 31) / 32 * 32;
@@ -940,7 +932,6 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       hipLaunchKernelGGL(set_minlinks_kernel, dim3((unsigned)R), dim3(64), 0, h->stream, P, dmin, d->min_links_stride == 0 ? (int64_t)0 : 3 * (int64_t)N);
       HIP_TRY(hipGetLastError());
       HIP_TRY(h->sync_all());
-      h->small_tree = false;  // (the LDS-resident kernel assumes the log starts at the checkpoint)
     }
     if (fw && d->min_slices) {  // row 1 of every replica's [2][L] slices record
       std::vector<uint64_t> rows((size_t)R * LKw, 0);
@@ -1000,7 +991,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       if (part > 0.02 && part < 0.85) G = 2;
     }
     if (const char* e = std::getenv("TNCO_HIP_GROUPS")) G = std::max(1, std::min((int)tnco_hip_ctx::MAX_GROUPS, std::atoi(e)));
-    if (h->small_tree || nblocks < 2 * G) G = 1;
+    if (nblocks < 2 * G) G = 1;
     if (G > 1) {
       for (int q = 0; q < G; ++q) {
         HIP_TRY(hipStreamCreateWithFlags(&h->gstream[q], hipStreamNonBlocking));
