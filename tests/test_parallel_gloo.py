@@ -105,3 +105,108 @@ def test_bench_reduction_over_two_ranks():
     for rank, dt, moves, acc, kms, best, per_rank in out:
         assert dt == 0.75 and moves == 3000 and acc == 300 and kms == 2.0 and best == 7.0
         assert per_rank == [(0, 1000.0), (1, 2000.0)]
+
+
+class _FileCollectives:
+    """Stand-in for the tnco_hip_comm_* entry points of libtnco_hip.so (csrc/host_comm.cpp: RCCL, needs a GPU per rank):
+    the same C signatures over files in a shared directory, so that tnco_amd.parallel.NativeComm -- the rendezvous over
+    a TCP socket, the two-phase object all-gather, the reductions built on it -- runs with world_size 2 on a CPU box."""
+
+    def __init__(self, root, rank, world):
+        import ctypes
+        self.C, self.root, self.rank, self.world, self.seq, self.uid = ctypes, Path(root), rank, world, 0, None
+
+    def tnco_hip_comm_last_error(self):
+        return b"stand-in"
+
+    def tnco_hip_comm_unique_id(self, uid):
+        for i in range(128):
+            uid[i] = (i * 7 + 3) & 0xFF
+        return 0
+
+    def tnco_hip_comm_init(self, rank, world, uid, device, out):
+        self.uid = bytes(uid)
+        out._obj.value = 1
+        return 0
+
+    def tnco_hip_comm_destroy(self, h):
+        pass
+
+    def _exchange(self, blob: bytes):
+        import time
+        self.seq += 1
+        tmp = self.root / f"{self.seq}_{self.rank}.tmp"
+        tmp.write_bytes(blob)
+        tmp.rename(self.root / f"{self.seq}_{self.rank}.bin")
+        out = []
+        for k in range(self.world):
+            f = self.root / f"{self.seq}_{k}.bin"
+            t0 = time.monotonic()
+            while not f.exists():
+                assert time.monotonic() - t0 < 60
+                time.sleep(0.005)
+            out.append(f.read_bytes())
+        return out
+
+    def tnco_hip_comm_allgather(self, h, send, recv, nbytes):
+        parts = self._exchange(self.C.string_at(send, nbytes))
+        self.C.memmove(recv, b"".join(parts), nbytes * self.world)
+        return 0
+
+    def tnco_hip_comm_allreduce_min(self, h, handle, local, out):
+        import struct
+        assert handle is None
+        vals = [struct.unpack("d", b)[0] for b in self._exchange(struct.pack("d", local))]
+        out._obj.value = min(vals)
+        return 0
+
+    def tnco_hip_comm_barrier(self, h):
+        self._exchange(b"x")
+        return 0
+
+
+def _native_worker(rank, world, port, root, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from tnco_amd import parallel
+    fake = _FileCollectives(root, rank, world)
+    parallel._native = parallel.NativeComm(rank, world, 0, lib=fake)
+    try:
+        assert "torch" not in sys.modules and parallel.rank_world() == (rank, world)
+        assert fake.uid == bytes((i * 7 + 3) & 0xFF for i in range(128))  # rank 0's id reached every rank
+        n_runs = 11
+        lo, hi = parallel.shard_bounds(n_runs, world, rank)
+        costs = np.array([50.0, 7.0, 9.0, 30.0, 7.0, 12.0, 99.0, 8.0, 41.0, 7.5, 60.0])
+        mine = costs[lo:hi]
+        best = parallel.global_best(float(mine.min()), rank, world)
+        gid = lo + int(np.argmin(mine))
+        wc, wid, wp = parallel.global_winner(float(mine.min()), gid, np.full((3, 5), gid, np.int32), rank, world)
+        # (heads of different pickled sizes on the two ranks: the object all-gather pads to the longest)
+        local = sorted(((float(c), lo + k, [c] * (1 + rank * 5), [[(0, 1)]]) for k, c in enumerate(mine)))[:3]
+        merged = parallel.merge_heads(local, 3, rank, world)
+        parallel._native.barrier()
+        q.put((rank, best, wc, wid, wp.tolist(), [(c, g) for c, g, _, _ in merged]))
+    finally:
+        parallel.shutdown_native()
+
+
+@pytest.mark.timeout(120)
+def test_two_ranks_through_the_native_communicator_logic(tmp_path):
+    """tnco_amd.parallel over NativeComm with world_size 2: socket rendezvous of the 128-byte id, rank_world,
+    global_best / global_winner / merge_heads on the native branch -- the collectives themselves replaced by files
+    (the real ones are RCCL's: tests/test_gpu_two_ranks.py runs them as a group of one on the GPU box)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_native_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=90) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank, best, wc, wid, wp, merged in out:
+        assert best == 7.0 and wc == 7.0 and wid == 1
+        assert wp == [[1] * 5] * 3
+        assert merged == [(7.0, 1), (7.0, 4), (7.5, 9)]
