@@ -2170,16 +2170,24 @@ static __device__ unsigned long long g_fwt_prof[8];
 #else
 #define FWT_T(i)
 #endif
-template <int J>  // nodes per lane: n - 1 <= 64 J
-static __global__ __launch_bounds__(256, (J <= 9 ? 4 : 2)) void fw_tree_kernel(const Params P, const FwParams F) {
+// GW lanes per replica (64: one per wavefront; 32: two -- half the instructions per replica, for networks of at most
+// 2048 indices), J = ceil((n - 1) / GW) nodes per lane.
+template <int J, int GW>
+static __global__ __launch_bounds__(256, (J * GW <= 576 ? 4 : 2)) void fw_tree_kernel(const Params P, const FwParams F) {
   FWT_T(0);
   extern __shared__ __attribute__((aligned(16))) uint8_t fwt_smem[];
+  constexpr int GPW = 64 / GW;   // replicas per wavefront
+  constexpr int IPP = GW / 2;    // changed indices per pass over the paths: one lane per (index, holder)
   const int n = P.n, N = P.N, ni = N - n, LK = F.I64 / 64;
   const int nip = (ni + 63) & ~63;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t r = (int64_t)blockIdx.x * 4 + wv;
+  const int gl = lane & (GW - 1), g = lane / GW;
+  const int64_t r = ((int64_t)blockIdx.x * 4 + wv) * GPW + g;
   if (r >= P.R) return;
-  uint8_t* base = fwt_smem + (size_t)wv * fwt_lds_bytes(n);
+  // (every exchange below stays inside the GW lanes of a replica: a replica that leaves early takes nobody with it)
+  const unsigned long long gmask = GW == 64 ? ~0ull : (0xFFFFFFFFull << (32 * g));
+  auto gany = [&](bool x) -> bool { return (__ballot(x) & gmask) != 0ull; };
+  uint8_t* base = fwt_smem + (size_t)(wv * GPW + g) * fwt_lds_bytes(n);
   // node i of the table: lo = left | right << 16; hi = parent | cost exponent << 16 | children still to arrive << 27;
   // Pn = the new partial sum -- before that the two path masks of the node (see below)
   TNCO_LDS volatile double* Pn = (TNCO_LDS volatile double*)base;                        // [nip]
@@ -2189,7 +2197,7 @@ static __global__ __launch_bounds__(256, (J <= 9 ? 4 : 2)) void fw_tree_kernel(c
   TNCO_LDS uint32_t* hi = (TNCO_LDS uint32_t*)(lo + nip);                                // [nip] (atomic arrivals)
   TNCO_LDS volatile uint32_t* hiv = (TNCO_LDS volatile uint32_t*)hi;                     // (plain accesses)
   TNCO_LDS volatile uint32_t* misc = (TNCO_LDS volatile uint32_t*)(hi + nip);            // [8]
-  if (lane == 0) F.fastflag[r] = 0;
+  if (gl == 0) F.fastflag[r] = 0;
   uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
   const FwScratch sc(F, r, N);
   // ---- everything this replica needs, in flight at once: the node table fw_order_kernel has left (8 bytes per
@@ -2199,9 +2207,11 @@ static __global__ __launch_bounds__(256, (J <= 9 ? 4 : 2)) void fw_tree_kernel(c
   const uint32_t* chg = reinterpret_cast<const uint32_t*>(F.delta_scr + r * 64);
   const uint2 c0 = *reinterpret_cast<const uint2*>(chg);
   const uint4 c1 = *reinterpret_cast<const uint4*>(chg + 4);
-  const uint32_t myent = chg[8 + lane];  // (FWT_MAXD = 64 entries: one per lane)
+  uint32_t myent[GPW];  // (FWT_MAXD = 64 entries: 64 / GW per lane)
+#pragma unroll
+  for (int q = 0; q < GPW; ++q) myent[q] = chg[8 + q * GW + gl];
   uint64_t myold = 0;
-  if (lane < P.W) myold = sl[lane];
+  if (gl < P.W) myold = sl[gl];
   const double cur = reinterpret_cast<const NodeRec*>(hb + (int64_t)(ni - 1) * P.BS)->partial;
   const int nwide_r = F.nwide[r];
   const uint2* img = reinterpret_cast<const uint2*>(sc.rec);
@@ -2210,7 +2220,7 @@ static __global__ __launch_bounds__(256, (J <= 9 ? 4 : 2)) void fw_tree_kernel(c
   int32_t iw[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) {
-    const int i = j * 64 + lane;
+    const int i = j * GW + gl;
     im[j] = make_uint2(0, 0);
     iw[j] = 0;
     if (i < ni) {
@@ -2218,22 +2228,23 @@ static __global__ __launch_bounds__(256, (J <= 9 ? 4 : 2)) void fw_tree_kernel(c
       iw[j] = imgw[i];
     }
   }
-  if (!__any(myold != 0)) return;  // (nothing was proposed: greedy/optimizer.hpp:359)
+  if (!gany(myold != 0)) return;  // (nothing was proposed: greedy/optimizer.hpp:359)
   // (-2: fw_reslice_a_kernel has traversed this replica itself -- over the node table; no list: the full rebuild)
   if (nwide_r == -2 || c0.x == 0xFFFFFFFFu) {
-    if (lane == 0) atomicAdd(F.slowstat, 1ull);
+    if (gl == 0) atomicAdd(F.slowstat, 1ull);
     return;
   }
   const int nd = (int)c0.x;
   // bit k of the pair: changed index number k joins / leaves the slices
-  const int dbase = __popc(c1.x) + __popc(c1.y) - __popc(c1.z) - __popc(c1.w);
+  const uint64_t plus64 = (uint64_t)c1.x | ((uint64_t)c1.y << 32), minus64 = (uint64_t)c1.z | ((uint64_t)c1.w << 32);
+  const int dbase = __popcll(plus64) - __popcll(minus64);
   FWT_T(1);
   // ---- the node table (links, old exponents, arrival counters), path masks cleared ------------------
   uint32_t startmask = 0;
   bool bad = false;
 #pragma unroll
   for (int j = 0; j < J; ++j) {
-    const int i = j * 64 + lane;
+    const int i = j * GW + gl;
     if (i < ni) {
       const int e = (int)((im[j].y >> 16) & 0x7FFu);
       bad = bad || e <= 0 || e >= 2047;
@@ -2248,19 +2259,24 @@ static __global__ __launch_bounds__(256, (J <= 9 ? 4 : 2)) void fw_tree_kernel(c
   // An index held by two tensors is a leg of a subtree exactly when the subtree holds ONE of them: of the
   // nodes above the first holder (mask 0) and above the second (mask 1), those below their meeting point have
   // it among their children's legs, the meeting point too, the nodes above it not.  One lane per (index,
-  // holder) walks its path to the root; 32 indices per pass (a second pass: one re-slice in some hundreds).
+  // holder) walks its path to the root; GW / 2 indices per pass (more passes: one re-slice in some hundreds).
   const int log2d = P.log2d;
-  for (int pass = 0; pass * 32 < nd || pass == 0; ++pass) {
-    const uint32_t plus = pass ? c1.y : c1.x, minus = pass ? c1.w : c1.z;
+  for (int pass = 0; pass * IPP < nd || pass == 0; ++pass) {
+    const uint32_t plus = (uint32_t)(plus64 >> (IPP * pass)) & (uint32_t)((1ull << IPP) - 1ull);
+    const uint32_t minus = (uint32_t)(minus64 >> (IPP * pass)) & (uint32_t)((1ull << IPP) - 1ull);
     if (pass) {
-      for (int i = lane; i < ni; i += 64) { onv[2 * i] = 0; onv[2 * i + 1] = 0; }
+      for (int i = gl; i < ni; i += GW) { onv[2 * i] = 0; onv[2 * i + 1] = 0; }
     }
     {
-      const int k = lane >> 1, which = lane & 1;
-      const uint32_t e = (uint32_t)__shfl((int)myent, 32 * pass + k);
+      const int k = gl >> 1, which = gl & 1;
+      const int idx = IPP * pass + k;  // this lane's changed index; its entry sits in lane idx % GW, slot idx / GW
+      uint32_t esel = myent[0];
+#pragma unroll
+      for (int q = 1; q < GPW; ++q) esel = (idx / GW == q) ? myent[q] : esel;  // (idx / GW is the same for the whole pass)
+      const uint32_t e = (uint32_t)__shfl((int)esel, idx & (GW - 1), GW);
       const int st = which ? (int)(e >> 16) : (int)(e & 0xFFFFu);
-      int x = (32 * pass + k < nd && st != 0xFFFF) ? st : -1;  // the path of a holder starts at its parent
-      for (int guard = 0; __any(x >= 0); ++guard) {
+      int x = (idx < nd && st != 0xFFFF) ? st : -1;  // the path of a holder starts at its parent
+      for (int guard = 0; gany(x >= 0); ++guard) {
         if (guard > ni) { bad = true; break; }  // (cannot happen in a tree: never spin on corrupt links)
         if (x >= 0) {
           __hip_atomic_fetch_or(&on[2 * (x - n) + which], 1u << k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2269,7 +2285,7 @@ static __global__ __launch_bounds__(256, (J <= 9 ? 4 : 2)) void fw_tree_kernel(c
         }
       }
     }
-    for (int i = lane; i < ni; i += 64) {
+    for (int i = gl; i < ni; i += GW) {
       const uint32_t w = lo[i], h = hiv[i];
       const int l = (int)(w & 0xFFFFu), rr = (int)(w >> 16);
       const uint32_t a = onv[2 * i], b = onv[2 * i + 1];
@@ -2294,11 +2310,11 @@ static __global__ __launch_bounds__(256, (J <= 9 ? 4 : 2)) void fw_tree_kernel(c
     if (p < 0 && startmask) {
       const int j = __ffs(startmask) - 1;
       startmask &= startmask - 1;
-      p = j * 64 + lane;
+      p = j * GW + gl;
       phi = hiv[p];
       plo = lo[p];
     }
-    if (!__any(p >= 0)) break;
+    if (!gany(p >= 0)) break;
 #ifdef TNCO_FWT_PROF
     ++iters_;
 #endif
@@ -2321,15 +2337,15 @@ static __global__ __launch_bounds__(256, (J <= 9 ? 4 : 2)) void fw_tree_kernel(c
     }
   }
   FWT_T(3);
-  if (__any(bad)) {  // (a cost outside the powers of two of a double: the full rebuild decides)
-    if (lane == 0) atomicAdd(F.slowstat, 1ull);
+  if (gany(bad)) {  // (a cost outside the powers of two of a double: the full rebuild decides)
+    if (gl == 0) atomicAdd(F.slowstat, 1ull);
     return;
   }
-  if (lane == ((ni - 1) & 63)) misc[0] = (Pn[ni - 1] < cur) ? 1u : 0u;  // greedy/optimizer.hpp:371-374
+  if (gl == ((ni - 1) & (GW - 1))) misc[0] = (Pn[ni - 1] < cur) ? 1u : 0u;  // greedy/optimizer.hpp:371-374
   if (misc[0]) {
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      const int i = j * 64 + lane;
+      const int i = j * GW + gl;
       if (i < ni) {
         // the whole header, links and width as they were: two 16-byte stores per node that leave the L2 as whole
         // lines (the second halves alone, 16 of every 32 bytes, were read-modify-writes in the memory: 2.5 x the time)
@@ -2342,11 +2358,11 @@ static __global__ __launch_bounds__(256, (J <= 9 ? 4 : 2)) void fw_tree_kernel(c
       }
     }
     const uint64_t* prop = reinterpret_cast<const uint64_t*>(const_cast<const int16_t*>(sc.pos));
-    if (lane < LK) sl[lane] = lane < P.W ? prop[lane] : 0ull;
+    if (gl < LK) sl[gl] = gl < P.W ? prop[gl] : 0ull;
   }
-  if (lane == 0) F.fastflag[r] = 1;
+  if (gl == 0) F.fastflag[r] = 1;
 #ifdef TNCO_FWT_PROF
-  if (lane == 0) {
+  if (gl == 0) {
     const unsigned long long tt4 = __builtin_amdgcn_s_memtime();
     atomicAdd(&g_fwt_prof[0], tt1 - tt0); atomicAdd(&g_fwt_prof[1], tt2 - tt1); atomicAdd(&g_fwt_prof[2], tt3 - tt2);
     atomicAdd(&g_fwt_prof[3], tt4 - tt3); atomicAdd(&g_fwt_prof[4], iters_); atomicAdd(&g_fwt_prof[5], 1ull);

@@ -122,8 +122,8 @@ void launch_fw_move_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, in
 template <int LOG2L, int K>
 bool fw_tree_prepare_lk(tnco_hip_ctx* h) {
   bool ok = hipFuncSetAttribute((const void*)fw_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess;
-#define TNCO_FWT(JJ) ok = ok && hipFuncSetAttribute((const void*)fw_tree_kernel<JJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess
-  TNCO_FWT(2); TNCO_FWT(4); TNCO_FWT(6); TNCO_FWT(9); TNCO_FWT(12); TNCO_FWT(16);
+#define TNCO_FWT(JJ, GG) ok = ok && hipFuncSetAttribute((const void*)fw_tree_kernel<JJ, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess
+  TNCO_FWT(2, 64); TNCO_FWT(4, 64); TNCO_FWT(6, 64); TNCO_FWT(9, 64); TNCO_FWT(12, 64); TNCO_FWT(16, 64);
 #undef TNCO_FWT
   if (!ok) {
     (void)hipGetLastError();
@@ -143,12 +143,16 @@ void launch_fw_reslice_lk(tnco_hip_ctx* h, int prewalked) {
   if (h->F.fast_ok && prewalked == 3 && !h->hyper) {  // no walk: get_slices from fw_order_kernel's list | fw_tree_kernel | end of the sweep
     hipLaunchKernelGGL((fw_reslice_a_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, 2);
     {
-      const dim3 tg((unsigned)((h->P.R + 3) / 4));
-      const size_t tb = 4 * fwt_lds_bytes(h->P.n);
-      const int need = (h->P.n - 1 + 63) / 64;
-#define TNCO_FWT(JJ) hipLaunchKernelGGL(fw_tree_kernel<JJ>, tg, dim3(256), tb, h->stream, h->P, h->F)
-      if (need <= 2) TNCO_FWT(2); else if (need <= 4) TNCO_FWT(4); else if (need <= 6) TNCO_FWT(6);
-      else if (need <= 9) TNCO_FWT(9); else if (need <= 12) TNCO_FWT(12); else TNCO_FWT(16);
+      // (one wavefront per replica.  Two replicas per wavefront, 32 lanes each -- fw_tree_kernel<J, 32> -- measured
+      //  SLOWER on config 5, 0.57 against 0.44 ms per launch: the kernel waits on its LDS chain, not on issue slots,
+      //  and half as many wavefronts hide half as much of it; profiles/experiments.md)
+      const int gw = 64, per_block = 4;
+      const dim3 tg((unsigned)((h->P.R + per_block - 1) / per_block));
+      const size_t tb = (size_t)per_block * fwt_lds_bytes(h->P.n);
+      const int need = (h->P.n - 1 + gw - 1) / gw;
+#define TNCO_FWT(JJ, GG) hipLaunchKernelGGL((fw_tree_kernel<JJ, GG>), tg, dim3(256), tb, h->stream, h->P, h->F)
+      if (need <= 2) TNCO_FWT(2, 64); else if (need <= 4) TNCO_FWT(4, 64); else if (need <= 6) TNCO_FWT(6, 64);
+      else if (need <= 9) TNCO_FWT(9, 64); else if (need <= 12) TNCO_FWT(12, 64); else TNCO_FWT(16, 64);
 #undef TNCO_FWT
     }
     hipLaunchKernelGGL((fw_reslice_b_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, 1);
