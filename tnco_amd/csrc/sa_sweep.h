@@ -320,7 +320,12 @@ template <int LOG2L, int K, bool HYPER, bool GENERIC, bool FW = false>
 #endif
 // (four mask words per lane: at three wavefronts per SIMD the kernel spills; at two, 1360 leaves
 // (8 lanes x 4 words) run 3.25 -> 3.6e9 move-evals/s, 680 leaves the same within the +-3 % of the boxes)
-__global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES : ((HYPER || K >= 4) ? TNCO_HYPER_WAVES : TNCO_WAVES_PER_SIMD)))) void sa_run_kernel(
+// (the general cost models -- dims tables, per-index dims, sparse legs, float32 -- spill 80 bytes per lane at three
+// wavefronts per SIMD; at two: +12 ... +18 % on every one of them, round 3, profiles/r03_other_configs.md)
+#ifndef TNCO_GENERIC_WAVES
+#define TNCO_GENERIC_WAVES 2
+#endif
+__global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES : ((HYPER || K >= 4) ? TNCO_HYPER_WAVES : (GENERIC ? TNCO_GENERIC_WAVES : TNCO_WAVES_PER_SIMD))))) void sa_run_kernel(
     const Params P, const double* __restrict__ betas, const int64_t n_steps, const int prob_kind,
     const FwParams F, const int tail_last, const int block0) {
   constexpr int L = 1 << LOG2L;

@@ -551,6 +551,13 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       P.BS = P.hoff + (8 * W + 127) / 128 * 128;
     }
   }
+  // Blocks longer than a line: whole lines each (a 224-byte block at 24 mask words straddles two or three
+  // 128-byte lines depending on where it starts; 256 bytes are always two).  TNCO_HIP_BLOCK_ALIGN=0 packs them.
+  if (P.BS > 128 && !h->hyper) {
+    const char* e = std::getenv("TNCO_HIP_BLOCK_ALIGN");
+    const int al = e ? std::atoi(e) : 0;
+    if (al > 0) P.BS = (P.BS + al - 1) / al * al;
+  }
   P.WS = P.BS; P.WOFF = 32; P.RB = (int64_t)(n - 1) * P.BS;
   if (fw && !h->hyper && !std::getenv("TNCO_HIP_FW_UNIFIED")) {  // split layout (sa_kernels.h, Params)
     P.BS = 32;
