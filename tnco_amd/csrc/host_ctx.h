@@ -130,8 +130,10 @@ struct tnco_hip_ctx {
     if ((region_b_set || hipEventRecord(region_b, stream) == hipSuccess) && hipEventSynchronize(region_b) == hipSuccess &&
         hipEventElapsedTime(&ms, region_a, region_b) == hipSuccess) {
       kernel_ms += ms;
-      kind_ms[TNCO_KIND_SWEEP] += ms;
-      kind_launches[TNCO_KIND_SWEEP] += region_calls;
+      if (!fw) {  // (the only kernel of an infinite-memory handle; a finite-width one times its kernels on their streams)
+        kind_ms[TNCO_KIND_SWEEP] += ms;
+        kind_launches[TNCO_KIND_SWEEP] += region_calls;
+      }
     }
     region_open = false;
     region_b_set = false;
@@ -149,7 +151,7 @@ struct tnco_hip_ctx {
     for (auto& ev : pending) {
       float ms = 0;
       if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
-        kernel_ms += ms;
+        if (n_groups <= 1) kernel_ms += ms;  // (grouped: concurrent kernels -- the total is the region's, close_region)
         kind_ms[ev.kind] += ms;
         kind_launches[ev.kind]++;
       }

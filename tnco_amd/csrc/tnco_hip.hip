@@ -129,7 +129,7 @@ void launch_fw_walk(tnco_hip_ctx* h, int two_ended) {
 // n_steps sweeps of the finite-width optimizer: [moves up to and including the next re-slicing
 // sweep][re-slice] ... [the remaining moves]  (sweep k re-slices when (off + k) % every == 0)
 hipError_t launch_fw_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, int64_t off,
-                         int64_t every) {
+                         int64_t every, bool count_reslices = true) {
   int64_t cur = 0;
   while (cur < n_steps) {
     int64_t next = n_steps;  // first re-slicing sweep >= cur
@@ -163,7 +163,7 @@ hipError_t launch_fw_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, 
         e = h->timed(TNCO_KIND_FW_WALK, [&]() { launch_fw_walk(h, prewalked == 2); });
         if (e != hipSuccess) return e;
       }
-      if (h->F.fast_ok && prewalked >= 2 && !h->hyper) h->fw_delta_reslices += 1;
+      if (count_reslices && h->F.fast_ok && prewalked >= 2 && !h->hyper) h->fw_delta_reslices += 1;
       e = h->timed(TNCO_KIND_FW_RESLICE, [&]() {
 #define CALL_FWS(LL, KK) launch_fw_reslice_lk<LL, KK>(h, prewalked)
         DISPATCH_LK(h, CALL_FWS)
@@ -175,6 +175,40 @@ hipError_t launch_fw_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, 
   }
   return hipSuccess;
 }
+
+// The replicas [r0, r0 + cnt) of a handle as a batch of their own: every per-replica array starts at r0, so the
+// kernels -- which index everything by the replica's number in the launch -- run unchanged on a part of the batch.
+// A finite-width handle runs its halves on two streams that way (tnco_hip_run_fw): the request-bound moves of one
+// half overlap the latency-bound re-slice kernels of the other (two handles of half the replicas: +11 ... +15 %,
+// tools/fw_two_handles_probe.py).
+struct GroupView {
+  tnco_hip_ctx* h;
+  Params P0;
+  FwParams F0;
+  hipStream_t s0;
+  GroupView(tnco_hip_ctx* h_, int64_t r0, int64_t cnt, hipStream_t s) : h(h_), P0(h_->P), F0(h_->F), s0(h_->stream) {
+    Params& P = h->P;
+    FwParams& F = h->F;
+    const int64_t N = P.N, n = P.n, LK = (int64_t)h->L * h->K;
+    P.R = cnt;
+    P.blocks += r0 * P.RB; P.lpar += r0 * n * LPS; P.mt += r0 * 624; P.mtshadow += r0 * MT_SHADOW; P.rs += r0;
+    P.minlinks += r0 * N; P.jlog += r0 * (int64_t)P.jcap;
+    if (h->fw) {
+      F.slices += r0 * 2 * LK; F.scratch_i += r0 * fw_scratch_ints((int)N, F.I64); F.scratch_d += r0 * 2 * N; F.status += r0;
+      if (F.width64) F.width64 += r0 * N;
+      if (F.nwide) F.nwide += r0;
+      if (F.nwfront) F.nwfront += r0;
+      if (F.fastflag) F.fastflag += r0;
+      if (F.delta_scr) F.delta_scr += r0 * 64;
+    }
+    h->stream = s;
+  }
+  ~GroupView() {
+    h->P = P0;
+    h->F = F0;
+    h->stream = s0;
+  }
+};
 
 // checkpoint := current tree, replica state := fresh
 __global__ void finish_init_kernel(Params P, const double* sum, const double* total) {
@@ -987,15 +1021,21 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   // Infinite memory: do the replicas fill whole rounds of resident blocks?  If the last round would be
   // partial (65536 replicas at 512 leaves: 1024 blocks, 768 resident), every step is split over two streams
   // (host_ctx.h, tnco_hip_run).  TNCO_HIP_GROUPS=1..4 overrides.
-  if (!fw) {
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, d->device));
-    h->run_slots = run_blocks_per_cu(h) * prop.multiProcessorCount;
+  {
     const int64_t nblocks = (R + (256 / h->L) - 1) / (256 / h->L);
     int G = 1;
-    if (h->run_slots > 0 && nblocks > h->run_slots) {
-      const double rounds = (double)nblocks / (double)h->run_slots, part = rounds - std::floor(rounds);
-      if (part > 0.02 && part < 0.85) G = 2;
+    if (!fw) {
+      hipDeviceProp_t prop;
+      HIP_TRY(hipGetDeviceProperties(&prop, d->device));
+      h->run_slots = run_blocks_per_cu(h) * prop.multiProcessorCount;
+      if (h->run_slots > 0 && nblocks > h->run_slots) {
+        const double rounds = (double)nblocks / (double)h->run_slots, part = rounds - std::floor(rounds);
+        if (part > 0.02 && part < 0.85) G = 2;
+      }
+    } else if (nblocks >= 64 && h->F.max_new_slices == 0) {
+      // finite width: two halves on two streams whatever the rounds -- what overlaps are KERNELS of different
+      // bounds (the moves wait on memory requests, get_slices and the tree kernel on LDS / instruction latency)
+      G = 2;
     }
     if (const char* e = std::getenv("TNCO_HIP_GROUPS")) G = std::max(1, std::min((int)tnco_hip_ctx::MAX_GROUPS, std::atoi(e)));
     if (nblocks < 2 * G) G = 1;
@@ -1139,11 +1179,31 @@ int tnco_hip_run_fw(tnco_hip_handle h, int prob_kind, const double* betas, int64
   }
   HIP_TRY(hipMemcpyAsync(h->d_betas, betas, (size_t)n_steps * 8, hipMemcpyHostToDevice, h->stream));
   const int64_t max_steps = std::max<int64_t>(1, (int64_t)0xF0000000u / std::max(1, h->P.n));
+  if (h->n_groups > 1) {  // the halves of the batch on streams of their own (GroupView), after this call's betas
+    if (h->region_open && h->region_b_set) h->close_region();
+    if (!h->region_open) {
+      HIP_TRY(hipEventRecord(h->region_a, h->stream));
+      h->region_open = true;
+    }
+    HIP_TRY(hipEventRecord(h->gfork, h->stream));
+    for (int q = 0; q < h->n_groups; ++q) HIP_TRY(hipStreamWaitEvent(h->gstream[q], h->gfork, 0));
+  }
   for (int64_t s0 = 0; s0 < n_steps; s0 += max_steps) {
     const int64_t cnt = std::min(max_steps, n_steps - s0);
-    HIP_TRY(launch_fw_run(h, h->d_betas + s0, cnt, prob_kind, step_offset + s0, update_slices_every));
+    if (h->n_groups > 1) {
+      const int64_t R = h->P.R;
+      for (int q = 0; q < h->n_groups; ++q) {
+        const int64_t r0 = R * q / h->n_groups, r1 = R * (q + 1) / h->n_groups;
+        GroupView gv(h, r0, r1 - r0, h->gstream[q]);
+        HIP_TRY(launch_fw_run(h, h->d_betas + s0, cnt, prob_kind, step_offset + s0, update_slices_every, q == 0));
+      }
+      h->groups_dirty = true;
+    } else {
+      HIP_TRY(launch_fw_run(h, h->d_betas + s0, cnt, prob_kind, step_offset + s0, update_slices_every));
+    }
     h->launches++;
   }
+  if (h->n_groups > 1) h->region_calls++;
   if (h->pending.size() > 256) h->resolve_events();
   return TNCO_HIP_OK;
 }
@@ -1196,9 +1256,12 @@ int tnco_hip_kernel_times(tnco_hip_handle h, double* ms4, int64_t* launches4, in
   HIP_TRY(h->sync_all());
   h->close_region();
   h->resolve_events();
+  // (a finite-width handle on two streams: the AVERAGE time a stream spent in each kernel -- the streams run
+  //  concurrently, so these add up to about the device time tnco_hip_kernel_time reports, not to twice it)
+  const double div = (h->fw && h->n_groups > 1) ? (double)h->n_groups : 1.0;
   for (int k = 0; k < TNCO_KINDS; ++k) {
-    if (ms4) ms4[k] = h->kind_ms[k];
-    if (launches4) launches4[k] = h->kind_launches[k];
+    if (ms4) ms4[k] = h->kind_ms[k] / div;
+    if (launches4) launches4[k] = (int64_t)((double)h->kind_launches[k] / div);
   }
   if (reset) h->reset_times();
   return TNCO_HIP_OK;
