@@ -298,12 +298,12 @@ def pmc_passes(args, lib_version):
     res = {"library": lib_version, "seconds": None, "kernels": {}}
     for (short, ctr), v in vals.items():
         n = per_step[short]
-        for mult in (1, 2, 3, 4):
-            # (a step of the headline leg is two concurrent dispatches when the handle splits it over two streams; the
-            #  re-slice by re-pricing is three: get_slices | fw_tree_kernel | end of the sweep)
-            if len(v) == mult * n * (args.warmup + args.steps):
-                n *= mult
-                break
+        # (a step is two concurrent dispatches per kernel when the handle splits it over two streams; the re-slice by
+        #  re-pricing is three kernels: get_slices | fw_tree_kernel | end of the sweep -- so 1, 2, 3 or 6 times n)
+        mult, rest = divmod(len(v), n * (args.warmup + args.steps))
+        if rest or mult < 1:
+            continue
+        n *= mult
         timed = v[args.warmup * n:(args.warmup + args.steps) * n]  # the timed steps' dispatches
         if len(timed) != args.steps * n:
             continue
@@ -333,15 +333,17 @@ def traffic_fields(k, moves_per_step, step_s):
         rd_raw, wr = k["FETCH_SIZE"] * 1024.0, k["WRITE_SIZE"] * 1024.0
         out["traffic"] = 2 * rd_raw + wr
         out["traffic_raw"] = rd_raw + wr
-        out["traffic_frac"] = out["traffic"] / step_s / 1e9 / HBM_PEAK_GBS
-        out["traffic_frac_raw"] = out["traffic_raw"] / step_s / 1e9 / HBM_PEAK_GBS
+        if step_s:
+            out["traffic_frac"] = out["traffic"] / step_s / 1e9 / HBM_PEAK_GBS
+            out["traffic_frac_raw"] = out["traffic_raw"] / step_s / 1e9 / HBM_PEAK_GBS
     if "TCC_EA0_RDREQ_sum" in k and "TCC_EA0_WRREQ_sum" in k:
         rd, wr = k["TCC_EA0_RDREQ_sum"], k["TCC_EA0_WRREQ_sum"]
         out["requests_per_move"] = {"read": rd / moves_per_step, "write": wr / moves_per_step,
                                     "read_32B": k.get("TCC_EA0_RDREQ_32B_sum", 0.0) / moves_per_step,
                                     "write_64B": k.get("TCC_EA0_WRREQ_64B_sum", 0.0) / moves_per_step}
-        out["request_rate"] = (rd + wr) / step_s
-        out["request_rate_frac"] = out["request_rate"] / RANDOM_REQ_PEAK
+        if step_s:
+            out["request_rate"] = (rd + wr) / step_s
+            out["request_rate_frac"] = out["request_rate"] / RANDOM_REQ_PEAK
     return out
 
 
@@ -519,8 +521,9 @@ def main() -> None:
                             "47e9/s random-request ceiling, tools/hbm_random.hip) say what binds the kernel"}
             if kind == "fw":  # the moves' bytes alone over the leg's device time, and over the move kernel's
                 roof["frac_moves_only"] = extra["algorithmic_bytes_moves_only"] / (step_ms / 1e3) / 1e9 / HBM_PEAK_GBS
-                roof["frac_move_kernel"] = (extra["algorithmic_bytes_moves_only"] / (kt["fw_move_kernel"][0] / args.steps / 1e3)
-                                            / 1e9 / HBM_PEAK_GBS)
+                if leg.groups <= 1:  # (two streams: the move kernel's time is a per-stream average, beside other kernels)
+                    roof["frac_move_kernel"] = (extra["algorithmic_bytes_moves_only"] / (kt["fw_move_kernel"][0] / args.steps / 1e3)
+                                                / 1e9 / HBM_PEAK_GBS)
                 if leg.groups > 1:
                     roof["streams"] = leg.groups
                     roof["note_streams"] = ("the two halves of the batch run the whole step -- moves, fw_order | get_slices | fw_tree | "
@@ -541,7 +544,9 @@ def main() -> None:
                     kc = pmc["kernels"].get(k)
                     if not kc:
                         continue
-                    f = traffic_fields(kc, moves_per_step_gpu, kt[k][0] / args.steps / 1e3)
+                    # (two streams: the kernels of the two halves overlap -- rates per kernel mean nothing, the leg's do)
+                    overlapped = kind == "fw" and leg.groups > 1
+                    f = traffic_fields(kc, moves_per_step_gpu, None if overlapped else kt[k][0] / args.steps / 1e3)
                     roof["kernels"][k].update(f)
                     for c, v in kc.items():
                         tot[c] = tot.get(c, 0.0) + v
