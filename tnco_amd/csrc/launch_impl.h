@@ -20,7 +20,7 @@ static const void* run_kernel_ptr(const tnco_hip_ctx* h) {
 template <int LOG2L, int K>
 int run_blocks_per_cu_lk(tnco_hip_ctx* h) {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, run_kernel_ptr<LOG2L, K>(h), 256, 0) != hipSuccess) {
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, run_kernel_ptr<LOG2L, K>(h), SWT, 0) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
@@ -32,18 +32,18 @@ template <int LOG2L, int K>
 void launch_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, hipStream_t s, int block0,
                    int nblocks) {
   const Params& P = h->P;
-  const int gpb = 256 >> LOG2L;
+  const int gpb = SWT >> LOG2L;
   dim3 grid((unsigned)(nblocks >= 0 ? nblocks : (P.R + gpb - 1) / gpb));
   if (h->hyper) {
     if (h->generic)
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, true, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1, block0);
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, true, false>), grid, dim3(SWT), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1, block0);
     else
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, false, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1, block0);
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, false, false>), grid, dim3(SWT), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1, block0);
   } else {
     if (h->generic)
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, true, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1, block0);
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, true, false>), grid, dim3(SWT), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1, block0);
     else
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, false, false>), grid, dim3(256), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1, block0);
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, false, false>), grid, dim3(SWT), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1, block0);
   }
 }
 
@@ -93,12 +93,12 @@ void launch_fw_check_lk(tnco_hip_ctx* h, const BuildArgs& a, int which_min, doub
 
 template <int LOG2L, int K>
 void launch_fw_move_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, int tail_last) {
-  const int gpb = 256 >> LOG2L;
-  dim3 grid((unsigned)((h->P.R + gpb - 1) / gpb));
+  const int gpb = 256 >> LOG2L, gpb_staged = SWT >> LOG2L;
+  dim3 grid((unsigned)((h->P.R + gpb - 1) / gpb)), grid_staged((unsigned)((h->P.R + gpb_staged - 1) / gpb_staged));
   const bool maxnew = h->F.max_new_slices > 0;
   if (!maxnew && !std::getenv("TNCO_HIP_FW_UNSTAGED")) {  // the staged state machine (sa_sweep.h, FW = true)
 #define TNCO_FW_STAGED(HY, GE)                                                                                          \
-  hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, HY, GE, true>), grid, dim3(256), 0, h->stream, h->P, betas, n_steps, \
+  hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, HY, GE, true>), grid_staged, dim3(SWT), 0, h->stream, h->P, betas, n_steps, \
                      prob_kind, h->F, tail_last, 0)
     if (h->hyper) {
       if (h->generic) TNCO_FW_STAGED(true, true); else TNCO_FW_STAGED(true, false);

@@ -310,6 +310,12 @@ typedef TNCO_LDS volatile ColdState lds_cold;
 #define TNCO_PROF_OUT(rs)
 #endif
 
+// Threads per block of the sweep kernel.  Replicas never talk to each other, so a block is only a unit of
+// dispatch: a block's resources go back to the dispatcher when its LAST wavefront ends.
+#ifndef TNCO_SWEEP_THREADS
+#define TNCO_SWEEP_THREADS 256
+#endif
+constexpr int SWT = TNCO_SWEEP_THREADS;
 #ifndef TNCO_FW_STAGED_WAVES
 #define TNCO_FW_STAGED_WAVES 2
 #endif
@@ -325,11 +331,11 @@ template <int LOG2L, int K, bool HYPER, bool GENERIC, bool FW = false>
 #ifndef TNCO_GENERIC_WAVES
 #define TNCO_GENERIC_WAVES 2
 #endif
-__global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES : ((HYPER || K >= 4) ? TNCO_HYPER_WAVES : (GENERIC ? TNCO_GENERIC_WAVES : TNCO_WAVES_PER_SIMD))))) void sa_run_kernel(
+__global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES : ((HYPER || K >= 4) ? TNCO_HYPER_WAVES : (GENERIC ? TNCO_GENERIC_WAVES : TNCO_WAVES_PER_SIMD))))) void sa_run_kernel(
     const Params P, const double* __restrict__ betas, const int64_t n_steps, const int prob_kind,
     const FwParams F, const int tail_last, const int block0) {
   constexpr int L = 1 << LOG2L;
-  constexpr int GPB = 256 >> LOG2L;  // groups (replicas) per block
+  constexpr int GPB = SWT >> LOG2L;  // groups (replicas) per block
   using M = Mask<K>;
   using R = Rng<LOG2L>;
   __shared__ uint32_t rngbuf[GPB * R::RING];
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(256, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
   lds_cdouble* sdims = nullptr;
   if constexpr (GENERIC) {
     if (P.cost_mode == 2) {
-      for (int i = threadIdx.x; i < L * K * 64; i += 256) sdimbuf[i] = P.dimsd[i];
+      for (int i = threadIdx.x; i < L * K * 64; i += SWT) sdimbuf[i] = P.dimsd[i];
       __syncthreads();
       sdims = (lds_cdouble*)sdimbuf;
     }

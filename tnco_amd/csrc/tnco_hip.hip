@@ -1022,7 +1022,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   // partial (65536 replicas at 512 leaves: 1024 blocks, 768 resident), every step is split over two streams
   // (host_ctx.h, tnco_hip_run).  TNCO_HIP_GROUPS=1..4 overrides.
   {
-    const int64_t nblocks = (R + (256 / h->L) - 1) / (256 / h->L);
+    const int64_t nblocks = (R + (SWT / h->L) - 1) / (SWT / h->L);
     int G = 1;
     if (!fw) {
       hipDeviceProp_t prop;
@@ -1121,7 +1121,7 @@ int tnco_hip_run(tnco_hip_handle h, int prob_kind, const double* betas, int64_t 
     h->region_open = true;
   }
   HIP_TRY(hipEventRecord(h->gfork, h->stream));
-  const int gpb = 256 / h->L;
+  const int gpb = SWT / h->L;
   const int nblocks = (int)((h->P.R + gpb - 1) / gpb);
   const int64_t n_slices = std::max<int64_t>(1, std::max<int64_t>((n_steps + max_steps - 1) / max_steps, (n_steps + 50) / 100));
   for (int q = 0; q < h->n_groups; ++q) HIP_TRY(hipStreamWaitEvent(h->gstream[q], h->gfork, 0));
