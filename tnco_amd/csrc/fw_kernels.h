@@ -6,17 +6,18 @@
 // every internal node (WidthCache, finite_width/utils.hpp:49-76: float32 in the `pad` word of the
 // node header, or a float64 array of its own), and scratch for the greedy re-slice.
 //
-// Two kernels: fw_move_kernel (the moves of a run of sweeps; every move reads its operands from
-// memory, no staging as in sa_sweep.h) and fw_reslice_kernel (the end of a re-slicing sweep:
-// greedy/utils.hpp:21-125 + the full CostCache rebuild of greedy/optimizer.hpp:359-376).  The
-// re-slice is organised around what bounds it on this machine -- the number of random memory
-// transactions (tools/mem_latency.hip: ~47 G/s chip-wide, so a dependent load takes 0.8 us with two
-// wavefronts per SIMD all waiting) and the divergence of 16 different trees per wavefront:
-//   * ONE walk over the tree reads every node header once and leaves sequential lists (internal
-//     nodes in post-order with their links; the too-wide tensors in post-order);
-//   * every later stage iterates over those lists, the k-th entry of all 16 replicas together, with
-//     the loads of the next entries in flight;
-//   * counters, candidate lists, shuffles and picks live in registers / LDS.
+// The moves of a run of sweeps are the staged sweep kernel (sa_sweep.h, FW = true); fw_move_kernel here is the
+// unstaged version kept for max_number_new_slices > 0.  The end of a re-slicing sweep (greedy/utils.hpp:21-125
+// + the CostCache rebuild of greedy/optimizer.hpp:359-376) comes in two forms:
+//   * the general one: a walk kernel (fw_walk2_kernel from both ends of the post-order, fw_walk_kernel) leaves
+//     sequential lists (internal nodes in post-order with their links; the too-wide tensors in post-order), then
+//     fw_reslice_kernel iterates over them -- the k-th entry of all 16 replicas of a wavefront together, the next
+//     entries' loads in flight; counters, candidate lists, shuffles and picks in registers / LDS; the cache
+//     rebuilt from the leg masks;
+//   * when every cost is a power of two (fast_ok / tree_ok): no walk -- fw_order_kernel | fw_reslice_a_kernel
+//     (get_slices) | fw_tree_kernel (the cache RE-PRICED from the old costs) | fw_reslice_b_kernel; see the
+//     comment block at fw_order_kernel.  (fw_delta_kernel: the re-pricing over the walk's post-order records,
+//     round 2, behind TNCO_HIP_FW_NO_TREE.)
 // Covered: SimpleCostModel and SimpleSparseIndsCostModel (finite_width/cost_model/simple.hpp,
 // simple_sparse_inds.hpp), uniform and per-index dims, width_type float32 / float64, and the
 // max_number_new_slices > 0 branch (greedy/optimizer.hpp:226-321).

@@ -25,13 +25,14 @@ struct FwParams {
   double* width64;          // [R][N] widths of the internal nodes when width_type is float64
   int32_t* nwide;           // [R] fw_walk_kernel -> fw_reslice_kernel: too-wide tensors listed (-1: no slices, nothing to do)
   int32_t* nwfront;         // [R] ... how many of them at the front of the list (fw_walk2_kernel: the rest at its end)
-  // the re-slice re-priced from the OLD costs (fw_delta_kernel): usable when fast_ok
+  // the re-slice re-priced from the OLD costs (fw_tree_kernel, or fw_delta_kernel after a walk): usable when fast_ok
   int32_t fast_ok;          // uniform power-of-two dims, float64 cost, no sparse legs, no hyper-indices, <= 1024 tensors
   int32_t tree_ok;          // ... and no too-wide leaf, split layout: the re-slice without a walk (fw_order_kernel, fw_tree_kernel)
   const int32_t* holder2;   // [I64][2] the (one or two) tensors holding an index, -1: none / index not supported
-  int32_t* fastflag;        // [R] 1: fw_delta_kernel has done this replica's rebuild (+ commit)
-  unsigned long long* slowstat;  // [1] replicas fw_delta_kernel has left to the full rebuild since the host last looked
-  uint64_t* delta_scr;      // [R][64] fw_delta_kernel: holders of the changed indices (u16[128]), second count-vector words
+  int32_t* fastflag;        // [R] 1: fw_tree_kernel / fw_delta_kernel has done this replica's rebuild (+ commit)
+  unsigned long long* slowstat;  // [1] replicas the re-pricing has left to the full rebuild since the host last looked
+  uint64_t* delta_scr;      // [R][64] fw_reslice_a_kernel -> fw_tree_kernel: the changed indices and the starts of their paths;
+                            //          fw_delta_kernel: holders of the changed indices (u16[128]), second count-vector words
   int32_t* status;          // [R] runtime problems (1: candidate legs beyond the scratch; cannot happen
                             //     since the scratch holds every index)
 };

@@ -38,7 +38,8 @@
 // contraction costs (:191-193), the cached width of a node travels with its header (the spare
 // word), a move whose new B is wider than max_width once sliced draws no uniform and is not
 // accepted (:188-201), an accepted one stores B's new width (:216).  The re-slice at the end of a
-// sweep is fw_walk_kernel + fw_reslice_kernel: the host launches [moves][walk][re-slice]...
+// sweep is a sequence of kernels of its own (fw_kernels.h: fw_order_kernel | fw_reslice_a_kernel | fw_tree_kernel |
+// fw_reslice_b_kernel, or a walk kernel + fw_reslice_kernel): the host launches [moves][re-slice]...
 #pragma once
 #include "sa_kernels.h"
 #include "fw_params.h"
