@@ -419,8 +419,11 @@ def main() -> None:
                 torch.cuda.set_device(0)
                 dist.init_process_group("gloo")
             else:
+                import datetime
                 torch.cuda.set_device(local_rank)
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                # (a fall-back taken by SOME ranks only can never complete: fail within minutes, not after the default half hour)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                        timeout=datetime.timedelta(seconds=300 if comm_note else 1800))
             comm_kind = f"torch.distributed {dist.get_backend()}"
     else:
         import torch  # (one rank: nothing to exchange; torch only for the contract's torch.cuda.synchronize())
