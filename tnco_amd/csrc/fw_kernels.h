@@ -1726,8 +1726,11 @@ constexpr int FWD_LANES = TNCO_FWD_LANES;  // replicas (busy lanes) per wavefron
 #ifdef TNCO_FWA_PROF  // (diagnostic build: shader cycles per wavefront of [generator init, too-wide counts, greedy pass], wavefronts, too-wide tensors of lane 0's replica)
 static __device__ unsigned long long g_fwa_prof[8];
 #endif
+#ifndef TNCO_FW_RESLICE_A_WAVES
+#define TNCO_FW_RESLICE_A_WAVES TNCO_FW_RESLICE_WAVES
+#endif
 template <int LOG2L, int K, bool HYPER>
-__global__ __launch_bounds__(256, TNCO_FW_RESLICE_WAVES) void fw_reslice_a_kernel(const Params P, const FwParams F, const int prewalked) {
+__global__ __launch_bounds__(256, TNCO_FW_RESLICE_A_WAVES) void fw_reslice_a_kernel(const Params P, const FwParams F, const int prewalked) {
   constexpr int L = 1 << LOG2L;
   constexpr int GPB = 256 >> LOG2L;
   constexpr int LK = L * K;
