@@ -67,8 +67,8 @@ def kernel_of(name: str):
             return short
     if "fw_walk2_kernel" in name or "fw_order_kernel" in name:  # (what lists the too-wide tensors in post-order)
         return "fw_walk_kernel"
-    if ("fw_reslice_a_kernel" in name or "fw_delta_kernel" in name or "fw_tree_kernel" in name
-            or "fw_reslice_b_kernel" in name):
+    if ("fw_reslice_a_kernel" in name or "fw_slices_kernel" in name or "fw_delta_kernel" in name
+            or "fw_tree_kernel" in name or "fw_reslice_b_kernel" in name):
         return "fw_reslice_kernel"  # (the re-slice by re-pricing: get_slices | fw_tree_kernel | end of the sweep)
     return None
 
@@ -299,7 +299,8 @@ def pmc_passes(args, lib_version):
     for (short, ctr), v in vals.items():
         n = per_step[short]
         # (a step is two concurrent dispatches per kernel when the handle splits it over two streams; the re-slice by
-        #  re-pricing is three kernels: get_slices | fw_tree_kernel | end of the sweep -- so 1, 2, 3 or 6 times n)
+        #  re-pricing is four kernels: get_slices (fw_slices_kernel, its stragglers in fw_reslice_a_kernel) | fw_tree_kernel |
+        #  end of the sweep -- so 1, 2, 4 or 8 times n)
         mult, rest = divmod(len(v), n * (args.warmup + args.steps))
         if rest or mult < 1:
             continue

@@ -369,3 +369,48 @@ def test_config5_many_changed_indices_from_random_starts(core, oracle_lib, monke
             H.assert_replica_equal(gpu, r, o)
             assert tot[r] == o.total_cost and mn[r] == o.min_total_cost
             assert all(np.array_equal(a, b) for a, b in zip(gpu.slices(r), o.slices()))
+
+
+def test_get_slices_per_wavefront_equals_the_lockstep_kernel(core, monkeypatch):
+    """fw_slices_kernel (one wavefront per replica: the default on the tree path) against fw_reslice_a_kernel
+    (TNCO_HIP_FW_NO_WAVE_SLICES=1) on the config-5 topology, 4 096 replicas x 60 sweeps -- some 2 500 outputs of
+    every generator, so the 624-word generations end inside shuffles -- and with its knobs turned so that the
+    rare paths are the common ones: no legs kept in LDS between the passes (TNCO_HIP_FWS_CAP=1), and tensors
+    with more than 44 candidate legs left to the lock-step kernel (TNCO_HIP_FWS_MAXNP=44: the two kernels
+    share a launch).  Totals, best totals, slices, best slices and generator states identical."""
+    from tnco_amd import synthetic as syn
+    R = 4096
+    p = syn.sycamore_problem(20)
+    seeds = np.asarray(syn.replica_seeds(R, S=21))
+    links = core.greedy_trees(p.ts_inds, p.n_inds, seeds, device=0)
+    betas = H.linear_betas(0, 100, 1200)[:60]
+    ids = np.arange(R)
+
+    def run(env):
+        for k in ("TNCO_HIP_FW_NO_WAVE_SLICES", "TNCO_HIP_FWS_CAP", "TNCO_HIP_FWS_MAXNP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with core.BatchedOptimizer(p.leaf_masks, links, seeds, n_inds=p.n_inds, max_width=40) as g:
+            for c in range(0, 60, 20):
+                g.run(betas[c:c + 20], update_slices_every=10)
+            assert g.validate() == (0, -1)
+            return g.costs(), g.slices_many(ids), np.asarray(g.prng_states())
+
+    ref = run({"TNCO_HIP_FW_NO_WAVE_SLICES": "1"})
+    for env in ({}, {"TNCO_HIP_FWS_CAP": "1"}, {"TNCO_HIP_FWS_MAXNP": "44"}):
+        got = run(env)
+        assert np.array_equal(got[0][0], ref[0][0]) and np.array_equal(got[0][1], ref[0][1]), env
+        assert np.array_equal(got[1][0], ref[1][0]) and np.array_equal(got[1][1], ref[1][1]), env
+        assert np.array_equal(got[2], ref[2]), env
+
+
+def test_fw_more_than_64_candidate_legs_in_one_wavefront(core, oracle_lib):
+    """A 100-leg centre tensor, its 100 neighbours in a ring, max_width 70: the tensors around the centre have
+    71..100 candidate legs -- two per lane of fw_slices_kernel, up to 50 variates drawn at once -- against the
+    oracle."""
+    m = 100
+    ts = [list(range(m))] + [[i, m + i, m + (i + 1) % m] for i in range(m)]
+    prob = H.Problem(ts, 2)
+    seeds = H.replica_seeds(16, S=4)
+    _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 30, 24), 70, chunks=[24], every=3)

@@ -14,9 +14,10 @@
 //     fw_reslice_kernel iterates over them -- the k-th entry of all 16 replicas of a wavefront together, the next
 //     entries' loads in flight; counters, candidate lists, shuffles and picks in registers / LDS; the cache
 //     rebuilt from the leg masks;
-//   * when every cost is a power of two (fast_ok / tree_ok): no walk -- fw_order_kernel | fw_reslice_a_kernel
-//     (get_slices) | fw_tree_kernel (the cache RE-PRICED from the old costs) | fw_reslice_b_kernel; see the
-//     comment block at fw_order_kernel.  (fw_delta_kernel: the re-pricing over the walk's post-order records,
+//   * when every cost is a power of two (fast_ok / tree_ok): no walk -- fw_order_kernel | get_slices
+//     (fw_slices_kernel, one wavefront per replica; its stragglers and networks of more than 16 mask words:
+//     fw_reslice_a_kernel) | fw_tree_kernel (the cache RE-PRICED from the old costs) | fw_reslice_b_kernel; see
+//     the comment blocks at fw_order_kernel and fw_slices_kernel.  (fw_delta_kernel: the re-pricing over the walk's post-order records,
 //     round 2, behind TNCO_HIP_FW_NO_TREE.)
 // Covered: SimpleCostModel and SimpleSparseIndsCostModel (finite_width/cost_model/simple.hpp,
 // simple_sparse_inds.hpp), uniform and per-index dims, width_type float32 / float64, and the
@@ -1752,6 +1753,7 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_A_WAVES) void fw_reslice_a_ker
   v.init(P, P.blocks + r * P.RB, P.lpar + r * (int64_t)n * LPS, lig);
   ReplicaState* rs = P.rs + r;
   FwScratch sc(F, r, N);
+  if (prewalked && F.nwide[r] == -3) return;  // (fw_slices_kernel has done this replica)
   // (-2: fw_order_kernel has left this replica's too-wide tensors to the traverse in here)
   const int nw_pre = prewalked ? (F.nwide[r] == -2 ? -1 : F.nwide[r]) : -1;
   if (prewalked == 2 && nw_pre >= 0) sc.nwf = F.nwfront[r];
@@ -2188,6 +2190,406 @@ static __global__ __launch_bounds__(256) void fw_order_kernel(const Params P, co
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// get_slices (finite_width/greedy/utils.hpp:21-125) with one WAVEFRONT per replica: fw_slices_kernel, between
+// fw_order_kernel and fw_tree_kernel, for the networks of the tree path (uniform power-of-two dims, no sparse
+// legs) with at most 16 mask words.  fw_reslice_a_kernel (16 replicas per wavefront, in lock step) read the legs
+// of every too-wide tensor twice -- once for the counts, once in the greedy pass: ~2 x 110 lines per replica on
+// config 5, 2/3 of the chip's random-request rate for the length of the kernel -- and then gathered the counts
+// one byte per candidate leg from memory.  Here
+//   * lane 16 g + w holds word w of a mask, four tensors per load instruction; the legs read for the counts stay
+//     in LDS (the first `cap` tensors of the list) for the greedy pass; the counts become a byte table in LDS;
+//   * the scan for the next tensor that does not fit tests four tensors per step;
+//   * std::shuffle's variates are drawn for all pairs of swaps at once (lane k: pair k) and the permutation is
+//     applied by every lane tracing ITS final position back through the swaps -- registers only; the rare cases
+//     (a re-draw of uniform_int_distribution, the generator's 624 words ending inside the shuffle) run the
+//     sequential fw_shuffle_lds from the same generator position;
+//   * a pick is one maximum over the wavefront.
+// The generator is RngWave: 64 outputs per memory round trip, never ahead of the generation being consumed.
+// Replicas it leaves alone (nwide -2, > 255 too-wide tensors, > FWS_MAXNP candidate legs in a tensor) are done by
+// fw_reslice_a_kernel, which skips those marked done (nwide = -3).  Same outputs as that kernel: the proposed
+// slices, the change list for fw_tree_kernel, the generator's position.
+// ---------------------------------------------------------------------------------------------
+#ifndef TNCO_FWS_CAP
+#define TNCO_FWS_CAP 32
+#endif
+constexpr int FWS_CAP = TNCO_FWS_CAP;  // too-wide tensors whose legs stay in LDS between the two passes (default)
+constexpr int FWS_MAXNP = 128;          // candidate legs of one tensor: two per lane
+__host__ __device__ inline size_t fws_lds_bytes(int cap) {
+  return (size_t)cap * 128 + 1024 /* counts */ + 1024 /* generator ring */ + 512 /* positions */ + 512 /* list */;
+}
+
+// std::mt19937 for one wavefront: outputs [.., hi) of the CURRENT generation are in the ring (256 entries, batches
+// of 64 aligned to 64), words below `tw` of the state array are twisted.  A fill produces up to three batches in ONE
+// memory round trip (a dependent round trip costs this kernel 5-10 us: everything it touches is cold): word i is
+// twisted from words i, i + 1, i + 397 (mod 624), of which only i + 397 - 624 = i - 227 must be a NEW value, and
+// that word lies before the 192 being produced.  (mti, mtw) in and out as Rng<> keeps them.
+struct RngWave {
+  uint32_t* s;
+  lds_vu32* ring;
+  int lane;
+  uint32_t cons, tw, hi;
+  bool pend;  // (fw_shuffle_lds's interface: nothing is ever in flight here)
+  __device__ __forceinline__ void init(uint32_t* st, lds_vu32* ring_, int mti, int mtw, int lane_) {
+    s = st; ring = ring_; lane = lane_; pend = false;
+    if (mti >= 624) { cons = 624; tw = 624; } else { cons = (uint32_t)mti; tw = (uint32_t)mtw; }
+    hi = cons >= 624 ? 624u : (cons & ~63u);
+  }
+  __device__ __forceinline__ void roll() { cons = 0; tw = 0; hi = 0; }
+  // the (at most) three batches that start at hi
+  __device__ __forceinline__ void fill() {
+    const uint32_t k0 = hi, end = (k0 + 192u) < 624u ? (k0 + 192u) : 624u;
+    uint32_t v[3], nx[3], far[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const uint32_t i = k0 + 64u * (uint32_t)b + (uint32_t)lane;
+      v[b] = nx[b] = far[b] = 0u;
+      if (i < end) {
+        v[b] = s[i];
+        if (i >= tw) {
+          nx[b] = s[i + 1u == 624u ? 0u : i + 1u];
+          far[b] = s[i + 397u >= 624u ? i + 397u - 624u : i + 397u];
+        }
+      }
+    }
+    // (every load of the wavefront above, every store below: word i + 1 is read before its lane rewrites it)
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const uint32_t i = k0 + 64u * (uint32_t)b + (uint32_t)lane;
+      if (i < end) {
+        uint32_t x = v[b];
+        if (i >= tw) {
+          const uint32_t y = (x & 0x80000000u) | (nx[b] & 0x7fffffffu);
+          x = far[b] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+          s[i] = x;
+        }
+        ring[i & 255u] = mt_temper(x);
+      }
+    }
+    if (end > tw) tw = end;
+    hi = end;
+  }
+  __device__ __forceinline__ uint32_t next() {
+    if (cons == 624u) roll();
+    if (cons >= hi) fill();
+    const uint32_t x = ring[cons & 255u];
+    ++cons;
+    return x;
+  }
+  // m <= 64 outputs from here on in the ring?  (false: the generation ends first)
+  __device__ __forceinline__ bool ensure(uint32_t m) {
+    if (cons == 624u) roll();
+    if (cons + m > 624u) return false;
+    while (hi < cons + m) fill();  // (hi - 256 <= cons - 64: nothing unconsumed is overwritten)
+    return true;
+  }
+  __device__ __forceinline__ uint32_t peek(uint32_t k) const { return ring[(cons + k) & 255u]; }
+  __device__ __forceinline__ void advance(uint32_t m) { cons += m; }
+  // fw_shuffle_lds's interface
+  __device__ __forceinline__ bool room() const { return false; }
+  __device__ __forceinline__ void request() {}
+  __device__ __forceinline__ void produce() {}
+  __device__ __forceinline__ void prefetch() {}
+  __device__ __forceinline__ uint32_t next_sync() { return next(); }
+  __device__ __forceinline__ void finish(int& mti, int& mtw) const { mti = (int)cons; mtw = (int)tw; }
+};
+
+__device__ __forceinline__ uint64_t fws_shfl64(uint64_t x, int src) {
+  const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)x, src), hi = (uint32_t)__shfl((int)(uint32_t)(x >> 32), src);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t fws_shflx64(uint64_t x, int m) {
+  const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), m);
+  return ((uint64_t)hi << 32) | lo;
+}
+// inclusive sum over the lanes 0..w of a row of 16
+__device__ __forceinline__ uint32_t fws_rowscan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+  return v;
+}
+
+#ifdef TNCO_FWS_PROF  // (diagnostic build: shader cycles per replica of [list + counts, count table, greedy pass; of it scan, positions, generator, shuffle, keys + picks], replicas, slicings)
+static __device__ unsigned long long g_fws_prof[12];
+#define FWS_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define FWS_ACC(i, a, b) acc_[i] += (b) - (a)
+#else
+#define FWS_T(v)
+#define FWS_ACC(i, a, b)
+#endif
+static __global__ __launch_bounds__(64) void fw_slices_kernel(const Params P, const FwParams F, const int cap, const int maxnp) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t fws_smem[];
+  const int lane = threadIdx.x, w = lane & 15, g = lane >> 4;
+  const int64_t r = blockIdx.x;
+  // (everything that does not depend on anything else is requested first: a dependent round trip costs 5-10 us here)
+  const int nw = F.nwide[r];
+  const int n = P.n, N = P.N, W = P.W, LK = F.I64 / 64;
+  TNCO_LDS volatile uint64_t* cache = (TNCO_LDS volatile uint64_t*)fws_smem;          // [cap][16] legs of the listed tensors
+  TNCO_LDS volatile uint8_t* nbig = (TNCO_LDS volatile uint8_t*)(cache + (size_t)cap * 16);  // [1024] too-wide counts
+  lds_vu32* ring = (lds_vu32*)(nbig + 1024);                                          // [256]
+  lds_vi32* pos = (lds_vi32*)(ring + 256);                                            // [FWS_MAXNP]
+  TNCO_LDS volatile uint16_t* wls = (TNCO_LDS volatile uint16_t*)(pos + FWS_MAXNP);    // [256] the list
+  const FwScratch sc(F, r, N);
+  const uint8_t* legs = P.blocks + r * P.RB + P.WOFF;
+  const int WS = P.WS;
+  const bool has = w < W;
+  ReplicaState* rs = P.rs + r;
+  const int mti0 = rs->mti, mtw0 = rs->mtw;
+  const uint64_t old = has ? F.slices[r * 2 * (int64_t)LK + w] : 0ull;
+  const uint64_t skip = (F.skip != nullptr && has) ? F.skip[w] : 0ull;
+  int wlq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) wlq[q] = (64 * q + lane < sc.wcap) ? sc.wlist[64 * q + lane] : n;
+  if (nw < 0 || nw > 255) return;  // (-1: no slices, nothing to do; the others: fw_reslice_a_kernel)
+#ifdef TNCO_FWS_PROF
+  unsigned long long acc_[6] = {0, 0, 0, 0, 0, 0};
+#endif
+  FWS_T(q0_);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) wls[64 * q + lane] = (uint16_t)(64 * q + lane < nw ? wlq[q] : n);
+  // ---- :41-48: for every index the number of too-wide tensors it appears in (bit-sliced, four tensors side by side)
+  uint64_t pl[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) pl[p] = 0ull;
+  uint32_t maxc = 0;
+  uint64_t m[4];
+  auto load16 = [&](int t0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + 4 * u + g;
+      const int node = wls[t < nw ? t : 0];
+      m[u] = 0ull;
+      if (t < nw && has) m[u] = *reinterpret_cast<const uint64_t*>(legs + (int64_t)(node - n) * WS + 8 * w);
+    }
+  };
+  load16(0);
+  // the generator's first outputs travel with the first legs
+  RngWave rng;
+  rng.init(P.mt + r * 624, ring, mti0, mtw0, lane);
+  if (nw > 0) rng.fill();
+  for (int t0 = 0; t0 < nw; t0 += 16) {
+    if (t0) load16(t0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + 4 * u + g;
+      if (t < nw && t < cap) cache[t * 16 + w] = m[u];
+      const uint32_t c = gsum<4>((uint32_t)__popcll(m[u] & ~skip));
+      maxc = c > maxc ? c : maxc;
+      uint64_t carry = m[u];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const uint64_t tt = pl[p] & carry;
+        pl[p] ^= carry;
+        carry = tt;
+      }
+    }
+  }
+  if (gmax<6>(maxc) > (uint32_t)maxnp) {  // (nothing drawn yet; the generator's words twisted ahead stay)
+    if (lane == 0) rs->mtw = (int)rng.tw;
+    return;
+  }
+  FWS_T(q1_);
+  // the four partial counts of a lane's 64 indices, added
+#pragma unroll
+  for (int step = 16; step <= 32; step <<= 1) {
+    uint64_t o[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) o[p] = fws_shflx64(pl[p], step);
+    uint64_t c = 0ull;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const uint64_t a = pl[p], b = o[p];
+      pl[p] = a ^ b ^ c;
+      c = (a & b) | (c & (a ^ b));
+    }
+  }
+  {  // counters 16 g .. 16 g + 15 of word w -> sixteen bytes (a nibble of plane bits is spread over the bytes of a word)
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t c = 0;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const uint32_t nib = (uint32_t)(pl[p] >> (16 * g + 4 * j)) & 0xFu;
+        c |= ((nib * 0x00204081u) & 0x01010101u) << p;
+      }
+      o[j] = c;
+    }
+    TNCO_LDS volatile uint32_t* d = (TNCO_LDS volatile uint32_t*)(nbig + w * 64 + 16 * g);
+    d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3];
+  }
+  // ---- :62-101: the greedy pass over the list, in post-order
+  FWS_T(q2_);
+  uint64_t ns = 0ull;  // the new slices, word w (the same in the four rows of lanes)
+  const double mdl = fw_wr(F, -F.log2d);  // get_delta_width of a set position (simple.hpp:59-76)
+  int j = 0;
+  while (j < nw) {
+    FWS_T(s0_);
+    const int t = j + g;
+    uint64_t m = 0ull;
+    if (t < nw) {
+      if (t < cap) m = cache[t * 16 + w];
+      else if (has) m = *reinterpret_cast<const uint64_t*>(legs + (int64_t)((int)wls[t] - n) * WS + 8 * w);
+    }
+    const uint64_t sx = m & ~ns;
+    const uint32_t cnt = gsum<4>((uint32_t)__popcll(sx));
+    const bool wide = t < nw && fw_wr(F, F.log2d * (double)cnt) > F.max_width;
+    const unsigned long long bal = __ballot(wide);
+    if (bal == 0ull) {
+      j += 4;
+      FWS_T(s1_);
+      FWS_ACC(0, s0_, s1_);
+      continue;
+    }
+    FWS_T(s1_);
+    FWS_ACC(0, s0_, s1_);
+    const int gs = (__ffsll(bal) - 1) >> 4;  // the first of the four that does not fit
+    j += gs + 1;
+    const uint64_t sxw = fws_shfl64(sx, 16 * gs + w);
+    double sw = fw_wr(F, F.log2d * (double)(uint32_t)__shfl((int)cnt, 16 * gs));
+    // candidate positions, ascending
+    const uint64_t cand = sxw & ~skip;
+    const uint32_t mine = (uint32_t)__popcll(cand);
+    const uint32_t incl = fws_rowscan(mine);
+    const int np = __builtin_amdgcn_readlane((int)incl, 15);
+    if (g == 0) {
+      uint32_t o = incl - mine;
+      uint64_t x = cand;
+      while (x) {
+        const int b = __ffsll((unsigned long long)x) - 1;
+        pos[o++] = w * 64 + b;
+        x &= x - 1;
+      }
+    }
+    // :80 std::shuffle -- src0 / src1: where the candidates that end at ranks lane / lane + 64 stand before it
+    int src0 = lane, src1 = lane + 64;
+    FWS_T(s2_);
+    FWS_ACC(1, s1_, s2_);
+    if (np >= 2) {
+      const uint32_t nd = (uint32_t)np >> 1;  // variates: one per pair of swaps (+ the single swap of an even count)
+      bool fast = rng.ensure(nd);
+      FWS_T(s3_);
+      FWS_ACC(2, s2_, s3_);
+      uint32_t p0 = 0, p1 = 0;
+      const int base = (np & 1) ? 1 : 0;  // lane k swaps positions base + 2 k, base + 2 k + 1 (position 0 with itself)
+      if (fast) {
+        const uint32_t raw = rng.peek((uint32_t)lane);
+        const uint32_t i0 = (uint32_t)(base + 2 * lane);
+        const bool single = base == 0 && lane == 0;  // (stl_algo.h:3760-3765: d(0, 1), the swap of position 1)
+        const uint32_t range = single ? 2u : (i0 + 1u) * (i0 + 2u);
+        const uint64_t product = (uint64_t)raw * (uint64_t)range;
+        const uint32_t low = (uint32_t)product;
+        bool rej = false;
+        if ((uint32_t)lane < nd && low < range) rej = low < (0u - range) % range;
+        if (__any(rej)) {
+          fast = false;
+        } else {
+          const uint32_t x = (uint32_t)(product >> 32);
+          if (single) {
+            p0 = 0;
+            p1 = x;
+          } else {
+            p0 = x / (i0 + 2u);
+            p1 = x - p0 * (i0 + 2u);
+          }
+          rng.advance(nd);
+        }
+      }
+      if (fast) {
+        const bool two = np > 64;
+        for (int k = (int)nd - 1; k >= 0; --k) {
+          const int j1 = __builtin_amdgcn_readlane((int)p1, k), j0 = __builtin_amdgcn_readlane((int)p0, k);
+          const int i = base + 2 * k;
+          src0 = src0 == i + 1 ? j1 : (src0 == j1 ? i + 1 : src0);
+          src0 = src0 == i ? j0 : (src0 == j0 ? i : src0);
+          if (two) {
+            src1 = src1 == i + 1 ? j1 : (src1 == j1 ? i + 1 : src1);
+            src1 = src1 == i ? j0 : (src1 == j0 ? i : src1);
+          }
+        }
+      } else {
+        fw_shuffle_lds<6>(rng, pos, np, lane == 0);
+      }
+      FWS_T(s4_);
+      FWS_ACC(3, s3_, s4_);
+    }
+    FWS_T(s5_);
+    // :83-101 the keys ((too-wide count << 16) | 0xFFFF - shuffled rank: the stable order of :83); picks until it fits
+    const int xp0 = lane < np ? (int)pos[src0] : 0, xp1 = lane + 64 < np ? (int)pos[src1] : 0;
+    uint32_t k0 = lane < np ? (((uint32_t)nbig[xp0] << 16) | (0xFFFFu - (uint32_t)lane)) : 0u;
+    uint32_t k1 = lane + 64 < np ? (((uint32_t)nbig[xp1] << 16) | (0xFFFFu - (uint32_t)(lane + 64))) : 0u;
+    for (int taken = 0; taken < np; ++taken) {
+      const uint32_t best = gmax<6>(k0 > k1 ? k0 : k1);
+      const int qb = (int)(0xFFFFu - (best & 0xFFFFu));
+      const int xpos = __shfl(qb >= 64 ? xp1 : xp0, qb & 63);
+      if (lane == (qb & 63)) {
+        if (qb >= 64) k1 = 0u; else k0 = 0u;
+      }
+      if (w == (xpos >> 6)) ns |= 1ull << (xpos & 63);
+      sw = fw_wr(F, sw + mdl);
+      if (sw <= F.max_width) break;
+    }
+    FWS_T(s6_);
+    FWS_ACC(4, s5_, s6_);
+#ifdef TNCO_FWS_PROF
+    acc_[5] += 1;
+#endif
+  }
+  FWS_T(q3_);
+  // ---- the proposed slices, and for fw_tree_kernel the indices that changed (as fw_reslice_a_kernel leaves them)
+  uint64_t* prop = reinterpret_cast<uint64_t*>(const_cast<int16_t*>(sc.pos));
+  if (g == 0 && w < LK) prop[w] = ns;
+  {
+    uint32_t* chg = reinterpret_cast<uint32_t*>(F.delta_scr + r * 64);
+    const int32_t* lpar = P.lpar + r * (int64_t)n * LPS;
+    uint64_t ch = g == 0 ? (ns ^ old) : 0ull;
+    const uint32_t mine = (uint32_t)__popcll(ch);
+    const uint32_t incl = fws_rowscan(mine);
+    const int total = __builtin_amdgcn_readlane((int)incl, 15);
+    bool unsup = total > FWT_MAXD;
+    uint64_t plus = 0ull, minus = 0ull;
+    if (!unsup) {
+      uint32_t off = incl - mine;
+      while (ch) {
+        const int bit = __ffsll((unsigned long long)ch) - 1;
+        ch &= ch - 1;
+        const int2 t12 = *reinterpret_cast<const int2*>(F.holder2 + 2 * (w * 64 + bit));
+        if (t12.x < 0) { unsup = true; break; }
+        const int s1 = lpar[(int64_t)t12.x * LPS], s2 = t12.y < 0 ? 0xFFFF : lpar[(int64_t)t12.y * LPS];
+        chg[8 + off] = (uint32_t)s1 | ((uint32_t)s2 << 16);
+        if ((ns >> bit) & 1ull) plus |= 1ull << off; else minus |= 1ull << off;
+        ++off;
+      }
+    }
+    unsup = __any(unsup);
+    // (disjoint bits: the sum over the row is the union)
+    const uint32_t a0 = gsum<4>((uint32_t)plus), a1 = gsum<4>((uint32_t)(plus >> 32));
+    const uint32_t b0 = gsum<4>((uint32_t)minus), b1 = gsum<4>((uint32_t)(minus >> 32));
+    if (lane == 0) {
+      chg[0] = unsup ? 0xFFFFFFFFu : (uint32_t)total;
+      *reinterpret_cast<uint4*>(chg + 4) = make_uint4(a0, a1, b0, b1);
+    }
+  }
+  int mti, mtw;
+  rng.finish(mti, mtw);
+  if (lane == 0) {
+    rs->mti = mti;
+    rs->mtw = mtw;
+    F.nwide[r] = -3;  // done: fw_reslice_a_kernel skips this replica
+  }
+#ifdef TNCO_FWS_PROF
+  if (lane == 0) {
+    atomicAdd(&g_fws_prof[0], q1_ - q0_); atomicAdd(&g_fws_prof[1], q2_ - q1_); atomicAdd(&g_fws_prof[2], q3_ - q2_);
+    for (int q = 0; q < 5; ++q) atomicAdd(&g_fws_prof[3 + q], acc_[q]);
+    atomicAdd(&g_fws_prof[8], 1ull); atomicAdd(&g_fws_prof[9], acc_[5]); atomicAdd(&g_fws_prof[10], (unsigned long long)nw);
+    atomicAdd(&g_fws_prof[11], __builtin_amdgcn_s_memtime() - q0_);
+  }
+#endif
+}
+
 #ifdef TNCO_FWT_PROF  // (diagnostic build: shader cycles of [setup, header load, the loop, commit], loop iterations, replicas, commits)
 static __device__ unsigned long long g_fwt_prof[8];
 #define FWT_T(i) const unsigned long long tt##i = __builtin_amdgcn_s_memtime()
@@ -2395,8 +2797,11 @@ static __global__ __launch_bounds__(256, (J * GW <= 576 ? 4 : 2)) void fw_tree_k
 #endif
 }
 
+#ifndef TNCO_FW_RESLICE_B_WAVES
+#define TNCO_FW_RESLICE_B_WAVES TNCO_FW_RESLICE_WAVES
+#endif
 template <int LOG2L, int K, bool HYPER>
-__global__ __launch_bounds__(256, TNCO_FW_RESLICE_WAVES) void fw_reslice_b_kernel(const Params P, const FwParams F, const int need_rec) {
+__global__ __launch_bounds__(256, TNCO_FW_RESLICE_B_WAVES) void fw_reslice_b_kernel(const Params P, const FwParams F, const int need_rec) {
   constexpr int L = 1 << LOG2L;
   constexpr int GPB = 256 >> LOG2L;
   constexpr int LK = L * K;

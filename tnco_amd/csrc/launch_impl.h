@@ -140,7 +140,11 @@ void launch_fw_reslice_lk(tnco_hip_ctx* h, int prewalked) {
   const int gpb = 256 >> LOG2L;
   dim3 grid((unsigned)((h->P.R + gpb - 1) / gpb));
 #ifndef TNCO_PROFILE
-  if (h->F.fast_ok && prewalked == 3 && !h->hyper) {  // no walk: get_slices from fw_order_kernel's list | fw_tree_kernel | end of the sweep
+  if (h->F.fast_ok && prewalked == 3 && !h->hyper) {  // no walk: get_slices from fw_order_kernel's list (fw_slices_kernel) | fw_tree_kernel | end of the sweep
+    if (h->fw_wave_slices > 0)
+      hipLaunchKernelGGL(fw_slices_kernel, dim3((unsigned)h->P.R), dim3(64), fws_lds_bytes(h->fw_wave_slices), h->stream, h->P, h->F,
+                         h->fw_wave_slices, h->fw_wave_maxnp);
+    // (the replicas fw_slices_kernel has left alone, usually none: 5 us of an empty launch)
     hipLaunchKernelGGL((fw_reslice_a_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, 2);
     {
       // (one wavefront per replica.  Two replicas per wavefront, 32 lanes each -- fw_tree_kernel<J, 32> -- measured
@@ -156,6 +160,21 @@ void launch_fw_reslice_lk(tnco_hip_ctx* h, int prewalked) {
 #undef TNCO_FWT
     }
     hipLaunchKernelGGL((fw_reslice_b_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, 1);
+#ifdef TNCO_FWS_PROF
+    {
+      static int scalls = 0;
+      if (++scalls % 80 == 0) {
+        unsigned long long st[12];
+        (void)hipDeviceSynchronize();
+        if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_fws_prof), sizeof(st)) == hipSuccess && st[8]) {
+          const double d = (double)st[8];
+          std::fprintf(stderr, "fw_slices after %d launches: cycles per replica: list + counts %.0f, table %.0f, greedy pass %.0f (scan %.0f, positions %.0f, "
+                       "generator %.0f, shuffle %.0f, keys + picks %.0f), whole %.0f; %.1f too-wide tensors, %.1f sliced\n", scalls, st[0] / d, st[1] / d, st[2] / d,
+                       st[3] / d, st[4] / d, st[5] / d, st[6] / d, st[7] / d, st[11] / d, st[10] / d, st[9] / d);
+        }
+      }
+    }
+#endif
 #ifdef TNCO_FWA_PROF
     {
       static int acalls = 0;

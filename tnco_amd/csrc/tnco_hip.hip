@@ -912,6 +912,13 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
 #undef CALL_FWP
         if (!ok) F.tree_ok = 0;
       }
+      // ... and get_slices with one wavefront per replica when a mask fits a row of sixteen lanes
+      if (F.tree_ok && W <= 16 && F.I64 <= 1024 && !std::getenv("TNCO_HIP_FW_NO_WAVE_SLICES")) {
+        h->fw_wave_slices = FWS_CAP;
+        if (const char* e = std::getenv("TNCO_HIP_FWS_CAP")) h->fw_wave_slices = std::max(1, std::min(256, std::atoi(e)));
+        h->fw_wave_maxnp = FWS_MAXNP;
+        if (const char* e = std::getenv("TNCO_HIP_FWS_MAXNP")) h->fw_wave_maxnp = std::max(0, std::min(FWS_MAXNP, std::atoi(e)));
+      }
     }
     // rows of W words (one shared, or one per replica) -> rows of L words on the device, zero-padded
     auto upload_rows = [&](const uint64_t* src, uint64_t** dst) -> int {
