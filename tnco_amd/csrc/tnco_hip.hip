@@ -1025,9 +1025,9 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     }
   }
 
-  // Infinite memory: do the replicas fill whole rounds of resident blocks?  If the last round would be
-  // partial (65536 replicas at 512 leaves: 1024 blocks, 768 resident), every step is split over two streams
-  // (host_ctx.h, tnco_hip_run).  TNCO_HIP_GROUPS=1..4 overrides.
+  // Infinite memory: more blocks than resident ones (65536 replicas at 512 leaves: 1024 blocks, 768 resident)?  Then
+  // every step is split over two streams (host_ctx.h, tnco_hip_run), unless the last round is nearly full anyway.
+  // TNCO_HIP_GROUPS=1..4 overrides.
   {
     const int64_t nblocks = (R + (SWT / h->L) - 1) / (SWT / h->L);
     int G = 1;
@@ -1037,7 +1037,9 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       h->run_slots = run_blocks_per_cu(h) * prop.multiProcessorCount;
       if (h->run_slots > 0 && nblocks > h->run_slots) {
         const double rounds = (double)nblocks / (double)h->run_slots, part = rounds - std::floor(rounds);
-        if (part > 0.02 && part < 0.85) G = 2;
+        // (also with whole rounds: the blocks of a round do not end together -- the general cost path at two
+        //  wavefronts per SIMD, 1024 blocks on 512 slots: +2 ... +8 % on two streams, profiles/r03_other_configs.md)
+        if (part < 0.85) G = 2;
       }
     } else if (nblocks >= 64 && h->F.max_new_slices == 0) {
       // finite width: two halves on two streams whatever the rounds -- what overlaps are KERNELS of different
