@@ -383,8 +383,9 @@ def main() -> None:
 
     # N > 1 (or TNCO_BENCH_FORCE_GROUP, the test of a group of ONE rank on a 1-GPU box): the ranks talk through RCCL bound
     # inside libtnco_hip.so (tnco_amd/parallel.py NativeComm: this process then holds ONE HIP runtime, torch is only the
-    # launcher); TNCO_BENCH_COMM=torch, or a failure to set that up, goes through torch.distributed ("nccl" = RCCL in
-    # PyTorch's bundled runtime) as rounds 1-2 did; TNCO_BENCH_SHARE_GPU (tests: N ranks on one GPU) through gloo.
+    # launcher) -- or, if RCCL does not come up on every rank, through plain sockets (16 bytes per exchange; the line
+    # says so); TNCO_BENCH_COMM=torch goes through torch.distributed ("nccl" = RCCL in PyTorch's bundled runtime) as
+    # rounds 1-2 did; TNCO_BENCH_SHARE_GPU (tests: N ranks on one GPU) through gloo.
     from tnco_amd import parallel
     grouped = world > 1 or bool(os.environ.get("TNCO_BENCH_FORCE_GROUP"))
     torch = dist = None
@@ -403,13 +404,16 @@ def main() -> None:
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         want = "gloo" if os.environ.get("TNCO_BENCH_SHARE_GPU") else os.environ.get("TNCO_BENCH_COMM", "native")
+        if os.environ.get("TNCO_BENCH_SHARE_GPU") == "sockets":
+            # test knob: N ranks on ONE GPU over the socket transport (what a launch falls back to when RCCL does not
+            # come up on every rank), no torch in the ranks
+            want, local_rank = "native", 0
+            os.environ["TNCO_COMM"] = "sockets"
         if want == "native":
-            try:
-                parallel.init_native(rank, world, local_rank)
-                comm_kind = "rccl (librccl.so bound inside libtnco_hip.so)"
-            except Exception as e:  # noqa: BLE001 -- reported in the line; the run goes on through torch.distributed
-                comm_note = f"native communicator failed ({e!r}): torch.distributed instead"
-                want = "torch"
+            # RCCL if it comes up on every rank, else sockets on every rank (parallel.init_native: the ranks agree on a
+            # side channel; ncclCommInitRank runs under a time limit) -- the line says which, and why
+            c = parallel.init_native(rank, world, local_rank)
+            comm_kind, comm_note = c.kind, getattr(c, "note", None)
         if want != "native":
             import torch
             import torch.distributed as dist
@@ -422,9 +426,8 @@ def main() -> None:
             else:
                 import datetime
                 torch.cuda.set_device(local_rank)
-                # (a fall-back taken by SOME ranks only can never complete: fail within minutes, not after the default half hour)
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
-                                        timeout=datetime.timedelta(seconds=300 if comm_note else 1800))
+                                        timeout=datetime.timedelta(seconds=1800))
             comm_kind = f"torch.distributed {dist.get_backend()}"
     else:
         import torch  # (one rank: nothing to exchange; torch only for the contract's torch.cuda.synchronize())
@@ -625,8 +628,13 @@ def main() -> None:
         if leg.opt is not None:
             leg.opt.close()
     if parallel._native is not None:
+        hung = bool(getattr(parallel._native, "hung", False))
         parallel._native.barrier()
         parallel.shutdown_native()
+        if hung:  # (a thread of this process still sits in ncclCommInitRank: leave without RCCL's exit handlers)
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
     elif grouped:
         dist.barrier()
         dist.destroy_process_group()

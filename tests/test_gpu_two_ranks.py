@@ -100,6 +100,30 @@ def test_bench_line_of_a_two_rank_launch():
 
 
 @pytest.mark.timeout(600)
+def test_bench_line_of_a_two_rank_launch_over_the_socket_transport():
+    """The same launch with the ranks' exchanges on the transport of last resort (tnco_amd.parallel.SocketComm: what
+    init_native falls back to on ALL ranks when RCCL does not come up on every one of them), both ranks on the one
+    GPU: one valid line, the transport and the reason named in it."""
+    import json
+    import subprocess
+    env = dict(os.environ, TNCO_BENCH_SHARE_GPU="sockets", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--replicas", "2048", "--sweeps-per-step", "20", "--pmc", "0", "--cpu-sample", "0"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=540, env=env, cwd=str(ROOT))
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and len(j["config"]["devices"]) == 2
+    assert all("tcp sockets" in d["backend"] for d in j["config"]["devices"])
+    assert "TNCO_COMM=sockets" in j["config"]["comm_note"]
+    for obj in (j, j["fw"]):
+        ranks = obj["config"]["ranks"]
+        assert [r["rank"] for r in ranks] == [0, 1] and sum(r["moves"] for r in ranks) == obj["config"]["moves_timed"]
+
+
+@pytest.mark.timeout(600)
 def test_bench_line_through_rccl_group_of_one():
     """The RCCL side of bench.py on a 1-GPU box: a launch of one rank that still goes through the communicator
     (TNCO_BENCH_FORCE_GROUP) -- natively (RCCL bound inside libtnco_hip.so: no torch in the process, the best cost

@@ -210,3 +210,68 @@ def test_two_ranks_through_the_native_communicator_logic(tmp_path):
         assert best == 7.0 and wc == 7.0 and wid == 1
         assert wp == [[1] * 5] * 3
         assert merged == [(7.0, 1), (7.0, 4), (7.5, 9)]
+
+
+class _FlakyLib(_FileCollectives):
+    """The stand-in library with RCCL failing in a chosen way on ONE rank."""
+
+    def __init__(self, root, rank, world, mode, bad_rank):
+        super().__init__(root, rank, world)
+        self.mode, self.bad = mode, rank == bad_rank
+
+    def tnco_hip_comm_last_error(self):
+        return b"librccl.so: cannot open shared object file"
+
+    def tnco_hip_comm_unique_id(self, uid):
+        if self.bad and self.mode == "no_library":
+            return 1
+        return super().tnco_hip_comm_unique_id(uid)
+
+    def tnco_hip_comm_init(self, rank, world, uid, device, out):
+        if self.mode == "init_hangs":  # (ncclCommInitRank waits for a rank that never comes)
+            import time
+            time.sleep(3600 if not self.bad else 0)
+            return 1
+        return super().tnco_hip_comm_init(rank, world, uid, device, out)
+
+
+def _init_native_worker(rank, world, port, root, mode, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from tnco_amd import parallel
+    lib = _FlakyLib(root, rank, world, mode, bad_rank=1)
+    c = parallel.init_native(rank, world, 0, lib=lib, timeout=3.0 if mode == "init_hangs" else 60.0)
+    try:
+        best = parallel.global_best(10.0 - rank, rank, world)
+        wc, wid, wp = parallel.global_winner(10.0 - rank, 100 + rank, np.full(4, rank, np.int32), rank, world)
+        merged = parallel.merge_heads([(10.0 - rank, 100 + rank, "x" * (rank * 50))], 2, rank, world)
+        c.barrier()
+        q.put((rank, type(c).__name__, c.kind, getattr(c, "note", None), best, wc, wid, wp.tolist(), [t[:2] for t in merged]))
+    finally:
+        parallel.shutdown_native()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("mode", ["fine", "no_library", "init_hangs"])
+def test_three_ranks_agree_on_the_transport(tmp_path, mode):
+    """init_native with world_size 3: RCCL (here the stand-in library) when it comes up on every rank; when ONE rank
+    cannot load it, or ncclCommInitRank does not return, ALL ranks go through the sockets -- same results, the reason
+    in `.note` -- instead of a launch that hangs."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_init_native_worker, args=(r, 3, port, str(tmp_path), mode, q), daemon=True) for r in range(3)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(30)
+    for rank, cls, kind, note, best, wc, wid, wp, merged in out:
+        assert best == 8.0 and (wc, wid) == (8.0, 102) and wp == [2] * 4
+        assert merged == [(8.0, 102), (9.0, 101)]
+        if mode == "fine":
+            assert cls == "NativeComm" and note is None and kind.startswith("rccl")
+        else:
+            assert cls == "SocketComm" and kind.startswith("tcp") and "rank" in note
+            assert ("cannot open" in note) if mode == "no_library" else ("did not return" in note or "rank 1" in note)

@@ -19,7 +19,7 @@ import time
 
 import numpy as np
 
-__all__ = ["shard_bounds", "global_best", "global_winner", "NativeComm", "init_native", "shutdown_native"]
+__all__ = ["shard_bounds", "global_best", "global_winner", "NativeComm", "SocketComm", "init_native", "shutdown_native"]
 
 
 class NativeComm:
@@ -29,8 +29,10 @@ class NativeComm:
     rank 0 to the others over a plain TCP socket on MASTER_ADDR : MASTER_PORT + 17 (`TNCO_COMM_PORT`
     overrides), so a launch by `torch.distributed.run` needs torch for the launcher only."""
 
+    kind = "rccl (librccl.so bound inside libtnco_hip.so)"
+
     def __init__(self, rank: int, world: int, device: int, addr: str | None = None, port: int | None = None,
-                 timeout: float = 90.0, lib=None):
+                 timeout: float = 90.0, lib=None, side: "SocketComm | None" = None):
         if lib is None:  # (tests pass a stand-in with the tnco_hip_comm_* entry points: the rendezvous and the
             from . import _lib  # host logic above the collectives run on a CPU box that way)
             lib = _lib.load()
@@ -40,7 +42,12 @@ class NativeComm:
         addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
         port = int(port or os.environ.get("TNCO_COMM_PORT") or int(os.environ.get("MASTER_PORT", "29533")) + 17)
         uid = (C.c_uint8 * 128)()
-        if self.rank == 0:
+        if side is not None:  # the id travels over the side channel the ranks already share (init_native)
+            if self.rank == 0:
+                self._check(self._L.tnco_hip_comm_unique_id(uid))
+            data = side.allgather_object(bytes(uid) if self.rank == 0 else None)[0]
+            C.memmove(uid, data, 128)
+        elif self.rank == 0:
             self._check(self._L.tnco_hip_comm_unique_id(uid))
             if self.world > 1:
                 srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
@@ -73,9 +80,30 @@ class NativeComm:
                         raise RuntimeError(f"rank {self.rank}: no ncclUniqueId from rank 0 at {addr}:{port}")
                     time.sleep(0.05)
             C.memmove(uid, data, 128)
+        # ncclCommInitRank blocks until every rank has called it and has no time limit of its own: it runs on a
+        # thread that is given `timeout` seconds (a rank that gives up says so to the others -- init_native)
         h = C.c_void_p()
-        self._check(self._L.tnco_hip_comm_init(self.rank, self.world, uid, self.device, C.byref(h)))
+        box: dict = {}
+
+        def _init():
+            try:
+                box["rc"] = self._L.tnco_hip_comm_init(self.rank, self.world, uid, self.device, C.byref(h))
+            except Exception as e:  # noqa: BLE001
+                box["exc"] = e
+
+        import threading
+        th = threading.Thread(target=_init, name="tnco-rccl-init", daemon=True)
+        th.start()
+        th.join(timeout)
+        if th.is_alive():
+            self.hung = True
+            raise TimeoutError(f"rank {self.rank}: ncclCommInitRank did not return within {timeout:.0f} s")
+        if "exc" in box:
+            raise box["exc"]
+        self._check(box["rc"])
         self._h = h
+
+    hung = False
 
     def _check(self, rc):
         if rc:
@@ -121,25 +149,161 @@ class NativeComm:
         return [pickle.loads(allb[k, :int(sizes[k])].tobytes()) for k in range(self.world)]
 
 
-_native: NativeComm | None = None
+class SocketComm:
+    """The same five calls over TCP through rank 0 (a star on MASTER_ADDR : MASTER_PORT + 18, `TNCO_COMM_SIDE_PORT`
+    overrides): the side channel on which the ranks agree whether RCCL came up on ALL of them, and the transport of
+    last resort when it did not -- what the ranks exchange is 16 bytes per launch chunk and the heads of the result
+    lists at the end, so a launch on N GPUs still reports its numbers (and says which transport carried them)."""
+
+    kind = "tcp sockets through rank 0"
+    hung = False
+
+    def __init__(self, rank: int, world: int, addr: str | None = None, port: int | None = None, timeout: float = 90.0):
+        self.rank, self.world = int(rank), int(world)
+        self._peers: dict[int, socket.socket] = {}
+        self._up: socket.socket | None = None
+        if self.world == 1:
+            return
+        addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(port or os.environ.get("TNCO_COMM_SIDE_PORT") or int(os.environ.get("MASTER_PORT", "29533")) + 18)
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(self.world)
+            srv.settimeout(timeout)
+            try:
+                while len(self._peers) < self.world - 1:
+                    conn, _peer = srv.accept()
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    conn.settimeout(None)
+                    k = int.from_bytes(self._recv_exact(conn, 4), "little")
+                    self._peers[k] = conn
+            finally:
+                srv.close()
+        else:
+            t0 = time.monotonic()
+            while True:
+                try:
+                    c = socket.create_connection((addr, port), timeout=5.0)
+                    break
+                except OSError:
+                    if time.monotonic() - t0 > timeout:
+                        raise RuntimeError(f"rank {self.rank}: rank 0 does not answer at {addr}:{port}") from None
+                    time.sleep(0.05)
+            c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            c.settimeout(None)
+            c.sendall(self.rank.to_bytes(4, "little"))
+            self._up = c
+
+    @staticmethod
+    def _recv_exact(c: socket.socket, n: int) -> bytes:
+        buf = bytearray()
+        while len(buf) < n:
+            chunk = c.recv(n - len(buf))
+            if not chunk:
+                raise ConnectionError("peer closed the side channel")
+            buf += chunk
+        return bytes(buf)
+
+    @classmethod
+    def _send_msg(cls, c: socket.socket, blob: bytes) -> None:
+        c.sendall(len(blob).to_bytes(8, "little") + blob)
+
+    @classmethod
+    def _recv_msg(cls, c: socket.socket) -> bytes:
+        return cls._recv_exact(c, int.from_bytes(cls._recv_exact(c, 8), "little"))
+
+    def allgather_object(self, obj) -> list:
+        if self.world == 1:
+            return [obj]
+        if self.rank == 0:
+            parts = [obj] + [pickle.loads(self._recv_msg(self._peers[k])) for k in range(1, self.world)]
+            blob = pickle.dumps(parts)
+            for k in range(1, self.world):
+                self._send_msg(self._peers[k], blob)
+            return parts
+        self._send_msg(self._up, pickle.dumps(obj))
+        return pickle.loads(self._recv_msg(self._up))
+
+    def allgather_array(self, a: np.ndarray) -> np.ndarray:
+        return np.stack(self.allgather_object(np.ascontiguousarray(a)))
+
+    def allreduce_min(self, opt_or_cost) -> float:
+        c = float(opt_or_cost.best(1)[0][0]) if hasattr(opt_or_cost, "best") else float(opt_or_cost)
+        return min(self.allgather_object(c))
+
+    def barrier(self) -> None:
+        self.allgather_object(None)
+
+    def close(self) -> None:
+        for c in list(self._peers.values()) + ([self._up] if self._up is not None else []):
+            try:
+                c.close()
+            except OSError:
+                pass
+        self._peers, self._up = {}, None
 
 
-def init_native(rank: int | None = None, world: int | None = None, device: int | None = None, **kw) -> NativeComm:
-    """The process-wide communicator (rank / world / device default to the torchrun environment)."""
-    global _native
-    if _native is None:
-        rank = int(os.environ.get("RANK", "0")) if rank is None else rank
-        world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
-        device = local_device() if device is None else device
-        _native = NativeComm(rank, world, device, **kw)
+_native: "NativeComm | SocketComm | None" = None
+_side: SocketComm | None = None
+
+
+def init_native(rank: int | None = None, world: int | None = None, device: int | None = None, **kw):
+    """The process-wide communicator (rank / world / device default to the torchrun environment): RCCL inside the
+    library if it comes up on EVERY rank, else the socket transport on all of them -- never a mix, which could only
+    hang.  The ranks first meet on the side channel (SocketComm); each probes RCCL (a unique id can be made: the
+    library is there); if all can, each runs ncclCommInitRank under a time limit (`TNCO_COMM_INIT_TIMEOUT`, 120 s)
+    and they compare notes again.  `.kind` of the result says which transport it is, `.note` why RCCL was not."""
+    global _native, _side
+    if _native is not None:
+        return _native
+    rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+    world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+    device = local_device() if device is None else device
+    lib = kw.pop("lib", None)
+    timeout = float(kw.pop("timeout", os.environ.get("TNCO_COMM_INIT_TIMEOUT", "120")))
+    side = SocketComm(rank, world, timeout=max(timeout, 90.0), **{k: v for k, v in kw.items() if k in ("addr",)})
+    note = None
+    try:
+        if os.environ.get("TNCO_COMM", "") == "sockets":
+            raise RuntimeError("TNCO_COMM=sockets")
+        if lib is None:
+            from . import _lib
+            lib = _lib.load()
+        probe = (C.c_uint8 * 128)()
+        ok = lib.tnco_hip_comm_unique_id(probe) == 0
+        why = None if ok else lib.tnco_hip_comm_last_error().decode()
+    except Exception as e:  # noqa: BLE001 -- whatever it is, the other ranks must hear of it
+        ok, why = False, repr(e)
+    votes = side.allgather_object((ok, why))
+    comm = None
+    if all(v[0] for v in votes):
+        try:
+            comm = NativeComm(rank, world, device, lib=lib, side=side, timeout=timeout)
+            ok, why = True, None
+        except Exception as e:  # noqa: BLE001
+            ok, why = False, repr(e)
+        votes = side.allgather_object((ok, why))
+    if all(v[0] for v in votes):
+        _native, _side = comm, side
+        comm.note = None
+        return _native
+    note = "; ".join(f"rank {k}: {v[1]}" for k, v in enumerate(votes) if not v[0])
+    if comm is not None:
+        comm.close()
+    side.note = "RCCL not used -- " + note
+    side.hung = "did not return" in note
+    _native, _side = side, None
     return _native
 
 
 def shutdown_native() -> None:
-    global _native
-    if _native is not None:
-        _native.close()
-        _native = None
+    global _native, _side
+    for c in (_native, _side):
+        if c is not None:
+            c.close()
+    _native = _side = None
 
 
 def shard_bounds(n_runs: int, world: int, rank: int) -> tuple[int, int]:
