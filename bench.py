@@ -67,7 +67,7 @@ def kernel_of(name: str):
             return short
     if "fw_walk2_kernel" in name or "fw_order_kernel" in name:  # (what lists the too-wide tensors in post-order)
         return "fw_walk_kernel"
-    if ("fw_reslice_a_kernel" in name or "fw_slices_kernel" in name or "fw_delta_kernel" in name
+    if ("fw_reslice_a_kernel" in name or "fw_slices_kernel" in name or "fw_wave_kernel" in name or "fw_delta_kernel" in name
             or "fw_tree_kernel" in name or "fw_reslice_b_kernel" in name):
         return "fw_reslice_kernel"  # (the re-slice by re-pricing: get_slices | fw_tree_kernel | end of the sweep)
     return None
@@ -299,8 +299,8 @@ def pmc_passes(args, lib_version):
     for (short, ctr), v in vals.items():
         n = per_step[short]
         # (a step is two concurrent dispatches per kernel when the handle splits it over two streams; the re-slice by
-        #  re-pricing is four kernels: get_slices (fw_slices_kernel, its stragglers in fw_reslice_a_kernel) | fw_tree_kernel |
-        #  end of the sweep -- so 1, 2, 4 or 8 times n)
+        #  re-pricing is three kernels: fw_wave_kernel (order | get_slices | re-pricing of a replica in one wavefront) |
+        #  its stragglers in fw_reslice_a_kernel | end of the sweep -- so 1, 2, 3 or 6 times n)
         mult, rest = divmod(len(v), n * (args.warmup + args.steps))
         if rest or mult < 1:
             continue
@@ -510,7 +510,8 @@ def main() -> None:
                 n_res = FW_RESLICE_LAUNCHES(sps, every) * R
                 alg_per_step = bmove * moves_per_step_gpu + bres * n_res
                 extra = {"algorithmic_bytes_per_move": bmove, "algorithmic_bytes_per_reslice": bres,
-                         "reslice_form": ("re-priced: fw_order_kernel | get_slices | fw_tree_kernel (no walk, no leg mask read)"
+                         "reslice_form": ("re-priced, one wavefront per replica: too-wide tensors ordered | get_slices | costs re-priced from the old ones "
+                                          "(fw_wave_kernel; no walk, no leg masks read but the too-wide tensors')"
                                           if leg.repriced else "full CostCache rebuild"),
                          "reslices_per_step": n_res, "algorithmic_bytes_moves_only": bmove * moves_per_step_gpu}
             step_ms = sum(kt[k][0] for k in kernels) / args.steps  # device time of one step's kernels
@@ -533,7 +534,7 @@ def main() -> None:
                                                 / 1e9 / HBM_PEAK_GBS)
                 if leg.groups > 1:
                     roof["streams"] = leg.groups
-                    roof["note_streams"] = ("the two halves of the batch run the whole step -- moves, fw_order | get_slices | fw_tree | "
+                    roof["note_streams"] = ("the two halves of the batch run the whole step -- moves, re-slice (fw_wave_kernel), "
                                             "end of sweep -- on streams of their own: request-bound moves of one half overlap the "
                                             "latency-bound re-slice kernels of the other; avg_launch_ms = device time of the timed "
                                             "region / steps, kernels[*].ms_per_step = average time a stream spent in that kernel")

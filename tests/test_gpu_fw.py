@@ -372,7 +372,9 @@ def test_config5_many_changed_indices_from_random_starts(core, oracle_lib, monke
 
 
 def test_get_slices_per_wavefront_equals_the_lockstep_kernel(core, monkeypatch):
-    """fw_slices_kernel (one wavefront per replica: the default on the tree path) against fw_reslice_a_kernel
+    """The re-slice of a replica in one wavefront (fw_wave_kernel: order | get_slices | re-pricing, the default on the
+    tree path) and its three steps as kernels of their own (TNCO_HIP_FW_NO_FUSED=1: fw_order_kernel | fw_slices_kernel |
+    fw_tree_kernel) against fw_reslice_a_kernel
     (TNCO_HIP_FW_NO_WAVE_SLICES=1) on the config-5 topology, 4 096 replicas x 60 sweeps -- some 2 500 outputs of
     every generator, so the 624-word generations end inside shuffles -- and with its knobs turned so that the
     rare paths are the common ones: no legs kept in LDS between the passes (TNCO_HIP_FWS_CAP=1), and tensors
@@ -387,7 +389,7 @@ def test_get_slices_per_wavefront_equals_the_lockstep_kernel(core, monkeypatch):
     ids = np.arange(R)
 
     def run(env):
-        for k in ("TNCO_HIP_FW_NO_WAVE_SLICES", "TNCO_HIP_FWS_CAP", "TNCO_HIP_FWS_MAXNP"):
+        for k in ("TNCO_HIP_FW_NO_WAVE_SLICES", "TNCO_HIP_FW_NO_FUSED", "TNCO_HIP_FWS_CAP", "TNCO_HIP_FWS_MAXNP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -398,7 +400,8 @@ def test_get_slices_per_wavefront_equals_the_lockstep_kernel(core, monkeypatch):
             return g.costs(), g.slices_many(ids), np.asarray(g.prng_states())
 
     ref = run({"TNCO_HIP_FW_NO_WAVE_SLICES": "1"})
-    for env in ({}, {"TNCO_HIP_FWS_CAP": "1"}, {"TNCO_HIP_FWS_MAXNP": "44"}):
+    for env in ({}, {"TNCO_HIP_FWS_CAP": "1"}, {"TNCO_HIP_FWS_MAXNP": "44"}, {"TNCO_HIP_FW_NO_FUSED": "1"},
+                {"TNCO_HIP_FW_NO_FUSED": "1", "TNCO_HIP_FWS_CAP": "1"}, {"TNCO_HIP_FW_NO_FUSED": "1", "TNCO_HIP_FWS_MAXNP": "44"}):
         got = run(env)
         assert np.array_equal(got[0][0], ref[0][0]) and np.array_equal(got[0][1], ref[0][1]), env
         assert np.array_equal(got[1][0], ref[1][0]) and np.array_equal(got[1][1], ref[1][1]), env

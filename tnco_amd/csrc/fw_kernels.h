@@ -2797,6 +2797,478 @@ static __global__ __launch_bounds__(256, (J * GW <= 576 ? 4 : 2)) void fw_tree_k
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// The three steps above as ONE kernel, one wavefront per replica: fw_wave_kernel = fw_order_kernel |
+// fw_slices_kernel | fw_tree_kernel without the memory between them.  Separately, every step started cold (a
+// dependent round trip costs 5-10 us here) and the tree kernel's first act was to read back the 12 bytes per node
+// the order kernel had just written: per replica and re-slice 6.5 KB written + 6.5 KB read, the list, the change
+// list and the proposal through memory, two launches.  Here the headers are read once (J nodes per lane, all loads
+// in flight together with the old slices and the generator's position), the node table goes straight into the LDS
+// layout of the tree step (lo / hi), the list of the too-wide tensors stays in LDS, the change list is built in LDS.
+// LDS per replica: the node table (8 bytes per node) + one region used three times (keys of the ordering; legs,
+// counts, generator ring and candidate positions of get_slices; path masks / partial sums of the re-pricing).
+// A replica one of the steps cannot do leaves with nwide = -2 (fw_reslice_a_kernel traverses it) or with the
+// proposal written and fastflag = 0 (fw_reslice_b_kernel rebuilds it in full), exactly as from the separate kernels.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t fww_lds_bytes(int n, int cap) {
+  const size_t nip = (size_t)((n - 1 + 63) & ~63);
+  const size_t u1 = (size_t)FWO_MAXW * (8 + 2 + 2);                         // keys, nodes, depths
+  const size_t u2 = (size_t)cap * 128 + 1024 + 1024 + 512;                  // legs, counts, ring, positions
+  const size_t u3 = nip * 8 + 256 + 32;                                     // masks / partial sums, change list, flags
+  size_t u = u1 > u2 ? u1 : u2;
+  u = u > u3 ? u : u3;
+  return (nip * 8 + 512 /* list */ + u + 15) & ~(size_t)15;
+}
+
+template <int J>
+static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, const FwParams F, const int cap, const int maxnp) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t fww_smem[];
+  constexpr int GW = 64, IPP = 32;
+  const int lane = threadIdx.x, w = lane & 15, g = lane >> 4;
+  const int64_t r = blockIdx.x;
+  const int n = P.n, N = P.N, ni = N - n, W = P.W, LK = F.I64 / 64;
+  const int nip = (ni + 63) & ~63;
+  // node i of the table: lo = left | right << 16; hi = parent | cost exponent << 16 | internal children (later: still to arrive) << 27
+  TNCO_LDS volatile uint32_t* lo = (TNCO_LDS volatile uint32_t*)fww_smem;                 // [nip]
+  TNCO_LDS uint32_t* hi = (TNCO_LDS uint32_t*)(lo + nip);                                  // [nip] (atomic arrivals)
+  TNCO_LDS volatile uint32_t* hiv = (TNCO_LDS volatile uint32_t*)hi;
+  TNCO_LDS volatile uint16_t* wls = (TNCO_LDS volatile uint16_t*)(hi + nip);               // [256] too-wide tensors, post-order
+  uint8_t* U = fww_smem + (size_t)nip * 8 + 512;                                           // the region used three times
+  // ordering
+  TNCO_LDS volatile uint64_t* key = (TNCO_LDS volatile uint64_t*)U;                        // [FWO_MAXW]
+  TNCO_LDS volatile uint16_t* wnode = (TNCO_LDS volatile uint16_t*)(key + FWO_MAXW);       // [FWO_MAXW]
+  TNCO_LDS volatile uint16_t* dep = wnode + FWO_MAXW;                                      // [FWO_MAXW]
+  // get_slices
+  TNCO_LDS volatile uint64_t* cache = (TNCO_LDS volatile uint64_t*)U;                      // [cap][16]
+  TNCO_LDS volatile uint8_t* nbig = (TNCO_LDS volatile uint8_t*)(cache + (size_t)cap * 16);  // [1024]
+  lds_vu32* ring = (lds_vu32*)(nbig + 1024);                                               // [256]
+  lds_vi32* pos = (lds_vi32*)(ring + 256);                                                 // [FWS_MAXNP]
+  // re-pricing
+  TNCO_LDS volatile double* Pn = (TNCO_LDS volatile double*)U;                             // [nip]
+  TNCO_LDS uint32_t* on = (TNCO_LDS uint32_t*)U;                                           // [nip][2] (the same memory)
+  TNCO_LDS volatile uint32_t* onv = (TNCO_LDS volatile uint32_t*)U;
+  TNCO_LDS volatile uint32_t* chgl = (TNCO_LDS volatile uint32_t*)(Pn + nip);              // [64] starts of the paths
+  TNCO_LDS volatile uint32_t* misc = chgl + 64;                                            // [8]
+
+  // ---- everything that depends on nothing, in flight at once
+  uint8_t* hb = P.blocks + r * P.RB;
+  uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
+  const FwScratch sc(F, r, N);
+  ReplicaState* rs = P.rs + r;
+  const bool has = w < W;
+  const uint64_t old = has ? sl[w] : 0ull;                       // word w, in each of the four rows of sixteen lanes
+  const uint64_t skip = (F.skip != nullptr && has) ? F.skip[w] : 0ull;
+  const int mti0 = rs->mti, mtw0 = rs->mtw;
+  const double cur = reinterpret_cast<const NodeRec*>(hb + (int64_t)(ni - 1) * P.BS)->partial;
+  const double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
+  int4 hd[J];
+  uint32_t ce[J];
+  double wd[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int i = j * GW + lane;
+    hd[j] = make_int4(0, 0, 0, 0);
+    ce[j] = 0;
+    wd[j] = 0.0;
+    if (i < ni) {
+      hd[j] = *reinterpret_cast<const int4*>(hb + (int64_t)i * P.BS);
+      ce[j] = *reinterpret_cast<const uint32_t*>(hb + (int64_t)i * P.BS + 20);  // high word of the cached cost
+      if (!F.width_f32) wd[j] = w64[n + i];
+    }
+  }
+  if (lane == 0) F.fastflag[r] = 0;
+  if (!__any(old != 0ull)) {  // greedy/optimizer.hpp:359: nothing to do without slices
+    if (lane == 0) F.nwide[r] = -1;
+    return;
+  }
+  auto leave_to_a = [&]() {  // fw_reslice_a_kernel traverses this replica, fw_reslice_b_kernel rebuilds it
+    if (lane == 0) {
+      F.nwide[r] = -2;
+      atomicAdd(F.slowstat, 1ull);
+    }
+  };
+  // ---- the node table; the too-wide tensors (fw_order_kernel)
+  int32_t iw[J];  // (the spare header words: a kept re-slice rewrites whole headers)
+  int nw = 0;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int i = j * GW + lane;
+    bool wide = false;
+    iw[j] = hd[j].w;
+    if (i < ni) {
+      const uint32_t c = (hd[j].x >= n ? 1u : 0u) + (hd[j].y >= n ? 1u : 0u);
+      lo[i] = (uint32_t)hd[j].x | ((uint32_t)hd[j].y << 16);
+      hiv[i] = ((uint32_t)hd[j].z & 0xFFFFu) | (((ce[j] >> 20) & 0x7FFu) << 16) | (c << 27);  // (the root: parent 0xFFFF)
+      const double wv = F.width_f32 ? (double)__int_as_float(hd[j].w) : wd[j];
+      wide = wv > F.max_width;
+    }
+    const unsigned long long b = __ballot(wide);
+    if (wide) {
+      const int k = nw + __popcll(b & ((1ull << lane) - 1ull));
+      if (k < FWO_MAXW) wnode[k] = (uint16_t)(n + i);
+    }
+    nw += __popcll(b);
+  }
+  if (nw > 255) {
+    leave_to_a();
+    return;
+  }
+  {  // root-path keys, ranks: ascending key, deeper first on equal keys (a node and its all-right ancestors)
+    bool deep = false;
+    for (int k0 = 0; k0 < nw; k0 += 64) {
+      const int k = k0 + lane;
+      if (k < nw) {
+        int x = wnode[k], d = 0;
+        uint64_t rev = 0;
+        while (x != N - 1 && d <= 64) {
+          const int p = (int)(hiv[x - n] & 0xFFFFu);
+          rev = (rev << 1) | (uint64_t)((int)(lo[p - n] >> 16) == x);
+          x = p;
+          ++d;
+        }
+        if (d > 64) deep = true;
+        uint64_t ky = d ? (__brevll((unsigned long long)rev)) : 0ull;  // level 0 (below the root) in bit 63
+        if (d < 64) ky |= ~0ull >> d;
+        key[k] = ky;
+        dep[k] = (uint16_t)d;
+      }
+    }
+    if (__any(deep)) {
+      leave_to_a();
+      return;
+    }
+    for (int k = lane; k < 256; k += 64) wls[k] = (uint16_t)n;
+    for (int k0 = 0; k0 < nw; k0 += 64) {
+      const int k = k0 + lane;
+      if (k < nw) {
+        const uint64_t ky = key[k];
+        const int d = dep[k];
+        int rank = 0;
+        for (int m = 0; m < nw; ++m) {
+          const uint64_t km = key[m];
+          const int dm = dep[m];
+          rank += (km < ky || (km == ky && dm > d)) ? 1 : 0;
+        }
+        wls[rank] = wnode[k];
+      }
+    }
+  }
+  // ---- get_slices (fw_slices_kernel; the ordering's keys are dead: the region is the legs' now)
+  const uint8_t* legs = P.blocks + r * P.RB + P.WOFF;
+  const int WS = P.WS;
+  uint64_t pl[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) pl[p] = 0ull;
+  uint32_t maxc = 0;
+  uint64_t m[4];
+  auto load16 = [&](int t0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + 4 * u + g;
+      const int node = wls[t < nw ? t : 0];
+      m[u] = 0ull;
+      if (t < nw && has) m[u] = *reinterpret_cast<const uint64_t*>(legs + (int64_t)(node - n) * WS + 8 * w);
+    }
+  };
+  load16(0);
+  RngWave rng;
+  rng.init(P.mt + r * 624, ring, mti0, mtw0, lane);
+  if (nw > 0) rng.fill();
+  for (int t0 = 0; t0 < nw; t0 += 16) {
+    if (t0) load16(t0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + 4 * u + g;
+      if (t < nw && t < cap) cache[t * 16 + w] = m[u];
+      const uint32_t c = gsum<4>((uint32_t)__popcll(m[u] & ~skip));
+      maxc = c > maxc ? c : maxc;
+      uint64_t carry = m[u];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const uint64_t tt = pl[p] & carry;
+        pl[p] ^= carry;
+        carry = tt;
+      }
+    }
+  }
+  if (gmax<6>(maxc) > (uint32_t)maxnp) {  // (nothing drawn yet; the generator's words twisted ahead stay)
+    if (lane == 0) rs->mtw = (int)rng.tw;
+    leave_to_a();
+    return;
+  }
+#pragma unroll
+  for (int step = 16; step <= 32; step <<= 1) {
+    uint64_t o[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) o[p] = fws_shflx64(pl[p], step);
+    uint64_t c = 0ull;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const uint64_t a = pl[p], b = o[p];
+      pl[p] = a ^ b ^ c;
+      c = (a & b) | (c & (a ^ b));
+    }
+  }
+  {
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t c = 0;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const uint32_t nib = (uint32_t)(pl[p] >> (16 * g + 4 * j)) & 0xFu;
+        c |= ((nib * 0x00204081u) & 0x01010101u) << p;
+      }
+      o[j] = c;
+    }
+    TNCO_LDS volatile uint32_t* d = (TNCO_LDS volatile uint32_t*)(nbig + w * 64 + 16 * g);
+    d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3];
+  }
+  uint64_t ns = 0ull;  // the new slices, word w (the same in the four rows of lanes)
+  {
+    const double mdl = fw_wr(F, -F.log2d);
+    int j = 0;
+    while (j < nw) {
+      const int t = j + g;
+      uint64_t mm = 0ull;
+      if (t < nw) {
+        if (t < cap) mm = cache[t * 16 + w];
+        else if (has) mm = *reinterpret_cast<const uint64_t*>(legs + (int64_t)((int)wls[t] - n) * WS + 8 * w);
+      }
+      const uint64_t sx = mm & ~ns;
+      const uint32_t cnt = gsum<4>((uint32_t)__popcll(sx));
+      const bool wide = t < nw && fw_wr(F, F.log2d * (double)cnt) > F.max_width;
+      const unsigned long long bal = __ballot(wide);
+      if (bal == 0ull) {
+        j += 4;
+        continue;
+      }
+      const int gs = (__ffsll(bal) - 1) >> 4;
+      j += gs + 1;
+      const uint64_t sxw = fws_shfl64(sx, 16 * gs + w);
+      double sw = fw_wr(F, F.log2d * (double)(uint32_t)__shfl((int)cnt, 16 * gs));
+      const uint64_t cand = sxw & ~skip;
+      const uint32_t mine = (uint32_t)__popcll(cand);
+      const uint32_t incl = fws_rowscan(mine);
+      const int np = __builtin_amdgcn_readlane((int)incl, 15);
+      if (g == 0) {
+        uint32_t o = incl - mine;
+        uint64_t x = cand;
+        while (x) {
+          const int b = __ffsll((unsigned long long)x) - 1;
+          pos[o++] = w * 64 + b;
+          x &= x - 1;
+        }
+      }
+      int src0 = lane, src1 = lane + 64;
+      if (np >= 2) {
+        const uint32_t nd = (uint32_t)np >> 1;
+        bool fast = rng.ensure(nd);
+        uint32_t p0 = 0, p1 = 0;
+        const int base = (np & 1) ? 1 : 0;
+        if (fast) {
+          const uint32_t raw = rng.peek((uint32_t)lane);
+          const uint32_t i0 = (uint32_t)(base + 2 * lane);
+          const uint32_t range = (i0 + 1u) * (i0 + 2u);  // (lane 0 of an even count: 2 -- d(0, 1), the swap of position 1)
+          const uint64_t product = (uint64_t)raw * (uint64_t)range;
+          const uint32_t low = (uint32_t)product;
+          bool rej = false;
+          if ((uint32_t)lane < nd && low < range) rej = low < (0u - range) % range;
+          if (__any(rej)) {
+            fast = false;
+          } else {
+            const uint32_t x = (uint32_t)(product >> 32);
+            p0 = x / (i0 + 2u);
+            p1 = x - p0 * (i0 + 2u);
+            rng.advance(nd);
+          }
+        }
+        if (fast) {
+          const bool two = np > 64;
+          for (int k = (int)nd - 1; k >= 0; --k) {
+            const int j1 = __builtin_amdgcn_readlane((int)p1, k), j0 = __builtin_amdgcn_readlane((int)p0, k);
+            const int i = base + 2 * k;
+            src0 = src0 == i + 1 ? j1 : (src0 == j1 ? i + 1 : src0);
+            src0 = src0 == i ? j0 : (src0 == j0 ? i : src0);
+            if (two) {
+              src1 = src1 == i + 1 ? j1 : (src1 == j1 ? i + 1 : src1);
+              src1 = src1 == i ? j0 : (src1 == j0 ? i : src1);
+            }
+          }
+        } else {
+          fw_shuffle_lds<6>(rng, pos, np, lane == 0);
+        }
+      }
+      const int xp0 = lane < np ? (int)pos[src0] : 0, xp1 = lane + 64 < np ? (int)pos[src1] : 0;
+      uint32_t k0 = lane < np ? (((uint32_t)nbig[xp0] << 16) | (0xFFFFu - (uint32_t)lane)) : 0u;
+      uint32_t k1 = lane + 64 < np ? (((uint32_t)nbig[xp1] << 16) | (0xFFFFu - (uint32_t)(lane + 64))) : 0u;
+      for (int taken = 0; taken < np; ++taken) {
+        const uint32_t best = gmax<6>(k0 > k1 ? k0 : k1);
+        const int qb = (int)(0xFFFFu - (best & 0xFFFFu));
+        const int xpos = __shfl(qb >= 64 ? xp1 : xp0, qb & 63);
+        if (lane == (qb & 63)) {
+          if (qb >= 64) k1 = 0u; else k0 = 0u;
+        }
+        if (w == (xpos >> 6)) ns |= 1ull << (xpos & 63);
+        sw = fw_wr(F, sw + mdl);
+        if (sw <= F.max_width) break;
+      }
+    }
+  }
+  {
+    int mti, mtw;
+    rng.finish(mti, mtw);
+    if (lane == 0) {
+      rs->mti = mti;
+      rs->mtw = mtw;
+      F.nwide[r] = -3;  // get_slices done: fw_reslice_a_kernel skips this replica
+    }
+  }
+  // the proposal (fw_reslice_b_kernel reads it if the re-pricing below gives up)
+  uint64_t* prop = reinterpret_cast<uint64_t*>(const_cast<int16_t*>(sc.pos));
+  if (g == 0 && w < LK) prop[w] = ns;
+  // ---- the indices that changed, with the starts of their paths (the region is the re-pricing's now)
+  uint32_t* chg = reinterpret_cast<uint32_t*>(F.delta_scr + r * 64);  // (word 0: the count, for tnco_hip_get_reslice_info)
+  int nd;
+  uint64_t plus64, minus64;
+  {
+    const int32_t* lpar = P.lpar + r * (int64_t)n * LPS;
+    uint64_t ch = g == 0 ? (ns ^ old) : 0ull;
+    const uint32_t mine = (uint32_t)__popcll(ch);
+    const uint32_t incl = fws_rowscan(mine);
+    nd = __builtin_amdgcn_readlane((int)incl, 15);
+    bool unsup = nd > FWT_MAXD;
+    uint64_t plus = 0ull, minus = 0ull;
+    if (!unsup) {
+      uint32_t off = incl - mine;
+      while (ch) {
+        const int bit = __ffsll((unsigned long long)ch) - 1;
+        ch &= ch - 1;
+        const int2 t12 = *reinterpret_cast<const int2*>(F.holder2 + 2 * (w * 64 + bit));
+        if (t12.x < 0) { unsup = true; break; }
+        const int s1 = lpar[(int64_t)t12.x * LPS], s2 = t12.y < 0 ? 0xFFFF : lpar[(int64_t)t12.y * LPS];
+        chgl[off] = (uint32_t)s1 | ((uint32_t)s2 << 16);
+        if ((ns >> bit) & 1ull) plus |= 1ull << off; else minus |= 1ull << off;
+        ++off;
+      }
+    }
+    unsup = __any(unsup);
+    const uint32_t a0 = gsum<4>((uint32_t)plus), a1 = gsum<4>((uint32_t)(plus >> 32));
+    const uint32_t b0 = gsum<4>((uint32_t)minus), b1 = gsum<4>((uint32_t)(minus >> 32));
+    plus64 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)a0) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)a1) << 32);
+    minus64 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)b0) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)b1) << 32);
+    if (lane == 0) chg[0] = unsup ? 0xFFFFFFFFu : (uint32_t)nd;
+    if (unsup) {  // more than FWT_MAXD indices, or an index held otherwise: the full rebuild
+      if (lane == 0) atomicAdd(F.slowstat, 1ull);
+      return;
+    }
+  }
+  const int dbase = __popcll(plus64) - __popcll(minus64);
+  // ---- the re-priced costs (fw_tree_kernel): path masks cleared, arrival counters = internal children
+  uint32_t startmask = 0;
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int i = j * GW + lane;
+    if (i < ni) {
+      const uint32_t h = hiv[i];
+      const int e = (int)((h >> 16) & 0x7FFu);
+      bad = bad || e <= 0 || e >= 2047;
+      onv[2 * i] = 0;
+      onv[2 * i + 1] = 0;
+      if ((h >> 27) == 0u) startmask |= 1u << j;
+    }
+  }
+  const int log2d = P.log2d;
+  for (int pass = 0; pass * IPP < nd || pass == 0; ++pass) {
+    const uint32_t plus = (uint32_t)(plus64 >> (IPP * pass)), minus = (uint32_t)(minus64 >> (IPP * pass));
+    if (pass) {
+      for (int i = lane; i < ni; i += GW) { onv[2 * i] = 0; onv[2 * i + 1] = 0; }
+    }
+    {
+      const int k = lane >> 1, which = lane & 1;
+      const int idx = IPP * pass + k;  // this lane's changed index
+      const uint32_t e = idx < nd ? chgl[idx] : 0xFFFFFFFFu;
+      const int st = which ? (int)(e >> 16) : (int)(e & 0xFFFFu);
+      int x = (idx < nd && st != 0xFFFF) ? st : -1;  // the path of a holder starts at its parent
+      for (int guard = 0; __any(x >= 0); ++guard) {
+        if (guard > ni) { bad = true; break; }  // (cannot happen in a tree: never spin on corrupt links)
+        if (x >= 0) {
+          __hip_atomic_fetch_or(&on[2 * (x - n) + which], 1u << k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const int pp = (int)(hiv[x - n] & 0xFFFFu);
+          x = pp == 0xFFFF ? -1 : pp;
+        }
+      }
+    }
+    for (int i = lane; i < ni; i += GW) {
+      const uint32_t wq = lo[i], h = hiv[i];
+      const int l = (int)(wq & 0xFFFFu), rr = (int)(wq >> 16);
+      const uint32_t a = onv[2 * i], b = onv[2 * i + 1];
+      const int il = l >= n ? l - n : i, ir = rr >= n ? rr - n : i;
+      const uint32_t bl = onv[2 * il] & onv[2 * il + 1], br = onv[2 * ir] & onv[2 * ir + 1];
+      const uint32_t both_below = (l >= n ? bl : 0u) | (rr >= n ? br : 0u);
+      const uint32_t in_u = (a ^ b) | (a & b & ~both_below);
+      const int dex = (pass ? 0 : dbase) - __popc(in_u & plus) + __popc(in_u & minus);
+      const int ne = (int)((h >> 16) & 0x7FFu) + log2d * dex;
+      bad = bad || ne <= 0 || ne >= 2047;  // (also between the passes: the full rebuild decides then)
+      hiv[i] = (h & 0xF800FFFFu) | ((uint32_t)(ne & 0x7FF) << 16);
+    }
+  }
+  // ---- children before parents: every lane starts at its nodes with two leaf children; the second child to
+  // arrive at a parent goes on with it (the arrival returns the parent's record)
+  int p = -1;
+  uint32_t phi = 0, plo = 0;
+  for (int guard = 0;; ++guard) {
+    if (guard > 2 * ni + 64) { bad = true; break; }  // (cannot happen in a tree)
+    if (p < 0 && startmask) {
+      const int j = __ffs(startmask) - 1;
+      startmask &= startmask - 1;
+      p = j * GW + lane;
+      phi = hiv[p];
+      plo = lo[p];
+    }
+    if (!__any(p >= 0)) break;
+    if (p >= 0) {
+      const uint32_t wq = plo;
+      const int l = (int)(wq & 0xFFFFu), rr = (int)(wq >> 16);
+      const bool li = l >= n, ri = rr >= n;
+      const double pl0 = Pn[li ? l - n : p], pr0 = Pn[ri ? rr - n : p];
+      const double pL = li ? pl0 : 0.0, pR = ri ? pr0 : 0.0;
+      const double c = __longlong_as_double((long long)((uint64_t)((phi >> 16) & 0x7FFu) << 52));
+      Pn[p] = (c + pL) + pR;  // (the association order of finite_width/utils.hpp:36-47)
+      if (p == ni - 1) {
+        p = -1;  // the root
+      } else {
+        const int q = (int)(phi & 0xFFFFu) - n;
+        const uint32_t oldc = __hip_atomic_fetch_add(&hi[q], 0u - (1u << 27), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t qlo = lo[q];
+        if ((oldc >> 27) == 1u) { p = q; phi = oldc; plo = qlo; } else { p = -1; }
+      }
+    }
+  }
+  if (__any(bad)) {  // (a cost outside the powers of two of a double: the full rebuild decides)
+    if (lane == 0) atomicAdd(F.slowstat, 1ull);
+    return;
+  }
+  if (lane == ((ni - 1) & (GW - 1))) misc[0] = (Pn[ni - 1] < cur) ? 1u : 0u;  // greedy/optimizer.hpp:371-374
+  if (misc[0]) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int i = j * GW + lane;
+      if (i < ni) {
+        const uint32_t wq = lo[i], h = hiv[i];
+        const double c = __longlong_as_double((long long)((uint64_t)((h >> 16) & 0x7FFu) << 52)), pp = Pn[i];
+        const int par = (int)(h & 0xFFFFu);
+        int4* d = reinterpret_cast<int4*>(hb + (int64_t)i * P.BS);
+        d[0] = make_int4((int)(wq & 0xFFFFu), (int)(wq >> 16), par == 0xFFFF ? -1 : par, iw[j]);
+        d[1] = make_int4(__double2loint(c), __double2hiint(c), __double2loint(pp), __double2hiint(pp));
+      }
+    }
+    if (lane < LK) sl[lane] = lane < W ? ns : 0ull;  // (lanes 0..15 hold word `lane` of the proposal)
+  }
+  if (lane == 0) F.fastflag[r] = 1;
+}
+
 #ifndef TNCO_FW_RESLICE_B_WAVES
 #define TNCO_FW_RESLICE_B_WAVES TNCO_FW_RESLICE_WAVES
 #endif

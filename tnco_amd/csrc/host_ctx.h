@@ -29,6 +29,7 @@ struct tnco_hip_ctx {
   // mode of a tnco_hip_run_fw call follows the fall-backs counted during the previous one
   bool fw_delta_capable = false, fw_delta_on = false;
   int fw_wave_maxnp = 128;  // ... candidate legs of one tensor it handles (test knob TNCO_HIP_FWS_MAXNP)
+  bool fw_fused = false;   // ... and the whole re-slice of a replica in one wavefront (fw_wave_kernel)
   int fw_wave_slices = 0;  // get_slices by fw_slices_kernel (one wavefront per replica): listed tensors it keeps in LDS; 0: off
   int64_t fw_delta_reslices = 0;  // re-slices launched in that mode since the count was read
   int fw_single_calls = 0;        // calls in the other mode since the last probe

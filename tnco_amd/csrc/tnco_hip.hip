@@ -152,7 +152,9 @@ hipError_t launch_fw_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, 
       int prewalked = (h->P.N <= 8192 && h->F.stack_cap > 0 && h->F.nwide != nullptr) ? 1 : 0;
       if (prewalked && h->F.nwfront != nullptr && !h->F.leaf_wide) prewalked = 2;
       if (prewalked == 2 && h->F.fast_ok && h->F.tree_ok && !h->hyper) prewalked = 3;  // no walk at all (fw_order_kernel, fw_tree_kernel)
-      if (prewalked == 3) {
+      if (prewalked == 3 && h->fw_fused) {
+        // (fw_wave_kernel lists the too-wide tensors itself: launch_fw_reslice_lk)
+      } else if (prewalked == 3) {
         e = h->timed(TNCO_KIND_FW_WALK, [&]() {
 #define CALL_FWO(LL, KK) launch_fw_order_lk<LL, KK>(h)
           DISPATCH_LK(h, CALL_FWO)
@@ -916,6 +918,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       if (F.tree_ok && W <= 16 && F.I64 <= 1024 && !std::getenv("TNCO_HIP_FW_NO_WAVE_SLICES")) {
         h->fw_wave_slices = FWS_CAP;
         if (const char* e = std::getenv("TNCO_HIP_FWS_CAP")) h->fw_wave_slices = std::max(1, std::min(256, std::atoi(e)));
+        h->fw_fused = !std::getenv("TNCO_HIP_FW_NO_FUSED") && fww_lds_bytes(n, h->fw_wave_slices) <= 64 * 1024;
         h->fw_wave_maxnp = FWS_MAXNP;
         if (const char* e = std::getenv("TNCO_HIP_FWS_MAXNP")) h->fw_wave_maxnp = std::max(0, std::min(FWS_MAXNP, std::atoi(e)));
       }
