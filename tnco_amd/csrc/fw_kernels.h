@@ -2211,7 +2211,7 @@ static __global__ __launch_bounds__(256) void fw_order_kernel(const Params P, co
 // slices, the change list for fw_tree_kernel, the generator's position.
 // ---------------------------------------------------------------------------------------------
 #ifndef TNCO_FWS_CAP
-#define TNCO_FWS_CAP 32
+#define TNCO_FWS_CAP 16
 #endif
 constexpr int FWS_CAP = TNCO_FWS_CAP;  // too-wide tensors whose legs stay in LDS between the two passes (default)
 constexpr int FWS_MAXNP = 128;          // candidate legs of one tensor: two per lane
@@ -2820,9 +2820,16 @@ __host__ __device__ inline size_t fww_lds_bytes(int n, int cap) {
   return (nip * 8 + 512 /* list */ + u + 15) & ~(size_t)15;
 }
 
+#ifdef TNCO_FWW_PROF  // (diagnostic build: shader cycles per replica between the steps of fw_wave_kernel)
+static __device__ unsigned long long g_fww_prof[12];
+#define FWW_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define FWW_T(v)
+#endif
 template <int J>
 static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, const FwParams F, const int cap, const int maxnp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fww_smem[];
+  FWW_T(w0_);
   constexpr int GW = 64, IPP = 32;
   const int lane = threadIdx.x, w = lane & 15, g = lane >> 4;
   const int64_t r = blockIdx.x;
@@ -2887,6 +2894,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
       atomicAdd(F.slowstat, 1ull);
     }
   };
+  FWW_T(w1_);
   // ---- the node table; the too-wide tensors (fw_order_kernel)
   int32_t iw[J];  // (the spare header words: a kept re-slice rewrites whole headers)
   int nw = 0;
@@ -2953,6 +2961,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
       }
     }
   }
+  FWW_T(w2_);
   // ---- get_slices (fw_slices_kernel; the ordering's keys are dead: the region is the legs' now)
   const uint8_t* legs = P.blocks + r * P.RB + P.WOFF;
   const int WS = P.WS;
@@ -2996,6 +3005,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
     leave_to_a();
     return;
   }
+  FWW_T(w3_);
 #pragma unroll
   for (int step = 16; step <= 32; step <<= 1) {
     uint64_t o[8];
@@ -3115,41 +3125,64 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
       }
     }
   }
-  {
-    int mti, mtw;
-    rng.finish(mti, mtw);
-    if (lane == 0) {
-      rs->mti = mti;
-      rs->mtw = mtw;
-      F.nwide[r] = -3;  // get_slices done: fw_reslice_a_kernel skips this replica
-    }
-  }
-  // the proposal (fw_reslice_b_kernel reads it if the re-pricing below gives up)
-  uint64_t* prop = reinterpret_cast<uint64_t*>(const_cast<int16_t*>(sc.pos));
-  if (g == 0 && w < LK) prop[w] = ns;
-  // ---- the indices that changed, with the starts of their paths (the region is the re-pricing's now)
+  FWW_T(w4_);
+  // ---- the indices that changed, with the starts of their paths (the region is the re-pricing's now).  Their
+  // holders are requested first -- up to four per lane in one flight -- and only then the stores of this step are
+  // issued: a load behind a store waits for the store's acknowledgement too.
   uint32_t* chg = reinterpret_cast<uint32_t*>(F.delta_scr + r * 64);  // (word 0: the count, for tnco_hip_get_reslice_info)
   int nd;
   uint64_t plus64, minus64;
   {
-    const int32_t* lpar = P.lpar + r * (int64_t)n * LPS;
     uint64_t ch = g == 0 ? (ns ^ old) : 0ull;
     const uint32_t mine = (uint32_t)__popcll(ch);
     const uint32_t incl = fws_rowscan(mine);
     nd = __builtin_amdgcn_readlane((int)incl, 15);
     bool unsup = nd > FWT_MAXD;
+    int bits[4];
+    int2 hold[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      bits[q] = ch ? __ffsll((unsigned long long)ch) - 1 : -1;
+      ch &= ch - 1;  // (0 stays 0)
+      hold[q] = make_int2(-1, -1);
+      if (bits[q] >= 0 && !unsup) hold[q] = *reinterpret_cast<const int2*>(F.holder2 + 2 * (w * 64 + bits[q]));
+    }
+    {  // get_slices is done: the generator's position, the proposal (fw_reslice_b_kernel reads it if the re-pricing gives up)
+      int mti, mtw;
+      rng.finish(mti, mtw);
+      if (lane == 0) {
+        rs->mti = mti;
+        rs->mtw = mtw;
+        F.nwide[r] = -3;  // fw_reslice_a_kernel skips this replica
+      }
+      uint64_t* prop = reinterpret_cast<uint64_t*>(const_cast<int16_t*>(sc.pos));
+      if (g == 0 && w < LK) prop[w] = ns;
+    }
+    // the parents of the leaves from the node table, not from the replica's (cold) parent array: one round trip less
+    TNCO_LDS volatile uint16_t* lparL = (TNCO_LDS volatile uint16_t*)U;  // [n] (the path masks' memory: cleared below)
+    for (int i = lane; i < ni; i += GW) {
+      const uint32_t wq = lo[i];
+      const int l = (int)(wq & 0xFFFFu), rr = (int)(wq >> 16);
+      if (l < n) lparL[l] = (uint16_t)(n + i);
+      if (rr < n) lparL[rr] = (uint16_t)(n + i);
+    }
     uint64_t plus = 0ull, minus = 0ull;
     if (!unsup) {
       uint32_t off = incl - mine;
-      while (ch) {
-        const int bit = __ffsll((unsigned long long)ch) - 1;
-        ch &= ch - 1;
-        const int2 t12 = *reinterpret_cast<const int2*>(F.holder2 + 2 * (w * 64 + bit));
-        if (t12.x < 0) { unsup = true; break; }
-        const int s1 = lpar[(int64_t)t12.x * LPS], s2 = t12.y < 0 ? 0xFFFF : lpar[(int64_t)t12.y * LPS];
+      auto entry = [&](int bit, int2 t12) {
+        if (t12.x < 0) { unsup = true; return; }
+        const int s1 = lparL[t12.x], s2 = t12.y < 0 ? 0xFFFF : (int)lparL[t12.y];
         chgl[off] = (uint32_t)s1 | ((uint32_t)s2 << 16);
         if ((ns >> bit) & 1ull) plus |= 1ull << off; else minus |= 1ull << off;
         ++off;
+      };
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (bits[q] >= 0 && !unsup) entry(bits[q], hold[q]);
+      while (ch && !unsup) {  // (more than four changed indices in one mask word)
+        const int bit = __ffsll((unsigned long long)ch) - 1;
+        ch &= ch - 1;
+        entry(bit, *reinterpret_cast<const int2*>(F.holder2 + 2 * (w * 64 + bit)));
       }
     }
     unsup = __any(unsup);
@@ -3164,6 +3197,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
     }
   }
   const int dbase = __popcll(plus64) - __popcll(minus64);
+  FWW_T(w5_);
   // ---- the re-priced costs (fw_tree_kernel): path masks cleared, arrival counters = internal children
   uint32_t startmask = 0;
   bool bad = false;
@@ -3216,6 +3250,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
   }
   // ---- children before parents: every lane starts at its nodes with two leaf children; the second child to
   // arrive at a parent goes on with it (the arrival returns the parent's record)
+  FWW_T(w6_);
   int p = -1;
   uint32_t phi = 0, plo = 0;
   for (int guard = 0;; ++guard) {
@@ -3250,6 +3285,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
     if (lane == 0) atomicAdd(F.slowstat, 1ull);
     return;
   }
+  FWW_T(w7_);
   if (lane == ((ni - 1) & (GW - 1))) misc[0] = (Pn[ni - 1] < cur) ? 1u : 0u;  // greedy/optimizer.hpp:371-374
   if (misc[0]) {
 #pragma unroll
@@ -3267,6 +3303,14 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
     if (lane < LK) sl[lane] = lane < W ? ns : 0ull;  // (lanes 0..15 hold word `lane` of the proposal)
   }
   if (lane == 0) F.fastflag[r] = 1;
+#ifdef TNCO_FWW_PROF
+  if (lane == 0) {
+    const unsigned long long w8_ = __builtin_amdgcn_s_memtime();
+    atomicAdd(&g_fww_prof[0], w1_ - w0_); atomicAdd(&g_fww_prof[1], w2_ - w1_); atomicAdd(&g_fww_prof[2], w3_ - w2_);
+    atomicAdd(&g_fww_prof[3], w4_ - w3_); atomicAdd(&g_fww_prof[4], w5_ - w4_); atomicAdd(&g_fww_prof[5], w6_ - w5_);
+    atomicAdd(&g_fww_prof[6], w7_ - w6_); atomicAdd(&g_fww_prof[7], w8_ - w7_); atomicAdd(&g_fww_prof[8], 1ull);
+  }
+#endif
 }
 
 #ifndef TNCO_FW_RESLICE_B_WAVES

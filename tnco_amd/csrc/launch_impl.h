@@ -150,6 +150,21 @@ void launch_fw_reslice_lk(tnco_hip_ctx* h, int prewalked) {
 #undef TNCO_FWW
       hipLaunchKernelGGL((fw_reslice_a_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, 2);
       hipLaunchKernelGGL((fw_reslice_b_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, 1);
+#ifdef TNCO_FWW_PROF
+      {
+        static int wcalls = 0;
+        if (++wcalls % 80 == 0) {
+          unsigned long long st[12];
+          (void)hipDeviceSynchronize();
+          if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_fww_prof), sizeof(st)) == hipSuccess && st[8]) {
+            const double d = (double)st[8];
+            std::fprintf(stderr, "fw_wave after %d launches: cycles per replica: loads %.0f, ordering %.0f, legs + counts %.0f, greedy pass %.0f, "
+                         "change list %.0f, marks + prices %.0f, partial sums %.0f, commit %.0f\n", wcalls, st[0] / d, st[1] / d, st[2] / d, st[3] / d,
+                         st[4] / d, st[5] / d, st[6] / d, st[7] / d);
+          }
+        }
+      }
+#endif
       return;
     }
     if (h->fw_wave_slices > 0)
