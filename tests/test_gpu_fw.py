@@ -417,3 +417,21 @@ def test_fw_more_than_64_candidate_legs_in_one_wavefront(core, oracle_lib):
     prob = H.Problem(ts, 2)
     seeds = H.replica_seeds(16, S=4)
     _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 30, 24), 70, chunks=[24], every=3)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_fw_skip_slices_and_initial_slices_on_the_one_wavefront_path(core, oracle_lib, monkeypatch, fused):
+    """`skip_slices` (indices get_slices must not slice) and caller-given initial `slices` on a network the
+    one-wavefront re-slice takes (uniform dims 2, 96 tensors): fw_wave_kernel, and its three steps as kernels of
+    their own, against the oracle."""
+    if not fused:
+        monkeypatch.setenv("TNCO_HIP_FW_NO_FUSED", "1")
+    else:
+        monkeypatch.delenv("TNCO_HIP_FW_NO_FUSED", raising=False)
+    prob = H.regular_problem(96, graph_seed=5)
+    seeds = H.replica_seeds(12, S=5)
+    w0 = _initial_max_width(prob, prob.tree(seeds[0]))
+    skip = ct.pack_masks([list(range(0, prob.n_inds, 3))], prob.n_inds)[0]
+    init = ct.pack_masks([[1, 2, 4, 5, 7, 8, 10, 11]], prob.n_inds)[0]
+    _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 50, 60), max(3, w0 // 2), chunks=[25, 35], every=5,
+           skip_slices=skip, slices=init)
