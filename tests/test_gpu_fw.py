@@ -435,3 +435,31 @@ def test_fw_skip_slices_and_initial_slices_on_the_one_wavefront_path(core, oracl
     init = ct.pack_masks([[1, 2, 4, 5, 7, 8, 10, 11]], prob.n_inds)[0]
     _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 50, 60), max(3, w0 // 2), chunks=[25, 35], every=5,
            skip_slices=skip, slices=init)
+
+
+@pytest.mark.parametrize("n,degree,words", [(720, 3, 17), (900, 5, 36)])
+def test_fw_one_wavefront_reslice_on_wide_networks(core, oracle_lib, monkeypatch, n, degree, words):
+    """Networks of more than 16 mask words on the one-wavefront re-slice: a mask in 32 lanes (1 080 indices, two
+    tensors per load) and in 64 lanes (2 250 indices, one) -- from the reference's greedy starts (random trees of
+    the second network are wider than a double's exponent allows), against the oracle, and against the lock-step
+    path (TNCO_HIP_FW_NO_WAVE_SLICES=1) on more replicas."""
+    prob = H.regular_problem(n, graph_seed=n + degree, degree=degree)
+    assert (prob.n_inds + 63) // 64 == words
+    seeds = np.asarray(H.replica_seeds(512, S=n))
+    links = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds, device=0)
+    w0 = _initial_max_width(prob, links[0])
+    mw = max(3, int(w0 * 0.6))
+    betas = H.linear_betas(0, 40, 24)
+    monkeypatch.delenv("TNCO_HIP_FW_NO_WAVE_SLICES", raising=False)
+    _check(core, oracle_lib, prob, seeds[:4], betas, mw, chunks=[24], every=4, links=links[:4])
+    out = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("TNCO_HIP_FW_NO_WAVE_SLICES", "1")
+        with core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, max_width=mw) as g:
+            g.run(betas, update_slices_every=4)
+            assert g.validate() == (0, -1)
+            out.append((g.costs(), g.slices_many(np.arange(len(seeds))), np.asarray(g.prng_states())))
+    a, b = out
+    assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1])
+    assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1]) and np.array_equal(a[2], b[2])

@@ -497,11 +497,6 @@ class BatchedOptimizer:
         return out
 
     def kernel_time_ms(self, reset: bool = False):
-        ms, n = C.c_double(0), C.c_int64(0)
-        _lib.check(self._L.tnco_hip_kernel_time(self._h, C.byref(ms), C.byref(n), int(reset)))
-        return ms.value, n.value
-
-    def kernel_time_ms(self, reset: bool = False):
         """(device ms, schedule chunks) of the run calls since the last reset; with two streams the time from the first
         launch to the end of the last (tnco_hip_kernel_time)."""
         ms, n = C.c_double(0.0), C.c_int64(0)

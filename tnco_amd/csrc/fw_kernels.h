@@ -2810,10 +2810,10 @@ static __global__ __launch_bounds__(256, (J * GW <= 576 ? 4 : 2)) void fw_tree_k
 // A replica one of the steps cannot do leaves with nwide = -2 (fw_reslice_a_kernel traverses it) or with the
 // proposal written and fastflag = 0 (fw_reslice_b_kernel rebuilds it in full), exactly as from the separate kernels.
 // ---------------------------------------------------------------------------------------------
-__host__ __device__ inline size_t fww_lds_bytes(int n, int cap) {
+__host__ __device__ inline size_t fww_lds_bytes(int n, int cap, int T) {  // T: lanes per mask (16, 32 or 64)
   const size_t nip = (size_t)((n - 1 + 63) & ~63);
   const size_t u1 = (size_t)FWO_MAXW * (8 + 2 + 2);                         // keys, nodes, depths
-  const size_t u2 = (size_t)cap * 128 + 1024 + 1024 + 512;                  // legs, counts, ring, positions
+  const size_t u2 = (size_t)cap * T * 8 + (size_t)64 * T + 1024 + 512;       // legs, counts, ring, positions
   const size_t u3 = nip * 8 + 256 + 32;                                     // masks / partial sums, change list, flags
   size_t u = u1 > u2 ? u1 : u2;
   u = u > u3 ? u : u3;
@@ -2826,12 +2826,29 @@ static __device__ unsigned long long g_fww_prof[12];
 #else
 #define FWW_T(v)
 #endif
-template <int J>
+// inclusive sum over the lanes 0..w of a mask's 2^LOGT lanes
+template <int LOGT>
+__device__ __forceinline__ uint32_t fws_scan(uint32_t v, int lane) {
+  v = fws_rowscan(v);
+  if constexpr (LOGT == 5) {
+    const uint32_t r0 = (uint32_t)__shfl((int)v, (lane & 32) + 15);
+    v += (lane & 16) ? r0 : 0u;
+  } else if constexpr (LOGT == 6) {
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
+    const int row = lane >> 4;
+    v += row == 1 ? r0 : (row == 2 ? r0 + r1 : (row == 3 ? r0 + r1 + r2 : 0u));
+  }
+  return v;
+}
+
+// LOGT: lanes per leg mask (4, 5, 6: networks of at most 16, 32, 64 mask words); 64 >> LOGT tensors per load instruction
+template <int J, int LOGT>
 static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, const FwParams F, const int cap, const int maxnp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fww_smem[];
   FWW_T(w0_);
-  constexpr int GW = 64, IPP = 32;
-  const int lane = threadIdx.x, w = lane & 15, g = lane >> 4;
+  constexpr int GW = 64, IPP = 32, T = 1 << LOGT, TPL = 64 >> LOGT;
+  const int lane = threadIdx.x, w = lane & (T - 1), g = lane >> LOGT;
   const int64_t r = blockIdx.x;
   const int n = P.n, N = P.N, ni = N - n, W = P.W, LK = F.I64 / 64;
   const int nip = (ni + 63) & ~63;
@@ -2846,9 +2863,9 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
   TNCO_LDS volatile uint16_t* wnode = (TNCO_LDS volatile uint16_t*)(key + FWO_MAXW);       // [FWO_MAXW]
   TNCO_LDS volatile uint16_t* dep = wnode + FWO_MAXW;                                      // [FWO_MAXW]
   // get_slices
-  TNCO_LDS volatile uint64_t* cache = (TNCO_LDS volatile uint64_t*)U;                      // [cap][16]
-  TNCO_LDS volatile uint8_t* nbig = (TNCO_LDS volatile uint8_t*)(cache + (size_t)cap * 16);  // [1024]
-  lds_vu32* ring = (lds_vu32*)(nbig + 1024);                                               // [256]
+  TNCO_LDS volatile uint64_t* cache = (TNCO_LDS volatile uint64_t*)U;                      // [cap][T]
+  TNCO_LDS volatile uint8_t* nbig = (TNCO_LDS volatile uint8_t*)(cache + (size_t)cap * T);   // [64 T]
+  lds_vu32* ring = (lds_vu32*)(nbig + 64 * T);                                             // [256]
   lds_vi32* pos = (lds_vi32*)(ring + 256);                                                 // [FWS_MAXNP]
   // re-pricing
   TNCO_LDS volatile double* Pn = (TNCO_LDS volatile double*)U;                             // [nip]
@@ -2863,7 +2880,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
   const FwScratch sc(F, r, N);
   ReplicaState* rs = P.rs + r;
   const bool has = w < W;
-  const uint64_t old = has ? sl[w] : 0ull;                       // word w, in each of the four rows of sixteen lanes
+  const uint64_t old = has ? sl[w] : 0ull;                       // word w, in each of the 64 / T rows of T lanes
   const uint64_t skip = (F.skip != nullptr && has) ? F.skip[w] : 0ull;
   const int mti0 = rs->mti, mtw0 = rs->mtw;
   const double cur = reinterpret_cast<const NodeRec*>(hb + (int64_t)(ni - 1) * P.BS)->partial;
@@ -2973,7 +2990,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
   auto load16 = [&](int t0) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int t = t0 + 4 * u + g;
+      const int t = t0 + TPL * u + g;
       const int node = wls[t < nw ? t : 0];
       m[u] = 0ull;
       if (t < nw && has) m[u] = *reinterpret_cast<const uint64_t*>(legs + (int64_t)(node - n) * WS + 8 * w);
@@ -2983,13 +3000,13 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
   RngWave rng;
   rng.init(P.mt + r * 624, ring, mti0, mtw0, lane);
   if (nw > 0) rng.fill();
-  for (int t0 = 0; t0 < nw; t0 += 16) {
+  for (int t0 = 0; t0 < nw; t0 += 4 * TPL) {
     if (t0) load16(t0);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int t = t0 + 4 * u + g;
-      if (t < nw && t < cap) cache[t * 16 + w] = m[u];
-      const uint32_t c = gsum<4>((uint32_t)__popcll(m[u] & ~skip));
+      const int t = t0 + TPL * u + g;
+      if (t < nw && t < cap) cache[t * T + w] = m[u];
+      const uint32_t c = gsum<LOGT>((uint32_t)__popcll(m[u] & ~skip));
       maxc = c > maxc ? c : maxc;
       uint64_t carry = m[u];
 #pragma unroll
@@ -3007,7 +3024,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
   }
   FWW_T(w3_);
 #pragma unroll
-  for (int step = 16; step <= 32; step <<= 1) {
+  for (int step = T; step <= 32; step <<= 1) {
     uint64_t o[8];
 #pragma unroll
     for (int p = 0; p < 8; ++p) o[p] = fws_shflx64(pl[p], step);
@@ -3020,19 +3037,18 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
     }
   }
   {
-    uint32_t o[4];
+    // counters T g .. T g + T - 1 of word w -> T bytes (a nibble of plane bits is spread over the bytes of a word)
+    TNCO_LDS volatile uint32_t* d = (TNCO_LDS volatile uint32_t*)(nbig + w * 64 + T * g);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < T / 4; ++j) {
       uint32_t c = 0;
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
-        const uint32_t nib = (uint32_t)(pl[p] >> (16 * g + 4 * j)) & 0xFu;
+        const uint32_t nib = (uint32_t)(pl[p] >> (T * g + 4 * j)) & 0xFu;
         c |= ((nib * 0x00204081u) & 0x01010101u) << p;
       }
-      o[j] = c;
+      d[j] = c;
     }
-    TNCO_LDS volatile uint32_t* d = (TNCO_LDS volatile uint32_t*)(nbig + w * 64 + 16 * g);
-    d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3];
   }
   uint64_t ns = 0ull;  // the new slices, word w (the same in the four rows of lanes)
   {
@@ -3042,25 +3058,25 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
       const int t = j + g;
       uint64_t mm = 0ull;
       if (t < nw) {
-        if (t < cap) mm = cache[t * 16 + w];
+        if (t < cap) mm = cache[t * T + w];
         else if (has) mm = *reinterpret_cast<const uint64_t*>(legs + (int64_t)((int)wls[t] - n) * WS + 8 * w);
       }
       const uint64_t sx = mm & ~ns;
-      const uint32_t cnt = gsum<4>((uint32_t)__popcll(sx));
+      const uint32_t cnt = gsum<LOGT>((uint32_t)__popcll(sx));
       const bool wide = t < nw && fw_wr(F, F.log2d * (double)cnt) > F.max_width;
       const unsigned long long bal = __ballot(wide);
       if (bal == 0ull) {
-        j += 4;
+        j += TPL;
         continue;
       }
-      const int gs = (__ffsll(bal) - 1) >> 4;
+      const int gs = (__ffsll(bal) - 1) >> LOGT;
       j += gs + 1;
-      const uint64_t sxw = fws_shfl64(sx, 16 * gs + w);
-      double sw = fw_wr(F, F.log2d * (double)(uint32_t)__shfl((int)cnt, 16 * gs));
+      const uint64_t sxw = fws_shfl64(sx, T * gs + w);
+      double sw = fw_wr(F, F.log2d * (double)(uint32_t)__shfl((int)cnt, T * gs));
       const uint64_t cand = sxw & ~skip;
       const uint32_t mine = (uint32_t)__popcll(cand);
-      const uint32_t incl = fws_rowscan(mine);
-      const int np = __builtin_amdgcn_readlane((int)incl, 15);
+      const uint32_t incl = fws_scan<LOGT>(mine, lane);
+      const int np = __builtin_amdgcn_readlane((int)incl, T - 1);
       if (g == 0) {
         uint32_t o = incl - mine;
         uint64_t x = cand;
@@ -3135,8 +3151,8 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
   {
     uint64_t ch = g == 0 ? (ns ^ old) : 0ull;
     const uint32_t mine = (uint32_t)__popcll(ch);
-    const uint32_t incl = fws_rowscan(mine);
-    nd = __builtin_amdgcn_readlane((int)incl, 15);
+    const uint32_t incl = fws_scan<LOGT>(mine, lane);
+    nd = __builtin_amdgcn_readlane((int)incl, T - 1);
     bool unsup = nd > FWT_MAXD;
     int bits[4];
     int2 hold[4];
@@ -3186,8 +3202,8 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
       }
     }
     unsup = __any(unsup);
-    const uint32_t a0 = gsum<4>((uint32_t)plus), a1 = gsum<4>((uint32_t)(plus >> 32));
-    const uint32_t b0 = gsum<4>((uint32_t)minus), b1 = gsum<4>((uint32_t)(minus >> 32));
+    const uint32_t a0 = gsum<LOGT>((uint32_t)plus), a1 = gsum<LOGT>((uint32_t)(plus >> 32));
+    const uint32_t b0 = gsum<LOGT>((uint32_t)minus), b1 = gsum<LOGT>((uint32_t)(minus >> 32));
     plus64 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)a0) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)a1) << 32);
     minus64 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)b0) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)b1) << 32);
     if (lane == 0) chg[0] = unsup ? 0xFFFFFFFFu : (uint32_t)nd;
@@ -3300,7 +3316,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
         d[1] = make_int4(__double2loint(c), __double2hiint(c), __double2loint(pp), __double2hiint(pp));
       }
     }
-    if (lane < LK) sl[lane] = lane < W ? ns : 0ull;  // (lanes 0..15 hold word `lane` of the proposal)
+    if (lane < LK) sl[lane] = lane < W ? ns : 0ull;  // (lanes 0..T-1 hold word `lane` of the proposal)
   }
   if (lane == 0) F.fastflag[r] = 1;
 #ifdef TNCO_FWW_PROF

@@ -142,9 +142,11 @@ void launch_fw_reslice_lk(tnco_hip_ctx* h, int prewalked) {
 #ifndef TNCO_PROFILE
   if (h->F.fast_ok && prewalked == 3 && !h->hyper) {  // no walk: get_slices from fw_order_kernel's list (fw_slices_kernel) | fw_tree_kernel | end of the sweep
     if (h->fw_fused) {  // order | get_slices | re-pricing of one replica in one wavefront, then the two clean-up launches
-      const size_t lb = fww_lds_bytes(h->P.n, h->fw_wave_slices);
+      // lanes per leg mask: the L * K words of this translation unit's networks fit 16, 32 or 64 lanes
+      constexpr int LKW = (1 << LOG2L) * K, LT = LKW <= 16 ? 4 : (LKW <= 32 ? 5 : 6);
+      const size_t lb = fww_lds_bytes(h->P.n, h->fw_wave_slices, 1 << LT);
       const int need = (h->P.n - 1 + 63) / 64;
-#define TNCO_FWW(JJ) hipLaunchKernelGGL((fw_wave_kernel<JJ>), dim3((unsigned)h->P.R), dim3(64), lb, h->stream, h->P, h->F, h->fw_wave_slices, h->fw_wave_maxnp)
+#define TNCO_FWW(JJ) hipLaunchKernelGGL((fw_wave_kernel<JJ, LT>), dim3((unsigned)h->P.R), dim3(64), lb, h->stream, h->P, h->F, h->fw_wave_slices, h->fw_wave_maxnp)
       if (need <= 2) TNCO_FWW(2); else if (need <= 4) TNCO_FWW(4); else if (need <= 6) TNCO_FWW(6);
       else if (need <= 9) TNCO_FWW(9); else if (need <= 12) TNCO_FWW(12); else TNCO_FWW(16);
 #undef TNCO_FWW
@@ -167,7 +169,7 @@ void launch_fw_reslice_lk(tnco_hip_ctx* h, int prewalked) {
 #endif
       return;
     }
-    if (h->fw_wave_slices > 0)
+    if (h->fw_wave_slices > 0 && h->P.W <= 16)
       hipLaunchKernelGGL(fw_slices_kernel, dim3((unsigned)h->P.R), dim3(64), fws_lds_bytes(h->fw_wave_slices), h->stream, h->P, h->F,
                          h->fw_wave_slices, h->fw_wave_maxnp);
     // (the replicas fw_slices_kernel has left alone, usually none: 5 us of an empty launch)

@@ -914,11 +914,14 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
 #undef CALL_FWP
         if (!ok) F.tree_ok = 0;
       }
-      // ... and get_slices with one wavefront per replica when a mask fits a row of sixteen lanes
-      if (F.tree_ok && W <= 16 && F.I64 <= 1024 && !std::getenv("TNCO_HIP_FW_NO_WAVE_SLICES")) {
+      // ... and the whole re-slice of a replica in one wavefront (a mask in 16, 32 or 64 lanes); as separate kernels,
+      // get_slices with one wavefront per replica when a mask fits a row of sixteen lanes
+      if (F.tree_ok && F.I64 <= 4096 && !std::getenv("TNCO_HIP_FW_NO_WAVE_SLICES")) {
         h->fw_wave_slices = FWS_CAP;
         if (const char* e = std::getenv("TNCO_HIP_FWS_CAP")) h->fw_wave_slices = std::max(1, std::min(256, std::atoi(e)));
-        h->fw_fused = !std::getenv("TNCO_HIP_FW_NO_FUSED") && fww_lds_bytes(n, h->fw_wave_slices) <= 64 * 1024;
+        const int lkw = F.I64 / 64, lanes_per_mask = lkw <= 16 ? 16 : (lkw <= 32 ? 32 : 64);
+        h->fw_fused = !std::getenv("TNCO_HIP_FW_NO_FUSED") && fww_lds_bytes(n, h->fw_wave_slices, lanes_per_mask) <= 64 * 1024;
+        if (!h->fw_fused && W > 16) h->fw_wave_slices = 0;  // (the separate get_slices kernel holds a mask in sixteen lanes)
         h->fw_wave_maxnp = FWS_MAXNP;
         if (const char* e = std::getenv("TNCO_HIP_FWS_MAXNP")) h->fw_wave_maxnp = std::max(0, std::min(FWS_MAXNP, std::atoi(e)));
       }
