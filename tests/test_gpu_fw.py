@@ -463,3 +463,16 @@ def test_fw_one_wavefront_reslice_on_wide_networks(core, oracle_lib, monkeypatch
     a, b = out
     assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1])
     assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1]) and np.array_equal(a[2], b[2])
+
+
+def test_fw_more_too_wide_tensors_than_the_one_wavefront_reslice_lists(core, oracle_lib, monkeypatch):
+    """400 tensors under a bound nearly every contraction exceeds: some 390 too-wide tensors per replica, more than
+    the 255 fw_wave_kernel lists -- with the re-pricing pinned (TNCO_HIP_FW_DELTA=1: the library would leave the mode)
+    every replica leaves that kernel for the traverse of fw_reslice_a_kernel and the full rebuild of
+    fw_reslice_b_kernel; against the oracle."""
+    monkeypatch.setenv("TNCO_HIP_FW_DELTA", "1")
+    prob = H.regular_problem(400, graph_seed=9)
+    seeds = H.replica_seeds(6, S=9)
+    gpu = _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 30, 12), 4, chunks=[5, 7], every=3)
+    how, nch = gpu.reslice_info()
+    assert (how == 0).all()  # (rebuilt in full: none was re-priced)
