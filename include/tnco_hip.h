@@ -144,6 +144,14 @@ int tnco_hip_get_slices_many(tnco_hip_handle h, int64_t k, const int64_t* replic
  * than the re-pricing handles).  Either may be NULL.  EINVAL for a handle without re-pricing. */
 int tnco_hip_get_reslice_info(tnco_hip_handle h, int32_t* how, int32_t* n_changed);
 
+/* Diagnostics (no reference counterpart): what the re-slices of this handle did since it was created, in replica
+ * re-slices (one replica at the end of one re-slicing sweep, greedy/optimizer.hpp:359-376).  out8[0] launched in
+ * the re-priced form (one wavefront per replica); out8[1] of those, left to the full rebuild; why: out8[2] more
+ * too-wide tensors / a deeper tree / more candidate legs than the wavefront form lists, out8[3] more changed indices
+ * than it re-prices or an index it cannot place, out8[4] a cost outside a double's powers of two; out8[5] launched
+ * in the walk + full-rebuild form; out8[6..7] reserved (0).  bench.py reports out8[1] / out8[0]. */
+int tnco_hip_get_fw_stats(tnco_hip_handle h, int64_t* out8);
+
 int tnco_hip_sync(tnco_hip_handle h);
 
 /* total_cost / min_total_cost properties (optimizer.hpp:253-257) of every
@@ -233,7 +241,9 @@ int tnco_hip_kernel_time(tnco_hip_handle h, double* ms, int64_t* launches, int r
  * [1] the moves of the finite-width optimizer (finite_width/greedy/optimizer.hpp:130-331), [2] its re-slice
  * (:359-389: get_slices, the cost cache rebuilt or re-priced, the end of the sweep), [3] what orders the too-wide
  * tensors for get_slices (greedy/utils.hpp:62: the walk kernels, or fw_order_kernel; 0 when the whole re-slice of a
- * replica is one wavefront of fw_wave_kernel: counted under [2]); launches4 = launches of each.  Either array ([4]) may be NULL. */
+ * replica is one wavefront of fw_wave_kernel: counted under [2]); launches4 = launches of each -- for a finite-width
+ * handle that runs its halves on two streams, launches PER STREAM (every event is one launch on each stream; the counts
+ * are whole numbers because both streams launch the same sequence).  Either array ([4]) may be NULL. */
 int tnco_hip_kernel_times(tnco_hip_handle h, double* ms4, int64_t* launches4, int reset);
 
 /* Concurrent launches a step of tnco_hip_run is split into (1, or 2 when there are more workgroups than resident ones: see
@@ -303,8 +313,8 @@ int64_t tnco_hip_greedy_device_redone(void);
  * The exchange between the GPUs of one node -- replaces what little tnco/parallel.py:330-341 moves between its worker
  * processes (the results; here: the best cost, the heads of the result lists).  One process per GPU; RCCL over xGMI,
  * loaded with dlopen from the ROCm installation, i.e. on this library's own HIP runtime.  Rendezvous: rank 0 calls
- * tnco_hip_comm_unique_id and hands the 128 bytes to the other ranks by any means (tnco_amd/parallel.py: a file named
- * after the torchrun environment); then every rank calls tnco_hip_comm_init (collective).
+ * tnco_hip_comm_unique_id and hands the 128 bytes to the other ranks by any means (tnco_amd/parallel.py: over TCP,
+ * on the side channel the ranks share); then every rank calls tnco_hip_comm_init (collective).
  */
 typedef struct tnco_hip_comm_s* tnco_hip_comm;
 int tnco_hip_comm_unique_id(uint8_t* id128);

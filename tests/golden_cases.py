@@ -32,7 +32,7 @@ def problem_of(case):
     elif kind == "regular":
         prob = H.regular_problem(case["tn"][1], graph_seed=case["tn"][2])
     elif kind == "sycamore":
-        prob = syn.sycamore_problem(case["tn"][1])
+        prob = syn.sycamore_problem(case["tn"][1], "alternating")  # (the easier network of rounds 1-3: the fixture was made on it)
     else:
         _k, n, n_inds, k, n_out, choices = case["tn"]
         ts, dims, out = syn.random_hyper_tn(n, n_inds, k=k, n_output=n_out, seed=case["seed_base"], dims_choices=choices)

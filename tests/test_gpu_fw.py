@@ -150,12 +150,12 @@ def test_fw_max_number_new_slices(core, oracle_lib, m):
 
 
 def test_sycamore53_depth20_finite_width(core, oracle_lib):
-    """BASELINE config 5 topology (Sycamore-53-style RQC, depth 20: 541 tensors, 923 indices,
-    15 mask words -> 4 lanes x 4 words), memory-constrained, against the oracle."""
+    """BASELINE config 5 topology (Sycamore-53 supremacy circuit, depth 20, pattern ABCDCDAB: 430 two-qubit
+    gates, 536 tensors, 913 indices, 15 mask words -> 4 lanes x 4 words), memory-constrained, against the oracle."""
     from tnco_amd import synthetic as syn
     ts, dims, out = syn.sycamore53_tn(20)
     prob = H.Problem(ts, 2, out)
-    assert prob.n == 541 and prob.n_inds == 923
+    assert prob.n == 536 and prob.n_inds == 913 and sum(len(t) == 4 for t in ts) == 430
     seeds = H.replica_seeds(6, S=53)
     betas = H.linear_betas(0, 100, 60)
     gpu = _check(core, oracle_lib, prob, seeds, betas, 40, chunks=[25, 35], every=10)

@@ -123,7 +123,27 @@ def test_bench_line_of_a_two_rank_launch_over_the_socket_transport():
         assert [r["rank"] for r in ranks] == [0, 1] and sum(r["moves"] for r in ranks) == obj["config"]["moves_timed"]
 
 
-@pytest.mark.timeout(600)
+def _run_with_traceback_on_timeout(cmd, timeout, env):
+    """subprocess.run that, when the child does not finish, makes it say where it hangs: SIGABRT -> faulthandler
+    prints every thread's Python stack, and the failure message carries it."""
+    import signal
+    import subprocess
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=str(ROOT))
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        p.send_signal(signal.SIGABRT)
+        try:
+            out, err = p.communicate(timeout=20)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, err = p.communicate()
+        pytest.fail(f"{' '.join(cmd[-12:])} with {[k for k in env if k.startswith('TNCO_')]} did not finish within "
+                    f"{timeout} s; it was at:\n{err[-4000:]}")
+    return subprocess.CompletedProcess(cmd, p.returncode, out, err)
+
+
+@pytest.mark.timeout(900)
 def test_bench_line_through_rccl_group_of_one():
     """The RCCL side of bench.py on a 1-GPU box: a launch of one rank that still goes through the communicator
     (TNCO_BENCH_FORCE_GROUP) -- natively (RCCL bound inside libtnco_hip.so: no torch in the process, the best cost
@@ -137,7 +157,7 @@ def test_bench_line_through_rccl_group_of_one():
     for extra in ({"TNCO_BENCH_FORCE_GROUP": "1", "MASTER_PORT": str(_free_port())},
                   {"TNCO_BENCH_FORCE_GROUP": "1", "MASTER_PORT": str(_free_port()), "TNCO_BENCH_COMM": "torch"}, {}):
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
-        p = subprocess.run([sys.executable, *tail], capture_output=True, text=True, timeout=280, env=env, cwd=str(ROOT))
+        p = _run_with_traceback_on_timeout([sys.executable, "-X", "faulthandler", *tail], 280, env)
         assert p.returncode == 0, p.stderr[-2000:]
         assert len(p.stdout.strip().splitlines()) == 1, p.stdout[-500:]  # ONE line on stdout, nothing else (RCCL's banner: stderr)
         lines.append(json.loads(p.stdout))

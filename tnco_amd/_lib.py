@@ -52,7 +52,7 @@ class Desc(C.Structure):
 
 
 EXPORTS = [
-    "tnco_hip_create", "tnco_hip_run", "tnco_hip_run_fw", "tnco_hip_get_slices", "tnco_hip_get_slices_many", "tnco_hip_get_reslice_info", "tnco_hip_sync", "tnco_hip_get_costs", "tnco_hip_get_tree",
+    "tnco_hip_create", "tnco_hip_run", "tnco_hip_run_fw", "tnco_hip_get_slices", "tnco_hip_get_slices_many", "tnco_hip_get_reslice_info", "tnco_hip_get_fw_stats", "tnco_hip_sync", "tnco_hip_get_costs", "tnco_hip_get_tree",
     "tnco_hip_get_caches", "tnco_hip_validate", "tnco_hip_get_prng", "tnco_hip_set_prng", "tnco_hip_get_prng_many", "tnco_hip_set_prng_many",
     "tnco_hip_best", "tnco_hip_min_cost_device", "tnco_hip_get_trees", "tnco_hip_linear_paths", "tnco_hip_linear_paths_ssa", "tnco_hip_get_counters", "tnco_hip_get_moves", "tnco_hip_get_full_copies",
     "tnco_hip_kernel_time", "tnco_hip_kernel_times", "tnco_hip_get_stage_cycles",
@@ -66,6 +66,17 @@ EXPORTS = [
 _lib = None
 
 
+def torch_first() -> None:
+    """Initialise PyTorch's bundled HIP runtime (see load()); a no-op without a GPU."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception as e:  # noqa: BLE001 -- reported, not swallowed: the ordering problem would come back silently
+        warnings.warn(f"tnco_amd: could not initialise torch's HIP runtime before libtnco_hip.so ({e!r}); "
+                      "torch may report 'No HIP GPUs are available' later in this process.")
+
+
 def load() -> C.CDLL:
     global _lib
     if _lib is not None:
@@ -77,19 +88,14 @@ def load() -> C.CDLL:
             "tnco_amd has no CPU fallback.")
     # PyTorch-ROCm bundles its own HIP / HSA runtime (torch/lib/libamdhip64.so, no soname) next to the
     # system one this library links (/opt/rocm/lib/libamdhip64.so.7): both end up in a process that
-    # uses torch (torch.distributed over RCCL, the device-side reduction operand).  They coexist when
-    # torch's runtime initialises FIRST; the other way round torch reports "No HIP GPUs are available".
-    # So if torch can be imported, its runtime is initialised here, before the library touches the GPU.
-    # Only a process that uses torch pays for this: torch already imported, or a torch.distributed launch
-    # (tnco_amd.parallel imports torch before it creates a process group).
-    if not os.environ.get("TNCO_HIP_NO_TORCH_FIRST") and ("torch" in sys.modules or "WORLD_SIZE" in os.environ):
-        try:
-            import torch
-            if torch.cuda.is_available():
-                torch.cuda.init()
-        except Exception as e:  # noqa: BLE001 -- reported, not swallowed: the ordering problem would come back silently
-            warnings.warn(f"tnco_amd: could not initialise torch's HIP runtime before libtnco_hip.so ({e!r}); "
-                          "torch may report 'No HIP GPUs are available' later in this process.")
+    # uses torch.  They coexist when torch's runtime initialises FIRST; the other way round torch
+    # reports "No HIP GPUs are available".  So a process that HAS imported torch gets torch's runtime
+    # initialised here, before the library touches the GPU -- and only such a process: a rank of a
+    # torchrun launch that talks through the native communicator (parallel.NativeComm) never imports
+    # torch and holds ONE HIP runtime; the torch.distributed transport imports torch before it loads
+    # the library (parallel._dist).
+    if not os.environ.get("TNCO_HIP_NO_TORCH_FIRST") and "torch" in sys.modules:
+        torch_first()
     L = C.CDLL(str(_PATH))
     vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
     L.tnco_hip_create.argtypes = [C.POINTER(Desc), C.POINTER(vp)]
@@ -98,6 +104,7 @@ def load() -> C.CDLL:
     L.tnco_hip_get_slices.argtypes = [vp, i64, vp, vp]
     L.tnco_hip_get_slices_many.argtypes = [vp, i64, vp, vp, vp]
     L.tnco_hip_get_reslice_info.argtypes = [vp, vp, vp]
+    L.tnco_hip_get_fw_stats.argtypes = [vp, vp]
     L.tnco_hip_sync.argtypes = [vp]
     L.tnco_hip_get_costs.argtypes = [vp, vp, vp]
     L.tnco_hip_get_tree.argtypes = [vp, i64, C.c_int, vp, vp, vp, vp]

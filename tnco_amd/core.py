@@ -357,6 +357,13 @@ class BatchedOptimizer:
         _lib.check(self._L.tnco_hip_get_reslice_info(self._h, _ptr(how), _ptr(nch)))
         return how, nch
 
+    def fw_stats(self) -> dict:
+        """What this handle's re-slices did since it was created, in replica re-slices (tnco_hip_get_fw_stats)."""
+        o = np.zeros(8, np.int64)
+        _lib.check(self._L.tnco_hip_get_fw_stats(self._h, _ptr(o)))
+        return dict(repriced=int(o[0]), fell_back=int(o[1]), too_many_wide=int(o[2]), too_many_changed=int(o[3]),
+                    cost_range=int(o[4]), full_rebuild_form=int(o[5]))
+
     def update(self, beta: float = 0.0, prob="mh") -> None:
         self.run([beta], prob)
 

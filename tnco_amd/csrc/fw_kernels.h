@@ -2909,6 +2909,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
     if (lane == 0) {
       F.nwide[r] = -2;
       atomicAdd(F.slowstat, 1ull);
+      atomicAdd(F.slowstat + 1, 1ull);
     }
   };
   FWW_T(w1_);
@@ -3208,7 +3209,10 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
     minus64 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)b0) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)b1) << 32);
     if (lane == 0) chg[0] = unsup ? 0xFFFFFFFFu : (uint32_t)nd;
     if (unsup) {  // more than FWT_MAXD indices, or an index held otherwise: the full rebuild
-      if (lane == 0) atomicAdd(F.slowstat, 1ull);
+      if (lane == 0) {
+        atomicAdd(F.slowstat, 1ull);
+        atomicAdd(F.slowstat + 2, 1ull);
+      }
       return;
     }
   }
@@ -3298,7 +3302,10 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
     }
   }
   if (__any(bad)) {  // (a cost outside the powers of two of a double: the full rebuild decides)
-    if (lane == 0) atomicAdd(F.slowstat, 1ull);
+    if (lane == 0) {
+      atomicAdd(F.slowstat, 1ull);
+      atomicAdd(F.slowstat + 3, 1ull);
+    }
     return;
   }
   FWW_T(w7_);

@@ -30,7 +30,9 @@ struct FwParams {
   int32_t tree_ok;          // ... and no too-wide leaf, split layout: the re-slice without a walk (fw_order_kernel, fw_tree_kernel)
   const int32_t* holder2;   // [I64][2] the (one or two) tensors holding an index, -1: none / index not supported
   int32_t* fastflag;        // [R] 1: fw_tree_kernel / fw_delta_kernel has done this replica's rebuild (+ commit)
-  unsigned long long* slowstat;  // [1] replicas the re-pricing has left to the full rebuild since the host last looked
+  unsigned long long* slowstat;  // [4] replicas the re-pricing has left to the full rebuild since the host last looked; of those (fw_wave_kernel)
+                                 //     [1] too many / too deep / too leggy too-wide tensors, [2] too many changed indices or an index
+                                 //     held otherwise, [3] a cost outside a double's powers of two
   uint64_t* delta_scr;      // [R][64] fw_reslice_a_kernel -> fw_tree_kernel: the changed indices and the starts of their paths;
                             //          fw_delta_kernel: holders of the changed indices (u16[128]), second count-vector words
   int32_t* status;          // [R] runtime problems (1: candidate legs beyond the scratch; cannot happen

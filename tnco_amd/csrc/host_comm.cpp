@@ -6,8 +6,8 @@
 // bound HERE with dlopen("librccl.so") of the ROCm installation, i.e. the same HIP / HSA runtime this
 // library links: no pointer crosses between PyTorch's bundled runtime and the system's (round 2 reduced into
 // a torch tensor: two HIP runtimes writing each other's memory in one process).  The rendezvous (the 128-byte
-// ncclUniqueId from rank 0 to the others) is the caller's: tnco_amd/parallel.py passes it through a file
-// named after the torchrun environment.
+// ncclUniqueId from rank 0 to the others) is the caller's: tnco_amd/parallel.py sends it over TCP (the side
+// channel the ranks share, or a socket on MASTER_ADDR : MASTER_PORT + 17).
 #include "../../include/tnco_hip.h"
 
 #include <dlfcn.h>
@@ -16,10 +16,27 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 namespace {
-thread_local std::string g_comm_err;
+// One message per process (ncclCommInitRank runs on a helper thread of the caller's: the thread that asks for the
+// text is not the one that failed).  tnco_hip_comm_last_error hands out a per-thread copy.
+std::mutex g_comm_err_mu;
+std::string g_comm_err;
+void set_comm_err(const std::string& m) {
+  std::lock_guard<std::mutex> lk(g_comm_err_mu);
+  g_comm_err = m;
+}
+
+// the directory a shared object was loaded from, by one of its symbols
+std::string dir_of(const void* sym) {
+  Dl_info info;
+  if (!dladdr(sym, &info) || !info.dli_fname) return std::string();
+  std::string p(info.dli_fname);
+  const size_t k = p.rfind('/');
+  return k == std::string::npos ? std::string() : p.substr(0, k);
+}
 
 struct Rccl {
   void* lib = nullptr;
@@ -31,18 +48,28 @@ struct Rccl {
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   bool load() {
     if (lib) return true;
-    const char* names[] = {"/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so", "librccl.so.1", "librccl.so"};
-    for (const char* nm : names) {
-      lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+    // RCCL must sit on the HIP runtime THIS library links -- a process may hold a second one (PyTorch's bundled
+    // copy, with an RCCL of its own): only absolute paths, first the directory our libamdhip64 came from; a bare
+    // soname could resolve to whatever copy the process has already mapped.
+    const std::string hipdir = dir_of(reinterpret_cast<const void*>(&hipGetDeviceCount));
+    std::string tried;
+    for (const std::string& dir : {hipdir, std::string("/opt/rocm/lib")}) {
+      if (dir.empty()) continue;
+      for (const char* nm : {"/librccl.so.1", "/librccl.so"}) {
+        const std::string path = dir + nm;
+        lib = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (lib) break;
+        tried += path + " ";
+      }
       if (lib) break;
     }
     if (!lib) {
-      g_comm_err = std::string("librccl.so not found: ") + dlerror();
+      set_comm_err("librccl.so not found next to the HIP runtime (tried: " + tried + ")");
       return false;
     }
 #define TNCO_SYM(field, name)                                   \
   field = reinterpret_cast<decltype(field)>(dlsym(lib, name)); \
-  if (!field) { g_comm_err = std::string("librccl.so lacks ") + name; return false; }
+  if (!field) { set_comm_err(std::string("librccl.so lacks ") + name); return false; }
     TNCO_SYM(GetUniqueId, "ncclGetUniqueId")
     TNCO_SYM(CommInitRank, "ncclCommInitRank")
     TNCO_SYM(CommDestroy, "ncclCommDestroy")
@@ -66,7 +93,7 @@ struct tnco_hip_comm_s {
 
 namespace {
 int cfail(int code, const std::string& msg) {
-  g_comm_err = msg;
+  set_comm_err(msg);
   return code;
 }
 #define CH(expr)                                                                                  \
@@ -94,7 +121,12 @@ int ensure_slots(tnco_hip_comm_s* c, size_t bytes) {
 
 extern "C" {
 
-const char* tnco_hip_comm_last_error(void) { return g_comm_err.c_str(); }
+const char* tnco_hip_comm_last_error(void) {
+  thread_local std::string copy;
+  std::lock_guard<std::mutex> lk(g_comm_err_mu);
+  copy = g_comm_err;
+  return copy.c_str();
+}
 
 int tnco_hip_comm_unique_id(uint8_t* id128) {
   if (!id128) return cfail(TNCO_HIP_EINVAL, "null argument.");

@@ -34,6 +34,9 @@ struct tnco_hip_ctx {
   int64_t fw_delta_reslices = 0;  // re-slices launched in that mode since the count was read
   int fw_single_calls = 0;        // calls in the other mode since the last probe
   int fw_probe_wait = 4;          // ... before the next probe (doubles after a probe that failed)
+  // tnco_hip_get_fw_stats: [0] replica re-slices launched in the re-pricing form, [1] of those left to the full rebuild,
+  // [2..4] why (FwParams::slowstat[1..3]), [5] replica re-slices launched in the walk + full-rebuild form
+  int64_t fw_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   tnco::FwParams F{};
   std::vector<void*> allocs;
   int64_t bytes = 0;
@@ -67,6 +70,17 @@ struct tnco_hip_ctx {
   double kind_ms[TNCO_KINDS] = {0, 0, 0, 0};     // the same time, per kernel (HIP events around every launch)
   int64_t kind_launches[TNCO_KINDS] = {0, 0, 0, 0};
 
+  // the device's fall-back counters since the last look -> fw_stats; *slow = their total (may be NULL)
+  hipError_t collect_fw_stats(unsigned long long* slow) {
+    unsigned long long c[4] = {0, 0, 0, 0};
+    hipError_t e = hipMemcpy(c, F.slowstat, 32, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(F.slowstat, 0, 32, stream);
+    if (e != hipSuccess) return e;
+    for (int i = 0; i < 4; ++i) fw_stats[1 + i] += (int64_t)c[i];
+    if (slow) *slow = c[0];
+    return hipSuccess;
+  }
   template <typename T>
   hipError_t alloc(T** p, int64_t count) {
     void* q = nullptr;

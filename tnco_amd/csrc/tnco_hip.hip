@@ -166,6 +166,7 @@ hipError_t launch_fw_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, 
         if (e != hipSuccess) return e;
       }
       if (count_reslices && h->F.fast_ok && prewalked >= 2 && !h->hyper) h->fw_delta_reslices += 1;
+      h->fw_stats[h->F.fast_ok && prewalked >= 2 && !h->hyper ? 0 : 5] += h->P.R;
       e = h->timed(TNCO_KIND_FW_RESLICE, [&]() {
 #define CALL_FWS(LL, KK) launch_fw_reslice_lk<LL, KK>(h, prewalked)
         DISPATCH_LK(h, CALL_FWS)
@@ -587,8 +588,9 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       P.BS = P.hoff + (8 * W + 127) / 128 * 128;
     }
   }
-  // Blocks longer than a line: whole lines each (a 224-byte block at 24 mask words straddles two or three
-  // 128-byte lines depending on where it starts; 256 bytes are always two).  TNCO_HIP_BLOCK_ALIGN=0 packs them.
+  // Blocks longer than a line are PACKED (a 224-byte block at 24 mask words straddles two or three 128-byte lines
+  // depending on where it starts).  TNCO_HIP_BLOCK_ALIGN=128 pads them to whole lines (experiment knob: measured no
+  // faster in round 3 -- the padding costs as many lines as it saves).
   if (P.BS > 128 && !h->hyper) {
     const char* e = std::getenv("TNCO_HIP_BLOCK_ALIGN");
     const int al = e ? std::atoi(e) : 0;
@@ -865,8 +867,8 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       F.holder2 = dh;
       HIP_TRY(h->alloc(&F.fastflag, R));
       HIP_TRY(h->alloc(&F.delta_scr, R * 64));
-      HIP_TRY(h->alloc(&F.slowstat, 1));
-      HIP_TRY(hipMemset(F.slowstat, 0, 8));
+      HIP_TRY(h->alloc(&F.slowstat, 4));
+      HIP_TRY(hipMemset(F.slowstat, 0, 32));
       F.fast_ok = 1;
       h->fw_delta_capable = h->fw_delta_on = true;
       // ... without any walk over the tree when the headers are one array per replica (split layout), no leaf is too
@@ -1172,8 +1174,7 @@ int tnco_hip_run_fw(tnco_hip_handle h, int prob_kind, const double* betas, int64
     // the other mode, this call probes again.
     if (h->fw_delta_reslices > 0) {
       unsigned long long slow = 0;
-      HIP_TRY(hipMemcpy(&slow, h->F.slowstat, 8, hipMemcpyDeviceToHost));
-      HIP_TRY(hipMemsetAsync(h->F.slowstat, 0, 8, h->stream));
+      HIP_TRY(h->collect_fw_stats(&slow));
       const bool was_on = h->fw_delta_on;
       h->fw_delta_on = (double)slow < 0.02 * (double)h->fw_delta_reslices * (double)h->P.R;
       h->fw_probe_wait = h->fw_delta_on ? 4 : (was_on && h->fw_single_calls == 0 ? std::min(64, 2 * h->fw_probe_wait) : h->fw_probe_wait);
@@ -1250,6 +1251,16 @@ int tnco_hip_get_reslice_info(tnco_hip_handle h, int32_t* how, int32_t* n_change
     else
       for (int64_t r = 0; r < R; ++r) n_changed[r] = -1;
   }
+  return TNCO_HIP_OK;
+}
+
+int tnco_hip_get_fw_stats(tnco_hip_handle h, int64_t* out8) {
+  if (!h || !out8) return fail(TNCO_HIP_EINVAL, "null argument.");
+  if (!h->fw) return fail(TNCO_HIP_EINVAL, "handle was created without 'max_width'.");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(h->sync_all());
+  if (h->F.slowstat) HIP_TRY(h->collect_fw_stats(nullptr));
+  for (int i = 0; i < 8; ++i) out8[i] = h->fw_stats[i];
   return TNCO_HIP_OK;
 }
 

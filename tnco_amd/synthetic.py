@@ -73,30 +73,51 @@ def chain_tn(n: int):
     return ts_inds, 2, ()
 
 
-def sycamore53_tn(depth: int = 20, dead=(0, 0)):
-    """Tensor network of a Sycamore-53-style random quantum circuit amplitude <x|U|0>.
+# Coupler patterns of the 54-qubit lattice (9 rows x 6; qubit (r, j) at column 2 j + r % 2; a coupler joins
+# (r, c) to (r + 1, c +- 1)).  Key: (row parity of the upper qubit, direction of the step down).
+_SYCAMORE_LAYOUTS = {
+    # the supremacy experiment (Arute et al., Nature 574, 505 (2019), Fig. 3 and the published circuit files
+    # circuit_n53_m20_s*_e0_pABCDCDAB): in the rotated (cirq GridQubit) picture A, B are the two staggered
+    # halves of ONE coupler orientation and C, D the halves of the other.  With (R, C) the grid coordinates,
+    # r = R + C - 5 and c = C - R + 5 here: a "vertical" pair (R, C)-(R + 1, C) is a step down-LEFT, a
+    # "horizontal" pair (R, C)-(R, C + 1) a step down-RIGHT; A = vertical with R + C even (r odd), B =
+    # vertical with R + C odd (r even), C = horizontal with R + C odd (r even), D = horizontal with R + C even.
+    "supremacy": {(1, -1): "A", (0, -1): "B", (0, +1): "C", (1, +1): "D"},
+    # rounds 1-3 of this build: the two diagonal orientations ALTERNATE from cycle to cycle -- a much easier
+    # network (greedy trees 5-7 orders of magnitude cheaper); kept for the regression fixtures made on it.
+    "alternating": {(0, +1): "A", (0, -1): "B", (1, +1): "C", (1, -1): "D"},
+}
+# the qubit that did not work in the experiment: GridQubit(3, 2) -> (r, c) = (0, 4)
+_SYCAMORE_DEAD = {"supremacy": (0, 4), "alternating": (0, 0)}
+
+
+def sycamore53_tn(depth: int = 20, layout: str = "supremacy", dead=None, order: str = "ABCDCDAB"):
+    """Tensor network of a Sycamore-53 random quantum circuit amplitude <x|U|0>.
 
     BASELINE config 5 names a "Sycamore-53 depth-20 RQC"; the reference ships no such network (its
     circuit front-end needs cirq), so the topology is generated here: 54 qubits on a rotated square
     lattice of 9 rows x 6 (qubit (r, j) at column 2j + r % 2, diagonal nearest neighbours, 88
-    couplers), one dead qubit removed (53 qubits, 86 couplers); couplers split into the four
-    patterns A, B, C, D by (parity of the row gap, diagonal direction); every cycle applies one
-    pattern in the order A B C D C D A B; single-qubit gates are absorbed into the two-qubit gates.
+    couplers), the dead qubit removed (53 qubits, 86 couplers); the couplers split into the four
+    patterns A, B, C, D (`_SYCAMORE_LAYOUTS`); cycle k applies pattern order[k % 8] of the supremacy
+    sequence A B C D C D A B; single-qubit gates are absorbed into the two-qubit gates.
     Tensors: one 1-leg tensor per qubit at the input and at the output, one 4-leg tensor per
     two-qubit gate; indices: the wire segments between consecutive tensors of a qubit, all of
-    dimension 2.  depth 20 -> 435 gates, 541 tensors, 923 indices (15 mask words).
+    dimension 2.  layout "supremacy", depth 20 -> 430 two-qubit gates (the published count), 536
+    tensors, 913 indices (15 mask words); layout "alternating" (the easier network of rounds 1-3):
+    435 gates, 541 tensors, 923 indices.
 
     Returns (ts_inds, dims, output_inds) like random_regular_tn.
     """
-    qubits = [(r, 2 * j + (r % 2)) for r in range(9) for j in range(6) if (r, 2 * j + (r % 2)) != tuple(dead)]
+    names = _SYCAMORE_LAYOUTS[layout]
+    dead = _SYCAMORE_DEAD[layout] if dead is None else tuple(dead)
+    qubits = [(r, 2 * j + (r % 2)) for r in range(9) for j in range(6) if (r, 2 * j + (r % 2)) != dead]
     qset = set(qubits)
     patterns = {"A": [], "B": [], "C": [], "D": []}
     for (r, c) in qubits:
-        for dc, name_even, name_odd in ((+1, "A", "C"), (-1, "B", "D")):
+        for dc in (+1, -1):
             other = (r + 1, c + dc)
             if other in qset:
-                patterns[name_even if r % 2 == 0 else name_odd].append(((r, c), other))
-    order = "ABCDCDAB"
+                patterns[names[(r % 2, dc)]].append(((r, c), other))
     wire = {q: None for q in qubits}  # current open index of every qubit
     ts_inds, n_idx = [], 0
 
@@ -196,8 +217,8 @@ def regular_problem(n, graph_seed, degree=3):
     return Problem(ts, d, out)
 
 
-def sycamore_problem(depth=20):
-    ts, d, out = sycamore53_tn(depth)
+def sycamore_problem(depth=20, layout="supremacy"):
+    ts, d, out = sycamore53_tn(depth, layout)
     return Problem(ts, d, out)
 
 
