@@ -15,9 +15,16 @@ same TN (weak scaling, configs[3] at N = 8); the only collective is one RCCL all
 best cost inside the timed region.
 
 Second leg ("fw" object of the same line): BASELINE.json configs[4], the memory-constrained
-optimizer (finite_width/greedy/optimizer.hpp:117-390) on a Sycamore-53-style depth-20 circuit
-network, max_width 40, re-slicing every 10 sweeps, 65536 replicas per GPU; a step = one
-tnco_hip_run_fw call of `--sweeps-per-step` sweeps (11 move launches + 10 re-slice launches).
+optimizer (finite_width/greedy/optimizer.hpp:117-390) on the Sycamore-53 supremacy circuit network
+(depth 20, coupler sequence ABCDCDAB, 430 two-qubit gates), max_width 32, re-slicing every 10 sweeps,
+65536 replicas per GPU; a step = one tnco_hip_run_fw call of `--sweeps-per-step` sweeps (11 move
+launches + 10 re-slices).
+
+`roofline.frac` is MEASURED traffic / device time / 8 TB/s: bytes from the L2's memory-side request
+counters (every read request moves a 128-byte line: profiles/r04_pmc_calibration.md), so it is a
+fraction; the contract's algorithmic bytes (no caching credit: the kernel carries 5 of the
+7 masks of a move in registers from one level to the next) are kept as `frac_algorithmic`, and
+`frac_compulsory` prices the traffic the kernel as built cannot avoid.
 
 `roofline.traffic` and the request counts are measured in THIS run: after the timed legs, rank 0
 (N = 1 only) re-runs the same command under `rocprofv3 --pmc` as child processes, one pass per
@@ -50,26 +57,34 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 RANDOM_REQ_PEAK = 47e9
 METRIC = "SA move-evaluations/s (whole node) + best log10(flops) vs ref, 512-leaf TN"
 PMC_GROUPS = (("FETCH_SIZE",), ("WRITE_SIZE",), ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum"),
-              ("TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"))
+              ("TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"), ("TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"))
 KERNELS = ("sa_run_kernel", "fw_move_kernel", "fw_reslice_kernel", "fw_walk_kernel")
 FW_MOVE_LAUNCHES = lambda sps, every: (sps + every - 1) // every + 1  # noqa: E731
 FW_RESLICE_LAUNCHES = lambda sps, every: (sps + every - 1) // every   # noqa: E731
 
 
+# what the library's four timers (tnco_hip_kernel_times) cover, by the kernels' names in a rocprofv3 trace
+TRACE_NAMES = {
+    "sa_run_kernel": "sa_run_kernel<LOG2L, K, HYPER, GENERIC, false> (infinite-memory sweeps)",
+    "fw_move_kernel": "sa_run_kernel<LOG2L, K, HYPER, GENERIC, true> (the finite-width moves; fw_move_kernel<> with max_number_new_slices > 0)",
+    "fw_reslice_kernel": "fw_wave_kernel<J, LOGT> + fw_reslice_a_kernel<> + fw_reslice_b_kernel<> (one wavefront per replica, "
+                         "stragglers, end of sweep); fw_reslice_kernel<> in the walk + full-rebuild form",
+    "fw_walk_kernel": "fw_walk2_kernel (walk + full-rebuild form only)",
+}
+
+
 def kernel_of(name: str):
-    """Kernel name of a rocprofv3 row -> the names used here.  The staged sweep kernel also runs the
+    """Kernel name of a rocprofv3 row -> the library's timer it belongs to.  The staged sweep kernel also runs the
     moves of the finite-width optimizer: sa_run_kernel<LOG2L, K, HYPER, GENERIC, FW = true>."""
     if "sa_run_kernel<" in name:
         targs = name.split("sa_run_kernel<", 1)[1].split(">", 1)[0].split(",")
         return "fw_move_kernel" if len(targs) >= 5 and targs[4].strip() == "true" else "sa_run_kernel"
-    for short in ("fw_move_kernel", "fw_reslice_kernel", "fw_walk_kernel"):
-        if short in name:
-            return short
-    if "fw_walk2_kernel" in name or "fw_order_kernel" in name:  # (what lists the too-wide tensors in post-order)
+    if "fw_move_kernel" in name:
+        return "fw_move_kernel"
+    if "fw_walk2_kernel" in name:
         return "fw_walk_kernel"
-    if ("fw_reslice_a_kernel" in name or "fw_slices_kernel" in name or "fw_wave_kernel" in name or "fw_delta_kernel" in name
-            or "fw_tree_kernel" in name or "fw_reslice_b_kernel" in name):
-        return "fw_reslice_kernel"  # (the re-slice by re-pricing: get_slices | fw_tree_kernel | end of the sweep)
+    if any(k in name for k in ("fw_wave_kernel", "fw_reslice_a_kernel", "fw_reslice_b_kernel", "fw_reslice_kernel")):
+        return "fw_reslice_kernel"
     return None
 
 
@@ -82,6 +97,30 @@ def algorithmic_bytes_per_move_fw(W: int, a: float, q: float) -> float:
     """The same move of the finite-width optimizer: + the slices mask read
     (8W, finite_width/greedy/optimizer.hpp:177,191-193) + the cached width written on accept (4a, :216)."""
     return algorithmic_bytes_per_move(W, a, q) + 8 * W + 4 * a
+
+
+def compulsory_bytes_per_move(W: int, a: float, q: float, depth: float, fw: bool) -> dict:
+    """HBM traffic per move evaluation the sweep kernel AS BUILT cannot avoid: every read is a
+    128-byte line (profiles/r04_pmc_calibration.md), dirty data leaves the L2 in 64-byte sectors (a 4-byte update of a
+    parent link: 32).  The working set (65 536 replicas x ~100 KB) is hundreds of times the L2, so every node first
+    met is fetched and every line a move dirties is written back once.
+      reads:  the next A's header line and the next C's line(s) -- unified layout (infinite memory): header + legs of a
+              node in ceil((32 + 8W) / 128) lines; split layout (finite width): a 32-byte header in one line, the legs in
+              ceil(8W / 128) more; + the leaf's parent line once per sweep (1 / depth per move); + 4 bytes of generator
+              state per draw (2 + q per move, + 1 / depth for the leaf pick);
+      writes: B's header sector (the partial sums change with every move evaluated; this move's A is the next move's
+              B); per ACCEPTED move B's leg sectors beyond the header's and the parent words of C and E; the generator
+              state back."""
+    draws = 2.0 + q + 1.0 / max(depth, 1.0)
+    if fw:
+        legs_lines = -(-8 * W // 128)
+        read = 128.0 * (1 + (1 + legs_lines)) + 128.0 / max(depth, 1.0) + 4.0 * draws
+        write = 64.0 + a * (64.0 * -(-8 * W // 64) + 2 * 32.0) + 4.0 * draws
+    else:
+        node_lines = -(-(32 + 8 * W) // 128)
+        read = 128.0 * (1 + node_lines) + 128.0 / max(depth, 1.0) + 4.0 * draws
+        write = 64.0 + a * (64.0 * max(0, -(-(32 + 8 * W) // 64) - 1) + 2 * 32.0) + 4.0 * draws
+    return {"read": read, "write": write, "total": read + write}
 
 
 def algorithmic_bytes_per_reslice_repriced(n: int) -> float:
@@ -179,7 +218,7 @@ class Leg:
             self.prob = synthetic.regular_problem(args.leaves, graph_seed=args.graph_seed)
             kw = {}
         else:
-            self.prob = synthetic.sycamore_problem(args.fw_depth)
+            self.prob = synthetic.sycamore_problem(args.fw_depth, args.fw_layout)
             kw = dict(max_width=args.fw_max_width)
         all_seeds = synthetic.replica_seeds(R * world, S=0)
         self.seeds = all_seeds[rank * R:(rank + 1) * R]
@@ -205,6 +244,7 @@ class Leg:
             self.step(s)
         barrier(opt)
         c0 = opt.counters()
+        self.fw_stats0 = opt.fw_stats() if self.kind == "fw" else None
         opt.kernel_times_ms(reset=True)
         t0 = time.perf_counter()
         for s in range(a.warmup, a.warmup + a.steps):
@@ -217,12 +257,11 @@ class Leg:
         self.device_ms = opt.kernel_time_ms()[0]  # (all kernels of the timed steps; two streams: first launch -> last end)
         d = {k: c1[k] - c0[k] for k in c1}
         self.groups = opt.launch_groups
-        self.repriced = False
+        self.repriced, self.fw_stats = False, None
         if self.kind == "fw":
-            try:
-                self.repriced = bool((opt.reslice_info()[1] >= 0).any())
-            except ValueError:
-                pass
+            st1 = opt.fw_stats()
+            self.fw_stats = {k: st1[k] - self.fw_stats0[k] for k in st1}  # (the timed steps' re-slices)
+            self.repriced = self.fw_stats["repriced"] > 0 and self.fw_stats["full_rebuild_form"] == 0
         return dict(dt=dt, best=best, kt=kt, **d)
 
 
@@ -266,8 +305,9 @@ def pmc_passes(args, lib_version):
                 "--replicas", str(args.replicas), "--graph-seed", str(args.graph_seed), "--init", args.init,
                 "--workload", args.workload, "--fw-max-width", str(args.fw_max_width),
                 "--fw-update-slices", str(args.fw_update_slices), "--fw-depth", str(args.fw_depth),
-                "--cpu-sample", "0", "--pmc", "0"]
+                "--fw-layout", args.fw_layout, "--cpu-sample", "0", "--pmc", "0"]
     vals = {}  # (kernel short name, counter) -> per-dispatch values in dispatch order
+    names = {}  # kernel short name -> the kernels' names in the trace
     t0 = time.perf_counter()
     for gi, grp in enumerate(PMC_GROUPS):
         out = tmp / f"g{gi}"
@@ -290,12 +330,13 @@ def pmc_passes(args, lib_version):
             short = kernel_of(r["Kernel_Name"])
             if short:
                 vals.setdefault((short, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+                names.setdefault(short, set()).add(r["Kernel_Name"].split("(")[0].replace("tnco::", "").replace("(anonymous namespace)::", ""))
     shutil.rmtree(tmp, ignore_errors=True)
     every = args.fw_update_slices
     per_step = {"sa_run_kernel": 1, "fw_move_kernel": FW_MOVE_LAUNCHES(args.sweeps_per_step, every),
                 "fw_reslice_kernel": FW_RESLICE_LAUNCHES(args.sweeps_per_step, every),
                 "fw_walk_kernel": FW_RESLICE_LAUNCHES(args.sweeps_per_step, every)}
-    res = {"library": lib_version, "seconds": None, "kernels": {}}
+    res = {"library": lib_version, "seconds": None, "kernels": {}, "trace_names": {k: sorted(v) for k, v in names.items()}}
     for (short, ctr), v in vals.items():
         n = per_step[short]
         # (a step is two concurrent dispatches per kernel when the handle splits it over two streams; the re-slice by
@@ -326,26 +367,47 @@ def pmc_from_file(lib_version, key):
 
 
 def traffic_fields(k, moves_per_step, step_s):
-    """From one kernel's per-step counters: HBM bytes with the guide's gfx950 correction
-    (FETCH_SIZE in KiB, tallied at 64 B per 128-B request: x2; WRITE_SIZE in KiB as is), and the
-    fabric request counts the kernel is really bound by."""
+    """From one kernel's per-step counters: the bytes that crossed the L2's memory side -- every read request is a
+    128-byte line whatever the kernel asked for (RDREQ_128B == RDREQ on every pattern of profiles/r04_pmc_calibration.md;
+    FETCH_SIZE tallies them at 64), writes are WRITE_SIZE as is -- and the request counts."""
     out = {}
-    if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
-        rd_raw, wr = k["FETCH_SIZE"] * 1024.0, k["WRITE_SIZE"] * 1024.0
-        out["traffic"] = 2 * rd_raw + wr
-        out["traffic_raw"] = rd_raw + wr
+    wr = k["WRITE_SIZE"] * 1024.0 if "WRITE_SIZE" in k else None
+    rd = None
+    if "TCC_EA0_RDREQ_128B_sum" in k and "TCC_EA0_RDREQ_64B_sum" in k and "TCC_EA0_RDREQ_sum" in k:
+        r128, r64, r32 = k["TCC_EA0_RDREQ_128B_sum"], k["TCC_EA0_RDREQ_64B_sum"], k.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+        rest = max(0.0, k["TCC_EA0_RDREQ_sum"] - r128 - r64 - r32)  # (requests in no size class: priced as lines)
+        rd = 128.0 * (r128 + rest) + 64.0 * r64 + 32.0 * r32
+        out["read_requests_by_size"] = {"128B": r128 / moves_per_step, "64B": r64 / moves_per_step, "32B": r32 / moves_per_step}
+    elif "FETCH_SIZE" in k:
+        rd = 2.0 * k["FETCH_SIZE"] * 1024.0
+    if rd is not None and wr is not None:
+        out["traffic"] = rd + wr
+        out["traffic_read"], out["traffic_write"] = rd, wr
+        out["traffic_per_move"] = {"read": rd / moves_per_step, "write": wr / moves_per_step}
+        if "FETCH_SIZE" in k:
+            out["traffic_uncorrected"] = k["FETCH_SIZE"] * 1024.0 + wr  # (FETCH_SIZE as printed: 64 bytes per read request)
         if step_s:
             out["traffic_frac"] = out["traffic"] / step_s / 1e9 / HBM_PEAK_GBS
-            out["traffic_frac_raw"] = out["traffic_raw"] / step_s / 1e9 / HBM_PEAK_GBS
     if "TCC_EA0_RDREQ_sum" in k and "TCC_EA0_WRREQ_sum" in k:
-        rd, wr = k["TCC_EA0_RDREQ_sum"], k["TCC_EA0_WRREQ_sum"]
-        out["requests_per_move"] = {"read": rd / moves_per_step, "write": wr / moves_per_step,
+        rq, wq = k["TCC_EA0_RDREQ_sum"], k["TCC_EA0_WRREQ_sum"]
+        out["requests_per_move"] = {"read": rq / moves_per_step, "write": wq / moves_per_step,
                                     "read_32B": k.get("TCC_EA0_RDREQ_32B_sum", 0.0) / moves_per_step,
                                     "write_64B": k.get("TCC_EA0_WRREQ_64B_sum", 0.0) / moves_per_step}
         if step_s:
-            out["request_rate"] = (rd + wr) / step_s
+            out["request_rate"] = (rq + wq) / step_s
             out["request_rate_frac"] = out["request_rate"] / RANDOM_REQ_PEAK
     return out
+
+
+def transport_verdict(comm_kind, world, requested):
+    """(transport, rccl_ranks, exit_code) of a grouped run.  A launch on N > 1 GPUs whose ranks did not talk through
+    RCCL must not pass for an N-GPU measurement: non-zero exit unless sockets / gloo were ASKED for (tests)."""
+    kind = comm_kind or "none"
+    is_rccl = "rccl" in kind.lower() or "nccl" in kind.lower()
+    rccl_ranks = world if is_rccl else 0
+    asked_otherwise = requested in ("sockets", "gloo")
+    code = 0 if (world <= 1 or is_rccl or asked_otherwise) else 3
+    return kind, rccl_ranks, code
 
 
 def main() -> None:
@@ -362,7 +424,10 @@ def main() -> None:
                          "on the GPU) or the build's random-Kruskal generator (the line of round 1)")
     ap.add_argument("--workload", choices=("both", "im", "fw"), default="both",
                     help="im: the headline leg only; fw: the finite-width leg as the headline; both: im + 'fw' object")
-    ap.add_argument("--fw-max-width", type=float, default=40.0)
+    ap.add_argument("--fw-max-width", type=float, default=32.0)
+    ap.add_argument("--fw-layout", choices=("supremacy", "alternating"), default="supremacy",
+                    help="coupler patterns of the Sycamore-53 network: the supremacy experiment's (A, B one orientation on alternate "
+                         "rows, C, D the other) or the easier assignment of rounds 1-3")
     ap.add_argument("--fw-update-slices", type=int, default=10)
     ap.add_argument("--fw-depth", type=int, default=20)
     ap.add_argument("--cpu-sample", type=int, default=-1,
@@ -389,7 +454,7 @@ def main() -> None:
     from tnco_amd import parallel
     grouped = world > 1 or bool(os.environ.get("TNCO_BENCH_FORCE_GROUP"))
     torch = dist = None
-    comm_kind, comm_note = None, None
+    comm_kind, comm_note, comm_requested = None, None, None
     if grouped:
         # RCCL prints a version banner on the C-level stdout, flushed when the process ends -- after the JSON line.  The
         # line must be the only thing on stdout: everything written to file descriptor 1 from here on goes to stderr,
@@ -414,6 +479,7 @@ def main() -> None:
             # side channel; ncclCommInitRank runs under a time limit) -- the line says which, and why
             c = parallel.init_native(rank, world, local_rank)
             comm_kind, comm_note = c.kind, getattr(c, "note", None)
+        comm_requested = "sockets" if os.environ.get("TNCO_COMM") == "sockets" else want
         if want != "native":
             import torch
             import torch.distributed as dist
@@ -472,7 +538,7 @@ def main() -> None:
     if rank == 0:
         R, sps, every = args.replicas, args.sweeps_per_step, args.fw_update_slices
         key = (f"{args.workload}/{args.leaves}/{R}/{sps}/{args.steps}/{args.warmup}/{args.fw_max_width}/{every}/"
-               f"{args.fw_depth}/{args.init}")
+               f"{args.fw_depth}/{args.fw_layout}/{args.init}")
         pmc, pmc_note = None, None
         if args.pmc and world == 1:
             for leg in objs.values():  # free the GPU memory of this process first
@@ -519,19 +585,30 @@ def main() -> None:
                 # two halves of the batch on two streams: their kernels overlap -- the leg's device time is the region's
                 # (first launch of the timed steps to the end of the last), the per-kernel times are per-stream averages
                 step_ms = leg.device_ms / args.steps
-            achieved = alg_per_step / (step_ms / 1e3) / 1e9
-            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            achieved_alg = alg_per_step / (step_ms / 1e3) / 1e9
+            depth = moves_per_step_gpu / max(R * sps, 1)  # moves per sweep = depth of the drawn leaf - 1, on average
+            comp = compulsory_bytes_per_move(prob.W, a, q, depth, kind == "fw")
+            comp_per_step = comp["total"] * moves_per_step_gpu
+            if kind == "fw" and leg.repriced:  # + the re-slice: headers read once, a kept one rewrites them, legs of the too-wide tensors
+                comp_per_step += (32.0 * (prob.n - 1) * 1.4 + 2500.0) * n_res
+            roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                    "achieved_algorithmic": achieved_alg, "frac_algorithmic": achieved_alg / HBM_PEAK_GBS,
+                    "compulsory_bytes_per_move": comp, "compulsory_bytes_per_step": comp_per_step,
+                    "frac_compulsory": comp_per_step / (step_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
                     "kernel": max(kernels, key=lambda k: kt[k][0]), "avg_launch_ms": step_ms,
                     "launches": args.steps, **extra,
-                    "note": "achieved/frac are the contract's ALGORITHMIC bytes (SURVEY 8(d), no caching credit) / "
-                            "device time; traffic_frac (PMC bytes) and request_rate_frac (fabric requests vs the "
-                            "47e9/s random-request ceiling, tools/hbm_random.hip) say what binds the kernel"}
+                    "trace_names": {k: TRACE_NAMES[k] for k in kernels},
+                    "note": "frac = traffic / device time / peak with traffic MEASURED in this run (rocprofv3 --pmc: 128 bytes per "
+                            "read request of the L2's memory side -- profiles/r04_pmc_calibration.md -- + WRITE_SIZE); "
+                            "frac_compulsory = the traffic the kernel as built cannot avoid (model) <= frac <= 1; frac_algorithmic = "
+                            "the contract's bytes (SURVEY 8(d): 7 masks read per move, no caching credit) over the same time -- above 1 "
+                            "where the kernel carries masks in registers from one level of the walk to the next; request_rate_frac = "
+                            "fabric requests vs the 47e9/s random-request ceiling (tools/hbm_random.hip: 47e9 x 128 B = 6.0 TB/s)"}
             if kind == "fw":  # the moves' bytes alone over the leg's device time, and over the move kernel's
-                roof["frac_moves_only"] = extra["algorithmic_bytes_moves_only"] / (step_ms / 1e3) / 1e9 / HBM_PEAK_GBS
-                if leg.groups <= 1:  # (two streams: the move kernel's time is a per-stream average, beside other kernels)
-                    roof["frac_move_kernel"] = (extra["algorithmic_bytes_moves_only"] / (kt["fw_move_kernel"][0] / args.steps / 1e3)
-                                                / 1e9 / HBM_PEAK_GBS)
+                roof["frac_algorithmic_moves_only"] = extra["algorithmic_bytes_moves_only"] / (step_ms / 1e3) / 1e9 / HBM_PEAK_GBS
+                st = leg.fw_stats or {}
+                tot_res = max(1, st.get("repriced", 0) + st.get("full_rebuild_form", 0))
+                roof["reslices"] = dict(st, left_one_wavefront_path_frac=(st.get("fell_back", 0) + st.get("full_rebuild_form", 0)) / tot_res)
                 if leg.groups > 1:
                     roof["streams"] = leg.groups
                     roof["note_streams"] = ("the two halves of the batch run the whole step -- moves, re-slice (fw_wave_kernel), "
@@ -560,15 +637,30 @@ def main() -> None:
                         tot[c] = tot.get(c, 0.0) + v
                 roof.update(traffic_fields(tot, moves_per_step_gpu, step_ms / 1e3))
                 roof["traffic_source"] = pmc_note or f"rocprofv3 --pmc child passes of this run ({pmc.get('seconds', 0):.0f} s), {pmc['library']}"
+                if pmc.get("trace_names"):
+                    roof["trace_names_seen"] = {k: pmc["trace_names"].get(k) for k in kernels}
             else:
                 roof["traffic_source"] = pmc_note
+            if roof.get("traffic") is not None:
+                roof["achieved"] = roof["traffic"] / (step_ms / 1e3) / 1e9
+                roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+                roof["frac_source"] = "measured traffic (this run's PMC passes)" if not pmc_note else f"measured traffic ({pmc_note})"
+            else:  # no counters (rocprofv3 missing, --pmc 0, N > 1): the model of the compulsory traffic, said so
+                roof["achieved"] = comp_per_step / (step_ms / 1e3) / 1e9
+                roof["frac"] = roof["frac_compulsory"]
+                roof["frac_source"] = "compulsory-traffic MODEL (no PMC counters in this run)"
             obj = {
                 "value": moves / res["dt"], "unit": "move-evals/s", "ms_per_step": res["dt"] / args.steps * 1e3,
                 "config": {
                     "workload": (f"{prob.n}-leaf random 3-regular TN (bond dim 2, {prob.n_inds} indices, {prob.W} mask words), "
                                  f"{R} replicas per GPU, {sps} SA sweeps per step, beta linear 0->100 over "
                                  f"{leg.total_sweeps} sweeps, Metropolis-Hastings, float64 cost") if kind == "im" else
-                                (f"Sycamore-53-style depth-{args.fw_depth} circuit TN ({prob.n} tensors, {prob.n_inds} indices, "
+                                ((f"Sycamore-53 supremacy circuit, depth {args.fw_depth}, coupler sequence ABCDCDAB (A, B: one coupler "
+                                  f"orientation on alternate rows; C, D: the other), amplitude TN, single-qubit gates absorbed "
+                                  if args.fw_layout == "supremacy" else
+                                  f"Sycamore-53-style depth-{args.fw_depth} circuit with the two coupler orientations ALTERNATING per cycle "
+                                  f"(the easier network of rounds 1-3), amplitude TN ") +
+                                 f"({prob.n} tensors, {sum(len(t) == 4 for t in prob.ts_inds)} two-qubit gates, {prob.n_inds} indices, "
                                  f"{prob.W} mask words), max_width {args.fw_max_width:g} (float32 width), re-slice every {every} "
                                  f"sweeps, {R} replicas per GPU, {sps} sweeps per step, beta linear 0->100 over "
                                  f"{leg.total_sweeps} sweeps, Metropolis-Hastings, float64 cost"),
@@ -618,6 +710,9 @@ def main() -> None:
         }
         if "cpu_baseline" in head:
             out["cpu_baseline"] = head["cpu_baseline"]
+        # what carried the exchange between the ranks: an N > 1 line is an N-GPU measurement only if rccl_ranks == N
+        out["transport"], out["rccl_ranks"], _code = transport_verdict(comm_kind if grouped else "none (one rank, nothing to exchange)",
+                                                                        world, comm_requested)
         if devices is not None:
             out["config"]["devices"] = devices
             if comm_note:
@@ -628,17 +723,26 @@ def main() -> None:
     for leg in objs.values():
         if leg.opt is not None:
             leg.opt.close()
+    # A launch on N > 1 GPUs that did not talk through RCCL exits non-zero (after the line: the numbers are real, the
+    # transport is not what was asked for), unless sockets / gloo were requested (tests).  A rank with a thread still
+    # inside ncclCommInitRank cannot run RCCL's exit handlers: it leaves through os._exit, also non-zero.
+    exit_code = transport_verdict(comm_kind, world, comm_requested)[2] if grouped else 0
     if parallel._native is not None:
         hung = bool(getattr(parallel._native, "hung", False))
         parallel._native.barrier()
         parallel.shutdown_native()
-        if hung:  # (a thread of this process still sits in ncclCommInitRank: leave without RCCL's exit handlers)
+        if hung:
             sys.stdout.flush()
             sys.stderr.flush()
-            os._exit(0)
+            os._exit(exit_code or 3)
     elif grouped:
         dist.barrier()
         dist.destroy_process_group()
+    if exit_code:
+        sys.stdout.flush()
+        print(f"bench.py: {world} ranks exchanged their results over '{comm_kind}', not RCCL"
+              + (f" ({comm_note})" if comm_note else "") + ": exit code 3", file=sys.stderr)
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":

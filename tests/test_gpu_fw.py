@@ -51,16 +51,14 @@ def _check(core, orc, prob, seeds, betas, max_width, chunks, every=10, links=Non
     return gpu
 
 
-@pytest.mark.parametrize("delta", [True, False])
+@pytest.mark.parametrize("wave", [True, False])
 @pytest.mark.parametrize("n,frac", [(24, 0.5), (48, 0.6), (64, 0.4)])
-def test_fw_regular(core, oracle_lib, monkeypatch, n, frac, delta):
-    """Both forms of the re-slice's cache rebuild: the re-pricing of the old costs (fw_delta_kernel: uniform
-    power-of-two dims, the default here) and the full rebuild from the legs (TNCO_HIP_FW_NO_DELTA=1; what
-    hyper-indices, per-index dims, sparse legs and float32 costs always get)."""
-    if not delta:
-        monkeypatch.setenv("TNCO_HIP_FW_NO_DELTA", "1")
-    else:
-        monkeypatch.setenv("TNCO_HIP_FW_DELTA", "1")  # (pinned: the library would leave the mode when many replicas fall back)
+def test_fw_regular(core, oracle_lib, monkeypatch, n, frac, wave):
+    """Both forms of the re-slice: one wavefront per replica with the cost cache re-priced from the old costs
+    (fw_wave_kernel: uniform power-of-two dims, pinned here -- the library would leave the form while many replicas
+    fall back) and the general one, walk + full rebuild from the legs (TNCO_HIP_FW_WAVE=0; what hyper-indices,
+    per-index dims, sparse legs and float32 costs always get)."""
+    monkeypatch.setenv("TNCO_HIP_FW_WAVE", "1" if wave else "0")
     prob = H.regular_problem(n, graph_seed=n + 1)
     seeds = H.replica_seeds(24, S=n)
     w0 = _initial_max_width(prob, prob.tree(seeds[0]))
@@ -256,13 +254,14 @@ def test_fw_repricing_equals_the_full_rebuild_at_scale(core, monkeypatch):
     seeds = np.asarray(syn.replica_seeds(R))
     links = core.greedy_trees(p.ts_inds, p.n_inds, seeds, device=0)
     betas = H.linear_betas(0, 100, 1200)[:30]
-    monkeypatch.delenv("TNCO_HIP_FW_NO_DELTA", raising=False)
-    monkeypatch.setenv("TNCO_HIP_FW_DELTA", "1")
+    monkeypatch.setenv("TNCO_HIP_FW_WAVE", "1")
     a = core.BatchedOptimizer(p.leaf_masks, links, seeds, n_inds=p.n_inds, max_width=40)
-    monkeypatch.setenv("TNCO_HIP_FW_NO_DELTA", "1")
+    monkeypatch.setenv("TNCO_HIP_FW_WAVE", "0")
     b = core.BatchedOptimizer(p.leaf_masks, links, seeds, n_inds=p.n_inds, max_width=40)
     for c in range(0, 30, 10):
+        monkeypatch.setenv("TNCO_HIP_FW_WAVE", "1")
         a.run(betas[c:c + 10], update_slices_every=10)
+        monkeypatch.setenv("TNCO_HIP_FW_WAVE", "0")
         b.run(betas[c:c + 10], update_slices_every=10)
         (ta, ma), (tb, mb) = a.costs(), b.costs()
         assert np.array_equal(ta, tb) and np.array_equal(ma, mb), c
@@ -285,9 +284,9 @@ def test_fw_form_of_the_reslice_chosen_per_call(core, monkeypatch):
     out = []
     for pin in (None, "0", "1"):
         if pin is None:
-            monkeypatch.delenv("TNCO_HIP_FW_DELTA", raising=False)
+            monkeypatch.delenv("TNCO_HIP_FW_WAVE", raising=False)
         else:
-            monkeypatch.setenv("TNCO_HIP_FW_DELTA", pin)
+            monkeypatch.setenv("TNCO_HIP_FW_WAVE", pin)
         o = core.BatchedOptimizer(p.leaf_masks, links, seeds, n_inds=p.n_inds, max_width=40)
         for c in range(0, 240, 20):  # twelve calls: the adaptive run changes form in between
             o.run(betas[c:c + 20], update_slices_every=10)
@@ -301,15 +300,13 @@ def test_fw_form_of_the_reslice_chosen_per_call(core, monkeypatch):
 
 def test_config5_from_the_reference_starts_at_scale_against_the_oracle(core, oracle_lib, monkeypatch):
     """What bench.py's finite-width leg runs -- the config-5 topology from DEVICE-drawn greedy starts, the
-    re-slice without a walk (fw_order_kernel | get_slices | fw_tree_kernel) -- against the oracle: 32 768
+    re-slice of a replica in one wavefront (fw_wave_kernel) -- against the oracle: 32 768
     replicas x 40 sweeps (re-slices at sweeps 0, 10, 20, 30), then every replica whose re-slice took a rare
     path at one of them (rebuilt in full although it has slices; more than 32 changed indices: the second
     pass over the paths) and 64 others, compared in full: trees, best trees, caches, slices, PRNG."""
     from tnco_amd import synthetic as syn
     orc = oracle_lib
-    monkeypatch.delenv("TNCO_HIP_FW_DELTA", raising=False)
-    monkeypatch.delenv("TNCO_HIP_FW_NO_DELTA", raising=False)
-    monkeypatch.delenv("TNCO_HIP_FW_NO_TREE", raising=False)
+    monkeypatch.delenv("TNCO_HIP_FW_WAVE", raising=False)
     R = 32768
     p = syn.sycamore_problem(20)
     seeds = np.asarray(syn.replica_seeds(R))
@@ -345,7 +342,7 @@ def test_config5_many_changed_indices_from_random_starts(core, oracle_lib, monke
     fw_reslice_b_kernel, its own traverse) are all there; each kind against the oracle."""
     from tnco_amd import synthetic as syn
     orc = oracle_lib
-    monkeypatch.setenv("TNCO_HIP_FW_DELTA", "1")
+    monkeypatch.setenv("TNCO_HIP_FW_WAVE", "1")
     R = 2048
     p = syn.sycamore_problem(20)
     seeds = np.asarray(syn.replica_seeds(R, S=9))
@@ -372,14 +369,14 @@ def test_config5_many_changed_indices_from_random_starts(core, oracle_lib, monke
 
 
 def test_get_slices_per_wavefront_equals_the_lockstep_kernel(core, monkeypatch):
-    """The re-slice of a replica in one wavefront (fw_wave_kernel: order | get_slices | re-pricing, the default on the
-    tree path) and its three steps as kernels of their own (TNCO_HIP_FW_NO_FUSED=1: fw_order_kernel | fw_slices_kernel |
-    fw_tree_kernel) against fw_reslice_a_kernel
-    (TNCO_HIP_FW_NO_WAVE_SLICES=1) on the config-5 topology, 4 096 replicas x 60 sweeps -- some 2 500 outputs of
-    every generator, so the 624-word generations end inside shuffles -- and with its knobs turned so that the
-    rare paths are the common ones: no legs kept in LDS between the passes (TNCO_HIP_FWS_CAP=1), and tensors
-    with more than 44 candidate legs left to the lock-step kernel (TNCO_HIP_FWS_MAXNP=44: the two kernels
-    share a launch).  Totals, best totals, slices, best slices and generator states identical."""
+    """The re-slice of a replica in one wavefront (fw_wave_kernel: order | get_slices | re-pricing) against the general
+    form (TNCO_HIP_FW_WAVE=0: fw_walk2_kernel | fw_reslice_kernel -- get_slices of sixteen replicas per wavefront in
+    lock step, the cost cache rebuilt from the legs) on the config-5 network, 4 096 replicas x 60 sweeps -- some 5 000
+    outputs of every generator, so the 624-word generations end inside shuffles -- and with its knobs turned so that
+    the rare paths are the common ones: ONE tensor's legs kept in LDS between the passes, the others re-read from
+    memory with the next group's request in flight (TNCO_HIP_FWS_CAP=1), and tensors with more than 44 candidate
+    legs left to fw_reslice_a_kernel (TNCO_HIP_FWS_MAXNP=44: the two kernels share a launch).  Totals, best totals,
+    slices, best slices and generator states identical."""
     from tnco_amd import synthetic as syn
     R = 4096
     p = syn.sycamore_problem(20)
@@ -389,7 +386,7 @@ def test_get_slices_per_wavefront_equals_the_lockstep_kernel(core, monkeypatch):
     ids = np.arange(R)
 
     def run(env):
-        for k in ("TNCO_HIP_FW_NO_WAVE_SLICES", "TNCO_HIP_FW_NO_FUSED", "TNCO_HIP_FWS_CAP", "TNCO_HIP_FWS_MAXNP"):
+        for k in ("TNCO_HIP_FW_WAVE", "TNCO_HIP_FWS_CAP", "TNCO_HIP_FWS_MAXNP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -397,12 +394,16 @@ def test_get_slices_per_wavefront_equals_the_lockstep_kernel(core, monkeypatch):
             for c in range(0, 60, 20):
                 g.run(betas[c:c + 20], update_slices_every=10)
             assert g.validate() == (0, -1)
-            return g.costs(), g.slices_many(ids), np.asarray(g.prng_states())
+            st = g.fw_stats()
+            return g.costs(), g.slices_many(ids), np.asarray(g.prng_states()), st
 
-    ref = run({"TNCO_HIP_FW_NO_WAVE_SLICES": "1"})
-    for env in ({}, {"TNCO_HIP_FWS_CAP": "1"}, {"TNCO_HIP_FWS_MAXNP": "44"}, {"TNCO_HIP_FW_NO_FUSED": "1"},
-                {"TNCO_HIP_FW_NO_FUSED": "1", "TNCO_HIP_FWS_CAP": "1"}, {"TNCO_HIP_FW_NO_FUSED": "1", "TNCO_HIP_FWS_MAXNP": "44"}):
-        got = run(env)
+    ref = run({"TNCO_HIP_FW_WAVE": "0"})
+    assert ref[3]["repriced"] == 0 and ref[3]["full_rebuild_form"] == 6 * R
+    for env in ({}, {"TNCO_HIP_FWS_CAP": "1"}, {"TNCO_HIP_FWS_MAXNP": "44"}):
+        got = run(dict(env, TNCO_HIP_FW_WAVE="1"))
+        assert got[3]["repriced"] == 6 * R and got[3]["full_rebuild_form"] == 0, env
+        if "TNCO_HIP_FWS_MAXNP" in env:
+            assert got[3]["too_many_wide"] > 0  # (replicas left to fw_reslice_a_kernel: the knob bites)
         assert np.array_equal(got[0][0], ref[0][0]) and np.array_equal(got[0][1], ref[0][1]), env
         assert np.array_equal(got[1][0], ref[1][0]) and np.array_equal(got[1][1], ref[1][1]), env
         assert np.array_equal(got[2], ref[2]), env
@@ -410,7 +411,7 @@ def test_get_slices_per_wavefront_equals_the_lockstep_kernel(core, monkeypatch):
 
 def test_fw_more_than_64_candidate_legs_in_one_wavefront(core, oracle_lib):
     """A 100-leg centre tensor, its 100 neighbours in a ring, max_width 70: the tensors around the centre have
-    71..100 candidate legs -- two per lane of fw_slices_kernel, up to 50 variates drawn at once -- against the
+    71..100 candidate legs -- two per lane of fw_wave_kernel, up to 50 variates drawn at once -- against the
     oracle."""
     m = 100
     ts = [list(range(m))] + [[i, m + i, m + (i + 1) % m] for i in range(m)]
@@ -419,15 +420,12 @@ def test_fw_more_than_64_candidate_legs_in_one_wavefront(core, oracle_lib):
     _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 30, 24), 70, chunks=[24], every=3)
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_fw_skip_slices_and_initial_slices_on_the_one_wavefront_path(core, oracle_lib, monkeypatch, fused):
+@pytest.mark.parametrize("wave", [True, False])
+def test_fw_skip_slices_and_initial_slices_on_the_one_wavefront_path(core, oracle_lib, monkeypatch, wave):
     """`skip_slices` (indices get_slices must not slice) and caller-given initial `slices` on a network the
-    one-wavefront re-slice takes (uniform dims 2, 96 tensors): fw_wave_kernel, and its three steps as kernels of
-    their own, against the oracle."""
-    if not fused:
-        monkeypatch.setenv("TNCO_HIP_FW_NO_FUSED", "1")
-    else:
-        monkeypatch.delenv("TNCO_HIP_FW_NO_FUSED", raising=False)
+    one-wavefront re-slice takes (uniform dims 2, 96 tensors): fw_wave_kernel, and the general form, against the
+    oracle."""
+    monkeypatch.setenv("TNCO_HIP_FW_WAVE", "1" if wave else "0")
     prob = H.regular_problem(96, graph_seed=5)
     seeds = H.replica_seeds(12, S=5)
     w0 = _initial_max_width(prob, prob.tree(seeds[0]))
@@ -441,8 +439,8 @@ def test_fw_skip_slices_and_initial_slices_on_the_one_wavefront_path(core, oracl
 def test_fw_one_wavefront_reslice_on_wide_networks(core, oracle_lib, monkeypatch, n, degree, words):
     """Networks of more than 16 mask words on the one-wavefront re-slice: a mask in 32 lanes (1 080 indices, two
     tensors per load) and in 64 lanes (2 250 indices, one) -- from the reference's greedy starts (random trees of
-    the second network are wider than a double's exponent allows), against the oracle, and against the lock-step
-    path (TNCO_HIP_FW_NO_WAVE_SLICES=1) on more replicas."""
+    the second network are wider than a double's exponent allows), against the oracle, and against the general
+    form (TNCO_HIP_FW_WAVE=0) on more replicas."""
     prob = H.regular_problem(n, graph_seed=n + degree, degree=degree)
     assert (prob.n_inds + 63) // 64 == words
     seeds = np.asarray(H.replica_seeds(512, S=n))
@@ -450,12 +448,11 @@ def test_fw_one_wavefront_reslice_on_wide_networks(core, oracle_lib, monkeypatch
     w0 = _initial_max_width(prob, links[0])
     mw = max(3, int(w0 * 0.6))
     betas = H.linear_betas(0, 40, 24)
-    monkeypatch.delenv("TNCO_HIP_FW_NO_WAVE_SLICES", raising=False)
+    monkeypatch.setenv("TNCO_HIP_FW_WAVE", "1")
     _check(core, oracle_lib, prob, seeds[:4], betas, mw, chunks=[24], every=4, links=links[:4])
     out = []
     for off in (False, True):
-        if off:
-            monkeypatch.setenv("TNCO_HIP_FW_NO_WAVE_SLICES", "1")
+        monkeypatch.setenv("TNCO_HIP_FW_WAVE", "0" if off else "1")
         with core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, max_width=mw) as g:
             g.run(betas, update_slices_every=4)
             assert g.validate() == (0, -1)
@@ -467,10 +464,10 @@ def test_fw_one_wavefront_reslice_on_wide_networks(core, oracle_lib, monkeypatch
 
 def test_fw_more_too_wide_tensors_than_the_one_wavefront_reslice_lists(core, oracle_lib, monkeypatch):
     """400 tensors under a bound nearly every contraction exceeds: some 390 too-wide tensors per replica, more than
-    the 255 fw_wave_kernel lists -- with the re-pricing pinned (TNCO_HIP_FW_DELTA=1: the library would leave the mode)
+    the 255 fw_wave_kernel lists -- with the form pinned (TNCO_HIP_FW_WAVE=1: the library would leave it)
     every replica leaves that kernel for the traverse of fw_reslice_a_kernel and the full rebuild of
     fw_reslice_b_kernel; against the oracle."""
-    monkeypatch.setenv("TNCO_HIP_FW_DELTA", "1")
+    monkeypatch.setenv("TNCO_HIP_FW_WAVE", "1")
     prob = H.regular_problem(400, graph_seed=9)
     seeds = H.replica_seeds(6, S=9)
     gpu = _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 30, 12), 4, chunks=[5, 7], every=3)

@@ -275,3 +275,80 @@ def test_three_ranks_agree_on_the_transport(tmp_path, mode):
         else:
             assert cls == "SocketComm" and kind.startswith("tcp") and "rank" in note
             assert ("cannot open" in note) if mode == "no_library" else ("did not return" in note or "rank 1" in note)
+
+
+def test_a_run_that_lost_rccl_cannot_pass_for_an_n_gpu_measurement():
+    """bench.py's verdict on the transport: N > 1 ranks that exchanged their results over anything
+    but RCCL exit non-zero -- unless sockets / gloo were ASKED for -- and the line says how many ranks RCCL carried."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    rccl = "rccl (librccl.so bound inside libtnco_hip.so)"
+    assert bench.transport_verdict(rccl, 8, "native") == (rccl, 8, 0)
+    assert bench.transport_verdict("torch.distributed nccl", 4, "torch") == ("torch.distributed nccl", 4, 0)
+    tcp = "tcp sockets through rank 0"
+    assert bench.transport_verdict(tcp, 8, "native") == (tcp, 0, 3)            # RCCL did not come up: the launch fails
+    assert bench.transport_verdict(tcp, 2, "sockets") == (tcp, 0, 0)           # TNCO_COMM=sockets: asked for
+    assert bench.transport_verdict("torch.distributed gloo", 2, "gloo") == ("torch.distributed gloo", 0, 0)
+    assert bench.transport_verdict("torch.distributed gloo", 2, "native")[2] == 3
+    assert bench.transport_verdict(tcp, 1, "native")[1:] == (0, 0)             # a group of one: nothing to fake
+    # ... and the exit path itself never leaves with 0 after a hung ncclCommInitRank
+    src = (ROOT / "bench.py").read_text()
+    assert "os._exit(0)" not in src and "os._exit(exit_code or 3)" in src
+
+
+def _side_rank(rank, world, port, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TORCHELASTIC_RUN_ID="job-7")
+    from tnco_amd import parallel
+    c = parallel.SocketComm(rank, world, timeout=30.0)
+    out = c.allgather_object({"rank": rank})
+    q.put((rank, [o["rank"] for o in out], c.allreduce_min(10.0 - rank)))
+    c.close()
+
+
+@pytest.mark.timeout(120)
+def test_side_channel_drops_strangers(tmp_path):
+    """The TCP side channel: a connection that does not open with this job's token, claims a rank out of
+    range or a rank that has already joined, or sends nothing at all, is dropped -- rank 0 neither registers it nor
+    waits for it -- and messages are authenticated before they are unpickled."""
+    import multiprocessing as mp
+    import time
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    p0 = ctx.Process(target=_side_rank, args=(0, 3, port, q), daemon=True)
+    p0.start()
+    side = port + 18
+    strangers = []
+    t0 = time.monotonic()
+    while time.monotonic() - t0 < 20:  # a silent stranger, a wrong token, and (below) a bad rank number
+        try:
+            s1 = socket.create_connection(("127.0.0.1", side), timeout=1.0)
+            break
+        except OSError:
+            time.sleep(0.05)
+    strangers.append(s1)
+    s2 = socket.create_connection(("127.0.0.1", side), timeout=1.0)
+    s2.sendall(b"x" * 16 + (1).to_bytes(4, "little"))
+    strangers.append(s2)
+    procs = [ctx.Process(target=_side_rank, args=(r, 3, port, q), daemon=True) for r in (1, 2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=60) for _ in range(3))
+    for p in [p0] + procs:
+        p.join(20)
+    for s_ in strangers:
+        s_.close()
+    assert out == [(0, [0, 1, 2], 8.0), (1, [0, 1, 2], 8.0), (2, [0, 1, 2], 8.0)]
+    # a forged message is rejected before pickle sees it
+    sys.path.insert(0, str(ROOT))
+    from tnco_amd import parallel
+    a, b = socket.socketpair()
+    c = parallel.SocketComm(0, 1)
+    c._key = b"k" * 32
+    import pickle
+    blob = pickle.dumps("hello")
+    a.sendall(len(blob).to_bytes(8, "little") + b"\0" * 32 + blob)
+    with pytest.raises(ConnectionError):
+        c._recv_msg(b)
+    a.close(); b.close()

@@ -9,16 +9,14 @@
 // The moves of a run of sweeps are the staged sweep kernel (sa_sweep.h, FW = true); fw_move_kernel here is the
 // unstaged version kept for max_number_new_slices > 0.  The end of a re-slicing sweep (greedy/utils.hpp:21-125
 // + the CostCache rebuild of greedy/optimizer.hpp:359-376) comes in two forms:
-//   * the general one: a walk kernel (fw_walk2_kernel from both ends of the post-order, fw_walk_kernel) leaves
+//   * the general one: fw_walk2_kernel (two lanes per replica, from both ends of the post-order) leaves
 //     sequential lists (internal nodes in post-order with their links; the too-wide tensors in post-order), then
 //     fw_reslice_kernel iterates over them -- the k-th entry of all 16 replicas of a wavefront together, the next
 //     entries' loads in flight; counters, candidate lists, shuffles and picks in registers / LDS; the cache
 //     rebuilt from the leg masks;
-//   * when every cost is a power of two (fast_ok / tree_ok): no walk -- fw_order_kernel | get_slices
-//     (fw_slices_kernel, one wavefront per replica; its stragglers and networks of more than 16 mask words:
-//     fw_reslice_a_kernel) | fw_tree_kernel (the cache RE-PRICED from the old costs) | fw_reslice_b_kernel; see
-//     the comment blocks at fw_order_kernel and fw_slices_kernel.  (fw_delta_kernel: the re-pricing over the walk's post-order records,
-//     round 2, behind TNCO_HIP_FW_NO_TREE.)
+//   * when every cost is a power of two (FwParams::fast_ok): fw_wave_kernel, one wavefront per replica, no walk --
+//     the too-wide tensors ordered by their root paths | get_slices | the cache RE-PRICED from the old costs; then
+//     fw_reslice_a_kernel (get_slices of its stragglers) | fw_reslice_b_kernel (their full rebuild, end of sweep).
 // Covered: SimpleCostModel and SimpleSparseIndsCostModel (finite_width/cost_model/simple.hpp,
 // simple_sparse_inds.hpp), uniform and per-index dims, width_type float32 / float64, and the
 // max_number_new_slices > 0 branch (greedy/optimizer.hpp:226-321).
@@ -131,8 +129,8 @@ __device__ __forceinline__ uint32_t fw_uniform_int_from(RNG& rng, uint32_t raw, 
 // read from the ring before this pair's LDS traffic; the four array reads of a pair (a[i], a[i + 1]
 // early, a[p0], a[p1] together once the variate is known) are independent, and the four writes in
 // program order give exactly the two swaps (the second swap sees the first through the selects).
-template <int LOG2L, typename RNG>
-__device__ __forceinline__ void fw_shuffle_lds(RNG& rng, lds_vi32* a, int n, bool lane0) {
+template <int LOG2L, typename RNG, typename A = lds_vi32*>
+__device__ __forceinline__ void fw_shuffle_lds(RNG& rng, A a, int n, bool lane0) {
   if (n <= 1) return;
   // The generator: the sixteen replicas of a wavefront are at sixteen different phases of their
   // 16-word blocks, so "refill when there is room" makes the wavefront run the (long) request and
@@ -177,7 +175,7 @@ typedef TNCO_LDS volatile uint16_t lds_vu16;
 
 // One internal node of the post-order list: node | left << 16 | right << 32 | e << 48 (finite width: at
 // most 65 535 nodes).  e = the exponent field of the node's cached contraction cost (the walk kernels
-// read it with the links: fw_delta_kernel re-prices the node from it), 0 where nobody recorded it.
+// read it with the links), 0 where nobody recorded it.
 __device__ __forceinline__ uint64_t fw_rec(int node, int l, int rr, int e = 0) {
   return (uint64_t)(uint32_t)node | ((uint64_t)(uint32_t)l << 16) | ((uint64_t)(uint32_t)rr << 32) | ((uint64_t)(uint32_t)e << 48);
 }
@@ -671,7 +669,7 @@ template <int LOG2L, int K, bool HYPER>
 __device__ __forceinline__ int fw_gs_mark(const Params& P, const FwParams& F, const View<LOG2L, K, HYPER>& v,
                                           const double* w64, const FwScratch& sc, FwStack st, bool lane0, int gbase,
                                           unsigned long long* prof = nullptr, int nw_pre = -1) {
-  // (nw_pre >= 0: fw_walk_kernel has left sc.rec / sc.wlist and this count)
+  // (nw_pre >= 0: fw_walk2_kernel has left sc.rec / sc.wlist and this count)
   const int nw = nw_pre >= 0 ? nw_pre
                              : fw_traverse<LOG2L, K, HYPER>(P, F, v, w64, sc.rec, sc.wlist, lane0, gbase, st, sc.gstk);
 #ifdef TNCO_PROFILE
@@ -855,159 +853,21 @@ __global__ __launch_bounds__(256) void fw_leaf_bits_kernel(const Params P, const
   }
 }
 
-// The walk of the re-slice as a kernel of its own, ONE LANE per replica (fw_reslice_kernel then
-// starts from the lists).  The walk is scalar work per replica -- links and cached widths, no leg
-// masks -- and a chain of dependent header reads: with four lanes per replica it ran 16 chains per
-// wavefront and every lane of a group repeated the same instructions.  Here a wavefront runs 64
-// chains, so the same number of resident wavefronts keeps four times as many header reads in
-// flight (the chip retires ~47 G random reads/s, tools/hbm_random.hip; the 4-lane walk reached 25 G/s)
-// at a quarter of the instructions.  Same step structure as fw_traverse: one fetch per iteration, an
-// up-step before and after it; stack entries lane-interleaved in LDS (no bank conflicts whatever
-// the depths), the deep end in global scratch.  Trees of at most 8192 nodes (13-bit stack fields).
-// Measured and rejected (config 5, 65536 replicas, ms per walk): this loop 1.41; up to 3 or 4 up-steps
-// per iteration 1.65 / 1.68; both children's headers requested together, the right one's kept in
-// the stack entry until its subtree is entered (half the dependent reads, six actions per
-// iteration) 3.85 -- the loop is bound by its instructions under 32- / 64-way divergence, not by
-// the reads; 64 busy lanes per wavefront instead of 32: 1.44.
+// The walk of the re-slice as a kernel of its own (fw_reslice_kernel then starts from the lists): scalar
+// work per replica -- links and cached widths, no leg masks -- and a chain of dependent header reads.  Same
+// step structure as fw_traverse: one fetch per iteration, an up-step before and after it; stack entries
+// lane-interleaved in LDS (no bank conflicts whatever the depths), the deep end in global scratch.  Trees of
+// at most 8192 nodes (13-bit stack fields).
 #ifndef TNCO_FW_WALK_CAP
 #define TNCO_FW_WALK_CAP 40
 #endif
 #ifndef TNCO_FW_WALK_POPS
 #define TNCO_FW_WALK_POPS 1
 #endif
-#ifndef TNCO_FW_WALK_LANES
-#define TNCO_FW_WALK_LANES 32
-#endif
 constexpr int FW_WALK_CAP = TNCO_FW_WALK_CAP;
-// Only FW_WALK_LANES lanes of a wavefront carry a replica: with all 64 busy, 65536 replicas are one
-// wavefront per SIMD, and nothing overlaps that wavefront's LDS / ALU latency with its memory waits;
-// half-empty wavefronts give every SIMD two.
-constexpr int FW_WALK_LANES = TNCO_FW_WALK_LANES;
-constexpr int FW_WALK_PER_BLOCK = 4 * FW_WALK_LANES;  // replicas per 256-thread block
 
-static __global__ __launch_bounds__(256) void fw_walk_kernel(const Params P, const FwParams F) {
-  constexpr int NT = FW_WALK_PER_BLOCK;  // replicas (busy lanes) per block: the stride of the LDS arrays
-  __shared__ int32_t se[FW_WALK_CAP * NT];
-  __shared__ uint16_t sl[FW_WALK_CAP * NT];
-  // The lists leave through LDS, eight entries at a time: a lane's 8-byte stores to its own list
-  // reached the memory one by one, as partial writes (rocprofv3: 660 write requests per replica, 83 %
-  // of them 32-byte ones -- the header reads turn the L2 over long before a line of records is full);
-  // eight records are four back-to-back 16-byte stores of one 64-byte piece.
-  __shared__ uint32_t rbuf[16 * NT];  // 8 records (low, high words) per replica
-  __shared__ int32_t wbuf[8 * NT];    // 8 too-wide tensors per replica
-  const int tid = threadIdx.x;
-  if ((tid & 63) >= FW_WALK_LANES) return;
-  const int slot = (tid >> 6) * FW_WALK_LANES + (tid & 63);
-  const int64_t r = (int64_t)blockIdx.x * FW_WALK_PER_BLOCK + slot;
-  if (r >= P.R) return;
-  const int n = P.n, N = P.N, LK = F.I64 / 64;
-  {  // greedy/optimizer.hpp:359: nothing to do without slices
-    const uint64_t* sl0 = F.slices + r * 2 * (int64_t)LK;
-    uint64_t any = 0;
-    for (int w = 0; w < P.W; ++w) any |= sl0[w];
-    if (!any) {
-      F.nwide[r] = -1;
-      return;
-    }
-  }
-  const FwScratch sc(F, r, N);
-  const uint8_t* blk = P.blocks + r * P.RB;
-  const double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
-  uint64_t* rec = sc.rec;  // (64-byte aligned: fw_np, fw_scratch_ints)
-  int32_t* wlist = sc.wlist;
-  volatile int32_t* gstk = sc.gstk;
-  TNCO_LDS volatile int32_t* e_ = (TNCO_LDS volatile int32_t*)se + slot;
-  TNCO_LDS volatile uint16_t* l_ = (TNCO_LDS volatile uint16_t*)sl + slot;
-  TNCO_LDS volatile uint32_t* rb = (TNCO_LDS volatile uint32_t*)rbuf + slot;
-  TNCO_LDS volatile int32_t* wb = (TNCO_LDS volatile int32_t*)wbuf + slot;
-  const int gh = (N + 1) / 2;
-  int ni = 0, nw = 0;
-  auto put_wide = [&](int x) {
-    wb[(nw & 7) * NT] = x;
-    ++nw;
-    if ((nw & 7) == 0) {
-      int4* d = reinterpret_cast<int4*>(wlist + nw - 8);
-      d[0] = make_int4(wb[0], wb[NT], wb[2 * NT], wb[3 * NT]);
-      d[1] = make_int4(wb[4 * NT], wb[5 * NT], wb[6 * NT], wb[7 * NT]);
-    }
-  };
-  auto put_rec = [&](uint64_t x) {
-    rb[(2 * (ni & 7)) * NT] = (uint32_t)x;
-    rb[(2 * (ni & 7) + 1) * NT] = (uint32_t)(x >> 32);
-    ++ni;
-    if ((ni & 7) == 0) {
-      uint4* d = reinterpret_cast<uint4*>(rec + ni - 8);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        d[q] = make_uint4(rb[(4 * q) * NT], rb[(4 * q + 1) * NT], rb[(4 * q + 2) * NT], rb[(4 * q + 3) * NT]);
-    }
-  };
-  auto emit_leaf = [&](int x) {
-    if (F.leaf_wide && ((F.leaf_bits[x >> 5] >> (x & 31)) & 1u)) put_wide(x);
-  };
-  int sp = 0, x = N - 1;
-  bool done = false;
-  if (x < n) {
-    emit_leaf(x);
-    done = true;
-  }
-  auto up = [&]() {
-    int e, l;
-    if (sp <= FW_WALK_CAP) {
-      e = e_[(sp - 1) * NT];
-      l = l_[(sp - 1) * NT];
-    } else {
-      e = gstk[sp - 1 - FW_WALK_CAP];
-      l = gstk[gh + sp - 1 - FW_WALK_CAP];
-    }
-    const int node = e & 0x1FFF, rr = (e >> 13) & 0x1FFF;
-    const bool fresh = ((e >> 26) & 1) == 0;
-    if (fresh && rr >= n) {  // into the right subtree
-      if (sp <= FW_WALK_CAP) e_[(sp - 1) * NT] = e | (1 << 26); else gstk[sp - 1 - FW_WALK_CAP] = e | (1 << 26);
-      x = rr;
-    } else {
-      if (fresh) emit_leaf(rr);
-      --sp;
-      put_rec(fw_rec(node, l, rr));
-      if ((e >> 27) & 1) put_wide(node);
-      if (sp == 0) done = true;
-    }
-  };
-  while (!done) {
-    if (x < 0) up();
-    if (x >= n) {  // down: the only read of this node's header (links + cached width, one line)
-      const int4 h = *reinterpret_cast<const int4*>(blk + (int64_t)(x - n) * P.BS);
-      const double w = F.width_f32 ? (double)__int_as_float(h.w) : w64[x];
-      const bool wide = w > F.max_width;
-      ++sp;
-      const int e = x | (h.y << 13) | (wide ? (1 << 27) : 0);
-      if (sp <= FW_WALK_CAP) {
-        e_[(sp - 1) * NT] = e;
-        l_[(sp - 1) * NT] = (uint16_t)h.x;
-      } else {
-        gstk[sp - 1 - FW_WALK_CAP] = e;
-        gstk[gh + sp - 1 - FW_WALK_CAP] = h.x;
-      }
-      x = h.x;
-      if (x < n) {
-        emit_leaf(x);
-        x = -1;
-      }
-    }
-    // (up-steps are LDS only: a few per iteration, so that nearly every iteration of the wavefront --
-    // one memory latency each -- fetches a header for every lane)
-#pragma unroll 1
-    for (int q = 0; q < TNCO_FW_WALK_POPS && !done && x < 0; ++q) up();
-  }
-  // the unfinished pieces of the lists
-  for (int k = ni & ~7; k < ni; ++k)
-    rec[k] = (uint64_t)rb[(2 * (k & 7)) * NT] | ((uint64_t)rb[(2 * (k & 7) + 1) * NT] << 32);
-  for (int k = nw & ~7; k < nw; ++k) wlist[k] = wb[(k & 7) * NT];
-  F.nwide[r] = nw;
-}
-
-// The same walk from BOTH ends of the post-order, two lanes per replica (lanes 0-31 of a wavefront walk
-// forward, lane 32 + i walks backward for the replica of lane i).  The one-ended walk keeps one header
+// The walk from BOTH ends of the post-order, two lanes per replica (lanes 0-31 of a wavefront walk
+// forward, lane 32 + i walks backward for the replica of lane i).  A one-ended walk keeps one header
 // read in flight per replica and sits at half of the chip's request rate; the reverse of a post-order
 // is the pre-order that takes the RIGHT child first, so a second walker can emit the list from its end:
 // node x at the moment its header arrives (position n - 2 - b for the b-th node), right subtree next,
@@ -1017,7 +877,7 @@ static __global__ __launch_bounds__(256) void fw_walk_kernel(const Params P, con
 // only while left >= 2, the forward walker gets the rest -- every node exactly once.  A backward
 // walker whose stack outgrows its LDS entries stops for good (the forward walker finishes alone).
 // Not for trees with too-wide LEAVES (F.leaf_wide: their place in the list is the forward walker's
-// business): the host launches fw_walk_kernel for those.
+// business): fw_reslice_kernel traverses those itself.
 constexpr int FW_WALK2_CAPB = 32;
 static __global__ __launch_bounds__(256) void fw_walk2_kernel(const Params P, const FwParams F) {
   constexpr int NT = 128;  // replicas per block: the stride of the LDS arrays
@@ -1055,7 +915,7 @@ static __global__ __launch_bounds__(256) void fw_walk2_kernel(const Params P, co
   TNCO_LDS volatile uint32_t* rb = (TNCO_LDS volatile uint32_t*)rbuf + (fwd ? 0 : 16 * NT) + slot;
   const int gh = (N + 1) / 2;
   int cnt = 0, nw = 0;  // nodes / too-wide tensors this walker has listed
-  // ---- forward walker (as fw_walk_kernel) ----
+  // ---- forward walker ----
   int sp = 0, x = N - 1;
   auto f_put_wide = [&](int t) { wlist[nw++] = t; };
   auto f_put_rec = [&](uint64_t v) {
@@ -1629,7 +1489,7 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_WAVES) void fw_reslice_kernel(
   const int64_t r = (int64_t)blockIdx.x * GPB + gib;
   if (r >= P.R) return;
   lds_vi32* lpos = (lds_vi32*)posbuf + gib * FW_LDSPOS;
-  // (the walk is fw_walk_kernel's; without it -- trees of more than 8192 nodes, test knobs -- the
+  // (the walk is fw_walk2_kernel's; without it -- trees of more than 8192 nodes, test knobs -- the
   // links are walked in place, no LDS stack)
   const FwStack st{nullptr, nullptr, 0};
   const bool lane0 = lig == 0;
@@ -1690,39 +1550,15 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_WAVES) void fw_reslice_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// The re-slice as three kernels when the costs are powers of two (uniform dims 2^k, no sparse legs, no
-// hyper-indices, float64): get_slices (phase A, four lanes per replica as before) | the cache rebuild
-// as a RE-PRICING of the old costs, one lane per replica (fw_delta_kernel) | the end of the sweep (phase
-// B, which also does the full rebuild of the few replicas the re-pricing has left).
-//
-// Why: from the reference's greedy starts four fifths of a re-slice were the rebuild -- the legs of
-// all n - 1 nodes re-derived (16 words each) only to count |legs(left) | legs(right) | slices| again,
-// although the new slices S' differ from the old S in a handful of indices.  A node's contraction cost
-// is 2^(k |u | S|), u = legs(left) | legs(right), and |u | S'| - |u | S| = sum over the changed
-// indices d of (+1 if d joined, -1 if d left) * [d not in u].  An index held by two tensors is a leg
-// of a subtree exactly when the subtree holds ONE of them, so per subtree a count vector suffices
-// (two bits per changed index: holders inside), added up the post-order like the partial sums.  The
-// walk kernels record the exponent field of every node's old cost next to its links (the same 32-byte
-// header): the new cost is that exponent moved, a double built from bits -- exact, like the power of
-// two the full rebuild computes.  No leg masks, no leaf table, no reductions: a stack machine of
-// scalars, 64 replicas per wavefront; the total first, and only if it improves a second pass that
-// writes (cost, partial sum) straight into the node headers (no scratch list, no scatter pass).
+// The re-slice by RE-PRICING when the costs are powers of two (uniform dims 2^k, no sparse legs, float64):
+// fw_wave_kernel below -- one wavefront per replica: get_slices, then the cost cache re-priced from the old
+// costs (the new slices S' differ from the old S in a handful of indices; a node's contraction cost is
+// 2^(k |u | S|), u = legs(left) | legs(right), and |u | S'| - |u | S| = sum over the changed indices d of
+// (+1 if d joined, -1 if d left) * [d not in u]).  The replicas it leaves alone: get_slices by
+// fw_reslice_a_kernel (lock-step, its own traverse), the full rebuild + the end of the sweep by
+// fw_reslice_b_kernel.
 // ---------------------------------------------------------------------------------------------
-constexpr int FWT_MAXD = 64;   // changed indices handled by fw_tree_kernel (below), 32 per pass over the paths (more: the full rebuild)
-constexpr int FWD_MAXD = 64;   // changed indices per re-slice handled here (more: the full rebuild); beyond 32 a
-                               // second count-vector word joins in (early in a schedule, one re-slice in 2 000)
-#ifdef TNCO_FW_DELTA_STATS  // (diagnostic build: how many indices change, why replicas take the full rebuild)
-__device__ unsigned long long g_fwd_stats[80];
-#define FWD_STAT(i) atomicAdd(&g_fwd_stats[i], 1ull)
-#else
-#define FWD_STAT(i)
-#endif
-constexpr int FWD_STK = 24;    // stack entries in LDS per replica (deeper: global scratch)
-constexpr int FWD_BITW = 32;   // words of the per-replica leaf bitmap: <= 1024 tensors
-#ifndef TNCO_FWD_LANES
-#define TNCO_FWD_LANES 32
-#endif
-constexpr int FWD_LANES = TNCO_FWD_LANES;  // replicas (busy lanes) per wavefront of fw_delta_kernel
+constexpr int FWT_MAXD = 64;   // changed indices the re-pricing handles, 32 per pass over the paths (more: the full rebuild)
 
 #ifdef TNCO_FWA_PROF  // (diagnostic build: shader cycles per wavefront of [generator init, too-wide counts, greedy pass], wavefronts, too-wide tensors of lane 0's replica)
 static __device__ unsigned long long g_fwa_prof[8];
@@ -1753,8 +1589,8 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_A_WAVES) void fw_reslice_a_ker
   v.init(P, P.blocks + r * P.RB, P.lpar + r * (int64_t)n * LPS, lig);
   ReplicaState* rs = P.rs + r;
   FwScratch sc(F, r, N);
-  if (prewalked && F.nwide[r] == -3) return;  // (fw_slices_kernel has done this replica)
-  // (-2: fw_order_kernel has left this replica's too-wide tensors to the traverse in here)
+  if (prewalked && F.nwide[r] == -3) return;  // (fw_wave_kernel has done this replica)
+  // (-2: fw_wave_kernel has left this replica's too-wide tensors to the traverse in here)
   const int nw_pre = prewalked ? (F.nwide[r] == -2 ? -1 : F.nwide[r]) : -1;
   if (prewalked == 2 && nw_pre >= 0) sc.nwf = F.nwfront[r];
   double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
@@ -1789,50 +1625,7 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_A_WAVES) void fw_reslice_a_ker
   uint64_t* prop = reinterpret_cast<uint64_t*>(const_cast<int16_t*>(sc.pos));
 #pragma unroll
   for (int k = 0; k < K; ++k) prop[v.widx(k)] = ns.w[k];
-  if (F.tree_ok) {
-    // ... and for fw_tree_kernel the indices that changed, each with the parents of the (one or two) leaves
-    // holding it -- where its two paths to the root start: F.delta_scr, as 32-bit words
-    //   [0] how many (0xFFFFFFFF: more than FWT_MAXD, or an index held otherwise: the full rebuild)
-    //   [4..5] [6..7] which of them join / leave the slices (64 bits each)
-    //   [8 + k] first start | second start << 16 (0xFFFF: none)
-    uint32_t* chg = reinterpret_cast<uint32_t*>(F.delta_scr + r * 64);
-    int mine = 0;
-#pragma unroll
-    for (int k = 0; k < K; ++k) mine += __popcll(ns.w[k] ^ slices.w[k]);
-    int off = 0, total = 0;
-#pragma unroll
-    for (int j = 0; j < L; ++j) {
-      const int c = __shfl(mine, gbase + j);
-      off += j < lig ? c : 0;
-      total += c;
-    }
-    bool unsup = total > FWT_MAXD;
-    uint64_t plus = 0, minus = 0;
-    if (!unsup) {
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        uint64_t ch = ns.w[k] ^ slices.w[k];
-        while (ch) {
-          const int bit = __ffsll((unsigned long long)ch) - 1;
-          ch &= ch - 1;
-          const int2 t12 = *reinterpret_cast<const int2*>(F.holder2 + 2 * (v.widx(k) * 64 + bit));
-          if (t12.x < 0) { unsup = true; break; }
-          const int s1 = v.lpar[(int64_t)t12.x * LPS], s2 = t12.y < 0 ? 0xFFFF : v.lpar[(int64_t)t12.y * LPS];
-          chg[8 + off] = (uint32_t)s1 | ((uint32_t)s2 << 16);
-          if ((ns.w[k] >> bit) & 1ull) plus |= 1ull << off; else minus |= 1ull << off;
-          ++off;
-        }
-      }
-    }
-    unsup = gany<LOG2L>(unsup);
-    // (disjoint bits: the sum over the group is the union)
-    const uint32_t p0 = gsum<LOG2L>((uint32_t)plus), p1 = gsum<LOG2L>((uint32_t)(plus >> 32));
-    const uint32_t m0 = gsum<LOG2L>((uint32_t)minus), m1 = gsum<LOG2L>((uint32_t)(minus >> 32));
-    if (lane0) {
-      chg[0] = unsup ? 0xFFFFFFFFu : (uint32_t)total;
-      *reinterpret_cast<uint4*>(chg + 4) = make_uint4(p0, p1, m0, m1);
-    }
-  }
+  if (lane0) reinterpret_cast<uint32_t*>(F.delta_scr + r * 64)[0] = 0xFFFFFFFFu;  // (tnco_hip_get_reslice_info: not re-priced)
   int mti, mtw;
   rng.finish(mti, mtw);
   if (lane0) {
@@ -1841,383 +1634,26 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_A_WAVES) void fw_reslice_a_ker
   }
 }
 
-static __global__ __launch_bounds__(64) void fw_delta_kernel(const Params P, const FwParams F) {
-  // FWD_LANES busy lanes per wavefront: the work of a replica is a chain (LDS stack, record loads), so
-  // more, emptier wavefronts hide more of its latency (as in fw_walk_kernel)
-  constexpr int NL = FWD_LANES;
-  __shared__ double sstk[FWD_STK * NL];
-  __shared__ uint64_t scv[FWD_STK * NL];
-  __shared__ uint32_t sbm[FWD_BITW * NL];
-  __shared__ uint16_t sh[2 * 32 * NL];  // holders of the first 32 changed indices (the others: memory)
-  const int lane = threadIdx.x;
-  if (lane >= NL) return;
-  const int64_t r = (int64_t)blockIdx.x * NL + lane;
-  if (r >= P.R) return;
-  const int n = P.n, N = P.N, LK = F.I64 / 64, ni = N - n;
-  F.fastflag[r] = 0;
-  const FwScratch sc(F, r, N);
-  uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
-  const uint64_t* prop = reinterpret_cast<const uint64_t*>(const_cast<const int16_t*>(sc.pos));
-  {
-    uint64_t any = 0;
-    for (int w = 0; w < P.W; ++w) any |= sl[w];
-    if (!any) return;  // (nothing was proposed)
-  }
-  TNCO_LDS volatile double* stk = (TNCO_LDS volatile double*)sstk + lane;
-  TNCO_LDS volatile uint64_t* cvs = (TNCO_LDS volatile uint64_t*)scv + lane;
-  TNCO_LDS volatile uint32_t* bm = (TNCO_LDS volatile uint32_t*)sbm + lane;
-  TNCO_LDS volatile uint16_t* hl = (TNCO_LDS volatile uint16_t*)sh + lane;
-  // (rarely touched: in memory -- 20 KB of LDS per 32 replicas keep all 65 536 of a launch resident)
-  volatile uint16_t* hl2 = reinterpret_cast<volatile uint16_t*>(F.delta_scr + r * 64);  // holders of the indices 32..63
-  volatile uint64_t* cvs2 = F.delta_scr + r * 64 + 32;                                  // second words of the stack
-  // the changed indices, their holders, which way they changed
-  for (int w = 0; w < FWD_BITW; ++w) bm[w * NL] = 0;
-  int nd = 0, base = 0;
-  uint64_t plus = 0, minus = 0, plus2 = 0, minus2 = 0;
-  bool slow = false;
-  for (int w = 0; w < P.W && !slow; ++w) {
-    const uint64_t o = sl[w], q = prop[w];
-    uint64_t ch = o ^ q;
-    while (ch) {
-      const int bit = __ffsll((unsigned long long)ch) - 1;
-      ch &= ch - 1;
-      const int d = w * 64 + bit;
-      const int t1 = F.holder2[2 * d], t2 = F.holder2[2 * d + 1];
-      if (nd >= FWD_MAXD || t1 < 0) {
-        slow = true;
-        FWD_STAT(t1 < 0 ? 70 : 71);
-        break;
-      }
-      const uint16_t u1 = (uint16_t)t1, u2 = (uint16_t)(t2 < 0 ? 0xFFFF : t2);
-      if (nd < 32) {
-        hl[(2 * nd) * NL] = u1;
-        hl[(2 * nd + 1) * NL] = u2;
-      } else {
-        hl2[2 * (nd - 32)] = u1;
-        hl2[2 * (nd - 32) + 1] = u2;
-      }
-      bm[(t1 >> 5) * NL] |= 1u << (t1 & 31);
-      if (t2 >= 0) bm[(t2 >> 5) * NL] |= 1u << (t2 & 31);
-      const uint64_t fld = 1ull << (2 * (nd & 31));
-      if ((q >> bit) & 1ull) {
-        if (nd < 32) plus |= fld; else plus2 |= fld;
-        base += 1;
-      } else {
-        if (nd < 32) minus |= fld; else minus2 |= fld;
-        base -= 1;
-      }
-      ++nd;
-    }
-  }
-  if (slow) {  // (phase B rebuilds this replica in full; the host watches how often: tnco_hip_run_fw)
-    atomicAdd(F.slowstat, 1ull);
-    return;
-  }
-  FWD_STAT(nd < 40 ? nd : 40);
-  // (nd == 0, the slices the replica has: the rebuild still runs -- its partial sums are those of
-  //  finite_width/utils.hpp:36-47, (cost + left) + right at every node, which the moves' incremental
-  //  updates do not always reproduce to the last bit: the reference compares and may commit)
-  // holders of changed indices inside a leaf: two bits per index
-  const bool wide = nd > 32;
-  auto leafcv = [&](int t, uint64_t& hi) -> uint64_t {
-    hi = 0;
-    if (!((bm[(t >> 5) * NL] >> (t & 31)) & 1u)) return 0ull;
-    uint64_t cv = 0;
-    const int n1 = nd < 32 ? nd : 32;
-    for (int k = 0; k < n1; ++k)
-      if (hl[(2 * k) * NL] == t || hl[(2 * k + 1) * NL] == t) cv += 1ull << (2 * k);
-    for (int k = 32; k < nd; ++k)
-      if (hl2[2 * (k - 32)] == t || hl2[2 * (k - 32) + 1] == t) hi += 1ull << (2 * (k - 32));
-    return cv;
-  };
-  const uint8_t* blk = P.blocks + r * P.RB;
-  const int log2d = P.log2d;
-  bool bad = false;
-  const uint4* rec4 = reinterpret_cast<const uint4*>(sc.rec);  // (64-byte aligned; 8 records per 64 bytes)
-  // ONE pass: the new (cost, partial sum) of every node go to the sequential scratch list (whole lines);
-  // only a replica whose total improves scatters them into its node headers afterwards.  (Recomputing
-  // in a second, storing pass cost as much as the first for EVERY wavefront: one improving replica
-  // among its lanes is enough.)  Straight-line code with selects -- the lanes of a wavefront are at
-  // different (left internal?, right internal?) cases at every node.
-  // the new partial sums (8 B) and cost exponents (2 B) of the nodes, by post-order number: whole 64-byte
-  // pieces per eight nodes (a (cost, partial) pair per node was 135 lines per replica instead of 85)
-  double* plist = reinterpret_cast<double*>(sc.cp);
-  uint16_t* elist = reinterpret_cast<uint16_t*>(plist + ((ni + 9) & ~1));
-  double part = 0.0;
-  uint64_t cvp = 0, cvp2 = 0;
-  int sp = 0;
-  {
-    uint4 nb[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) nb[q] = rec4[q];
-    for (int j0 = 0; j0 < ni; j0 += 8) {
-      uint64_t rc[8];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        rc[2 * q] = (uint64_t)nb[q].x | ((uint64_t)nb[q].y << 32);
-        rc[2 * q + 1] = (uint64_t)nb[q].z | ((uint64_t)nb[q].w << 32);
-      }
-      const int jn = j0 + 8 < ni ? j0 + 8 : j0;  // (past the end: the same piece again)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) nb[q] = rec4[(jn >> 1) + q];
-      double pv[8];
-      uint32_t ev[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        pv[i] = 0.0;
-        ev[i] = 0;
-        if (j0 + i < ni) {
-          const uint64_t cur = rc[i];
-          const int l = fw_rec_left(cur), rr = fw_rec_right(cur), e = fw_rec_exp(cur);
-          const bool li = l >= n, ri = rr >= n, both = li && ri, none = !li && !ri;
-          // the entry below the newest finished subtree (read whether needed or not)
-          const int k2 = sp - 2 < 0 ? 0 : sp - 2;
-          double top;
-          uint64_t topcv, topcv2 = 0;
-          if (k2 < FWD_STK) {
-            top = stk[k2 * NL];
-            topcv = cvs[k2 * NL];
-            if (wide) topcv2 = cvs2[k2];
-          } else {
-            top = sc.pstk[k2];
-            topcv = reinterpret_cast<const uint64_t*>(sc.gstk)[k2];
-            if (wide) bad = true;  // (both at once never seen: the full rebuild takes it)
-          }
-          if (none && sp >= 1) {  // a new subtree starts: the finished one waits on the stack
-            const int k1 = sp - 1;
-            if (k1 < FWD_STK) {
-              stk[k1 * NL] = part;
-              cvs[k1 * NL] = cvp;
-              if (wide) cvs2[k1] = cvp2;
-            } else {
-              sc.pstk[k1] = part;
-              reinterpret_cast<uint64_t*>(sc.gstk)[k1] = cvp;
-            }
-          }
-          uint64_t lcl2 = 0, lcr2 = 0;
-          const uint64_t lcl = li ? 0ull : leafcv(l, lcl2), lcr = ri ? 0ull : leafcv(rr, lcr2);
-          const double pl = both ? top : (li ? part : 0.0);
-          const double pr = ri ? part : 0.0;
-          const uint64_t cvl = both ? topcv : (li ? cvp : lcl);
-          const uint64_t cvr = ri ? cvp : lcr;
-          // a changed index is among the legs of a child that holds exactly one of its tensors
-          const uint64_t in_u = ((cvl & ~(cvl >> 1)) | (cvr & ~(cvr >> 1))) & 0x5555555555555555ull;
-          int dex = base - __popcll(in_u & plus) + __popcll(in_u & minus);
-          if (wide) {  // (indices 32..63 of the list)
-            const uint64_t cvl2 = both ? topcv2 : (li ? cvp2 : lcl2), cvr2 = ri ? cvp2 : lcr2;
-            const uint64_t in_u2 = ((cvl2 & ~(cvl2 >> 1)) | (cvr2 & ~(cvr2 >> 1))) & 0x5555555555555555ull;
-            dex += __popcll(in_u2 & minus2) - __popcll(in_u2 & plus2);
-            cvp2 = cvl2 + cvr2;
-          }
-          const int ne = e + log2d * dex;
-          bad = bad || e <= 0 || e >= 2047 || ne <= 0 || ne >= 2047;
-          const double c = __longlong_as_double((long long)((uint64_t)(uint32_t)ne << 52));
-          part = (c + pl) + pr;  // (the association order of finite_width/utils.hpp:36-47)
-          cvp = cvl + cvr;
-          pv[i] = part;
-          ev[i] = (uint32_t)ne & 0xFFFFu;
-          sp += both ? -1 : (none ? 1 : 0);
-        }
-      }
-      // (the lists are padded by eight entries: whole pieces also at the end)
-      double2* pd = reinterpret_cast<double2*>(plist + j0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) pd[q] = make_double2(pv[2 * q], pv[2 * q + 1]);
-      *reinterpret_cast<uint4*>(elist + j0) = make_uint4(ev[0] | (ev[1] << 16), ev[2] | (ev[3] << 16), ev[4] | (ev[5] << 16), ev[6] | (ev[7] << 16));
-    }
-  }
-  if (bad) {
-    FWD_STAT(72);
-    atomicAdd(F.slowstat, 1ull);
-    return;  // (a cost outside the powers of two of a double: the full rebuild decides)
-  }
-  const double cur = reinterpret_cast<const NodeRec*>(blk + (int64_t)(N - 1 - n) * P.BS)->partial;
-  if (part < cur) {  // greedy/optimizer.hpp:371-374
-#ifndef TNCO_FWD_NO_STORE  // (measurement builds only)
-    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (int j0 = 0; j0 < ni; j0 += 4) {
-      uint64_t x[4];
-      double pp[4];
-      uint32_t ee[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int j = j0 + i < ni ? j0 + i : ni - 1;
-        x[i] = sc.rec[j];
-        pp[i] = plist[j];
-        ee[i] = elist[j];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (j0 + i < ni)
-          *reinterpret_cast<double2*>(const_cast<uint8_t*>(blk) + (int64_t)(fw_rec_node(x[i]) - n) * P.BS + 16) =
-              make_double2(__longlong_as_double((long long)((uint64_t)ee[i] << 52)), pp[i]);
-    }
-#endif
-    for (int w = 0; w < LK; ++w) sl[w] = prop[w];
-  }
-  F.fastflag[r] = 1;
-}
-
 // ---------------------------------------------------------------------------------------------
-// Round 3: the re-slice WITHOUT a walk over the tree (split layout, re-pricing form).
-//
-// fw_walk2_kernel + fw_delta_kernel were n - 1 dependent, random header reads per replica and re-slice
-// (at the chip's random-request ceiling: 0.9 ms), 8-byte records written and read again, and -- for the
-// replicas that keep their new slices -- n - 1 scattered 16-byte stores.  Neither needs a traversal:
-//   * get_slices wants the TOO-WIDE tensors in post-order -- a handful.  fw_order_kernel reads the replica's
-//     header array (one contiguous piece in the split layout), lists the too-wide nodes and gives each the
-//     key of its root path (one bit per level, 0 = left; padded with ones; deeper first on ties):
-//     ascending keys ARE the post-order of include/tnco/utils.hpp:34-51.
-//   * the re-priced CostCache (finite_width/utils.hpp:36-47) only needs children before parents.
-//     fw_tree_kernel: one wavefront per replica, the node table in LDS (16 bytes per node).  The new cost
-//     of a node is its old one times 2^(k * (joined - left)) over the changed indices that are NOT among
-//     its children's legs -- and those that are sit on the paths from the indices' holders up to where the
-//     two paths meet: one lane per (index, holder) marks its path, then every node prices itself.  The
-//     partial sums follow: every lane starts at its nodes with two leaf children, and the LAST of two
-//     children to arrive at a parent (an LDS counter) goes on with the parent.  partial = (cost + left)
-//     + right whatever the order of evaluation, so the sums are the reference's bit for bit.  A replica
+// fw_wave_kernel's pieces.
+//   * get_slices wants the TOO-WIDE tensors in post-order -- some tens.  The header array (one contiguous piece
+//     in the split layout) is read once; every too-wide node gets the key of its root path (one bit per level,
+//     0 = left; padded with ones; deeper first on ties): ascending keys ARE the post-order of
+//     include/tnco/utils.hpp:34-51.  Ranks by counting.
+//   * the re-priced CostCache (finite_width/utils.hpp:36-47) only needs children before parents: the node table
+//     in LDS (8 bytes per node).  The new cost of a node is its old one times 2^(k * (joined - left)) over the
+//     changed indices that are NOT among its children's legs -- and those that are sit on the paths from the
+//     indices' holders up to where the paths meet: one lane per (index, holder) marks its path, then every node
+//     prices itself.  The partial sums follow: every lane starts at its nodes with two leaf children, and the
+//     LAST of two children to arrive at a parent (an LDS counter) goes on with the parent.  partial = (cost +
+//     left) + right whatever the order of evaluation, so the sums are the reference's bit for bit.  A replica
 //     that keeps the new slices rewrites its header array as whole lines.
 // ---------------------------------------------------------------------------------------------
-constexpr int FWO_MAXW = 256;   // too-wide tensors fw_order_kernel orders (more: the traverse inside fw_reslice_a_kernel)
-constexpr int FWT_JMAX = 16;    // internal nodes per lane of fw_tree_kernel at most: n - 1 <= 1024
-__host__ __device__ inline size_t fwo_lds_bytes(int n) {  // per replica (wavefront)
-  const size_t ni = (size_t)((n - 1 + 63) & ~63);
-  return (ni * 4 + ni * 2 + (size_t)FWO_MAXW * (8 + 2 + 2) + 15) & ~(size_t)15;
-}
-__host__ __device__ inline size_t fwt_lds_bytes(int n) {
-  const size_t ni = (size_t)((n - 1 + 63) & ~63), nl = (size_t)((n + 31) / 32);
-  (void)nl;
-  return (ni * (8 + 4 + 4) + 32 + 15) & ~(size_t)15;
-}
+constexpr int FWO_MAXW = 256;   // too-wide tensors the wavefront form orders (more: the traverse inside fw_reslice_a_kernel)
+constexpr int FWT_JMAX = 16;    // internal nodes per lane at most: n - 1 <= 1024
 
-static __global__ __launch_bounds__(256) void fw_order_kernel(const Params P, const FwParams F) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t fwo_smem[];
-  const int n = P.n, N = P.N, ni = N - n, LK = F.I64 / 64;
-  const int nip = (ni + 63) & ~63;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t r = (int64_t)blockIdx.x * 4 + wv;
-  if (r >= P.R) return;
-  uint8_t* base = fwo_smem + (size_t)wv * fwo_lds_bytes(n);
-  TNCO_LDS volatile uint64_t* key = (TNCO_LDS volatile uint64_t*)base;                 // [FWO_MAXW]
-  TNCO_LDS volatile uint32_t* lr = (TNCO_LDS volatile uint32_t*)(key + FWO_MAXW);       // [nip] left | right << 16
-  TNCO_LDS volatile uint16_t* par = (TNCO_LDS volatile uint16_t*)(lr + nip);            // [nip]
-  TNCO_LDS volatile uint16_t* wnode = par + nip;                                        // [FWO_MAXW]
-  TNCO_LDS volatile uint16_t* dep = wnode + FWO_MAXW;                                   // [FWO_MAXW]
-  {  // greedy/optimizer.hpp:359: nothing to do without slices
-    const uint64_t* sl0 = F.slices + r * 2 * (int64_t)LK;
-    uint64_t any = 0;
-    for (int w = lane; w < P.W; w += 64) any |= sl0[w];
-    if (!__any(any != 0)) {
-      if (lane == 0) F.nwide[r] = -1;
-      return;
-    }
-  }
-  const uint8_t* hb = P.blocks + r * P.RB;
-  const double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
-  const FwScratch sc(F, r, N);
-  uint2* img = reinterpret_cast<uint2*>(sc.rec);
-  int32_t* imgw = sc.gstk;  // [n - 1] (the deep end of the traversal stacks: unused without a walk)
-  int nw = 0;
-  for (int j0 = 0; j0 < ni; j0 += 64) {
-    const int i = j0 + lane;
-    bool wide = false;
-    if (i < ni) {
-      const int4 h = *reinterpret_cast<const int4*>(hb + (int64_t)i * P.BS);
-      const uint32_t ce = *reinterpret_cast<const uint32_t*>(hb + (int64_t)i * P.BS + 20);  // high word of the cached cost
-      lr[i] = (uint32_t)h.x | ((uint32_t)h.y << 16);
-      par[i] = (uint16_t)h.z;  // (the root: 0xFFFF)
-      const double w = F.width_f32 ? (double)__int_as_float(h.w) : w64[n + i];
-      wide = w > F.max_width;
-      // the node table of fw_tree_kernel, 8 bytes per node, in the (otherwise unused) record scratch:
-      // left | right << 16;  parent | cost exponent << 16 | internal children << 27
-      const uint32_t c = (h.x >= n ? 1u : 0u) + (h.y >= n ? 1u : 0u);
-      img[i] = make_uint2((uint32_t)h.x | ((uint32_t)h.y << 16), ((uint32_t)h.z & 0xFFFFu) | (((ce >> 20) & 0x7FFu) << 16) | (c << 27));
-      imgw[i] = h.w;  // (the spare header word -- the cached float32 width: a kept re-slice rewrites whole headers)
-    }
-    const unsigned long long b = __ballot(wide);
-    if (wide) {
-      const int k = nw + __popcll(b & ((1ull << lane) - 1ull));
-      if (k < FWO_MAXW) wnode[k] = (uint16_t)(n + i);
-    }
-    nw += __popcll(b);
-  }
-  if (nw > FWO_MAXW) {  // (fw_reslice_a_kernel traverses this replica itself)
-    if (lane == 0) F.nwide[r] = -2;
-    return;
-  }
-  // root-path keys
-  bool deep = false;
-  for (int k0 = 0; k0 < nw; k0 += 64) {
-    const int k = k0 + lane;
-    if (k < nw) {
-      int x = wnode[k], d = 0;
-      uint64_t rev = 0;
-      while (x != N - 1 && d <= 64) {
-        const int p = par[x - n];
-        rev = (rev << 1) | (uint64_t)((int)(lr[p - n] >> 16) == x);
-        x = p;
-        ++d;
-      }
-      if (d > 64) deep = true;
-      uint64_t ky = d ? (__brevll((unsigned long long)rev)) : 0ull;  // level 0 (below the root) in bit 63
-      if (d < 64) ky |= ~0ull >> d;
-      key[k] = ky;
-      dep[k] = (uint16_t)d;
-    }
-  }
-  if (__any(deep)) {
-    if (lane == 0) F.nwide[r] = -2;
-    return;
-  }
-  // ranks: ascending key, deeper first on equal keys (a node and its all-right ancestors)
-  for (int k0 = 0; k0 < nw; k0 += 64) {
-    const int k = k0 + lane;
-    if (k < nw) {
-      const uint64_t ky = key[k];
-      const int d = dep[k];
-      int rank = 0;
-      for (int m = 0; m < nw; ++m) {
-        const uint64_t km = key[m];
-        const int dm = dep[m];
-        rank += (km < ky || (km == ky && dm > d)) ? 1 : 0;
-      }
-      sc.wlist[rank] = wnode[k];
-    }
-  }
-  if (lane == 0) {
-    F.nwide[r] = nw;
-    F.nwfront[r] = nw;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// get_slices (finite_width/greedy/utils.hpp:21-125) with one WAVEFRONT per replica: fw_slices_kernel, between
-// fw_order_kernel and fw_tree_kernel, for the networks of the tree path (uniform power-of-two dims, no sparse
-// legs) with at most 16 mask words.  fw_reslice_a_kernel (16 replicas per wavefront, in lock step) read the legs
-// of every too-wide tensor twice -- once for the counts, once in the greedy pass: ~2 x 110 lines per replica on
-// config 5, 2/3 of the chip's random-request rate for the length of the kernel -- and then gathered the counts
-// one byte per candidate leg from memory.  Here
-//   * lane 16 g + w holds word w of a mask, four tensors per load instruction; the legs read for the counts stay
-//     in LDS (the first `cap` tensors of the list) for the greedy pass; the counts become a byte table in LDS;
-//   * the scan for the next tensor that does not fit tests four tensors per step;
-//   * std::shuffle's variates are drawn for all pairs of swaps at once (lane k: pair k) and the permutation is
-//     applied by every lane tracing ITS final position back through the swaps -- registers only; the rare cases
-//     (a re-draw of uniform_int_distribution, the generator's 624 words ending inside the shuffle) run the
-//     sequential fw_shuffle_lds from the same generator position;
-//   * a pick is one maximum over the wavefront.
-// The generator is RngWave: 64 outputs per memory round trip, never ahead of the generation being consumed.
-// Replicas it leaves alone (nwide -2, > 255 too-wide tensors, > FWS_MAXNP candidate legs in a tensor) are done by
-// fw_reslice_a_kernel, which skips those marked done (nwide = -3).  Same outputs as that kernel: the proposed
-// slices, the change list for fw_tree_kernel, the generator's position.
-// ---------------------------------------------------------------------------------------------
-#ifndef TNCO_FWS_CAP
-#define TNCO_FWS_CAP 16
-#endif
-constexpr int FWS_CAP = TNCO_FWS_CAP;  // too-wide tensors whose legs stay in LDS between the two passes (default)
-constexpr int FWS_MAXNP = 128;          // candidate legs of one tensor: two per lane
-__host__ __device__ inline size_t fws_lds_bytes(int cap) {
-  return (size_t)cap * 128 + 1024 /* counts */ + 1024 /* generator ring */ + 512 /* positions */ + 512 /* list */;
-}
+constexpr int FWS_MINCAP = 16;   // too-wide tensors whose legs stay in LDS at least (the wavefront form sizes its LDS for that)
+constexpr int FWS_MAXNP = 128;   // candidate legs of one tensor: two per lane
 
 // std::mt19937 for one wavefront: outputs [.., hi) of the CURRENT generation are in the ring (256 entries, batches
 // of 64 aligned to 64), words below `tw` of the state array are twisted.  A fill produces up to three batches in ONE
@@ -2312,519 +1748,44 @@ __device__ __forceinline__ uint32_t fws_rowscan(uint32_t v) {
   return v;
 }
 
-#ifdef TNCO_FWS_PROF  // (diagnostic build: shader cycles per replica of [list + counts, count table, greedy pass; of it scan, positions, generator, shuffle, keys + picks], replicas, slicings)
-static __device__ unsigned long long g_fws_prof[12];
-#define FWS_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
-#define FWS_ACC(i, a, b) acc_[i] += (b) - (a)
-#else
-#define FWS_T(v)
-#define FWS_ACC(i, a, b)
-#endif
-static __global__ __launch_bounds__(64) void fw_slices_kernel(const Params P, const FwParams F, const int cap, const int maxnp) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t fws_smem[];
-  const int lane = threadIdx.x, w = lane & 15, g = lane >> 4;
-  const int64_t r = blockIdx.x;
-  // (everything that does not depend on anything else is requested first: a dependent round trip costs 5-10 us here)
-  const int nw = F.nwide[r];
-  const int n = P.n, N = P.N, W = P.W, LK = F.I64 / 64;
-  TNCO_LDS volatile uint64_t* cache = (TNCO_LDS volatile uint64_t*)fws_smem;          // [cap][16] legs of the listed tensors
-  TNCO_LDS volatile uint8_t* nbig = (TNCO_LDS volatile uint8_t*)(cache + (size_t)cap * 16);  // [1024] too-wide counts
-  lds_vu32* ring = (lds_vu32*)(nbig + 1024);                                          // [256]
-  lds_vi32* pos = (lds_vi32*)(ring + 256);                                            // [FWS_MAXNP]
-  TNCO_LDS volatile uint16_t* wls = (TNCO_LDS volatile uint16_t*)(pos + FWS_MAXNP);    // [256] the list
-  const FwScratch sc(F, r, N);
-  const uint8_t* legs = P.blocks + r * P.RB + P.WOFF;
-  const int WS = P.WS;
-  const bool has = w < W;
-  ReplicaState* rs = P.rs + r;
-  const int mti0 = rs->mti, mtw0 = rs->mtw;
-  const uint64_t old = has ? F.slices[r * 2 * (int64_t)LK + w] : 0ull;
-  const uint64_t skip = (F.skip != nullptr && has) ? F.skip[w] : 0ull;
-  int wlq[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) wlq[q] = (64 * q + lane < sc.wcap) ? sc.wlist[64 * q + lane] : n;
-  if (nw < 0 || nw > 255) return;  // (-1: no slices, nothing to do; the others: fw_reslice_a_kernel)
-#ifdef TNCO_FWS_PROF
-  unsigned long long acc_[6] = {0, 0, 0, 0, 0, 0};
-#endif
-  FWS_T(q0_);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) wls[64 * q + lane] = (uint16_t)(64 * q + lane < nw ? wlq[q] : n);
-  // ---- :41-48: for every index the number of too-wide tensors it appears in (bit-sliced, four tensors side by side)
-  uint64_t pl[8];
-#pragma unroll
-  for (int p = 0; p < 8; ++p) pl[p] = 0ull;
-  uint32_t maxc = 0;
-  uint64_t m[4];
-  auto load16 = [&](int t0) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int t = t0 + 4 * u + g;
-      const int node = wls[t < nw ? t : 0];
-      m[u] = 0ull;
-      if (t < nw && has) m[u] = *reinterpret_cast<const uint64_t*>(legs + (int64_t)(node - n) * WS + 8 * w);
-    }
-  };
-  load16(0);
-  // the generator's first outputs travel with the first legs
-  RngWave rng;
-  rng.init(P.mt + r * 624, ring, mti0, mtw0, lane);
-  if (nw > 0) rng.fill();
-  for (int t0 = 0; t0 < nw; t0 += 16) {
-    if (t0) load16(t0);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int t = t0 + 4 * u + g;
-      if (t < nw && t < cap) cache[t * 16 + w] = m[u];
-      const uint32_t c = gsum<4>((uint32_t)__popcll(m[u] & ~skip));
-      maxc = c > maxc ? c : maxc;
-      uint64_t carry = m[u];
-#pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const uint64_t tt = pl[p] & carry;
-        pl[p] ^= carry;
-        carry = tt;
-      }
-    }
-  }
-  if (gmax<6>(maxc) > (uint32_t)maxnp) {  // (nothing drawn yet; the generator's words twisted ahead stay)
-    if (lane == 0) rs->mtw = (int)rng.tw;
-    return;
-  }
-  FWS_T(q1_);
-  // the four partial counts of a lane's 64 indices, added
-#pragma unroll
-  for (int step = 16; step <= 32; step <<= 1) {
-    uint64_t o[8];
-#pragma unroll
-    for (int p = 0; p < 8; ++p) o[p] = fws_shflx64(pl[p], step);
-    uint64_t c = 0ull;
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const uint64_t a = pl[p], b = o[p];
-      pl[p] = a ^ b ^ c;
-      c = (a & b) | (c & (a ^ b));
-    }
-  }
-  {  // counters 16 g .. 16 g + 15 of word w -> sixteen bytes (a nibble of plane bits is spread over the bytes of a word)
-    uint32_t o[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      uint32_t c = 0;
-#pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const uint32_t nib = (uint32_t)(pl[p] >> (16 * g + 4 * j)) & 0xFu;
-        c |= ((nib * 0x00204081u) & 0x01010101u) << p;
-      }
-      o[j] = c;
-    }
-    TNCO_LDS volatile uint32_t* d = (TNCO_LDS volatile uint32_t*)(nbig + w * 64 + 16 * g);
-    d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3];
-  }
-  // ---- :62-101: the greedy pass over the list, in post-order
-  FWS_T(q2_);
-  uint64_t ns = 0ull;  // the new slices, word w (the same in the four rows of lanes)
-  const double mdl = fw_wr(F, -F.log2d);  // get_delta_width of a set position (simple.hpp:59-76)
-  int j = 0;
-  while (j < nw) {
-    FWS_T(s0_);
-    const int t = j + g;
-    uint64_t m = 0ull;
-    if (t < nw) {
-      if (t < cap) m = cache[t * 16 + w];
-      else if (has) m = *reinterpret_cast<const uint64_t*>(legs + (int64_t)((int)wls[t] - n) * WS + 8 * w);
-    }
-    const uint64_t sx = m & ~ns;
-    const uint32_t cnt = gsum<4>((uint32_t)__popcll(sx));
-    const bool wide = t < nw && fw_wr(F, F.log2d * (double)cnt) > F.max_width;
-    const unsigned long long bal = __ballot(wide);
-    if (bal == 0ull) {
-      j += 4;
-      FWS_T(s1_);
-      FWS_ACC(0, s0_, s1_);
-      continue;
-    }
-    FWS_T(s1_);
-    FWS_ACC(0, s0_, s1_);
-    const int gs = (__ffsll(bal) - 1) >> 4;  // the first of the four that does not fit
-    j += gs + 1;
-    const uint64_t sxw = fws_shfl64(sx, 16 * gs + w);
-    double sw = fw_wr(F, F.log2d * (double)(uint32_t)__shfl((int)cnt, 16 * gs));
-    // candidate positions, ascending
-    const uint64_t cand = sxw & ~skip;
-    const uint32_t mine = (uint32_t)__popcll(cand);
-    const uint32_t incl = fws_rowscan(mine);
-    const int np = __builtin_amdgcn_readlane((int)incl, 15);
-    if (g == 0) {
-      uint32_t o = incl - mine;
-      uint64_t x = cand;
-      while (x) {
-        const int b = __ffsll((unsigned long long)x) - 1;
-        pos[o++] = w * 64 + b;
-        x &= x - 1;
-      }
-    }
-    // :80 std::shuffle -- src0 / src1: where the candidates that end at ranks lane / lane + 64 stand before it
-    int src0 = lane, src1 = lane + 64;
-    FWS_T(s2_);
-    FWS_ACC(1, s1_, s2_);
-    if (np >= 2) {
-      const uint32_t nd = (uint32_t)np >> 1;  // variates: one per pair of swaps (+ the single swap of an even count)
-      bool fast = rng.ensure(nd);
-      FWS_T(s3_);
-      FWS_ACC(2, s2_, s3_);
-      uint32_t p0 = 0, p1 = 0;
-      const int base = (np & 1) ? 1 : 0;  // lane k swaps positions base + 2 k, base + 2 k + 1 (position 0 with itself)
-      if (fast) {
-        const uint32_t raw = rng.peek((uint32_t)lane);
-        const uint32_t i0 = (uint32_t)(base + 2 * lane);
-        const bool single = base == 0 && lane == 0;  // (stl_algo.h:3760-3765: d(0, 1), the swap of position 1)
-        const uint32_t range = single ? 2u : (i0 + 1u) * (i0 + 2u);
-        const uint64_t product = (uint64_t)raw * (uint64_t)range;
-        const uint32_t low = (uint32_t)product;
-        bool rej = false;
-        if ((uint32_t)lane < nd && low < range) rej = low < (0u - range) % range;
-        if (__any(rej)) {
-          fast = false;
-        } else {
-          const uint32_t x = (uint32_t)(product >> 32);
-          if (single) {
-            p0 = 0;
-            p1 = x;
-          } else {
-            p0 = x / (i0 + 2u);
-            p1 = x - p0 * (i0 + 2u);
-          }
-          rng.advance(nd);
-        }
-      }
-      if (fast) {
-        const bool two = np > 64;
-        for (int k = (int)nd - 1; k >= 0; --k) {
-          const int j1 = __builtin_amdgcn_readlane((int)p1, k), j0 = __builtin_amdgcn_readlane((int)p0, k);
-          const int i = base + 2 * k;
-          src0 = src0 == i + 1 ? j1 : (src0 == j1 ? i + 1 : src0);
-          src0 = src0 == i ? j0 : (src0 == j0 ? i : src0);
-          if (two) {
-            src1 = src1 == i + 1 ? j1 : (src1 == j1 ? i + 1 : src1);
-            src1 = src1 == i ? j0 : (src1 == j0 ? i : src1);
-          }
-        }
-      } else {
-        fw_shuffle_lds<6>(rng, pos, np, lane == 0);
-      }
-      FWS_T(s4_);
-      FWS_ACC(3, s3_, s4_);
-    }
-    FWS_T(s5_);
-    // :83-101 the keys ((too-wide count << 16) | 0xFFFF - shuffled rank: the stable order of :83); picks until it fits
-    const int xp0 = lane < np ? (int)pos[src0] : 0, xp1 = lane + 64 < np ? (int)pos[src1] : 0;
-    uint32_t k0 = lane < np ? (((uint32_t)nbig[xp0] << 16) | (0xFFFFu - (uint32_t)lane)) : 0u;
-    uint32_t k1 = lane + 64 < np ? (((uint32_t)nbig[xp1] << 16) | (0xFFFFu - (uint32_t)(lane + 64))) : 0u;
-    for (int taken = 0; taken < np; ++taken) {
-      const uint32_t best = gmax<6>(k0 > k1 ? k0 : k1);
-      const int qb = (int)(0xFFFFu - (best & 0xFFFFu));
-      const int xpos = __shfl(qb >= 64 ? xp1 : xp0, qb & 63);
-      if (lane == (qb & 63)) {
-        if (qb >= 64) k1 = 0u; else k0 = 0u;
-      }
-      if (w == (xpos >> 6)) ns |= 1ull << (xpos & 63);
-      sw = fw_wr(F, sw + mdl);
-      if (sw <= F.max_width) break;
-    }
-    FWS_T(s6_);
-    FWS_ACC(4, s5_, s6_);
-#ifdef TNCO_FWS_PROF
-    acc_[5] += 1;
-#endif
-  }
-  FWS_T(q3_);
-  // ---- the proposed slices, and for fw_tree_kernel the indices that changed (as fw_reslice_a_kernel leaves them)
-  uint64_t* prop = reinterpret_cast<uint64_t*>(const_cast<int16_t*>(sc.pos));
-  if (g == 0 && w < LK) prop[w] = ns;
-  {
-    uint32_t* chg = reinterpret_cast<uint32_t*>(F.delta_scr + r * 64);
-    const int32_t* lpar = P.lpar + r * (int64_t)n * LPS;
-    uint64_t ch = g == 0 ? (ns ^ old) : 0ull;
-    const uint32_t mine = (uint32_t)__popcll(ch);
-    const uint32_t incl = fws_rowscan(mine);
-    const int total = __builtin_amdgcn_readlane((int)incl, 15);
-    bool unsup = total > FWT_MAXD;
-    uint64_t plus = 0ull, minus = 0ull;
-    if (!unsup) {
-      uint32_t off = incl - mine;
-      while (ch) {
-        const int bit = __ffsll((unsigned long long)ch) - 1;
-        ch &= ch - 1;
-        const int2 t12 = *reinterpret_cast<const int2*>(F.holder2 + 2 * (w * 64 + bit));
-        if (t12.x < 0) { unsup = true; break; }
-        const int s1 = lpar[(int64_t)t12.x * LPS], s2 = t12.y < 0 ? 0xFFFF : lpar[(int64_t)t12.y * LPS];
-        chg[8 + off] = (uint32_t)s1 | ((uint32_t)s2 << 16);
-        if ((ns >> bit) & 1ull) plus |= 1ull << off; else minus |= 1ull << off;
-        ++off;
-      }
-    }
-    unsup = __any(unsup);
-    // (disjoint bits: the sum over the row is the union)
-    const uint32_t a0 = gsum<4>((uint32_t)plus), a1 = gsum<4>((uint32_t)(plus >> 32));
-    const uint32_t b0 = gsum<4>((uint32_t)minus), b1 = gsum<4>((uint32_t)(minus >> 32));
-    if (lane == 0) {
-      chg[0] = unsup ? 0xFFFFFFFFu : (uint32_t)total;
-      *reinterpret_cast<uint4*>(chg + 4) = make_uint4(a0, a1, b0, b1);
-    }
-  }
-  int mti, mtw;
-  rng.finish(mti, mtw);
-  if (lane == 0) {
-    rs->mti = mti;
-    rs->mtw = mtw;
-    F.nwide[r] = -3;  // done: fw_reslice_a_kernel skips this replica
-  }
-#ifdef TNCO_FWS_PROF
-  if (lane == 0) {
-    atomicAdd(&g_fws_prof[0], q1_ - q0_); atomicAdd(&g_fws_prof[1], q2_ - q1_); atomicAdd(&g_fws_prof[2], q3_ - q2_);
-    for (int q = 0; q < 5; ++q) atomicAdd(&g_fws_prof[3 + q], acc_[q]);
-    atomicAdd(&g_fws_prof[8], 1ull); atomicAdd(&g_fws_prof[9], acc_[5]); atomicAdd(&g_fws_prof[10], (unsigned long long)nw);
-    atomicAdd(&g_fws_prof[11], __builtin_amdgcn_s_memtime() - q0_);
-  }
-#endif
-}
-
-#ifdef TNCO_FWT_PROF  // (diagnostic build: shader cycles of [setup, header load, the loop, commit], loop iterations, replicas, commits)
-static __device__ unsigned long long g_fwt_prof[8];
-#define FWT_T(i) const unsigned long long tt##i = __builtin_amdgcn_s_memtime()
-#else
-#define FWT_T(i)
-#endif
-// GW lanes per replica (64: one per wavefront; 32: two -- half the instructions per replica, for networks of at most
-// 2048 indices), J = ceil((n - 1) / GW) nodes per lane.
-template <int J, int GW>
-static __global__ __launch_bounds__(256, (J * GW <= 576 ? 4 : 2)) void fw_tree_kernel(const Params P, const FwParams F) {
-  FWT_T(0);
-  extern __shared__ __attribute__((aligned(16))) uint8_t fwt_smem[];
-  constexpr int GPW = 64 / GW;   // replicas per wavefront
-  constexpr int IPP = GW / 2;    // changed indices per pass over the paths: one lane per (index, holder)
-  const int n = P.n, N = P.N, ni = N - n, LK = F.I64 / 64;
-  const int nip = (ni + 63) & ~63;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int gl = lane & (GW - 1), g = lane / GW;
-  const int64_t r = ((int64_t)blockIdx.x * 4 + wv) * GPW + g;
-  if (r >= P.R) return;
-  // (every exchange below stays inside the GW lanes of a replica: a replica that leaves early takes nobody with it)
-  const unsigned long long gmask = GW == 64 ? ~0ull : (0xFFFFFFFFull << (32 * g));
-  auto gany = [&](bool x) -> bool { return (__ballot(x) & gmask) != 0ull; };
-  uint8_t* base = fwt_smem + (size_t)(wv * GPW + g) * fwt_lds_bytes(n);
-  // node i of the table: lo = left | right << 16; hi = parent | cost exponent << 16 | children still to arrive << 27;
-  // Pn = the new partial sum -- before that the two path masks of the node (see below)
-  TNCO_LDS volatile double* Pn = (TNCO_LDS volatile double*)base;                        // [nip]
-  TNCO_LDS uint32_t* on = (TNCO_LDS uint32_t*)base;                                      // [nip][2] (the same memory)
-  TNCO_LDS volatile uint32_t* onv = (TNCO_LDS volatile uint32_t*)base;
-  TNCO_LDS volatile uint32_t* lo = (TNCO_LDS volatile uint32_t*)(Pn + nip);              // [nip]
-  TNCO_LDS uint32_t* hi = (TNCO_LDS uint32_t*)(lo + nip);                                // [nip] (atomic arrivals)
-  TNCO_LDS volatile uint32_t* hiv = (TNCO_LDS volatile uint32_t*)hi;                     // (plain accesses)
-  TNCO_LDS volatile uint32_t* misc = (TNCO_LDS volatile uint32_t*)(hi + nip);            // [8]
-  if (gl == 0) F.fastflag[r] = 0;
-  uint64_t* sl = F.slices + r * 2 * (int64_t)LK;
-  const FwScratch sc(F, r, N);
-  // ---- everything this replica needs, in flight at once: the node table fw_order_kernel has left (8 bytes per
-  // node, one contiguous piece), the changed indices with the starts of their paths (fw_reslice_a_kernel), the
-  // current total, the old slices
-  uint8_t* hb = P.blocks + r * P.RB;
-  const uint32_t* chg = reinterpret_cast<const uint32_t*>(F.delta_scr + r * 64);
-  const uint2 c0 = *reinterpret_cast<const uint2*>(chg);
-  const uint4 c1 = *reinterpret_cast<const uint4*>(chg + 4);
-  uint32_t myent[GPW];  // (FWT_MAXD = 64 entries: 64 / GW per lane)
-#pragma unroll
-  for (int q = 0; q < GPW; ++q) myent[q] = chg[8 + q * GW + gl];
-  uint64_t myold = 0;
-  if (gl < P.W) myold = sl[gl];
-  const double cur = reinterpret_cast<const NodeRec*>(hb + (int64_t)(ni - 1) * P.BS)->partial;
-  const int nwide_r = F.nwide[r];
-  const uint2* img = reinterpret_cast<const uint2*>(sc.rec);
-  const int32_t* imgw = sc.gstk;  // (the spare header words: a kept re-slice rewrites whole headers)
-  uint2 im[J];  // (only until the table is in LDS: the kernel must stay below 128 registers, four wavefronts per SIMD)
-  int32_t iw[J];
-#pragma unroll
-  for (int j = 0; j < J; ++j) {
-    const int i = j * GW + gl;
-    im[j] = make_uint2(0, 0);
-    iw[j] = 0;
-    if (i < ni) {
-      im[j] = img[i];
-      iw[j] = imgw[i];
-    }
-  }
-  if (!gany(myold != 0)) return;  // (nothing was proposed: greedy/optimizer.hpp:359)
-  // (-2: fw_reslice_a_kernel has traversed this replica itself -- over the node table; no list: the full rebuild)
-  if (nwide_r == -2 || c0.x == 0xFFFFFFFFu) {
-    if (gl == 0) atomicAdd(F.slowstat, 1ull);
-    return;
-  }
-  const int nd = (int)c0.x;
-  // bit k of the pair: changed index number k joins / leaves the slices
-  const uint64_t plus64 = (uint64_t)c1.x | ((uint64_t)c1.y << 32), minus64 = (uint64_t)c1.z | ((uint64_t)c1.w << 32);
-  const int dbase = __popcll(plus64) - __popcll(minus64);
-  FWT_T(1);
-  // ---- the node table (links, old exponents, arrival counters), path masks cleared ------------------
-  uint32_t startmask = 0;
-  bool bad = false;
-#pragma unroll
-  for (int j = 0; j < J; ++j) {
-    const int i = j * GW + gl;
-    if (i < ni) {
-      const int e = (int)((im[j].y >> 16) & 0x7FFu);
-      bad = bad || e <= 0 || e >= 2047;
-      lo[i] = im[j].x;
-      hiv[i] = im[j].y;
-      onv[2 * i] = 0;
-      onv[2 * i + 1] = 0;
-      if ((im[j].y >> 27) == 0u) startmask |= 1u << j;
-    }
-  }
-  // ---- which nodes see a changed index among the legs of their children ------------------------------
-  // An index held by two tensors is a leg of a subtree exactly when the subtree holds ONE of them: of the
-  // nodes above the first holder (mask 0) and above the second (mask 1), those below their meeting point have
-  // it among their children's legs, the meeting point too, the nodes above it not.  One lane per (index,
-  // holder) walks its path to the root; GW / 2 indices per pass (more passes: one re-slice in some hundreds).
-  const int log2d = P.log2d;
-  for (int pass = 0; pass * IPP < nd || pass == 0; ++pass) {
-    const uint32_t plus = (uint32_t)(plus64 >> (IPP * pass)) & (uint32_t)((1ull << IPP) - 1ull);
-    const uint32_t minus = (uint32_t)(minus64 >> (IPP * pass)) & (uint32_t)((1ull << IPP) - 1ull);
-    if (pass) {
-      for (int i = gl; i < ni; i += GW) { onv[2 * i] = 0; onv[2 * i + 1] = 0; }
-    }
-    {
-      const int k = gl >> 1, which = gl & 1;
-      const int idx = IPP * pass + k;  // this lane's changed index; its entry sits in lane idx % GW, slot idx / GW
-      uint32_t esel = myent[0];
-#pragma unroll
-      for (int q = 1; q < GPW; ++q) esel = (idx / GW == q) ? myent[q] : esel;  // (idx / GW is the same for the whole pass)
-      const uint32_t e = (uint32_t)__shfl((int)esel, idx & (GW - 1), GW);
-      const int st = which ? (int)(e >> 16) : (int)(e & 0xFFFFu);
-      int x = (idx < nd && st != 0xFFFF) ? st : -1;  // the path of a holder starts at its parent
-      for (int guard = 0; gany(x >= 0); ++guard) {
-        if (guard > ni) { bad = true; break; }  // (cannot happen in a tree: never spin on corrupt links)
-        if (x >= 0) {
-          __hip_atomic_fetch_or(&on[2 * (x - n) + which], 1u << k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          const int pp = (int)(hiv[x - n] & 0xFFFFu);
-          x = pp == 0xFFFF ? -1 : pp;
-        }
-      }
-    }
-    for (int i = gl; i < ni; i += GW) {
-      const uint32_t w = lo[i], h = hiv[i];
-      const int l = (int)(w & 0xFFFFu), rr = (int)(w >> 16);
-      const uint32_t a = onv[2 * i], b = onv[2 * i + 1];
-      const int il = l >= n ? l - n : i, ir = rr >= n ? rr - n : i;
-      const uint32_t bl = onv[2 * il] & onv[2 * il + 1], br = onv[2 * ir] & onv[2 * ir + 1];
-      const uint32_t both_below = (l >= n ? bl : 0u) | (rr >= n ? br : 0u);
-      const uint32_t in_u = (a ^ b) | (a & b & ~both_below);
-      const int dex = (pass ? 0 : dbase) - __popc(in_u & plus) + __popc(in_u & minus);
-      const int ne = (int)((h >> 16) & 0x7FFu) + log2d * dex;
-      bad = bad || ne <= 0 || ne >= 2047;  // (also between the passes: the full rebuild decides then)
-      hiv[i] = (h & 0xF800FFFFu) | ((uint32_t)(ne & 0x7FF) << 16);  // (nobody reads another node's exponent in this pass)
-    }
-  }
-  FWT_T(2);
-  [[maybe_unused]] unsigned long long iters_ = 0;
-  // ---- children before parents: every lane starts at its nodes with two leaf children; the second child to
-  // arrive at a parent goes on with it (the arrival returns the parent's record)
-  int p = -1;
-  uint32_t phi = 0, plo = 0;
-  for (int guard = 0;; ++guard) {
-    if (guard > 2 * ni + 64) { bad = true; break; }  // (cannot happen in a tree)
-    if (p < 0 && startmask) {
-      const int j = __ffs(startmask) - 1;
-      startmask &= startmask - 1;
-      p = j * GW + gl;
-      phi = hiv[p];
-      plo = lo[p];
-    }
-    if (!gany(p >= 0)) break;
-#ifdef TNCO_FWT_PROF
-    ++iters_;
-#endif
-    if (p >= 0) {
-      const uint32_t w = plo;
-      const int l = (int)(w & 0xFFFFu), rr = (int)(w >> 16);
-      const bool li = l >= n, ri = rr >= n;
-      const double pl0 = Pn[li ? l - n : p], pr0 = Pn[ri ? rr - n : p];
-      const double pl = li ? pl0 : 0.0, pr = ri ? pr0 : 0.0;
-      const double c = __longlong_as_double((long long)((uint64_t)((phi >> 16) & 0x7FFu) << 52));
-      Pn[p] = (c + pl) + pr;  // (the association order of finite_width/utils.hpp:36-47)
-      if (p == ni - 1) {
-        p = -1;  // the root
-      } else {
-        const int q = (int)(phi & 0xFFFFu) - n;
-        const uint32_t old = __hip_atomic_fetch_add(&hi[q], 0u - (1u << 27), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint32_t qlo = lo[q];  // (with the arrival: the parent's children, in case this lane goes on with it)
-        if ((old >> 27) == 1u) { p = q; phi = old; plo = qlo; } else { p = -1; }
-      }
-    }
-  }
-  FWT_T(3);
-  if (gany(bad)) {  // (a cost outside the powers of two of a double: the full rebuild decides)
-    if (gl == 0) atomicAdd(F.slowstat, 1ull);
-    return;
-  }
-  if (gl == ((ni - 1) & (GW - 1))) misc[0] = (Pn[ni - 1] < cur) ? 1u : 0u;  // greedy/optimizer.hpp:371-374
-  if (misc[0]) {
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      const int i = j * GW + gl;
-      if (i < ni) {
-        // the whole header, links and width as they were: two 16-byte stores per node that leave the L2 as whole
-        // lines (the second halves alone, 16 of every 32 bytes, were read-modify-writes in the memory: 2.5 x the time)
-        const uint32_t w = lo[i], h = hiv[i];
-        const double c = __longlong_as_double((long long)((uint64_t)((h >> 16) & 0x7FFu) << 52)), pp = Pn[i];
-        const int par = (int)(h & 0xFFFFu);
-        int4* d = reinterpret_cast<int4*>(hb + (int64_t)i * P.BS);
-        d[0] = make_int4((int)(w & 0xFFFFu), (int)(w >> 16), par == 0xFFFF ? -1 : par, iw[j]);
-        d[1] = make_int4(__double2loint(c), __double2hiint(c), __double2loint(pp), __double2hiint(pp));
-      }
-    }
-    const uint64_t* prop = reinterpret_cast<const uint64_t*>(const_cast<const int16_t*>(sc.pos));
-    if (gl < LK) sl[gl] = gl < P.W ? prop[gl] : 0ull;
-  }
-  if (gl == 0) F.fastflag[r] = 1;
-#ifdef TNCO_FWT_PROF
-  if (gl == 0) {
-    const unsigned long long tt4 = __builtin_amdgcn_s_memtime();
-    atomicAdd(&g_fwt_prof[0], tt1 - tt0); atomicAdd(&g_fwt_prof[1], tt2 - tt1); atomicAdd(&g_fwt_prof[2], tt3 - tt2);
-    atomicAdd(&g_fwt_prof[3], tt4 - tt3); atomicAdd(&g_fwt_prof[4], iters_); atomicAdd(&g_fwt_prof[5], 1ull);
-    atomicAdd(&g_fwt_prof[6], misc[0] ? 1ull : 0ull); atomicAdd(&g_fwt_prof[7], (unsigned long long)nd);
-  }
-#endif
-}
-
 // ---------------------------------------------------------------------------------------------
-// The three steps above as ONE kernel, one wavefront per replica: fw_wave_kernel = fw_order_kernel |
-// fw_slices_kernel | fw_tree_kernel without the memory between them.  Separately, every step started cold (a
-// dependent round trip costs 5-10 us here) and the tree kernel's first act was to read back the 12 bytes per node
-// the order kernel had just written: per replica and re-slice 6.5 KB written + 6.5 KB read, the list, the change
-// list and the proposal through memory, two launches.  Here the headers are read once (J nodes per lane, all loads
-// in flight together with the old slices and the generator's position), the node table goes straight into the LDS
-// layout of the tree step (lo / hi), the list of the too-wide tensors stays in LDS, the change list is built in LDS.
-// LDS per replica: the node table (8 bytes per node) + one region used three times (keys of the ordering; legs,
-// counts, generator ring and candidate positions of get_slices; path masks / partial sums of the re-pricing).
+// fw_wave_kernel: the whole re-slice of a replica in one wavefront.  The headers are read once (J nodes per lane,
+// all loads in flight together with the old slices and the generator's position) and STAY IN REGISTERS; the node
+// table (lo / hi, 8 bytes per node in LDS) is built from them twice -- for the ordering of the too-wide tensors,
+// and again for the re-pricing -- because in between get_slices wants the LDS for the legs of the too-wide tensors:
+// on the Sycamore-53 supremacy network a replica has 30-60 of them, the scan of the greedy pass visits each several
+// times, and a visit that goes to memory is a cold round trip (5-10 us).
+// LDS per replica: [list of the too-wide tensors 512 B][node table][one more region]; get_slices overlays the last
+// two with [shuffle tables, generator ring, candidate list][legs of the first `cap` too-wide tensors]; the
+// re-pricing uses the region for path masks / partial sums, the ordering for its keys.
 // A replica one of the steps cannot do leaves with nwide = -2 (fw_reslice_a_kernel traverses it) or with the
-// proposal written and fastflag = 0 (fw_reslice_b_kernel rebuilds it in full), exactly as from the separate kernels.
+// proposal written and fastflag = 0 (fw_reslice_b_kernel rebuilds it in full).
 // ---------------------------------------------------------------------------------------------
-__host__ __device__ inline size_t fww_lds_bytes(int n, int cap, int T) {  // T: lanes per mask (16, 32 or 64)
+constexpr size_t FWW_GS_FIXED = 192 * 8 + 1024 + (size_t)FWS_MAXNP * 3 + 64;  // shuffle steps per position, ring, candidates + swap targets (+ padding to 16)
+__host__ __device__ inline size_t fww_lds_bytes(int n, int T) {  // T: lanes per mask (16, 32 or 64)
   const size_t nip = (size_t)((n - 1 + 63) & ~63);
   const size_t u1 = (size_t)FWO_MAXW * (8 + 2 + 2);                         // keys, nodes, depths
-  const size_t u2 = (size_t)cap * T * 8 + (size_t)64 * T + 1024 + 512;       // legs, counts, ring, positions
   const size_t u3 = nip * 8 + 256 + 32;                                     // masks / partial sums, change list, flags
-  size_t u = u1 > u2 ? u1 : u2;
-  u = u > u3 ? u : u3;
-  return (nip * 8 + 512 /* list */ + u + 15) & ~(size_t)15;
+  size_t body = nip * 8 + (u1 > u3 ? u1 : u3);
+  const size_t gs = FWW_GS_FIXED + (size_t)FWS_MINCAP * T * 8;              // get_slices at least
+  body = body > gs ? body : gs;
+  return (512 /* list */ + body + 15) & ~(size_t)15;
+}
+// too-wide tensors whose legs get_slices keeps in LDS
+__host__ __device__ inline int fww_cap(int n, int T) {
+  const size_t c = (fww_lds_bytes(n, T) - 512 - FWW_GS_FIXED) / ((size_t)T * 8);
+  return (int)(c < (size_t)FWO_MAXW ? c : (size_t)FWO_MAXW);
 }
 
 #ifdef TNCO_FWW_PROF  // (diagnostic build: shader cycles per replica between the steps of fw_wave_kernel)
-static __device__ unsigned long long g_fww_prof[12];
+static __device__ unsigned long long g_fww_prof[24];
 #define FWW_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define FWW_ACC(i, a, b) gacc_[i] += (b) - (a)
+#define FWW_CNT(i, x) gacc_[i] += (x)
 #else
 #define FWW_T(v)
+#define FWW_ACC(i, a, b)
+#define FWW_CNT(i, x)
 #endif
 // inclusive sum over the lanes 0..w of a mask's 2^LOGT lanes
 template <int LOGT>
@@ -2852,21 +1813,23 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
   const int64_t r = blockIdx.x;
   const int n = P.n, N = P.N, ni = N - n, W = P.W, LK = F.I64 / 64;
   const int nip = (ni + 63) & ~63;
+  TNCO_LDS volatile uint16_t* wls = (TNCO_LDS volatile uint16_t*)fww_smem;                 // [256] too-wide tensors, post-order
   // node i of the table: lo = left | right << 16; hi = parent | cost exponent << 16 | internal children (later: still to arrive) << 27
-  TNCO_LDS volatile uint32_t* lo = (TNCO_LDS volatile uint32_t*)fww_smem;                 // [nip]
+  TNCO_LDS volatile uint32_t* lo = (TNCO_LDS volatile uint32_t*)(fww_smem + 512);          // [nip]
   TNCO_LDS uint32_t* hi = (TNCO_LDS uint32_t*)(lo + nip);                                  // [nip] (atomic arrivals)
   TNCO_LDS volatile uint32_t* hiv = (TNCO_LDS volatile uint32_t*)hi;
-  TNCO_LDS volatile uint16_t* wls = (TNCO_LDS volatile uint16_t*)(hi + nip);               // [256] too-wide tensors, post-order
-  uint8_t* U = fww_smem + (size_t)nip * 8 + 512;                                           // the region used three times
+  uint8_t* U = fww_smem + 512 + (size_t)nip * 8;                                           // the region behind the table
   // ordering
   TNCO_LDS volatile uint64_t* key = (TNCO_LDS volatile uint64_t*)U;                        // [FWO_MAXW]
   TNCO_LDS volatile uint16_t* wnode = (TNCO_LDS volatile uint16_t*)(key + FWO_MAXW);       // [FWO_MAXW]
   TNCO_LDS volatile uint16_t* dep = wnode + FWO_MAXW;                                      // [FWO_MAXW]
-  // get_slices
-  TNCO_LDS volatile uint64_t* cache = (TNCO_LDS volatile uint64_t*)U;                      // [cap][T]
-  TNCO_LDS volatile uint8_t* nbig = (TNCO_LDS volatile uint8_t*)(cache + (size_t)cap * T);   // [64 T]
-  lds_vu32* ring = (lds_vu32*)(nbig + 64 * T);                                             // [256]
-  lds_vi32* pos = (lds_vi32*)(ring + 256);                                                 // [FWS_MAXNP]
+  // get_slices: over the node table and the region (the table is rebuilt from the registers afterwards)
+  TNCO_LDS uint64_t* Mlo = (TNCO_LDS uint64_t*)(fww_smem + 512);                            // [64]  shuffle steps < 64 that target a position
+  TNCO_LDS uint64_t* Mhi = Mlo + 64;                                                       // [128] ... steps 64..127 (the first T words: the picks, afterwards)
+  lds_vu32* ring = (lds_vu32*)(Mhi + 128);                                                 // [256]
+  lds_vu16* pos = (lds_vu16*)(ring + 256);                                                 // [FWS_MAXNP] candidate legs, ascending
+  TNCO_LDS volatile uint8_t* jL = (TNCO_LDS volatile uint8_t*)(pos + FWS_MAXNP);            // [FWS_MAXNP] the position step i swaps with
+  TNCO_LDS volatile uint64_t* cache = (TNCO_LDS volatile uint64_t*)(fww_smem + 512 + FWW_GS_FIXED);  // [cap][T] legs of the too-wide tensors
   // re-pricing
   TNCO_LDS volatile double* Pn = (TNCO_LDS volatile double*)U;                             // [nip]
   TNCO_LDS uint32_t* on = (TNCO_LDS uint32_t*)U;                                           // [nip][2] (the same memory)
@@ -2885,19 +1848,35 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
   const int mti0 = rs->mti, mtw0 = rs->mtw;
   const double cur = reinterpret_cast<const NodeRec*>(hb + (int64_t)(ni - 1) * P.BS)->partial;
   const double* w64 = F.width64 ? F.width64 + r * (int64_t)N : nullptr;
-  int4 hd[J];
-  uint32_t ce[J];
-  double wd[J];
+  // node i = j * 64 + lane of the table, as it stays in registers: tl = left | right << 16; th = parent | cost exponent
+  // << 16 | internal children << 27 (the root: parent 0xFFFF); iw = the spare header word (the cached float32 width)
+  uint32_t tl[J], th[J];
+  int32_t iw[J];
+  bool widej[J];
+  {
+    int4 hd[J];
+    uint32_t ce[J];
+    double wd[J];
 #pragma unroll
-  for (int j = 0; j < J; ++j) {
-    const int i = j * GW + lane;
-    hd[j] = make_int4(0, 0, 0, 0);
-    ce[j] = 0;
-    wd[j] = 0.0;
-    if (i < ni) {
-      hd[j] = *reinterpret_cast<const int4*>(hb + (int64_t)i * P.BS);
-      ce[j] = *reinterpret_cast<const uint32_t*>(hb + (int64_t)i * P.BS + 20);  // high word of the cached cost
-      if (!F.width_f32) wd[j] = w64[n + i];
+    for (int j = 0; j < J; ++j) {
+      const int i = j * GW + lane;
+      hd[j] = make_int4(0, 0, 0, 0);
+      ce[j] = 0;
+      wd[j] = 0.0;
+      if (i < ni) {
+        hd[j] = *reinterpret_cast<const int4*>(hb + (int64_t)i * P.BS);
+        ce[j] = *reinterpret_cast<const uint32_t*>(hb + (int64_t)i * P.BS + 20);  // high word of the cached cost
+        if (!F.width_f32) wd[j] = w64[n + i];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const uint32_t c = (hd[j].x >= n ? 1u : 0u) + (hd[j].y >= n ? 1u : 0u);
+      tl[j] = (uint32_t)hd[j].x | ((uint32_t)hd[j].y << 16);
+      th[j] = ((uint32_t)hd[j].z & 0xFFFFu) | (((ce[j] >> 20) & 0x7FFu) << 16) | (c << 27);
+      iw[j] = hd[j].w;
+      const double wv = F.width_f32 ? (double)__int_as_float(hd[j].w) : wd[j];
+      widej[j] = (j * GW + lane < ni) && wv > F.max_width;
     }
   }
   if (lane == 0) F.fastflag[r] = 0;
@@ -2913,21 +1892,23 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
     }
   };
   FWW_T(w1_);
-  // ---- the node table; the too-wide tensors (fw_order_kernel)
-  int32_t iw[J];  // (the spare header words: a kept re-slice rewrites whole headers)
+  // ---- the node table; the too-wide tensors
+  auto build_table = [&]() {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int i = j * GW + lane;
+      if (i < ni) {
+        lo[i] = tl[j];
+        hiv[i] = th[j];
+      }
+    }
+  };
+  build_table();
   int nw = 0;
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     const int i = j * GW + lane;
-    bool wide = false;
-    iw[j] = hd[j].w;
-    if (i < ni) {
-      const uint32_t c = (hd[j].x >= n ? 1u : 0u) + (hd[j].y >= n ? 1u : 0u);
-      lo[i] = (uint32_t)hd[j].x | ((uint32_t)hd[j].y << 16);
-      hiv[i] = ((uint32_t)hd[j].z & 0xFFFFu) | (((ce[j] >> 20) & 0x7FFu) << 16) | (c << 27);  // (the root: parent 0xFFFF)
-      const double wv = F.width_f32 ? (double)__int_as_float(hd[j].w) : wd[j];
-      wide = wv > F.max_width;
-    }
+    const bool wide = widej[j];
     const unsigned long long b = __ballot(wide);
     if (wide) {
       const int k = nw + __popcll(b & ((1ull << lane) - 1ull));
@@ -2980,7 +1961,8 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
     }
   }
   FWW_T(w2_);
-  // ---- get_slices (fw_slices_kernel; the ordering's keys are dead: the region is the legs' now)
+  // ---- get_slices (the ordering's keys and the node table are dead: their memory is the legs' now)
+  __builtin_amdgcn_wave_barrier();
   const uint8_t* legs = P.blocks + r * P.RB + P.WOFF;
   const int WS = P.WS;
   uint64_t pl[8];
@@ -3037,62 +2019,82 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
       c = (a & b) | (c & (a ^ b));
     }
   }
+  // The greedy pass (greedy/utils.hpp:62-101).  A tensor that is still too wide after the slices chosen so far has
+  // its candidate legs shuffled, sorted (stable) by their too-wide counts and sliced in that order until it fits.
+  // With uniform dims every slice narrows it by log2(d), so the NUMBER of picks is known up front (cnt - capw) and
+  // only the SET matters: the `need` legs with the largest (count, -shuffled position).
+  //   * by count: a radix select over the bit-sliced counters pl[] (the planes this lane holds for its mask word),
+  //     most significant plane first -- a few popcounts over the row per plane, whatever the number of picks;
+  //   * ties at the threshold count go by shuffled position, and only then is the permutation needed: std::shuffle
+  //     swaps a[i] with a[j_i], j_i <= i, for i = 1 .. np - 1 (two per variate, stl_algo.h:3706-3792).  Position x
+  //     is filled at step x and refilled by every later step i with j_i = x, which brings element i: the FINAL
+  //     occupant of x is the element of the LAST such step -- the highest bit of M[x], the set of those steps -- or,
+  //     if no later step touched x, what step x put there: x itself if j_x = x, else the occupant position j_x had
+  //     before step x (the same question with steps below x only).  Every lane resolves its own final position
+  //     that way: a chain of two or three LDS reads instead of one pass over all the swaps per tensor.
+  // The variates are always drawn (the generator's position is part of the state); a re-draw of
+  // uniform_int_distribution or the end of the generator's 624 words inside a shuffle runs the sequential shuffle.
+  uint64_t ns = 0ull;  // the new slices, word w (the same in the rows of lanes)
   {
-    // counters T g .. T g + T - 1 of word w -> T bytes (a nibble of plane bits is spread over the bytes of a word)
-    TNCO_LDS volatile uint32_t* d = (TNCO_LDS volatile uint32_t*)(nbig + w * 64 + T * g);
-#pragma unroll
-    for (int j = 0; j < T / 4; ++j) {
-      uint32_t c = 0;
-#pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const uint32_t nib = (uint32_t)(pl[p] >> (T * g + 4 * j)) & 0xFu;
-        c |= ((nib * 0x00204081u) & 0x01010101u) << p;
-      }
-      d[j] = c;
-    }
-  }
-  uint64_t ns = 0ull;  // the new slices, word w (the same in the four rows of lanes)
-  {
-    const double mdl = fw_wr(F, -F.log2d);
-    int j = 0;
-    while (j < nw) {
-      const int t = j + g;
-      uint64_t mm = 0ull;
+#ifdef TNCO_FWW_PROF
+    unsigned long long gacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    const int capw = (int)floor(F.max_width / F.log2d);  // legs a tensor may keep
+    const int nplanes = 32 - __clz(nw | 1);              // (a count is at most nw)
+    // The list is scanned in groups of TPL tensors (one per row of lanes).  A group's legs are read ONCE -- from
+    // LDS, or, beyond `cap` tensors, from memory with the next group's request in flight -- and after a tensor of
+    // the group was sliced the rest of the group is re-tested from the registers.
+    auto load_group = [&](int t0) -> uint64_t {
+      const int t = t0 + g;
+      uint64_t x = 0ull;
       if (t < nw) {
-        if (t < cap) mm = cache[t * T + w];
-        else if (has) mm = *reinterpret_cast<const uint64_t*>(legs + (int64_t)((int)wls[t] - n) * WS + 8 * w);
+        if (t < cap) x = cache[t * T + w];
+        else if (has) x = *reinterpret_cast<const uint64_t*>(legs + (int64_t)((int)wls[t] - n) * WS + 8 * w);
       }
+      return x;
+    };
+    uint64_t mnext = load_group(0);
+    int j = 0, gdone = -1;  // the group [j, j + TPL); its rows <= gdone are dealt with
+    uint64_t mm = 0ull;
+    bool fresh = true;
+    while (j < nw) {
+      FWW_T(g0_);
+      if (fresh) {
+        mm = mnext;
+        if (j + TPL < nw) mnext = load_group(j + TPL);
+        gdone = -1;
+        fresh = false;
+      }
+      const int t = j + g;
       const uint64_t sx = mm & ~ns;
       const uint32_t cnt = gsum<LOGT>((uint32_t)__popcll(sx));
-      const bool wide = t < nw && fw_wr(F, F.log2d * (double)cnt) > F.max_width;
+      const bool wide = t < nw && g > gdone && fw_wr(F, F.log2d * (double)cnt) > F.max_width;
       const unsigned long long bal = __ballot(wide);
       if (bal == 0ull) {
         j += TPL;
+        fresh = true;
+        FWW_T(g1a_);
+        FWW_ACC(0, g0_, g1a_);
         continue;
       }
       const int gs = (__ffsll(bal) - 1) >> LOGT;
-      j += gs + 1;
-      const uint64_t sxw = fws_shfl64(sx, T * gs + w);
-      double sw = fw_wr(F, F.log2d * (double)(uint32_t)__shfl((int)cnt, T * gs));
-      const uint64_t cand = sxw & ~skip;
+      gdone = gs;
+      FWW_T(g1_);
+      FWW_ACC(0, g0_, g1_);
+      FWW_CNT(6, 1);
+      const uint64_t cand = fws_shfl64(sx, T * gs + w) & ~skip;
+      const int cnts = __builtin_amdgcn_readlane((int)cnt, T * gs);
       const uint32_t mine = (uint32_t)__popcll(cand);
       const uint32_t incl = fws_scan<LOGT>(mine, lane);
       const int np = __builtin_amdgcn_readlane((int)incl, T - 1);
-      if (g == 0) {
-        uint32_t o = incl - mine;
-        uint64_t x = cand;
-        while (x) {
-          const int b = __ffsll((unsigned long long)x) - 1;
-          pos[o++] = w * 64 + b;
-          x &= x - 1;
-        }
-      }
-      int src0 = lane, src1 = lane + 64;
+      int need = cnts - capw;
+      need = need < np ? need : np;  // (fewer candidates than that: all of them, greedy/utils.hpp:86-100 runs out)
+      // -- std::shuffle's variates: lane k draws the pair of swaps k
+      const int nd = np >> 1, base = np & 1;
+      bool fast = true;
+      uint32_t p0 = 0, p1 = 0;
       if (np >= 2) {
-        const uint32_t nd = (uint32_t)np >> 1;
-        bool fast = rng.ensure(nd);
-        uint32_t p0 = 0, p1 = 0;
-        const int base = (np & 1) ? 1 : 0;
+        fast = rng.ensure((uint32_t)nd);
         if (fast) {
           const uint32_t raw = rng.peek((uint32_t)lane);
           const uint32_t i0 = (uint32_t)(base + 2 * lane);
@@ -3100,48 +2102,132 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
           const uint64_t product = (uint64_t)raw * (uint64_t)range;
           const uint32_t low = (uint32_t)product;
           bool rej = false;
-          if ((uint32_t)lane < nd && low < range) rej = low < (0u - range) % range;
+          if (lane < nd && low < range) rej = low < (0u - range) % range;
           if (__any(rej)) {
             fast = false;
           } else {
             const uint32_t x = (uint32_t)(product >> 32);
             p0 = x / (i0 + 2u);
             p1 = x - p0 * (i0 + 2u);
-            rng.advance(nd);
+            rng.advance((uint32_t)nd);
           }
         }
-        if (fast) {
-          const bool two = np > 64;
-          for (int k = (int)nd - 1; k >= 0; --k) {
-            const int j1 = __builtin_amdgcn_readlane((int)p1, k), j0 = __builtin_amdgcn_readlane((int)p0, k);
-            const int i = base + 2 * k;
-            src0 = src0 == i + 1 ? j1 : (src0 == j1 ? i + 1 : src0);
-            src0 = src0 == i ? j0 : (src0 == j0 ? i : src0);
-            if (two) {
-              src1 = src1 == i + 1 ? j1 : (src1 == j1 ? i + 1 : src1);
-              src1 = src1 == i ? j0 : (src1 == j0 ? i : src1);
+      }
+      FWW_T(g2_);
+      FWW_ACC(1, g1_, g2_);
+      // -- by count
+      uint64_t alive = cand, taken = 0ull;
+#pragma unroll
+      for (int p = 7; p >= 0; --p) {
+        if (p < nplanes) {
+          const uint64_t hi = alive & pl[p];
+          const int c = __builtin_amdgcn_readfirstlane((int)gsum<LOGT>((uint32_t)__popcll(hi)));
+          if (c >= need) {
+            alive = hi;
+          } else {
+            taken |= hi;
+            need -= c;
+            alive &= ~pl[p];
+          }
+        }
+      }
+      const int calive = __builtin_amdgcn_readfirstlane((int)gsum<LOGT>((uint32_t)__popcll(alive)));
+      FWW_T(g3_);
+      FWW_ACC(2, g2_, g3_);
+      FWW_CNT(8, np);
+      if (need >= calive && fast) {  // the whole tie group (need == calive; need == 0 == np: nothing)
+        ns |= taken | alive;
+        continue;
+      }
+      FWW_CNT(7, 1);
+      // -- by shuffled position: the candidates in ascending order (row g lists bits T g .. T g + T - 1 of its word)
+      {
+        const uint64_t part = (T == 64) ? cand : ((cand >> (T * g)) & ((1ull << (T & 63)) - 1ull));
+        uint32_t o = (incl - mine) + ((T == 64) ? 0u : (uint32_t)__popcll(cand & ((1ull << ((T * g) & 63)) - 1ull)));
+        uint64_t x = part;
+        while (x) {
+          const int b = __ffsll((unsigned long long)x) - 1;
+          pos[o++] = (uint16_t)(w * 64 + ((T == 64) ? 0 : T * g) + b);
+          x &= x - 1;
+        }
+      }
+      FWW_T(g4_);
+      FWW_ACC(3, g3_, g4_);
+      int e0 = lane, e1 = lane + 64;  // the element (candidate number) at final position lane, lane + 64
+      if (fast) {
+        const bool two = np > 64;
+        Mlo[lane] = 0ull;
+        Mhi[lane] = 0ull;
+        if (two) Mhi[lane + 64] = 0ull;
+        if (lane == 0) jL[0] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nd) {
+          const uint32_t i0 = (uint32_t)(base + 2 * lane), i1 = i0 + 1u;
+          jL[i0] = (uint8_t)p0;
+          jL[i1] = (uint8_t)p1;
+          if (p0 < i0) __hip_atomic_fetch_or(i0 < 64u ? &Mlo[p0] : &Mhi[p0], 1ull << (i0 & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (p1 < i1) __hip_atomic_fetch_or(i1 < 64u ? &Mlo[p1] : &Mhi[p1], 1ull << (i1 & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __builtin_amdgcn_wave_barrier();
+        TNCO_LDS volatile uint64_t* MloV = (TNCO_LDS volatile uint64_t*)Mlo;
+        TNCO_LDS volatile uint64_t* MhiV = (TNCO_LDS volatile uint64_t*)Mhi;
+        auto occupant = [&](int f) -> int {
+          int x = f, s = 128;
+          for (;;) {  // (x falls with every round)
+            uint64_t mh = two ? MhiV[x] : 0ull, ml = x < 64 ? MloV[x] : 0ull;
+            if (s <= 64) {
+              mh = 0ull;
+              ml &= (s == 64) ? ~0ull : ((1ull << s) - 1ull);
+            } else if (s < 128) {
+              mh &= (1ull << (s - 64)) - 1ull;
             }
+            if (mh) return 127 - __clzll((long long)mh);
+            if (ml) return 63 - __clzll((long long)ml);
+            const int jx = jL[x];
+            if (jx == x) return x;
+            s = x;
+            x = jx;
           }
-        } else {
-          fw_shuffle_lds<6>(rng, pos, np, lane == 0);
-        }
+        };
+        if (lane < np) e0 = occupant(lane);
+        if (lane + 64 < np) e1 = occupant(lane + 64);
+      } else if (np >= 2) {
+        __builtin_amdgcn_wave_barrier();
+        fw_shuffle_lds<6>(rng, pos, np, lane == 0);  // (in place: position f holds its leg)
       }
-      const int xp0 = lane < np ? (int)pos[src0] : 0, xp1 = lane + 64 < np ? (int)pos[src1] : 0;
-      uint32_t k0 = lane < np ? (((uint32_t)nbig[xp0] << 16) | (0xFFFFu - (uint32_t)lane)) : 0u;
-      uint32_t k1 = lane + 64 < np ? (((uint32_t)nbig[xp1] << 16) | (0xFFFFu - (uint32_t)(lane + 64))) : 0u;
-      for (int taken = 0; taken < np; ++taken) {
-        const uint32_t best = gmax<6>(k0 > k1 ? k0 : k1);
-        const int qb = (int)(0xFFFFu - (best & 0xFFFFu));
-        const int xpos = __shfl(qb >= 64 ? xp1 : xp0, qb & 63);
-        if (lane == (qb & 63)) {
-          if (qb >= 64) k1 = 0u; else k0 = 0u;
-        }
-        if (w == (xpos >> 6)) ns |= 1ull << (xpos & 63);
-        sw = fw_wr(F, sw + mdl);
-        if (sw <= F.max_width) break;
-      }
+      __builtin_amdgcn_wave_barrier();
+      FWW_T(g5_);
+      FWW_ACC(4, g4_, g5_);
+      // the first `need` members of the tie group in shuffled order
+      const bool shuffled_in_place = !fast;
+      const int leg0 = lane < np ? (int)pos[shuffled_in_place ? lane : e0] : 0;
+      const int leg1 = lane + 64 < np ? (int)pos[shuffled_in_place ? lane + 64 : e1] : 0;
+      const uint64_t aw0 = fws_shfl64(alive, leg0 >> 6), aw1 = fws_shfl64(alive, leg1 >> 6);
+      const bool in0 = lane < np && ((aw0 >> (leg0 & 63)) & 1ull), in1 = lane + 64 < np && ((aw1 >> (leg1 & 63)) & 1ull);
+      const unsigned long long b0 = __ballot(in0), b1 = __ballot(in1);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      const bool pick0 = in0 && (int)__popcll(b0 & below) < need;
+      const bool pick1 = in1 && (int)(__popcll(b0) + __popcll(b1 & below)) < need;
+      if (lane < T) Mhi[lane] = 0ull;
+      __builtin_amdgcn_wave_barrier();
+      if (pick0) __hip_atomic_fetch_or(&Mhi[leg0 >> 6], 1ull << (leg0 & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (pick1) __hip_atomic_fetch_or(&Mhi[leg1 >> 6], 1ull << (leg1 & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __builtin_amdgcn_wave_barrier();
+      ns |= taken | ((TNCO_LDS volatile uint64_t*)Mhi)[w];
+      __builtin_amdgcn_wave_barrier();
+      FWW_T(g6_);
+      FWW_ACC(5, g5_, g6_);
     }
+#ifdef TNCO_FWW_PROF
+    if (lane == 0) {
+      for (int i = 0; i < 9; ++i) atomicAdd(&g_fww_prof[12 + i], gacc_[i]);
+      atomicAdd(&g_fww_prof[21], (unsigned long long)nw);
+    }
+#endif
   }
+  __builtin_amdgcn_wave_barrier();
+  build_table();  // (get_slices used its memory)
+  __builtin_amdgcn_wave_barrier();
   FWW_T(w4_);
   // ---- the indices that changed, with the starts of their paths (the region is the re-pricing's now).  Their
   // holders are requested first -- up to four per lane in one flight -- and only then the stores of this step are
@@ -3218,7 +2304,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
   }
   const int dbase = __popcll(plus64) - __popcll(minus64);
   FWW_T(w5_);
-  // ---- the re-priced costs (fw_tree_kernel): path masks cleared, arrival counters = internal children
+  // ---- the re-priced costs: path masks cleared, arrival counters = internal children
   uint32_t startmask = 0;
   bool bad = false;
 #pragma unroll
@@ -3369,7 +2455,7 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_B_WAVES) void fw_reslice_b_ker
 #pragma unroll
     for (int k = 0; k < K; ++k) ns.w[k] = prop[v.widx(k)];
     __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (need_rec) {  // (no walk kernel ran -- fw_order_kernel / fw_tree_kernel: the post-order of this replica, here)
+    if (need_rec) {  // (no walk kernel ran: the post-order of this replica, here)
       const FwStack st{nullptr, nullptr, 0};
       fw_traverse<LOG2L, K, HYPER>(P, F, v, F.width64 ? F.width64 + r * (int64_t)N : nullptr, sc.rec, nullptr, lane0, gbase,
                                    st, sc.gstk);

@@ -23,18 +23,18 @@ struct FwParams {
   int32_t* scratch_i;       // [R][fw_scratch_ints]  see FwScratch
   double* scratch_d;        // [R][2N]        see FwScratch
   double* width64;          // [R][N] widths of the internal nodes when width_type is float64
-  int32_t* nwide;           // [R] fw_walk_kernel -> fw_reslice_kernel: too-wide tensors listed (-1: no slices, nothing to do)
+  int32_t* nwide;           // [R] too-wide tensors listed by fw_walk2_kernel for fw_reslice_kernel; from fw_wave_kernel: -1 no slices,
+                            //     nothing to do; -2 left to fw_reslice_a_kernel's own traverse; -3 get_slices done
   int32_t* nwfront;         // [R] ... how many of them at the front of the list (fw_walk2_kernel: the rest at its end)
-  // the re-slice re-priced from the OLD costs (fw_tree_kernel, or fw_delta_kernel after a walk): usable when fast_ok
-  int32_t fast_ok;          // uniform power-of-two dims, float64 cost, no sparse legs, no hyper-indices, <= 1024 tensors
-  int32_t tree_ok;          // ... and no too-wide leaf, split layout: the re-slice without a walk (fw_order_kernel, fw_tree_kernel)
+  // the re-slice of a replica in one wavefront, its cost cache re-priced from the OLD costs (fw_wave_kernel)
+  int32_t fast_ok;          // this call runs it: uniform power-of-two dims, float64 cost, no sparse legs, no hyper-indices,
+                            // <= 1024 tensors, no too-wide leaf, split layout; few fall-backs lately (tnco_hip_run_fw)
   const int32_t* holder2;   // [I64][2] the (one or two) tensors holding an index, -1: none / index not supported
-  int32_t* fastflag;        // [R] 1: fw_tree_kernel / fw_delta_kernel has done this replica's rebuild (+ commit)
-  unsigned long long* slowstat;  // [4] replicas the re-pricing has left to the full rebuild since the host last looked; of those (fw_wave_kernel)
+  int32_t* fastflag;        // [R] 1: fw_wave_kernel has done this replica's rebuild (+ commit)
+  unsigned long long* slowstat;  // [4] replicas the re-pricing has left to the full rebuild since the host last looked; of those
                                  //     [1] too many / too deep / too leggy too-wide tensors, [2] too many changed indices or an index
                                  //     held otherwise, [3] a cost outside a double's powers of two
-  uint64_t* delta_scr;      // [R][64] fw_reslice_a_kernel -> fw_tree_kernel: the changed indices and the starts of their paths;
-                            //          fw_delta_kernel: holders of the changed indices (u16[128]), second count-vector words
+  uint64_t* delta_scr;      // [R][64] word 0: indices the last proposal changed (0xFFFFFFFF: not re-priced), for tnco_hip_get_reslice_info
   int32_t* status;          // [R] runtime problems (1: candidate legs beyond the scratch; cannot happen
                             //     since the scratch holds every index)
 };

@@ -25,13 +25,12 @@ struct tnco_hip_ctx {
   int log2l = 2, K = 1, L = 4;  // lanes per replica = L, mask words per lane = K
   bool hyper = false, generic = false;
   bool fw = false;  // finite-width optimizer
-  // the re-slice by re-pricing (fw_delta_kernel) pays while few replicas fall back to the full rebuild: the
-  // mode of a tnco_hip_run_fw call follows the fall-backs counted during the previous one
-  bool fw_delta_capable = false, fw_delta_on = false;
+  // the re-slice of a replica in one wavefront (fw_wave_kernel, the cost cache re-priced) pays while few replicas fall
+  // back to the full rebuild: the form of a tnco_hip_run_fw call follows the fall-backs counted during the previous one
+  bool fw_wave_capable = false, fw_wave_on = false;
   int fw_wave_maxnp = 128;  // ... candidate legs of one tensor it handles (test knob TNCO_HIP_FWS_MAXNP)
-  bool fw_fused = false;   // ... and the whole re-slice of a replica in one wavefront (fw_wave_kernel)
-  int fw_wave_slices = 0;  // get_slices by fw_slices_kernel (one wavefront per replica): listed tensors it keeps in LDS; 0: off
-  int64_t fw_delta_reslices = 0;  // re-slices launched in that mode since the count was read
+  int fw_wave_cap = 0;      // ... too-wide tensors whose legs it keeps in LDS (fww_cap; test knob TNCO_HIP_FWS_CAP)
+  int64_t fw_wave_reslices = 0;  // re-slices launched in that form since the count was read
   int fw_single_calls = 0;        // calls in the other mode since the last probe
   int fw_probe_wait = 4;          // ... before the next probe (doubles after a probe that failed)
   // tnco_hip_get_fw_stats: [0] replica re-slices launched in the re-pricing form, [1] of those left to the full rebuild,
@@ -223,7 +222,3 @@ template <int LOG2L, int K>
 void launch_fw_move_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, int tail_last);
 template <int LOG2L, int K>
 void launch_fw_reslice_lk(tnco_hip_ctx* h, int prewalked);
-template <int LOG2L, int K>
-bool fw_tree_prepare_lk(tnco_hip_ctx* h);
-template <int LOG2L, int K>
-void launch_fw_order_lk(tnco_hip_ctx* h);

@@ -96,7 +96,7 @@ void launch_fw_move_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, in
   const int gpb = 256 >> LOG2L, gpb_staged = SWT >> LOG2L;
   dim3 grid((unsigned)((h->P.R + gpb - 1) / gpb)), grid_staged((unsigned)((h->P.R + gpb_staged - 1) / gpb_staged));
   const bool maxnew = h->F.max_new_slices > 0;
-  if (!maxnew && !std::getenv("TNCO_HIP_FW_UNSTAGED")) {  // the staged state machine (sa_sweep.h, FW = true)
+  if (!maxnew) {  // the staged state machine (sa_sweep.h, FW = true)
 #define TNCO_FW_STAGED(HY, GE)                                                                                          \
   hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, HY, GE, true>), grid_staged, dim3(SWT), 0, h->stream, h->P, betas, n_steps, \
                      prob_kind, h->F, tail_last, 0)
@@ -118,87 +118,39 @@ void launch_fw_move_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, in
   }
 #undef TNCO_FW_MOVE
 }
-// (every translation unit has its own copy of the static kernels: the attribute is set where they are launched)
-template <int LOG2L, int K>
-bool fw_tree_prepare_lk(tnco_hip_ctx* h) {
-  bool ok = hipFuncSetAttribute((const void*)fw_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess;
-#define TNCO_FWT(JJ, GG) ok = ok && hipFuncSetAttribute((const void*)fw_tree_kernel<JJ, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess
-  TNCO_FWT(2, 64); TNCO_FWT(4, 64); TNCO_FWT(6, 64); TNCO_FWT(9, 64); TNCO_FWT(12, 64); TNCO_FWT(16, 64);
-#undef TNCO_FWT
-  if (!ok) {
-    (void)hipGetLastError();
-    return false;
-  }
-  return 4 * fwt_lds_bytes(h->P.n) <= 160 * 1024 - 256 && 4 * fwo_lds_bytes(h->P.n) <= 160 * 1024 - 256;
-}
-template <int LOG2L, int K>
-void launch_fw_order_lk(tnco_hip_ctx* h) {
-  hipLaunchKernelGGL(fw_order_kernel, dim3((unsigned)((h->P.R + 3) / 4)), dim3(256), 4 * fwo_lds_bytes(h->P.n), h->stream, h->P, h->F);
-}
 template <int LOG2L, int K>
 void launch_fw_reslice_lk(tnco_hip_ctx* h, int prewalked) {
   const int gpb = 256 >> LOG2L;
   dim3 grid((unsigned)((h->P.R + gpb - 1) / gpb));
 #ifndef TNCO_PROFILE
-  if (h->F.fast_ok && prewalked == 3 && !h->hyper) {  // no walk: get_slices from fw_order_kernel's list (fw_slices_kernel) | fw_tree_kernel | end of the sweep
-    if (h->fw_fused) {  // order | get_slices | re-pricing of one replica in one wavefront, then the two clean-up launches
-      // lanes per leg mask: the L * K words of this translation unit's networks fit 16, 32 or 64 lanes
-      constexpr int LKW = (1 << LOG2L) * K, LT = LKW <= 16 ? 4 : (LKW <= 32 ? 5 : 6);
-      const size_t lb = fww_lds_bytes(h->P.n, h->fw_wave_slices, 1 << LT);
-      const int need = (h->P.n - 1 + 63) / 64;
-#define TNCO_FWW(JJ) hipLaunchKernelGGL((fw_wave_kernel<JJ, LT>), dim3((unsigned)h->P.R), dim3(64), lb, h->stream, h->P, h->F, h->fw_wave_slices, h->fw_wave_maxnp)
-      if (need <= 2) TNCO_FWW(2); else if (need <= 4) TNCO_FWW(4); else if (need <= 6) TNCO_FWW(6);
-      else if (need <= 9) TNCO_FWW(9); else if (need <= 12) TNCO_FWW(12); else TNCO_FWW(16);
+  if (prewalked == 3) {
+    // the re-slice of a replica in one wavefront (order | get_slices | re-pricing), then the two clean-up launches:
+    // get_slices of the replicas it has left alone (usually none: 5 us of an empty launch), the full rebuild of those
+    // and of the ones it could not re-price + the end of the sweep for everybody
+    // lanes per leg mask: the L * K words of this translation unit's networks fit 16, 32 or 64 lanes
+    constexpr int LKW = (1 << LOG2L) * K, LT = LKW <= 16 ? 4 : (LKW <= 32 ? 5 : 6);
+    const size_t lb = fww_lds_bytes(h->P.n, 1 << LT);
+    const int need = (h->P.n - 1 + 63) / 64;
+#define TNCO_FWW(JJ) hipLaunchKernelGGL((fw_wave_kernel<JJ, LT>), dim3((unsigned)h->P.R), dim3(64), lb, h->stream, h->P, h->F, h->fw_wave_cap, h->fw_wave_maxnp)
+    if (need <= 2) TNCO_FWW(2); else if (need <= 4) TNCO_FWW(4); else if (need <= 6) TNCO_FWW(6);
+    else if (need <= 9) TNCO_FWW(9); else if (need <= 12) TNCO_FWW(12); else TNCO_FWW(16);
 #undef TNCO_FWW
-      hipLaunchKernelGGL((fw_reslice_a_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, 2);
-      hipLaunchKernelGGL((fw_reslice_b_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, 1);
-#ifdef TNCO_FWW_PROF
-      {
-        static int wcalls = 0;
-        if (++wcalls % 80 == 0) {
-          unsigned long long st[12];
-          (void)hipDeviceSynchronize();
-          if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_fww_prof), sizeof(st)) == hipSuccess && st[8]) {
-            const double d = (double)st[8];
-            std::fprintf(stderr, "fw_wave after %d launches: cycles per replica: loads %.0f, ordering %.0f, legs + counts %.0f, greedy pass %.0f, "
-                         "change list %.0f, marks + prices %.0f, partial sums %.0f, commit %.0f\n", wcalls, st[0] / d, st[1] / d, st[2] / d, st[3] / d,
-                         st[4] / d, st[5] / d, st[6] / d, st[7] / d);
-          }
-        }
-      }
-#endif
-      return;
-    }
-    if (h->fw_wave_slices > 0 && h->P.W <= 16)
-      hipLaunchKernelGGL(fw_slices_kernel, dim3((unsigned)h->P.R), dim3(64), fws_lds_bytes(h->fw_wave_slices), h->stream, h->P, h->F,
-                         h->fw_wave_slices, h->fw_wave_maxnp);
-    // (the replicas fw_slices_kernel has left alone, usually none: 5 us of an empty launch)
     hipLaunchKernelGGL((fw_reslice_a_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, 2);
-    {
-      // (one wavefront per replica.  Two replicas per wavefront, 32 lanes each -- fw_tree_kernel<J, 32> -- measured
-      //  SLOWER on config 5, 0.57 against 0.44 ms per launch: the kernel waits on its LDS chain, not on issue slots,
-      //  and half as many wavefronts hide half as much of it; profiles/experiments.md)
-      const int gw = 64, per_block = 4;
-      const dim3 tg((unsigned)((h->P.R + per_block - 1) / per_block));
-      const size_t tb = (size_t)per_block * fwt_lds_bytes(h->P.n);
-      const int need = (h->P.n - 1 + gw - 1) / gw;
-#define TNCO_FWT(JJ, GG) hipLaunchKernelGGL((fw_tree_kernel<JJ, GG>), tg, dim3(256), tb, h->stream, h->P, h->F)
-      if (need <= 2) TNCO_FWT(2, 64); else if (need <= 4) TNCO_FWT(4, 64); else if (need <= 6) TNCO_FWT(6, 64);
-      else if (need <= 9) TNCO_FWT(9, 64); else if (need <= 12) TNCO_FWT(12, 64); else TNCO_FWT(16, 64);
-#undef TNCO_FWT
-    }
     hipLaunchKernelGGL((fw_reslice_b_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, 1);
-#ifdef TNCO_FWS_PROF
+#ifdef TNCO_FWW_PROF
     {
-      static int scalls = 0;
-      if (++scalls % 80 == 0) {
-        unsigned long long st[12];
+      static int wcalls = 0;
+      if (++wcalls % 80 == 0) {
+        unsigned long long st[24];
         (void)hipDeviceSynchronize();
-        if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_fws_prof), sizeof(st)) == hipSuccess && st[8]) {
+        if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_fww_prof), sizeof(st)) == hipSuccess && st[8]) {
           const double d = (double)st[8];
-          std::fprintf(stderr, "fw_slices after %d launches: cycles per replica: list + counts %.0f, table %.0f, greedy pass %.0f (scan %.0f, positions %.0f, "
-                       "generator %.0f, shuffle %.0f, keys + picks %.0f), whole %.0f; %.1f too-wide tensors, %.1f sliced\n", scalls, st[0] / d, st[1] / d, st[2] / d,
-                       st[3] / d, st[4] / d, st[5] / d, st[6] / d, st[7] / d, st[11] / d, st[10] / d, st[9] / d);
+          std::fprintf(stderr, "fw_wave after %d launches: cycles per replica: loads %.0f, ordering %.0f, legs + counts %.0f, greedy pass %.0f, "
+                       "change list %.0f, marks + prices %.0f, partial sums %.0f, commit %.0f\n", wcalls, st[0] / d, st[1] / d, st[2] / d, st[3] / d,
+                       st[4] / d, st[5] / d, st[6] / d, st[7] / d);
+          std::fprintf(stderr, "   greedy pass: scan %.0f, draws %.0f, select by count %.0f, candidate list %.0f, permutation %.0f, tie picks %.0f; per replica "
+                       "%.1f too-wide tensors, %.1f still too wide, %.1f of them with a split tie group, %.1f candidate legs each\n", st[12] / d, st[13] / d,
+                       st[14] / d, st[15] / d, st[16] / d, st[17] / d, st[21] / d, st[18] / d, st[19] / d, st[18] ? (double)st[20] / st[18] : 0.0);
         }
       }
     }
@@ -213,35 +165,6 @@ void launch_fw_reslice_lk(tnco_hip_ctx* h, int prewalked) {
           std::fprintf(stderr, "fw_reslice_a after %d launches: cycles per wavefront: generator init %.0f, too-wide counts %.0f, greedy pass %.0f; "
                        "of it scan %.0f, positions %.0f, shuffle %.0f, keys + picks %.0f\n", acalls, (double)st[0] / st[3], (double)st[1] / st[3],
                        (double)st[2] / st[3], (double)st[4] / st[3], (double)st[5] / st[3], (double)st[6] / st[3], (double)st[7] / st[3]);
-      }
-    }
-#endif
-#ifdef TNCO_FWT_PROF
-    static int calls = 0;
-    if (++calls % 40 == 0) {
-      unsigned long long st[8];
-      (void)hipStreamSynchronize(h->stream);
-      if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_fwt_prof), sizeof(st)) == hipSuccess && st[5])
-        std::fprintf(stderr, "fw_tree after %d re-slices: per replica cycles setup %.0f load %.0f loop %.0f commit %.0f; %.1f iterations, "
-                     "%.2f kept, %.1f changed indices\n", calls, (double)st[0] / st[5], (double)st[1] / st[5], (double)st[2] / st[5],
-                     (double)st[3] / st[5], (double)st[4] / st[5], (double)st[6] / st[5], (double)st[7] / st[5]);
-    }
-#endif
-    return;
-  }
-  if (h->F.fast_ok && prewalked == 2 && !h->hyper) {  // get_slices | re-pricing of the old costs | end of the sweep
-    hipLaunchKernelGGL((fw_reslice_a_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, prewalked);
-    hipLaunchKernelGGL(fw_delta_kernel, dim3((unsigned)((h->P.R + FWD_LANES - 1) / FWD_LANES)), dim3(64), 0, h->stream, h->P, h->F);
-    hipLaunchKernelGGL((fw_reslice_b_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, 0);
-#ifdef TNCO_FW_DELTA_STATS  // (diagnostic build: the counters of this translation unit, every 40 re-slices)
-    static int calls = 0;
-    if (++calls % 40 == 0) {
-      unsigned long long st[80];
-      (void)hipStreamSynchronize(h->stream);
-      if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_fwd_stats), sizeof(st)) == hipSuccess) {
-        std::fprintf(stderr, "fw_delta after %d re-slices: changed indices:", calls);
-        for (int i = 0; i <= 40; ++i) std::fprintf(stderr, " %d:%llu", i, st[i]);
-        std::fprintf(stderr, " | full rebuild: unsupported index %llu, > %d changed %llu, cost not 2^k %llu\n", st[70], FWD_MAXD, st[71], st[72]);
       }
     }
 #endif
@@ -263,5 +186,3 @@ template void launch_fw_init_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const F
 template void launch_fw_check_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const BuildArgs&, int, double, int32_t*);
 template void launch_fw_move_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const double*, int64_t, int, int);
 template void launch_fw_reslice_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, int);
-template bool fw_tree_prepare_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*);
-template void launch_fw_order_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*);

@@ -116,14 +116,9 @@ void launch_fw_init(tnco_hip_ctx* h, const FwInitArgs& a) {
 #undef CALL_FWI
 }
 
-// (one lane per replica: the same kernel whatever the lane layout of the handle)
-void launch_fw_walk(tnco_hip_ctx* h, int two_ended) {
-  if (two_ended) {  // two lanes per replica, from both ends of the post-order
-    hipLaunchKernelGGL(fw_walk2_kernel, dim3((unsigned)((h->P.R + 127) / 128)), dim3(256), 0, h->stream, h->P, h->F);
-    return;
-  }
-  hipLaunchKernelGGL(fw_walk_kernel, dim3((unsigned)((h->P.R + FW_WALK_PER_BLOCK - 1) / FW_WALK_PER_BLOCK)), dim3(256), 0, h->stream,
-                     h->P, h->F);
+// (two lanes per replica, from both ends of the post-order: the same kernel whatever the lane layout of the handle)
+void launch_fw_walk(tnco_hip_ctx* h) {
+  hipLaunchKernelGGL(fw_walk2_kernel, dim3((unsigned)((h->P.R + 127) / 128)), dim3(256), 0, h->stream, h->P, h->F);
 }
 
 // n_steps sweeps of the finite-width optimizer: [moves up to and including the next re-slicing
@@ -147,26 +142,17 @@ hipError_t launch_fw_run(tnco_hip_ctx* h, const double* betas, int64_t n_steps, 
     });
     if (e != hipSuccess) return e;
     if (reslice) {
-      // the walk over the tree as a kernel of its own (one lane per replica), unless the tree is too
-      // large for its stack fields or the test knob TNCO_HIP_FW_STACK=0 asks for the link-walking path
-      int prewalked = (h->P.N <= 8192 && h->F.stack_cap > 0 && h->F.nwide != nullptr) ? 1 : 0;
-      if (prewalked && h->F.nwfront != nullptr && !h->F.leaf_wide) prewalked = 2;
-      if (prewalked == 2 && h->F.fast_ok && h->F.tree_ok && !h->hyper) prewalked = 3;  // no walk at all (fw_order_kernel, fw_tree_kernel)
-      if (prewalked == 3 && h->fw_fused) {
-        // (fw_wave_kernel lists the too-wide tensors itself: launch_fw_reslice_lk)
-      } else if (prewalked == 3) {
-        e = h->timed(TNCO_KIND_FW_WALK, [&]() {
-#define CALL_FWO(LL, KK) launch_fw_order_lk<LL, KK>(h)
-          DISPATCH_LK(h, CALL_FWO)
-#undef CALL_FWO
-        });
-        if (e != hipSuccess) return e;
-      } else if (prewalked) {
-        e = h->timed(TNCO_KIND_FW_WALK, [&]() { launch_fw_walk(h, prewalked == 2); });
+      // the wavefront form lists the too-wide tensors itself; the general form gets them (and the post-order) from a
+      // walk kernel, unless the tree is too large for its stack fields, a leaf is too wide, or the test knob
+      // TNCO_HIP_FW_STACK=0 asks for the link-walking traverse inside fw_reslice_kernel
+      const bool wave = h->F.fast_ok != 0;
+      const int prewalked = wave ? 3 : ((h->P.N <= 8192 && h->F.stack_cap > 0 && !h->F.leaf_wide) ? 2 : 0);
+      if (prewalked == 2) {
+        e = h->timed(TNCO_KIND_FW_WALK, [&]() { launch_fw_walk(h); });
         if (e != hipSuccess) return e;
       }
-      if (count_reslices && h->F.fast_ok && prewalked >= 2 && !h->hyper) h->fw_delta_reslices += 1;
-      h->fw_stats[h->F.fast_ok && prewalked >= 2 && !h->hyper ? 0 : 5] += h->P.R;
+      if (count_reslices && wave) h->fw_wave_reslices += 1;
+      h->fw_stats[wave ? 0 : 5] += h->P.R;
       e = h->timed(TNCO_KIND_FW_RESLICE, [&]() {
 #define CALL_FWS(LL, KK) launch_fw_reslice_lk<LL, KK>(h, prewalked)
         DISPATCH_LK(h, CALL_FWS)
@@ -597,7 +583,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     if (al > 0) P.BS = (P.BS + al - 1) / al * al;
   }
   P.WS = P.BS; P.WOFF = 32; P.RB = (int64_t)(n - 1) * P.BS;
-  if (fw && !h->hyper && !std::getenv("TNCO_HIP_FW_UNIFIED")) {  // split layout (sa_kernels.h, Params)
+  if (fw && !h->hyper) {  // split layout (sa_kernels.h, Params)
     P.BS = 32;
     P.WS = (8 * W + 63) / 64 * 64;
     P.WOFF = ((n - 1) * 32 + 127) / 128 * 128;
@@ -840,15 +826,17 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     HIP_TRY(h->alloc(&F.scratch_i, R * fw_scratch_ints(N, F.I64)));
     HIP_TRY(h->alloc(&F.scratch_d, R * 2 * (int64_t)N));
     HIP_TRY(h->alloc(&F.status, R));
-    if (!std::getenv("TNCO_HIP_FW_NO_WALK_KERNEL")) {
-      HIP_TRY(h->alloc(&F.nwide, R));
-      if (!std::getenv("TNCO_HIP_FW_ONE_ENDED_WALK")) HIP_TRY(h->alloc(&F.nwfront, R));  // (test knob: fw_walk_kernel)
-    }
+    HIP_TRY(h->alloc(&F.nwide, R));
+    HIP_TRY(h->alloc(&F.nwfront, R));
     HIP_TRY(hipMemset(F.status, 0, (size_t)R * 4));
-    // the re-slice by re-pricing (fw_delta_kernel): costs must be powers of two and a leg of a subtree
-    // decidable from the holders it contains
-    if (F.nwfront != nullptr && P.cost_mode == 0 && !P.f32 && d->sparse_mask == nullptr && !h->hyper && n >= 16 && n <= 32 * FWD_BITW &&
-        !std::getenv("TNCO_HIP_FW_NO_DELTA")) {
+    // The re-slice of a replica in one wavefront, its cost cache RE-PRICED (fw_wave_kernel): costs must be powers of
+    // two (uniform dims 2^k, float64, no sparse legs), a leg of a subtree decidable from the holders it contains (no
+    // hyper-indices), the headers one array per replica (split layout), a lane's share of the nodes in registers.
+    // TNCO_HIP_FW_WAVE=0: never (tests compare the two forms), =1: always where possible (else: by the fall-backs).
+    const char* wave_env = std::getenv("TNCO_HIP_FW_WAVE");
+    const int lkw = F.I64 / 64, lanes_per_mask = lkw <= 16 ? 16 : (lkw <= 32 ? 32 : 64);
+    if (P.cost_mode == 0 && !P.f32 && d->sparse_mask == nullptr && !h->hyper && P.BS == 32 && n >= 16 && n - 1 <= 64 * FWT_JMAX &&
+        F.I64 <= 4096 && fww_lds_bytes(n, lanes_per_mask) <= 64 * 1024 && !(wave_env && std::atoi(wave_env) == 0)) {
       std::vector<int32_t> hold((size_t)F.I64 * 2, -1);
       std::vector<int32_t> cnt((size_t)I, 0);
       for (int t = 0; t < n; ++t)
@@ -865,19 +853,16 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       HIP_TRY(h->alloc(&dh, (int64_t)hold.size()));
       HIP_TRY(hipMemcpy(dh, hold.data(), hold.size() * 4, hipMemcpyHostToDevice));
       F.holder2 = dh;
-      HIP_TRY(h->alloc(&F.fastflag, R));
-      HIP_TRY(h->alloc(&F.delta_scr, R * 64));
       HIP_TRY(h->alloc(&F.slowstat, 4));
       HIP_TRY(hipMemset(F.slowstat, 0, 32));
-      F.fast_ok = 1;
-      h->fw_delta_capable = h->fw_delta_on = true;
-      // ... without any walk over the tree when the headers are one array per replica (split layout), no leaf is too
-      // wide (set below) and a lane of fw_tree_kernel can hold its share of the nodes
-      F.tree_ok = (P.BS == 32 && n - 1 <= 64 * FWT_JMAX && !std::getenv("TNCO_HIP_FW_NO_TREE")) ? 1 : 0;
+      h->fw_wave_capable = true;
 #ifdef TNCO_PROFILE  // (the stage counters live in the single re-slice kernel)
-      F.tree_ok = 0;
+      h->fw_wave_capable = false;
 #endif
     }
+    HIP_TRY(h->alloc(&F.fastflag, R));
+    HIP_TRY(hipMemset(F.fastflag, 0, (size_t)R * 4));
+    HIP_TRY(h->alloc(&F.delta_scr, R * 64));
     F.stack_cap = FW_LDSPOS;
     if (const char* e = std::getenv("TNCO_HIP_FW_STACK")) F.stack_cap = std::max(0, std::min(FW_LDSPOS, std::atoi(e)));
     auto upload_mask = [&](const uint64_t* src, const uint64_t** dst) -> int {
@@ -908,25 +893,15 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       HIP_TRY(hipMemcpyAsync(&a1, any, 4, hipMemcpyDeviceToHost, h->stream));
       HIP_TRY(h->sync_all());
       F.leaf_wide = a1 ? 1 : 0;
-      if (F.leaf_wide) F.tree_ok = 0;
-      if (F.tree_ok) {
-        bool ok = false;
-#define CALL_FWP(LL, KK) ok = fw_tree_prepare_lk<LL, KK>(h)
-        DISPATCH_LK(h, CALL_FWP)
-#undef CALL_FWP
-        if (!ok) F.tree_ok = 0;
-      }
-      // ... and the whole re-slice of a replica in one wavefront (a mask in 16, 32 or 64 lanes); as separate kernels,
-      // get_slices with one wavefront per replica when a mask fits a row of sixteen lanes
-      if (F.tree_ok && F.I64 <= 4096 && !std::getenv("TNCO_HIP_FW_NO_WAVE_SLICES")) {
-        h->fw_wave_slices = FWS_CAP;
-        if (const char* e = std::getenv("TNCO_HIP_FWS_CAP")) h->fw_wave_slices = std::max(1, std::min(256, std::atoi(e)));
-        const int lkw = F.I64 / 64, lanes_per_mask = lkw <= 16 ? 16 : (lkw <= 32 ? 32 : 64);
-        h->fw_fused = !std::getenv("TNCO_HIP_FW_NO_FUSED") && fww_lds_bytes(n, h->fw_wave_slices, lanes_per_mask) <= 64 * 1024;
-        if (!h->fw_fused && W > 16) h->fw_wave_slices = 0;  // (the separate get_slices kernel holds a mask in sixteen lanes)
+      if (F.leaf_wide) h->fw_wave_capable = false;  // (a too-wide leaf has no header to carry its width)
+      if (h->fw_wave_capable) {
+        h->fw_wave_on = true;
+        h->fw_wave_cap = fww_cap(n, lanes_per_mask);
+        if (const char* e = std::getenv("TNCO_HIP_FWS_CAP")) h->fw_wave_cap = std::max(1, std::min(h->fw_wave_cap, std::atoi(e)));  // (test knob: legs from memory)
         h->fw_wave_maxnp = FWS_MAXNP;
         if (const char* e = std::getenv("TNCO_HIP_FWS_MAXNP")) h->fw_wave_maxnp = std::max(0, std::min(FWS_MAXNP, std::atoi(e)));
       }
+      F.fast_ok = h->fw_wave_on ? 1 : 0;
     }
     // rows of W words (one shared, or one per replica) -> rows of L words on the device, zero-padded
     auto upload_rows = [&](const uint64_t* src, uint64_t** dst) -> int {
@@ -1166,25 +1141,24 @@ int tnco_hip_run_fw(tnco_hip_handle h, int prob_kind, const double* betas, int64
   if (n_steps == 0) return TNCO_HIP_OK;
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(h->sync_all());
-  if (h->fw_delta_capable) {
-    // Re-pricing or the single re-slice kernel for this call?  Re-pricing (three kernels) wins while
-    // fewer than ~3 % of the replicas fall back to the full rebuild (more than 64 changed indices: random
-    // initial trees early in a schedule) -- a fall-back costs its whole wavefront the rebuild.  The
-    // previous call's kernels are complete here: its fall-backs are counted, or, after 4, 8, 16 ... calls in
-    // the other mode, this call probes again.
-    if (h->fw_delta_reslices > 0) {
+  if (h->fw_wave_capable) {
+    // The wavefront form or the general one (walk + full rebuild) for this call?  The first wins while fewer than
+    // ~2 % of the replicas fall back to the full rebuild (more changed indices than it re-prices: random initial
+    // trees early in a schedule) -- a fall-back costs the full rebuild on top.  The previous call's kernels are
+    // complete here: its fall-backs are counted, or, after 4, 8, 16 ... calls in the other form, this call probes again.
+    if (h->fw_wave_reslices > 0) {
       unsigned long long slow = 0;
       HIP_TRY(h->collect_fw_stats(&slow));
-      const bool was_on = h->fw_delta_on;
-      h->fw_delta_on = (double)slow < 0.02 * (double)h->fw_delta_reslices * (double)h->P.R;
-      h->fw_probe_wait = h->fw_delta_on ? 4 : (was_on && h->fw_single_calls == 0 ? std::min(64, 2 * h->fw_probe_wait) : h->fw_probe_wait);
-      h->fw_delta_reslices = 0;
+      const bool was_on = h->fw_wave_on;
+      h->fw_wave_on = (double)slow < 0.02 * (double)h->fw_wave_reslices * (double)h->P.R;
+      h->fw_probe_wait = h->fw_wave_on ? 4 : (was_on && h->fw_single_calls == 0 ? std::min(64, 2 * h->fw_probe_wait) : h->fw_probe_wait);
+      h->fw_wave_reslices = 0;
       h->fw_single_calls = 0;
-    } else if (!h->fw_delta_on && ++h->fw_single_calls >= h->fw_probe_wait) {
-      h->fw_delta_on = true;
+    } else if (!h->fw_wave_on && ++h->fw_single_calls >= h->fw_probe_wait) {
+      h->fw_wave_on = true;
     }
-    if (const char* e = std::getenv("TNCO_HIP_FW_DELTA")) h->fw_delta_on = std::atoi(e) != 0;  // (test knob: pin the mode)
-    h->F.fast_ok = h->fw_delta_on ? 1 : 0;
+    if (const char* e = std::getenv("TNCO_HIP_FW_WAVE")) h->fw_wave_on = std::atoi(e) != 0;  // (test knob: pin the form)
+    h->F.fast_ok = h->fw_wave_on ? 1 : 0;
   }
   if (n_steps > h->betas_cap) {
     if (h->d_betas) (void)hipFree(h->d_betas);
@@ -1240,16 +1214,13 @@ int tnco_hip_get_slices(tnco_hip_handle h, int64_t r, uint64_t* slices, uint64_t
 
 int tnco_hip_get_reslice_info(tnco_hip_handle h, int32_t* how, int32_t* n_changed) {
   if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
-  if (!h->fw || !h->F.fastflag) return fail(TNCO_HIP_EINVAL, "handle has no re-pricing re-slice.");
+  if (!h->fw || !h->fw_wave_capable) return fail(TNCO_HIP_EINVAL, "handle has no re-pricing re-slice.");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(h->sync_all());
   const int64_t R = h->P.R;
   if (how) HIP_TRY(hipMemcpy(how, h->F.fastflag, (size_t)R * 4, hipMemcpyDeviceToHost));
   if (n_changed) {  // word 0 of every replica's change list (fw_reslice_a_kernel), 512 bytes apart
-    if (h->F.tree_ok)
-      HIP_TRY(hipMemcpy2D(n_changed, 4, h->F.delta_scr, 512, 4, (size_t)R, hipMemcpyDeviceToHost));
-    else
-      for (int64_t r = 0; r < R; ++r) n_changed[r] = -1;
+    HIP_TRY(hipMemcpy2D(n_changed, 4, h->F.delta_scr, 512, 4, (size_t)R, hipMemcpyDeviceToHost));
   }
   return TNCO_HIP_OK;
 }

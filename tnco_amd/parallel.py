@@ -12,6 +12,8 @@ tests; nccl if a caller has initialised one).
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
+import hmac
 import os
 import pickle
 import socket
@@ -88,6 +90,8 @@ class NativeComm:
         def _init():
             try:
                 box["rc"] = self._L.tnco_hip_comm_init(self.rank, self.world, uid, self.device, C.byref(h))
+                if box["rc"]:  # (the text, from the thread that failed)
+                    box["err"] = self._L.tnco_hip_comm_last_error().decode()
             except Exception as e:  # noqa: BLE001
                 box["exc"] = e
 
@@ -96,11 +100,15 @@ class NativeComm:
         th.start()
         th.join(timeout)
         if th.is_alive():
+            # (the thread may still finish: init_native joins it once more after the ranks have voted and destroys the
+            #  communicator if it did come up -- a rank that gave up must not leave a live communicator behind)
+            _abandoned_inits.append((th, box, h, self._L))
             self.hung = True
             raise TimeoutError(f"rank {self.rank}: ncclCommInitRank did not return within {timeout:.0f} s")
         if "exc" in box:
             raise box["exc"]
-        self._check(box["rc"])
+        if box["rc"]:
+            raise RuntimeError(box.get("err") or "ncclCommInitRank failed")
         self._h = h
 
     hung = False
@@ -166,18 +174,37 @@ class SocketComm:
             return
         addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
         port = int(port or os.environ.get("TNCO_COMM_SIDE_PORT") or int(os.environ.get("MASTER_PORT", "29533")) + 18)
+        # Only ranks of THIS job may join, and what they send is checked before it is unpickled: every connection opens
+        # with a token derived from the launch (torchrun's run id, the rendezvous address, the world size; TNCO_COMM_TOKEN
+        # adds a secret), every message carries an HMAC under it.  A stray connection is dropped, not waited for.
+        seed = "|".join([os.environ.get("TORCHELASTIC_RUN_ID", ""), str(addr), os.environ.get("MASTER_PORT", ""), str(self.world),
+                         os.environ.get("TNCO_COMM_TOKEN", "")])
+        self._key = hashlib.sha256(("tnco-side-channel|" + seed).encode()).digest()
+        io_timeout = float(os.environ.get("TNCO_COMM_IO_TIMEOUT", "3600"))
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind((addr, port))
-            srv.listen(self.world)
-            srv.settimeout(timeout)
+            srv.listen(self.world + 8)
+            deadline = time.monotonic() + timeout
             try:
                 while len(self._peers) < self.world - 1:
+                    left = deadline - time.monotonic()
+                    if left <= 0:
+                        raise TimeoutError(f"rank 0: {self.world - 1 - len(self._peers)} ranks did not join the side channel at {addr}:{port}")
+                    srv.settimeout(left)
                     conn, _peer = srv.accept()
+                    try:
+                        conn.settimeout(min(10.0, max(left, 0.1)))  # (the hello must come at once)
+                        hello = self._recv_exact(conn, 20)
+                        k = int.from_bytes(hello[16:], "little")
+                        if not hmac.compare_digest(hello[:16], self._key[:16]) or not 0 < k < self.world or k in self._peers:
+                            raise ConnectionError("not a rank of this job")
+                    except (OSError, ConnectionError):
+                        conn.close()
+                        continue
                     conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    conn.settimeout(None)
-                    k = int.from_bytes(self._recv_exact(conn, 4), "little")
+                    conn.settimeout(io_timeout)
                     self._peers[k] = conn
             finally:
                 srv.close()
@@ -192,8 +219,8 @@ class SocketComm:
                         raise RuntimeError(f"rank {self.rank}: rank 0 does not answer at {addr}:{port}") from None
                     time.sleep(0.05)
             c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            c.settimeout(None)
-            c.sendall(self.rank.to_bytes(4, "little"))
+            c.settimeout(io_timeout)
+            c.sendall(self._key[:16] + self.rank.to_bytes(4, "little"))
             self._up = c
 
     @staticmethod
@@ -206,13 +233,18 @@ class SocketComm:
             buf += chunk
         return bytes(buf)
 
-    @classmethod
-    def _send_msg(cls, c: socket.socket, blob: bytes) -> None:
-        c.sendall(len(blob).to_bytes(8, "little") + blob)
+    def _send_msg(self, c: socket.socket, blob: bytes) -> None:
+        c.sendall(len(blob).to_bytes(8, "little") + hmac.new(self._key, blob, hashlib.sha256).digest() + blob)
 
-    @classmethod
-    def _recv_msg(cls, c: socket.socket) -> bytes:
-        return cls._recv_exact(c, int.from_bytes(cls._recv_exact(c, 8), "little"))
+    def _recv_msg(self, c: socket.socket) -> bytes:
+        n = int.from_bytes(self._recv_exact(c, 8), "little")
+        if n > (1 << 31):
+            raise ConnectionError("side channel: message length out of range")
+        mac = self._recv_exact(c, 32)
+        blob = self._recv_exact(c, n)
+        if not hmac.compare_digest(mac, hmac.new(self._key, blob, hashlib.sha256).digest()):
+            raise ConnectionError("side channel: message not from a rank of this job")
+        return blob
 
     def allgather_object(self, obj) -> list:
         if self.world == 1:
@@ -247,6 +279,22 @@ class SocketComm:
 
 _native: "NativeComm | SocketComm | None" = None
 _side: SocketComm | None = None
+_abandoned_inits: list = []  # (thread, result box, handle, library) of ncclCommInitRank calls that outlived their time limit
+
+
+def _reap_abandoned_inits(grace: float = 5.0) -> bool:
+    """After the ranks have agreed NOT to use RCCL: give the init threads that outlived their limit a last moment and
+    destroy the communicators that did come up.  Returns whether a thread is still inside ncclCommInitRank."""
+    still = False
+    for th, box, h, lib in list(_abandoned_inits):
+        th.join(grace)
+        if th.is_alive():
+            still = True
+            continue
+        _abandoned_inits.remove((th, box, h, lib))
+        if box.get("rc") == 0 and h:
+            lib.tnco_hip_comm_destroy(h)
+    return still
 
 
 def init_native(rank: int | None = None, world: int | None = None, device: int | None = None, **kw):
@@ -293,7 +341,7 @@ def init_native(rank: int | None = None, world: int | None = None, device: int |
     if comm is not None:
         comm.close()
     side.note = "RCCL not used -- " + note
-    side.hung = "did not return" in note
+    side.hung = _reap_abandoned_inits()  # (a thread of this process still sits in ncclCommInitRank)
     _native, _side = side, None
     return _native
 
