@@ -473,3 +473,59 @@ def test_fw_more_too_wide_tensors_than_the_one_wavefront_reslice_lists(core, ora
     gpu = _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 30, 12), 4, chunks=[5, 7], every=3)
     how, nch = gpu.reslice_info()
     assert (how == 0).all()  # (rebuilt in full: none was re-priced)
+
+
+@pytest.mark.parametrize("wave", [True, False])
+@pytest.mark.parametrize("net", ["random_k4", "cz_fused", "cz_raw"])
+def test_fw_hyper_index_networks_both_forms(core, oracle_lib, monkeypatch, net, wave):
+    """Networks with hyper-indices -- what the reference's loader makes of diagonal gates (tnco/utils/tn.py:827, on by
+    default) -- through both forms of the re-slice against the oracle: a random hypergraph with indices on up to four
+    tensors and output indices, and the Sycamore lattice with CZ gates (wire segments held by two or three tensors),
+    pre-fused as the loader does (fuse = 4) and raw.  In the one-wavefront form an index is among a node's children's
+    legs while some, but not all, of its holders are below the node: marks up from every holder, then down from the
+    root to where the paths meet."""
+    from tnco_amd import synthetic as syn
+    monkeypatch.setenv("TNCO_HIP_FW_WAVE", "1" if wave else "0")
+    if net == "random_k4":
+        ts, dims, out = syn.random_hyper_tn(60, 130, k=4, n_output=3, seed=12)
+    elif net == "cz_fused":
+        ts, dims, out = syn.sycamore53_cz_tn(6, fuse=4, seed=3)
+    else:
+        ts, dims, out = syn.sycamore53_cz_tn(4, fuse=None)  # (four cycles: both coupler orientations, a connected network)
+    prob = H.Problem(ts, 2, out)
+    assert any(len(h) > 2 for h in prob.holders)
+    seeds = H.replica_seeds(12, S=31)
+    links = core.greedy_trees(prob.ts_inds, prob.n_inds, np.asarray(seeds), output_mask=prob.output_mask)
+    w0 = _initial_max_width(prob, links[0])
+    gpu = _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 50, 60), max(3, int(0.7 * w0)), chunks=[25, 35], every=5, links=links)
+    st = gpu.fw_stats()
+    assert (st["repriced"] > 0) == wave and (st["full_rebuild_form"] > 0) == (not wave)
+    if wave:
+        assert st["fell_back"] < st["repriced"]  # (the re-pricing did take most of them)
+
+
+def test_fw_hyper_index_network_forms_agree_at_scale(core, monkeypatch):
+    """The CZ circuit network (depth 12, fused: ~220 tensors, 40 % of the indices on three tensors), 8 192 replicas x 60
+    sweeps from greedy starts: the one-wavefront form and the general form end at identical totals, best totals,
+    slices and generator states."""
+    from tnco_amd import synthetic as syn
+    ts, dims, out = syn.sycamore53_cz_tn(12, fuse=4, seed=0)
+    p = syn.Problem(ts, 2, out)
+    R = 8192
+    seeds = np.asarray(syn.replica_seeds(R, S=77))
+    links = core.greedy_trees(p.ts_inds, p.n_inds, seeds, device=0)
+    w0 = _initial_max_width(p, links[0])
+    betas = H.linear_betas(0, 100, 600)[:60]
+    res = []
+    for pin in ("1", "0"):
+        monkeypatch.setenv("TNCO_HIP_FW_WAVE", pin)
+        with core.BatchedOptimizer(p.leaf_masks, links, seeds, n_inds=p.n_inds, max_width=int(0.7 * w0)) as g:
+            for c in range(0, 60, 20):
+                g.run(betas[c:c + 20], update_slices_every=10)
+            assert g.validate() == (0, -1)
+            res.append((g.costs(), g.slices_many(np.arange(R)), np.asarray(g.prng_states()), g.fw_stats()))
+    a, b = res
+    assert a[3]["repriced"] == 6 * R and b[3]["full_rebuild_form"] == 6 * R
+    assert a[3]["fell_back"] < 0.05 * a[3]["repriced"], a[3]
+    assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1])
+    assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1]) and np.array_equal(a[2], b[2])

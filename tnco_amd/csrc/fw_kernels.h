@@ -1762,18 +1762,20 @@ __device__ __forceinline__ uint32_t fws_rowscan(uint32_t v) {
 // proposal written and fastflag = 0 (fw_reslice_b_kernel rebuilds it in full).
 // ---------------------------------------------------------------------------------------------
 constexpr size_t FWW_GS_FIXED = 192 * 8 + 1024 + (size_t)FWS_MAXNP * 3 + 64;  // shuffle steps per position, ring, candidates + swap targets (+ padding to 16)
-__host__ __device__ inline size_t fww_lds_bytes(int n, int T) {  // T: lanes per mask (16, 32 or 64)
+constexpr int FWH_MAXH = 7;      // tensors holding one index at most, for the re-pricing (more: the full rebuild)
+constexpr size_t FWW_HYPER_EXTRA = 64 * 8 * 2 * 2 + 64;  // per changed index 8 slots of (path start, leaf), + the holder counts
+__host__ __device__ inline size_t fww_lds_bytes(int n, int T, bool hyper = false) {  // T: lanes per mask (16, 32 or 64)
   const size_t nip = (size_t)((n - 1 + 63) & ~63);
   const size_t u1 = (size_t)FWO_MAXW * (8 + 2 + 2);                         // keys, nodes, depths
-  const size_t u3 = nip * 8 + 256 + 32;                                     // masks / partial sums, change list, flags
+  const size_t u3 = nip * 8 + 256 + 32 + (hyper ? FWW_HYPER_EXTRA : 0);     // masks / partial sums, change list, flags
   size_t body = nip * 8 + (u1 > u3 ? u1 : u3);
   const size_t gs = FWW_GS_FIXED + (size_t)FWS_MINCAP * T * 8;              // get_slices at least
   body = body > gs ? body : gs;
   return (512 /* list */ + body + 15) & ~(size_t)15;
 }
 // too-wide tensors whose legs get_slices keeps in LDS
-__host__ __device__ inline int fww_cap(int n, int T) {
-  const size_t c = (fww_lds_bytes(n, T) - 512 - FWW_GS_FIXED) / ((size_t)T * 8);
+__host__ __device__ inline int fww_cap(int n, int T, bool hyper = false) {
+  const size_t c = (fww_lds_bytes(n, T, hyper) - 512 - FWW_GS_FIXED) / ((size_t)T * 8);
   return (int)(c < (size_t)FWO_MAXW ? c : (size_t)FWO_MAXW);
 }
 
@@ -1804,7 +1806,8 @@ __device__ __forceinline__ uint32_t fws_scan(uint32_t v, int lane) {
 }
 
 // LOGT: lanes per leg mask (4, 5, 6: networks of at most 16, 32, 64 mask words); 64 >> LOGT tensors per load instruction
-template <int J, int LOGT>
+// HYPER: indices held by more than two tensors (FwParams::holdern, up to FWH_MAXH each): the marks of the re-pricing below
+template <int J, int LOGT, bool HYPER>
 static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, const FwParams F, const int cap, const int maxnp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fww_smem[];
   FWW_T(w0_);
@@ -1836,6 +1839,10 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
   TNCO_LDS volatile uint32_t* onv = (TNCO_LDS volatile uint32_t*)U;
   TNCO_LDS volatile uint32_t* chgl = (TNCO_LDS volatile uint32_t*)(Pn + nip);              // [64] starts of the paths
   TNCO_LDS volatile uint32_t* misc = chgl + 64;                                            // [8]
+  // (HYPER) changed index o: its holders' path starts / leaves in slots 8 o .. 8 o + 7, their number | open << 7
+  TNCO_LDS volatile uint16_t* pstart = (TNCO_LDS volatile uint16_t*)(misc + 8);            // [64][8]
+  TNCO_LDS volatile uint16_t* pleaf = pstart + 512;                                        // [64][8]
+  TNCO_LDS volatile uint8_t* pcnt = (TNCO_LDS volatile uint8_t*)(pleaf + 512);             // [64]
 
   // ---- everything that depends on nothing, in flight at once
   uint8_t* hb = P.blocks + r * P.RB;
@@ -2243,12 +2250,18 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
     bool unsup = nd > FWT_MAXD;
     int bits[4];
     int2 hold[4];
+    uint4 holdn[HYPER ? 4 : 1];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       bits[q] = ch ? __ffsll((unsigned long long)ch) - 1 : -1;
       ch &= ch - 1;  // (0 stays 0)
       hold[q] = make_int2(-1, -1);
-      if (bits[q] >= 0 && !unsup) hold[q] = *reinterpret_cast<const int2*>(F.holder2 + 2 * (w * 64 + bits[q]));
+      if constexpr (HYPER) {
+        holdn[q] = make_uint4(0, 0, 0, 0);
+        if (bits[q] >= 0 && !unsup) holdn[q] = *reinterpret_cast<const uint4*>(F.holdern + 8 * (w * 64 + bits[q]));
+      } else {
+        if (bits[q] >= 0 && !unsup) hold[q] = *reinterpret_cast<const int2*>(F.holder2 + 2 * (w * 64 + bits[q]));
+      }
     }
     {  // get_slices is done: the generator's position, the proposal (fw_reslice_b_kernel reads it if the re-pricing gives up)
       int mti, mtw;
@@ -2279,13 +2292,31 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
         if ((ns >> bit) & 1ull) plus |= 1ull << off; else minus |= 1ull << off;
         ++off;
       };
+      // (HYPER) the index's entry of FwParams::holdern: count | open << 15, then the holders
+      auto entry_n = [&](int bit, uint4 hv) {
+        const uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w};
+        const int m = (int)(hw[0] & 0x7FFFu), open = (int)((hw[0] >> 15) & 1u);
+        if (m < 1 || m > FWH_MAXH) { unsup = true; return; }
+        pcnt[off] = (uint8_t)(m | (open << 7));
+        for (int j = 0; j < m; ++j) {
+          const int t = (int)((hw[(j + 1) >> 1] >> (((j + 1) & 1) * 16)) & 0xFFFFu);
+          pleaf[off * 8 + j] = (uint16_t)t;
+          pstart[off * 8 + j] = lparL[t];
+        }
+        if ((ns >> bit) & 1ull) plus |= 1ull << off; else minus |= 1ull << off;
+        ++off;
+      };
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (bits[q] >= 0 && !unsup) entry(bits[q], hold[q]);
+      for (int q = 0; q < 4; ++q) {
+        if (bits[q] >= 0 && !unsup) {
+          if constexpr (HYPER) entry_n(bits[q], holdn[q]); else entry(bits[q], hold[q]);
+        }
+      }
       while (ch && !unsup) {  // (more than four changed indices in one mask word)
         const int bit = __ffsll((unsigned long long)ch) - 1;
         ch &= ch - 1;
-        entry(bit, *reinterpret_cast<const int2*>(F.holder2 + 2 * (w * 64 + bit)));
+        if constexpr (HYPER) entry_n(bit, *reinterpret_cast<const uint4*>(F.holdern + 8 * (w * 64 + bit)));
+        else entry(bit, *reinterpret_cast<const int2*>(F.holder2 + 2 * (w * 64 + bit)));
       }
     }
     unsup = __any(unsup);
@@ -2325,7 +2356,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
     if (pass) {
       for (int i = lane; i < ni; i += GW) { onv[2 * i] = 0; onv[2 * i + 1] = 0; }
     }
-    {
+    if constexpr (!HYPER) {
       const int k = lane >> 1, which = lane & 1;
       const int idx = IPP * pass + k;  // this lane's changed index
       const uint32_t e = idx < nd ? chgl[idx] : 0xFFFFFFFFu;
@@ -2339,15 +2370,78 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
           x = pp == 0xFFFF ? -1 : pp;
         }
       }
+    } else {
+      // An index d held by m tensors is a leg of a subtree exactly when the subtree holds some but not all of them
+      // (all of them: only if d is open -- an output, or held by one tensor).  So d is among the legs of node x's
+      // children when x has a holder below and is not STRICTLY ABOVE the node where all the holders' paths have met.
+      //   any[x] (on[2 x]):      a holder of index k below x -- every (index, holder) walks up from the holder's
+      //                          parent; a walk that meets a node already marked for its index stops, the one
+      //                          that marked it goes on to the root;
+      //   above[x] (on[2 x + 1]): x strictly above the meeting point -- one lane per closed index walks DOWN from
+      //                          the root while exactly one child has holders below.
+      for (int rd = 0; rd < 4; ++rd) {
+        const int sidx = rd * 64 + lane, k = sidx >> 3, jj = sidx & 7;
+        const int idx = IPP * pass + k;
+        int x = -1;
+        if (idx < nd && jj < (int)(pcnt[idx] & 0x7Fu)) x = pstart[idx * 8 + jj];
+        for (int guard = 0; __any(x >= 0); ++guard) {
+          if (guard > ni) { bad = true; break; }
+          if (x >= 0) {
+            const uint32_t was = __hip_atomic_fetch_or(&on[2 * (x - n)], 1u << k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int pp = (int)(hiv[x - n] & 0xFFFFu);
+            x = (((was >> k) & 1u) || pp == 0xFFFF) ? -1 : pp;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      {
+        const int k = lane, idx = IPP * pass + k;
+        const int c = (k < IPP && idx < nd) ? (int)pcnt[idx] : 0x80;
+        const int m = c & 0x7F;
+        int x = (c & 0x80) ? -1 : N - 1;  // (open indices: a leg all the way up)
+        for (int guard = 0; __any(x >= 0); ++guard) {
+          if (guard > ni) { bad = true; break; }
+          if (x >= 0) {
+            const uint32_t wq = lo[x - n];
+            const int l = (int)(wq & 0xFFFFu), rr = (int)(wq >> 16);
+            bool cl, cr;
+            if (l >= n) {
+              cl = (onv[2 * (l - n)] >> k) & 1u;
+            } else {
+              cl = false;
+              for (int j = 0; j < m; ++j) cl = cl || (int)pleaf[idx * 8 + j] == l;
+            }
+            if (rr >= n) {
+              cr = (onv[2 * (rr - n)] >> k) & 1u;
+            } else {
+              cr = false;
+              for (int j = 0; j < m; ++j) cr = cr || (int)pleaf[idx * 8 + j] == rr;
+            }
+            if (cl == cr) {  // both: the paths meet here (neither: cannot happen)
+              x = -1;
+            } else {
+              __hip_atomic_fetch_or(&on[2 * (x - n) + 1], 1u << k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              x = cl ? l : rr;
+              if (x < n) x = -1;  // (cannot happen: a closed index has two holders at least)
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
     }
     for (int i = lane; i < ni; i += GW) {
       const uint32_t wq = lo[i], h = hiv[i];
       const int l = (int)(wq & 0xFFFFu), rr = (int)(wq >> 16);
       const uint32_t a = onv[2 * i], b = onv[2 * i + 1];
-      const int il = l >= n ? l - n : i, ir = rr >= n ? rr - n : i;
-      const uint32_t bl = onv[2 * il] & onv[2 * il + 1], br = onv[2 * ir] & onv[2 * ir + 1];
-      const uint32_t both_below = (l >= n ? bl : 0u) | (rr >= n ? br : 0u);
-      const uint32_t in_u = (a ^ b) | (a & b & ~both_below);
+      uint32_t in_u;
+      if constexpr (HYPER) {
+        in_u = a & ~b;
+      } else {
+        const int il = l >= n ? l - n : i, ir = rr >= n ? rr - n : i;
+        const uint32_t bl = onv[2 * il] & onv[2 * il + 1], br = onv[2 * ir] & onv[2 * ir + 1];
+        const uint32_t both_below = (l >= n ? bl : 0u) | (rr >= n ? br : 0u);
+        in_u = (a ^ b) | (a & b & ~both_below);
+      }
       const int dex = (pass ? 0 : dbase) - __popc(in_u & plus) + __popc(in_u & minus);
       const int ne = (int)((h >> 16) & 0x7FFu) + log2d * dex;
       bad = bad || ne <= 0 || ne >= 2047;  // (also between the passes: the full rebuild decides then)

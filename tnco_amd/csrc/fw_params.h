@@ -30,6 +30,8 @@ struct FwParams {
   int32_t fast_ok;          // this call runs it: uniform power-of-two dims, float64 cost, no sparse legs, no hyper-indices,
                             // <= 1024 tensors, no too-wide leaf, split layout; few fall-backs lately (tnco_hip_run_fw)
   const int32_t* holder2;   // [I64][2] the (one or two) tensors holding an index, -1: none / index not supported
+  const uint16_t* holdern;  // [I64][8] networks with hyper-indices instead: count | open << 15 (open: an output index, or held by
+                            //          one tensor), then the (up to 7) tensors holding the index; count 0: not supported
   int32_t* fastflag;        // [R] 1: fw_wave_kernel has done this replica's rebuild (+ commit)
   unsigned long long* slowstat;  // [4] replicas the re-pricing has left to the full rebuild since the host last looked; of those
                                  //     [1] too many / too deep / too leggy too-wide tensors, [2] too many changed indices or an index

@@ -36,6 +36,7 @@ struct tnco_hip_ctx {
   // tnco_hip_get_fw_stats: [0] replica re-slices launched in the re-pricing form, [1] of those left to the full rebuild,
   // [2..4] why (FwParams::slowstat[1..3]), [5] replica re-slices launched in the walk + full-rebuild form
   int64_t fw_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long fw_slow_pending = 0;  // fall-backs collected since tnco_hip_run_fw last chose a form
   tnco::FwParams F{};
   std::vector<void*> allocs;
   int64_t bytes = 0;
@@ -77,7 +78,11 @@ struct tnco_hip_ctx {
     e = hipMemsetAsync(F.slowstat, 0, 32, stream);
     if (e != hipSuccess) return e;
     for (int i = 0; i < 4; ++i) fw_stats[1 + i] += (int64_t)c[i];
-    if (slow) *slow = c[0];
+    fw_slow_pending += c[0];
+    if (slow) {  // (the caller that decides the next call's form: everything since it last asked, whoever collected it)
+      *slow = fw_slow_pending;
+      fw_slow_pending = 0;
+    }
     return hipSuccess;
   }
   template <typename T>

@@ -11,7 +11,7 @@
 // small groups (L = 4) keep that redundancy low and put 16 replicas in one wavefront.
 //
 // HBM layout, replica-major (everything of one replica is contiguous):
-//   node block of internal node p (BS bytes, BS = 32 + 8*W [*2 with hyper legs, at P.hoff], rounded to 32):
+//   node block of internal node p (BS bytes, BS = 32 + 8*W [*2 with hyper legs, P.hoff bytes behind the legs], rounded to 32):
 //       [ left right parent pad | ccost | partial | legs: W words | hyper legs: W words ]
 //     so one move touches ONE line per node it reads or writes (512-leaf TN: W = 12, BS = 128 B
 //     = exactly one 128-B line).  HBM here is bound by the number of random line activations,
@@ -66,14 +66,14 @@ struct Params {
   // Two layouts of a replica's region (RB bytes, at blocks + r * RB):
   //   unified  [ header | legs (| hyper legs) ] per node, BS bytes: WOFF = 32, WS = BS -- one line per node
   //            at <= 12 mask words (the infinite-memory benchmark);
-  //   split    [ all headers, 32 B each ][ all legs, WS bytes each, 128-byte aligned ]: BS = 32 -- the
+  //   split    [ all headers, 32 B each ][ all legs (| hyper legs), WS bytes each, 128-byte aligned ]: BS = 32 -- the
   //            finite-width optimizer: its node blocks (15 words: 160 B) straddled lines anyway, the walk of
   //            the re-slice reads the header array as ONE coalesced 17-KB piece instead of n - 1 random
   //            32-byte reads, and a kept re-slice rewrites it the same way.
   int32_t WS;                // bytes between the legs of consecutive nodes
   int32_t WOFF;              // byte offset of node n's legs from the replica's base
   int64_t RB;                // bytes per replica
-  int32_t hoff;              // byte offset of the hyper legs inside a block (networks with hyper-indices)
+  int32_t hoff;              // byte offset of a node's hyper legs from its legs (networks with hyper-indices)
   int32_t jcap;              // rotation-log entries per replica
   int64_t R;
   uint8_t* blocks;           // [R][RB]
@@ -167,9 +167,6 @@ struct View {
     blk = blk_; lpar = lpar_; leafmask = P.leafmask; n = P.n; BS = P.BS; W = P.W; lig = lig_; hoff = P.hoff;
     WS = P.WS; WOFF = P.WOFF;
   }
-  __device__ __forceinline__ uint64_t* hwords(int p) const {  // (networks with hyper-indices: unified layout)
-    return reinterpret_cast<uint64_t*>(blk + (int64_t)(p - n) * BS + hoff);
-  }
   __device__ __forceinline__ NodeRec* hdr(int p) const {
     return reinterpret_cast<NodeRec*>(blk + (int64_t)(p - n) * BS);
   }
@@ -179,6 +176,10 @@ struct View {
   __device__ __forceinline__ uint64_t* words(int p) const {
     if constexpr (UNI) return reinterpret_cast<uint64_t*>(blk + (int64_t)(p - n) * BS + 32);
     return reinterpret_cast<uint64_t*>(blk + WOFF + (int64_t)(p - n) * WS);
+  }
+  // (networks with hyper-indices: the hyper legs follow the node's legs, hoff bytes behind them, in both layouts)
+  __device__ __forceinline__ uint64_t* hwords(int p) const {
+    return reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(words(p)) + hoff);
   }
   // Legs of node x (this lane's words).  The ADDRESS is selected (leaf table / node block), not the
   // value: one load per word, one definition -- two loads in the arms of a branch merge where the

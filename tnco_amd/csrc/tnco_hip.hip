@@ -564,14 +564,14 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   P.BS = (32 + 8 * W + 31) / 32 * 32;
   P.hoff = 0;
   if (h->hyper) {  // the hyper legs follow the legs
-    P.hoff = 32 + 8 * W;
+    P.hoff = 8 * W;
     P.BS = (32 + 16 * W + 31) / 32 * 32;
     if (std::getenv("TNCO_HIP_HYPER_ALIGNED")) {
       // experiment: header + legs | hyper legs, each part in whole 128-byte lines of its own.  Measured
       // on the 512-tensor hyper-index network: 4.16e9 against 4.15e9 move-evals/s -- no gain for 14 %
       // more memory (what did help was two wavefronts per SIMD: no spills, 2.5e9 -> 4.2e9).
-      P.hoff = (32 + 8 * W + 127) / 128 * 128;
-      P.BS = P.hoff + (8 * W + 127) / 128 * 128;
+      P.hoff = (32 + 8 * W + 127) / 128 * 128 - 32;
+      P.BS = 32 + P.hoff + (8 * W + 127) / 128 * 128;
     }
   }
   // Blocks longer than a line are PACKED (a 224-byte block at 24 mask words straddles two or three 128-byte lines
@@ -583,9 +583,10 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     if (al > 0) P.BS = (P.BS + al - 1) / al * al;
   }
   P.WS = P.BS; P.WOFF = 32; P.RB = (int64_t)(n - 1) * P.BS;
-  if (fw && !h->hyper) {  // split layout (sa_kernels.h, Params)
+  if (fw) {  // split layout (sa_kernels.h, Params)
     P.BS = 32;
-    P.WS = (8 * W + 63) / 64 * 64;
+    P.hoff = h->hyper ? 8 * W : 0;
+    P.WS = ((h->hyper ? 16 : 8) * W + 63) / 64 * 64;
     P.WOFF = ((n - 1) * 32 + 127) / 128 * 128;
     P.RB = ((int64_t)P.WOFF + (int64_t)(n - 1) * P.WS + 127) / 128 * 128;
   }
@@ -835,8 +836,8 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     // TNCO_HIP_FW_WAVE=0: never (tests compare the two forms), =1: always where possible (else: by the fall-backs).
     const char* wave_env = std::getenv("TNCO_HIP_FW_WAVE");
     const int lkw = F.I64 / 64, lanes_per_mask = lkw <= 16 ? 16 : (lkw <= 32 ? 32 : 64);
-    if (P.cost_mode == 0 && !P.f32 && d->sparse_mask == nullptr && !h->hyper && P.BS == 32 && n >= 16 && n - 1 <= 64 * FWT_JMAX &&
-        F.I64 <= 4096 && fww_lds_bytes(n, lanes_per_mask) <= 64 * 1024 && !(wave_env && std::atoi(wave_env) == 0)) {
+    if (P.cost_mode == 0 && !P.f32 && d->sparse_mask == nullptr && P.BS == 32 && n >= 16 && n - 1 <= 64 * FWT_JMAX &&
+        F.I64 <= 4096 && fww_lds_bytes(n, lanes_per_mask, h->hyper) <= 64 * 1024 && !(wave_env && std::atoi(wave_env) == 0)) {
       std::vector<int32_t> hold((size_t)F.I64 * 2, -1);
       std::vector<int32_t> cnt((size_t)I, 0);
       for (int t = 0; t < n; ++t)
@@ -853,6 +854,24 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       HIP_TRY(h->alloc(&dh, (int64_t)hold.size()));
       HIP_TRY(hipMemcpy(dh, hold.data(), hold.size() * 4, hipMemcpyHostToDevice));
       F.holder2 = dh;
+      if (h->hyper) {  // ... every holder of an index (up to FWH_MAXH), and whether it is open
+        std::vector<uint16_t> hn((size_t)F.I64 * 8, 0);
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (int t = 0; t < n; ++t)
+          for (int i = 0; i < I; ++i)
+            if ((d->leaf_masks[(size_t)t * W + (i >> 6)] >> (i & 63)) & 1ull) {
+              if (cnt[i] < FWH_MAXH) hn[(size_t)8 * i + 1 + cnt[i]] = (uint16_t)t;
+              cnt[i] += 1;
+            }
+        for (int i = 0; i < I; ++i) {
+          const bool is_out = d->output_mask && ((d->output_mask[i >> 6] >> (i & 63)) & 1ull);
+          if (cnt[i] >= 1 && cnt[i] <= FWH_MAXH) hn[(size_t)8 * i] = (uint16_t)(cnt[i] | ((is_out || cnt[i] == 1) ? 0x8000 : 0));
+        }
+        uint16_t* dn;
+        HIP_TRY(h->alloc(&dn, (int64_t)hn.size()));
+        HIP_TRY(hipMemcpy(dn, hn.data(), hn.size() * 2, hipMemcpyHostToDevice));
+        F.holdern = dn;
+      }
       HIP_TRY(h->alloc(&F.slowstat, 4));
       HIP_TRY(hipMemset(F.slowstat, 0, 32));
       h->fw_wave_capable = true;
@@ -896,7 +915,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       if (F.leaf_wide) h->fw_wave_capable = false;  // (a too-wide leaf has no header to carry its width)
       if (h->fw_wave_capable) {
         h->fw_wave_on = true;
-        h->fw_wave_cap = fww_cap(n, lanes_per_mask);
+        h->fw_wave_cap = fww_cap(n, lanes_per_mask, h->hyper);
         if (const char* e = std::getenv("TNCO_HIP_FWS_CAP")) h->fw_wave_cap = std::max(1, std::min(h->fw_wave_cap, std::atoi(e)));  // (test knob: legs from memory)
         h->fw_wave_maxnp = FWS_MAXNP;
         if (const char* e = std::getenv("TNCO_HIP_FWS_MAXNP")) h->fw_wave_maxnp = std::max(0, std::min(FWS_MAXNP, std::atoi(e)));
@@ -1374,7 +1393,7 @@ int tnco_hip_get_caches(tnco_hip_handle h, int64_t r, double* ccost, double* par
     if (ccost) ccost[i] = i < n ? 0.0 : hd.ccost;
     if (partial) partial[i] = i < n ? 0.0 : hd.partial;
     if (hyper && h->hyper && i >= n)
-      std::memcpy(hyper + (size_t)i * W, blk.data() + (size_t)(i - n) * BS + h->P.hoff, (size_t)W * 8);
+      std::memcpy(hyper + (size_t)i * W, blk.data() + (size_t)h->P.WOFF + (size_t)(i - n) * h->P.WS + h->P.hoff, (size_t)W * 8);
   }
   return TNCO_HIP_OK;
 }

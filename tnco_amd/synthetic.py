@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["random_regular_tn", "random_hyper_tn", "chain_tn", "sycamore53_tn", "Problem",
+__all__ = ["random_regular_tn", "random_hyper_tn", "chain_tn", "sycamore53_tn", "sycamore53_cz_tn", "Problem",
            "regular_problem", "sycamore_problem", "replica_seeds", "linear_betas"]
 
 
@@ -137,6 +137,51 @@ def sycamore53_tn(depth: int = 20, layout: str = "supremacy", dead=None, order: 
             wire[qa], wire[qb] = oa, ob
     for q in qubits:  # <x| on every qubit
         ts_inds.append([wire[q]])
+    return ts_inds, 2, ()
+
+
+def sycamore53_cz_tn(depth: int = 12, fuse: float | None = 4, seed: int = 0, order: str = "ABCDCDAB"):
+    """A hyper-index network as the reference's loader produces them: the Sycamore-53 lattice and coupler sequence
+    with DIAGONAL two-qubit gates (CZ, as in the 2018 supremacy proposals) and a layer of non-diagonal single-qubit
+    gates on every qubit before each cycle.  `decompose_hyper_inds` (tnco/utils/tn.py:827, on by default,
+    tnco/app/app.py:157,351-358) turns a diagonal gate into a tensor whose input and output leg on a wire are ONE
+    index: the CZ of qubits (a, b) is the 2-leg tensor [wire_a, wire_b], and a wire segment is an index held by the
+    single-qubit gates at its ends and by every CZ in between -- 2 or 3 tensors here.  `fuse` (default 4, the
+    loader's default, tnco/app/app.py:156): the random pre-contraction of tnco/utils/tn.py:598-824 (restated in
+    tnco_amd/app/tn.py) applied with `seed`; None: the raw network.
+
+    Returns (ts_inds, dims, output_inds); amplitude: no output indices."""
+    names = _SYCAMORE_LAYOUTS["supremacy"]
+    dead = _SYCAMORE_DEAD["supremacy"]
+    qubits = [(r, 2 * j + (r % 2)) for r in range(9) for j in range(6) if (r, 2 * j + (r % 2)) != dead]
+    qset = set(qubits)
+    patterns = {"A": [], "B": [], "C": [], "D": []}
+    for (r, c) in qubits:
+        for dc in (+1, -1):
+            other = (r + 1, c + dc)
+            if other in qset:
+                patterns[names[(r % 2, dc)]].append(((r, c), other))
+    ts_inds, n_idx, wire = [], 0, {}
+    for q in qubits:  # |0>
+        wire[q] = n_idx
+        ts_inds.append([n_idx])
+        n_idx += 1
+    for cycle in range(depth):
+        for q in qubits:  # non-diagonal single-qubit gate: a new wire segment
+            ts_inds.append([wire[q], n_idx])
+            wire[q] = n_idx
+            n_idx += 1
+        for qa, qb in patterns[order[cycle % len(order)]]:  # CZ, diagonal: both wires pass through
+            ts_inds.append([wire[qa], wire[qb]])
+    for q in qubits:  # <x|
+        ts_inds.append([wire[q]])
+    if fuse is not None:
+        from .app import tn as apptn
+        path = apptn.fuse(ts_inds, 2, fuse, output_inds=(), seed=seed)
+        ts_inds = [list(x) for x in apptn.contract(path, ts_inds, output_inds=(), dims=None)[0]] if path else ts_inds
+        used = sorted({i for t in ts_inds for i in t})
+        ren = {i: k for k, i in enumerate(used)}
+        ts_inds = [[ren[i] for i in t] for t in ts_inds if t] + [t for t in ts_inds if not t]
     return ts_inds, 2, ()
 
 

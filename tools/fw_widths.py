@@ -25,7 +25,8 @@ def popcounts(a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layout", default="supremacy")
-    ap.add_argument("--network", default="sycamore", help="sycamore | regular:<n> | hyper:<n>:<inds>")
+    ap.add_argument("--network", default="sycamore", help="sycamore | cz:<depth>:<fuse|raw> | regular:<n> | hyper:<n>:<inds>")
+    ap.add_argument("--frac", default=None, help="max_width as fractions of the median width of the greedy starts, e.g. 0.7,0.85 (instead of --widths)")
     ap.add_argument("--widths", default="28,32,40")
     ap.add_argument("--replicas", type=int, default=32768)
     ap.add_argument("--sweeps", type=int, default=500)
@@ -37,6 +38,11 @@ def main():
     if a.network == "sycamore":
         p = synthetic.sycamore_problem(a.depth, a.layout)
         name = f"Sycamore-53 depth-{a.depth} ({a.layout})"
+    elif a.network.startswith("cz:"):
+        _, depth, fz = a.network.split(":")
+        ts, dims, out = synthetic.sycamore53_cz_tn(int(depth), None if fz == "raw" else float(fz))
+        p = synthetic.Problem(ts, 2, out)
+        name = f"Sycamore-53 lattice, CZ gates decomposed into hyper-indices, depth {depth}, fuse {fz}"
     elif a.network.startswith("regular:"):
         p = synthetic.regular_problem(int(a.network.split(":")[1]), 11)
         name = a.network
@@ -50,6 +56,14 @@ def main():
     t0 = time.perf_counter()
     links = core.greedy_trees(p.ts_inds, p.n_inds, seeds, device=0)
     print(f"# greedy initial trees: {time.perf_counter() - t0:.2f} s", flush=True)
+    widths8 = []
+    for r in range(8):
+        m = p.node_masks(links[r, 0], links[r, 1])
+        widths8.append(int(popcounts(m).max()))
+    print(f"# widths of the first 8 greedy trees: {sorted(widths8)}; indices held by > 2 tensors: "
+          f"{sum(len(h) > 2 for h in p.holders)} of {p.n_inds}", flush=True)
+    if a.frac:
+        a.widths = ",".join(str(int(round(float(f) * float(np.median(widths8))))) for f in a.frac.split(","))
     betas = synthetic.linear_betas(0.0, 100.0, a.sweeps)
     if a.im:
         with core.BatchedOptimizer(p.leaf_masks, links, seeds, n_inds=p.n_inds, device=0) as opt:
