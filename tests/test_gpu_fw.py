@@ -462,17 +462,47 @@ def test_fw_one_wavefront_reslice_on_wide_networks(core, oracle_lib, monkeypatch
     assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1]) and np.array_equal(a[2], b[2])
 
 
-def test_fw_more_too_wide_tensors_than_the_one_wavefront_reslice_lists(core, oracle_lib, monkeypatch):
+@pytest.mark.parametrize("big", ["0", "1", None])
+def test_fw_more_too_wide_tensors_than_the_one_wavefront_reslice_lists(core, oracle_lib, monkeypatch, big):
     """400 tensors under a bound nearly every contraction exceeds: some 390 too-wide tensors per replica, more than
-    the 255 fw_wave_kernel lists -- with the form pinned (TNCO_HIP_FW_WAVE=1: the library would leave it)
-    every replica leaves that kernel for the traverse of fw_reslice_a_kernel and the full rebuild of
-    fw_reslice_b_kernel; against the oracle."""
+    the 255 the lean configuration of fw_wave_kernel lists -- with the form pinned (TNCO_HIP_FW_WAVE=1: the library
+    would leave it).  TNCO_HIP_FW_BIG=0: every replica leaves that kernel for the traverse of fw_reslice_a_kernel and
+    the full rebuild of fw_reslice_b_kernel; =1: the roomier configuration (1 023 tensors, ten count planes) takes
+    them; unset: the library switches to it after the first call.  Against the oracle each time."""
     monkeypatch.setenv("TNCO_HIP_FW_WAVE", "1")
+    if big is None:
+        monkeypatch.delenv("TNCO_HIP_FW_BIG", raising=False)
+    else:
+        monkeypatch.setenv("TNCO_HIP_FW_BIG", big)
     prob = H.regular_problem(400, graph_seed=9)
     seeds = H.replica_seeds(6, S=9)
     gpu = _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 30, 12), 4, chunks=[5, 7], every=3)
     how, nch = gpu.reslice_info()
-    assert (how == 0).all()  # (rebuilt in full: none was re-priced)
+    st = gpu.fw_stats()
+    if big == "0":
+        assert (how == 0).all() and st["too_many_wide"] == st["repriced"]  # (rebuilt in full: none was re-priced)
+    elif big == "1":  # (the few left: a too-wide tensor more than 64 levels below the root -- the ordering's keys are 64 bits)
+        assert st["too_many_wide"] < st["repriced"] and (how == 1).any()
+    else:
+        assert 0 < st["too_many_wide"] < st["repriced"] and (how == 1).any()  # (the first call's re-slices only)
+
+
+def test_fw_more_than_128_candidate_legs_on_the_one_wavefront_path(core, oracle_lib, monkeypatch):
+    """A 300-spoke hub made of three 100-spoke tensors (no LEAF is too wide) with the 300 rim tensors in a ring,
+    max_width 150: the contractions around the hub have 150..300 candidate legs -- beyond the 128 the parallel shuffle
+    of fw_wave_kernel draws at once; its roomier configuration lists up to 512 and runs the sequential shuffle for
+    those.  Against the oracle."""
+    monkeypatch.setenv("TNCO_HIP_FW_WAVE", "1")
+    monkeypatch.setenv("TNCO_HIP_FW_BIG", "1")
+    m = 300
+    hub = [list(range(100 * j, 100 * j + 100)) for j in range(3)]
+    hub[0].append(2 * m); hub[1] += [2 * m, 2 * m + 1]; hub[2].append(2 * m + 1)
+    ts = hub + [[i, m + i, m + (i + 1) % m] for i in range(m)]
+    prob = H.Problem(ts, 2)
+    seeds = H.replica_seeds(8, S=4)
+    gpu = _check(core, oracle_lib, prob, seeds, H.linear_betas(0, 30, 12), 150, chunks=[12], every=3)
+    st = gpu.fw_stats()
+    assert st["repriced"] > 0 and st["fell_back"] < st["repriced"]
 
 
 @pytest.mark.parametrize("wave", [True, False])

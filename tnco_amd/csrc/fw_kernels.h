@@ -1558,7 +1558,7 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_WAVES) void fw_reslice_kernel(
 // fw_reslice_a_kernel (lock-step, its own traverse), the full rebuild + the end of the sweep by
 // fw_reslice_b_kernel.
 // ---------------------------------------------------------------------------------------------
-constexpr int FWT_MAXD = 64;   // changed indices the re-pricing handles, 32 per pass over the paths (more: the full rebuild)
+template <bool BIG> constexpr int FWT_MAXD = BIG ? 128 : 64;  // changed indices the re-pricing handles, 32 per pass over the paths (more: the full rebuild)
 
 #ifdef TNCO_FWA_PROF  // (diagnostic build: shader cycles per wavefront of [generator init, too-wide counts, greedy pass], wavefronts, too-wide tensors of lane 0's replica)
 static __device__ unsigned long long g_fwa_prof[8];
@@ -1649,11 +1649,14 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_A_WAVES) void fw_reslice_a_ker
 //     left) + right whatever the order of evaluation, so the sums are the reference's bit for bit.  A replica
 //     that keeps the new slices rewrites its header array as whole lines.
 // ---------------------------------------------------------------------------------------------
-constexpr int FWO_MAXW = 256;   // too-wide tensors the wavefront form orders (more: the traverse inside fw_reslice_a_kernel)
-constexpr int FWT_JMAX = 16;    // internal nodes per lane at most: n - 1 <= 1024
-
+// BIG = false: up to 255 too-wide tensors per replica, 128 candidate legs per tensor -- the lean configuration (Sycamore-53:
+// 30-60 too-wide tensors of up to ~90 legs); BIG = true: up to 1 023 and 512 -- networks sliced far below their natural width
+// (1 000 tensors at 0.7 of the greedy width: hundreds of too-wide tensors of ~200 legs); more LDS and two more count planes.
+template <bool BIG> constexpr int FWO_MAXW = BIG ? 1024 : 256;   // too-wide tensors the wavefront form orders (more: fw_reslice_a_kernel's traverse)
+template <bool BIG> constexpr int FWS_MAXNP = BIG ? 512 : 128;   // candidate legs of one tensor (beyond 128: the sequential shuffle)
+template <bool BIG> constexpr int FWS_NPL = BIG ? 10 : 8;        // planes of the bit-sliced too-wide counts
+constexpr int FWT_JMAX = 16;     // internal nodes per lane at most: n - 1 <= 1024
 constexpr int FWS_MINCAP = 16;   // too-wide tensors whose legs stay in LDS at least (the wavefront form sizes its LDS for that)
-constexpr int FWS_MAXNP = 128;   // candidate legs of one tensor: two per lane
 
 // std::mt19937 for one wavefront: outputs [.., hi) of the CURRENT generation are in the ring (256 entries, batches
 // of 64 aligned to 64), words below `tw` of the state array are twisted.  A fill produces up to three batches in ONE
@@ -1761,22 +1764,25 @@ __device__ __forceinline__ uint32_t fws_rowscan(uint32_t v) {
 // A replica one of the steps cannot do leaves with nwide = -2 (fw_reslice_a_kernel traverses it) or with the
 // proposal written and fastflag = 0 (fw_reslice_b_kernel rebuilds it in full).
 // ---------------------------------------------------------------------------------------------
-constexpr size_t FWW_GS_FIXED = 192 * 8 + 1024 + (size_t)FWS_MAXNP * 3 + 64;  // shuffle steps per position, ring, candidates + swap targets (+ padding to 16)
 constexpr int FWH_MAXH = 7;      // tensors holding one index at most, for the re-pricing (more: the full rebuild)
-constexpr size_t FWW_HYPER_EXTRA = 64 * 8 * 2 * 2 + 64;  // per changed index 8 slots of (path start, leaf), + the holder counts
-__host__ __device__ inline size_t fww_lds_bytes(int n, int T, bool hyper = false) {  // T: lanes per mask (16, 32 or 64)
-  const size_t nip = (size_t)((n - 1 + 63) & ~63);
-  const size_t u1 = (size_t)FWO_MAXW * (8 + 2 + 2);                         // keys, nodes, depths
-  const size_t u3 = nip * 8 + 256 + 32 + (hyper ? FWW_HYPER_EXTRA : 0);     // masks / partial sums, change list, flags
+// re-pricing, per changed index: the two path starts (4 B) and joined / left (1 B); HYPER: 8 slots of (path start, leaf) + the holder count
+__host__ __device__ inline size_t fww_chg_bytes(bool hyper, bool big) { return (size_t)(big ? 128 : 64) * (4 + 1 + (hyper ? 8 * 2 * 2 + 1 : 0)) + 32; }
+// get_slices' fixed part: shuffle steps per position [64 + 128], ring [256], candidates + swap targets (+ padding to 16)
+__host__ __device__ inline size_t fww_gs_fixed(bool big) { return 192 * 8 + 1024 + (size_t)(big ? 512 : 128) * 3 + 64; }
+__host__ __device__ inline size_t fww_lds_bytes(int n, int T, bool hyper = false, bool big = false) {  // T: lanes per mask (16, 32 or 64)
+  const size_t nip = (size_t)((n - 1 + 63) & ~63), mw = big ? 1024 : 256;
+  const size_t u1 = mw * (8 + 2 + 2);                                       // keys, nodes, depths
+  const size_t u3 = nip * 8 + fww_chg_bytes(hyper, big);                    // masks / partial sums, change list, flags
   size_t body = nip * 8 + (u1 > u3 ? u1 : u3);
-  const size_t gs = FWW_GS_FIXED + (size_t)FWS_MINCAP * T * 8;              // get_slices at least
+  const size_t gs = fww_gs_fixed(big) + (size_t)FWS_MINCAP * T * 8;         // get_slices at least
   body = body > gs ? body : gs;
-  return (512 /* list */ + body + 15) & ~(size_t)15;
+  return (2 * mw /* list */ + body + 15) & ~(size_t)15;
 }
 // too-wide tensors whose legs get_slices keeps in LDS
-__host__ __device__ inline int fww_cap(int n, int T, bool hyper = false) {
-  const size_t c = (fww_lds_bytes(n, T, hyper) - 512 - FWW_GS_FIXED) / ((size_t)T * 8);
-  return (int)(c < (size_t)FWO_MAXW ? c : (size_t)FWO_MAXW);
+__host__ __device__ inline int fww_cap(int n, int T, bool hyper = false, bool big = false) {
+  const size_t mw = big ? 1024 : 256;
+  const size_t c = (fww_lds_bytes(n, T, hyper, big) - 2 * mw - fww_gs_fixed(big)) / ((size_t)T * 8);
+  return (int)(c < mw ? c : mw);
 }
 
 #ifdef TNCO_FWW_PROF  // (diagnostic build: shader cycles per replica between the steps of fw_wave_kernel)
@@ -1807,7 +1813,7 @@ __device__ __forceinline__ uint32_t fws_scan(uint32_t v, int lane) {
 
 // LOGT: lanes per leg mask (4, 5, 6: networks of at most 16, 32, 64 mask words); 64 >> LOGT tensors per load instruction
 // HYPER: indices held by more than two tensors (FwParams::holdern, up to FWH_MAXH each): the marks of the re-pricing below
-template <int J, int LOGT, bool HYPER>
+template <int J, int LOGT, bool HYPER, bool BIG>
 static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, const FwParams F, const int cap, const int maxnp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fww_smem[];
   FWW_T(w0_);
@@ -1816,33 +1822,36 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
   const int64_t r = blockIdx.x;
   const int n = P.n, N = P.N, ni = N - n, W = P.W, LK = F.I64 / 64;
   const int nip = (ni + 63) & ~63;
-  TNCO_LDS volatile uint16_t* wls = (TNCO_LDS volatile uint16_t*)fww_smem;                 // [256] too-wide tensors, post-order
+  constexpr int MW = FWO_MAXW<BIG>, MAXNP = FWS_MAXNP<BIG>, NPL = FWS_NPL<BIG>;
+  TNCO_LDS volatile uint16_t* wls = (TNCO_LDS volatile uint16_t*)fww_smem;                 // [MW] too-wide tensors, post-order
   // node i of the table: lo = left | right << 16; hi = parent | cost exponent << 16 | internal children (later: still to arrive) << 27
-  TNCO_LDS volatile uint32_t* lo = (TNCO_LDS volatile uint32_t*)(fww_smem + 512);          // [nip]
+  TNCO_LDS volatile uint32_t* lo = (TNCO_LDS volatile uint32_t*)(fww_smem + 2 * MW);       // [nip]
   TNCO_LDS uint32_t* hi = (TNCO_LDS uint32_t*)(lo + nip);                                  // [nip] (atomic arrivals)
   TNCO_LDS volatile uint32_t* hiv = (TNCO_LDS volatile uint32_t*)hi;
-  uint8_t* U = fww_smem + 512 + (size_t)nip * 8;                                           // the region behind the table
+  uint8_t* U = fww_smem + 2 * MW + (size_t)nip * 8;                                        // the region behind the table
   // ordering
-  TNCO_LDS volatile uint64_t* key = (TNCO_LDS volatile uint64_t*)U;                        // [FWO_MAXW]
-  TNCO_LDS volatile uint16_t* wnode = (TNCO_LDS volatile uint16_t*)(key + FWO_MAXW);       // [FWO_MAXW]
-  TNCO_LDS volatile uint16_t* dep = wnode + FWO_MAXW;                                      // [FWO_MAXW]
+  TNCO_LDS volatile uint64_t* key = (TNCO_LDS volatile uint64_t*)U;                        // [MW]
+  TNCO_LDS volatile uint16_t* wnode = (TNCO_LDS volatile uint16_t*)(key + MW);             // [MW]
+  TNCO_LDS volatile uint16_t* dep = wnode + MW;                                            // [MW]
   // get_slices: over the node table and the region (the table is rebuilt from the registers afterwards)
-  TNCO_LDS uint64_t* Mlo = (TNCO_LDS uint64_t*)(fww_smem + 512);                            // [64]  shuffle steps < 64 that target a position
+  TNCO_LDS uint64_t* Mlo = (TNCO_LDS uint64_t*)(fww_smem + 2 * MW);                         // [64]  shuffle steps < 64 that target a position
   TNCO_LDS uint64_t* Mhi = Mlo + 64;                                                       // [128] ... steps 64..127 (the first T words: the picks, afterwards)
   lds_vu32* ring = (lds_vu32*)(Mhi + 128);                                                 // [256]
-  lds_vu16* pos = (lds_vu16*)(ring + 256);                                                 // [FWS_MAXNP] candidate legs, ascending
-  TNCO_LDS volatile uint8_t* jL = (TNCO_LDS volatile uint8_t*)(pos + FWS_MAXNP);            // [FWS_MAXNP] the position step i swaps with
-  TNCO_LDS volatile uint64_t* cache = (TNCO_LDS volatile uint64_t*)(fww_smem + 512 + FWW_GS_FIXED);  // [cap][T] legs of the too-wide tensors
+  lds_vu16* pos = (lds_vu16*)(ring + 256);                                                 // [MAXNP] candidate legs, ascending
+  TNCO_LDS volatile uint8_t* jL = (TNCO_LDS volatile uint8_t*)(pos + MAXNP);                // [MAXNP] the position step i swaps with (np <= 128)
+  TNCO_LDS volatile uint64_t* cache = (TNCO_LDS volatile uint64_t*)(fww_smem + 2 * MW + fww_gs_fixed(BIG));  // [cap][T] legs of the too-wide tensors
   // re-pricing
   TNCO_LDS volatile double* Pn = (TNCO_LDS volatile double*)U;                             // [nip]
   TNCO_LDS uint32_t* on = (TNCO_LDS uint32_t*)U;                                           // [nip][2] (the same memory)
   TNCO_LDS volatile uint32_t* onv = (TNCO_LDS volatile uint32_t*)U;
-  TNCO_LDS volatile uint32_t* chgl = (TNCO_LDS volatile uint32_t*)(Pn + nip);              // [64] starts of the paths
-  TNCO_LDS volatile uint32_t* misc = chgl + 64;                                            // [8]
+  constexpr int MAXD = FWT_MAXD<BIG>;
+  TNCO_LDS volatile uint32_t* misc = (TNCO_LDS volatile uint32_t*)(Pn + nip);              // [8]
+  TNCO_LDS volatile uint32_t* chgl = misc + 8;                                             // [MAXD] starts of the paths
+  TNCO_LDS volatile uint8_t* pm = (TNCO_LDS volatile uint8_t*)(chgl + MAXD);               // [MAXD] 1: the index joins the slices, 0: it leaves
   // (HYPER) changed index o: its holders' path starts / leaves in slots 8 o .. 8 o + 7, their number | open << 7
-  TNCO_LDS volatile uint16_t* pstart = (TNCO_LDS volatile uint16_t*)(misc + 8);            // [64][8]
-  TNCO_LDS volatile uint16_t* pleaf = pstart + 512;                                        // [64][8]
-  TNCO_LDS volatile uint8_t* pcnt = (TNCO_LDS volatile uint8_t*)(pleaf + 512);             // [64]
+  TNCO_LDS volatile uint16_t* pstart = (TNCO_LDS volatile uint16_t*)(pm + MAXD);           // [MAXD][8]
+  TNCO_LDS volatile uint16_t* pleaf = pstart + MAXD * 8;                                   // [MAXD][8]
+  TNCO_LDS volatile uint8_t* pcnt = (TNCO_LDS volatile uint8_t*)(pleaf + MAXD * 8);        // [MAXD]
 
   // ---- everything that depends on nothing, in flight at once
   uint8_t* hb = P.blocks + r * P.RB;
@@ -1919,11 +1928,11 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
     const unsigned long long b = __ballot(wide);
     if (wide) {
       const int k = nw + __popcll(b & ((1ull << lane) - 1ull));
-      if (k < FWO_MAXW) wnode[k] = (uint16_t)(n + i);
+      if (k < MW) wnode[k] = (uint16_t)(n + i);
     }
     nw += __popcll(b);
   }
-  if (nw > 255) {
+  if (nw > MW - 1) {  // (a count fits NPL planes)
     leave_to_a();
     return;
   }
@@ -1951,7 +1960,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
       leave_to_a();
       return;
     }
-    for (int k = lane; k < 256; k += 64) wls[k] = (uint16_t)n;
+    for (int k = lane; k < MW; k += 64) wls[k] = (uint16_t)n;
     for (int k0 = 0; k0 < nw; k0 += 64) {
       const int k = k0 + lane;
       if (k < nw) {
@@ -1972,9 +1981,9 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
   __builtin_amdgcn_wave_barrier();
   const uint8_t* legs = P.blocks + r * P.RB + P.WOFF;
   const int WS = P.WS;
-  uint64_t pl[8];
+  uint64_t pl[NPL];
 #pragma unroll
-  for (int p = 0; p < 8; ++p) pl[p] = 0ull;
+  for (int p = 0; p < NPL; ++p) pl[p] = 0ull;
   uint32_t maxc = 0;
   uint64_t m[4];
   auto load16 = [&](int t0) {
@@ -2000,7 +2009,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
       maxc = c > maxc ? c : maxc;
       uint64_t carry = m[u];
 #pragma unroll
-      for (int p = 0; p < 8; ++p) {
+      for (int p = 0; p < NPL; ++p) {
         const uint64_t tt = pl[p] & carry;
         pl[p] ^= carry;
         carry = tt;
@@ -2015,12 +2024,12 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
   FWW_T(w3_);
 #pragma unroll
   for (int step = T; step <= 32; step <<= 1) {
-    uint64_t o[8];
+    uint64_t o[NPL];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) o[p] = fws_shflx64(pl[p], step);
+    for (int p = 0; p < NPL; ++p) o[p] = fws_shflx64(pl[p], step);
     uint64_t c = 0ull;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
+    for (int p = 0; p < NPL; ++p) {
       const uint64_t a = pl[p], b = o[p];
       pl[p] = a ^ b ^ c;
       c = (a & b) | (c & (a ^ b));
@@ -2101,7 +2110,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
       bool fast = true;
       uint32_t p0 = 0, p1 = 0;
       if (np >= 2) {
-        fast = rng.ensure((uint32_t)nd);
+        fast = np <= 128 && rng.ensure((uint32_t)nd);  // (more candidates, BIG only: the sequential shuffle below)
         if (fast) {
           const uint32_t raw = rng.peek((uint32_t)lane);
           const uint32_t i0 = (uint32_t)(base + 2 * lane);
@@ -2125,7 +2134,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
       // -- by count
       uint64_t alive = cand, taken = 0ull;
 #pragma unroll
-      for (int p = 7; p >= 0; --p) {
+      for (int p = NPL - 1; p >= 0; --p) {
         if (p < nplanes) {
           const uint64_t hi = alive & pl[p];
           const int c = __builtin_amdgcn_readfirstlane((int)gsum<LOGT>((uint32_t)__popcll(hi)));
@@ -2205,20 +2214,22 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
       __builtin_amdgcn_wave_barrier();
       FWW_T(g5_);
       FWW_ACC(4, g4_, g5_);
-      // the first `need` members of the tie group in shuffled order
+      // the first `need` members of the tie group in shuffled order, 64 final positions at a time
       const bool shuffled_in_place = !fast;
-      const int leg0 = lane < np ? (int)pos[shuffled_in_place ? lane : e0] : 0;
-      const int leg1 = lane + 64 < np ? (int)pos[shuffled_in_place ? lane + 64 : e1] : 0;
-      const uint64_t aw0 = fws_shfl64(alive, leg0 >> 6), aw1 = fws_shfl64(alive, leg1 >> 6);
-      const bool in0 = lane < np && ((aw0 >> (leg0 & 63)) & 1ull), in1 = lane + 64 < np && ((aw1 >> (leg1 & 63)) & 1ull);
-      const unsigned long long b0 = __ballot(in0), b1 = __ballot(in1);
-      const unsigned long long below = (1ull << lane) - 1ull;
-      const bool pick0 = in0 && (int)__popcll(b0 & below) < need;
-      const bool pick1 = in1 && (int)(__popcll(b0) + __popcll(b1 & below)) < need;
       if (lane < T) Mhi[lane] = 0ull;
       __builtin_amdgcn_wave_barrier();
-      if (pick0) __hip_atomic_fetch_or(&Mhi[leg0 >> 6], 1ull << (leg0 & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (pick1) __hip_atomic_fetch_or(&Mhi[leg1 >> 6], 1ull << (leg1 & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      int cum = 0;
+      for (int q = 0; q * 64 < np && cum < need; ++q) {
+        const int f = lane + 64 * q;
+        const int leg = f < np ? (int)pos[shuffled_in_place ? f : (q == 0 ? e0 : e1)] : 0;
+        const uint64_t aw = fws_shfl64(alive, leg >> 6);
+        const bool in = f < np && ((aw >> (leg & 63)) & 1ull);
+        const unsigned long long bq = __ballot(in);
+        if (in && cum + (int)__popcll(bq & below) < need)
+          __hip_atomic_fetch_or(&Mhi[leg >> 6], 1ull << (leg & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        cum += (int)__popcll(bq);
+      }
       __builtin_amdgcn_wave_barrier();
       ns |= taken | ((TNCO_LDS volatile uint64_t*)Mhi)[w];
       __builtin_amdgcn_wave_barrier();
@@ -2241,13 +2252,12 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
   // issued: a load behind a store waits for the store's acknowledgement too.
   uint32_t* chg = reinterpret_cast<uint32_t*>(F.delta_scr + r * 64);  // (word 0: the count, for tnco_hip_get_reslice_info)
   int nd;
-  uint64_t plus64, minus64;
   {
     uint64_t ch = g == 0 ? (ns ^ old) : 0ull;
     const uint32_t mine = (uint32_t)__popcll(ch);
     const uint32_t incl = fws_scan<LOGT>(mine, lane);
     nd = __builtin_amdgcn_readlane((int)incl, T - 1);
-    bool unsup = nd > FWT_MAXD;
+    bool unsup = nd > MAXD;
     int bits[4];
     int2 hold[4];
     uint4 holdn[HYPER ? 4 : 1];
@@ -2282,14 +2292,13 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
       if (l < n) lparL[l] = (uint16_t)(n + i);
       if (rr < n) lparL[rr] = (uint16_t)(n + i);
     }
-    uint64_t plus = 0ull, minus = 0ull;
     if (!unsup) {
       uint32_t off = incl - mine;
       auto entry = [&](int bit, int2 t12) {
         if (t12.x < 0) { unsup = true; return; }
         const int s1 = lparL[t12.x], s2 = t12.y < 0 ? 0xFFFF : (int)lparL[t12.y];
         chgl[off] = (uint32_t)s1 | ((uint32_t)s2 << 16);
-        if ((ns >> bit) & 1ull) plus |= 1ull << off; else minus |= 1ull << off;
+        pm[off] = (uint8_t)((ns >> bit) & 1ull);
         ++off;
       };
       // (HYPER) the index's entry of FwParams::holdern: count | open << 15, then the holders
@@ -2303,7 +2312,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
           pleaf[off * 8 + j] = (uint16_t)t;
           pstart[off * 8 + j] = lparL[t];
         }
-        if ((ns >> bit) & 1ull) plus |= 1ull << off; else minus |= 1ull << off;
+        pm[off] = (uint8_t)((ns >> bit) & 1ull);
         ++off;
       };
 #pragma unroll
@@ -2320,10 +2329,6 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
       }
     }
     unsup = __any(unsup);
-    const uint32_t a0 = gsum<LOGT>((uint32_t)plus), a1 = gsum<LOGT>((uint32_t)(plus >> 32));
-    const uint32_t b0 = gsum<LOGT>((uint32_t)minus), b1 = gsum<LOGT>((uint32_t)(minus >> 32));
-    plus64 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)a0) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)a1) << 32);
-    minus64 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)b0) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)b1) << 32);
     if (lane == 0) chg[0] = unsup ? 0xFFFFFFFFu : (uint32_t)nd;
     if (unsup) {  // more than FWT_MAXD indices, or an index held otherwise: the full rebuild
       if (lane == 0) {
@@ -2333,7 +2338,6 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
       return;
     }
   }
-  const int dbase = __popcll(plus64) - __popcll(minus64);
   FWW_T(w5_);
   // ---- the re-priced costs: path masks cleared, arrival counters = internal children
   uint32_t startmask = 0;
@@ -2352,7 +2356,15 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
   }
   const int log2d = P.log2d;
   for (int pass = 0; pass * IPP < nd || pass == 0; ++pass) {
-    const uint32_t plus = (uint32_t)(plus64 >> (IPP * pass)), minus = (uint32_t)(minus64 >> (IPP * pass));
+    uint32_t plus, minus;  // which of this pass's 32 indices join / leave the slices
+    {
+      const int idx = IPP * pass + lane;
+      const bool mine_ = lane < IPP && idx < nd;
+      const bool joins = mine_ && pm[mine_ ? idx : 0] != 0;
+      plus = (uint32_t)__ballot(joins);
+      minus = (uint32_t)__ballot(mine_ && !joins);
+    }
+    const int dbase = __popc(plus) - __popc(minus);
     if (pass) {
       for (int i = lane; i < ni; i += GW) { onv[2 * i] = 0; onv[2 * i + 1] = 0; }
     }
@@ -2442,7 +2454,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
         const uint32_t both_below = (l >= n ? bl : 0u) | (rr >= n ? br : 0u);
         in_u = (a ^ b) | (a & b & ~both_below);
       }
-      const int dex = (pass ? 0 : dbase) - __popc(in_u & plus) + __popc(in_u & minus);
+      const int dex = dbase - __popc(in_u & plus) + __popc(in_u & minus);
       const int ne = (int)((h >> 16) & 0x7FFu) + log2d * dex;
       bad = bad || ne <= 0 || ne >= 2047;  // (also between the passes: the full rebuild decides then)
       hiv[i] = (h & 0xF800FFFFu) | ((uint32_t)(ne & 0x7FF) << 16);

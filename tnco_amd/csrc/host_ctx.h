@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 #include "sa_kernels.h"
@@ -30,13 +31,21 @@ struct tnco_hip_ctx {
   bool fw_wave_capable = false, fw_wave_on = false;
   int fw_wave_maxnp = 128;  // ... candidate legs of one tensor it handles (test knob TNCO_HIP_FWS_MAXNP)
   int fw_wave_cap = 0;      // ... too-wide tensors whose legs it keeps in LDS (fww_cap; test knob TNCO_HIP_FWS_CAP)
+  int fw_wave_lanes = 16;   // ... lanes per leg mask
+  bool fw_wave_big = false, fw_wave_big_ok = false;  // ... its roomier configuration (fw_kernels.h, BIG): in use / its LDS fits
+  void set_wave_config() {
+    fw_wave_cap = tnco::fww_cap(P.n, fw_wave_lanes, hyper, fw_wave_big);
+    if (const char* e = std::getenv("TNCO_HIP_FWS_CAP")) fw_wave_cap = std::max(1, std::min(fw_wave_cap, std::atoi(e)));  // (test knob: legs from memory)
+    fw_wave_maxnp = fw_wave_big ? 512 : 128;
+    if (const char* e = std::getenv("TNCO_HIP_FWS_MAXNP")) fw_wave_maxnp = std::max(0, std::min(fw_wave_maxnp, std::atoi(e)));
+  }
   int64_t fw_wave_reslices = 0;  // re-slices launched in that form since the count was read
   int fw_single_calls = 0;        // calls in the other mode since the last probe
   int fw_probe_wait = 4;          // ... before the next probe (doubles after a probe that failed)
   // tnco_hip_get_fw_stats: [0] replica re-slices launched in the re-pricing form, [1] of those left to the full rebuild,
   // [2..4] why (FwParams::slowstat[1..3]), [5] replica re-slices launched in the walk + full-rebuild form
   int64_t fw_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long fw_slow_pending = 0;  // fall-backs collected since tnco_hip_run_fw last chose a form
+  unsigned long long fw_slow_pending = 0, fw_slow_wide_pending = 0;  // fall-backs collected since tnco_hip_run_fw last chose a form
   tnco::FwParams F{};
   std::vector<void*> allocs;
   int64_t bytes = 0;
@@ -71,7 +80,7 @@ struct tnco_hip_ctx {
   int64_t kind_launches[TNCO_KINDS] = {0, 0, 0, 0};
 
   // the device's fall-back counters since the last look -> fw_stats; *slow = their total (may be NULL)
-  hipError_t collect_fw_stats(unsigned long long* slow) {
+  hipError_t collect_fw_stats(unsigned long long* slow, unsigned long long* slow_wide = nullptr) {
     unsigned long long c[4] = {0, 0, 0, 0};
     hipError_t e = hipMemcpy(c, F.slowstat, 32, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return e;
@@ -79,9 +88,12 @@ struct tnco_hip_ctx {
     if (e != hipSuccess) return e;
     for (int i = 0; i < 4; ++i) fw_stats[1 + i] += (int64_t)c[i];
     fw_slow_pending += c[0];
+    fw_slow_wide_pending += c[1];
     if (slow) {  // (the caller that decides the next call's form: everything since it last asked, whoever collected it)
       *slow = fw_slow_pending;
       fw_slow_pending = 0;
+      if (slow_wide) *slow_wide = fw_slow_wide_pending;
+      fw_slow_wide_pending = 0;
     }
     return hipSuccess;
   }

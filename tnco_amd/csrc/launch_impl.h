@@ -129,18 +129,18 @@ void launch_fw_reslice_lk(tnco_hip_ctx* h, int prewalked) {
     // and of the ones it could not re-price + the end of the sweep for everybody
     // lanes per leg mask: the L * K words of this translation unit's networks fit 16, 32 or 64 lanes
     constexpr int LKW = (1 << LOG2L) * K, LT = LKW <= 16 ? 4 : (LKW <= 32 ? 5 : 6);
-    const size_t lb = fww_lds_bytes(h->P.n, 1 << LT, h->hyper);
+    const size_t lb = fww_lds_bytes(h->P.n, 1 << LT, h->hyper, h->fw_wave_big);
     const int need = (h->P.n - 1 + 63) / 64;
-#define TNCO_FWW(JJ, HY) hipLaunchKernelGGL((fw_wave_kernel<JJ, LT, HY>), dim3((unsigned)h->P.R), dim3(64), lb, h->stream, h->P, h->F, h->fw_wave_cap, h->fw_wave_maxnp)
-#define TNCO_FWW_J(HY)                                                                                        \
-    if (need <= 2) TNCO_FWW(2, HY); else if (need <= 4) TNCO_FWW(4, HY); else if (need <= 6) TNCO_FWW(6, HY); \
-    else if (need <= 9) TNCO_FWW(9, HY); else if (need <= 12) TNCO_FWW(12, HY); else TNCO_FWW(16, HY)
+#define TNCO_FWW(JJ, HY, BG) hipLaunchKernelGGL((fw_wave_kernel<JJ, LT, HY, BG>), dim3((unsigned)h->P.R), dim3(64), lb, h->stream, h->P, h->F, h->fw_wave_cap, h->fw_wave_maxnp)
+#define TNCO_FWW_J(HY, BG)                                                                                                \
+    if (need <= 2) TNCO_FWW(2, HY, BG); else if (need <= 4) TNCO_FWW(4, HY, BG); else if (need <= 6) TNCO_FWW(6, HY, BG); \
+    else if (need <= 9) TNCO_FWW(9, HY, BG); else if (need <= 12) TNCO_FWW(12, HY, BG); else TNCO_FWW(16, HY, BG)
     if (h->hyper) {
-      TNCO_FWW_J(true);
+      if (h->fw_wave_big) { TNCO_FWW_J(true, true); } else { TNCO_FWW_J(true, false); }
       hipLaunchKernelGGL((fw_reslice_a_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, h->F, 2);
       hipLaunchKernelGGL((fw_reslice_b_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, h->F, 1);
     } else {
-      TNCO_FWW_J(false);
+      if (h->fw_wave_big) { TNCO_FWW_J(false, true); } else { TNCO_FWW_J(false, false); }
       hipLaunchKernelGGL((fw_reslice_a_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, 2);
       hipLaunchKernelGGL((fw_reslice_b_kernel<LOG2L, K, false>), grid, dim3(256), 0, h->stream, h->P, h->F, 1);
     }

@@ -915,10 +915,12 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       if (F.leaf_wide) h->fw_wave_capable = false;  // (a too-wide leaf has no header to carry its width)
       if (h->fw_wave_capable) {
         h->fw_wave_on = true;
-        h->fw_wave_cap = fww_cap(n, lanes_per_mask, h->hyper);
-        if (const char* e = std::getenv("TNCO_HIP_FWS_CAP")) h->fw_wave_cap = std::max(1, std::min(h->fw_wave_cap, std::atoi(e)));  // (test knob: legs from memory)
-        h->fw_wave_maxnp = FWS_MAXNP;
-        if (const char* e = std::getenv("TNCO_HIP_FWS_MAXNP")) h->fw_wave_maxnp = std::max(0, std::min(FWS_MAXNP, std::atoi(e)));
+        h->fw_wave_lanes = lanes_per_mask;
+        // the roomier configuration (up to 1 023 too-wide tensors, 512 candidate legs) where its LDS fits; taken when the
+        // lean one leaves replicas behind for that reason (tnco_hip_run_fw), or from the start with TNCO_HIP_FW_BIG=1
+        h->fw_wave_big_ok = fww_lds_bytes(n, lanes_per_mask, h->hyper, true) <= 64 * 1024;
+        h->fw_wave_big = h->fw_wave_big_ok && std::getenv("TNCO_HIP_FW_BIG") && std::atoi(std::getenv("TNCO_HIP_FW_BIG")) != 0;
+        h->set_wave_config();
       }
       F.fast_ok = h->fw_wave_on ? 1 : 0;
     }
@@ -1162,14 +1164,24 @@ int tnco_hip_run_fw(tnco_hip_handle h, int prob_kind, const double* betas, int64
   HIP_TRY(h->sync_all());
   if (h->fw_wave_capable) {
     // The wavefront form or the general one (walk + full rebuild) for this call?  The first wins while fewer than
-    // ~2 % of the replicas fall back to the full rebuild (more changed indices than it re-prices: random initial
+    // ~3 % of the replicas fall back to the full rebuild (more changed indices than it re-prices: random initial
     // trees early in a schedule) -- a fall-back costs the full rebuild on top.  The previous call's kernels are
     // complete here: its fall-backs are counted, or, after 4, 8, 16 ... calls in the other form, this call probes again.
     if (h->fw_wave_reslices > 0) {
-      unsigned long long slow = 0;
-      HIP_TRY(h->collect_fw_stats(&slow));
+      unsigned long long slow = 0, slow_wide = 0;
+      HIP_TRY(h->collect_fw_stats(&slow, &slow_wide));
       const bool was_on = h->fw_wave_on;
-      h->fw_wave_on = (double)slow < 0.02 * (double)h->fw_wave_reslices * (double)h->P.R;
+      // (a replica that falls back costs its wavefront of fw_reslice_b_kernel the full rebuild -- sixteen replicas in lock
+      //  step: at 3 % every third wavefront.  The roomier configuration serves networks whose full rebuild is tens of times
+      //  the wavefront form: it keeps winning further out.)
+      const double lim = (h->fw_wave_big ? 0.10 : 0.03) * (double)h->fw_wave_reslices * (double)h->P.R;
+      if (!h->fw_wave_big && h->fw_wave_big_ok && (double)slow_wide >= lim && !std::getenv("TNCO_HIP_FW_BIG")) {
+        // too many / too leggy too-wide tensors for the lean configuration: the roomier one before giving up the form
+        h->fw_wave_big = true;
+        h->set_wave_config();
+        slow -= slow_wide;
+      }
+      h->fw_wave_on = (double)slow < lim;
       h->fw_probe_wait = h->fw_wave_on ? 4 : (was_on && h->fw_single_calls == 0 ? std::min(64, 2 * h->fw_probe_wait) : h->fw_probe_wait);
       h->fw_wave_reslices = 0;
       h->fw_single_calls = 0;
