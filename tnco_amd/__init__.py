@@ -7,4 +7,4 @@ HIP kernels for gfx950 behind a C ABI (include/tnco_hip.h).  There is no CPU fal
 """
 from .app import Optimizer  # noqa: F401
 
-__version__ = "0.2"
+__version__ = "0.5"  # (= the library: tnco_hip_version)
