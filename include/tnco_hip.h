@@ -139,7 +139,7 @@ int tnco_hip_get_slices_many(tnco_hip_handle h, int64_t k, const int64_t* replic
 
 /* Diagnostics of the LAST re-slice of every replica (no reference counterpart; tests pick the replicas whose
  * re-slice took a rare path and compare exactly those with the oracle): how[r] = 1 the cost cache was re-priced
- * (fw_wave_kernel / fw_tree_kernel / fw_delta_kernel), 0 it was rebuilt in full (or the replica has no slices); n_changed[r] = indices
+ * (fw_wave_kernel), 0 it was rebuilt in full (or the replica has no slices); n_changed[r] = indices
  * by which the proposed slices differed from the current ones (-1: not recorded -- the single-kernel form, or more
  * than the re-pricing handles).  Either may be NULL.  EINVAL for a handle without re-pricing. */
 int tnco_hip_get_reslice_info(tnco_hip_handle h, int32_t* how, int32_t* n_changed);
@@ -240,7 +240,7 @@ int tnco_hip_kernel_time(tnco_hip_handle h, double* ms, int64_t* launches, int r
 /* The same time split by kernel: [0] sa_run_kernel (Optimizer::update, infinite memory),
  * [1] the moves of the finite-width optimizer (finite_width/greedy/optimizer.hpp:130-331), [2] its re-slice
  * (:359-389: get_slices, the cost cache rebuilt or re-priced, the end of the sweep), [3] what orders the too-wide
- * tensors for get_slices (greedy/utils.hpp:62: the walk kernels, or fw_order_kernel; 0 when the whole re-slice of a
+ * tensors for get_slices (greedy/utils.hpp:62: fw_walk2_kernel; 0 when the whole re-slice of a
  * replica is one wavefront of fw_wave_kernel: counted under [2]); launches4 = launches of each -- for a finite-width
  * handle that runs its halves on two streams, launches PER STREAM (every event is one launch on each stream; the counts
  * are whole numbers because both streams launch the same sequence).  Either array ([4]) may be NULL. */

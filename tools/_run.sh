@@ -1,10 +1,9 @@
-timeout 1200 python -m pytest tests/test_gpu_fw.py tests/test_gpu_restore.py tests/test_gpu_app.py -x -q 2>&1 | tail -5
-for g in 1 2; do
-  TNCO_HIP_GROUPS=$g timeout 200 python bench.py --workload fw --pmc 0 --cpu-sample 0 --steps 10 --warmup 2 > /tmp/fw_$g.json 2>/dev/null
-  python - <<PY
-import json
-j=json.load(open("/tmp/fw_$g.json"))
-r=j["roofline"]
-print("groups", $g, "%.3e"%j["value"], "ms/step %.2f"%j["ms_per_step"], {k:(round(v["ms_per_step"],3)) for k,v in r["kernels"].items()}, j["config"]["best_log10_flops"])
-PY
-done
+mkdir -p gpurun_out/r04
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+( echo "# tools/fuzz_gpu.py on the round-4 library (tnco_hip 0.5), fresh random cases against the oracle"
+  echo "## --cases 1200 --seed 41 (both optimizers, 4..40 tensors, every option)"; timeout 1500 python tools/fuzz_gpu.py --cases 1200 --seed 41 2>&1 | tail -4
+  echo "## --cases 500 --seed 42 --which fw --nmin 40 --nmax 130 --dims two (hyper-index networks on the one-wavefront re-slice)"; timeout 1500 python tools/fuzz_gpu.py --cases 500 --seed 42 --which fw --nmin 40 --nmax 130 --dims two 2>&1 | tail -4
+  echo "## TNCO_HIP_FW_BIG=1 --cases 300 --seed 43 --which fw --nmin 20 --nmax 90 --dims two (its roomier configuration)"; TNCO_HIP_FW_BIG=1 timeout 1500 python tools/fuzz_gpu.py --cases 300 --seed 43 --which fw --nmin 20 --nmax 90 --dims two 2>&1 | tail -4
+  echo "## TNCO_HIP_FW_WAVE=0 --cases 300 --seed 44 --which fw --nmin 20 --nmax 90 (walk + full rebuild on the split layout, hyper legs included)"; TNCO_HIP_FW_WAVE=0 timeout 1500 python tools/fuzz_gpu.py --cases 300 --seed 44 --which fw --nmin 20 --nmax 90 2>&1 | tail -4
+) > gpurun_out/r04/fuzz.txt 2>&1
+cat gpurun_out/r04/fuzz.txt
