@@ -307,13 +307,14 @@ def test_config5_from_the_reference_starts_at_scale_against_the_oracle(core, ora
     from tnco_amd import synthetic as syn
     orc = oracle_lib
     monkeypatch.delenv("TNCO_HIP_FW_WAVE", raising=False)
-    R = 32768
+    R, MW = 32768, 32  # (max_width as in bench.py's finite-width leg)
     p = syn.sycamore_problem(20)
+    assert p.n == 536 and p.n_inds == 913  # the supremacy sequence
     seeds = np.asarray(syn.replica_seeds(R))
     links = core.greedy_trees(p.ts_inds, p.n_inds, seeds, device=0)
     betas = H.linear_betas(0, 100, 1200)[:40]
     rare = set()
-    with core.BatchedOptimizer(p.leaf_masks, links, seeds, n_inds=p.n_inds, max_width=40) as gpu:
+    with core.BatchedOptimizer(p.leaf_masks, links, seeds, n_inds=p.n_inds, max_width=MW) as gpu:
         for c in (1, 10, 10, 10, 9):  # every chunk but the last ends right after a re-slicing sweep
             lo = gpu._steps_done
             gpu.run(betas[lo:lo + c], update_slices_every=10)
@@ -328,7 +329,7 @@ def test_config5_from_the_reference_starts_at_scale_against_the_oracle(core, ora
         ids = sorted(rare)[:96] + [int(x) for x in rng.choice(R, 64, replace=False)]
         tot, mn = gpu.costs()
         for r in ids:
-            o = H.make_oracle(orc, p, links[r], seeds[r], max_width=40)
+            o = H.make_oracle(orc, p, links[r], seeds[r], max_width=MW)
             o.run(orc.PROB_MH, betas, update_slices_every=10)
             H.assert_replica_equal(gpu, r, o)
             assert tot[r] == o.total_cost and mn[r] == o.min_total_cost
@@ -373,8 +374,8 @@ def test_get_slices_per_wavefront_equals_the_lockstep_kernel(core, monkeypatch):
     form (TNCO_HIP_FW_WAVE=0: fw_walk2_kernel | fw_reslice_kernel -- get_slices of sixteen replicas per wavefront in
     lock step, the cost cache rebuilt from the legs) on the config-5 network, 4 096 replicas x 60 sweeps -- some 5 000
     outputs of every generator, so the 624-word generations end inside shuffles -- and with its knobs turned so that
-    the rare paths are the common ones: ONE tensor's legs kept in LDS between the passes, the others re-read from
-    memory with the next group's request in flight (TNCO_HIP_FWS_CAP=1), and tensors with more than 44 candidate
+    the rare paths are the common ones: NO tensor's legs kept in LDS, all of them read from memory at every visit
+    with the next group's request in flight (TNCO_HIP_FWS_CAP=0), and tensors with more than 44 candidate
     legs left to fw_reslice_a_kernel (TNCO_HIP_FWS_MAXNP=44: the two kernels share a launch).  Totals, best totals,
     slices, best slices and generator states identical."""
     from tnco_amd import synthetic as syn
@@ -399,7 +400,7 @@ def test_get_slices_per_wavefront_equals_the_lockstep_kernel(core, monkeypatch):
 
     ref = run({"TNCO_HIP_FW_WAVE": "0"})
     assert ref[3]["repriced"] == 0 and ref[3]["full_rebuild_form"] == 6 * R
-    for env in ({}, {"TNCO_HIP_FWS_CAP": "1"}, {"TNCO_HIP_FWS_MAXNP": "44"}):
+    for env in ({}, {"TNCO_HIP_FWS_CAP": "0"}, {"TNCO_HIP_FWS_CAP": "8"}, {"TNCO_HIP_FWS_MAXNP": "44"}):
         got = run(dict(env, TNCO_HIP_FW_WAVE="1"))
         assert got[3]["repriced"] == 6 * R and got[3]["full_rebuild_form"] == 0, env
         if "TNCO_HIP_FWS_MAXNP" in env:

@@ -1781,8 +1781,9 @@ __host__ __device__ inline size_t fww_lds_bytes(int n, int T, bool hyper = false
 // too-wide tensors whose legs get_slices keeps in LDS
 __host__ __device__ inline int fww_cap(int n, int T, bool hyper = false, bool big = false) {
   const size_t mw = big ? 1024 : 256;
-  const size_t c = (fww_lds_bytes(n, T, hyper, big) - 2 * mw - fww_gs_fixed(big)) / ((size_t)T * 8);
-  return (int)(c < mw ? c : mw);
+  size_t c = (fww_lds_bytes(n, T, hyper, big) - 2 * mw - fww_gs_fixed(big)) / ((size_t)T * 8);
+  c = c < mw ? c : mw;
+  return (int)(c & ~(size_t)7);  // (whole instructions of the LDS-direct loads: up to 8 tensors each)
 }
 
 #ifdef TNCO_FWW_PROF  // (diagnostic build: shader cycles per replica between the steps of fw_wave_kernel)
@@ -1869,6 +1870,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
   uint32_t tl[J], th[J];
   int32_t iw[J];
   bool widej[J];
+  double wmax = 0.0;  // the widest too-wide tensor of this lane's nodes: legs = width / log2(d) bounds its candidate legs
   {
     int4 hd[J];
     uint32_t ce[J];
@@ -1893,6 +1895,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
       iw[j] = hd[j].w;
       const double wv = F.width_f32 ? (double)__int_as_float(hd[j].w) : wd[j];
       widej[j] = (j * GW + lane < ni) && wv > F.max_width;
+      if (widej[j] && wv > wmax) wmax = wv;
     }
   }
   if (lane == 0) F.fastflag[r] = 0;
@@ -1932,7 +1935,9 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
     }
     nw += __popcll(b);
   }
-  if (nw > MW - 1) {  // (a count fits NPL planes)
+  // (more too-wide tensors than the counts' planes hold, or a tensor with more legs -- hence possibly more candidate
+  //  legs -- than the shuffle takes: nothing has been drawn yet)
+  if (nw > MW - 1 || __any(wmax > F.log2d * (double)maxnp + 0.5)) {
     leave_to_a();
     return;
   }
@@ -1984,42 +1989,59 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
   uint64_t pl[NPL];
 #pragma unroll
   for (int p = 0; p < NPL; ++p) pl[p] = 0ull;
-  uint32_t maxc = 0;
+  // The legs of the first `cap` too-wide tensors go STRAIGHT into LDS (global_load_lds, 16 bytes per lane: 1 KB = TPI
+  // tensors per instruction), all requests in one flight together with the generator's first batches -- through
+  // registers it took a round trip per sixteen tensors (three on the Sycamore network) before the counting could start.
+  constexpr int LPT = T / 2, TPI = 64 / LPT;  // lanes per tensor at 16 bytes each; tensors per instruction
+  const int nres = nw < cap ? nw : cap;
+  for (int t0 = 0; t0 < nres; t0 += TPI) {  // (cap is a multiple of TPI: the last instruction stays inside the cache)
+    const int t = t0 + lane / LPT;
+    const int node = wls[t < nw ? t : nw - 1];
+    const uint8_t* src = legs + (int64_t)(node - n) * WS + 16 * (lane % LPT);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(cache + (size_t)t0 * T), 16, 0, 0);
+  }
   uint64_t m[4];
-  auto load16 = [&](int t0) {
+  auto load16 = [&](int t0) {  // four rows of tensors from LDS, or (beyond the cache) from memory
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int t = t0 + TPL * u + g;
-      const int node = wls[t < nw ? t : 0];
       m[u] = 0ull;
-      if (t < nw && has) m[u] = *reinterpret_cast<const uint64_t*>(legs + (int64_t)(node - n) * WS + 8 * w);
+      if (t < nw && has) {
+        if (t < nres) m[u] = cache[t * T + w];
+        else m[u] = *reinterpret_cast<const uint64_t*>(legs + (int64_t)((int)wls[t] - n) * WS + 8 * w);
+      }
     }
   };
-  load16(0);
   RngWave rng;
   rng.init(P.mt + r * 624, ring, mti0, mtw0, lane);
   if (nw > 0) rng.fill();
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the legs have landed in LDS)
+  __builtin_amdgcn_wave_barrier();
+  // Every index belongs to one lane (bit b of its word), so the too-wide counts are kept there, bit-sliced: plane p
+  // holds bit p of the lane's 64 counters.  Four tensors are added per step with carry-save adders (three 3:2
+  // compressors: ones, twos, one carry of weight four), the carry then ripples through the planes from 2 up --
+  // 16 operations per tensor instead of the 24 of a ripple-carry per tensor.
+  auto csa = [](uint64_t a, uint64_t b, uint64_t c, uint64_t& sum, uint64_t& carry) {
+    const uint64_t x = a ^ b;
+    sum = x ^ c;
+    carry = (a & b) | (x & c);
+  };
   for (int t0 = 0; t0 < nw; t0 += 4 * TPL) {
-    if (t0) load16(t0);
+    load16(t0);
+    uint64_t s1, c1, s2, c2, s4, c4;
+    csa(pl[0], m[0], m[1], s1, c1);
+    csa(s1, m[2], m[3], s2, c2);
+    pl[0] = s2;
+    csa(pl[1], c1, c2, s4, c4);
+    pl[1] = s4;
+    uint64_t carry = c4;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int t = t0 + TPL * u + g;
-      if (t < nw && t < cap) cache[t * T + w] = m[u];
-      const uint32_t c = gsum<LOGT>((uint32_t)__popcll(m[u] & ~skip));
-      maxc = c > maxc ? c : maxc;
-      uint64_t carry = m[u];
-#pragma unroll
-      for (int p = 0; p < NPL; ++p) {
-        const uint64_t tt = pl[p] & carry;
-        pl[p] ^= carry;
-        carry = tt;
-      }
+    for (int p = 2; p < NPL; ++p) {
+      const uint64_t tt = pl[p] & carry;
+      pl[p] ^= carry;
+      carry = tt;
     }
-  }
-  if (gmax<6>(maxc) > (uint32_t)maxnp) {  // (nothing drawn yet; the generator's words twisted ahead stay)
-    if (lane == 0) rs->mtw = (int)rng.tw;
-    leave_to_a();
-    return;
   }
   FWW_T(w3_);
 #pragma unroll
@@ -2064,8 +2086,9 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
       const int t = t0 + g;
       uint64_t x = 0ull;
       if (t < nw) {
-        if (t < cap) x = cache[t * T + w];
-        else if (has) x = *reinterpret_cast<const uint64_t*>(legs + (int64_t)((int)wls[t] - n) * WS + 8 * w);
+        if (!has) x = 0ull;  // (LDS holds whole records: the words beyond W are padding)
+        else if (t < cap) x = cache[t * T + w];
+        else x = *reinterpret_cast<const uint64_t*>(legs + (int64_t)((int)wls[t] - n) * WS + 8 * w);
       }
       return x;
     };

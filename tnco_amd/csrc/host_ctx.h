@@ -35,7 +35,7 @@ struct tnco_hip_ctx {
   bool fw_wave_big = false, fw_wave_big_ok = false;  // ... its roomier configuration (fw_kernels.h, BIG): in use / its LDS fits
   void set_wave_config() {
     fw_wave_cap = tnco::fww_cap(P.n, fw_wave_lanes, hyper, fw_wave_big);
-    if (const char* e = std::getenv("TNCO_HIP_FWS_CAP")) fw_wave_cap = std::max(1, std::min(fw_wave_cap, std::atoi(e)));  // (test knob: legs from memory)
+    if (const char* e = std::getenv("TNCO_HIP_FWS_CAP")) fw_wave_cap = std::max(0, std::min(fw_wave_cap, std::atoi(e))) & ~7;  // (test knob: legs from memory)
     fw_wave_maxnp = fw_wave_big ? 512 : 128;
     if (const char* e = std::getenv("TNCO_HIP_FWS_MAXNP")) fw_wave_maxnp = std::max(0, std::min(fw_wave_maxnp, std::atoi(e)));
   }
