@@ -2107,7 +2107,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
       const int t = j + g;
       const uint64_t sx = mm & ~ns;
       const uint32_t cnt = gsum<LOGT>((uint32_t)__popcll(sx));
-      const bool wide = t < nw && g > gdone && fw_wr(F, F.log2d * (double)cnt) > F.max_width;
+      const bool wide = t < nw && g > gdone && (int)cnt > capw;  // (log2(d) * cnt > max_width: whole numbers, exact in either width type)
       const unsigned long long bal = __ballot(wide);
       if (bal == 0ull) {
         j += TPL;
@@ -2145,9 +2145,14 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
           if (__any(rej)) {
             fast = false;
           } else {
-            const uint32_t x = (uint32_t)(product >> 32);
-            p0 = x / (i0 + 2u);
-            p1 = x - p0 * (i0 + 2u);
+            // x < (i0 + 1) (i0 + 2) <= 128 * 129: the quotient through a float reciprocal, one step of correction either way
+            const uint32_t x = (uint32_t)(product >> 32), dv = i0 + 2u;
+            uint32_t q = (uint32_t)((float)x * __frcp_rn((float)dv));
+            int rem = (int)x - (int)(q * dv);
+            if (rem < 0) { q -= 1u; rem += (int)dv; }
+            else if (rem >= (int)dv) { q += 1u; rem -= (int)dv; }
+            p0 = q;
+            p1 = (uint32_t)rem;
             rng.advance((uint32_t)nd);
           }
         }
