@@ -553,7 +553,7 @@ __device__ __forceinline__ int fw_nbig_at(const int32_t* n_big, bool nb8, int x)
   return nb8 ? (int)reinterpret_cast<const uint8_t*>(n_big)[x] : n_big[x];
 }
 
-#if (defined(TNCO_PROFILE) && TNCO_PROFILE == 4) || defined(TNCO_FWA_PROF)  // cycles inside the greedy pass: [scan, positions, shuffle, keys + picks]
+#if defined(TNCO_PROFILE) && TNCO_PROFILE == 4  // cycles inside the greedy pass: [scan, positions, shuffle, keys + picks]
 #define FW_GP_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define FW_GP_ADD(i, a, b) do { if (cnt) cnt[i] += (b) - (a); } while (0)
 #define FW_GP_COUNT(i, x)
@@ -1560,9 +1560,6 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_WAVES) void fw_reslice_kernel(
 // ---------------------------------------------------------------------------------------------
 template <bool BIG> constexpr int FWT_MAXD = BIG ? 128 : 64;  // changed indices the re-pricing handles, 32 per pass over the paths (more: the full rebuild)
 
-#ifdef TNCO_FWA_PROF  // (diagnostic build: shader cycles per wavefront of [generator init, too-wide counts, greedy pass], wavefronts, too-wide tensors of lane 0's replica)
-static __device__ unsigned long long g_fwa_prof[8];
-#endif
 #ifndef TNCO_FW_RESLICE_A_WAVES
 #define TNCO_FW_RESLICE_A_WAVES TNCO_FW_RESLICE_WAVES
 #endif
@@ -1599,27 +1596,10 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_A_WAVES) void fw_reslice_a_ker
 #pragma unroll
   for (int k = 0; k < K; ++k) slices.w[k] = sl[v.widx(k)];
   if (!gany<LOG2L>(mnonzero<K>(slices))) return;  // greedy/optimizer.hpp:359
-#ifdef TNCO_FWA_PROF
-  const unsigned long long ta0 = __builtin_amdgcn_s_memtime();
-#endif
   R rng;
   rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
-#ifdef TNCO_FWA_PROF
-  const unsigned long long ta1 = __builtin_amdgcn_s_memtime();
-  const int nwm = fw_gs_mark<LOG2L, K, HYPER>(P, F, v, w64, sc, st, lane0, gbase, nullptr, nw_pre);
-  const unsigned long long ta2 = __builtin_amdgcn_s_memtime();
-  unsigned long long gp_[4] = {0, 0, 0, 0};
-  const M ns = fw_gs_pick<LOG2L, K, HYPER>(P, F, v, rng, sc, nwm, lpos, lane0, gbase, F.status + r, gp_);
-  const unsigned long long ta3 = __builtin_amdgcn_s_memtime();
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&g_fwa_prof[0], ta1 - ta0); atomicAdd(&g_fwa_prof[1], ta2 - ta1); atomicAdd(&g_fwa_prof[2], ta3 - ta2);
-    atomicAdd(&g_fwa_prof[3], 1ull);
-    for (int q = 0; q < 4; ++q) atomicAdd(&g_fwa_prof[4 + q], gp_[q]);
-  }
-#else
   const M ns = fw_get_slices<LOG2L, K, HYPER>(P, F, v, w64, rng, sc, st, lpos, lane0, gbase, F.status + r, nullptr, nullptr,
                                               nw_pre);
-#endif
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last reads of the position scratch)
   // the proposed slices travel in the candidate-position scratch, free now
   uint64_t* prop = reinterpret_cast<uint64_t*>(const_cast<int16_t*>(sc.pos));

@@ -164,19 +164,6 @@ void launch_fw_reslice_lk(tnco_hip_ctx* h, int prewalked) {
       }
     }
 #endif
-#ifdef TNCO_FWA_PROF
-    {
-      static int acalls = 0;
-      if (++acalls % 80 == 0) {
-        unsigned long long st[8];
-        (void)hipDeviceSynchronize();
-        if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_fwa_prof), sizeof(st)) == hipSuccess && st[3])
-          std::fprintf(stderr, "fw_reslice_a after %d launches: cycles per wavefront: generator init %.0f, too-wide counts %.0f, greedy pass %.0f; "
-                       "of it scan %.0f, positions %.0f, shuffle %.0f, keys + picks %.0f\n", acalls, (double)st[0] / st[3], (double)st[1] / st[3],
-                       (double)st[2] / st[3], (double)st[4] / st[3], (double)st[5] / st[3], (double)st[6] / st[3], (double)st[7] / st[3]);
-      }
-    }
-#endif
     return;
   }
 #endif
