@@ -639,6 +639,11 @@ def main() -> None:
                 roof["traffic_source"] = pmc_note or f"rocprofv3 --pmc child passes of this run ({pmc.get('seconds', 0):.0f} s), {pmc['library']}"
                 if pmc.get("trace_names"):
                     roof["trace_names_seen"] = {k: pmc["trace_names"].get(k) for k in kernels}
+                    seen = pmc["trace_names"].get(roof["kernel"]) or []
+                    # (the dominant kernel by its name in the trace: profiles/r04_kernel_stats.csv has this row)
+                    dom = [x for x in seen if "fw_wave_kernel" in x or "sa_run_kernel" in x]
+                    if dom:
+                        roof["kernel"] = dom[0].replace("void ", "")
             else:
                 roof["traffic_source"] = pmc_note
             if roof.get("traffic") is not None:
