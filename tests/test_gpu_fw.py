@@ -560,3 +560,31 @@ def test_fw_hyper_index_network_forms_agree_at_scale(core, monkeypatch):
     assert a[3]["fell_back"] < 0.05 * a[3]["repriced"], a[3]
     assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1])
     assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1]) and np.array_equal(a[2], b[2])
+
+
+def test_fw_more_than_1024_tensors_on_the_one_wavefront_path(core, oracle_lib, monkeypatch):
+    """The raw CZ circuit at depth 14: 1 149 tensors (24 or 32 nodes per lane of fw_wave_kernel, 19 KB of node table),
+    three quarters of its indices on three tensors -- against the oracle, and the two forms of the re-slice against
+    each other on 1 024 replicas."""
+    from tnco_amd import synthetic as syn
+    ts, dims, out = syn.sycamore53_cz_tn(14, fuse=None)
+    p = H.Problem(ts, 2, out)
+    assert 1024 < p.n <= 2048
+    seeds = np.asarray(H.replica_seeds(1024, S=14))
+    links = core.greedy_trees(p.ts_inds, p.n_inds, seeds, device=0)
+    w0 = _initial_max_width(p, links[0])
+    mw = int(0.7 * w0)
+    monkeypatch.setenv("TNCO_HIP_FW_WAVE", "1")
+    gpu = _check(core, oracle_lib, p, seeds[:4], H.linear_betas(0, 40, 30), mw, chunks=[30], every=5, links=links[:4])
+    assert gpu.fw_stats()["repriced"] > 0
+    betas = H.linear_betas(0, 60, 40)
+    res = []
+    for pin in ("1", "0"):
+        monkeypatch.setenv("TNCO_HIP_FW_WAVE", pin)
+        with core.BatchedOptimizer(p.leaf_masks, links, seeds, n_inds=p.n_inds, max_width=mw) as g:
+            g.run(betas, update_slices_every=10)
+            assert g.validate() == (0, -1)
+            res.append((g.costs(), g.slices_many(np.arange(len(seeds))), np.asarray(g.prng_states())))
+    a, b = res
+    assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1])
+    assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1]) and np.array_equal(a[2], b[2])

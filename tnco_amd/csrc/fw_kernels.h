@@ -1635,7 +1635,7 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_A_WAVES) void fw_reslice_a_ker
 template <bool BIG> constexpr int FWO_MAXW = BIG ? 1024 : 256;   // too-wide tensors the wavefront form orders (more: fw_reslice_a_kernel's traverse)
 template <bool BIG> constexpr int FWS_MAXNP = BIG ? 512 : 128;   // candidate legs of one tensor (beyond 128: the sequential shuffle)
 template <bool BIG> constexpr int FWS_NPL = BIG ? 10 : 8;        // planes of the bit-sliced too-wide counts
-constexpr int FWT_JMAX = 16;     // internal nodes per lane at most: n - 1 <= 1024
+constexpr int FWT_JMAX = 32;     // internal nodes per lane at most: n - 1 <= 2048
 constexpr int FWS_MINCAP = 16;   // too-wide tensors whose legs stay in LDS at least (the wavefront form sizes its LDS for that)
 
 // std::mt19937 for one wavefront: outputs [.., hi) of the CURRENT generation are in the ring (256 entries, batches

@@ -134,7 +134,8 @@ void launch_fw_reslice_lk(tnco_hip_ctx* h, int prewalked) {
 #define TNCO_FWW(JJ, HY, BG) hipLaunchKernelGGL((fw_wave_kernel<JJ, LT, HY, BG>), dim3((unsigned)h->P.R), dim3(64), lb, h->stream, h->P, h->F, h->fw_wave_cap, h->fw_wave_maxnp)
 #define TNCO_FWW_J(HY, BG)                                                                                                \
     if (need <= 2) TNCO_FWW(2, HY, BG); else if (need <= 4) TNCO_FWW(4, HY, BG); else if (need <= 6) TNCO_FWW(6, HY, BG); \
-    else if (need <= 9) TNCO_FWW(9, HY, BG); else if (need <= 12) TNCO_FWW(12, HY, BG); else TNCO_FWW(16, HY, BG)
+    else if (need <= 9) TNCO_FWW(9, HY, BG); else if (need <= 12) TNCO_FWW(12, HY, BG); else if (need <= 16) TNCO_FWW(16, HY, BG); \
+    else if (need <= 24) TNCO_FWW(24, HY, BG); else TNCO_FWW(32, HY, BG)
     if (h->hyper) {
       if (h->fw_wave_big) { TNCO_FWW_J(true, true); } else { TNCO_FWW_J(true, false); }
       hipLaunchKernelGGL((fw_reslice_a_kernel<LOG2L, K, true>), grid, dim3(256), 0, h->stream, h->P, h->F, 2);
