@@ -1977,7 +1977,8 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
   for (int t0 = 0; t0 < nres; t0 += TPI) {  // (cap is a multiple of TPI: the last instruction stays inside the cache)
     const int t = t0 + lane / LPT;
     const int node = wls[t < nw ? t : nw - 1];
-    const uint8_t* src = legs + (int64_t)(node - n) * WS + 16 * (lane % LPT);
+    const int off = 16 * (lane % LPT);  // (a record is WS <= 8 T bytes: the lanes beyond it re-read its start -- words >= W are never used)
+    const uint8_t* src = legs + (int64_t)(node - n) * WS + (off < WS ? off : 0);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(cache + (size_t)t0 * T), 16, 0, 0);
   }

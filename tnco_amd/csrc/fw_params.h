@@ -27,8 +27,8 @@ struct FwParams {
                             //     nothing to do; -2 left to fw_reslice_a_kernel's own traverse; -3 get_slices done
   int32_t* nwfront;         // [R] ... how many of them at the front of the list (fw_walk2_kernel: the rest at its end)
   // the re-slice of a replica in one wavefront, its cost cache re-priced from the OLD costs (fw_wave_kernel)
-  int32_t fast_ok;          // this call runs it: uniform power-of-two dims, float64 cost, no sparse legs, no hyper-indices,
-                            // <= 1024 tensors, no too-wide leaf, split layout; few fall-backs lately (tnco_hip_run_fw)
+  int32_t fast_ok;          // this call runs it: uniform power-of-two dims, float64 cost, no sparse legs, hyper-indices on <= 7 tensors,
+                            // <= 2048 tensors, no too-wide leaf, split layout; few fall-backs lately (tnco_hip_run_fw)
   const int32_t* holder2;   // [I64][2] the (one or two) tensors holding an index, -1: none / index not supported
   const uint16_t* holdern;  // [I64][8] networks with hyper-indices instead: count | open << 15 (open: an output index, or held by
                             //          one tensor), then the (up to 7) tensors holding the index; count 0: not supported
