@@ -303,3 +303,40 @@ def test_greedy_cost_key_orders_like_the_exact_cost():
     check([(a, b, c) for a in rng for b in rng for c in rng])
     far = [0, 1, 2, 3, 5, 60, 61, 62, 63, 64, 65, 100, 101, 102, 103, 1000, 1001, 2038, 2039, 2040]
     check([(a, b, c) for a in far for b in far for c in far])
+
+
+def test_sycamore53_supremacy_sequence():
+    """BASELINE config 5's network (tnco_amd/synthetic.py; the reference ships none -- tnco/utils/circuit.py would build it
+    from cirq): 53 qubits, 86 couplers in four patterns with A, B the two staggered halves of ONE orientation and C, D
+    those of the other (cirq's GRID_STAGGERED_PATTERN), ABCDCDAB -> 430 two-qubit gates at depth 20, the published count;
+    the easier assignment of rounds 1-3 (the orientations alternate per cycle) is kept for the fixtures made on it."""
+    from tnco_amd import synthetic as syn
+    ts, dims, out = syn.sycamore53_tn(20)
+    gates = [t for t in ts if len(t) == 4]
+    assert (len(ts), len(gates), dims, out) == (536, 430, 2, ()) and sum(len(t) == 1 for t in ts) == 106
+    n_inds = 1 + max(i for t in ts for i in t)
+    assert n_inds == 913 and all(sum(i in t for t in ts) == 2 for i in (0, 500, 912))
+    # the patterns: rebuild them as the generator does and look at their orientation
+    names = syn._SYCAMORE_LAYOUTS["supremacy"]
+    assert {names[(1, -1)], names[(0, -1)]} == {"A", "B"} and {names[(0, +1)], names[(1, +1)]} == {"C", "D"}
+    alt = syn._SYCAMORE_LAYOUTS["alternating"]
+    assert {alt[(0, +1)], alt[(0, -1)]} == {"A", "B"}  # (A, B of the old assignment: BOTH orientations from even rows)
+    per_cycle = [len([t for t in syn.sycamore53_tn(d)[0] if len(t) == 4]) for d in range(1, 9)]
+    steps = [b - a for a, b in zip([0] + per_cycle, per_cycle)]  # gates of cycles A B C D C D A B
+    assert steps[0] == steps[6] and steps[1] == steps[7] and steps[2] == steps[4] and steps[3] == steps[5]
+    assert steps[0] + steps[1] + steps[2] + steps[3] == 86
+    # four cycles connect the lattice (two alone, one orientation, do not)
+    from tnco_amd.app.tn import get_connected_components
+    assert len(get_connected_components(syn.sycamore53_tn(4)[0])) == 1
+    assert len(get_connected_components(syn.sycamore53_tn(2)[0])) > 1
+    old = syn.sycamore53_tn(20, "alternating")[0]
+    assert (len(old), sum(len(t) == 4 for t in old)) == (541, 435)
+    # the CZ variant: diagonal gates decomposed into hyper-indices (wire segments on two or three tensors), fused or raw
+    raw = syn.sycamore53_cz_tn(12, fuse=None)[0]
+    holders = {}
+    for t in raw:
+        for i in t:
+            holders[i] = holders.get(i, 0) + 1
+    assert len(raw) == 1000 and set(holders.values()) == {2, 3}
+    fused = syn.sycamore53_cz_tn(12, fuse=4, seed=0)[0]
+    assert len(fused) < len(raw) / 3 and max(len(t) for t in fused) <= 4 and len(get_connected_components(fused)) == 1
