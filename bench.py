@@ -702,7 +702,15 @@ def main() -> None:
                     "sample": f"oracle/tnco_oracle.c (plain-C restatement of the reference's "
                               f"{'infinite-memory' if kind == 'im' else 'finite-width'} optimizer), {ns} of the same "
                               f"replicas, full {leg.total_sweeps}-sweep schedule each, {cores} threads; {m} moves in {t:.1f} s",
+                    "per_core": v / max(cores, 1),
                 }
+                if kind == "im":  # (what is known about port / reference: BASELINE.md sections 2-3)
+                    obj["cpu_baseline"]["reference_note"] = (
+                        "the real reference cannot be built here (Boost absent; no stand-ins), so rho = port / reference is "
+                        "not measured; the survey-time probe of the reference's own classes (BASELINE.md section 2: stand-in "
+                        "dynamic_bitset header, one update() per Python call) ran 2-2.5e6 move-evals/s per core on this "
+                        "network -- the port, which allocates nothing per move, is several times faster per core: a "
+                        "conservative baseline")
             return obj
 
         head_kind = legs[0]
