@@ -845,7 +845,8 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
   }
   const size_t lds = lds_bytes(W, SMAX, I, QC, TS);
-  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (size_t)(160 * 1024) / lds));
+  int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (size_t)(160 * 1024) / lds));
+  if (const char* e = std::getenv("TNCO_HIP_GREEDY_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(e)));  // (experiment: occupancy sensitivity)
   const int G = (int)std::min<int64_t>(R, (int64_t)cus * per_cu);
 
   std::lock_guard<std::mutex> pool_lock(g_pool.mu);
