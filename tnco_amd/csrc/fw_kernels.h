@@ -2059,7 +2059,10 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
     unsigned long long gacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     const int capw = (int)floor(F.max_width / F.log2d);  // legs a tensor may keep
-    const int nplanes = 32 - __clz(nw | 1);              // (a count is at most nw)
+    int nplanes = 0;  // planes in use: the largest count over all indices is usually far below the number of too-wide tensors
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+      if (__any(pl[p] != 0ull)) nplanes = p + 1;
     // The list is scanned in groups of TPL tensors (one per row of lanes).  A group's legs are read ONCE -- from
     // LDS, or, beyond `cap` tensors, from memory with the next group's request in flight -- and after a tensor of
     // the group was sliced the rest of the group is re-tested from the registers.
