@@ -301,7 +301,7 @@ def init_native(rank: int | None = None, world: int | None = None, device: int |
     """The process-wide communicator (rank / world / device default to the torchrun environment): RCCL inside the
     library if it comes up on EVERY rank, else the socket transport on all of them -- never a mix, which could only
     hang.  The ranks first meet on the side channel (SocketComm); each probes RCCL (a unique id can be made: the
-    library is there); if all can, each runs ncclCommInitRank under a time limit (`TNCO_COMM_INIT_TIMEOUT`, 120 s)
+    library is there); if all can, each runs ncclCommInitRank under a time limit (`TNCO_COMM_INIT_TIMEOUT`, 240 s)
     and they compare notes again.  `.kind` of the result says which transport it is, `.note` why RCCL was not."""
     global _native, _side
     if _native is not None:
@@ -310,7 +310,7 @@ def init_native(rank: int | None = None, world: int | None = None, device: int |
     world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
     device = local_device() if device is None else device
     lib = kw.pop("lib", None)
-    timeout = float(kw.pop("timeout", os.environ.get("TNCO_COMM_INIT_TIMEOUT", "120")))
+    timeout = float(kw.pop("timeout", os.environ.get("TNCO_COMM_INIT_TIMEOUT", "240")))
     side = SocketComm(rank, world, timeout=max(timeout, 90.0), **{k: v for k, v in kw.items() if k in ("addr",)})
     note = None
     try:
