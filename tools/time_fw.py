@@ -1,5 +1,5 @@
-"""Throughput of the finite-width kernels on the BASELINE config-5 topology (Sycamore-53-style
-depth-20 circuit, 541 tensors, 923 indices), memory-constrained.
+"""Throughput of the finite-width kernels on the BASELINE config-5 network (the Sycamore-53 supremacy circuit at
+depth 20: 536 tensors, 913 indices), memory-constrained, from random-Kruskal starts.
 
     python tools/time_fw.py [--replicas 4096] [--sweeps 100] [--max-width 40] [--cpu-sample 32]
 
