@@ -116,6 +116,65 @@ __global__ __launch_bounds__(256) void move_pattern_kernel(uint8_t* buf, uint64_
   if (acc == 0x1234567) sink[0] = acc;
 }
 
+// The memory side of one move of the FINITE-WIDTH sweep kernel in the split layout (headers 32 B each in one array, legs
+// 128 B each in another): read A's header, C's header (CHDR = 1; 0: a parent that carried its children's partial sums would
+// make this read unnecessary -- DESIGN section 9, "next"), C's legs line; write B's header (a 32-byte partial sector) and, for
+// an accepted move (ACC of 4), B's legs line and two 4-byte parent words.
+template <int UNROLL, int ACC, int CHDR>
+__global__ __launch_bounds__(256) void fw_pattern_kernel(uint8_t* hdr, uint8_t* legs, uint64_t n_nodes, int iters, uint64_t* sink) {
+  const int lane = threadIdx.x & 3;
+  const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  uint64_t acc = 0;
+  for (int it = 0; it < iters; it += UNROLL) {
+    uint64_t ha[UNROLL], hc[UNROLL], y[UNROLL][4], base[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      base[u] = mix(gid * 0x9e3779b97f4a7c15ull + (uint64_t)(it + u));
+      const uint64_t A = base[u] % n_nodes, C = mix(base[u] + 1) % n_nodes;
+      ha[u] = *reinterpret_cast<const uint64_t*>(hdr + A * 32 + lane * 8);
+      hc[u] = 0;
+      if (CHDR) hc[u] = *reinterpret_cast<const uint64_t*>(hdr + C * 32 + lane * 8);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) y[u][w] = *reinterpret_cast<const uint64_t*>(legs + C * 128 + w * 32 + lane * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint64_t B = mix(base[u] + 2) % n_nodes, U = mix(base[u] + 3) % n_nodes, V = mix(base[u] + 4) % n_nodes;
+      const uint64_t sres = ha[u] + hc[u] + y[u][0] + y[u][1] + y[u][2] + y[u][3];
+      acc += sres;
+      *reinterpret_cast<uint64_t*>(hdr + B * 32 + lane * 8) = sres;
+      if (((it + u) & 3) < ACC) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) *reinterpret_cast<uint64_t*>(legs + B * 128 + w * 32 + lane * 8) = sres + w;
+        if (lane == 0) {
+          *reinterpret_cast<uint32_t*>(hdr + U * 32 + 8) = (uint32_t)sres;
+          *reinterpret_cast<uint32_t*>(hdr + V * 32 + 8) = (uint32_t)sres + 1;
+        }
+      }
+    }
+  }
+  if (acc == 0x1234567) sink[0] = acc;
+}
+template <int UNROLL, int ACC, int CHDR>
+static void run_fw_pattern(uint8_t* buf, size_t bytes, uint64_t* sink, int waves_per_simd) {
+  const int blocks = 256 * waves_per_simd, iters = 1024;
+  hipEvent_t a, b;
+  CHECK(hipEventCreate(&a));
+  CHECK(hipEventCreate(&b));
+  const uint64_t n_nodes = bytes / 160;  // headers in the first fifth of the buffer, legs behind them
+  uint8_t* legs = buf + n_nodes * 32;
+  fw_pattern_kernel<UNROLL, ACC, CHDR><<<blocks, 256>>>(buf, legs, n_nodes, 64, sink);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(a));
+  fw_pattern_kernel<UNROLL, ACC, CHDR><<<blocks, 256>>>(buf, legs, n_nodes, iters, sink);
+  CHECK(hipEventRecord(b));
+  CHECK(hipEventSynchronize(b));
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, a, b));
+  printf("finite-width move pattern (split layout), accepted %d/4, C's header %s, in-flight/group %d, waves/SIMD %d : %6.2f G moves/s\n",
+         ACC, CHDR ? "read    " : "not read", UNROLL, waves_per_simd, (double)blocks * 64 * iters / ms * 1e-6);
+}
+
 template <int UNROLL, int ACC, int PARENTS>
 static void run_pattern(uint8_t* buf, size_t bytes, uint64_t* sink, int waves_per_simd) {
   const int blocks = 256 * waves_per_simd;
@@ -213,6 +272,8 @@ int main(int argc, char** argv) {
     run_pattern<4, 3, 2>(buf, bytes, sink, w);
     run_pattern<4, 4, 2>(buf, bytes, sink, w);
     run_pattern<4, 0, 2>(buf, bytes, sink, w);
+    run_fw_pattern<4, 3, 1>(buf, bytes, sink, w);
+    run_fw_pattern<4, 3, 0>(buf, bytes, sink, w);
   }
   // streaming reference: same kernel shape, consecutive grains
   CHECK(hipFree(buf));
