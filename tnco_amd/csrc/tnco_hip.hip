@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -524,6 +525,16 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   if (d->device < 0 || d->device >= ndev) return fail(TNCO_HIP_EINVAL, "'device' is not valid.");
   HIP_TRY(hipSetDevice(d->device));
 
+  // TNCO_HIP_CREATE_DEBUG: wall time of the steps of this call on stderr (the device drained at every mark)
+  const bool cdbg = std::getenv("TNCO_HIP_CREATE_DEBUG") != nullptr;
+  auto c_t0 = std::chrono::steady_clock::now();
+  auto cmark = [&](const char* what) {
+    if (!cdbg) return;
+    (void)hipDeviceSynchronize();
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "create: %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t - c_t0).count());
+    c_t0 = t;
+  };
   tnco_hip_ctx* h = new tnco_hip_ctx();
   struct Guard {
     tnco_hip_ctx* h;
@@ -621,6 +632,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     P.jcap = (int32_t)cap;
   }
 
+  cmark("checks, stream");
   HIP_TRY(h->alloc(&P.blocks, R * h->block_bytes()));
   HIP_TRY(h->alloc(&P.lpar, R * n * LPS + 16));  // the sweep kernel reads 8 bytes at a leaf's record
   HIP_TRY(h->alloc(&P.mt, R * 624));
@@ -629,6 +641,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   HIP_TRY(h->alloc(&P.minlinks, R * N));
   HIP_TRY(h->alloc(&P.jlog, R * (int64_t)P.jcap));
 
+  cmark("allocations");
   // shared tables
   {
     std::vector<uint64_t> lm((size_t)n * L, 0), om((size_t)L, 0), sp((size_t)L, 0);
@@ -718,6 +731,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     }
   }
 
+  cmark("shared tables");
   TempBufs tmp;
   // seeds -> MT state
   if (d->prng_states) {  // the string-seed form of the constructor (optimize/optimizer.hpp:68-71): whole states
@@ -737,6 +751,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     HIP_TRY(h->sync_all());
   }
 
+  cmark("generator states");
   // links (+ optional explicit legs) -> node blocks and caches
   {
     const int64_t ntrees = d->links_stride == 0 ? 1 : R;
@@ -767,6 +782,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       for (int64_t r = 0; r < ntrees; ++r)
         if (chk[r]) return fail(TNCO_HIP_EINVAL, tree_check_message(chk[r]));
     }
+  cmark("trees checked");
     const int64_t nmasks = d->node_masks ? (d->node_masks_stride == 0 ? 1 : R) : 0;
     if (nmasks) {
       HIP_TRY(tmp.alloc(&dmasks, nmasks * N * W));
@@ -790,6 +806,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     launch_build(h, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(h->sync_all());
+  cmark("trees -> node records");
     HIP_TRY(hipMemcpy(total.data(), dtotal, (size_t)R * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(sum.data(), dsum, (size_t)R * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(status.data(), dstatus, (size_t)R * 4, hipMemcpyDeviceToHost));
@@ -802,6 +819,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
         if (bad_log2(total[r]) || bad_log2(sum[r])) return fail(TNCO_HIP_EINVAL, "Precision is too low.");
   }
 
+  cmark("costs back, best trees");
   // finite width: WidthCache, initial slices (greedy, draws from the PRNG), CostCache(slices)
   // -- finite_width/greedy/optimizer.hpp:72-115
   if (fw) {
@@ -1064,6 +1082,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     }
   }
 
+  cmark("the rest (finite width, min trees)");
   guard.h = nullptr;
   *out = h;
   return TNCO_HIP_OK;

@@ -1,0 +1,16 @@
+import sys, time, pathlib, warnings
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+warnings.simplefilter("ignore")
+import numpy as np
+from tnco_amd import synthetic as syn
+from tnco_amd.app import Optimizer
+def spec_of(n, seed):
+    ts, _d, _ = syn.random_regular_tn(n, 3, seed)
+    n_inds = max(max(x) for x in ts) + 1
+    return [(2, *[f"t{t}" for t in range(n) if k in ts[t]]) for k in range(n_inds)]
+sp = spec_of(512, 11)
+for i in range(3):
+    opt = Optimizer(method="sa", seed=0)
+    t0 = time.perf_counter()
+    tn, res = opt.optimize(sp, betas=(0, 100), n_steps=1000, n_runs=65536, top_k=16, fuse=None)
+    print(f"e2e {time.perf_counter()-t0:.3f} s", file=sys.stderr)
