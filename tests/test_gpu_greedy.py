@@ -35,8 +35,18 @@ def _supported(ts, n_inds):
     return bool(_lib.load().tnco_hip_greedy_device_supported(len(ts), n_inds, off.ctypes.data))
 
 
+@pytest.fixture(params=["graph", "set"])
+def form(request, monkeypatch):
+    """Both device forms of the greedy (the multigraph in LDS where the network has no hyper-index -- the
+    default -- and the index sets in memory) with both shuffle kernels (state in LDS / in memory)."""
+    if request.param == "set":
+        monkeypatch.setenv("TNCO_HIP_GREEDY_GRAPH", "0")
+        monkeypatch.setenv("TNCO_HIP_SHUFFLE_LDS", "0")
+    return request.param
+
+
 @pytest.mark.parametrize("n,gs", [(4, 1), (8, 1), (64, 7), (200, 3), (512, 11)])
-def test_regular_graphs(n, gs):
+def test_regular_graphs(n, gs, form):
     prob = syn.regular_problem(n, graph_seed=gs, degree=3 if n > 4 else 2)
     assert _supported(prob.ts_inds, prob.n_inds)
     seeds = np.concatenate([[0, 1, 42, 2**32 - 1, 123456789, 77], syn.replica_seeds(250)])
@@ -74,7 +84,66 @@ def test_fuzz_on_small_hyper_networks_against_the_python_spec():
             assert np.array_equal(dev[k], np.stack(ct.tree_from_contraction(con, len(ts)))), (len(ts), int(sd))
 
 
-def test_config5_topology_and_many_seeds():
+def _hubs(spokes, ring=True, double=()):
+    """Two hub tensors joined to each other and to every one of `spokes` small tensors (which form a ring):
+    neighbour lists far longer than a wavefront, every neighbour of one hub a neighbour of the other."""
+    ts = [[0], [0]] + [[] for _ in range(spokes)]
+    nxt = 1
+    for k in range(spokes):
+        for hub in (0, 1):
+            for _ in range(2 if (hub, k) in double else 1):
+                ts[hub].append(nxt)
+                ts[2 + k].append(nxt)
+                nxt += 1
+        if ring:
+            ts[2 + k].append(nxt)
+            ts[2 + (k + 1) % spokes].append(nxt)
+            nxt += 1
+    return ts, nxt
+
+
+def test_graph_form_long_lists_output_and_dangling_legs():
+    """What the regular graphs do not reach in the multigraph form: lists of several 64-entry pieces whose
+    entries meet again across the pieces (two hubs with the same 100 neighbours), pairs of tensors sharing
+    two legs, output legs, legs with a single holder; and its hand-backs: lists beyond 255 entries."""
+    seeds = syn.replica_seeds(48)
+    ts, n_inds = _hubs(100, double={(0, 3), (1, 3), (0, 50)})
+    assert _supported(ts, n_inds)
+    _both(ts, n_inds, seeds)
+    # output legs on some tensors, dangling (single-holder, not output) legs on others
+    ts2 = [list(x) for x in ts]
+    out = []
+    for k in range(0, 100, 7):
+        ts2[2 + k].append(n_inds + len(out))
+        out.append(n_inds + len(out))
+    n2 = n_inds + len(out)
+    for k in range(3, 100, 11):
+        ts2[2 + k].append(n2)
+        n2 += 1
+    ts2[0].append(n2)
+    n2 += 1
+    _both(ts2, n2, seeds, out_keep=out)
+    # a hub with 255 neighbours: its list and any other pass 255 entries -- every tree goes to the host inside the call
+    from tnco_amd import _lib
+    ts3 = [list(range(255))] + [[k, 255 + k, 255 + (k + 1) % 255] for k in range(255)]
+    host = core.greedy_trees(ts3, 510, seeds[:8])
+    dev = core.greedy_trees(ts3, 510, seeds[:8], device=0)
+    assert np.array_equal(host, dev) and _lib.load().tnco_hip_greedy_device_redone() == 8
+
+
+def test_both_shuffle_kernels_continue_a_generator(monkeypatch):
+    """`draws` (outputs of Random(seed) already consumed) through the LDS kernel and the in-memory one."""
+    a = syn.regular_problem(40, graph_seed=2)
+    seeds = np.array([3, 99, 2**31 + 5, 7, 8, 9, 2**32 - 1])
+    got = {}
+    for lds in ("1", "0"):
+        monkeypatch.setenv("TNCO_HIP_SHUFFLE_LDS", lds)
+        draws = np.array([0, 1, 623, 624, 625, 5000, 12], np.uint64)
+        got[lds] = (_both(a.ts_inds, a.n_inds, seeds, draws=draws), draws.copy())
+    assert np.array_equal(got["1"][0], got["0"][0]) and np.array_equal(got["1"][1], got["0"][1])
+
+
+def test_config5_topology_and_many_seeds(form):
     p = syn.sycamore_problem(20)
     assert _supported(p.ts_inds, p.n_inds)
     _both(p.ts_inds, p.n_inds, syn.replica_seeds(600))

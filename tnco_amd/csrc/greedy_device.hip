@@ -808,6 +808,7 @@ constexpr int GRAPH_MAXLIST = 255;  // entries of u and v together (more: the tr
 constexpr int GRAPH_SHORT = 8;      // a list this short moves through registers when the arena is compacted
 struct GraphParams {
   int32_t n, E, L, CAP;
+  int32_t dangling;          // 1: some tensor has a leg with a single holder that is no output leg (kept < legs)
   int64_t R;
   const uint16_t* perm;      // [R][n]
   // the network in the ORIGINAL numbering of its tensors (shared by all trees)
@@ -861,6 +862,7 @@ __global__ __launch_bounds__(64) void greedy_graph_kernel(const GraphParams p) {
   extern __shared__ uint64_t lds_raw[];
   const int lane = threadIdx.x;
   const int n = p.n, E = p.E, CAP = p.CAP, N2 = 2 * n, N = 2 * n - 1;
+  const bool dang = p.dangling != 0;
   // LDS: acc [64] | rec [2n] | perm [n] | list ids [CAP] || mark [2n] | kept [n] | list mult [CAP]
   lds_u32 acc = (lds_u32)lds_raw;
   // rec of a live id: 0x8000 | offset of its list, legs << 16, list length << 24; of a dead id: its parent
@@ -875,10 +877,13 @@ __global__ __launch_bounds__(64) void greedy_graph_kernel(const GraphParams p) {
 #ifdef TNCO_GREEDY_PROF
   unsigned long long prof_[16] = {0}, pt_ = __builtin_amdgcn_s_memtime();
 #endif
+  // The queue: cell[q] of lane l is cell 64 q + l; every lane knows the smallest of its cells (lkey, in row lrow).
+  // (Keeping the second smallest as well, so that the scan over the rows runs only when a lane is hit twice,
+  // was measured: the same instruction count -- the write into a row chosen at run time costs what the scan does.)
   uint64_t cell[ROWS];
   uint64_t lkey = KMAX;
   int lrow = 0;
-  auto rescan = [&]() {  // this lane: the minimum of its cells
+  auto rescan = [&]() {
     lkey = cell[0];
     lrow = 0;
 #pragma unroll
@@ -887,6 +892,13 @@ __global__ __launch_bounds__(64) void greedy_graph_kernel(const GraphParams p) {
         lkey = cell[q];
         lrow = q;
       }
+  };
+  // the smallest cell of the lanes in `who` becomes x
+  auto replace_min = [&](bool who, uint64_t x) {
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q)
+      if (who && q == lrow) cell[q] = x;
+    rescan();
   };
   for (int64_t r = g; r < p.R; r += gridDim.x) {
     const uint16_t* perm = p.perm + r * (int64_t)n;
@@ -991,11 +1003,7 @@ __global__ __launch_bounds__(64) void greedy_graph_kernel(const GraphParams p) {
         // obsolete -- and so may be the minima of other lanes: every lane looks at its own and drops it
         const bool any = lkey != KMAX;
         const uint32_t mu = (uint32_t)rec[any ? (int)(lkey & 0x3FFFu) : 0], mv = (uint32_t)rec[any ? (int)((lkey >> 14) & 0x3FFFu) : 0];
-        const bool gone = any && !(mu & mv & 0x8000u);
-#pragma unroll
-        for (int q = 0; q < ROWS; ++q)
-          if (q == lrow && gone) cell[q] = KMAX;
-        rescan();
+        replace_min(any && !(mu & mv & 0x8000u), KMAX);
         continue;
       }
       const int wl = __ffsll((unsigned long long)__ballot(lkey == best)) - 1;
@@ -1012,23 +1020,21 @@ __global__ __launch_bounds__(64) void greedy_graph_kernel(const GraphParams p) {
         ov = uni((int)rec[v]) & 0x7FFF;
       }
       const int fu = (int)((ru >> 16) & 0xFFu), fv = (int)((rv >> 16) & 0xFFu);
-      const int ku = u < n ? uni((int)kp8[u]) : fu, kv = v < n ? uni((int)kp8[v]) : fv;
+      const int ku = (dang && u < n) ? uni((int)kp8[u]) : fu, kv = (dang && v < n) ? uni((int)kp8[v]) : fv;
       const int dst = bump;
       if (lane == 0) {
         rec[u] = (uint32_t)z;
         rec[v] = (uint32_t)z;
         rec[z] = 0x8000u | (uint32_t)dst;
-        const int xs = u < n ? (int)permL[u] : u, ys = v < n ? (int)permL[v] : v;
-        lk[z] = xs < ys ? xs : ys;
-        lk[N + z] = xs < ys ? ys : xs;
-        lk[2 * N + xs] = z;
-        lk[2 * N + ys] = z;
       }
+      const int xs = u < n ? (int)permL[u] : u, ys = v < n ? (int)permL[v] : v;  // (for the links, at the end of the step)
       wsync();
       GP_T(2);
       int nz = 0;
       uint32_t sh = 0;
-      bool over = false;
+      bool over = false, lead1 = false;
+      int y1 = 0;
+      uint32_t w1 = 0;
       for (int c0 = 0; c0 < total; c0 += 64) {
         const int j = c0 + lane;
         const bool valid = j < total;
@@ -1075,6 +1081,9 @@ __global__ __launch_bounds__(64) void greedy_graph_kernel(const GraphParams p) {
         }
         over |= leader && w > 255u;
         nz += __popcll(ab);
+        lead1 = app;  // (total <= 64: the speakers hold the new list in registers)
+        y1 = rr;
+        w1 = w;
         wsync();
       }
       GP_T(3);
@@ -1087,21 +1096,30 @@ __global__ __launch_bounds__(64) void greedy_graph_kernel(const GraphParams p) {
       bump += nz;
       // ---- the cheapest (z, neighbour) into the cell just popped ----
       uint64_t bestk = KMAX;
-      for (int j0 = 0; j0 < nz; j0 += 64) {
-        const int j = j0 + lane;
-        const bool valid = j < nz;
-        const int y = ids[dst + (valid ? j : 0)];
-        const int w = mult[dst + (valid ? j : 0)];
-        const int fy = (int)(((uint32_t)rec[y] >> 16) & 0xFFu), ky = y < n ? (int)kp8[y] : fy;
-        const uint64_t k = greedy_cand_key(fz + ky - 2 * w, fz, fy, z, y);
-        if (valid && k < bestk) bestk = k;
+      if (total <= 64) {
+        const int y = lead1 ? y1 : 0;
+        const int fy = (int)(((uint32_t)rec[y] >> 16) & 0xFFu), ky = (dang && y < n) ? (int)kp8[y] : fy;
+        const uint64_t k = greedy_cand_key(fz + ky - 2 * (int)w1, fz, fy, z, y);
+        if (lead1) bestk = k;
+      } else {
+        for (int j0 = 0; j0 < nz; j0 += 64) {
+          const int j = j0 + lane;
+          const bool valid = j < nz;
+          const int y = ids[dst + (valid ? j : 0)];
+          const int w = mult[dst + (valid ? j : 0)];
+          const int fy = (int)(((uint32_t)rec[y] >> 16) & 0xFFu), ky = (dang && y < n) ? (int)kp8[y] : fy;
+          const uint64_t k = greedy_cand_key(fz + ky - 2 * w, fz, fy, z, y);
+          if (valid && k < bestk) bestk = k;
+        }
       }
       const uint64_t wk = nz > 0 ? wmin64_2(bestk) : KMAX;
-      const int row = (int)rdlane((uint32_t)lrow, wl);
-#pragma unroll
-      for (int q = 0; q < ROWS; ++q)
-        if (q == row && lane == wl) cell[q] = wk;
-      rescan();
+      replace_min(lane == wl, wk);
+      if (lane == 0) {
+        lk[z] = xs < ys ? xs : ys;
+        lk[N + z] = xs < ys ? ys : xs;
+        lk[2 * N + xs] = z;
+        lk[2 * N + ys] = z;
+      }
       ++z;
       wsync();
       GP_T(4);
@@ -1448,6 +1466,9 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
   if (graph) {
     GraphParams qp{};
     qp.n = n; qp.E = gh.E; qp.L = gh.L; qp.CAP = gh.CAP; qp.R = R; qp.perm = d_perm;
+    qp.dangling = 0;
+    for (int t = 0; t < n; ++t)
+      if (gh.t_kp[t] != gh.t_fp[t]) qp.dangling = 1;
     qp.t_off = d_toff; qp.t_nbr = d_tnbr; qp.t_mult = d_tmult; qp.t_fp = d_tfp; qp.t_kp = d_tkp;
     qp.e_ends = d_eends; qp.e_key = d_ekey; qp.links = gp.links; qp.status = gp.status; qp.prof = gp.prof;
     const int rows = (gh.E + 63) / 64;
