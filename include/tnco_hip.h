@@ -285,7 +285,8 @@ int tnco_hip_greedy_trees(int32_t n_leaves, int32_t n_inds, const int32_t* holde
                           int32_t n_threads);
 
 /* The same trees drawn ON THE DEVICE (csrc/greedy_device.hip: CPython's generator one lane per tree,
- * the greedy path finder one wavefront per tree); the trees come back in links_out (host memory).
+ * the greedy path finder one wavefront per tree -- over a multigraph held in LDS where the network has no
+ * hyper-index, over index sets in memory otherwise); the trees come back in links_out (host memory).
  * Networks outside the kernel's limits (tnco_hip_greedy_device_supported == 0: more than 2040
  * indices or 2000 tensors, an index held by more than 6 tensors) and single trees that end in outer
  * products are done by tnco_hip_greedy_trees on n_threads host threads: same result either way.

@@ -9,7 +9,11 @@
 // Why a kernel: for 65 536 runs of a 512-tensor network the host version takes 3 s on the GPU box's 16
 // threads -- seven times the 1 000 SA sweeps that follow.
 //
-// Two kernels.  py_shuffle_kernel: ONE LANE per tree (seeding and shuffling are a serial chain per
+// Two forms (round 4).  Networks without hyper-indices -- every circuit and graph network the benchmarks
+// use -- take py_shuffle_lds_kernel + greedy_graph_kernel (below: the greedy over a multigraph, a tree's
+// whole state in LDS and registers; 65 536 trees of 512 tensors in 2.6 + 35-41 ms).  The others take the
+// set form of round 2 (11 + 177 ms on the same network):
+// py_shuffle_kernel: ONE LANE per tree (seeding and shuffling are a serial chain per
 // tree, 2 500 dependent steps; the generator's state is a column of a [624][R] array, so the lanes of
 // a wavefront read and write whole lines).  greedy_kernel: ONE WAVEFRONT per tree, a persistent grid:
 //   * an index set = W 64-bit words, word x in lane x (W <= 64); |set| = a wave reduction;
