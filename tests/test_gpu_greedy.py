@@ -131,6 +131,58 @@ def test_graph_form_long_lists_output_and_dangling_legs():
     assert np.array_equal(host, dev) and _lib.load().tnco_hip_greedy_device_redone() == 8
 
 
+def _random_multigraph(rng):
+    """A connected network without hyper-indices: a random spanning tree + extra edges (some doubled or
+    tripled), output legs and dangling legs on a few tensors; now and then a second component (its trees end
+    in outer products: the host's, inside the call)."""
+    n = int(rng.integers(3, 70))
+    ts = [[] for _ in range(n)]
+    nxt = 0
+
+    def edge(a, b, m=1):
+        nonlocal nxt
+        for _ in range(m):
+            ts[a].append(nxt)
+            ts[b].append(nxt)
+            nxt += 1
+    split = int(rng.integers(2, n)) if (n > 6 and rng.random() < 0.1) else n
+    for t in range(1, n):
+        if t == split:
+            continue  # (t starts a second component)
+        lo = 0 if t < split else split
+        edge(int(rng.integers(lo, t)), t, int(rng.choice([1, 1, 1, 2, 3])))
+    for _ in range(int(rng.integers(0, 2 * n))):
+        a, b = (int(x) for x in rng.integers(0, n, 2))
+        if a != b and (a < split) == (b < split):
+            edge(a, b, int(rng.choice([1, 1, 2])))
+    out = []
+    for t in range(n):
+        if rng.random() < 0.15:
+            ts[t].append(nxt)
+            out.append(nxt)
+            nxt += 1
+        if rng.random() < 0.1:
+            ts[t].append(nxt)  # a leg nobody else holds and that is no output leg
+            nxt += 1
+    return ts, nxt, out
+
+
+def test_fuzz_graph_form_on_random_multigraphs():
+    rng = np.random.default_rng(20261003)
+    seeds = np.array([0, 1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144])
+    done = 0
+    for _ in range(160):
+        ts, n_inds, out = _random_multigraph(rng)
+        if not _supported(ts, n_inds):
+            continue
+        om = ct.pack_masks([out], n_inds)[0]
+        host = core.greedy_trees(ts, n_inds, seeds, output_mask=om)
+        dev = core.greedy_trees(ts, n_inds, seeds, output_mask=om, device=0)
+        assert np.array_equal(host, dev), (len(ts), n_inds)
+        done += 1
+    assert done > 100
+
+
 def test_both_shuffle_kernels_continue_a_generator(monkeypatch):
     """`draws` (outputs of Random(seed) already consumed) through the LDS kernel and the in-memory one."""
     a = syn.regular_problem(40, graph_seed=2)
