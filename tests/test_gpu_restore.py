@@ -147,3 +147,32 @@ def test_restore_arguments_are_checked(core):
         s2 = o.prng_states([3, 1])
         o.set_prng_states(s2[::-1].copy(), [3, 1])
         assert np.array_equal(o.prng_states([1, 3]), s2)
+
+
+def test_device_blocks_of_a_destroyed_optimizer_serve_the_next_one():
+    """csrc/dev_cache.h: destroy keeps the handle's blocks of >= 1 MB, the next create of the same shape takes
+    them (no hipMalloc), the run on recycled -- dirty -- memory is bit-identical, release_cached() empties it."""
+    import numpy as np
+
+    from tnco_amd import core, synthetic as syn
+    prob = syn.regular_problem(64, graph_seed=7)
+    seeds = syn.replica_seeds(2048)
+    links = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds)
+    betas = syn.linear_betas(0, 60, 30)
+    core.release_cached()
+
+    def run(**kw):
+        with core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, **kw) as opt:
+            opt.run(betas, **({"update_slices_every": 10} if kw else {}))
+            tot, mn = opt.costs()
+            return tot.copy(), mn.copy(), [x for r in (0, 7, 2047) for x in opt.tree(r, which_min=True, with_masks=False)]
+
+    first = run()
+    held = int(core._lib.load().tnco_hip_cached_bytes())
+    assert held > 2048 * 32 * 1024  # (the rotation logs alone are 128 KB per replica)
+    other = run(max_width=14)        # another shape in between: its blocks join the cache, dirtying nothing it should not
+    again = run()
+    assert np.array_equal(first[0], again[0]) and np.array_equal(first[1], again[1])
+    assert all(np.array_equal(a, b) for a, b in zip(first[2], again[2]))
+    assert np.array_equal(other[0], run(max_width=14)[0])
+    assert core.release_cached() >= held and int(core._lib.load().tnco_hip_cached_bytes()) == 0

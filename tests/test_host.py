@@ -340,3 +340,17 @@ def test_sycamore53_supremacy_sequence():
     assert len(raw) == 1000 and set(holders.values()) == {2, 3}
     fused = syn.sycamore53_cz_tn(12, fuse=4, seed=0)[0]
     assert len(fused) < len(raw) / 3 and max(len(t) for t in fused) <= 4 and len(get_connected_components(fused)) == 1
+
+
+def test_replica_seeds_through_numpy_are_random_choices():
+    """_sa_driver.replica_seeds: the per-run seeds of sa.py:237 (`Random(seed).choices(range(2**32), k=n_runs)`)
+    drawn through numpy's legacy MT19937 from the same state -- same seeds, same generator state afterwards."""
+    import random
+
+    from tnco_amd.app._sa_driver import replica_seeds
+    for seed, k, skip in [(0, 65536, 0), (1, 4096, 5), (12345, 70001, 623), (2**40 + 7, 5000, 1300), (3, 100, 0)]:
+        a, b = random.Random(seed), random.Random(seed)
+        for _ in range(skip):
+            a.random(), b.random()
+        assert a.choices(range(2**32), k=k) == replica_seeds(b, k)
+        assert a.getstate() == b.getstate() and a.random() == b.random()

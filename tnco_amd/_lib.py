@@ -56,7 +56,7 @@ EXPORTS = [
     "tnco_hip_get_caches", "tnco_hip_validate", "tnco_hip_get_prng", "tnco_hip_set_prng", "tnco_hip_get_prng_many", "tnco_hip_set_prng_many",
     "tnco_hip_best", "tnco_hip_min_cost_device", "tnco_hip_get_trees", "tnco_hip_linear_paths", "tnco_hip_linear_paths_ssa", "tnco_hip_get_counters", "tnco_hip_get_moves", "tnco_hip_get_full_copies",
     "tnco_hip_kernel_time", "tnco_hip_kernel_times", "tnco_hip_get_stage_cycles",
-    "tnco_hip_launch_groups", "tnco_hip_device_bytes", "tnco_hip_set_stream", "tnco_hip_destroy", "tnco_hip_random_trees", "tnco_hip_greedy_trees",
+    "tnco_hip_launch_groups", "tnco_hip_device_bytes", "tnco_hip_set_stream", "tnco_hip_destroy", "tnco_hip_release_cached", "tnco_hip_cached_bytes", "tnco_hip_random_trees", "tnco_hip_greedy_trees",
     "tnco_hip_greedy_trees_device", "tnco_hip_greedy_device_supported", "tnco_hip_greedy_device_redone", "tnco_hip_greedy_device_release", "tnco_hip_copy_to_host", "tnco_hip_greedy_cost_key",
     "tnco_hip_comm_unique_id", "tnco_hip_comm_init", "tnco_hip_comm_destroy", "tnco_hip_comm_allreduce_min", "tnco_hip_comm_allgather",
     "tnco_hip_comm_barrier", "tnco_hip_comm_last_error",
@@ -131,6 +131,10 @@ def load() -> C.CDLL:
     L.tnco_hip_set_stream.argtypes = [vp, vp]
     L.tnco_hip_destroy.argtypes = [vp]
     L.tnco_hip_destroy.restype = None
+    L.tnco_hip_release_cached.argtypes = []
+    L.tnco_hip_release_cached.restype = None
+    L.tnco_hip_cached_bytes.argtypes = []
+    L.tnco_hip_cached_bytes.restype = C.c_uint64
     L.tnco_hip_random_trees.argtypes = [i32, i32, vp, vp, i64, vp, vp, i32]
     L.tnco_hip_greedy_trees.argtypes = [i32, i32, vp, vp, vp, i64, vp, vp, vp, i32]
     L.tnco_hip_greedy_trees_device.argtypes = [i32, i32, i32, vp, vp, vp, i64, vp, vp, vp, vp, i32]

@@ -104,6 +104,15 @@ def greedy_trees(leaf_positions, n_inds: int, seeds, output_mask=None, draws=Non
     return DeviceLinks(dptr.value, shape, device) if keep_on_device else out
 
 
+def release_cached() -> int:
+    """Gives back the device memory the library keeps from destroyed optimizers for the next one
+    (csrc/dev_cache.h; `TNCO_HIP_CACHE_MB`); returns the bytes that were held."""
+    L = _lib.load()
+    held = int(L.tnco_hip_cached_bytes())
+    L.tnco_hip_release_cached()
+    return held
+
+
 def greedy_release() -> None:
     """Frees the device memory greedy_trees(..., device=) keeps between calls (one block per process,
     ~2.5 GB after 65536 x 512-leaf trees); a DeviceLinks handed out earlier is invalid afterwards."""

@@ -1,0 +1,104 @@
+// dev_cache.h -- device memory of destroyed handles kept for the next one.
+//
+// hipMalloc of a handle's buffers (12 GB for 65 536 replicas of the 512-leaf network) usually takes under a
+// millisecond, but one create() in ten waited 1-2 s in it when the previous handle had just been freed
+// (profiles/r04_e2e.txt), and hipFree of them is 6-11 ms of every destroy.  A job that builds optimizer after
+// optimizer -- the components of a network, a parameter sweep -- asks for the same sizes again and again:
+// blocks of >= 1 MB go to this cache on destroy and are handed out again on an exact size match.
+//   * bounded: TNCO_HIP_CACHE_MB (default a quarter of the device's memory; 0: no cache); when full the oldest
+//     blocks are freed;
+//   * a failed hipMalloc empties the cache and is tried again;
+//   * tnco_hip_release_cached() gives everything back (for a process that shares the GPU with another allocator).
+// The cache object is never destroyed (at exit the HIP runtime may already be gone).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <mutex>
+#include <vector>
+
+namespace tnco {
+
+class DevCache {
+ public:
+  static DevCache& get() {
+    static DevCache* c = new DevCache();
+    return *c;
+  }
+  hipError_t take(void** p, size_t bytes, int device) {
+    if (bytes >= kMin) {
+      std::lock_guard<std::mutex> lock(mu_);
+      for (size_t i = blocks_.size(); i-- > 0;)
+        if (blocks_[i].bytes == bytes && blocks_[i].device == device) {
+          *p = blocks_[i].p;
+          held_ -= bytes;
+          blocks_.erase(blocks_.begin() + (long)i);
+          return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      release_all();
+      e = hipMalloc(p, bytes);
+    }
+    return e;
+  }
+  void give(void* p, size_t bytes, int device) {
+    if (!p) return;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      const size_t cap = capacity(device);
+      if (bytes >= kMin && bytes <= cap) {
+        while (held_ + bytes > cap && !blocks_.empty()) {  // the oldest go first
+          (void)hipFree(blocks_.front().p);
+          held_ -= blocks_.front().bytes;
+          blocks_.erase(blocks_.begin());
+        }
+        blocks_.push_back(Block{p, bytes, device});
+        held_ += bytes;
+        return;
+      }
+    }
+    (void)hipFree(p);
+  }
+  void release_all() {
+    std::lock_guard<std::mutex> lock(mu_);
+    for (auto& b : blocks_) (void)hipFree(b.p);
+    blocks_.clear();
+    held_ = 0;
+  }
+  size_t held() {
+    std::lock_guard<std::mutex> lock(mu_);
+    return held_;
+  }
+
+ private:
+  struct Block {
+    void* p;
+    size_t bytes;
+    int device;
+  };
+  static constexpr size_t kMin = (size_t)1 << 20;
+  size_t capacity(int device) {
+    if (cap_ == (size_t)-1) {
+      if (const char* e = std::getenv("TNCO_HIP_CACHE_MB")) {
+        cap_ = (size_t)std::max<long long>(0, std::atoll(e)) << 20;
+      } else {
+        size_t free_b = 0, total_b = 0;
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != device) (void)hipSetDevice(device);
+        cap_ = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? total_b / 4 : 0;
+        if (cur != device && cur >= 0) (void)hipSetDevice(cur);
+      }
+    }
+    return cap_;
+  }
+  std::mutex mu_;
+  std::vector<Block> blocks_;
+  size_t held_ = 0, cap_ = (size_t)-1;
+};
+
+}  // namespace tnco

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <vector>
 
+#include "dev_cache.h"
 #include "sa_kernels.h"
 #include "sa_sweep.h"
 #include "fw_kernels.h"
@@ -48,6 +49,7 @@ struct tnco_hip_ctx {
   unsigned long long fw_slow_pending = 0, fw_slow_wide_pending = 0;  // fall-backs collected since tnco_hip_run_fw last chose a form
   tnco::FwParams F{};
   std::vector<void*> allocs;
+  std::vector<size_t> alloc_bytes;  // (destroy hands the blocks to tnco::DevCache)
   int64_t bytes = 0;
   std::vector<uint64_t> leafmask_w;  // [n][W]
   std::vector<uint64_t> outmask_w;   // [W]
@@ -101,9 +103,10 @@ struct tnco_hip_ctx {
   hipError_t alloc(T** p, int64_t count) {
     void* q = nullptr;
     int64_t nb = std::max<int64_t>(count, 1) * (int64_t)sizeof(T);
-    hipError_t e = hipMalloc(&q, (size_t)nb);
+    hipError_t e = tnco::DevCache::get().take(&q, (size_t)nb, device);
     if (e == hipSuccess) {
       allocs.push_back(q);
+      alloc_bytes.push_back((size_t)nb);
       bytes += nb;
       *p = (T*)q;
     }
@@ -211,7 +214,7 @@ struct tnco_hip_ctx {
       (void)hipEventDestroy(ev.a);
       (void)hipEventDestroy(ev.b);
     }
-    for (void* p : allocs) (void)hipFree(p);
+    for (size_t i = 0; i < allocs.size(); ++i) tnco::DevCache::get().give(allocs[i], alloc_bytes[i], device);
     if (d_betas) (void)hipFree(d_betas);
     if (own_stream) (void)hipStreamDestroy(own_stream);
   }

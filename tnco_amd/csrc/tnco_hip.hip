@@ -38,18 +38,28 @@ int fail(int code, const std::string& msg) {
   } while (0)
 
 // frees a set of temporary device buffers on scope exit
+// scratch of one call, from / back to the cache of device blocks (dev_cache.h)
 struct TempBufs {
   std::vector<void*> ptrs;
+  std::vector<size_t> sizes;
+  int device = 0;
+  TempBufs() { (void)hipGetDevice(&device); }
   template <typename T>
   hipError_t alloc(T** p, int64_t count) {
     void* q = nullptr;
-    hipError_t e = hipMalloc(&q, (size_t)std::max<int64_t>(count, 1) * sizeof(T));
-    if (e == hipSuccess) ptrs.push_back(q);
+    const size_t nb = (size_t)std::max<int64_t>(count, 1) * sizeof(T);
+    hipError_t e = tnco::DevCache::get().take(&q, nb, device);
+    if (e == hipSuccess) {
+      ptrs.push_back(q);
+      sizes.push_back(nb);
+    }
     *p = (T*)q;
     return e;
   }
   ~TempBufs() {
-    for (void* p : ptrs) (void)hipFree(p);
+    if (ptrs.empty()) return;
+    (void)hipDeviceSynchronize();  // (hipFree used to wait for the kernels still reading these)
+    for (size_t i = 0; i < ptrs.size(); ++i) tnco::DevCache::get().give(ptrs[i], sizes[i], device);
   }
 };
 
@@ -449,6 +459,10 @@ int tnco_hip_device_count(void) {
 
 void tnco_hip_destroy(tnco_hip_handle h) { delete h; }
 
+// device memory of destroyed handles kept for the next create (dev_cache.h): given back / how much is held
+void tnco_hip_release_cached(void) { tnco::DevCache::get().release_all(); }
+uint64_t tnco_hip_cached_bytes(void) { return (uint64_t)tnco::DevCache::get().held(); }
+
 int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   if (!d || !out) return fail(TNCO_HIP_EINVAL, "null argument.");
   *out = nullptr;
@@ -625,6 +639,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    free_b += tnco::DevCache::get().held();  // (what destroyed handles left for this one counts as free)
     int64_t cap = (int64_t)(free_b / 8) / (R * 4);
     cap = std::max<int64_t>(1024, std::min<int64_t>(cap, (int64_t)1 << 15));
     if (const char* e = std::getenv("TNCO_HIP_JLOG_CAP")) cap = std::max<int64_t>(1, std::atoll(e));  // test knob

@@ -23,6 +23,27 @@ def spec_of(n, seed):
 
 
 sp = spec_of(512, 11)
+
+
+def _timed(obj, name, label):
+    f = getattr(obj, name)
+
+    def g(*a, **k):
+        t0 = time.perf_counter()
+        try:
+            return f(*a, **k)
+        finally:
+            dt = time.perf_counter() - t0
+            if dt > 0.03:
+                print(f"    {label} took {1e3 * dt:.0f} ms")
+    setattr(obj, name, g)
+
+
+_timed(core, "greedy_release", "greedy_release()")
+_timed(core, "greedy_trees", "greedy_trees()")
+_timed(core.BatchedOptimizer, "close", "BatchedOptimizer.close()")
+_timed(core.BatchedOptimizer, "__init__", "BatchedOptimizer()")
+_timed(core.BatchedOptimizer, "costs", "costs() [waits for the sweeps]")
 for i in range(reps):
     opt = Optimizer(method="sa", seed=0)
     t0 = time.perf_counter()
