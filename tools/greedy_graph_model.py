@@ -1,4 +1,4 @@
-"""Model of the GRAPH form of the initial-tree generator (csrc/greedy_graph.hip) in plain Python, checked
+"""Model of the GRAPH form of the initial-tree generator (csrc/greedy_graph.h) in plain Python, checked
 against the set form (`ctree.ssa_greedy`, the restatement of opt_einsum's greedy) -- and the numbers the
 kernel's LDS budget is sized by (list lengths, entries created, depth of the parent chains).
 
