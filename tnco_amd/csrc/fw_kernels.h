@@ -1558,14 +1558,17 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_WAVES) void fw_reslice_kernel(
 // fw_reslice_a_kernel (lock-step, its own traverse), the full rebuild + the end of the sweep by
 // fw_reslice_b_kernel.
 // ---------------------------------------------------------------------------------------------
-// changed indices the re-pricing handles, 32 per pass over the paths (more: the full rebuild).  128 in both
-// configurations since round 4: on config 5 at max_width 32 one re-slice in 10^4 changes more than 64 indices
-// (99.99 % at most 62, tools/fw_changed_hist.py), and each of those few held the whole batch up for the
-// 0.5-1.7 ms of a lock-step full rebuild -- a third of the re-slice time.
+// changed indices the re-pricing handles, 32 per pass over the paths (more: the full rebuild).  96 instead of 64 in
+// the lean configuration since round 4: on config 5 at max_width 32 one re-slice in 10^4 changes more than 64
+// indices (99.99 % at most 62, none above 85 in 7.8 M: tools/fw_changed_hist.py), and each of those few held
+// the whole batch up for the 0.5-1.7 ms of a lock-step full rebuild: +4 ... +9 % on the bench's schedule (A/B on
+// one box, three times each).  96 keeps the 536-tensor network at 10 240 B of LDS, 16 wavefronts per CU; 128
+// (10 400 B, 15 per CU) gained nothing more.  Late in a schedule, where no re-slice changes that much, the
+// limits do not differ beyond the +-3 % between two runs.
 #ifndef TNCO_FWT_MAXD
-#define TNCO_FWT_MAXD 128  // (-DTNCO_FWT_MAXD=64: the earlier limit, for A/B runs)
+#define TNCO_FWT_MAXD 96  // (-DTNCO_FWT_MAXD=64: the earlier limit, for A/B runs)
 #endif
-template <bool BIG> constexpr int FWT_MAXD = TNCO_FWT_MAXD;
+template <bool BIG> constexpr int FWT_MAXD = BIG ? 128 : TNCO_FWT_MAXD;
 
 #ifndef TNCO_FW_RESLICE_A_WAVES
 #define TNCO_FW_RESLICE_A_WAVES TNCO_FW_RESLICE_WAVES
@@ -1753,7 +1756,7 @@ __device__ __forceinline__ uint32_t fws_rowscan(uint32_t v) {
 // ---------------------------------------------------------------------------------------------
 constexpr int FWH_MAXH = 7;      // tensors holding one index at most, for the re-pricing (more: the full rebuild)
 // re-pricing, per changed index: the two path starts (4 B) and joined / left (1 B); HYPER: 8 slots of (path start, leaf) + the holder count
-__host__ __device__ inline size_t fww_chg_bytes(bool hyper, bool big) { return (size_t)FWT_MAXD<false> * (4 + 1 + (hyper ? 8 * 2 * 2 + 1 : 0)) + 32; }
+__host__ __device__ inline size_t fww_chg_bytes(bool hyper, bool big) { return (size_t)(big ? FWT_MAXD<true> : FWT_MAXD<false>) * (4 + 1 + (hyper ? 8 * 2 * 2 + 1 : 0)) + 32; }
 // get_slices' fixed part: shuffle steps per position [64 + 128], ring [256], candidates + swap targets (+ padding to 16)
 __host__ __device__ inline size_t fww_gs_fixed(bool big) { return 192 * 8 + 1024 + (size_t)(big ? 512 : 128) * 3 + 64; }
 __host__ __device__ inline size_t fww_lds_bytes(int n, int T, bool hyper = false, bool big = false) {  // T: lanes per mask (16, 32 or 64)
