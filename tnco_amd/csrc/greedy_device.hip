@@ -207,7 +207,7 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
   const bool graph = build_graph(n, I, holders_off, holders, output_mask, gh);
   const size_t lds = graph ? graph_lds_bytes(n, gh.CAP) : lds_bytes(W, SMAX, I, QC, TS);
   int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (size_t)(160 * 1024) / lds));
-  if (per_cu > 8) per_cu &= ~3;  // (whole wavefronts per SIMD: 13 per CU measured a third slower than 12)
+  if (per_cu > 12) per_cu &= ~3;  // (13 per CU measured a third slower than 12; 9, 10, 11 each faster than the one before)
   if (const char* e = std::getenv("TNCO_HIP_GREEDY_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(e)));  // (experiment: occupancy sensitivity)
   const int G = (int)std::min<int64_t>(R, (int64_t)cus * per_cu);
 

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
     GP_T(3);
     // ---- the greedy loop ----
     const bool innw = lane < NW;
-    while (status == 0) {
+    while (status == 0 && n_alive > 1) {  // (one tensor left: every candidate still queued is obsolete)
       const uint64_t best = wmin64(lkey);
       if (best == KMAX) break;
       const int wl = __ffsll((unsigned long long)__ballot(lkey == best)) - 1;
