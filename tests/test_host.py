@@ -354,3 +354,39 @@ def test_replica_seeds_through_numpy_are_random_choices():
             a.random(), b.random()
         assert a.choices(range(2**32), k=k) == replica_seeds(b, k)
         assert a.getstate() == b.getstate() and a.random() == b.random()
+
+
+def test_graph_form_of_the_greedy_equals_the_set_form():
+    """The claim greedy_graph_kernel rests on (csrc/greedy_graph.h), on the CPU: without hyper-indices opt_einsum's
+    greedy over index sets is a greedy over a multigraph -- ssa ids, leg counts, (neighbour, shared legs) lists,
+    a union-find over dead ids.  tools/greedy_graph_model.py against ctree.ssa_greedy, path for path."""
+    import pathlib
+    import sys
+    from random import Random
+
+    import numpy as np
+
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1] / "tools"))
+    import greedy_graph_model as gm
+    from tests.test_gpu_greedy import _hubs, _random_multigraph
+    from tnco_amd import ctree as ct, synthetic as syn
+
+    rng = np.random.default_rng(7)
+    nets = [_random_multigraph(rng) for _ in range(40)]
+    nets.append((*_hubs(30, double={(0, 3)}), []))
+    reg = syn.regular_problem(64, 7)
+    nets.append((reg.ts_inds, reg.n_inds, []))
+    same = 0
+    for ts, _n_inds, out in nets:
+        for seed in (0, 5):
+            order = list(range(len(ts)))
+            Random(seed).shuffle(order)
+            inputs = [frozenset(ts[t]) for t in order]
+            ref = ct.ssa_greedy(inputs, frozenset(out))
+            got = gm.graph_greedy(inputs, frozenset(out))
+            if got is None:  # (a second component: the set form goes on with outer products)
+                continue
+            norm = lambda p: [(min(a, b), max(a, b)) for a, b in p]  # noqa: E731
+            assert norm(got) == norm(ref)
+            same += 1
+    assert same > 60

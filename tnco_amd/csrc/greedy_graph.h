@@ -422,7 +422,7 @@ bool build_graph(int n, int I, const int32_t* off, const int32_t* holders, const
   g.t_kp.resize((size_t)n);
   size_t L = 0;
   for (int t = 0; t < n; ++t) L += adj[t].size();
-  if (L > 12000) return false;
+  if (L + 256 > 0x7FFF) return false;  // (a list's offset is 15 bits of its tensor's record)
   g.L = (int)L;
   g.CAP = std::max((int)L + 256, n);
   for (int t = 0; t < n; ++t) {
