@@ -1568,7 +1568,10 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_WAVES) void fw_reslice_kernel(
 #ifndef TNCO_FWT_MAXD
 #define TNCO_FWT_MAXD 96  // (-DTNCO_FWT_MAXD=64: the earlier limit, for A/B runs)
 #endif
-template <bool BIG> constexpr int FWT_MAXD = BIG ? 128 : TNCO_FWT_MAXD;
+#ifndef TNCO_FWT_MAXD_BIG
+#define TNCO_FWT_MAXD_BIG 256  // (the roomier configuration: networks sliced far below their width change more at once)
+#endif
+template <bool BIG> constexpr int FWT_MAXD = BIG ? TNCO_FWT_MAXD_BIG : TNCO_FWT_MAXD;
 
 #ifndef TNCO_FW_RESLICE_A_WAVES
 #define TNCO_FW_RESLICE_A_WAVES TNCO_FW_RESLICE_WAVES

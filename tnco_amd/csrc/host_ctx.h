@@ -46,6 +46,7 @@ struct tnco_hip_ctx {
   // tnco_hip_get_fw_stats: [0] replica re-slices launched in the re-pricing form, [1] of those left to the full rebuild,
   // [2..4] why (FwParams::slowstat[1..3]), [5] replica re-slices launched in the walk + full-rebuild form
   int64_t fw_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool fw_probed = false;  // the first re-slice interval of the handle has run on its own (tnco_hip_run_fw)
   unsigned long long fw_slow_pending = 0, fw_slow_wide_pending = 0;  // fall-backs collected since tnco_hip_run_fw last chose a form
   tnco::FwParams F{};
   std::vector<void*> allocs;
