@@ -74,7 +74,10 @@ __global__ __launch_bounds__(256) void rnd_kernel(uint8_t* buf, uint64_t n_grain
 // would cost); 1: 4-byte writes; 2: every write is a whole aligned 64-byte piece (the parent field
 // together with the rest of the first half of the block, and the header together with legs 0..3).
 // moves/s of this kernel = the memory system's ceiling for the pattern.
-template <int UNROLL, int ACC, int PARENTS>
+// WIDE = 1: the block of an accepted move written by TWO instructions of 64 bytes per group (16 bytes per lane)
+// instead of FOUR of 32 (the kernel's word-interleaved lanes: one 32-byte sector per instruction) -- fewer write
+// requests for the same bytes.
+template <int UNROLL, int ACC, int PARENTS, int WIDE = 0>
 __global__ __launch_bounds__(256) void move_pattern_kernel(uint8_t* buf, uint64_t n_lines, int iters, uint64_t* sink) {
   const int lane = threadIdx.x & 3;
   const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
@@ -96,12 +99,23 @@ __global__ __launch_bounds__(256) void move_pattern_kernel(uint8_t* buf, uint64_
       const uint64_t s = hx[u] + y[u][0] + y[u][1] + y[u][2] + y[u][3];
       acc += s;
       const bool accepted = ((it + u) & 3) < ACC;
-      *reinterpret_cast<uint64_t*>(buf + Z * 128 + lane * 8) = s;
-      if (PARENTS == 2) *reinterpret_cast<uint64_t*>(buf + Z * 128 + 32 + lane * 8) = s + 1;
+      if (WIDE) {
+        if (accepted) {
+          *reinterpret_cast<uint4*>(buf + Z * 128 + lane * 16) = make_uint4((uint32_t)s, (uint32_t)(s >> 32), 1, 2);
+          *reinterpret_cast<uint4*>(buf + Z * 128 + 64 + lane * 16) = make_uint4((uint32_t)s, (uint32_t)(s >> 32), 3, 4);
+        } else if (lane < 2) {
+          *reinterpret_cast<uint4*>(buf + Z * 128 + lane * 16) = make_uint4((uint32_t)s, (uint32_t)(s >> 32), 1, 2);
+        }
+      } else {
+        *reinterpret_cast<uint64_t*>(buf + Z * 128 + lane * 8) = s;
+        if (PARENTS == 2) *reinterpret_cast<uint64_t*>(buf + Z * 128 + 32 + lane * 8) = s + 1;
+      }
       if (accepted) {
+        if (!WIDE) {
 #pragma unroll
-        for (int w = (PARENTS == 2 ? 2 : 1); w < 4; ++w)
-          *reinterpret_cast<uint64_t*>(buf + Z * 128 + w * 32 + lane * 8) = s + w;
+          for (int w = (PARENTS == 2 ? 2 : 1); w < 4; ++w)
+            *reinterpret_cast<uint64_t*>(buf + Z * 128 + w * 32 + lane * 8) = s + w;
+        }
         if (PARENTS == 1 && lane == 0) {
           *reinterpret_cast<uint32_t*>(buf + U * 128 + 8) = (uint32_t)s;
           *reinterpret_cast<uint32_t*>(buf + V * 128 + 8) = (uint32_t)s + 1;
@@ -175,7 +189,7 @@ static void run_fw_pattern(uint8_t* buf, size_t bytes, uint64_t* sink, int waves
          ACC, CHDR ? "read    " : "not read", UNROLL, waves_per_simd, (double)blocks * 64 * iters / ms * 1e-6);
 }
 
-template <int UNROLL, int ACC, int PARENTS>
+template <int UNROLL, int ACC, int PARENTS, int WIDE = 0>
 static void run_pattern(uint8_t* buf, size_t bytes, uint64_t* sink, int waves_per_simd) {
   const int blocks = 256 * waves_per_simd;
   const int iters = 1024;
@@ -183,17 +197,17 @@ static void run_pattern(uint8_t* buf, size_t bytes, uint64_t* sink, int waves_pe
   CHECK(hipEventCreate(&a));
   CHECK(hipEventCreate(&b));
   const uint64_t n_lines = bytes / 128;
-  move_pattern_kernel<UNROLL, ACC, PARENTS><<<blocks, 256>>>(buf, n_lines, 64, sink);
+  move_pattern_kernel<UNROLL, ACC, PARENTS, WIDE><<<blocks, 256>>>(buf, n_lines, 64, sink);
   CHECK(hipDeviceSynchronize());
   CHECK(hipEventRecord(a));
-  move_pattern_kernel<UNROLL, ACC, PARENTS><<<blocks, 256>>>(buf, n_lines, iters, sink);
+  move_pattern_kernel<UNROLL, ACC, PARENTS, WIDE><<<blocks, 256>>>(buf, n_lines, iters, sink);
   CHECK(hipEventRecord(b));
   CHECK(hipEventSynchronize(b));
   float ms = 0;
   CHECK(hipEventElapsedTime(&ms, a, b));
   const double moves = (double)blocks * 64 * iters;
-  printf("move pattern, accepted %d/4, parent writes %s, in-flight/group %d, waves/SIMD %d : %6.2f G moves/s\n", ACC,
-         PARENTS == 0 ? "no " : (PARENTS == 1 ? "4 B" : "64B"), UNROLL, waves_per_simd, moves / ms * 1e-6);
+  printf("move pattern, accepted %d/4, parent writes %s, block written in %s, in-flight/group %d, waves/SIMD %d : %6.2f G moves/s\n", ACC,
+         PARENTS == 0 ? "no " : (PARENTS == 1 ? "4 B" : "64B"), WIDE ? "2 x 64 B" : "4 x 32 B", UNROLL, waves_per_simd, moves / ms * 1e-6);
 }
 
 // lane 0 of every group writes 4 bytes into a random 128-B block (a parent-pointer update)
@@ -268,6 +282,9 @@ int main(int argc, char** argv) {
     run<64, 2, 8>(buf, bytes, sink, w);
     run_tiny(buf, bytes, w);
     run_pattern<4, 3, 1>(buf, bytes, sink, w);
+    run_pattern<4, 2, 1>(buf, bytes, sink, w);
+    run_pattern<4, 2, 1, 1>(buf, bytes, sink, w);
+    run_pattern<4, 3, 1, 1>(buf, bytes, sink, w);
     run_pattern<4, 3, 0>(buf, bytes, sink, w);
     run_pattern<4, 3, 2>(buf, bytes, sink, w);
     run_pattern<4, 4, 2>(buf, bytes, sink, w);
