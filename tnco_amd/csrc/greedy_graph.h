@@ -25,7 +25,7 @@ namespace {
 // good) and two live tensors with equal sets are an isolated pair, so a slot IS an ssa id; the stored result
 // of a queued candidate is what contracting its two tensors gives as long as both are alive.
 //   * lists are never updated in place: an entry names the tensor its leg went to when the list was made,
-//     and link[] (the parent of a dead id) leads from there to the live tensor that holds it now -- a
+//     and rec[] (for a dead id: its parent) leads from there to the live tensor that holds it now -- a
 //     union-find whose paths the look-ups shorten; the entries of u and v resolve in parallel, one per lane;
 //   * equal neighbours are joined through a byte per id (mark: the lane that speaks for the id);
 //   * lists live in ONE arena of L + 256 entries (L = entries of the inputs; the live entries only ever
@@ -33,7 +33,8 @@ namespace {
 //   * the queue is greedy_kernel's (64-bit keys, cell c owned by lane c % 64, a push goes into the cell
 //     just popped) but IN REGISTERS, ROWS cells per lane; the cost keys of the initial candidates do not
 //     depend on the shuffle and come from the host.
-// 512 tensors / 768 indices: 12 KB of LDS per tree (13 trees per CU), no memory traffic but the links written out.
+// 512 tensors / 768 indices: 12 KB of LDS per tree (12 trees per CU: VALU-bound there), no memory traffic but the shuffled
+// order read and the links written out.
 constexpr int GRAPH_MAXLIST = 255;  // entries of u and v together (more: the tree goes to the host)
 constexpr int GRAPH_SHORT = 8;      // a list this short moves through registers when the arena is compacted
 struct GraphParams {
