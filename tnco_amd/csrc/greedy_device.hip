@@ -205,7 +205,19 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
   }
   GraphHost gh;
   const bool graph = build_graph(n, I, holders_off, holders, output_mask, gh);
-  const size_t lds = graph ? graph_lds_bytes(n, gh.CAP) : lds_bytes(W, SMAX, I, QC, TS);
+  // the set form's queue in registers where the dims' candidates fit 16 rows of 64 cells (greedy_set.h)
+  int m1 = 1, set_rows = 0;
+  for (int i = 0; i < I; ++i) {
+    const bool is_out = output_mask && ((output_mask[i >> 6] >> (i & 63)) & 1ull);
+    if (!is_out) m1 = std::max(m1, holders_off[i + 1] - holders_off[i] - 1);
+  }
+  if (!graph && !(std::getenv("TNCO_HIP_GREEDY_LDS_QUEUE") && std::atoi(std::getenv("TNCO_HIP_GREEDY_LDS_QUEUE")) != 0)) {
+    const int need = (I + 63) / 64 * m1;
+    for (int rw : {4, 8, 12, 16})  // (24 rows: 200 VGPRs, two wavefronts per SIMD -- fewer trees per CU than with the queue in LDS)
+      if (set_rows == 0 && need <= rw) set_rows = rw;
+  }
+  const int Qa = set_rows ? set_rows * 64 : Q;  // rows of the stored results (one per queue cell)
+  const size_t lds = graph ? graph_lds_bytes(n, gh.CAP) : lds_bytes(W, SMAX, I, set_rows ? 0 : QC, TS);
   int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (size_t)(160 * 1024) / lds));
   if (per_cu > 12) per_cu &= ~3;  // (13 per CU measured a third slower than 12; 9, 10, 11 each faster than the one before)
   if (const char* e = std::getenv("TNCO_HIP_GREEDY_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(e)));  // (experiment: occupancy sensitivity)
@@ -236,7 +248,7 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
     if (!graph) {
       G_TRY(db.alloc(&gp.keys, (size_t)G * SMAX * W));
       G_TRY(db.alloc(&gp.nbr, (size_t)G * SMAX * NW));
-      G_TRY(db.alloc(&gp.arena, (size_t)G * Q * W));
+      G_TRY(db.alloc(&gp.arena, (size_t)G * Qa * W));
       G_TRY(db.alloc(&gp.path, (size_t)G * n * 2));
       G_TRY(db.alloc(&gp.slot_of_leaf, (size_t)G * n));
     } else {
@@ -299,7 +311,7 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
   }
   G_TRY(hipGetLastError());
   if (dbg) G_TRY(hipEventRecord(ev[1], 0));
-  gp.n = n; gp.I = I; gp.W = W; gp.NW = NW; gp.SMAX = SMAX; gp.Q = Q; gp.TS = TS; gp.R = R;
+  gp.n = n; gp.I = I; gp.W = W; gp.NW = NW; gp.SMAX = SMAX; gp.Q = Qa; gp.M1 = m1; gp.TS = TS; gp.R = R;
   gp.leaf = d_leaf; gp.output = d_out; gp.hoff = d_hoff; gp.holders = d_hold; gp.perm = d_perm;
   if (graph) {
     GraphParams qp{};
@@ -318,7 +330,15 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
     else TNCO_GRAPH_LAUNCH(24);
 #undef TNCO_GRAPH_LAUNCH
   } else {
-    hipLaunchKernelGGL(greedy_kernel, dim3((unsigned)G), dim3(64), lds, 0, gp);
+#define TNCO_SET_LAUNCH(RW) hipLaunchKernelGGL(greedy_kernel<RW>, dim3((unsigned)G), dim3(64), lds, 0, gp)
+    switch (set_rows) {
+      case 4: TNCO_SET_LAUNCH(4); break;
+      case 8: TNCO_SET_LAUNCH(8); break;
+      case 12: TNCO_SET_LAUNCH(12); break;
+      case 16: TNCO_SET_LAUNCH(16); break;
+      default: TNCO_SET_LAUNCH(0); break;
+    }
+#undef TNCO_SET_LAUNCH
   }
   G_TRY(hipGetLastError());
   if (dbg) G_TRY(hipEventRecord(ev[2], 0));

@@ -12,6 +12,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 struct GreedyParams {
   int32_t n, I, W, NW, SMAX, Q, TS;  // TS: table size (a power of two)
+  int32_t M1;                         // (queue in registers) candidates a dim can start with: max holders - 1
   int64_t R;
   const uint64_t* leaf;     // [n][W] index sets of the tensors, original order
   const uint64_t* output;   // [W]
@@ -29,11 +30,17 @@ struct GreedyParams {
   unsigned long long* prof; // [G][16] (TNCO_GREEDY_PROF)
 };
 
+// ROWS > 0: the candidate queue in REGISTERS, ROWS cells per lane (as in greedy_graph_kernel: 6 KB of LDS less at
+// 768 candidates, 9 -> 15 trees per CU), cell (row, lane) = candidate `row % M1` of dim 64 (row / M1) + lane -- the
+// initial candidates of a dim stay in its lane, a push goes into the cell just popped.  ROWS = 0: the queue in LDS
+// (networks whose dims x candidates per dim need more than 16 rows: beyond that the registers cost more trees per CU
+// than the LDS did).
+template <int ROWS>
 __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
   extern __shared__ uint64_t lds_raw[];
   const int lane = threadIdx.x;
   const int n = p.n, I = p.I, W = p.W, NW = p.NW, SMAX = p.SMAX, Q = p.Q, TS = p.TS;
-  const int QC = (Q + 63) & ~63;  // queue cells (a multiple of 64)
+  const int QC = ROWS > 0 ? 0 : (Q + 63) & ~63;  // queue cells in LDS (a multiple of 64)
   // LDS: queue keys [QC] | broadcast rows a, output, ref2, ref3 [4 W] | ssa [SMAX] | holders per dim [I] |
   //      neighbour list [GREEDY_LCAP] | slot of an ssa id [2n] | table [TS]
   lds_u64 hk = (lds_u64)lds_raw;
@@ -55,11 +62,14 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
 #ifdef TNCO_GREEDY_PROF
   unsigned long long prof_[16] = {0}, pt_ = __builtin_amdgcn_s_memtime();
 #endif
+  uint64_t qc[ROWS > 0 ? ROWS : 1];
   for (int64_t r = g; r < p.R; r += gridDim.x) {
     const uint16_t* perm = p.perm + r * (int64_t)n;
     int status = 0;
     // ---- clear ----
     for (int c = lane; c < QC; c += 64) hk[c] = KMAX;
+#pragma unroll
+    for (int q = 0; q < (ROWS > 0 ? ROWS : 1); ++q) qc[q] = KMAX;
     for (int c = lane; c < TS; c += 64) table[c] = -1;
     for (int c = lane; c < I; c += 64) cnt[c] = 0;
     for (int c = lane; c < SMAX; c += 64) ssa[c] = DEAD;
@@ -232,12 +242,21 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
       int m = 0;
       if (d < I && !((bc[W + (d >> 6)] >> (d & 63)) & 1ull)) m = dim_slots(d, sl, id);
       const int mine = m >= 2 ? m - 1 : 0;
-      const int base = count + (int)wscan_excl((uint32_t)mine, lane);
-      count += (int)wsum((uint32_t)mine);
-      if (count > Q) {
+      int base = 0;
+      if constexpr (ROWS == 0) {
+        base = count + (int)wscan_excl((uint32_t)mine, lane);
+        count += (int)wsum((uint32_t)mine);
+        if (count > Q) {
+          status = 5;
+          break;
+        }
+      } else if (__any(mine > p.M1) || ((d0 >> 6) + 1) * p.M1 > ROWS) {
         status = 5;
         break;
       }
+      uint64_t bk[GREEDY_MAXH - 1];
+#pragma unroll
+      for (int i = 0; i + 1 < GREEDY_MAXH; ++i) bk[i] = KMAX;
 #pragma unroll
       for (int i = 0; i + 1 < GREEDY_MAXH; ++i) {
         if (i + 1 < m) {
@@ -259,15 +278,24 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
 #pragma unroll
           for (int j = 1; j < GREEDY_MAXH; ++j)
             if (j == bj) sj = sl[j];
-          const int seq = base + i;
+          const int seq = ROWS > 0 ? ((d0 >> 6) * p.M1 + i) * 64 + lane : base + i;
           uint64_t* row = arena + (size_t)seq * W;
           for (int x = 0; x < W; ++x) {
             const uint64_t a = keys[(size_t)sl[i] * W + x], b = keys[(size_t)sj * W + x];
             const uint64_t either = a | b, two = a & b, one = either & ~two;
             row[x] = (either & bc[W + x]) | (two & bc[3 * W + x]) | (one & bc[2 * W + x]);
           }
-          hk[seq] = bestk;
+          if constexpr (ROWS == 0) hk[seq] = bestk;
+          bk[i] = bestk;
         }
+      }
+      if constexpr (ROWS > 0) {  // this dim's candidates into this lane's cells, rows (d0 / 64) M1 + i
+        const int row0 = (d0 >> 6) * p.M1;
+#pragma unroll
+        for (int i = 0; i + 1 < GREEDY_MAXH; ++i)
+#pragma unroll
+          for (int q = 0; q < ROWS; ++q)
+            if (q == row0 + i && i + 1 < m) qc[q] = bk[i];
       }
     }
     __syncthreads();
@@ -277,6 +305,15 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
     auto rescan = [&]() {
       lkey = KMAX;
       lrow = 0;
+      if constexpr (ROWS > 0) {
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q)
+          if (qc[q] < lkey) {
+            lkey = qc[q];
+            lrow = q;
+          }
+        return;
+      }
       const __attribute__((address_space(3))) uint64_t* cells = (const __attribute__((address_space(3))) uint64_t*)hk + lane;
       const int rows = (count + 63) >> 6;
       for (int row = 0; row < rows; row += 4) {
@@ -299,8 +336,14 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
       const uint64_t best = wmin64(lkey);
       if (best == KMAX) break;
       const int wl = __ffsll((unsigned long long)__ballot(lkey == best)) - 1;
-      const int seq = uni(__shfl(lrow, wl)) * 64 + wl;
-      if (lane == wl) {
+      const int qrow = uni(__shfl(lrow, wl));
+      const int seq = qrow * 64 + wl;
+      if constexpr (ROWS > 0) {
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q)
+          if (q == qrow && lane == wl) qc[q] = KMAX;
+        rescan();
+      } else if (lane == wl) {
         hk[seq] = KMAX;
         rescan();
       }
@@ -451,8 +494,13 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
         // into the cell (and the arena row) of the candidate popped in this iteration: the queue never
         // holds more than the initial candidates
         if (inw) arena[(size_t)seq * W + lane] = res;
+        if constexpr (ROWS > 0) {
+#pragma unroll
+          for (int q = 0; q < ROWS; ++q)
+            if (q == qrow && lane == wl) qc[q] = wk;
+        }
         if (lane == wl) {
-          hk[seq] = wk;
+          if constexpr (ROWS == 0) hk[seq] = wk;
           if (wk < lkey) {
             lkey = wk;
             lrow = seq >> 6;
