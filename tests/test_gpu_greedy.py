@@ -35,13 +35,16 @@ def _supported(ts, n_inds):
     return bool(_lib.load().tnco_hip_greedy_device_supported(len(ts), n_inds, off.ctypes.data))
 
 
-@pytest.fixture(params=["graph", "set"])
+@pytest.fixture(params=["graph", "set", "set-lds-queue"])
 def form(request, monkeypatch):
-    """Both device forms of the greedy (the multigraph in LDS where the network has no hyper-index -- the
-    default -- and the index sets in memory) with both shuffle kernels (state in LDS / in memory)."""
-    if request.param == "set":
+    """The device forms of the greedy (the multigraph in LDS where the network has no hyper-index -- the
+    default -- and the index sets in memory, with the candidate queue in registers or in LDS) with both
+    shuffle kernels (state in LDS / in memory)."""
+    if request.param != "graph":
         monkeypatch.setenv("TNCO_HIP_GREEDY_GRAPH", "0")
         monkeypatch.setenv("TNCO_HIP_SHUFFLE_LDS", "0")
+    if request.param == "set-lds-queue":
+        monkeypatch.setenv("TNCO_HIP_GREEDY_LDS_QUEUE", "1")
     return request.param
 
 
@@ -55,7 +58,9 @@ def test_regular_graphs(n, gs, form):
         ct.derive_inds(links[k, 0], links[k, 1], prob.leaf_masks, prob.output_mask, check_shared_inds=True)
 
 
-def test_hyper_indices_outputs_equal_sets():
+@pytest.mark.parametrize("lds_queue", ["0", "1"])
+def test_hyper_indices_outputs_equal_sets(lds_queue, monkeypatch):
+    monkeypatch.setenv("TNCO_HIP_GREEDY_LDS_QUEUE", lds_queue)
     seeds = syn.replica_seeds(40)
     for seed in range(8):
         ts, _d, out = syn.random_hyper_tn(20, 37, k=3, n_output=4, seed=seed)
