@@ -60,12 +60,6 @@ typedef __attribute__((address_space(3))) volatile uint32_t* lds_u32;
 
 __host__ __device__ inline size_t graph_lds_bytes(int n, int CAP) { return 256 + (size_t)13 * n + (size_t)3 * CAP + 16; }  // (rec 8n, perm 2n, mark 2n, kept n)
 
-// LDS traffic of ONE wavefront needs no barrier: the LDS unit takes a wavefront's instructions in order.  (A
-// __syncthreads() would also wait for the links on their way to memory -- a microsecond per contraction.)
-__device__ __forceinline__ void wsync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
 __device__ __forceinline__ uint32_t wmin32(uint32_t v) {
   uint32_t t = dpp<0xB1>(v);
   v = t < v ? t : v;

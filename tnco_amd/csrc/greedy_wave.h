@@ -84,6 +84,13 @@ __device__ __forceinline__ uint32_t wscan_excl(uint32_t v, int lane) {
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// LDS traffic of ONE wavefront needs no barrier: the LDS unit takes a wavefront's instructions in order.  (A
+// __syncthreads() would also wait for the links on their way to memory -- a microsecond per contraction.)
+__device__ __forceinline__ void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 typedef __attribute__((address_space(3))) volatile uint64_t* lds_u64;
 typedef __attribute__((address_space(3))) volatile uint16_t* lds_u16;
 typedef __attribute__((address_space(3))) volatile int16_t* lds_i16;
