@@ -305,7 +305,7 @@ def pmc_passes(args, lib_version):
                 "--replicas", str(args.replicas), "--graph-seed", str(args.graph_seed), "--init", args.init,
                 "--workload", args.workload, "--fw-max-width", str(args.fw_max_width),
                 "--fw-update-slices", str(args.fw_update_slices), "--fw-depth", str(args.fw_depth),
-                "--fw-layout", args.fw_layout, "--cpu-sample", "0", "--pmc", "0"]
+                "--fw-layout", args.fw_layout, "--cpu-sample", "0", "--pmc", "0", "--e2e", "0"]
     vals = {}  # (kernel short name, counter) -> per-dispatch values in dispatch order
     names = {}  # kernel short name -> the kernels' names in the trace
     t0 = time.perf_counter()
@@ -410,6 +410,34 @@ def transport_verdict(comm_kind, world, requested):
     return kind, rccl_ranks, code
 
 
+def end_to_end(args):
+    """optimize() of the reference's plugin API on the headline network, wall time of the whole call: index-list spec
+    -> TensorNetwork -> initial trees as the reference draws them (on the device) -> create -> sweeps -> the 16 best
+    contraction paths as Python objects.  Informational (not `value`): the hot path is the `sweeps` part of it."""
+    try:
+        import warnings
+
+        from tnco_amd import synthetic
+        from tnco_amd.app import Optimizer
+        ts, _d, _o = synthetic.random_regular_tn(args.leaves, 3, args.graph_seed)
+        n_inds = max(max(x) for x in ts) + 1
+        spec = [(2, *[f"t{t}" for t in range(len(ts)) if k in ts[t]]) for k in range(n_inds)]
+        n_steps, times = 1000, []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for _ in range(3):
+                t0 = time.perf_counter()
+                _tn, res = Optimizer(method="sa", seed=0).optimize(spec, betas=(0, 100), n_steps=n_steps, n_runs=args.replicas,
+                                                                  top_k=16, fuse=None)
+                times.append(time.perf_counter() - t0)
+        return {"call": f"Optimizer(method='sa', seed=0).optimize(<{args.leaves}-tensor 3-regular network>, betas=(0, 100), "
+                        f"n_steps={n_steps}, n_runs={args.replicas}, top_k=16, fuse=None)",
+                "seconds": round(min(times[1:]), 4), "first_call_seconds": round(times[0], 4),
+                "best_log2_cost": round(float(np.log2(float(res[0].cost))), 4)}
+    except Exception as e:  # (informational: never fails the bench line)
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -436,6 +464,9 @@ def main() -> None:
     ap.add_argument("--pmc-timeout", type=float, default=240.0)
     ap.add_argument("--pmc-out", default=None, help="also write the per-step PMC counters of the timed kernels to this file")
     ap.add_argument("--validate", action="store_true", help="device-side is_valid() of every replica after the run")
+    ap.add_argument("--e2e", type=int, default=1,
+                    help="1 (N = 1): also time app.Optimizer(method='sa').optimize() of the headline network end to end "
+                         "(spec -> initial trees -> sweeps -> best paths): the `end_to_end` object, informational")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -732,6 +763,8 @@ def main() -> None:
                 out["config"]["comm_note"] = comm_note
         for kind in legs[1:]:
             out[kind] = leg_object(kind)
+        if args.e2e and world == 1:
+            out["end_to_end"] = end_to_end(args)
         print(json.dumps(out), flush=True)
     for leg in objs.values():
         if leg.opt is not None:
