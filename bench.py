@@ -763,7 +763,7 @@ def main() -> None:
                 out["config"]["comm_note"] = comm_note
         for kind in legs[1:]:
             out[kind] = leg_object(kind)
-        if args.e2e and world == 1:
+        if args.e2e and world == 1 and args.replicas <= 131072:  # (beside the legs' own handles: not for the 100-GB batches)
             out["end_to_end"] = end_to_end(args)
         print(json.dumps(out), flush=True)
     for leg in objs.values():
