@@ -558,6 +558,29 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
   }
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+  M csl = mzero<K>();
+  if (a.cost_slices) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) csl.w[k] = a.cost_slices[r * a.cost_slices_stride + v.widx(k)];
+  }
+  double sum = 0.0;
+  // validity (ctree.hpp:101-152), hyper cache, cost caches of one internal node whose children are done
+  auto finish_node = [&](int p, int l, int rr, const M& ia, const M& ib, const M& ip) {
+    const M uni = mor<K>(ia, ib);
+    if (!P.disable_shared && !gany<LOG2L>(mnonzero<K>(mand<K>(ia, ib)))) status = status ? status : 10;
+    if (gany<LOG2L>(mnonzero<K>(mor<K>(mandn<K>(mxor<K>(ia, ib), ip), mandn<K>(ip, uni))))) status = status ? status : 11;
+    v.set_hyper(p, mand<K>(ip, mand<K>(ia, ib)));
+    const double c = generic_cost<LOG2L, K>(P, mor<K>(uni, csl), lig, gbase);
+    const double part = rnd_cost(rnd_cost(c + v.partial(l), P.f32) + v.partial(rr), P.f32);  // utils.hpp:54
+    sum = rnd_cost(sum + c, P.f32);                                                          // utils.hpp:112
+    if (lane0) { v.hdr(p)->ccost = c; v.hdr(p)->partial = part; }
+  };
+  // Without hyper-indices and with legs derived from the links, a node's legs, checks and costs need nothing but its
+  // children's: everything is done when the traverse LEAVES the node -- one pass of dependent round trips over the
+  // tree instead of three (65 536 trees of 512 leaves: 16 ms of every create(); each replica's time is its chain of
+  // memory round trips, all replicas being resident at once).
+  const bool fused = !HYPER && !a.in_masks;
+
   // -- traverse (utils.hpp:34-51), every lane of the group redundantly -----
   int sp = 1, cnt = 0;
   if (lane0) stack[0] = N - 1;
@@ -569,6 +592,12 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
       --sp;
       if (lane0) order[cnt] = pos;
       ++cnt;
+      if (fused && l >= 0) {
+        const int rr = v.right(pos);
+        const M ia = v.mask(l), ib = v.mask(rr), ip = mxor<K>(ia, ib);
+        v.set_mask(pos, ip);
+        finish_node(pos, l, rr, ia, ib, ip);
+      }
     } else {
       const int rr = v.right(pos);
       if (lane0) { visited[pos] = 1; stack[sp] = rr; stack[sp + 1] = l; }
@@ -588,12 +617,7 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
       else if (gany<LOG2L>(mdiffer<K>(x, v.mask(p)))) status = 12;  // leaves must be the shared table
     }
   } else if constexpr (!HYPER) {
-    for (int i = 0; i < N; ++i) {
-      const int p = order[i];
-      const int l = v.left(p);
-      if (l < 0) continue;
-      v.set_mask(p, mxor<K>(v.mask(l), v.mask(v.right(p))));
-    }
+    // (done while traversing)
   } else {
     // union of leaves below (in the legs slot), legs held outside (in the hyper slot), then
     // legs = (a ^ b) | (a & b & outside)   [tnco/ctree.py:163-189]
@@ -623,28 +647,16 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
     }
   }
 
-  // -- validity, hyper cache, cost caches ----------------------------------
-  M csl = mzero<K>();
-  if (a.cost_slices) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) csl.w[k] = a.cost_slices[r * a.cost_slices_stride + v.widx(k)];
-  }
-  double sum = 0.0;
-  for (int i = 0; i < N; ++i) {
-    const int p = order[i];
-    const int l = v.left(p);
-    if (l < 0) continue;
-    const int rr = v.right(p);
-    const M ia = v.mask(l), ib = v.mask(rr), ip = v.mask(p);
-    const M uni = mor<K>(ia, ib);
-    if (!P.disable_shared && !gany<LOG2L>(mnonzero<K>(mand<K>(ia, ib)))) status = status ? status : 10;
-    if (gany<LOG2L>(mnonzero<K>(mor<K>(mandn<K>(mxor<K>(ia, ib), ip), mandn<K>(ip, uni))))) status = status ? status : 11;
-    v.set_hyper(p, mand<K>(ip, mand<K>(ia, ib)));
-    const double c = generic_cost<LOG2L, K>(P, mor<K>(uni, csl), lig, gbase);
-    const double part = rnd_cost(rnd_cost(c + v.partial(l), P.f32) + v.partial(rr), P.f32);  // utils.hpp:54
-    sum = rnd_cost(sum + c, P.f32);                                                          // utils.hpp:112
-    if (lane0) { v.hdr(p)->ccost = c; v.hdr(p)->partial = part; }
-    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // -- validity, hyper cache, cost caches (the other cases: in traverse order, once the legs are there) --------
+  if (!fused) {
+    for (int i = 0; i < N; ++i) {
+      const int p = order[i];
+      const int l = v.left(p);
+      if (l < 0) continue;
+      const int rr = v.right(p);
+      finish_node(p, l, rr, v.mask(l), v.mask(rr), v.mask(p));
+      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   }
   if (lane0) {
     a.out_total[q] = v.hdr(N - 1)->partial;
