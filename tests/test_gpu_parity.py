@@ -17,8 +17,8 @@ def core():
     return c
 
 
-def _run_both(core, orc, prob, seeds, betas, prob_kind="mh", n_check=None, **kw):
-    links = prob.links(seeds)
+def _run_both(core, orc, prob, seeds, betas, prob_kind="mh", n_check=None, links=None, **kw):
+    links = prob.links(seeds) if links is None else links
     okw = {k: v for k, v in kw.items() if k in ("cost_type", "disable_shared_inds", "n_projs")}
     gpu = core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, dims=prob.dims,
                                 output_mask=prob.output_mask, sparse_mask=prob.sparse_mask, **kw)
@@ -337,3 +337,30 @@ def test_vector_dims_powers_of_two(core, oracle_lib):
     _run_both(core, oracle_lib, prob, seeds, H.linear_betas(0, 30, 100), cost_type="float32")
     probs = H.Problem(ts, np.array(dims, np.uint64), out, sparse_inds=[2, 3, 11, 30, 31, 60])
     _run_both(core, oracle_lib, probs, seeds, H.linear_betas(0, 30, 100), n_projs=6)
+
+
+@pytest.mark.parametrize("left_deep", [True, False])
+def test_caterpillar_trees_deeper_than_the_build_kernels_lds_stack(core, oracle_lib, left_deep):
+    """create() from trees 239 levels deep (a chain network contracted end to end): build_kernel's traverse keeps
+    160 stack entries per replica in LDS and spills the rest to the replica's scratch -- a left-deep spine needs
+    ~480.  Caches, costs and a few sweeps bit for bit against the oracle; with finite width too (its own traverses)."""
+    from tnco_amd.synthetic import Problem
+    n = 240
+    ts = [[i, i + 1] for i in range(n)]  # (indices 0 and n: the open ends of the chain)
+    prob = Problem(ts, 2)
+    N = 2 * n - 1
+    left = np.full(N, -1, np.int32)
+    right = np.full(N, -1, np.int32)
+    parent = np.full(N, -1, np.int32)
+    order = list(range(n)) if left_deep else list(range(n - 1, -1, -1))
+    top = order[0]
+    for k, leaf in enumerate(order[1:]):
+        z = n + k
+        # (left-deep: the spine is child 0 and the traverse's stack grows by two entries a level; else the spine is child 1)
+        left[z], right[z] = (top, leaf) if left_deep else (leaf, top)
+        parent[left[z]] = parent[right[z]] = z
+        top = z
+    tree = np.stack([left, right, parent])
+    seeds = H.replica_seeds(6, S=11)
+    links = np.repeat(tree[None], len(seeds), axis=0)
+    _run_both(core, oracle_lib, prob, seeds, H.linear_betas(0, 30, 6), links=links)

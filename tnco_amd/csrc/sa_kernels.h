@@ -582,13 +582,26 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
   const bool fused = !HYPER && !a.in_masks;
 
   // -- traverse (utils.hpp:34-51), every lane of the group redundantly -----
+  // The stack's first SCAP entries live in LDS (bit 31 of an entry: its children have been pushed -- no `visited`
+  // array to consult), deeper ones in the replica's scratch: a step then costs the one header it needs instead of a
+  // stack read, a flag read and the acknowledgement of the stores before the next step may look at the stack.
+  constexpr int SCAP = (10240 / GPB) < 160 ? (10240 / GPB) : 160;
+  __shared__ uint32_t sstack[GPB * SCAP];
+  uint32_t* sst = sstack + (tid >> LOG2L) * SCAP;
+  auto st_get = [&](int i) -> uint32_t { return i < SCAP ? sst[i] : (uint32_t)stack[i]; };
+  auto st_set = [&](int i, uint32_t val) {
+    if (i < SCAP) sst[i] = val;
+    else if (lane0) stack[i] = (int32_t)val;
+  };
+  (void)visited;
   int sp = 1, cnt = 0;
-  if (lane0) stack[0] = N - 1;
-  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  st_set(0, (uint32_t)(N - 1));
   while (sp > 0) {
-    const int pos = stack[sp - 1];
+    const uint32_t top = st_get(sp - 1);
+    const int pos = (int)(top & 0x7FFFFFFFu);
     const int l = v.left(pos);
-    if (visited[pos] || l < 0) {
+    bool wrote = sp > SCAP;
+    if ((top >> 31) || l < 0) {
       --sp;
       if (lane0) order[cnt] = pos;
       ++cnt;
@@ -597,14 +610,19 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
         const M ia = v.mask(l), ib = v.mask(rr), ip = mxor<K>(ia, ib);
         v.set_mask(pos, ip);
         finish_node(pos, l, rr, ia, ib, ip);
+        wrote = true;  // (the parent's turn reads this node's partial cost, written by lane 0)
       }
     } else {
       const int rr = v.right(pos);
-      if (lane0) { visited[pos] = 1; stack[sp] = rr; stack[sp + 1] = l; }
+      st_set(sp - 1, top | 0x80000000u);
+      st_set(sp, (uint32_t)rr);
+      st_set(sp + 1, (uint32_t)l);
       sp += 2;
+      wrote = wrote || sp > SCAP;
     }
-    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wrote) __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (`order`, for the passes below)
 
   // -- legs of internal nodes ---------------------------------------------
   if (a.in_masks) {
