@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 namespace tnco {
@@ -99,6 +100,48 @@ class DevCache {
   std::mutex mu_;
   std::vector<Block> blocks_;
   size_t held_ = 0, cap_ = (size_t)-1;
+};
+
+// Streams of destroyed handles, for the next one: hipStreamCreateWithFlags takes ~2 ms, a handle has three (6 of the
+// 20 ms of a create()).  Idle (synchronised by the handle's destructor) non-blocking streams, per device; at most 16 kept.
+class StreamCache {
+ public:
+  static StreamCache& get() {
+    static StreamCache* c = new StreamCache();
+    return *c;
+  }
+  hipError_t take(hipStream_t* s, int device) {
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      for (size_t i = 0; i < idle_.size(); ++i)
+        if (idle_[i].second == device) {
+          *s = idle_[i].first;
+          idle_.erase(idle_.begin() + (long)i);
+          return hipSuccess;
+        }
+    }
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  }
+  void give(hipStream_t s, int device) {
+    if (!s) return;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      if (idle_.size() < 16) {
+        idle_.emplace_back(s, device);
+        return;
+      }
+    }
+    (void)hipStreamDestroy(s);
+  }
+  void release_all() {
+    std::lock_guard<std::mutex> lock(mu_);
+    for (auto& e : idle_) (void)hipStreamDestroy(e.first);
+    idle_.clear();
+  }
+
+ private:
+  std::mutex mu_;
+  std::vector<std::pair<hipStream_t, int>> idle_;
 };
 
 }  // namespace tnco

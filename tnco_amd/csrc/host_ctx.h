@@ -203,7 +203,7 @@ struct tnco_hip_ctx {
     if (stream) (void)hipStreamSynchronize(stream);
     resolve_events();
     for (int q = 0; q < MAX_GROUPS; ++q) {
-      if (gstream[q]) (void)hipStreamDestroy(gstream[q]);
+      if (gstream[q]) tnco::StreamCache::get().give(gstream[q], device);
       if (gjoin[q]) (void)hipEventDestroy(gjoin[q]);
     }
     if (gfork) (void)hipEventDestroy(gfork);
@@ -217,7 +217,7 @@ struct tnco_hip_ctx {
     }
     for (size_t i = 0; i < allocs.size(); ++i) tnco::DevCache::get().give(allocs[i], alloc_bytes[i], device);
     if (d_betas) (void)hipFree(d_betas);
-    if (own_stream) (void)hipStreamDestroy(own_stream);
+    if (own_stream) tnco::StreamCache::get().give(own_stream, device);
   }
   int64_t block_bytes() const { return P.RB; }
 };

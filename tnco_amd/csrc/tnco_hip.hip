@@ -460,7 +460,10 @@ int tnco_hip_device_count(void) {
 void tnco_hip_destroy(tnco_hip_handle h) { delete h; }
 
 // device memory of destroyed handles kept for the next create (dev_cache.h): given back / how much is held
-void tnco_hip_release_cached(void) { tnco::DevCache::get().release_all(); }
+void tnco_hip_release_cached(void) {
+  tnco::DevCache::get().release_all();
+  tnco::StreamCache::get().release_all();
+}
 uint64_t tnco_hip_cached_bytes(void) { return (uint64_t)tnco::DevCache::get().held(); }
 
 int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
@@ -555,7 +558,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     ~Guard() { delete h; }
   } guard{h};
   h->device = d->device;
-  HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+  HIP_TRY(tnco::StreamCache::get().take(&h->own_stream, d->device));
   h->stream = h->own_stream;
 
   choose_lanes(W, &h->log2l, &h->K);
@@ -1087,7 +1090,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     if (nblocks < 2 * G) G = 1;
     if (G > 1) {
       for (int q = 0; q < G; ++q) {
-        HIP_TRY(hipStreamCreateWithFlags(&h->gstream[q], hipStreamNonBlocking));
+        HIP_TRY(tnco::StreamCache::get().take(&h->gstream[q], h->device));
         HIP_TRY(hipEventCreateWithFlags(&h->gjoin[q], hipEventDisableTiming));
       }
       HIP_TRY(hipEventCreateWithFlags(&h->gfork, hipEventDisableTiming));
