@@ -529,7 +529,6 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
   live.init(P, P.blocks + r * P.RB, P.lpar + r * (int64_t)n * LPS, lig);
   int32_t* stack = a.scratch + q * 4 * (int64_t)N;
   int32_t* order = stack + N;
-  int32_t* visited = order + N;
   int status = 0;
   M om;
 #pragma unroll
@@ -554,7 +553,6 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
       o.left = l; o.right = rr; o.parent = p; o.pad = 0; o.ccost = 0; o.partial = 0;
       *v.hdr(i) = o;
     }
-    visited[i] = 0;
   }
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -593,7 +591,6 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
     if (i < SCAP) sst[i] = val;
     else if (lane0) stack[i] = (int32_t)val;
   };
-  (void)visited;
   int sp = 1, cnt = 0;
   st_set(0, (uint32_t)(N - 1));
   while (sp > 0) {
