@@ -1,5 +1,5 @@
 import sys, time, warnings
-sys.path.insert(0, "/root/repo"); warnings.simplefilter("ignore")
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1])); warnings.simplefilter("ignore")
 import numpy as np
 from tnco_amd import core, synthetic as syn
 from tnco_amd.app import Optimizer

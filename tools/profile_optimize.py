@@ -1,6 +1,6 @@
 """cProfile of one optimize() call (65 536 runs x 1 000 sweeps, 512 leaves):  python tools/profile_optimize.py [top_k]"""
 import sys, time, warnings, cProfile, pstats
-sys.path.insert(0, "/root/repo"); warnings.simplefilter("ignore")
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1])); warnings.simplefilter("ignore")
 from tnco_amd import synthetic as syn
 from tnco_amd.app import Optimizer
 def spec_of(n, seed):

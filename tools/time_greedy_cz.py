@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1]))
 import numpy as np
 from tnco_amd import _lib, core, synthetic as syn
 for depth, fuse in ((20, 4), (12, None)):
