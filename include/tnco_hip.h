@@ -261,8 +261,10 @@ void tnco_hip_destroy(tnco_hip_handle h);
 /* The device memory of a destroyed handle (blocks of 1 MB and more) is kept for the next tnco_hip_create
  * of the process -- a job that builds optimizer after optimizer asks for the same sizes again, and
  * hipMalloc right after hipFree of ~10 GB sporadically took seconds (csrc/dev_cache.h; bounded by
- * TNCO_HIP_CACHE_MB, default a quarter of the device's memory, 0: off; emptied when an allocation fails).
- * tnco_hip_release_cached gives it back now; tnco_hip_cached_bytes: how much is held. */
+ * TNCO_HIP_CACHE_MB, default min(an eighth of the device's memory, 32 GB), 0: off; emptied when ANY device
+ * allocation of this library fails, which is then retried).  Other allocators of the process (PyTorch,
+ * RCCL) cannot reach into it: CALL tnco_hip_release_cached BEFORE HANDING THE GPU TO ANOTHER ALLOCATOR.
+ * tnco_hip_release_cached gives everything back now; tnco_hip_cached_bytes: how much is held. */
 void tnco_hip_release_cached(void);
 uint64_t tnco_hip_cached_bytes(void);
 

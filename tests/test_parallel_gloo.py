@@ -329,7 +329,7 @@ def test_side_channel_drops_strangers(tmp_path):
             time.sleep(0.05)
     strangers.append(s1)
     s2 = socket.create_connection(("127.0.0.1", side), timeout=1.0)
-    s2.sendall(b"x" * 16 + (1).to_bytes(4, "little"))
+    s2.sendall(b"x" * 16 + (1).to_bytes(4, "little") + b"y" * 16)
     strangers.append(s2)
     procs = [ctx.Process(target=_side_rank, args=(r, 3, port, q), daemon=True) for r in (1, 2)]
     for p in procs:
@@ -340,15 +340,27 @@ def test_side_channel_drops_strangers(tmp_path):
     for s_ in strangers:
         s_.close()
     assert out == [(0, [0, 1, 2], 8.0), (1, [0, 1, 2], 8.0), (2, [0, 1, 2], 8.0)]
-    # a forged message is rejected before pickle sees it
+    # a forged message is refused, a replayed one too (the counter is part of the MAC), and nothing is unpickled
     sys.path.insert(0, str(ROOT))
     from tnco_amd import parallel
     a, b = socket.socketpair()
-    c = parallel.SocketComm(0, 1)
-    c._key = b"k" * 32
-    import pickle
-    blob = pickle.dumps("hello")
+    tx, rx = parallel.SocketComm(1, 1), parallel.SocketComm(0, 1)
+    tx._key = rx._key = b"k" * 32
+    blob = parallel._encode(("hello", 1.5, frozenset({3}), np.arange(3)))
     a.sendall(len(blob).to_bytes(8, "little") + b"\0" * 32 + blob)
     with pytest.raises(ConnectionError):
-        c._recv_msg(b)
+        rx._recv_msg(b)
+    rx._sess.clear()
+    tx._send_msg(a, blob)
+    first = parallel._decode(rx._recv_msg(b))
+    assert first[:3] == ("hello", 1.5, frozenset({3})) and np.array_equal(first[3], np.arange(3))
+    tx._sess[a.fileno()][1] = 0  # the same message once more: its number is 0 again, the receiver expects 1
+    tx._send_msg(a, blob)
+    with pytest.raises(ConnectionError):
+        rx._recv_msg(b)
+    assert "pickle" not in (ROOT / "tnco_amd" / "parallel.py").read_text().replace("never pickle", "").replace("unpickled", "")
+    # off the loopback interface the launch parameters are not a secret: a token is demanded
+    os.environ.pop("TNCO_COMM_TOKEN", None)
+    with pytest.raises(RuntimeError, match="TNCO_COMM_TOKEN"):
+        parallel.SocketComm(0, 2, addr="10.1.2.3", port=1)
     a.close(); b.close()

@@ -94,7 +94,10 @@ def load() -> C.CDLL:
     # torchrun launch that talks through the native communicator (parallel.NativeComm) never imports
     # torch and holds ONE HIP runtime; the torch.distributed transport imports torch before it loads
     # the library (parallel._dist).
-    if not os.environ.get("TNCO_HIP_NO_TORCH_FIRST") and "torch" in sys.modules:
+    # A process told to talk through torch.distributed (TNCO_COMM=torch*) WILL import torch later: its runtime goes
+    # first even if the caller loaded this library before anything imported torch.
+    will_use_torch = os.environ.get("TNCO_COMM", "").startswith("torch") and int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if not os.environ.get("TNCO_HIP_NO_TORCH_FIRST") and ("torch" in sys.modules or will_use_torch):
         torch_first()
     L = C.CDLL(str(_PATH))
     vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double

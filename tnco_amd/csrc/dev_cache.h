@@ -5,14 +5,17 @@
 // (profiles/r04_e2e.txt), and hipFree of them is 6-11 ms of every destroy.  A job that builds optimizer after
 // optimizer -- the components of a network, a parameter sweep -- asks for the same sizes again and again:
 // blocks of >= 1 MB go to this cache on destroy and are handed out again on an exact size match.
-//   * bounded: TNCO_HIP_CACHE_MB (default a quarter of the device's memory; 0: no cache); when full the oldest
-//     blocks are freed;
-//   * a failed hipMalloc empties the cache and is tried again;
-//   * tnco_hip_release_cached() gives everything back (for a process that shares the GPU with another allocator).
+//   * bounded: TNCO_HIP_CACHE_MB (default the smaller of an eighth of the device's memory and 32 GB -- two handles
+//     of the benchmark's size; 0: no cache); when full the oldest blocks are freed;
+//   * EVERY device allocation of the library goes through tnco::dev_malloc / DevCache::take: one that fails empties
+//     the cache and is tried again, so the cache can never be the reason for an out-of-memory error of the library;
+//   * other allocators in the process (PyTorch, RCCL) cannot do that: a process that shares the GPU with one calls
+//     tnco_hip_release_cached() before handing the device over (include/tnco_hip.h says so at destroy).
 // The cache object is never destroyed (at exit the HIP runtime may already be gone).
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <mutex>
@@ -91,7 +94,7 @@ class DevCache {
         int cur = -1;
         (void)hipGetDevice(&cur);
         if (cur != device) (void)hipSetDevice(device);
-        cap_ = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? total_b / 4 : 0;
+        cap_ = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? std::min<size_t>(total_b / 8, (size_t)32 << 30) : 0;
         if (cur != device && cur >= 0) (void)hipSetDevice(cur);
       }
     }
@@ -101,6 +104,18 @@ class DevCache {
   std::vector<Block> blocks_;
   size_t held_ = 0, cap_ = (size_t)-1;
 };
+
+// hipMalloc for everything that does not go through DevCache::take (blocks that are never handed back to the cache):
+// what the cache holds is given up before the allocation is reported as failed.
+inline hipError_t dev_malloc(void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess && DevCache::get().held() > 0) {
+    (void)hipGetLastError();
+    DevCache::get().release_all();
+    e = hipMalloc(p, bytes);
+  }
+  return e;
+}
 
 // Streams of destroyed handles, for the next one: hipStreamCreateWithFlags takes ~2 ms, a handle has three (6 of the
 // 20 ms of a create()).  Idle (synchronised by the handle's destructor) non-blocking streams, per device; at most 16 kept.

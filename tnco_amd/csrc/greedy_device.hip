@@ -43,6 +43,7 @@
 #include <vector>
 
 #include "../../include/tnco_hip.h"
+#include "dev_cache.h"
 #include "greedy_key.h"
 #include "greedy_wave.h"
 #include "greedy_shuffle.h"
@@ -80,7 +81,7 @@ struct DevBufs {
       if (g_pool.base) (void)hipFree(g_pool.base);
       g_pool.base = nullptr;
       g_pool.bytes = 0;
-      const hipError_t e = hipMalloc(&g_pool.base, need);
+      const hipError_t e = tnco::dev_malloc(&g_pool.base, need);
       if (e != hipSuccess) {
         g_pool.base = nullptr;
         return e;

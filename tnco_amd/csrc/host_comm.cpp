@@ -9,6 +9,7 @@
 // ncclUniqueId from rank 0 to the others) is the caller's: tnco_amd/parallel.py sends it over TCP (the side
 // channel the ranks share, or a socket on MASTER_ADDR : MASTER_PORT + 17).
 #include "../../include/tnco_hip.h"
+#include "dev_cache.h"
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -113,7 +114,7 @@ int ensure_slots(tnco_hip_comm_s* c, size_t bytes) {
   if (c->dbuf) (void)hipFree(c->dbuf);
   c->dbuf = nullptr;
   c->slot_bytes = 0;
-  CH(hipMalloc((void**)&c->dbuf, bytes * (size_t)(c->world + 1)));
+  CH(tnco::dev_malloc((void**)&c->dbuf, bytes * (size_t)(c->world + 1)));
   c->slot_bytes = bytes;
   return TNCO_HIP_OK;
 }

@@ -918,6 +918,9 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     HIP_TRY(h->alloc(&F.fastflag, R));
     HIP_TRY(hipMemset(F.fastflag, 0, (size_t)R * 4));
     HIP_TRY(h->alloc(&F.delta_scr, R * 64));
+    // (word 0 of a replica = the change count of its last re-pricing, tnco_hip_get_reslice_info: "none yet", whatever
+    //  a recycled block held)
+    HIP_TRY(hipMemset(F.delta_scr, 0xFF, (size_t)R * 64 * sizeof(*F.delta_scr)));
     F.stack_cap = FW_LDSPOS;
     if (const char* e = std::getenv("TNCO_HIP_FW_STACK")) F.stack_cap = std::max(0, std::min(FW_LDSPOS, std::atoi(e)));
     auto upload_mask = [&](const uint64_t* src, const uint64_t** dst) -> int {
@@ -1139,7 +1142,7 @@ int tnco_hip_run(tnco_hip_handle h, int prob_kind, const double* betas, int64_t 
     h->ring_cap = h->ring_pos = 0;
     const int64_t cap = std::max<int64_t>((int64_t)1 << 16, 4 * n_steps);
     HIP_TRY(hipHostMalloc((void**)&h->beta_pin, (size_t)cap * 8, hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void**)&h->beta_ring, (size_t)cap * 8));
+    HIP_TRY(tnco::dev_malloc((void**)&h->beta_ring, (size_t)cap * 8));
     h->ring_cap = cap;
   }
   if (h->ring_pos + n_steps > h->ring_cap) {
@@ -1248,7 +1251,7 @@ int tnco_hip_run_fw(tnco_hip_handle h, int prob_kind, const double* betas, int64
     if (h->d_betas) (void)hipFree(h->d_betas);
     h->d_betas = nullptr;
     h->betas_cap = 0;
-    HIP_TRY(hipMalloc((void**)&h->d_betas, (size_t)n_steps * 8));
+    HIP_TRY(tnco::dev_malloc((void**)&h->d_betas, (size_t)n_steps * 8));
     h->betas_cap = n_steps;
   }
   HIP_TRY(hipMemcpyAsync(h->d_betas, betas, (size_t)n_steps * 8, hipMemcpyHostToDevice, h->stream));

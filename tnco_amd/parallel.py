@@ -14,10 +14,12 @@ from __future__ import annotations
 import ctypes as C
 import hashlib
 import hmac
+import ipaddress
+import json
 import os
-import pickle
 import socket
 import time
+from decimal import Decimal
 
 import numpy as np
 
@@ -149,38 +151,118 @@ class NativeComm:
         return out
 
     def allgather_object(self, obj) -> list:
-        blob = np.frombuffer(pickle.dumps(obj), np.uint8)
+        blob = np.frombuffer(_encode(obj), np.uint8)
         sizes = self.allgather_array(np.array([len(blob)], np.int64))[:, 0]
         pad = np.zeros(int(sizes.max()), np.uint8)
         pad[:len(blob)] = blob
         allb = self.allgather_array(pad)
-        return [pickle.loads(allb[k, :int(sizes[k])].tobytes()) for k in range(self.world)]
+        return [_decode(allb[k, :int(sizes[k])].tobytes()) for k in range(self.world)]
+
+
+def _is_loopback(addr: str) -> bool:
+    if addr in ("localhost", "::1"):
+        return True
+    try:
+        return ipaddress.ip_address(addr).is_loopback
+    except ValueError:
+        return False
+
+
+def _encode(obj) -> bytes:
+    """Fixed wire format of the side channel: JSON with tagged containers, numpy arrays as (dtype, shape, hex).
+    Nothing received over a socket is ever unpickled."""
+    def enc(x):
+        if x is None or isinstance(x, (bool, str)):
+            return x
+        if isinstance(x, (int, np.integer)):
+            return int(x)
+        if isinstance(x, (float, np.floating)):
+            return {"!": "f", "v": float(x).hex()}
+        if isinstance(x, (bytes, bytearray)):
+            return {"!": "b", "v": bytes(x).hex()}
+        if isinstance(x, tuple):
+            return {"!": "t", "v": [enc(y) for y in x]}
+        if isinstance(x, list):
+            return [enc(y) for y in x]
+        if isinstance(x, (set, frozenset)):
+            return {"!": "s" if isinstance(x, set) else "z", "v": [enc(y) for y in sorted(x, key=repr)]}
+        if isinstance(x, dict):
+            return {"!": "d", "v": [[enc(k), enc(v)] for k, v in x.items()]}
+        if isinstance(x, Decimal):
+            return {"!": "D", "v": str(x)}
+        if isinstance(x, np.ndarray):
+            if x.dtype.hasobject:
+                raise TypeError("object arrays do not travel over the side channel")
+            return {"!": "a", "t": x.dtype.str, "s": list(x.shape), "v": np.ascontiguousarray(x).tobytes().hex()}
+        raise TypeError(f"side channel: cannot send a {type(x).__name__}")
+    return json.dumps(enc(obj), separators=(",", ":")).encode()
+
+
+def _decode(blob: bytes):
+    def dec(x):
+        if isinstance(x, list):
+            return [dec(y) for y in x]
+        if not isinstance(x, dict):
+            return x
+        k, v = x.get("!"), x.get("v")
+        if k == "f":
+            return float.fromhex(v)
+        if k == "b":
+            return bytes.fromhex(v)
+        if k == "t":
+            return tuple(dec(y) for y in v)
+        if k == "s":
+            return set(dec(y) for y in v)
+        if k == "z":
+            return frozenset(dec(y) for y in v)
+        if k == "d":
+            return {dec(a): dec(b) for a, b in v}
+        if k == "D":
+            return Decimal(v)
+        if k == "a":
+            dt = np.dtype(x["t"])
+            if dt.hasobject:
+                raise ConnectionError("side channel: object array refused")
+            return np.frombuffer(bytes.fromhex(v), dt).reshape(x["s"]).copy()
+        raise ConnectionError("side channel: unknown tag")
+    return dec(json.loads(blob.decode()))
 
 
 class SocketComm:
     """The same five calls over TCP through rank 0 (a star on MASTER_ADDR : MASTER_PORT + 18, `TNCO_COMM_SIDE_PORT`
     overrides): the side channel on which the ranks agree whether RCCL came up on ALL of them, and the transport of
     last resort when it did not -- what the ranks exchange is 16 bytes per launch chunk and the heads of the result
-    lists at the end, so a launch on N GPUs still reports its numbers (and says which transport carried them)."""
+    lists at the end, so a launch on N GPUs still reports its numbers (and says which transport carried them).
+
+    Trust.  One node is the design point: on a loopback rendezvous address the job key is derived from the
+    launch (run id, address, port, world size) + `TNCO_COMM_TOKEN`; on any OTHER address `TNCO_COMM_TOKEN` -- a secret
+    the launcher hands to every rank -- is mandatory.  Every connection opens with a challenge / response that mixes a
+    nonce of each side into a per-connection session key, every message carries an HMAC under that key over (direction,
+    message counter, body) -- a captured message can be neither replayed nor reflected --, and bodies are a fixed JSON
+    format, never pickle: the worst a forger who knows the key can do is feed wrong numbers, not run code."""
 
     kind = "tcp sockets through rank 0"
     hung = False
+    HELLO_TIMEOUT = 1.0  # a rank of this job sends its hello at once; a silent connection costs rank 0 this much
 
     def __init__(self, rank: int, world: int, addr: str | None = None, port: int | None = None, timeout: float = 90.0):
         self.rank, self.world = int(rank), int(world)
         self._peers: dict[int, socket.socket] = {}
         self._up: socket.socket | None = None
+        self._sess: dict[int, list] = {}  # fileno -> [session key, messages sent, messages received]
+        self._key = b""
         if self.world == 1:
             return
         addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
         port = int(port or os.environ.get("TNCO_COMM_SIDE_PORT") or int(os.environ.get("MASTER_PORT", "29533")) + 18)
-        # Only ranks of THIS job may join, and what they send is checked before it is unpickled: every connection opens
-        # with a token derived from the launch (torchrun's run id, the rendezvous address, the world size; TNCO_COMM_TOKEN
-        # adds a secret), every message carries an HMAC under it.  A stray connection is dropped, not waited for.
-        seed = "|".join([os.environ.get("TORCHELASTIC_RUN_ID", ""), str(addr), os.environ.get("MASTER_PORT", ""), str(self.world),
-                         os.environ.get("TNCO_COMM_TOKEN", "")])
+        token = os.environ.get("TNCO_COMM_TOKEN", "")
+        if not token and not _is_loopback(str(addr)):
+            raise RuntimeError(f"the side channel would listen on {addr}, which is not a loopback address: set TNCO_COMM_TOKEN "
+                               "to a secret shared by the ranks of this job (the launch parameters alone can be guessed)")
+        seed = "|".join([os.environ.get("TORCHELASTIC_RUN_ID", ""), str(addr), os.environ.get("MASTER_PORT", ""), str(self.world), token])
         self._key = hashlib.sha256(("tnco-side-channel|" + seed).encode()).digest()
-        io_timeout = float(os.environ.get("TNCO_COMM_IO_TIMEOUT", "3600"))
+        # (a collective waits for the slowest rank: TNCO_COMM_IO_TIMEOUT seconds, default one hour, 0 = for ever)
+        io_timeout = float(os.environ.get("TNCO_COMM_IO_TIMEOUT", "3600")) or None
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
@@ -195,17 +277,22 @@ class SocketComm:
                     srv.settimeout(left)
                     conn, _peer = srv.accept()
                     try:
-                        conn.settimeout(min(10.0, max(left, 0.1)))  # (the hello must come at once)
-                        hello = self._recv_exact(conn, 20)
-                        k = int.from_bytes(hello[16:], "little")
-                        if not hmac.compare_digest(hello[:16], self._key[:16]) or not 0 < k < self.world or k in self._peers:
+                        conn.settimeout(min(self.HELLO_TIMEOUT, max(left, 0.1)))
+                        hello = self._recv_exact(conn, 36)  # nonce of the rank | rank | HMAC(job key, "hello" | nonce | rank)
+                        nc, kb = hello[:16], hello[16:20]
+                        k = int.from_bytes(kb, "little")
+                        if (not hmac.compare_digest(hello[20:], self._mac(self._key, b"hello" + nc + kb)[:16])
+                                or not 0 < k < self.world or k in self._peers):
                             raise ConnectionError("not a rank of this job")
+                        ns = os.urandom(16)
+                        conn.sendall(ns + self._mac(self._key, b"welcome" + nc + ns)[:16])
                     except (OSError, ConnectionError):
                         conn.close()
                         continue
                     conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     conn.settimeout(io_timeout)
                     self._peers[k] = conn
+                    self._sess[conn.fileno()] = [self._mac(self._key, b"session" + nc + ns), 0, 0]
             finally:
                 srv.close()
         else:
@@ -219,9 +306,21 @@ class SocketComm:
                         raise RuntimeError(f"rank {self.rank}: rank 0 does not answer at {addr}:{port}") from None
                     time.sleep(0.05)
             c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            c.settimeout(max(timeout, 5.0))
+            nc, kb = os.urandom(16), self.rank.to_bytes(4, "little")
+            c.sendall(nc + kb + self._mac(self._key, b"hello" + nc + kb)[:16])
+            reply = self._recv_exact(c, 32)
+            ns = reply[:16]
+            if not hmac.compare_digest(reply[16:], self._mac(self._key, b"welcome" + nc + ns)[:16]):
+                c.close()
+                raise ConnectionError(f"rank {self.rank}: what answers at {addr}:{port} is not rank 0 of this job")
             c.settimeout(io_timeout)
-            c.sendall(self._key[:16] + self.rank.to_bytes(4, "little"))
             self._up = c
+            self._sess[c.fileno()] = [self._mac(self._key, b"session" + nc + ns), 0, 0]
+
+    @staticmethod
+    def _mac(key: bytes, data: bytes) -> bytes:
+        return hmac.new(key, data, hashlib.sha256).digest()
 
     @staticmethod
     def _recv_exact(c: socket.socket, n: int) -> bytes:
@@ -233,8 +332,16 @@ class SocketComm:
             buf += chunk
         return bytes(buf)
 
+    def _tag(self, c: socket.socket, sending: bool, blob: bytes) -> bytes:
+        """HMAC under the connection's session key over (who speaks, message number, body)."""
+        s = self._sess.setdefault(c.fileno(), [self._key, 0, 0])
+        n = s[1] if sending else s[2]
+        s[1 if sending else 2] += 1
+        speaker = (self.rank == 0) == sending  # True: rank 0 is the speaker of this message
+        return self._mac(s[0], (b"\1" if speaker else b"\0") + n.to_bytes(8, "little") + blob)
+
     def _send_msg(self, c: socket.socket, blob: bytes) -> None:
-        c.sendall(len(blob).to_bytes(8, "little") + hmac.new(self._key, blob, hashlib.sha256).digest() + blob)
+        c.sendall(len(blob).to_bytes(8, "little") + self._tag(c, True, blob) + blob)
 
     def _recv_msg(self, c: socket.socket) -> bytes:
         n = int.from_bytes(self._recv_exact(c, 8), "little")
@@ -242,21 +349,21 @@ class SocketComm:
             raise ConnectionError("side channel: message length out of range")
         mac = self._recv_exact(c, 32)
         blob = self._recv_exact(c, n)
-        if not hmac.compare_digest(mac, hmac.new(self._key, blob, hashlib.sha256).digest()):
-            raise ConnectionError("side channel: message not from a rank of this job")
+        if not hmac.compare_digest(mac, self._tag(c, False, blob)):
+            raise ConnectionError("side channel: message not from a rank of this job (or out of sequence)")
         return blob
 
     def allgather_object(self, obj) -> list:
         if self.world == 1:
             return [obj]
         if self.rank == 0:
-            parts = [obj] + [pickle.loads(self._recv_msg(self._peers[k])) for k in range(1, self.world)]
-            blob = pickle.dumps(parts)
+            parts = [obj] + [_decode(self._recv_msg(self._peers[k])) for k in range(1, self.world)]
+            blob = _encode(parts)
             for k in range(1, self.world):
                 self._send_msg(self._peers[k], blob)
             return parts
-        self._send_msg(self._up, pickle.dumps(obj))
-        return pickle.loads(self._recv_msg(self._up))
+        self._send_msg(self._up, _encode(obj))
+        return _decode(self._recv_msg(self._up))
 
     def allgather_array(self, a: np.ndarray) -> np.ndarray:
         return np.stack(self.allgather_object(np.ascontiguousarray(a)))
@@ -274,7 +381,7 @@ class SocketComm:
                 c.close()
             except OSError:
                 pass
-        self._peers, self._up = {}, None
+        self._peers, self._up, self._sess = {}, None, {}
 
 
 _native: "NativeComm | SocketComm | None" = None
