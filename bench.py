@@ -51,6 +51,9 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "HBM"
+# what the memory system delivers to RANDOM 128-byte lines (47e9 lines/s, tools/hbm_random.hip): the ceiling of a
+# kernel whose every access is a dependent, data-chosen node of a tree -- `roofline.frac_of_achievable`
+HBM_RANDOM_LINE_GBS = 6000.0
 # Random fabric requests the chip retires per second whatever their size (32 / 64 / 128 B):
 # tools/hbm_random.hip, profiles/r01v7_hbm_random.txt (47-52e9; 47e9 with dependent loads,
 # tools/mem_latency.hip).  The sweep kernels are bound by THIS, not by bytes.
@@ -305,7 +308,7 @@ def pmc_passes(args, lib_version):
                 "--replicas", str(args.replicas), "--graph-seed", str(args.graph_seed), "--init", args.init,
                 "--workload", args.workload, "--fw-max-width", str(args.fw_max_width),
                 "--fw-update-slices", str(args.fw_update_slices), "--fw-depth", str(args.fw_depth),
-                "--fw-layout", args.fw_layout, "--cpu-sample", "0", "--pmc", "0", "--e2e", "0"]
+                "--fw-layout", args.fw_layout, "--cpu-sample", "0", "--pmc", "0", "--e2e", "0", "--no-validate"]
     vals = {}  # (kernel short name, counter) -> per-dispatch values in dispatch order
     names = {}  # kernel short name -> the kernels' names in the trace
     t0 = time.perf_counter()
@@ -463,7 +466,8 @@ def main() -> None:
     ap.add_argument("--pmc", type=int, default=1, help="1: measure HBM traffic / fabric requests under rocprofv3 --pmc (N = 1)")
     ap.add_argument("--pmc-timeout", type=float, default=240.0)
     ap.add_argument("--pmc-out", default=None, help="also write the per-step PMC counters of the timed kernels to this file")
-    ap.add_argument("--validate", action="store_true", help="device-side is_valid() of every replica after the run")
+    ap.add_argument("--validate", action=argparse.BooleanOptionalAction, default=True,
+                    help="device-side is_valid() of every replica after the timed region (default on)")
     ap.add_argument("--e2e", type=int, default=1,
                     help="1 (N = 1): also time app.Optimizer(method='sa').optimize() of the headline network end to end "
                          "(spec -> initial trees -> sweeps -> best paths): the `end_to_end` object, informational")
@@ -547,8 +551,13 @@ def main() -> None:
     for kind in legs:
         leg = Leg(kind, args, rank, world, local_rank, grouped)
         res = reduce_legs(leg.run(barrier, dist), world, dist, torch, grouped)
+        # after the timed region: is_valid(atol) of EVERY replica, recomputed on the device from the trees alone
+        # (ContractionTree::is_valid + both caches against a from-scratch rebuild, infinite_memory/optimizer.hpp:223-251)
+        # -- the line certifies the work it counted; --no-validate skips it
         if args.validate:
-            res["n_bad"] = leg.opt.validate()[0]
+            tv = time.perf_counter()
+            res["n_bad"] = int(leg.opt.validate()[0])
+            res["validate_s"] = time.perf_counter() - tv
         results[kind], objs[kind] = res, leg
         if not (rank == 0 and world == 1 and args.cpu_sample != 0):
             leg.opt.close()
@@ -680,30 +689,43 @@ def main() -> None:
             if roof.get("traffic") is not None:
                 roof["achieved"] = roof["traffic"] / (step_ms / 1e3) / 1e9
                 roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+                roof["frac_of_achievable"] = roof["achieved"] / HBM_RANDOM_LINE_GBS
                 roof["frac_source"] = "measured traffic (this run's PMC passes)" if not pmc_note else f"measured traffic ({pmc_note})"
             else:  # no counters (rocprofv3 missing, --pmc 0, N > 1): the model of the compulsory traffic, said so
                 roof["achieved"] = comp_per_step / (step_ms / 1e3) / 1e9
                 roof["frac"] = roof["frac_compulsory"]
+                roof["frac_of_achievable"] = roof["achieved"] / HBM_RANDOM_LINE_GBS
                 roof["frac_source"] = "compulsory-traffic MODEL (no PMC counters in this run)"
             obj = {
                 "value": moves / res["dt"], "unit": "move-evals/s", "ms_per_step": res["dt"] / args.steps * 1e3,
                 "config": {
-                    "workload": (f"{prob.n}-leaf random 3-regular TN (bond dim 2, {prob.n_inds} indices, {prob.W} mask words), "
-                                 f"{R} replicas per GPU, {sps} SA sweeps per step, beta linear 0->100 over "
-                                 f"{leg.total_sweeps} sweeps, Metropolis-Hastings, float64 cost") if kind == "im" else
-                                ((f"Sycamore-53 supremacy circuit, depth {args.fw_depth}, coupler sequence ABCDCDAB (A, B: one coupler "
-                                  f"orientation on alternate rows; C, D: the other), amplitude TN, single-qubit gates absorbed "
-                                  if args.fw_layout == "supremacy" else
-                                  f"Sycamore-53-style depth-{args.fw_depth} circuit with the two coupler orientations ALTERNATING per cycle "
-                                  f"(the easier network of rounds 1-3), amplitude TN ") +
-                                 f"({prob.n} tensors, {sum(len(t) == 4 for t in prob.ts_inds)} two-qubit gates, {prob.n_inds} indices, "
-                                 f"{prob.W} mask words), max_width {args.fw_max_width:g} (float32 width), re-slice every {every} "
-                                 f"sweeps, {R} replicas per GPU, {sps} sweeps per step, beta linear 0->100 over "
-                                 f"{leg.total_sweeps} sweeps, Metropolis-Hastings, float64 cost"),
+                    # (short keys first: everything that identifies the workload, nothing of it in a long sentence)
+                    "workload": (f"C3: {prob.n}-leaf 3-regular TN d=2, {R} replicas/GPU, MH, f64, beta 0->100" if kind == "im" else
+                                 f"C5: Sycamore-53 depth {args.fw_depth} ({args.fw_layout}), max_width {args.fw_max_width:g}, "
+                                 f"{R} replicas/GPU, MH, f64"),
+                    "network": (f"random 3-regular graph, seed {args.graph_seed}: {prob.n} tensors, {prob.n_inds} indices of dimension 2, "
+                                f"{prob.W} mask words" if kind == "im" else
+                                (f"Sycamore-53 supremacy circuit, depth {args.fw_depth}, coupler sequence ABCDCDAB (A, B: one coupler "
+                                 f"orientation on alternate rows; C, D: the other), amplitude TN, single-qubit gates absorbed: "
+                                 if args.fw_layout == "supremacy" else
+                                 f"Sycamore-53-style depth-{args.fw_depth} circuit, the two coupler orientations ALTERNATING per cycle "
+                                 f"(the easier network of rounds 1-3), amplitude TN: ") +
+                                f"{prob.n} tensors, {sum(len(t) == 4 for t in prob.ts_inds)} two-qubit gates, {prob.n_inds} indices of "
+                                f"dimension 2, {prob.W} mask words"),
+                    "baseline_config": "configs[2]" if kind == "im" else "configs[4]",
+                    "optimizer": "infinite_memory" if kind == "im" else "finite_width/greedy",
+                    "rule": "MetropolisHastings", "cost_dtype": "float64",
+                    "beta": [0.0, 100.0, leg.total_sweeps], "replicas_per_gpu": R, "n_leaves": prob.n, "n_inds": prob.n_inds,
+                    "mask_words": prob.W,
+                    **({} if kind == "im" else {"max_width": args.fw_max_width, "width_dtype": "float32",
+                                                "update_slices_every": every}),
                     "replicas_total": R * world, "sweeps_per_step": sps, "moves_timed": moves, "accept_rate": a,
                     "random_pick_rate": q, "best_log10_flops": float(np.log10(res["best"])),
                     "improvements_timed": res["improved"], "full_tree_copies_timed": res["full_copies"],
-                    "validated_bad_replicas": res.get("n_bad"), "library": lib_version,
+                    "validated_bad_replicas": res.get("n_bad"),
+                    "validated": (f"tnco_hip_validate(atol=1e-5) over all {R} replicas after the timed region, "
+                                  f"{res.get('validate_s', 0.0):.2f} s (untimed)") if res.get("n_bad") is not None else None,
+                    "library": lib_version,
                     "initial_trees": "random Kruskal (tnco_hip_random_trees)" if args.init == "kruskal" else
                                      "Random(seed).shuffle + opt_einsum greedy restated (tnco_hip_greedy_trees_device)",
                 },

@@ -1,0 +1,44 @@
+"""The compiler-dependent properties the measured numbers lean on, asserted on the gfx950 code objects inside the
+libtnco_hip.so of the tree (tools/code_objects.py; no GPU, a few seconds): register budgets -> wavefronts per SIMD,
+scratch, and the shape of the sweep kernels' main loop -- ONE landing fence ("the single
+s_waitcnt vmcnt of the loop"), no scratch access inside it.  A toolchain bump that breaks one of them fails here, not
+in a benchmark."""
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tools"))
+
+
+@pytest.fixture(scope="module")
+def report():
+    import code_objects
+    if not code_objects.LIB.exists():
+        pytest.fail("tnco_amd/libtnco_hip.so is missing: run __graft_entry__.build()")
+    if not (code_objects.LLVM / "llvm-objdump").exists():
+        pytest.skip("no ROCm LLVM tools on this machine")
+    return code_objects.report()
+
+
+def test_register_budgets_of_the_occupancy_critical_kernels(report):
+    rows, _ = report
+    assert len(rows) == 4
+    for ok, line in rows:
+        assert ok, line
+
+
+def test_sweep_loops_have_one_landing_fence_and_no_scratch(report):
+    _, staged = report
+    assert len(staged) == 2
+    for what, rep in staged.items():
+        assert rep["fences"] == 1, (what, rep["vm_waits"], rep["memory_between_waits"])
+        assert rep["scratch_in_loop"] == [], (what, rep["scratch_in_loop"])
+        # (the loop of the state machine: one load sequence, one store sequence -- a duplicated body would double these)
+        assert 8 <= rep["loads"] <= 20 and 5 <= rep["stores"] <= 14, (what, rep["loads"], rep["stores"])
+
+
+def test_waves_per_simd_rule():
+    import code_objects
+    assert [code_objects.waves_per_simd(v) for v in (64, 96, 127, 128, 129, 168, 169, 215, 256, 257)] == [8, 5, 4, 4, 3, 3, 2, 2, 2, 1]

@@ -364,3 +364,49 @@ def test_side_channel_drops_strangers(tmp_path):
     with pytest.raises(RuntimeError, match="TNCO_COMM_TOKEN"):
         parallel.SocketComm(0, 2, addr="10.1.2.3", port=1)
     a.close(); b.close()
+
+
+def test_config4_shards_of_eight(monkeypatch):
+    """BASELINE config 4's split (524 288 runs over 8 ranks; tnco/app/infinite_memory/sa.py:237-257 draws ONE seed list
+    and sorts ONE result list, tnco/parallel.py:330-341 fans the runs out): the eight shards are contiguous 65 536-run
+    blocks whose seeds, concatenated, ARE the one-process list; the heads the ranks exchange merge into the head of
+    the one-process sort (ties to the lower global run id); the minimum of the shard minima is the batch minimum --
+    and bench.py slices its seeds the same way."""
+    import random
+    sys.path.insert(0, str(ROOT))
+    from tnco_amd import parallel, synthetic
+    from tnco_amd.app import _sa_driver
+    n_runs, world = 524288, 8
+    one = random.Random(0).choices(range(2**32), k=n_runs)          # the reference's line, one process
+    assert _sa_driver.replica_seeds(random.Random(0), n_runs) == one  # (the driver's numpy shortcut for large k)
+    assert synthetic.replica_seeds(n_runs, S=0) == one
+    bounds = [parallel.shard_bounds(n_runs, world, k) for k in range(world)]
+    assert bounds[0][0] == 0 and bounds[-1][1] == n_runs and all(b[1] - b[0] == 65536 for b in bounds)
+    assert all(bounds[k][1] == bounds[k + 1][0] for k in range(world - 1))
+    assert [s for lo, hi in bounds for s in one[lo:hi]] == one
+    # bench.py: rank k of an N-rank launch owns all_seeds[k * R:(k + 1) * R] of replica_seeds(R * N)
+    assert all(one[k * 65536:(k + 1) * 65536] == one[slice(*bounds[k])] for k in range(world))
+    # an uneven split (n_runs not a multiple of the world) still covers the list once, sizes differing by at most one
+    ub = [parallel.shard_bounds(524289, world, k) for k in range(world)]
+    assert [hi - lo for lo, hi in ub] == [65537] + [65536] * 7 and ub[-1][1] == 524289
+    # results: every rank contributes its top_k (cost, global id, ...) tuples; all receive the head of sorted(results)
+    rs = np.random.RandomState(5)
+    cost = np.round(rs.random_sample(n_runs) * 50.0, 1)  # (many ties: 500 distinct values)
+    top_k = 1024
+    locals_ = []
+    for lo, hi in bounds:
+        order = np.lexsort((np.arange(lo, hi), cost[lo:hi]))[:top_k]
+        locals_.append([(float(cost[lo + j]), int(lo + j), "payload") for j in order])
+
+    class AllRanks:  # stand-in communicator: what an all-gather over the 8 ranks returns
+        rank, world = 3, 8
+
+        def allgather_object(self, obj):
+            assert obj is locals_[self.rank]
+            return locals_
+
+    monkeypatch.setattr(parallel, "_native", AllRanks())
+    merged = parallel.merge_heads(locals_[3], top_k, 3, world)
+    head = np.lexsort((np.arange(n_runs), cost))[:top_k]
+    assert [(c, g) for c, g, _ in merged] == [(float(cost[g]), int(g)) for g in head]
+    assert min(float(cost[lo:hi].min()) for lo, hi in bounds) == float(cost.min()) == merged[0][0]
