@@ -441,6 +441,38 @@ def end_to_end(args):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def config2(local_rank):
+    """BASELINE configs[1] (64-leaf 3-regular TN, 4 096 replicas) -- the small, latency-bound end of the path: 4 096
+    replicas are 256 wavefronts, one per CU, and every replica advances one dependent memory round trip at a time.
+    Informational (N = 1): move-evals/s over 1 000 sweeps, every replica validated, 64 of them against the oracle."""
+    try:
+        from tnco_amd import core, synthetic
+        prob = synthetic.regular_problem(64, graph_seed=7)
+        R, sweeps = 4096, 1000
+        seeds = synthetic.replica_seeds(R)
+        links = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds)
+        betas = synthetic.linear_betas(0.0, 100.0, sweeps + 50)
+        with core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, device=local_rank) as opt:
+            opt.run(betas[:50])
+            opt.sync()
+            m0 = opt.counters()["moves"]
+            t0 = time.perf_counter()
+            opt.run(betas[50:])
+            opt.sync()
+            dt = time.perf_counter() - t0
+            moves = opt.counters()["moves"] - m0
+            bad = int(opt.validate()[0])
+            mn = opt.costs()[1]
+        from oracle import oracle as orc
+        orc.build()
+        _dt, _tot, omn, _mv = orc.run_batch(links[:64], prob.leaf_masks, seeds[:64], betas, n_inds=prob.n_inds, dims=2)
+        return {"workload": "C2: 64-leaf 3-regular TN d=2, 4096 replicas, MH, f64, 1000 sweeps (one launch)", "value": moves / dt,
+                "unit": "move-evals/s", "seconds": dt, "validated_bad_replicas": bad,
+                "cpu_sample_min_cost_bit_exact": bool(np.array_equal(omn, mn[:64])), "best_log10_flops": float(np.log10(mn.min()))}
+    except Exception as e:  # (informational: never fails the bench line)
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -787,6 +819,7 @@ def main() -> None:
             out[kind] = leg_object(kind)
         if args.e2e and world == 1 and args.replicas <= 131072:  # (beside the legs' own handles: not for the 100-GB batches)
             out["end_to_end"] = end_to_end(args)
+            out["c2"] = config2(local_rank)
         print(json.dumps(out), flush=True)
     for leg in objs.values():
         if leg.opt is not None:

@@ -148,6 +148,31 @@ def test_hyper_pow2_dims(core, oracle_lib):
     _run_both(core, oracle_lib, prob, seeds, H.linear_betas(0, 30, 300))
 
 
+@pytest.mark.parametrize("n,n_inds,k", [(200, 470, 3), (512, 768, 3), (700, 1330, 4)])
+@pytest.mark.parametrize("two_line", [True, False])
+def test_hyper_networks_with_blocks_longer_than_a_line(core, oracle_lib, monkeypatch, n, n_inds, k, two_line):
+    """Infinite memory + hyper-indices at 8 / 12 / 21 mask words: the two-line layout of round 5 ([header | hyper legs]
+    and [partial copy | legs] in lines of their own; the own legs of the nodes on the path derived, not loaded) and the
+    packed layout it replaces (TNCO_HIP_HYPER_ALIGNED=0), both against the oracle bit for bit -- trees, legs, both
+    caches (hyper legs included), generator -- with output legs, all three rules, and a restart from a snapshot."""
+    from tnco_amd import synthetic as syn
+    monkeypatch.setenv("TNCO_HIP_HYPER_ALIGNED", "1" if two_line else "0")
+    ts, dims, out = syn.random_hyper_tn(n, n_inds, k=k, n_output=7, seed=n)
+    prob = H.Problem(ts, 2, out)
+    seeds = H.replica_seeds(24, S=n)
+    gpu = _run_both(core, oracle_lib, prob, seeds, H.linear_betas(0, 40, 120), n_check=12)
+    gpu.run(H.linear_betas(0, 5, 10), "greedy")
+    gpu.run(np.zeros(5), "base")
+    assert gpu.validate() == (0, -1)
+    links = prob.links(seeds)
+    for r in range(4):
+        o = H.make_oracle(oracle_lib, prob, links[r], seeds[r])
+        o.run(oracle_lib.PROB_MH, H.linear_betas(0, 40, 120))
+        o.run(oracle_lib.PROB_GREEDY, H.linear_betas(0, 5, 10))
+        o.run(oracle_lib.PROB_BASE, np.zeros(5))
+        H.assert_replica_equal(gpu, r, o)
+
+
 def test_vector_dims(core, oracle_lib):
     from tnco_amd import synthetic as syn
     ts, dims, out = syn.random_hyper_tn(24, 60, k=3, n_output=3, seed=5, dims_choices=(2, 3, 4, 7))

@@ -73,7 +73,12 @@ struct Params {
   int32_t WS;                // bytes between the legs of consecutive nodes
   int32_t WOFF;              // byte offset of node n's legs from the replica's base
   int64_t RB;                // bytes per replica
-  int32_t hoff;              // byte offset of a node's hyper legs from its legs (networks with hyper-indices)
+  int32_t hoff;              // byte offset of a node's hyper legs from its legs (networks with hyper-indices; may be negative)
+  // Infinite memory with hyper-indices and node blocks longer than a line ("two-line" layout, tnco_hip_create): a block
+  // is [ header | hyper legs ] -- what a move needs of a node ON the path -- and, in lines of its own, [ partial-cost
+  // copy | legs ] -- what it needs of a SIBLING: 2 lines per move instead of 3-4.  pcoff = byte offset of that copy of
+  // NodeRec::partial from the node's legs (negative), 0 = no copy (every other layout).
+  int32_t pcoff;
   int32_t jcap;              // rotation-log entries per replica
   int64_t R;
   uint8_t* blocks;           // [R][RB]
@@ -161,11 +166,11 @@ struct View {
   uint8_t* blk;
   int32_t* lpar;
   const uint64_t* leafmask;
-  int n, BS, W, lig, hoff, WS, WOFF;
+  int n, BS, W, lig, hoff, WS, WOFF, pcoff;
 
   __device__ __forceinline__ void init(const Params& P, uint8_t* blk_, int32_t* lpar_, int lig_) {
     blk = blk_; lpar = lpar_; leafmask = P.leafmask; n = P.n; BS = P.BS; W = P.W; lig = lig_; hoff = P.hoff;
-    WS = P.WS; WOFF = P.WOFF;
+    WS = P.WS; WOFF = P.WOFF; pcoff = P.pcoff;
   }
   __device__ __forceinline__ NodeRec* hdr(int p) const {
     return reinterpret_cast<NodeRec*>(blk + (int64_t)(p - n) * BS);
@@ -174,8 +179,16 @@ struct View {
   // L consecutive words (one contiguous 8L-byte piece of the line) per instruction
   __device__ __forceinline__ int widx(int k) const { return k * L + lig; }
   __device__ __forceinline__ uint64_t* words(int p) const {
-    if constexpr (UNI) return reinterpret_cast<uint64_t*>(blk + (int64_t)(p - n) * BS + 32);
+    if constexpr (UNI) return reinterpret_cast<uint64_t*>(blk + (int64_t)(p - n) * BS + (HYPER ? WOFF : 32));
     return reinterpret_cast<uint64_t*>(blk + WOFF + (int64_t)(p - n) * WS);
+  }
+  // the copy of node p's partial cost that sits with its legs (two-line layout only: pcoff != 0)
+  __device__ __forceinline__ double* pcopy(int p) const {
+    return reinterpret_cast<double*>(reinterpret_cast<uint8_t*>(words(p)) + pcoff);
+  }
+  // where a SIBLING's partial cost is read from: next to its legs if the layout keeps a copy there
+  __device__ __forceinline__ const double* partial_of_sibling(int p) const {
+    return (HYPER && pcoff != 0) ? pcopy(p) : &hdr(p)->partial;
   }
   // (networks with hyper-indices: the hyper legs follow the node's legs, hoff bytes behind them, in both layouts)
   __device__ __forceinline__ uint64_t* hwords(int p) const {
@@ -571,7 +584,10 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
     const double c = generic_cost<LOG2L, K>(P, mor<K>(uni, csl), lig, gbase);
     const double part = rnd_cost(rnd_cost(c + v.partial(l), P.f32) + v.partial(rr), P.f32);  // utils.hpp:54
     sum = rnd_cost(sum + c, P.f32);                                                          // utils.hpp:112
-    if (lane0) { v.hdr(p)->ccost = c; v.hdr(p)->partial = part; }
+    if (lane0) {
+      v.hdr(p)->ccost = c; v.hdr(p)->partial = part;
+      if (HYPER && v.pcoff != 0) *v.pcopy(p) = part;
+    }
   };
   // Without hyper-indices and with legs derived from the links, a node's legs, checks and costs need nothing but its
   // children's: everything is done when the traverse LEAVES the node -- one pass of dependent round trips over the
@@ -710,6 +726,7 @@ __global__ __launch_bounds__(256) void compare_kernel(const Params P, const Buil
       if (!logclose(x.partial, y.partial)) bad = bad ? bad : 32;
       if (x.left != y.left || x.right != y.right) bad = bad ? bad : 2;
       if (cur.parent(y.left) != i || cur.parent(y.right) != i) bad = bad ? bad : 8;
+      if (HYPER && cur.pcoff != 0 && __double_as_longlong(*cur.pcopy(i)) != __double_as_longlong(y.partial)) bad = bad ? bad : 35;
     }
   }
   for (int p = n; p < N; ++p) {

@@ -416,14 +416,16 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
   int B = 0, bl = 0, br = 0, A = -1;
   [[maybe_unused]] int wB = 0, raW = 0, rnW = 0;  // finite width: the spare header word (cached width) of B, A, parent(A)
   double ccB = 0, partB = 0, total = 0, beta = 0;
-  M m0 = mzero<K>(), m1 = mzero<K>(), iB = mzero<K>(), hB = mzero<K>();
+  // (hyper-indices: the own legs of B and A are never loaded -- legs(p) = (legs(c0) ^ legs(c1)) | hyper(p) for every
+  //  valid contraction, ctree.hpp:139-146 with hyper(p) = legs(p) & legs(c0) & legs(c1), infinite_memory/utils.hpp:82-91)
+  M m0 = mzero<K>(), m1 = mzero<K>(), hB = mzero<K>();
   double p0 = 0, p1 = 0;
   // ---- operands of the coming moves (landed in earlier iterations) -----------
   int raL = -1, raR = -1, raP = -1;  // header of A
   double raC = 0;
   int rnL = -1, rnR = -1, rnP = -1;  // header of parent(A)
   double rnC = 0;
-  M mC = mzero<K>(), iA = mzero<K>(), hA = mzero<K>();
+  M mC = mzero<K>(), hA = mzero<K>();
   double pC = 0;
   int step = 0;
   int state = S_BEGIN;
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
     TNCO_PROF_F(1);
     // ======================= what does each replica need next? ================
     // Every state asks for at most: one node header (hN), the legs + partial cost of one node
-    // (x1), 8 bytes from anywhere (xa) and, with hyper-indices, the own + hyper legs of one node
+    // (x1), 8 bytes from anywhere (xa) and, with hyper-indices, the hyper legs of one node
     // (yN).  Only addresses are decided per state; the loads below are one sequence for all.
     int hN = -1, x1 = -1, yN = -1;
     const uint32_t* xa = nullptr;
@@ -550,19 +552,16 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
     double gMp = 0;
     if (x1 >= 0) {
       gM = v.mask_staged(x1);
-      if (x1 >= n) gMp = v.hdr(x1)->partial;
+      if (x1 >= n) gMp = *v.partial_of_sibling(x1);
     }
     uint32_t gXlo = 0, gXhi = 0;
     if (xa != nullptr) {
       gXlo = xa[0];
       gXhi = xa[1];
     }
-    M gI = mzero<K>(), gH = mzero<K>();
+    M gH = mzero<K>();
     if constexpr (HYPER) {
-      if (yN >= 0) {
-        gI = v.mask_staged(yN);
-        gH = v.hyper(yN);
-      }
+      if (yN >= 0) gH = v.hyper(yN);
     }
     if (rng.room()) rng.request();
     TNCO_PROF_F(3);
@@ -660,7 +659,9 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
         if (pick0) br = C; else bl = C;
         if (c_is_right) ar = E; else al = E;
         if constexpr (HYPER) {
-          hA = mand<K>(mand<K>(iA, newB), mE);  // :171
+          // :171 with legs(A) = (legs(B) ^ legs(C)) | hyper(A) before the move, legs(B) = (child ^ child) | hyper(B)
+          const M iA = mor<K>(mxor<K>(mor<K>(mxor<K>(m0, m1), hB), mC), hA);
+          hA = mand<K>(mand<K>(iA, newB), mE);
           hB = mand<K>(mand<K>(newB, mD), mC);  // :172
         }
         ccB = nB;
@@ -671,7 +672,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
         mBnow = newB;
         mX = mE;
       } else {
-        mBnow = HYPER ? iB : mxor<K>(m0, m1);
+        mBnow = HYPER ? mor<K>(mxor<K>(m0, m1), hB) : mxor<K>(m0, m1);
         mX = mC;
       }
       // :185-188
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       TNCO_LANDED(gM.w[k]);
-      if constexpr (HYPER) { TNCO_LANDED(gI.w[k]); TNCO_LANDED(gH.w[k]); }
+      if constexpr (HYPER) { TNCO_LANDED(gH.w[k]); }
     }
     TNCO_LANDED(rng.pb);
     TNCO_LANDED(rng.pa);
@@ -730,6 +731,9 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
         NodeRec o;
         o.left = stL; o.right = stR; o.parent = stA; o.pad = FW ? stW : 0; o.ccost = stCC; o.partial = stPart;
         *v.hdr(stB) = o;
+        if constexpr (HYPER && !FW) {  // (two-line layout: the copy a later move reads when this node is the sibling)
+          if (v.pcoff != 0) *v.pcopy(stB) = stPart;
+        }
         if constexpr (FW) {
           if (did_move && acc && !F.width_f32) F.width64[(int64_t)rng.r32 * N + stB] = stW64;
         }
@@ -740,7 +744,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       // hold it, so the short write never reaches HBM on its own; the extra store only costs issue.
 #ifdef TNCO_FIRST64
       if (!(did_move && acc))
-        v.set_mask_first(stB, did_move ? msel<K>(b_is_left_of_a, m0, m1) : (HYPER ? iB : mxor<K>(m0, m1)));
+        v.set_mask_first(stB, did_move ? msel<K>(b_is_left_of_a, m0, m1) : (HYPER ? mor<K>(mxor<K>(m0, m1), hB) : mxor<K>(m0, m1)));
 #endif
       if constexpr (HYPER) v.set_hyper(stB, stH);  // may also have changed one level below
       if (improved && lane0) cold.jmin = jtail;
@@ -755,7 +759,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       if (b_is_left_of_a) { p0 = stPart; p1 = x_pCcur; }
       else                { p1 = stPart; p0 = x_pCcur; }
       B = stA; bl = x_al; br = x_ar; ccB = x_ccA; partB = x_partA;
-      if constexpr (HYPER) { iB = iA; hB = hA; iA = gI; hA = gH; }
+      if constexpr (HYPER) { hB = hA; hA = gH; }
       A = x_aP;
       raL = rnL; raR = rnR; raP = rnP; raC = rnC;
       rnL = gL; rnR = gR; rnP = gP; rnC = gC;
@@ -776,14 +780,14 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       total = __hiloint2double((int)gXhi, (int)gXlo);
       raL = gL; raR = gR; raP = gP; raC = gC;
       if constexpr (FW) raW = gW;
-      if constexpr (HYPER) { iB = gI; hB = gH; }
+      if constexpr (HYPER) { hB = gH; }
       state = S_GOT_B1;
     } else if (state == S_GOT_B1) {
       m1 = gM; p1 = gMp;
       beta = __hiloint2double((int)gXhi, (int)gXlo);
       rnL = gL; rnR = gR; rnP = gP; rnC = gC;
       if constexpr (FW) rnW = gW;
-      if constexpr (HYPER) { iA = gI; hA = gH; }
+      if constexpr (HYPER) { hA = gH; }
       state = (A < 0) ? S_END : S_GOT_HA;
     } else if (state == S_GOT_HA) {
       mC = gM; pC = gMp;

@@ -591,15 +591,24 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   P.n = n; P.N = N; P.I = I; P.W = W; P.R = R;
   P.BS = (32 + 8 * W + 31) / 32 * 32;
   P.hoff = 0;
+  P.pcoff = 0;
+  int woff = 32;
   if (h->hyper) {  // the hyper legs follow the legs
     P.hoff = 8 * W;
     P.BS = (32 + 16 * W + 31) / 32 * 32;
-    if (std::getenv("TNCO_HIP_HYPER_ALIGNED")) {
-      // experiment: header + legs | hyper legs, each part in whole 128-byte lines of its own.  Measured
-      // on the 512-tensor hyper-index network: 4.16e9 against 4.15e9 move-evals/s -- no gain for 14 %
-      // more memory (what did help was two wavefronts per SIMD: no spills, 2.5e9 -> 4.2e9).
-      P.hoff = (32 + 8 * W + 127) / 128 * 128 - 32;
-      P.BS = 32 + P.hoff + (8 * W + 127) / 128 * 128;
+    const char* e = std::getenv("TNCO_HIP_HYPER_ALIGNED");
+    if (!fw && P.BS > 128 && !(e && std::atoi(e) == 0)) {
+      // Two-line layout (round 5; sa_kernels.h, Params::pcoff).  A move needs of the node ON the path its header and
+      // hyper legs (its own legs are (child ^ child) | hyper legs, infinite_memory/utils.hpp:82-91 + ctree.hpp:139-146),
+      // of the SIBLING its legs and partial cost: [ header | hyper legs ] and [ partial copy, pad | legs ], each part
+      // in whole 128-byte lines, make that 2 lines per move where the packed 224-byte block of 12 mask words cost 3-4
+      // (round 4 tried the alignment alone -- header + legs | hyper legs -- and gained nothing: still 3 lines).
+      // TNCO_HIP_HYPER_ALIGNED=0: the packed layout (A/B runs, tests).
+      const int path_b = (32 + 8 * W + 127) / 128 * 128, sib_b = (16 + 8 * W + 127) / 128 * 128;
+      P.BS = path_b + sib_b;
+      woff = path_b + 16;
+      P.hoff = 32 - woff;
+      P.pcoff = -16;
     }
   }
   // Blocks longer than a line are PACKED (a 224-byte block at 24 mask words straddles two or three 128-byte lines
@@ -610,7 +619,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     const int al = e ? std::atoi(e) : 0;
     if (al > 0) P.BS = (P.BS + al - 1) / al * al;
   }
-  P.WS = P.BS; P.WOFF = 32; P.RB = (int64_t)(n - 1) * P.BS;
+  P.WS = P.BS; P.WOFF = woff; P.RB = (int64_t)(n - 1) * P.BS;
   if (fw) {  // split layout (sa_kernels.h, Params)
     P.BS = 32;
     P.hoff = h->hyper ? 8 * W : 0;
@@ -1461,7 +1470,7 @@ int tnco_hip_get_caches(tnco_hip_handle h, int64_t r, double* ccost, double* par
     if (ccost) ccost[i] = i < n ? 0.0 : hd.ccost;
     if (partial) partial[i] = i < n ? 0.0 : hd.partial;
     if (hyper && h->hyper && i >= n)
-      std::memcpy(hyper + (size_t)i * W, blk.data() + (size_t)h->P.WOFF + (size_t)(i - n) * h->P.WS + h->P.hoff, (size_t)W * 8);
+      std::memcpy(hyper + (size_t)i * W, blk.data() + ((int64_t)h->P.WOFF + (int64_t)(i - n) * h->P.WS + h->P.hoff), (size_t)W * 8);
   }
   return TNCO_HIP_OK;
 }

@@ -40,8 +40,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--replicas", type=int, default=65536)
     ap.add_argument("--sweeps", type=int, default=100)
+    ap.add_argument("--only", default=None, help="hyper: the hyper-index network alone (for a rocprofv3 --pmc run)")
     a = ap.parse_args()
     R, S = a.replicas, a.sweeps
+    if a.only == "hyper":
+        hts, hd, hout = synthetic.random_hyper_tn(512, 768, k=3, n_output=8, seed=3)
+        run("hyper-index network, 512 tensors, 768 indices, dims 2", hts, 768, R, S, out=hout)
+        return
     ts, _d, _ = synthetic.random_regular_tn(512, 3, 11)
     I = 768
     run("3-regular 512 leaves, dims 2 (benchmark path)", ts, I, R, S)
