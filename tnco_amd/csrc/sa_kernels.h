@@ -76,8 +76,11 @@ struct Params {
   int32_t hoff;              // byte offset of a node's hyper legs from its legs (networks with hyper-indices; may be negative)
   // Infinite memory with hyper-indices and node blocks longer than a line ("two-line" layout, tnco_hip_create): a block
   // is [ header | hyper legs ] -- what a move needs of a node ON the path -- and, in lines of its own, [ partial-cost
-  // copy | legs ] -- what it needs of a SIBLING: 2 lines per move instead of 3-4.  pcoff = byte offset of that copy of
-  // NodeRec::partial from the node's legs (negative), 0 = no copy (every other layout).
+  // copy, pad | legs ] -- what it needs of a SIBLING: 2 lines per move instead of 3-4.  pcoff = byte offset of that copy
+  // of NodeRec::partial from the node's legs (negative), 0 = no copy (every other layout).  The copy is written wherever
+  // NodeRec::partial is: the sweep kernel's store phase and build_kernel; compare_kernel checks it.
+  // (Without hyper-indices the same idea -- headers in one array, [ copy | legs ] records in another -- LOST 5-30 % on
+  //  the networks of 15-48 mask words: the copy is one more dirty line per move, profiles/experiments_r05.md.)
   int32_t pcoff;
   int32_t jcap;              // rotation-log entries per replica
   int64_t R;
@@ -157,8 +160,8 @@ __device__ __forceinline__ Mask<K> msel(bool c, const Mask<K>& a, const Mask<K>&
   return r;
 }
 
-// Per-replica view of the node blocks.  UNI: the unified layout only (the infinite-memory sweep kernel:
-// one multiply per node, as before the split layout existed); else whatever Params says.
+// Per-replica view of the node blocks.  UNI: layouts whose legs are WS == BS bytes apart only (the infinite-memory sweep
+// kernel: one multiply per node, as before the split layout existed); else whatever Params says.
 template <int LOG2L, int K, bool HYPER, bool UNI = false>
 struct View {
   static constexpr int L = 1 << LOG2L;
@@ -586,7 +589,7 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
     sum = rnd_cost(sum + c, P.f32);                                                          // utils.hpp:112
     if (lane0) {
       v.hdr(p)->ccost = c; v.hdr(p)->partial = part;
-      if (HYPER && v.pcoff != 0) *v.pcopy(p) = part;
+      if (v.pcoff != 0) *v.pcopy(p) = part;
     }
   };
   // Without hyper-indices and with legs derived from the links, a node's legs, checks and costs need nothing but its
@@ -726,7 +729,7 @@ __global__ __launch_bounds__(256) void compare_kernel(const Params P, const Buil
       if (!logclose(x.partial, y.partial)) bad = bad ? bad : 32;
       if (x.left != y.left || x.right != y.right) bad = bad ? bad : 2;
       if (cur.parent(y.left) != i || cur.parent(y.right) != i) bad = bad ? bad : 8;
-      if (HYPER && cur.pcoff != 0 && __double_as_longlong(*cur.pcopy(i)) != __double_as_longlong(y.partial)) bad = bad ? bad : 35;
+      if (cur.pcoff != 0 && __double_as_longlong(*cur.pcopy(i)) != __double_as_longlong(y.partial)) bad = bad ? bad : 35;
     }
   }
   for (int p = n; p < N; ++p) {

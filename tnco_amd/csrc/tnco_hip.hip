@@ -80,7 +80,6 @@ void choose_lanes(int W, int* log2l, int* K) {
 // one (LOG2L, K) pair are compiled in a translation unit of their own (inst_<L>_<K>.hip).
 #define DISPATCH_LK(h, CALL)                                  \
   switch ((h)->log2l * 8 + (h)->K) {                          \
-    case 1 * 8 + 6: CALL(1, 6); break;                        \
     case 2 * 8 + 1: CALL(2, 1); break;                        \
     case 2 * 8 + 2: CALL(2, 2); break;                        \
     case 2 * 8 + 3: CALL(2, 3); break;                        \
@@ -562,9 +561,6 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   h->stream = h->own_stream;
 
   choose_lanes(W, &h->log2l, &h->K);
-  if (const char* e = std::getenv("TNCO_HIP_LANES")) {  // experiment knob: 2 lanes x 6 words
-    if (std::atoi(e) == 2 && W > 10 && W <= 12) { h->log2l = 1; h->K = 6; }
-  }
   h->L = 1 << h->log2l;
   const int L = h->L * h->K;  // padded words per mask row in the shared tables
 
