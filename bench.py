@@ -66,7 +66,7 @@ FW_MOVE_LAUNCHES = lambda sps, every: (sps + every - 1) // every + 1  # noqa: E7
 FW_RESLICE_LAUNCHES = lambda sps, every: (sps + every - 1) // every   # noqa: E731
 
 
-# what the library's four timers (tnco_hip_kernel_times) cover, by the kernels' names in a rocprofv3 trace
+# what the library's four timers (tnco_hip_diag_kernel_times) cover, by the kernels' names in a rocprofv3 trace
 TRACE_NAMES = {
     "sa_run_kernel": "sa_run_kernel<LOG2L, K, HYPER, GENERIC, false> (infinite-memory sweeps)",
     "fw_move_kernel": "sa_run_kernel<LOG2L, K, HYPER, GENERIC, true> (the finite-width moves; fw_move_kernel<> with max_number_new_slices > 0)",

@@ -20,6 +20,15 @@
  * TNCO_HIP_ERUNTIME -> RuntimeError; TNCO_HIP_ENOTIMPL -> NotImplementedError.
  * tnco_hip_last_error() returns the message of the last failing call on the
  * calling thread.
+ *
+ * Three families of entry points:
+ *   the operator   tnco_hip_create / _run / _run_fw / _sync / _get_* / _set_* / _validate / _best / _destroy ...:
+ *                  what the reference's Optimizer_<cost>[_<width>] objects do, batched;
+ *   helpers        tnco_hip_random_trees / _greedy_trees[_device] / _linear_paths* (the host code either side of the
+ *                  path), tnco_hip_comm_* (the one collective of a multi-GPU launch), device queries;
+ *   diagnostics    tnco_hip_diag_*: counters, timers and internals the tests, bench.py and tools/ read.  They have
+ *                  no reference counterpart and are NOT part of the drop-in contract (a binding of the reference
+ *                  needs none of them; INTEGRATION.md's stub uses none).
  */
 #ifndef TNCO_HIP_H_
 #define TNCO_HIP_H_
@@ -142,7 +151,7 @@ int tnco_hip_get_slices_many(tnco_hip_handle h, int64_t k, const int64_t* replic
  * (fw_wave_kernel), 0 it was rebuilt in full (or the replica has no slices); n_changed[r] = indices
  * by which the proposed slices differed from the current ones (-1: not recorded -- the single-kernel form, or more
  * than the re-pricing handles).  Either may be NULL.  EINVAL for a handle without re-pricing. */
-int tnco_hip_get_reslice_info(tnco_hip_handle h, int32_t* how, int32_t* n_changed);
+int tnco_hip_diag_reslice_info(tnco_hip_handle h, int32_t* how, int32_t* n_changed);
 
 /* Diagnostics (no reference counterpart): what the re-slices of this handle did since it was created, in replica
  * re-slices (one replica at the end of one re-slicing sweep, greedy/optimizer.hpp:359-376).  out8[0] launched in
@@ -150,7 +159,7 @@ int tnco_hip_get_reslice_info(tnco_hip_handle h, int32_t* how, int32_t* n_change
  * too-wide tensors / a deeper tree / more candidate legs than the wavefront form lists, out8[3] more changed indices
  * than it re-prices or an index it cannot place, out8[4] a cost outside a double's powers of two; out8[5] launched
  * in the walk + full-rebuild form; out8[6..7] reserved (0).  bench.py reports out8[1] / out8[0]. */
-int tnco_hip_get_fw_stats(tnco_hip_handle h, int64_t* out8);
+int tnco_hip_diag_fw_stats(tnco_hip_handle h, int64_t* out8);
 
 int tnco_hip_sync(tnco_hip_handle h);
 
@@ -216,27 +225,27 @@ int tnco_hip_linear_paths_ssa(int32_t n_tensors, int32_t steps, int64_t k, const
  * while loop at optimizer.hpp:117-192), accepted moves, best-tree updates, and
  * moves whose (D, E) order was drawn at random (optimize/optimizer.hpp:135-141).
  * Any pointer may be NULL. */
-int tnco_hip_get_counters(tnco_hip_handle h, uint64_t* moves, uint64_t* accepted,
+int tnco_hip_diag_counters(tnco_hip_handle h, uint64_t* moves, uint64_t* accepted,
                           uint64_t* improved, uint64_t* random_picks);
 /* Number of whole-tree copies taken for min_ctree (summed over replicas).  The
  * reference copies the tree on EVERY improvement (optimizer.hpp:198-201); this
  * build journals rotations and copies only after a journal overflow. */
-int tnco_hip_get_full_copies(tnco_hip_handle h, uint64_t* n);
+int tnco_hip_diag_full_copies(tnco_hip_handle h, uint64_t* n);
 /* Per replica move counter ([n_replicas]). */
-int tnco_hip_get_moves(tnco_hip_handle h, uint64_t* moves_per_replica);
+int tnco_hip_diag_moves(tnco_hip_handle h, uint64_t* moves_per_replica);
 /* Diagnostic (no reference counterpart): shader cycles per stage of the sweep
  * loop summed over replicas -- [mt19937, state branches, landing fence, store
  * phase, loop iterations].  All zero unless the library was built with
  * -DTNCO_PROFILE (`make -C tnco_amd/csrc profile`, tools/stage_cycles.py); with a finite-width
  * handle the slots are [too-wide counts, post-order, get_slices, rebuild + commit, re-slices]. */
-int tnco_hip_get_stage_cycles(tnco_hip_handle h, uint64_t* out5);
+int tnco_hip_diag_stage_cycles(tnco_hip_handle h, uint64_t* out5);
 
 /* Device time of the kernels launched by tnco_hip_run / tnco_hip_run_fw since the last reset (HIP
  * events on the handle's streams), and the number of schedule chunks launched (one per call unless the
- * schedule is very long).  A handle that splits its steps over two streams (tnco_hip_launch_groups() > 1)
+ * schedule is very long).  A handle that splits its steps over two streams (tnco_hip_diag_launch_groups() > 1)
  * reports the time from the first launch after the reset to the end of the last one: its concurrent
  * launches overlap, their durations do not add up. */
-int tnco_hip_kernel_time(tnco_hip_handle h, double* ms, int64_t* launches, int reset);
+int tnco_hip_diag_kernel_time(tnco_hip_handle h, double* ms, int64_t* launches, int reset);
 /* The same time split by kernel: [0] sa_run_kernel (Optimizer::update, infinite memory),
  * [1] the moves of the finite-width optimizer (finite_width/greedy/optimizer.hpp:130-331), [2] its re-slice
  * (:359-389: get_slices, the cost cache rebuilt or re-priced, the end of the sweep), [3] what orders the too-wide
@@ -244,14 +253,14 @@ int tnco_hip_kernel_time(tnco_hip_handle h, double* ms, int64_t* launches, int r
  * replica is one wavefront of fw_wave_kernel: counted under [2]); launches4 = launches of each -- for a finite-width
  * handle that runs its halves on two streams, launches PER STREAM (every event is one launch on each stream; the counts
  * are whole numbers because both streams launch the same sequence).  Either array ([4]) may be NULL. */
-int tnco_hip_kernel_times(tnco_hip_handle h, double* ms4, int64_t* launches4, int reset);
+int tnco_hip_diag_kernel_times(tnco_hip_handle h, double* ms4, int64_t* launches4, int reset);
 
 /* Concurrent launches a step of tnco_hip_run is split into (1, or 2 when there are more workgroups than resident ones: see
  * tnco_hip_run). */
-int tnco_hip_launch_groups(tnco_hip_handle h);
+int tnco_hip_diag_launch_groups(tnco_hip_handle h);
 
 /* Bytes of device memory held by the handle. */
-int64_t tnco_hip_device_bytes(tnco_hip_handle h);
+int64_t tnco_hip_diag_device_bytes(tnco_hip_handle h);
 
 /* Use an existing hipStream_t (e.g. torch's current stream) instead of the
  * handle's own. NULL restores the private stream. */
@@ -264,9 +273,9 @@ void tnco_hip_destroy(tnco_hip_handle h);
  * TNCO_HIP_CACHE_MB, default min(an eighth of the device's memory, 32 GB), 0: off; emptied when ANY device
  * allocation of this library fails, which is then retried).  Other allocators of the process (PyTorch,
  * RCCL) cannot reach into it: CALL tnco_hip_release_cached BEFORE HANDING THE GPU TO ANOTHER ALLOCATOR.
- * tnco_hip_release_cached gives everything back now; tnco_hip_cached_bytes: how much is held. */
+ * tnco_hip_release_cached gives everything back now; tnco_hip_diag_cached_bytes: how much is held. */
 void tnco_hip_release_cached(void);
-uint64_t tnco_hip_cached_bytes(void);
+uint64_t tnco_hip_diag_cached_bytes(void);
 
 /* Host helper replacing the per-run call
  * get_random_contraction_path(...) + ContractionTree(path, ...)
@@ -296,7 +305,7 @@ int tnco_hip_greedy_trees(int32_t n_leaves, int32_t n_inds, const int32_t* holde
 /* The same trees drawn ON THE DEVICE (csrc/greedy_device.hip: CPython's generator one lane per tree,
  * the greedy path finder one wavefront per tree -- over a multigraph held in LDS where the network has no
  * hyper-index, over index sets in memory otherwise); the trees come back in links_out (host memory).
- * Networks outside the kernel's limits (tnco_hip_greedy_device_supported == 0: more than 2040
+ * Networks outside the kernel's limits (tnco_hip_diag_greedy_device_supported == 0: more than 2040
  * indices or 2000 tensors, an index held by more than 6 tensors) and single trees that end in outer
  * products are done by tnco_hip_greedy_trees on n_threads host threads: same result either way.
  * links_out (host, may be NULL) receives the trees; links_device (may be NULL) receives a pointer to
@@ -310,14 +319,14 @@ int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, int32_t n_ind
                                  int32_t** links_device, int32_t n_threads);
 /* device -> host copy of such a buffer */
 int tnco_hip_copy_to_host(void* dst, const void* device_src, uint64_t bytes);
-int tnco_hip_greedy_device_supported(int32_t n_leaves, int32_t n_inds, const int32_t* holders_off);
+int tnco_hip_diag_greedy_device_supported(int32_t n_leaves, int32_t n_inds, const int32_t* holders_off);
 /* diagnostics: the 36-bit key of the cost 2^a - 2^b - 2^c by which the device generator orders its
  * candidates (larger cost <=> larger key; a, b, c <= 2040) */
-uint64_t tnco_hip_greedy_cost_key(int32_t a, int32_t b, int32_t c);
+uint64_t tnco_hip_diag_greedy_cost_key(int32_t a, int32_t b, int32_t c);
 /* the device memory tnco_hip_greedy_trees_device keeps between calls (one block, re-used) is freed */
 void tnco_hip_greedy_device_release(void);
 /* diagnostics: trees of the last device call that the host version did (-1: the whole batch) */
-int64_t tnco_hip_greedy_device_redone(void);
+int64_t tnco_hip_diag_greedy_device_redone(void);
 
 /*
  * The exchange between the GPUs of one node -- replaces what little tnco/parallel.py:330-341 moves between its worker

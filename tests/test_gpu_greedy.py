@@ -19,7 +19,7 @@ def _both(ts, n_inds, seeds, out_keep=(), draws=None, on_device=True):
     d_dev = None if draws is None else draws.copy()
     host = core.greedy_trees(ts, n_inds, seeds, output_mask=om, draws=d_host)
     dev = core.greedy_trees(ts, n_inds, seeds, output_mask=om, draws=d_dev, device=0)
-    redone = _lib.load().tnco_hip_greedy_device_redone()
+    redone = _lib.load().tnco_hip_diag_greedy_device_redone()
     assert (redone == 0) if on_device else (redone != 0), redone
     bad = [k for k in range(len(seeds)) if not np.array_equal(host[k], dev[k])]
     assert not bad, (len(ts), bad[:8])
@@ -32,7 +32,7 @@ def _both(ts, n_inds, seeds, out_keep=(), draws=None, on_device=True):
 def _supported(ts, n_inds):
     from tnco_amd import _lib
     off, _hold = core.holders_csr(ts, n_inds)
-    return bool(_lib.load().tnco_hip_greedy_device_supported(len(ts), n_inds, off.ctypes.data))
+    return bool(_lib.load().tnco_hip_diag_greedy_device_supported(len(ts), n_inds, off.ctypes.data))
 
 
 @pytest.fixture(params=["graph", "set", "set-lds-queue"])
@@ -133,7 +133,7 @@ def test_graph_form_long_lists_output_and_dangling_legs():
     ts3 = [list(range(255))] + [[k, 255 + k, 255 + (k + 1) % 255] for k in range(255)]
     host = core.greedy_trees(ts3, 510, seeds[:8])
     dev = core.greedy_trees(ts3, 510, seeds[:8], device=0)
-    assert np.array_equal(host, dev) and _lib.load().tnco_hip_greedy_device_redone() == 8
+    assert np.array_equal(host, dev) and _lib.load().tnco_hip_diag_greedy_device_redone() == 8
 
 
 def _random_multigraph(rng):

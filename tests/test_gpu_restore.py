@@ -168,11 +168,11 @@ def test_device_blocks_of_a_destroyed_optimizer_serve_the_next_one():
             return tot.copy(), mn.copy(), [x for r in (0, 7, 2047) for x in opt.tree(r, which_min=True, with_masks=False)]
 
     first = run()
-    held = int(core._lib.load().tnco_hip_cached_bytes())
+    held = int(core._lib.load().tnco_hip_diag_cached_bytes())
     assert held > 2048 * 32 * 1024  # (the rotation logs alone are 128 KB per replica)
     other = run(max_width=14)        # another shape in between: its blocks join the cache, dirtying nothing it should not
     again = run()
     assert np.array_equal(first[0], again[0]) and np.array_equal(first[1], again[1])
     assert all(np.array_equal(a, b) for a, b in zip(first[2], again[2]))
     assert np.array_equal(other[0], run(max_width=14)[0])
-    assert core.release_cached() >= held and int(core._lib.load().tnco_hip_cached_bytes()) == 0
+    assert core.release_cached() >= held and int(core._lib.load().tnco_hip_diag_cached_bytes()) == 0

@@ -296,7 +296,7 @@ def test_greedy_cost_key_orders_like_the_exact_cost():
     from tnco_amd import _lib
     L = _lib.load()
     def check(triples):
-        vals = sorted(((1 << a) - (1 << b) - (1 << c), L.tnco_hip_greedy_cost_key(a, b, c)) for a, b, c in triples)
+        vals = sorted(((1 << a) - (1 << b) - (1 << c), L.tnco_hip_diag_greedy_cost_key(a, b, c)) for a, b, c in triples)
         for (v0, k0), (v1, k1) in zip(vals, vals[1:]):
             assert (k0 < k1) if v0 < v1 else (k0 == k1), (v0, v1, k0, k1)
     rng = range(23)

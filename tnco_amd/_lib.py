@@ -52,12 +52,12 @@ class Desc(C.Structure):
 
 
 EXPORTS = [
-    "tnco_hip_create", "tnco_hip_run", "tnco_hip_run_fw", "tnco_hip_get_slices", "tnco_hip_get_slices_many", "tnco_hip_get_reslice_info", "tnco_hip_get_fw_stats", "tnco_hip_sync", "tnco_hip_get_costs", "tnco_hip_get_tree",
+    "tnco_hip_create", "tnco_hip_run", "tnco_hip_run_fw", "tnco_hip_get_slices", "tnco_hip_get_slices_many", "tnco_hip_diag_reslice_info", "tnco_hip_diag_fw_stats", "tnco_hip_sync", "tnco_hip_get_costs", "tnco_hip_get_tree",
     "tnco_hip_get_caches", "tnco_hip_validate", "tnco_hip_get_prng", "tnco_hip_set_prng", "tnco_hip_get_prng_many", "tnco_hip_set_prng_many",
-    "tnco_hip_best", "tnco_hip_min_cost_device", "tnco_hip_get_trees", "tnco_hip_linear_paths", "tnco_hip_linear_paths_ssa", "tnco_hip_get_counters", "tnco_hip_get_moves", "tnco_hip_get_full_copies",
-    "tnco_hip_kernel_time", "tnco_hip_kernel_times", "tnco_hip_get_stage_cycles",
-    "tnco_hip_launch_groups", "tnco_hip_device_bytes", "tnco_hip_set_stream", "tnco_hip_destroy", "tnco_hip_release_cached", "tnco_hip_cached_bytes", "tnco_hip_random_trees", "tnco_hip_greedy_trees",
-    "tnco_hip_greedy_trees_device", "tnco_hip_greedy_device_supported", "tnco_hip_greedy_device_redone", "tnco_hip_greedy_device_release", "tnco_hip_copy_to_host", "tnco_hip_greedy_cost_key",
+    "tnco_hip_best", "tnco_hip_min_cost_device", "tnco_hip_get_trees", "tnco_hip_linear_paths", "tnco_hip_linear_paths_ssa", "tnco_hip_diag_counters", "tnco_hip_diag_moves", "tnco_hip_diag_full_copies",
+    "tnco_hip_diag_kernel_time", "tnco_hip_diag_kernel_times", "tnco_hip_diag_stage_cycles",
+    "tnco_hip_diag_launch_groups", "tnco_hip_diag_device_bytes", "tnco_hip_set_stream", "tnco_hip_destroy", "tnco_hip_release_cached", "tnco_hip_diag_cached_bytes", "tnco_hip_random_trees", "tnco_hip_greedy_trees",
+    "tnco_hip_greedy_trees_device", "tnco_hip_diag_greedy_device_supported", "tnco_hip_diag_greedy_device_redone", "tnco_hip_greedy_device_release", "tnco_hip_copy_to_host", "tnco_hip_diag_greedy_cost_key",
     "tnco_hip_comm_unique_id", "tnco_hip_comm_init", "tnco_hip_comm_destroy", "tnco_hip_comm_allreduce_min", "tnco_hip_comm_allgather",
     "tnco_hip_comm_barrier", "tnco_hip_comm_last_error",
     "tnco_hip_device_name", "tnco_hip_device_count", "tnco_hip_last_error", "tnco_hip_version",
@@ -106,8 +106,8 @@ def load() -> C.CDLL:
     L.tnco_hip_run_fw.argtypes = [vp, C.c_int, vp, i64, i64, i64]
     L.tnco_hip_get_slices.argtypes = [vp, i64, vp, vp]
     L.tnco_hip_get_slices_many.argtypes = [vp, i64, vp, vp, vp]
-    L.tnco_hip_get_reslice_info.argtypes = [vp, vp, vp]
-    L.tnco_hip_get_fw_stats.argtypes = [vp, vp]
+    L.tnco_hip_diag_reslice_info.argtypes = [vp, vp, vp]
+    L.tnco_hip_diag_fw_stats.argtypes = [vp, vp]
     L.tnco_hip_sync.argtypes = [vp]
     L.tnco_hip_get_costs.argtypes = [vp, vp, vp]
     L.tnco_hip_get_tree.argtypes = [vp, i64, C.c_int, vp, vp, vp, vp]
@@ -122,33 +122,33 @@ def load() -> C.CDLL:
     L.tnco_hip_get_trees.argtypes = [vp, i64, vp, C.c_int, vp, vp]
     L.tnco_hip_linear_paths.argtypes = [i32, i32, vp, i64, vp, vp, i32]
     L.tnco_hip_linear_paths_ssa.argtypes = [i32, i32, i64, vp, vp, i32]
-    L.tnco_hip_get_counters.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4
-    L.tnco_hip_get_moves.argtypes = [vp, vp]
-    L.tnco_hip_get_stage_cycles.argtypes = [vp, vp]
-    L.tnco_hip_get_full_copies.argtypes = [vp, C.POINTER(C.c_uint64)]
-    L.tnco_hip_kernel_time.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.c_int]
-    L.tnco_hip_kernel_times.argtypes = [vp, vp, vp, C.c_int]
-    L.tnco_hip_launch_groups.argtypes = [vp]
-    L.tnco_hip_device_bytes.argtypes = [vp]
-    L.tnco_hip_device_bytes.restype = i64
+    L.tnco_hip_diag_counters.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4
+    L.tnco_hip_diag_moves.argtypes = [vp, vp]
+    L.tnco_hip_diag_stage_cycles.argtypes = [vp, vp]
+    L.tnco_hip_diag_full_copies.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.tnco_hip_diag_kernel_time.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.c_int]
+    L.tnco_hip_diag_kernel_times.argtypes = [vp, vp, vp, C.c_int]
+    L.tnco_hip_diag_launch_groups.argtypes = [vp]
+    L.tnco_hip_diag_device_bytes.argtypes = [vp]
+    L.tnco_hip_diag_device_bytes.restype = i64
     L.tnco_hip_set_stream.argtypes = [vp, vp]
     L.tnco_hip_destroy.argtypes = [vp]
     L.tnco_hip_destroy.restype = None
     L.tnco_hip_release_cached.argtypes = []
     L.tnco_hip_release_cached.restype = None
-    L.tnco_hip_cached_bytes.argtypes = []
-    L.tnco_hip_cached_bytes.restype = C.c_uint64
+    L.tnco_hip_diag_cached_bytes.argtypes = []
+    L.tnco_hip_diag_cached_bytes.restype = C.c_uint64
     L.tnco_hip_random_trees.argtypes = [i32, i32, vp, vp, i64, vp, vp, i32]
     L.tnco_hip_greedy_trees.argtypes = [i32, i32, vp, vp, vp, i64, vp, vp, vp, i32]
     L.tnco_hip_greedy_trees_device.argtypes = [i32, i32, i32, vp, vp, vp, i64, vp, vp, vp, vp, i32]
     L.tnco_hip_copy_to_host.argtypes = [vp, vp, C.c_uint64]
-    L.tnco_hip_greedy_cost_key.argtypes = [i32, i32, i32]
-    L.tnco_hip_greedy_cost_key.restype = C.c_uint64
-    L.tnco_hip_greedy_device_supported.argtypes = [i32, i32, vp]
+    L.tnco_hip_diag_greedy_cost_key.argtypes = [i32, i32, i32]
+    L.tnco_hip_diag_greedy_cost_key.restype = C.c_uint64
+    L.tnco_hip_diag_greedy_device_supported.argtypes = [i32, i32, vp]
     L.tnco_hip_greedy_device_release.argtypes = []
     L.tnco_hip_greedy_device_release.restype = None
-    L.tnco_hip_greedy_device_redone.argtypes = []
-    L.tnco_hip_greedy_device_redone.restype = i64
+    L.tnco_hip_diag_greedy_device_redone.argtypes = []
+    L.tnco_hip_diag_greedy_device_redone.restype = i64
     L.tnco_hip_comm_unique_id.argtypes = [vp]
     L.tnco_hip_comm_init.argtypes = [C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp)]
     L.tnco_hip_comm_destroy.argtypes = [vp]

@@ -108,7 +108,7 @@ def release_cached() -> int:
     """Gives back the device memory the library keeps from destroyed optimizers for the next one
     (csrc/dev_cache.h; `TNCO_HIP_CACHE_MB`); returns the bytes that were held."""
     L = _lib.load()
-    held = int(L.tnco_hip_cached_bytes())
+    held = int(L.tnco_hip_diag_cached_bytes())
     L.tnco_hip_release_cached()
     return held
 
@@ -359,17 +359,17 @@ class BatchedOptimizer:
         return a, b
 
     def reslice_info(self):
-        """(how, n_changed) of every replica's LAST re-slice (diagnostics, tnco_hip_get_reslice_info): how = 1
+        """(how, n_changed) of every replica's LAST re-slice (diagnostics, tnco_hip_diag_reslice_info): how = 1
         re-priced, 0 rebuilt in full / no slices; n_changed = indices the proposal differed by (-1 unknown)."""
         how = np.empty(self.n_replicas, np.int32)
         nch = np.empty(self.n_replicas, np.int32)
-        _lib.check(self._L.tnco_hip_get_reslice_info(self._h, _ptr(how), _ptr(nch)))
+        _lib.check(self._L.tnco_hip_diag_reslice_info(self._h, _ptr(how), _ptr(nch)))
         return how, nch
 
     def fw_stats(self) -> dict:
-        """What this handle's re-slices did since it was created, in replica re-slices (tnco_hip_get_fw_stats)."""
+        """What this handle's re-slices did since it was created, in replica re-slices (tnco_hip_diag_fw_stats)."""
         o = np.zeros(8, np.int64)
-        _lib.check(self._L.tnco_hip_get_fw_stats(self._h, _ptr(o)))
+        _lib.check(self._L.tnco_hip_diag_fw_stats(self._h, _ptr(o)))
         return dict(repriced=int(o[0]), fell_back=int(o[1]), too_many_wide=int(o[2]), too_many_changed=int(o[3]),
                     cost_range=int(o[4]), full_rebuild_form=int(o[5]))
 
@@ -501,29 +501,29 @@ class BatchedOptimizer:
 
     def counters(self) -> dict:
         a, b, c, q = (C.c_uint64(0) for _ in range(4))
-        _lib.check(self._L.tnco_hip_get_counters(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(q)))
+        _lib.check(self._L.tnco_hip_diag_counters(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(q)))
         f = C.c_uint64(0)
-        _lib.check(self._L.tnco_hip_get_full_copies(self._h, C.byref(f)))
+        _lib.check(self._L.tnco_hip_diag_full_copies(self._h, C.byref(f)))
         return dict(moves=a.value, accepted=b.value, improved=c.value, random_picks=q.value,
                     full_copies=f.value)
 
     def moves_per_replica(self) -> np.ndarray:
         out = np.empty(self.n_replicas, np.uint64)
-        _lib.check(self._L.tnco_hip_get_moves(self._h, _ptr(out)))
+        _lib.check(self._L.tnco_hip_diag_moves(self._h, _ptr(out)))
         return out
 
     def kernel_time_ms(self, reset: bool = False):
         """(device ms, schedule chunks) of the run calls since the last reset; with two streams the time from the first
-        launch to the end of the last (tnco_hip_kernel_time)."""
+        launch to the end of the last (tnco_hip_diag_kernel_time)."""
         ms, n = C.c_double(0.0), C.c_int64(0)
-        _lib.check(self._L.tnco_hip_kernel_time(self._h, C.byref(ms), C.byref(n), int(reset)))
+        _lib.check(self._L.tnco_hip_diag_kernel_time(self._h, C.byref(ms), C.byref(n), int(reset)))
         return ms.value, n.value
 
     def kernel_times_ms(self, reset: bool = False) -> dict:
         """{kernel: (ms, launches)} since the last reset, from HIP events around every launch."""
         ms = np.zeros(4, np.float64)
         n = np.zeros(4, np.int64)
-        _lib.check(self._L.tnco_hip_kernel_times(self._h, _ptr(ms), _ptr(n), int(reset)))
+        _lib.check(self._L.tnco_hip_diag_kernel_times(self._h, _ptr(ms), _ptr(n), int(reset)))
         names = ("sa_run_kernel", "fw_move_kernel", "fw_reslice_kernel", "fw_walk_kernel")
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
@@ -531,8 +531,8 @@ class BatchedOptimizer:
     def launch_groups(self) -> int:
         """Concurrent launches (streams) a step of run() is split into: 1, or 2 when the replicas do not fill
         whole rounds of resident workgroups (tnco_hip_run)."""
-        return int(self._L.tnco_hip_launch_groups(self._h))
+        return int(self._L.tnco_hip_diag_launch_groups(self._h))
 
     @property
     def device_bytes(self) -> int:
-        return int(self._L.tnco_hip_device_bytes(self._h))
+        return int(self._L.tnco_hip_diag_device_bytes(self._h))

@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(256, 2) void fw_init_kernel(const Params P, const F
 
 // Stage timing of a re-slicing sweep (diagnostic builds, -DTNCO_PROFILE): shader cycles of
 // [walk, too-wide counts, greedy pass, rebuild + commit] and the number of re-slices, per replica, in
-// ReplicaState::pad1 (tnco_hip_get_stage_cycles; tools/stage_cycles.py --fw).
+// ReplicaState::pad1 (tnco_hip_diag_stage_cycles; tools/stage_cycles.py --fw).
 #ifdef TNCO_PROFILE
 #define FW_PROF_DECL \
   unsigned long long ft_[5] = {0, 0, 0, 0, 0}, fa_[5] = {0, 0, 0, 0, 0}; \
@@ -1618,7 +1618,7 @@ __global__ __launch_bounds__(256, TNCO_FW_RESLICE_A_WAVES) void fw_reslice_a_ker
   uint64_t* prop = reinterpret_cast<uint64_t*>(const_cast<int16_t*>(sc.pos));
 #pragma unroll
   for (int k = 0; k < K; ++k) prop[v.widx(k)] = ns.w[k];
-  if (lane0) reinterpret_cast<uint32_t*>(F.delta_scr + r * 64)[0] = 0xFFFFFFFFu;  // (tnco_hip_get_reslice_info: not re-priced)
+  if (lane0) reinterpret_cast<uint32_t*>(F.delta_scr + r * 64)[0] = 0xFFFFFFFFu;  // (tnco_hip_diag_reslice_info: not re-priced)
   int mti, mtw;
   rng.finish(mti, mtw);
   if (lane0) {

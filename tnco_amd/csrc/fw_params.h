@@ -36,7 +36,7 @@ struct FwParams {
   unsigned long long* slowstat;  // [4] replicas the re-pricing has left to the full rebuild since the host last looked; of those
                                  //     [1] too many / too deep / too leggy too-wide tensors, [2] too many changed indices or an index
                                  //     held otherwise, [3] a cost outside a double's powers of two
-  uint64_t* delta_scr;      // [R][64] word 0: indices the last proposal changed (0xFFFFFFFF: not re-priced), for tnco_hip_get_reslice_info
+  uint64_t* delta_scr;      // [R][64] word 0: indices the last proposal changed (0xFFFFFFFF: not re-priced), for tnco_hip_diag_reslice_info
   int32_t* status;          // [R] runtime problems (1: candidate legs beyond the scratch; cannot happen
                             //     since the scratch holds every index)
 };

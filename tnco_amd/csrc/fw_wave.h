@@ -652,7 +652,7 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
   // ---- the indices that changed, with the starts of their paths (the region is the re-pricing's now).  Their
   // holders are requested first -- up to four per lane in one flight -- and only then the stores of this step are
   // issued: a load behind a store waits for the store's acknowledgement too.
-  uint32_t* chg = reinterpret_cast<uint32_t*>(F.delta_scr + r * 64);  // (word 0: the count, for tnco_hip_get_reslice_info)
+  uint32_t* chg = reinterpret_cast<uint32_t*>(F.delta_scr + r * 64);  // (word 0: the count, for tnco_hip_diag_reslice_info)
   int nd;
   {
     uint64_t ch = g == 0 ? (ns ^ old) : 0ull;

@@ -130,10 +130,10 @@ extern "C" void tnco_hip_greedy_device_release(void) {
 
 static int64_t g_last_redone = -1;
 // trees of the last tnco_hip_greedy_trees_device call that the host version did (-1: the whole batch)
-extern "C" int64_t tnco_hip_greedy_device_redone(void) { return g_last_redone; }
+extern "C" int64_t tnco_hip_diag_greedy_device_redone(void) { return g_last_redone; }
 
 // 1 when tnco_hip_greedy_trees_device takes this network itself (else it hands the batch to the host version)
-extern "C" int tnco_hip_greedy_device_supported(int32_t n_leaves, int32_t n_inds, const int32_t* holders_off) {
+extern "C" int tnco_hip_diag_greedy_device_supported(int32_t n_leaves, int32_t n_inds, const int32_t* holders_off) {
   if (n_leaves < 3 || n_leaves > 2000 || n_inds < 1 || n_inds > GREEDY_KEY_MAX_EXP || !holders_off) return 0;
   int64_t q = 0;  // candidates queued at most: the initial ones (a push takes the cell of the pop before it)
   for (int32_t i = 0; i < n_inds; ++i) {
@@ -157,7 +157,7 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
   if (links_device) *links_device = nullptr;
   if (n_replicas == 0) return TNCO_HIP_OK;
   g_last_redone = -1;
-  if (!tnco_hip_greedy_device_supported(n_leaves, n_inds, holders_off)) {
+  if (!tnco_hip_diag_greedy_device_supported(n_leaves, n_inds, holders_off)) {
     // the host version; the trees go to the device afterwards if the caller wants them there
     const size_t cnt = (size_t)n_replicas * 3 * (2 * (size_t)n_leaves - 1);
     std::vector<int32_t> tmp;
@@ -221,7 +221,6 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
   const size_t lds = graph ? graph_lds_bytes(n, gh.CAP) : lds_bytes(W, SMAX, I, set_rows ? 0 : QC, TS);
   int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (size_t)(160 * 1024) / lds));
   if (per_cu > 12) per_cu &= ~3;  // (13 per CU measured a third slower than 12; 9, 10, 11 each faster than the one before)
-  if (const char* e = std::getenv("TNCO_HIP_GREEDY_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(e)));  // (experiment: occupancy sensitivity)
   const int G = (int)std::min<int64_t>(R, (int64_t)cus * per_cu);
 
   std::lock_guard<std::mutex> pool_lock(g_pool.mu);
@@ -283,7 +282,7 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
     G_TRY(hipMemcpy(d_ekey, gh.e_key.data(), gh.e_key.size() * 8, hipMemcpyHostToDevice));
   }
 
-  const bool dbg = std::getenv("TNCO_HIP_GREEDY_DEBUG") != nullptr;
+  const bool dbg = std::getenv("TNCO_HIP_DEBUG") != nullptr;
   if (dbg) {
     G_TRY(hipDeviceSynchronize());
     std::fprintf(stderr, "greedy_device: set-up (allocations, inputs to the device) %.1f ms\n",
@@ -383,7 +382,7 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
     if (status[r] != 0) redo.push_back(r);
   g_last_redone = (int64_t)redo.size();
   if (!redo.empty()) {
-    if (std::getenv("TNCO_HIP_GREEDY_DEBUG"))
+    if (std::getenv("TNCO_HIP_DEBUG"))
       for (size_t k = 0; k < std::min<size_t>(redo.size(), 8); ++k)
         std::fprintf(stderr, "greedy_device: tree %lld status %d\n", (long long)redo[k], status[redo[k]]);
     std::vector<uint32_t> s2(redo.size());

@@ -43,7 +43,7 @@ struct tnco_hip_ctx {
   int64_t fw_wave_reslices = 0;  // re-slices launched in that form since the count was read
   int fw_single_calls = 0;        // calls in the other mode since the last probe
   int fw_probe_wait = 4;          // ... before the next probe (doubles after a probe that failed)
-  // tnco_hip_get_fw_stats: [0] replica re-slices launched in the re-pricing form, [1] of those left to the full rebuild,
+  // tnco_hip_diag_fw_stats: [0] replica re-slices launched in the re-pricing form, [1] of those left to the full rebuild,
   // [2..4] why (FwParams::slowstat[1..3]), [5] replica re-slices launched in the walk + full-rebuild form
   int64_t fw_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool fw_probed = false;  // the first re-slice interval of the handle has run on its own (tnco_hip_run_fw)

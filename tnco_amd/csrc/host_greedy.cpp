@@ -504,4 +504,4 @@ extern "C" int tnco_hip_greedy_trees(int32_t n_leaves, int32_t n_inds, const int
 
 // the order-preserving key of 2^a - 2^b - 2^c the device generator sorts its candidates by (greedy_key.h),
 // for the test that checks it against exact integers
-extern "C" uint64_t tnco_hip_greedy_cost_key(int32_t a, int32_t b, int32_t c) { return tnco::greedy_cost_key(a, b, c); }
+extern "C" uint64_t tnco_hip_diag_greedy_cost_key(int32_t a, int32_t b, int32_t c) { return tnco::greedy_cost_key(a, b, c); }

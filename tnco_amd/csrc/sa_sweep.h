@@ -280,7 +280,7 @@ struct ColdState {
 typedef TNCO_LDS volatile ColdState lds_cold;
 
 // Stage timing (diagnostic builds only, -DTNCO_PROFILE): shader cycles between five points of the
-// loop body, accumulated per replica into ReplicaState::pad1 (tnco_hip_get_stage_cycles).
+// loop body, accumulated per replica into ReplicaState::pad1 (tnco_hip_diag_stage_cycles).
 #ifdef TNCO_PROFILE
 #define TNCO_PROF_DECL unsigned long long pt_[5] = {0, 0, 0, 0, 0}, pa_[5] = {0, 0, 0, 0, 0}
 #if TNCO_PROFILE == 2

@@ -463,7 +463,7 @@ void tnco_hip_release_cached(void) {
   tnco::DevCache::get().release_all();
   tnco::StreamCache::get().release_all();
 }
-uint64_t tnco_hip_cached_bytes(void) { return (uint64_t)tnco::DevCache::get().held(); }
+uint64_t tnco_hip_diag_cached_bytes(void) { return (uint64_t)tnco::DevCache::get().held(); }
 
 int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   if (!d || !out) return fail(TNCO_HIP_EINVAL, "null argument.");
@@ -541,8 +541,8 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   if (d->device < 0 || d->device >= ndev) return fail(TNCO_HIP_EINVAL, "'device' is not valid.");
   HIP_TRY(hipSetDevice(d->device));
 
-  // TNCO_HIP_CREATE_DEBUG: wall time of the steps of this call on stderr (the device drained at every mark)
-  const bool cdbg = std::getenv("TNCO_HIP_CREATE_DEBUG") != nullptr;
+  // TNCO_HIP_DEBUG: wall time of the steps of this call on stderr (the device drained at every mark)
+  const bool cdbg = std::getenv("TNCO_HIP_DEBUG") != nullptr;
   auto c_t0 = std::chrono::steady_clock::now();
   auto cmark = [&](const char* what) {
     if (!cdbg) return;
@@ -608,13 +608,8 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     }
   }
   // Blocks longer than a line are PACKED (a 224-byte block at 24 mask words straddles two or three 128-byte lines
-  // depending on where it starts).  TNCO_HIP_BLOCK_ALIGN=128 pads them to whole lines (experiment knob: measured no
-  // faster in round 3 -- the padding costs as many lines as it saves).
-  if (P.BS > 128 && !h->hyper) {
-    const char* e = std::getenv("TNCO_HIP_BLOCK_ALIGN");
-    const int al = e ? std::atoi(e) : 0;
-    if (al > 0) P.BS = (P.BS + al - 1) / al * al;
-  }
+  // depending on where it starts): padding them to whole lines costs as many lines as it saves (round 3), and splitting
+  // them into headers + [partial copy | legs] records loses 5-30 % to the second dirty line per move (round 5).
   P.WS = P.BS; P.WOFF = woff; P.RB = (int64_t)(n - 1) * P.BS;
   if (fw) {  // split layout (sa_kernels.h, Params)
     P.BS = 32;
@@ -631,7 +626,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       const uint64_t x = d->dims[i];
       allp2 = (x & (x - 1)) == 0;
     }
-    if (allp2 && !std::getenv("TNCO_HIP_NO_POW2_CLASSES")) P.cost_mode = 3;
+    if (allp2) P.cost_mode = 3;
   }
   P.log2d = 0;
   if (pow2u) while ((1ull << P.log2d) < dim_u) ++P.log2d;
@@ -923,7 +918,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     HIP_TRY(h->alloc(&F.fastflag, R));
     HIP_TRY(hipMemset(F.fastflag, 0, (size_t)R * 4));
     HIP_TRY(h->alloc(&F.delta_scr, R * 64));
-    // (word 0 of a replica = the change count of its last re-pricing, tnco_hip_get_reslice_info: "none yet", whatever
+    // (word 0 of a replica = the change count of its last re-pricing, tnco_hip_diag_reslice_info: "none yet", whatever
     //  a recycled block held)
     HIP_TRY(hipMemset(F.delta_scr, 0xFF, (size_t)R * 64 * sizeof(*F.delta_scr)));
     F.stack_cap = FW_LDSPOS;
@@ -1304,7 +1299,7 @@ int tnco_hip_get_slices(tnco_hip_handle h, int64_t r, uint64_t* slices, uint64_t
   return TNCO_HIP_OK;
 }
 
-int tnco_hip_get_reslice_info(tnco_hip_handle h, int32_t* how, int32_t* n_changed) {
+int tnco_hip_diag_reslice_info(tnco_hip_handle h, int32_t* how, int32_t* n_changed) {
   if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
   if (!h->fw || !h->fw_wave_capable) return fail(TNCO_HIP_EINVAL, "handle has no re-pricing re-slice.");
   HIP_TRY(hipSetDevice(h->device));
@@ -1317,7 +1312,7 @@ int tnco_hip_get_reslice_info(tnco_hip_handle h, int32_t* how, int32_t* n_change
   return TNCO_HIP_OK;
 }
 
-int tnco_hip_get_fw_stats(tnco_hip_handle h, int64_t* out8) {
+int tnco_hip_diag_fw_stats(tnco_hip_handle h, int64_t* out8) {
   if (!h || !out8) return fail(TNCO_HIP_EINVAL, "null argument.");
   if (!h->fw) return fail(TNCO_HIP_EINVAL, "handle was created without 'max_width'.");
   HIP_TRY(hipSetDevice(h->device));
@@ -1327,7 +1322,7 @@ int tnco_hip_get_fw_stats(tnco_hip_handle h, int64_t* out8) {
   return TNCO_HIP_OK;
 }
 
-int tnco_hip_kernel_time(tnco_hip_handle h, double* ms, int64_t* launches, int reset) {
+int tnco_hip_diag_kernel_time(tnco_hip_handle h, double* ms, int64_t* launches, int reset) {
   if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(h->sync_all());
@@ -1339,14 +1334,14 @@ int tnco_hip_kernel_time(tnco_hip_handle h, double* ms, int64_t* launches, int r
   return TNCO_HIP_OK;
 }
 
-int tnco_hip_kernel_times(tnco_hip_handle h, double* ms4, int64_t* launches4, int reset) {
+int tnco_hip_diag_kernel_times(tnco_hip_handle h, double* ms4, int64_t* launches4, int reset) {
   if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(h->sync_all());
   h->close_region();
   h->resolve_events();
   // (a finite-width handle on two streams: the AVERAGE time a stream spent in each kernel -- the streams run
-  //  concurrently, so these add up to about the device time tnco_hip_kernel_time reports, not to twice it)
+  //  concurrently, so these add up to about the device time tnco_hip_diag_kernel_time reports, not to twice it)
   const double div = (h->fw && h->n_groups > 1) ? (double)h->n_groups : 1.0;
   for (int k = 0; k < TNCO_KINDS; ++k) {
     if (ms4) ms4[k] = h->kind_ms[k] / div;
@@ -1356,9 +1351,9 @@ int tnco_hip_kernel_times(tnco_hip_handle h, double* ms4, int64_t* launches4, in
   return TNCO_HIP_OK;
 }
 
-int tnco_hip_launch_groups(tnco_hip_handle h) { return h ? h->n_groups : 0; }
+int tnco_hip_diag_launch_groups(tnco_hip_handle h) { return h ? h->n_groups : 0; }
 
-int64_t tnco_hip_device_bytes(tnco_hip_handle h) { return h ? h->bytes : 0; }
+int64_t tnco_hip_diag_device_bytes(tnco_hip_handle h) { return h ? h->bytes : 0; }
 
 int tnco_hip_get_costs(tnco_hip_handle h, double* total_cost, double* min_total_cost) {
   if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
@@ -1755,7 +1750,7 @@ int tnco_hip_get_trees(tnco_hip_handle h, int64_t k, const int64_t* ids, int whi
   return TNCO_HIP_OK;
 }
 
-int tnco_hip_get_counters(tnco_hip_handle h, uint64_t* moves, uint64_t* accepted, uint64_t* improved,
+int tnco_hip_diag_counters(tnco_hip_handle h, uint64_t* moves, uint64_t* accepted, uint64_t* improved,
                           uint64_t* random_picks) {
   if (!h) return fail(TNCO_HIP_EINVAL, "null handle.");
   std::vector<ReplicaState> rs;
@@ -1769,7 +1764,7 @@ int tnco_hip_get_counters(tnco_hip_handle h, uint64_t* moves, uint64_t* accepted
   return TNCO_HIP_OK;
 }
 
-int tnco_hip_get_full_copies(tnco_hip_handle h, uint64_t* n) {
+int tnco_hip_diag_full_copies(tnco_hip_handle h, uint64_t* n) {
   if (!h || !n) return fail(TNCO_HIP_EINVAL, "null argument.");
   std::vector<ReplicaState> rs;
   if (int rc = fetch_rs(h, rs)) return rc;
@@ -1779,7 +1774,7 @@ int tnco_hip_get_full_copies(tnco_hip_handle h, uint64_t* n) {
   return TNCO_HIP_OK;
 }
 
-int tnco_hip_get_stage_cycles(tnco_hip_handle h, uint64_t* out5) {
+int tnco_hip_diag_stage_cycles(tnco_hip_handle h, uint64_t* out5) {
   if (!h || !out5) return fail(TNCO_HIP_EINVAL, "null argument.");
   std::vector<ReplicaState> rs;
   if (int rc = fetch_rs(h, rs)) return rc;
@@ -1789,7 +1784,7 @@ int tnco_hip_get_stage_cycles(tnco_hip_handle h, uint64_t* out5) {
   return TNCO_HIP_OK;
 }
 
-int tnco_hip_get_moves(tnco_hip_handle h, uint64_t* out) {
+int tnco_hip_diag_moves(tnco_hip_handle h, uint64_t* out) {
   if (!h || !out) return fail(TNCO_HIP_EINVAL, "null argument.");
   std::vector<ReplicaState> rs;
   if (int rc = fetch_rs(h, rs)) return rc;

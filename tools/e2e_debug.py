@@ -1,5 +1,5 @@
 """optimize() of 65 536 runs x 1 000 sweeps on the 512-leaf network, several times, and the same call in its
-pieces through the C ABI (diagnostic; TNCO_HIP_GREEDY_DEBUG=1 / TNCO_HIP_CREATE_DEBUG=1 print the steps inside):
+pieces through the C ABI (diagnostic; TNCO_HIP_DEBUG=1 print the steps inside):
     python tools/e2e_debug.py [repeats]"""
 import pathlib
 import sys

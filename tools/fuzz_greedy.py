@@ -41,7 +41,7 @@ for it in range(N):
                 ts[base_t + int(rng.integers(0, len(ts2)))].append(n_inds)
                 n_inds += 1
     off, _h = core.holders_csr(ts, n_inds)
-    if not L.tnco_hip_greedy_device_supported(len(ts), n_inds, off.ctypes.data):
+    if not L.tnco_hip_diag_greedy_device_supported(len(ts), n_inds, off.ctypes.data):
         continue
     om = ct.pack_masks([list(out)], n_inds)[0]
     host = core.greedy_trees(ts, n_inds, seeds, output_mask=om)
@@ -49,7 +49,7 @@ for it in range(N):
     assert np.array_equal(host, dev), (it, len(ts), n_inds)
     done += 1
     trees += S
-    redone += int(L.tnco_hip_greedy_device_redone())
+    redone += int(L.tnco_hip_diag_greedy_device_redone())
     sizes.append(len(ts))
 print(f"{done} networks ({min(sizes)}-{max(sizes)} tensors, every fifth a hypergraph) x {S} seeds = {trees} trees: device == host, "
       f"{redone} trees handed to the host inside the call (second components, long lists), {time.time() - t0:.0f} s")

@@ -1,4 +1,4 @@
-"""Finite-width throughput against max_width, and what the re-slices did (tnco_hip_get_fw_stats).
+"""Finite-width throughput against max_width, and what the re-slices did (tnco_hip_diag_fw_stats).
 
     python tools/fw_widths.py [--layout supremacy] [--widths 28,32,40] [--replicas 32768] [--sweeps 500] [--chunk 100]
 

@@ -39,12 +39,12 @@ def main():
     opt.run(betas[:5])
     L = _lib.load()
     base = np.zeros(5, np.uint64)
-    L.tnco_hip_get_stage_cycles(opt._h, base.ctypes.data_as(C.c_void_p))
+    L.tnco_hip_diag_stage_cycles(opt._h, base.ctypes.data_as(C.c_void_p))
     m0 = opt.counters()["moves"]
     opt.run(betas)
     opt.sync()
     cyc = np.zeros(5, np.uint64)
-    L.tnco_hip_get_stage_cycles(opt._h, cyc.ctypes.data_as(C.c_void_p))
+    L.tnco_hip_diag_stage_cycles(opt._h, cyc.ctypes.data_as(C.c_void_p))
     cyc = (cyc - base).astype(np.float64)
     moves = opt.counters()["moves"] - m0
     it = cyc[4]
@@ -68,11 +68,11 @@ def fw(a):
     opt = core.BatchedOptimizer(lm, links, seeds, n_inds=n_inds, max_width=40)
     L = _lib.load()
     base = np.zeros(5, np.uint64)
-    L.tnco_hip_get_stage_cycles(opt._h, base.ctypes.data_as(C.c_void_p))
+    L.tnco_hip_diag_stage_cycles(opt._h, base.ctypes.data_as(C.c_void_p))
     opt.run(np.linspace(0, 100, a.sweeps), update_slices_every=10)
     opt.sync()
     cyc = np.zeros(5, np.uint64)
-    L.tnco_hip_get_stage_cycles(opt._h, cyc.ctypes.data_as(C.c_void_p))
+    L.tnco_hip_diag_stage_cycles(opt._h, cyc.ctypes.data_as(C.c_void_p))
     cyc = (cyc - base).astype(np.float64)
     names = ["walk (post-order, widths)", "get_slices: too-wide counts", "get_slices: greedy pass", "rebuild + commit"]
     if a.fine:  # library built with -DTNCO_PROFILE=4: cycles inside the greedy pass

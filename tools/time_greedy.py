@@ -17,7 +17,7 @@ core.greedy_trees(prob.ts_inds, prob.n_inds, seeds[:64], device=0)  # (first cal
 t0 = time.perf_counter()
 dev = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds, device=0)
 t1 = time.perf_counter()
-redone = _lib.load().tnco_hip_greedy_device_redone()
+redone = _lib.load().tnco_hip_diag_greedy_device_redone()
 ns = min(R, 8192)
 host = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds[:ns])
 t2 = time.perf_counter()

@@ -15,4 +15,4 @@ for depth, fuse in ((20, 4), (12, None)):
     core.greedy_trees(ts, n_inds, seeds[:64], output_mask=om, device=0)
     t0 = time.perf_counter()
     core.greedy_trees(ts, n_inds, seeds, output_mask=om, device=0, keep_on_device=True)
-    print(f"cz depth {depth} fuse {fuse}: {len(ts)} tensors, {n_inds} indices, max holders {max(cnt.values())}: {time.perf_counter()-t0:.3f} s, redone {_lib.load().tnco_hip_greedy_device_redone()}")
+    print(f"cz depth {depth} fuse {fuse}: {len(ts)} tensors, {n_inds} indices, max holders {max(cnt.values())}: {time.perf_counter()-t0:.3f} s, redone {_lib.load().tnco_hip_diag_greedy_device_redone()}")
