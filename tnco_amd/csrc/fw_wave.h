@@ -182,6 +182,24 @@ __device__ __forceinline__ uint32_t fws_scan(uint32_t v, int lane) {
   return v;
 }
 
+// The root sum of the re-priced costs (exponents in the node table), when it is exact AND does not beat `cur`: out of line,
+// so that its few registers are not the ones that take fw_wave_kernel from four wavefronts per SIMD to three.
+__device__ __attribute__((noinline)) bool fww_rejected_exactly(TNCO_LDS volatile uint32_t* hiv, int ni, int lane, double cur) {
+  double s = 0.0;
+  int emin = 2047;
+  for (int i = lane; i < ni; i += 64) {
+    const int e = (int)((hiv[i] >> 16) & 0x7FFu);
+    emin = min(emin, e);
+    s += __longlong_as_double((long long)((uint64_t)e << 52));
+  }
+  for (int st = 1; st < 64; st <<= 1) {
+    emin = min(emin, __shfl_xor(emin, st));
+    s += __longlong_as_double((long long)fws_shflx64((uint64_t)__double_as_longlong(s), st));
+  }
+  const int es = (__double2hiint(s) >> 20) & 0x7FF;
+  return es - emin <= 51 && !(s < cur);  // (every partial sum is exact and the total does not beat the current one)
+}
+
 // LOGT: lanes per leg mask (4, 5, 6: networks of at most 16, 32, 64 mask words); 64 >> LOGT tensors per load instruction
 // HYPER: indices held by more than two tensors (FwParams::holdern, up to FWH_MAXH each): the marks of the re-pricing below
 template <int J, int LOGT, bool HYPER, bool BIG>
@@ -862,9 +880,21 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
       hiv[i] = (h & 0xF800FFFFu) | ((uint32_t)(ne & 0x7FF) << 16);
     }
   }
+  FWW_T(w6_);
+  // ---- is the proposal worth its partial sums?  The rebuilt cache is kept only if its root sum is below the current one
+  // (greedy/optimizer.hpp:371-374) -- about half of the proposals are not.  The new costs are powers of two >= 2^emin,
+  // so every sum over them is a multiple of 2^emin, and one below 2^(emin + 53) is a double whatever the order it was
+  // added up in: then the plain sum over the wavefront IS the root sum the reference's bottom-up order gives, bit for
+  // bit, and a proposal it rejects needs nothing more.  (A bit to spare in the test; a sum that might be inexact takes
+  // the long way below.)
+#ifndef TNCO_FWW_NO_REJECT  // (A/B builds)
+  if (!__any(bad) && fww_rejected_exactly(hiv, ni, lane, cur)) {
+    if (lane == 0) F.fastflag[r] = 1;  // fw_reslice_b_kernel only closes the sweep: slices and caches stay
+    return;
+  }
+#endif
   // ---- children before parents: every lane starts at its nodes with two leaf children; the second child to
   // arrive at a parent goes on with it (the arrival returns the parent's record)
-  FWW_T(w6_);
   int p = -1;
   uint32_t phi = 0, plo = 0;
   for (int guard = 0;; ++guard) {
