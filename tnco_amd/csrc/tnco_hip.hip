@@ -448,7 +448,7 @@ int fetch_rs(tnco_hip_handle h, std::vector<ReplicaState>& rs) {
 extern "C" {
 
 const char* tnco_hip_last_error(void) { return g_err.c_str(); }
-const char* tnco_hip_version(void) { return "tnco_hip 0.5 (gfx950), round 4"; }
+const char* tnco_hip_version(void) { return "tnco_hip 0.6 (gfx950), round 5"; }
 
 int tnco_hip_device_count(void) {
   int n = 0;
