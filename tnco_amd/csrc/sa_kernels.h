@@ -375,54 +375,81 @@ __device__ __forceinline__ uint64_t group_bcast(uint64_t x, int j, int gbase) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// Where the cost models' tables are read from.  TabsGlobal: the arrays of Params in device memory (constructors,
+// validation, the finite-width kernels).  TabsLds: copies in LDS / registers made once per launch by the sweep kernel
+// -- a table read from memory inside its loop is a load that is consumed at once, and the `s_waitcnt vmcnt(0)` in front
+// of the consumer also waits for every node the iteration has just requested: the general cost models ran 15-40 %
+// below the fast path for that, not for their arithmetic (round 5).
+struct TabsGlobal {
+  const Params& P;
+  lds_cdouble* sdims;  // the odd parts staged in LDS by the caller, or nullptr
+  __device__ __forceinline__ double ctab(int i) const { return P.ctab[i]; }
+  __device__ __forceinline__ double dimsd(int i) const { return sdims ? sdims[i] : P.dimsd[i]; }
+  __device__ __forceinline__ uint64_t oddmask(int w) const { return P.oddmask[w]; }
+  __device__ __forceinline__ uint64_t dimclass(int idx) const { return P.dimclass[idx]; }
+  __device__ __forceinline__ uint64_t sparse(int k, int w) const { return P.sparse[w]; }
+};
+typedef __attribute__((address_space(3))) const uint64_t lds_cu64;
+constexpr int TABS_MAXCLS = 32;  // exponent classes the LDS copy holds: dims up to 2^32 * odd (tnco_hip_create refuses larger ones)
+template <int K>
+struct TabsLds {
+  const Params& P;
+  lds_cdouble* tab;   // ctab (cost modes 1 and 2 with one odd part) or the odd parts (mode 2): never both in one mode
+  lds_cu64* cls;      // [n_dimclass][L K]
+  lds_cu64* odd;      // [L K]
+  Mask<K> sp;         // this lane's words of the sparse mask
+  __device__ __forceinline__ double ctab(int i) const { return tab[i]; }
+  __device__ __forceinline__ double dimsd(int i) const { return tab[i]; }
+  __device__ __forceinline__ uint64_t oddmask(int w) const { return odd[w]; }
+  __device__ __forceinline__ uint64_t dimclass(int idx) const { return cls[idx]; }
+  __device__ __forceinline__ uint64_t sparse(int k, int w) const { return sp.w[k]; }
+};
+
 // simple.hpp:51-53: the running product in cost_type over ascending set bits (Bitset::visit order;
 // word k*L + j is slot k of lane j).  A dimension 2^a * m (m odd) multiplies the running product by m
 // -- rounded -- and by 2^a -- exact: scaling by a power of two commutes with every rounding, and an
 // overflow is reached by the scaled chain exactly when the reference's reaches it (the chain only
 // grows).  So only the ODD parts are multiplied sequentially (dims that are powers of two drop out
 // of the chain) and the powers of two are one masked popcount per exponent class, applied at the end.
-template <int LOG2L, int K>
-__device__ __forceinline__ double seq_product(const Params& P, const Mask<K>& u, int lig, int gbase,
-                                              lds_cdouble* sdims = nullptr) {
+template <int LOG2L, int K, class T>
+__device__ __forceinline__ double seq_product(const Params& P, const T& tb, const Mask<K>& u, int lig, int gbase) {
   constexpr int L = 1 << LOG2L;
   if (P.odd_single) {
     // one odd part m for all of them (dims like {2, 3, 4, 6, 12}): the chain is m * m * ... rounded
     // after every factor, a function of the NUMBER of factors alone -- a table built on the host
     uint32_t et = 0;
 #pragma unroll
-    for (int k = 0; k < K; ++k) et += (uint32_t)__popcll(u.w[k] & P.oddmask[k * L + lig]) << 18;
+    for (int k = 0; k < K; ++k) et += (uint32_t)__popcll(u.w[k] & tb.oddmask(k * L + lig)) << 18;
     for (int j = 0; j < P.n_dimclass; ++j) {
-      const uint64_t* m = P.dimclass + (int64_t)j * (L * K);
       uint32_t cnt = 0;
 #pragma unroll
-      for (int k = 0; k < K; ++k) cnt += (uint32_t)__popcll(u.w[k] & m[k * L + lig]);
+      for (int k = 0; k < K; ++k) cnt += (uint32_t)__popcll(u.w[k] & tb.dimclass(j * (L * K) + k * L + lig));
       et += (uint32_t)(j + 1) * cnt;
     }
     et = gsum<LOG2L>(et);
-    return rnd_cost(ldexp(P.ctab[et >> 18], (int)(et & 0x3ffffu)), P.f32);
+    return rnd_cost(ldexp(tb.ctab((int)(et >> 18)), (int)(et & 0x3ffffu)), P.f32);
   }
   double c = 1.0;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    const uint64_t mine = u.w[k] & P.oddmask[k * L + lig];
+    const uint64_t mine = u.w[k] & tb.oddmask(k * L + lig);
     for (int j = 0; j < L; ++j) {
       const int w = k * L + j;
-      if (P.oddmask[w] == 0ull) continue;  // (uniform: no such dimension in this word)
+      if (tb.oddmask(w) == 0ull) continue;  // (uniform: no such dimension in this word)
       uint64_t x = group_bcast<LOG2L>(mine, j, gbase);
       while (x) {
         const int b = __ffsll((unsigned long long)x) - 1;
         // (one dependent table look-up per leg: from LDS when the caller staged the table there)
-        c = rnd_cost(c * (sdims ? sdims[w * 64 + b] : P.dimsd[w * 64 + b]), P.f32);
+        c = rnd_cost(c * tb.dimsd(w * 64 + b), P.f32);
         x &= x - 1;
       }
     }
   }
   uint32_t e = 0;
   for (int j = 0; j < P.n_dimclass; ++j) {
-    const uint64_t* m = P.dimclass + (int64_t)j * (L * K);
     uint32_t cnt = 0;
 #pragma unroll
-    for (int k = 0; k < K; ++k) cnt += (uint32_t)__popcll(u.w[k] & m[k * L + lig]);
+    for (int k = 0; k < K; ++k) cnt += (uint32_t)__popcll(u.w[k] & tb.dimclass(j * (L * K) + k * L + lig));
     e += (uint32_t)(j + 1) * cnt;
   }
   return rnd_cost(ldexp(c, (int)gsum<LOG2L>(e)), P.f32);
@@ -431,51 +458,54 @@ __device__ __forceinline__ double seq_product(const Params& P, const Mask<K>& u,
 // Per-index dims that are all powers of two: every partial product of simple.hpp:51-53 is an exact
 // power of two (or overflows to inf at the same point whatever the order), so the running product is
 // 2^(sum of exponents): one masked popcount per exponent class instead of a loop over the legs.
-template <int LOG2L, int K>
-__device__ __forceinline__ double pow2_product(const Params& P, const Mask<K>& u, int lig) {
+template <int LOG2L, int K, class T>
+__device__ __forceinline__ double pow2_product(const Params& P, const T& tb, const Mask<K>& u, int lig) {
   constexpr int L = 1 << LOG2L;
   uint32_t e = 0;
   for (int j = 0; j < P.n_dimclass; ++j) {
-    const uint64_t* m = P.dimclass + (int64_t)j * (L * K);
     uint32_t c = 0;
 #pragma unroll
-    for (int k = 0; k < K; ++k) c += (uint32_t)__popcll(u.w[k] & m[k * L + lig]);
+    for (int k = 0; k < K; ++k) c += (uint32_t)__popcll(u.w[k] & tb.dimclass(j * (L * K) + k * L + lig));
     e += (uint32_t)(j + 1) * c;
   }
   return pow2_cost((int)gsum<LOG2L>(e), P.f32);
 }
 
-template <int LOG2L, int K>
-__device__ __forceinline__ double product_cost(const Params& P, const Mask<K>& u, int lig, int gbase,
-                                               lds_cdouble* sdims = nullptr) {
-  return P.cost_mode == 3 ? pow2_product<LOG2L, K>(P, u, lig) : seq_product<LOG2L, K>(P, u, lig, gbase, sdims);
+template <int LOG2L, int K, class T>
+__device__ __forceinline__ double product_cost(const Params& P, const T& tb, const Mask<K>& u, int lig, int gbase) {
+  return P.cost_mode == 3 ? pow2_product<LOG2L, K>(P, tb, u, lig) : seq_product<LOG2L, K>(P, tb, u, lig, gbase);
 }
 
-__device__ __forceinline__ double uniform_cost(const Params& P, int pc) {
-  return P.cost_mode == 0 ? pow2_cost(P.log2d * pc, P.f32) : P.ctab[pc];
+template <class T>
+__device__ __forceinline__ double uniform_cost(const Params& P, const T& tb, int pc) {
+  return P.cost_mode == 0 ? pow2_cost(P.log2d * pc, P.f32) : tb.ctab(pc);
 }
 
 // cost of contracting two tensors whose leg union is `u` (this lane's words).
-template <int LOG2L, int K>
-__device__ __forceinline__ double generic_cost(const Params& P, const Mask<K>& u, int lig, int gbase,
-                                               lds_cdouble* sdims = nullptr) {
+template <int LOG2L, int K, class T>
+__device__ __forceinline__ double generic_cost_t(const Params& P, const T& tb, const Mask<K>& u, int lig, int gbase) {
   if (P.sparse == nullptr) {
-    if (P.cost_mode <= 1) return uniform_cost(P, (int)gsum<LOG2L>(mpopc<K>(u)));
-    return product_cost<LOG2L, K>(P, u, lig, gbase, sdims);
+    if (P.cost_mode <= 1) return uniform_cost(P, tb, (int)gsum<LOG2L>(mpopc<K>(u)));
+    return product_cost<LOG2L, K>(P, tb, u, lig, gbase);
   }
   Mask<K> s;
 #pragma unroll
-  for (int k = 0; k < K; ++k) s.w[k] = P.sparse[k * (1 << LOG2L) + lig];
+  for (int k = 0; k < K; ++k) s.w[k] = tb.sparse(k, k * (1 << LOG2L) + lig);
   double c1, c2;
   if (P.cost_mode <= 1) {
     const uint32_t v = gsum<LOG2L>(mpopc<K>(mandn<K>(u, s)) | (mpopc<K>(mand<K>(u, s)) << 16));
-    c1 = uniform_cost(P, (int)(v & 0xffffu));
-    c2 = uniform_cost(P, (int)(v >> 16));
+    c1 = uniform_cost(P, tb, (int)(v & 0xffffu));
+    c2 = uniform_cost(P, tb, (int)(v >> 16));
   } else {
-    c1 = product_cost<LOG2L, K>(P, mandn<K>(u, s), lig, gbase, sdims);
-    c2 = product_cost<LOG2L, K>(P, mand<K>(u, s), lig, gbase, sdims);
+    c1 = product_cost<LOG2L, K>(P, tb, mandn<K>(u, s), lig, gbase);
+    c2 = product_cost<LOG2L, K>(P, tb, mand<K>(u, s), lig, gbase);
   }
   return rnd_cost(c1 * (c2 < P.n_projs ? c2 : P.n_projs), P.f32);
+}
+template <int LOG2L, int K>
+__device__ __forceinline__ double generic_cost(const Params& P, const Mask<K>& u, int lig, int gbase,
+                                               lds_cdouble* sdims = nullptr) {
+  return generic_cost_t<LOG2L, K>(P, TabsGlobal{P, sdims}, u, lig, gbase);
 }
 
 // ---------------------------------------------------------------------------

@@ -342,15 +342,25 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
   __shared__ uint32_t rngbuf[GPB * R::RING];
   __shared__ ColdState coldbuf[GPB];
   __shared__ int32_t jbuf[GPB * 16];
-  // general per-index dims: the table of the sequential product (one dependent look-up per leg)
-  __shared__ double sdimbuf[GENERIC ? (L * K * 64) : 1];
-  lds_cdouble* sdims = nullptr;
+  // The general cost models read their tables from LDS (sa_kernels.h, TabsLds): the cost table d^k (uniform dims that
+  // are not a power of two; the one-odd-part chain) or the odd parts of per-index dims -- one buffer, a cost mode uses
+  // one of them --, the exponent classes, the odd-part mask; the sparse mask sits in registers.
+  __shared__ double tabbuf[GENERIC ? (L * K * 64 + 1) : 1];
+  __shared__ uint64_t clsbuf[GENERIC ? (TABS_MAXCLS * L * K) : 1];
+  __shared__ uint64_t oddbuf[GENERIC ? (L * K) : 1];
   if constexpr (GENERIC) {
-    if (P.cost_mode == 2) {
-      for (int i = threadIdx.x; i < L * K * 64; i += SWT) sdimbuf[i] = P.dimsd[i];
-      __syncthreads();
-      sdims = (lds_cdouble*)sdimbuf;
+    const bool use_ctab = P.cost_mode == 1 || (P.cost_mode == 2 && P.odd_single);
+    if (use_ctab) {
+      for (int i = threadIdx.x; i < P.W * 64 + 1; i += SWT) tabbuf[i] = P.ctab[i];
+    } else if (P.cost_mode == 2) {
+      for (int i = threadIdx.x; i < L * K * 64; i += SWT) tabbuf[i] = P.dimsd[i];
     }
+    if (P.cost_mode >= 2) {
+      for (int i = threadIdx.x; i < P.n_dimclass * L * K; i += SWT) clsbuf[i] = P.dimclass[i];  // (n_dimclass <= TABS_MAXCLS)
+      if (P.cost_mode == 2)
+        for (int i = threadIdx.x; i < L * K; i += SWT) oddbuf[i] = P.oddmask[i];
+    }
+    __syncthreads();
   }
 
   const int tid = threadIdx.x;
@@ -407,6 +417,13 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
 #pragma unroll
     for (int k = 0; k < K; ++k) sl.w[k] = s0[v.widx(k)];
   }
+  [[maybe_unused]] TabsLds<K> tabs{P, (lds_cdouble*)tabbuf, (lds_cu64*)clsbuf, (lds_cu64*)oddbuf, mzero<K>()};
+  if constexpr (GENERIC) {
+    if (P.sparse != nullptr) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) tabs.sp.w[k] = P.sparse[k * L + lig];
+    }
+  }
   const int f32 = GENERIC ? P.f32 : 0;
   const int log2d = P.log2d;
   const bool disable_shared = P.disable_shared != 0;
@@ -426,6 +443,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
   int rnL = -1, rnR = -1, rnP = -1;  // header of parent(A)
   double rnC = 0;
   M mC = mzero<K>(), hA = mzero<K>();
+  [[maybe_unused]] bool hB_dirty = false;  // hyper[B] in registers differs from memory (it was hyper[A] of an accepted move)
   double pC = 0;
   int step = 0;
   int state = S_BEGIN;
@@ -633,8 +651,8 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
         nA = pow2_cost(log2d * (pick0 ? pcA0 : pcA1), 0);
         nB = pow2_cost(log2d * (pick0 ? pcB0 : pcB1), 0);
       } else {
-        nA = generic_cost<LOG2L, K>(P, mor<K>(mor<K>(newB, mE), sl), lig, gbase, sdims);
-        nB = generic_cost<LOG2L, K>(P, mor<K>(mor<K>(mD, mC), sl), lig, gbase, sdims);
+        nA = generic_cost_t<LOG2L, K>(P, tabs, mor<K>(mor<K>(newB, mE), sl), lig, gbase);
+        nB = generic_cost_t<LOG2L, K>(P, tabs, mor<K>(mor<K>(mD, mC), sl), lig, gbase);
       }
       const double delta = rnd_cost(rnd_cost(nB - ccB, f32) + rnd_cost(nA - ccA, f32), f32);  // :158
       ++n_moves;
@@ -746,7 +764,11 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       if (!(did_move && acc))
         v.set_mask_first(stB, did_move ? msel<K>(b_is_left_of_a, m0, m1) : (HYPER ? mor<K>(mxor<K>(m0, m1), hB) : mxor<K>(m0, m1)));
 #endif
-      if constexpr (HYPER) v.set_hyper(stB, stH);  // may also have changed one level below
+      // (B's hyper legs change when this move was accepted -- or the one a level below, which made them as hyper[A]: a
+      //  node that neither touched keeps what memory holds: one move in ten, two sectors each)
+      if constexpr (HYPER) {
+        if ((did_move && acc) || hB_dirty) v.set_hyper(stB, stH);
+      }
       if (improved && lane0) cold.jmin = jtail;
       if (state < 0) break;
     }
@@ -759,7 +781,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       if (b_is_left_of_a) { p0 = stPart; p1 = x_pCcur; }
       else                { p1 = stPart; p0 = x_pCcur; }
       B = stA; bl = x_al; br = x_ar; ccB = x_ccA; partB = x_partA;
-      if constexpr (HYPER) { hB = hA; hA = gH; }
+      if constexpr (HYPER) { hB = hA; hA = gH; hB_dirty = acc; }
       A = x_aP;
       raL = rnL; raR = rnR; raP = rnP; raC = rnC;
       rnL = gL; rnR = gR; rnP = gP; rnC = gC;
@@ -780,7 +802,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       total = __hiloint2double((int)gXhi, (int)gXlo);
       raL = gL; raR = gR; raP = gP; raC = gC;
       if constexpr (FW) raW = gW;
-      if constexpr (HYPER) { hB = gH; }
+      if constexpr (HYPER) { hB = gH; hB_dirty = false; }
       state = S_GOT_B1;
     } else if (state == S_GOT_B1) {
       m1 = gM; p1 = gMp;

@@ -700,6 +700,8 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
         odd[i] = x;
         max_a = std::max(max_a, av[i]);
       }
+      if (max_a > TABS_MAXCLS)
+        return fail(TNCO_HIP_ENOTIMPL, "an index dimension with a power-of-two part above 2^32 is not supported on the GPU path.");
       std::vector<uint64_t> cls((size_t)std::max(max_a, 1) * L, 0);
       for (int i = 0; i < I; ++i)
         if (av[i] > 0) cls[(size_t)(av[i] - 1) * L + (i >> 6)] |= 1ull << (i & 63);
