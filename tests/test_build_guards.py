@@ -30,13 +30,15 @@ def test_register_budgets_of_the_occupancy_critical_kernels(report):
 
 
 def test_sweep_loops_have_one_landing_fence_and_no_scratch(report):
+    """Also the hyper-index and the general-cost-model instantiations: round 5 found 102 `s_waitcnt vmcnt(0)` in the
+    latter's loop (tables read from device memory inside it) -- 15-40 % of its throughput."""
     _, staged = report
-    assert len(staged) == 2
+    assert len(staged) == 5
     for what, rep in staged.items():
         assert rep["fences"] == 1, (what, rep["vm_waits"], rep["memory_between_waits"])
         assert rep["scratch_in_loop"] == [], (what, rep["scratch_in_loop"])
         # (the loop of the state machine: one load sequence, one store sequence -- a duplicated body would double these)
-        assert 8 <= rep["loads"] <= 20 and 5 <= rep["stores"] <= 14, (what, rep["loads"], rep["stores"])
+        assert rep["loads"] <= 20 and 5 <= rep["stores"] <= 16, (what, rep["loads"], rep["stores"])
 
 
 def test_waves_per_simd_rule():

@@ -30,8 +30,13 @@ BUDGET = {
     "fw_wave_kernelILi9ELi4ELb0ELb0E": ("fw_wave_kernel<9, 4, false, false> (config 5 re-slice)", 128, 4, 0),
     "fw_wave_kernelILi6ELi4ELb1ELb0E": ("fw_wave_kernel<6, 4, true, false> (hyper-index networks up to 384 nodes)", 128, 4, 0),
 }
-# kernels whose main loop must hold one landing fence and no scratch access
+# kernels whose main loop must hold one landing fence and no scratch access (the last two: not in BUDGET, loop check only)
 STAGED = ("sa_run_kernelILi2ELi3ELb0ELb0ELb0E", "sa_run_kernelILi2ELi4ELb0ELb0ELb1E")
+STAGED_ONLY = {
+    "sa_run_kernelILi2ELi3ELb1ELb0ELb0E": "sa_run_kernel<2, 3, true, false, false> (hyper-indices)",
+    "sa_run_kernelILi2ELi3ELb0ELb1ELb0E": "sa_run_kernel<2, 3, false, true, false> (general cost models: tables in LDS)",
+    "sa_run_kernelILi2ELi3ELb1ELb1ELb0E": "sa_run_kernel<2, 3, true, true, false> (hyper-indices + general cost models)",
+}
 
 
 def code_objects(lib: pathlib.Path = LIB) -> list[bytes]:
@@ -106,12 +111,26 @@ def loops(ins):
 
 
 def main_loop_report(ins) -> dict:
-    """The kernel's main loop = the widest backward branch.  Inside it, outside the loops nested in it (the rare paths:
-    the full copy of the best tree, the generator's refill): the `s_waitcnt vmcnt` instructions, whether memory
-    instructions sit between the first and the last of them (more than one landing fence), and scratch accesses."""
+    """The kernel's main loop = the smallest backward branch that spans the staged load sequence and the store phase (at least
+    8 global loads and 5 global stores); the widest one if none does.  Inside it, outside the loops nested in it (the rare
+    paths: the full copy of the best tree; the cost models' leg loops): the `s_waitcnt vmcnt` instructions, whether loads
+    sit between the first and the last of them (more than one landing fence), and scratch accesses."""
     lp = loops(ins)
-    head, tail = max(lp, key=lambda x: x[1] - x[0])
-    nested = [(t, a) for t, a in lp if head < t and a < tail and not (t == head)]
+    is_ld = lambda op: op.startswith(("global_load", "buffer_load"))  # noqa: E731
+    is_st = lambda op: op.startswith(("global_store", "buffer_store"))  # noqa: E731
+
+    def counts(t, a):
+        b = [i for i in ins if t <= i[0] <= a]
+        return sum(1 for i in b if is_ld(i[1])), sum(1 for i in b if is_st(i[1]))
+
+    good = [(a - t, t, a) for t, a in lp if counts(t, a)[0] >= 8 and counts(t, a)[1] >= 5]
+    if good:
+        _, head, tail = min(good)
+        # (several back edges to one head: the loop is the widest of them)
+        tail = max(a for t, a in lp if t == head or (head <= t and a >= tail and t - head < 64))
+    else:
+        head, tail = max(lp, key=lambda x: x[1] - x[0])
+    nested = [(t, a) for t, a in lp if head < t and a < tail]
     inner = lambda x: any(t <= x <= a for t, a in nested if (a - t) < (tail - head) * 0.5)  # noqa: E731
     body = [i for i in ins if head <= i[0] <= tail]
     flat = [i for i in body if not inner(i[0])]
@@ -122,8 +141,7 @@ def main_loop_report(ins) -> dict:
             "fences": 0 if not waits else 1 + sum(1 for i in between if i[1].startswith(("global_load", "buffer_load", "flat_load"))),
             "memory_between_waits": [(hex(a - ins[0][0]), op) for a, op, _ in between],
             "scratch_in_loop": [(hex(a - ins[0][0]), op) for a, op, _ in body if op.startswith("scratch_")],
-            "loads": sum(1 for i in flat if i[1].startswith(("global_load", "buffer_load"))),
-            "stores": sum(1 for i in flat if i[1].startswith(("global_store", "buffer_store")))}
+            "loads": sum(1 for i in flat if is_ld(i[1])), "stores": sum(1 for i in flat if is_st(i[1]))}
 
 
 def report(lib: pathlib.Path = LIB):
@@ -132,7 +150,7 @@ def report(lib: pathlib.Path = LIB):
     found = {}
     for elf in objs:
         for name, meta in kernel_table(elf).items():
-            for frag in BUDGET:
+            for frag in list(BUDGET) + list(STAGED_ONLY):
                 if frag in name:
                     found[frag] = (name, meta, elf)
     for frag, (what, max_v, min_w, max_scr) in BUDGET.items():
@@ -146,6 +164,13 @@ def report(lib: pathlib.Path = LIB):
                          f"(at most {max_scr}), {meta['vgpr_spill_count']} VGPRs spilled, LDS {meta['group_segment_fixed_size']} B"))
         if frag in STAGED:
             staged[what] = main_loop_report(disassemble(elf, name))
+    for frag, what in STAGED_ONLY.items():
+        if frag in found:
+            name, _meta, elf = found[frag]
+            staged[what] = main_loop_report(disassemble(elf, name))
+        else:
+            staged[what] = {"instructions": 0, "vm_waits": [], "fences": 0, "memory_between_waits": [], "scratch_in_loop": ["kernel not found"],
+                            "loads": 0, "stores": 0}
     return rows, staged
 
 
