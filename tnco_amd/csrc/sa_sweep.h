@@ -332,7 +332,11 @@ template <int LOG2L, int K, bool HYPER, bool GENERIC, bool FW = false>
 #ifndef TNCO_GENERIC_WAVES
 #define TNCO_GENERIC_WAVES 2
 #endif
-__global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES : ((HYPER || K >= 4) ? TNCO_HYPER_WAVES : (GENERIC ? TNCO_GENERIC_WAVES : TNCO_WAVES_PER_SIMD))))) void sa_run_kernel(
+// (four words per lane WITHOUT hyper-indices: round 5 -- what is spilled at three wavefronts per SIMD sits outside the loop)
+#ifndef TNCO_K4_WAVES
+#define TNCO_K4_WAVES 2
+#endif
+__global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES : (HYPER ? TNCO_HYPER_WAVES : (GENERIC ? TNCO_GENERIC_WAVES : (K >= 4 ? TNCO_K4_WAVES : TNCO_WAVES_PER_SIMD)))))) void sa_run_kernel(
     const Params P, const double* __restrict__ betas, const int64_t n_steps, const int prob_kind,
     const FwParams F, const int tail_last, const int block0) {
   constexpr int L = 1 << LOG2L;
