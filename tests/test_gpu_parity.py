@@ -149,14 +149,12 @@ def test_hyper_pow2_dims(core, oracle_lib):
 
 
 @pytest.mark.parametrize("n,n_inds,k", [(200, 470, 3), (512, 768, 3), (700, 1330, 4)])
-@pytest.mark.parametrize("two_line", [True, False])
-def test_hyper_networks_with_blocks_longer_than_a_line(core, oracle_lib, monkeypatch, n, n_inds, k, two_line):
-    """Infinite memory + hyper-indices at 8 / 12 / 21 mask words: the two-line layout of round 5 ([header | hyper legs]
-    and [partial copy | legs] in lines of their own; the own legs of the nodes on the path derived, not loaded) and the
-    packed layout it replaces (TNCO_HIP_HYPER_ALIGNED=0), both against the oracle bit for bit -- trees, legs, both
-    caches (hyper legs included), generator -- with output legs, all three rules, and a restart from a snapshot."""
+def test_hyper_networks_with_blocks_longer_than_a_line(core, oracle_lib, n, n_inds, k):
+    """Infinite memory + hyper-indices at 8 / 12 / 21 mask words (round 5: the hyper legs are not stored -- the sweep
+    kernel derives hyper[p] = legs(p) & legs(c0) & legs(c1) from the own legs of B and A and the children's legs it
+    carries -- and the caches the host reads back are derived the same way) against the oracle bit for bit: trees,
+    legs, both caches (hyper legs included), generator -- with output legs, all three rules, validation."""
     from tnco_amd import synthetic as syn
-    monkeypatch.setenv("TNCO_HIP_HYPER_ALIGNED", "1" if two_line else "0")
     ts, dims, out = syn.random_hyper_tn(n, n_inds, k=k, n_output=7, seed=n)
     prob = H.Problem(ts, 2, out)
     seeds = H.replica_seeds(24, S=n)

@@ -74,14 +74,13 @@ struct Params {
   int32_t WOFF;              // byte offset of node n's legs from the replica's base
   int64_t RB;                // bytes per replica
   int32_t hoff;              // byte offset of a node's hyper legs from its legs (networks with hyper-indices; may be negative)
-  // Infinite memory with hyper-indices and node blocks longer than a line ("two-line" layout, tnco_hip_create): a block
-  // is [ header | hyper legs ] -- what a move needs of a node ON the path -- and, in lines of its own, [ partial-cost
-  // copy, pad | legs ] -- what it needs of a SIBLING: 2 lines per move instead of 3-4.  pcoff = byte offset of that copy
-  // of NodeRec::partial from the node's legs (negative), 0 = no copy (every other layout).  The copy is written wherever
-  // NodeRec::partial is: the sweep kernel's store phase and build_kernel; compare_kernel checks it.
-  // (Without hyper-indices the same idea -- headers in one array, [ copy | legs ] records in another -- LOST 5-30 % on
-  //  the networks of 15-48 mask words: the copy is one more dirty line per move, profiles/experiments_r05.md.)
-  int32_t pcoff;
+  // Networks with hyper-indices.  hyper[p] = legs(p) & legs(c0) & legs(c1) (infinite_memory/utils.hpp:82-91) is a function
+  // of legs the sweep kernel holds anyway, so the infinite-memory layout does NOT store it (round 5: the blocks are
+  // those of a network without hyper-indices, one line per node at <= 12 mask words; rounds 1-4 kept W more words
+  // per node and read / wrote them with every move).  hyper_stored = 1: finite width, the hyper legs hoff bytes behind
+  // the legs, kept up to date by every finite-width kernel.  build_kernel needs a second mask per node while it derives
+  // the legs: BuildArgs::hyper_tmp when they are not stored.
+  int32_t hyper_stored;
   int32_t jcap;              // rotation-log entries per replica
   int64_t R;
   uint8_t* blocks;           // [R][RB]
@@ -169,11 +168,12 @@ struct View {
   uint8_t* blk;
   int32_t* lpar;
   const uint64_t* leafmask;
-  int n, BS, W, lig, hoff, WS, WOFF, pcoff;
+  uint64_t* hyp;  // hyper legs of internal node p at hyp + (p - n) * W when they are not part of the blocks (build_kernel), else nullptr
+  int n, BS, W, lig, hoff, WS, WOFF;
 
-  __device__ __forceinline__ void init(const Params& P, uint8_t* blk_, int32_t* lpar_, int lig_) {
+  __device__ __forceinline__ void init(const Params& P, uint8_t* blk_, int32_t* lpar_, int lig_, uint64_t* hyp_ = nullptr) {
     blk = blk_; lpar = lpar_; leafmask = P.leafmask; n = P.n; BS = P.BS; W = P.W; lig = lig_; hoff = P.hoff;
-    WS = P.WS; WOFF = P.WOFF; pcoff = P.pcoff;
+    WS = P.WS; WOFF = P.WOFF; hyp = hyp_;
   }
   __device__ __forceinline__ NodeRec* hdr(int p) const {
     return reinterpret_cast<NodeRec*>(blk + (int64_t)(p - n) * BS);
@@ -182,19 +182,13 @@ struct View {
   // L consecutive words (one contiguous 8L-byte piece of the line) per instruction
   __device__ __forceinline__ int widx(int k) const { return k * L + lig; }
   __device__ __forceinline__ uint64_t* words(int p) const {
-    if constexpr (UNI) return reinterpret_cast<uint64_t*>(blk + (int64_t)(p - n) * BS + (HYPER ? WOFF : 32));
+    if constexpr (UNI) return reinterpret_cast<uint64_t*>(blk + (int64_t)(p - n) * BS + 32);
     return reinterpret_cast<uint64_t*>(blk + WOFF + (int64_t)(p - n) * WS);
   }
-  // the copy of node p's partial cost that sits with its legs (two-line layout only: pcoff != 0)
-  __device__ __forceinline__ double* pcopy(int p) const {
-    return reinterpret_cast<double*>(reinterpret_cast<uint8_t*>(words(p)) + pcoff);
-  }
-  // where a SIBLING's partial cost is read from: next to its legs if the layout keeps a copy there
-  __device__ __forceinline__ const double* partial_of_sibling(int p) const {
-    return (HYPER && pcoff != 0) ? pcopy(p) : &hdr(p)->partial;
-  }
-  // (networks with hyper-indices: the hyper legs follow the node's legs, hoff bytes behind them, in both layouts)
+  // (networks with hyper-indices: the hyper legs follow the node's legs, hoff bytes behind them -- or, where the layout
+  //  does not store them, live in the caller's temporary array)
   __device__ __forceinline__ uint64_t* hwords(int p) const {
+    if (hyp != nullptr) return hyp + (int64_t)(p - n) * W;
     return reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(words(p)) + hoff);
   }
   // Legs of node x (this lane's words).  The ADDRESS is selected (leaf table / node block), not the
@@ -251,6 +245,7 @@ struct View {
   }
   __device__ __forceinline__ void set_hyper(int p, const Mask<K>& v) const {
     if constexpr (HYPER) {
+      if (hyp == nullptr && hoff == 0) return;  // (a layout without hyper legs, and no temporary array: nothing to keep)
       uint64_t* s = hwords(p);
 #pragma unroll
       for (int k = 0; k < K; ++k)
@@ -553,6 +548,8 @@ struct BuildArgs {
   // finite width: legs OR-ed into every contraction (sliced indices; finite_width/utils.hpp:36-47),
   // [LK] words per replica at cost_slices + r * cost_slices_stride; NULL: none
   const uint64_t* cost_slices; int64_t cost_slices_stride;
+  // networks with hyper-indices whose layout does not store the hyper legs (Params::hyper_stored == 0): [count][n - 1][W]
+  uint64_t* hyper_tmp;
 };
 
 template <int LOG2L, int K, bool HYPER>
@@ -570,7 +567,8 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
   const int n = P.n, N = P.N;
 
   View<LOG2L, K, HYPER> v;
-  v.init(P, a.out_blocks + q * P.RB, a.out_lpar + q * (int64_t)n * LPS, lig);
+  v.init(P, a.out_blocks + q * P.RB, a.out_lpar + q * (int64_t)n * LPS, lig,
+         (HYPER && a.hyper_tmp) ? a.hyper_tmp + q * (int64_t)(n - 1) * P.W : nullptr);
   View<LOG2L, K, HYPER> live;
   live.init(P, P.blocks + r * P.RB, P.lpar + r * (int64_t)n * LPS, lig);
   int32_t* stack = a.scratch + q * 4 * (int64_t)N;
@@ -617,10 +615,7 @@ __global__ __launch_bounds__(256) void build_kernel(const Params P, const BuildA
     const double c = generic_cost<LOG2L, K>(P, mor<K>(uni, csl), lig, gbase);
     const double part = rnd_cost(rnd_cost(c + v.partial(l), P.f32) + v.partial(rr), P.f32);  // utils.hpp:54
     sum = rnd_cost(sum + c, P.f32);                                                          // utils.hpp:112
-    if (lane0) {
-      v.hdr(p)->ccost = c; v.hdr(p)->partial = part;
-      if (v.pcoff != 0) *v.pcopy(p) = part;
-    }
+    if (lane0) { v.hdr(p)->ccost = c; v.hdr(p)->partial = part; }
   };
   // Without hyper-indices and with legs derived from the links, a node's legs, checks and costs need nothing but its
   // children's: everything is done when the traverse LEAVES the node -- one pass of dependent round trips over the
@@ -759,12 +754,11 @@ __global__ __launch_bounds__(256) void compare_kernel(const Params P, const Buil
       if (!logclose(x.partial, y.partial)) bad = bad ? bad : 32;
       if (x.left != y.left || x.right != y.right) bad = bad ? bad : 2;
       if (cur.parent(y.left) != i || cur.parent(y.right) != i) bad = bad ? bad : 8;
-      if (cur.pcoff != 0 && __double_as_longlong(*cur.pcopy(i)) != __double_as_longlong(y.partial)) bad = bad ? bad : 35;
     }
   }
   for (int p = n; p < N; ++p) {
     if (mdiffer<K>(ref.mask(p), cur.mask(p))) bad = bad ? bad : 34;
-    if (mdiffer<K>(ref.hyper(p), cur.hyper(p))) bad = bad ? bad : 33;
+    if (HYPER && P.hyper_stored && mdiffer<K>(ref.hyper(p), cur.hyper(p))) bad = bad ? bad : 33;
   }
   const uint32_t anybad = gsum<LOG2L>((uint32_t)(bad != 0));
   if (lig == 0) out_bad[q] = anybad ? (bad ? bad : 99) : 0;

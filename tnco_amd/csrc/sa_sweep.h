@@ -378,7 +378,14 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
   const bool lane0 = (lig == 0);
 
   const int n = P.n, N = P.N;
-  View<LOG2L, K, HYPER, !FW> v;  // (finite width: the split layout unless the network has hyper-indices)
+  View<LOG2L, K, HYPER, !FW> v;  // (finite width: the split layout)
+  // Hyper-indices.  The reference keeps hyper[p] = legs(p) & legs(c0) & legs(c1) per node (infinite_memory/utils.hpp:82-91)
+  // and updates it with that very formula (optimizer.hpp:171-172), so it never has to be STORED: the own legs of B and A
+  // sit in the line their headers come from, the children's legs are carried anyway.
+  //   HYD (infinite memory, round 5): own legs of B / A carried (hB / hA hold them), hyper legs derived; the node
+  //       blocks are those of a network without hyper-indices -- one line per node at <= 12 mask words;
+  //   HYS (finite width): the hyper legs stored behind the legs, as the other finite-width kernels keep them.
+  constexpr bool HYD = HYPER && !FW, HYS = HYPER && FW;
   v.init(P, P.blocks + r * P.RB, nullptr, lig);
   auto lpar = [&]() -> int32_t* { return P.lpar + r * (int64_t)n * LPS; };
   lds_cold& cold = *((lds_cold*)coldbuf + gib);
@@ -437,8 +444,8 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
   int B = 0, bl = 0, br = 0, A = -1;
   [[maybe_unused]] int wB = 0, raW = 0, rnW = 0;  // finite width: the spare header word (cached width) of B, A, parent(A)
   double ccB = 0, partB = 0, total = 0, beta = 0;
-  // (hyper-indices: the own legs of B and A are never loaded -- legs(p) = (legs(c0) ^ legs(c1)) | hyper(p) for every
-  //  valid contraction, ctree.hpp:139-146 with hyper(p) = legs(p) & legs(c0) & legs(c1), infinite_memory/utils.hpp:82-91)
+  // (hyper-indices: hB / hA = the OWN legs of B / A when they are derived (HYD), their hyper legs when stored (HYS: the
+  //  own legs are then (legs(c0) ^ legs(c1)) | hyper(p), ctree.hpp:139-146))
   M m0 = mzero<K>(), m1 = mzero<K>(), hB = mzero<K>();
   double p0 = 0, p1 = 0;
   // ---- operands of the coming moves (landed in earlier iterations) -----------
@@ -574,16 +581,16 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
     double gMp = 0;
     if (x1 >= 0) {
       gM = v.mask_staged(x1);
-      if (x1 >= n) gMp = *v.partial_of_sibling(x1);
+      if (x1 >= n) gMp = v.hdr(x1)->partial;
     }
     uint32_t gXlo = 0, gXhi = 0;
     if (xa != nullptr) {
       gXlo = xa[0];
       gXhi = xa[1];
     }
-    M gH = mzero<K>();
+    M gH = mzero<K>();  // own legs (HYD) / hyper legs (HYS) of node yN
     if constexpr (HYPER) {
-      if (yN >= 0) gH = v.hyper(yN);
+      if (yN >= 0) gH = HYD ? v.mask_staged(yN) : v.hyper(yN);
     }
     if (rng.room()) rng.request();
     TNCO_PROF_F(3);
@@ -597,7 +604,8 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       const int C = c_is_right ? ar : al;
 
       // ---- one move evaluation (optimizer.hpp:117-192) -----------------------
-      const M hy = HYPER ? mor<K>(hA, hB) : mzero<K>();
+      // hyper[A] | hyper[B] (optimizer.hpp:145-147); derived: hyper[B] = B & c0 & c1, hyper[A] = A & B & C
+      const M hy = HYD ? mand<K>(hB, mor<K>(mand<K>(hA, mC), mand<K>(m0, m1))) : (HYS ? mor<K>(hA, hB) : mzero<K>());
       // both candidate (D, E) assignments evaluated at once:
       //   cand0: D = child0, E = child1;  cand1: D = child1, E = child0
       // new legs of B: (D ^ C) | hyper_A | hyper_B   (optimizer.hpp:147)
@@ -680,12 +688,13 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
         // Tree::swap_with_nn(E): include/tnco/tree.hpp:176-184
         if (pick0) br = C; else bl = C;
         if (c_is_right) ar = E; else al = E;
-        if constexpr (HYPER) {
+        if constexpr (HYS) {
           // :171 with legs(A) = (legs(B) ^ legs(C)) | hyper(A) before the move, legs(B) = (child ^ child) | hyper(B)
           const M iA = mor<K>(mxor<K>(mor<K>(mxor<K>(m0, m1), hB), mC), hA);
           hA = mand<K>(mand<K>(iA, newB), mE);
           hB = mand<K>(mand<K>(newB, mD), mC);  // :172
         }
+        if constexpr (HYD) hB = newB;  // (B's own legs; A's stay)
         ccB = nB;
         ccA = nA;
         total = rnd_cost(total + delta, f32);  // :177
@@ -694,7 +703,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
         mBnow = newB;
         mX = mE;
       } else {
-        mBnow = HYPER ? mor<K>(mxor<K>(m0, m1), hB) : mxor<K>(m0, m1);
+        mBnow = HYD ? hB : (HYS ? mor<K>(mxor<K>(m0, m1), hB) : mxor<K>(m0, m1));
         mX = mC;
       }
       // :185-188
@@ -753,9 +762,6 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
         NodeRec o;
         o.left = stL; o.right = stR; o.parent = stA; o.pad = FW ? stW : 0; o.ccost = stCC; o.partial = stPart;
         *v.hdr(stB) = o;
-        if constexpr (HYPER && !FW) {  // (two-line layout: the copy a later move reads when this node is the sibling)
-          if (v.pcoff != 0) *v.pcopy(stB) = stPart;
-        }
         if constexpr (FW) {
           if (did_move && acc && !F.width_f32) F.width64[(int64_t)rng.r32 * N + stB] = stW64;
         }
@@ -766,11 +772,11 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       // hold it, so the short write never reaches HBM on its own; the extra store only costs issue.
 #ifdef TNCO_FIRST64
       if (!(did_move && acc))
-        v.set_mask_first(stB, did_move ? msel<K>(b_is_left_of_a, m0, m1) : (HYPER ? mor<K>(mxor<K>(m0, m1), hB) : mxor<K>(m0, m1)));
+        v.set_mask_first(stB, did_move ? msel<K>(b_is_left_of_a, m0, m1) : (HYD ? hB : (HYS ? mor<K>(mxor<K>(m0, m1), hB) : mxor<K>(m0, m1))));
 #endif
       // (B's hyper legs change when this move was accepted -- or the one a level below, which made them as hyper[A]: a
       //  node that neither touched keeps what memory holds: one move in ten, two sectors each)
-      if constexpr (HYPER) {
+      if constexpr (HYS) {
         if ((did_move && acc) || hB_dirty) v.set_hyper(stB, stH);
       }
       if (improved && lane0) cold.jmin = jtail;

@@ -587,30 +587,16 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   P.n = n; P.N = N; P.I = I; P.W = W; P.R = R;
   P.BS = (32 + 8 * W + 31) / 32 * 32;
   P.hoff = 0;
-  P.pcoff = 0;
-  int woff = 32;
-  if (h->hyper) {  // the hyper legs follow the legs
-    P.hoff = 8 * W;
-    P.BS = (32 + 16 * W + 31) / 32 * 32;
-    const char* e = std::getenv("TNCO_HIP_HYPER_ALIGNED");
-    if (!fw && P.BS > 128 && !(e && std::atoi(e) == 0)) {
-      // Two-line layout (round 5; sa_kernels.h, Params::pcoff).  A move needs of the node ON the path its header and
-      // hyper legs (its own legs are (child ^ child) | hyper legs, infinite_memory/utils.hpp:82-91 + ctree.hpp:139-146),
-      // of the SIBLING its legs and partial cost: [ header | hyper legs ] and [ partial copy, pad | legs ], each part
-      // in whole 128-byte lines, make that 2 lines per move where the packed 224-byte block of 12 mask words cost 3-4
-      // (round 4 tried the alignment alone -- header + legs | hyper legs -- and gained nothing: still 3 lines).
-      // TNCO_HIP_HYPER_ALIGNED=0: the packed layout (A/B runs, tests).
-      const int path_b = (32 + 8 * W + 127) / 128 * 128, sib_b = (16 + 8 * W + 127) / 128 * 128;
-      P.BS = path_b + sib_b;
-      woff = path_b + 16;
-      P.hoff = 32 - woff;
-      P.pcoff = -16;
-    }
+  P.hyper_stored = 0;
+  if (h->hyper && fw) {  // finite width keeps the hyper legs, behind the legs (the split layout below sets the offsets)
+    P.hyper_stored = 1;
   }
+  // (infinite memory with hyper-indices, round 5: hyper[p] = legs(p) & legs(c0) & legs(c1) is derived by the sweep
+  //  kernel from legs it holds anyway, so the blocks are those of a network without hyper-indices)
   // Blocks longer than a line are PACKED (a 224-byte block at 24 mask words straddles two or three 128-byte lines
   // depending on where it starts): padding them to whole lines costs as many lines as it saves (round 3), and splitting
   // them into headers + [partial copy | legs] records loses 5-30 % to the second dirty line per move (round 5).
-  P.WS = P.BS; P.WOFF = woff; P.RB = (int64_t)(n - 1) * P.BS;
+  P.WS = P.BS; P.WOFF = 32; P.RB = (int64_t)(n - 1) * P.BS;
   if (fw) {  // split layout (sa_kernels.h, Params)
     P.BS = 32;
     P.hoff = h->hyper ? 8 * W : 0;
@@ -823,6 +809,11 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     a.scratch = reinterpret_cast<int32_t*>(P.minlinks);  // 16 B * N per replica = 4N int32
     a.out_total = dtotal; a.out_sum = dsum; a.out_status = dstatus;
     a.r0 = 0; a.count = R;
+    if (h->hyper && !P.hyper_stored && !d->node_masks) {  // (the second mask per node build_kernel derives the legs with)
+      uint64_t* dhy = nullptr;
+      HIP_TRY(tmp.alloc(&dhy, R * (int64_t)(n - 1) * W));
+      a.hyper_tmp = dhy;
+    }
     launch_build(h, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(h->sync_all());
@@ -1043,11 +1034,14 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     HIP_TRY(tmp.alloc(&tbad, chunk));
     HIP_TRY(tmp.alloc(&ttot, chunk));
     HIP_TRY(tmp.alloc(&tsum, chunk));
+    uint64_t* thy = nullptr;
+    if (h->hyper && !P.hyper_stored) HIP_TRY(tmp.alloc(&thy, chunk * (int64_t)(n - 1) * W));
     std::vector<int32_t> hs((size_t)chunk), hb((size_t)chunk);
     std::vector<double> hsum((size_t)chunk);
     for (int64_t r0 = 0; r0 < R; r0 += chunk) {
       const int64_t cnt = std::min(chunk, R - r0);
       BuildArgs a{};
+      a.hyper_tmp = thy;
       a.out_blocks = tblk; a.out_lpar = tlpar; a.scratch = tscr;
       a.out_total = ttot; a.out_sum = tsum; a.out_status = tstat; a.r0 = r0; a.count = cnt;
       a.src_live = 0;
@@ -1462,8 +1456,18 @@ int tnco_hip_get_caches(tnco_hip_handle h, int64_t r, double* ccost, double* par
     if (i >= n) std::memcpy(&hd, blk.data() + (size_t)(i - n) * BS, sizeof(hd));
     if (ccost) ccost[i] = i < n ? 0.0 : hd.ccost;
     if (partial) partial[i] = i < n ? 0.0 : hd.partial;
-    if (hyper && h->hyper && i >= n)
-      std::memcpy(hyper + (size_t)i * W, blk.data() + ((int64_t)h->P.WOFF + (int64_t)(i - n) * h->P.WS + h->P.hoff), (size_t)W * 8);
+    if (hyper && h->hyper && i >= n) {
+      if (h->P.hyper_stored) {
+        std::memcpy(hyper + (size_t)i * W, blk.data() + ((int64_t)h->P.WOFF + (int64_t)(i - n) * h->P.WS + h->P.hoff), (size_t)W * 8);
+      } else {  // HyperCache (infinite_memory/utils.hpp:82-91): legs(p) & legs(c0) & legs(c1), from the stored legs
+        auto legs = [&](int x) -> const uint64_t* {
+          return x < n ? h->leafmask_w.data() + (size_t)x * W
+                       : reinterpret_cast<const uint64_t*>(blk.data() + ((int64_t)h->P.WOFF + (int64_t)(x - n) * h->P.WS));
+        };
+        const uint64_t *lp = legs(i), *l0 = legs(hd.left), *l1 = legs(hd.right);
+        for (int w = 0; w < W; ++w) hyper[(size_t)i * W + w] = lp[w] & l0[w] & l1[w];
+      }
+    }
   }
   return TNCO_HIP_OK;
 }
@@ -1490,6 +1494,8 @@ int tnco_hip_validate(tnco_hip_handle h, double atol, int64_t* n_bad, int64_t* f
   HIP_TRY(tmp.alloc(&tbad, chunk));
   HIP_TRY(tmp.alloc(&ttot, chunk));
   HIP_TRY(tmp.alloc(&tsum, chunk));
+  uint64_t* thy = nullptr;
+  if (h->hyper && !P.hyper_stored) HIP_TRY(tmp.alloc(&thy, chunk * (int64_t)(n - 1) * h->P.W));
   int64_t bad = 0, first = -1;
   std::vector<ReplicaState> rs;
   if (int rc = fetch_rs(h, rs)) return rc;
@@ -1498,6 +1504,7 @@ int tnco_hip_validate(tnco_hip_handle h, double atol, int64_t* n_bad, int64_t* f
   for (int64_t r0 = 0; r0 < R; r0 += chunk) {
     const int64_t cnt = std::min(chunk, R - r0);
     BuildArgs a{};
+    a.hyper_tmp = thy;
     a.out_blocks = tblk; a.out_lpar = tlpar; a.scratch = tscr;
     a.out_total = ttot; a.out_sum = tsum; a.out_status = tstat; a.r0 = r0; a.count = cnt;
     // (1) current tree: rebuild everything and compare
