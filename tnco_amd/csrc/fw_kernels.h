@@ -1274,10 +1274,12 @@ __global__ __launch_bounds__(256, MAXNEW ? TNCO_FW_MAXNEW_WAVES : TNCO_FW_MOVE_W
       const NodeRec ha = *v.hdr(A);
       const M m0 = v.mask(hb.left), m1 = v.mask(hb.right);
       const double p0 = v.partial(hb.left), p1 = v.partial(hb.right);
-      const M iA = v.mask(A), hA = v.hyper(A), hB = v.hyper(B);
       const bool c_is_right = (ha.left == B);
       int C = c_is_right ? ha.right : ha.left;
       const M mC = v.mask(C);
+      // hyper[p] = legs(p) & legs(c0) & legs(c1) (infinite_memory/utils.hpp:82-91): derived, not stored (sa_kernels.h, Params)
+      const M iA = v.mask(A), iB = HYPER ? v.mask(B) : mzero<K>();
+      const M hB = HYPER ? mand<K>(iB, mand<K>(m0, m1)) : mzero<K>(), hA = HYPER ? mand<K>(iA, mand<K>(iB, mC)) : mzero<K>();
       const double pC = v.partial(C);
       const uint32_t w = gsum<LOG2L>((mnonzero<K>(mand<K>(m0, mC)) ? 1u : 0u) |
                                      ((mnonzero<K>(mand<K>(m1, mC)) ? 1u : 0u) << 8));
@@ -1318,8 +1320,6 @@ __global__ __launch_bounds__(256, MAXNEW ? TNCO_FW_MAXNEW_WAVES : TNCO_FW_MOVE_W
             v.set_parent(E, A);
           }
           v.set_mask(B, newB);
-          v.set_hyper(A, mand<K>(mand<K>(iA, newB), mE));
-          v.set_hyper(B, mand<K>(mand<K>(newB, mD), mC));
           ccB = nB;
           ccA = nA;
           total = rnd_cost(total + delta, f32);
@@ -1366,8 +1366,6 @@ __global__ __launch_bounds__(256, MAXNEW ? TNCO_FW_MAXNEW_WAVES : TNCO_FW_MOVE_W
           if (accept_move(prob_kind, beta, delta, total, u, f32)) {
             // :296-312
             fw_commit<LOG2L, K, HYPER>(P, v, sc.rec, sc.cp);
-            v.set_hyper(A, mand<K>(mand<K>(iA, newB), mE));
-            v.set_hyper(B, mand<K>(mand<K>(newB, mD), mC));
             fw_set_node_width<LOG2L, K, HYPER>(F, v, w64, B, new_width_B, lane0);
             total = tot;
             slices = new_slices;

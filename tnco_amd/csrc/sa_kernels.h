@@ -11,8 +11,8 @@
 // small groups (L = 4) keep that redundancy low and put 16 replicas in one wavefront.
 //
 // HBM layout, replica-major (everything of one replica is contiguous):
-//   node block of internal node p (BS bytes, BS = 32 + 8*W [*2 with hyper legs, P.hoff bytes behind the legs], rounded to 32):
-//       [ left right parent pad | ccost | partial | legs: W words | hyper legs: W words ]
+//   node block of internal node p (BS bytes, BS = 32 + 8*W rounded to 32; with or without hyper-indices):
+//       [ left right parent pad | ccost | partial | legs: W words ]
 //     so one move touches ONE line per node it reads or writes (512-leaf TN: W = 12, BS = 128 B
 //     = exactly one 128-B line).  HBM here is bound by the number of random line activations,
 //     not by bytes.
@@ -73,14 +73,10 @@ struct Params {
   int32_t WS;                // bytes between the legs of consecutive nodes
   int32_t WOFF;              // byte offset of node n's legs from the replica's base
   int64_t RB;                // bytes per replica
-  int32_t hoff;              // byte offset of a node's hyper legs from its legs (networks with hyper-indices; may be negative)
   // Networks with hyper-indices.  hyper[p] = legs(p) & legs(c0) & legs(c1) (infinite_memory/utils.hpp:82-91) is a function
-  // of legs the sweep kernel holds anyway, so the infinite-memory layout does NOT store it (round 5: the blocks are
-  // those of a network without hyper-indices, one line per node at <= 12 mask words; rounds 1-4 kept W more words
-  // per node and read / wrote them with every move).  hyper_stored = 1: finite width, the hyper legs hoff bytes behind
-  // the legs, kept up to date by every finite-width kernel.  build_kernel needs a second mask per node while it derives
-  // the legs: BuildArgs::hyper_tmp when they are not stored.
-  int32_t hyper_stored;
+  // of legs the kernels hold anyway, so NO layout stores it (round 5: the blocks are those of a network without
+  // hyper-indices; rounds 1-4 kept W more words per node and read / wrote them with every move).  build_kernel needs a
+  // second mask per node while it derives the legs of a tree: BuildArgs::hyper_tmp (View::hyp).
   int32_t jcap;              // rotation-log entries per replica
   int64_t R;
   uint8_t* blocks;           // [R][RB]
@@ -169,10 +165,10 @@ struct View {
   int32_t* lpar;
   const uint64_t* leafmask;
   uint64_t* hyp;  // hyper legs of internal node p at hyp + (p - n) * W when they are not part of the blocks (build_kernel), else nullptr
-  int n, BS, W, lig, hoff, WS, WOFF;
+  int n, BS, W, lig, WS, WOFF;
 
   __device__ __forceinline__ void init(const Params& P, uint8_t* blk_, int32_t* lpar_, int lig_, uint64_t* hyp_ = nullptr) {
-    blk = blk_; lpar = lpar_; leafmask = P.leafmask; n = P.n; BS = P.BS; W = P.W; lig = lig_; hoff = P.hoff;
+    blk = blk_; lpar = lpar_; leafmask = P.leafmask; n = P.n; BS = P.BS; W = P.W; lig = lig_;
     WS = P.WS; WOFF = P.WOFF; hyp = hyp_;
   }
   __device__ __forceinline__ NodeRec* hdr(int p) const {
@@ -185,12 +181,8 @@ struct View {
     if constexpr (UNI) return reinterpret_cast<uint64_t*>(blk + (int64_t)(p - n) * BS + 32);
     return reinterpret_cast<uint64_t*>(blk + WOFF + (int64_t)(p - n) * WS);
   }
-  // (networks with hyper-indices: the hyper legs follow the node's legs, hoff bytes behind them -- or, where the layout
-  //  does not store them, live in the caller's temporary array)
-  __device__ __forceinline__ uint64_t* hwords(int p) const {
-    if (hyp != nullptr) return hyp + (int64_t)(p - n) * W;
-    return reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(words(p)) + hoff);
-  }
+  // (networks with hyper-indices: a second mask per node in the caller's temporary array -- build_kernel)
+  __device__ __forceinline__ uint64_t* hwords(int p) const { return hyp + (int64_t)(p - n) * W; }
   // Legs of node x (this lane's words).  The ADDRESS is selected (leaf table / node block), not the
   // value: one load per word, one definition -- two loads in the arms of a branch merge where the
   // arms meet, and the merge waits ("a loaded value has ONE definition"); several masks
@@ -245,7 +237,7 @@ struct View {
   }
   __device__ __forceinline__ void set_hyper(int p, const Mask<K>& v) const {
     if constexpr (HYPER) {
-      if (hyp == nullptr && hoff == 0) return;  // (a layout without hyper legs, and no temporary array: nothing to keep)
+      if (hyp == nullptr) return;  // (no temporary array: nothing to keep)
       uint64_t* s = hwords(p);
 #pragma unroll
       for (int k = 0; k < K; ++k)
@@ -548,7 +540,7 @@ struct BuildArgs {
   // finite width: legs OR-ed into every contraction (sliced indices; finite_width/utils.hpp:36-47),
   // [LK] words per replica at cost_slices + r * cost_slices_stride; NULL: none
   const uint64_t* cost_slices; int64_t cost_slices_stride;
-  // networks with hyper-indices whose layout does not store the hyper legs (Params::hyper_stored == 0): [count][n - 1][W]
+  // networks with hyper-indices: the second mask per node build_kernel works with (no layout stores hyper legs): [count][n - 1][W]
   uint64_t* hyper_tmp;
 };
 
@@ -758,7 +750,6 @@ __global__ __launch_bounds__(256) void compare_kernel(const Params P, const Buil
   }
   for (int p = n; p < N; ++p) {
     if (mdiffer<K>(ref.mask(p), cur.mask(p))) bad = bad ? bad : 34;
-    if (HYPER && P.hyper_stored && mdiffer<K>(ref.hyper(p), cur.hyper(p))) bad = bad ? bad : 33;
   }
   const uint32_t anybad = gsum<LOG2L>((uint32_t)(bad != 0));
   if (lig == 0) out_bad[q] = anybad ? (bad ? bad : 99) : 0;

@@ -382,10 +382,10 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
   // Hyper-indices.  The reference keeps hyper[p] = legs(p) & legs(c0) & legs(c1) per node (infinite_memory/utils.hpp:82-91)
   // and updates it with that very formula (optimizer.hpp:171-172), so it never has to be STORED: the own legs of B and A
   // sit in the line their headers come from, the children's legs are carried anyway.
-  //   HYD (infinite memory, round 5): own legs of B / A carried (hB / hA hold them), hyper legs derived; the node
-  //       blocks are those of a network without hyper-indices -- one line per node at <= 12 mask words;
-  //   HYS (finite width): the hyper legs stored behind the legs, as the other finite-width kernels keep them.
-  constexpr bool HYD = HYPER && !FW, HYS = HYPER && FW;
+  // The own legs of B / A are carried (hB / hA hold them), hyper legs derived; the node blocks are those of a network
+  // without hyper-indices -- one line per node at <= 12 mask words (round 5; rounds 1-4 stored W more words per node
+  // and read + wrote them with every move).
+  constexpr bool HYD = HYPER;
   v.init(P, P.blocks + r * P.RB, nullptr, lig);
   auto lpar = [&]() -> int32_t* { return P.lpar + r * (int64_t)n * LPS; };
   lds_cold& cold = *((lds_cold*)coldbuf + gib);
@@ -444,8 +444,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
   int B = 0, bl = 0, br = 0, A = -1;
   [[maybe_unused]] int wB = 0, raW = 0, rnW = 0;  // finite width: the spare header word (cached width) of B, A, parent(A)
   double ccB = 0, partB = 0, total = 0, beta = 0;
-  // (hyper-indices: hB / hA = the OWN legs of B / A when they are derived (HYD), their hyper legs when stored (HYS: the
-  //  own legs are then (legs(c0) ^ legs(c1)) | hyper(p), ctree.hpp:139-146))
+  // (hyper-indices: hB / hA = the OWN legs of B / A)
   M m0 = mzero<K>(), m1 = mzero<K>(), hB = mzero<K>();
   double p0 = 0, p1 = 0;
   // ---- operands of the coming moves (landed in earlier iterations) -----------
@@ -454,7 +453,6 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
   int rnL = -1, rnR = -1, rnP = -1;  // header of parent(A)
   double rnC = 0;
   M mC = mzero<K>(), hA = mzero<K>();
-  [[maybe_unused]] bool hB_dirty = false;  // hyper[B] in registers differs from memory (it was hyper[A] of an accepted move)
   double pC = 0;
   int step = 0;
   int state = S_BEGIN;
@@ -475,7 +473,6 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
     [[maybe_unused]] int stW = 0;
     [[maybe_unused]] double stW64 = 0;
     double stCC = 0, stPart = 0;
-    M stH = mzero<K>();
     int x_al = 0, x_ar = 0, x_aP = -1;
     double x_ccA = 0, x_partA = 0, x_pCcur = 0;
 
@@ -484,7 +481,6 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       did_end = true;
       stB = B; stA = -1; stL = bl; stR = br; stCC = ccB; stPart = partB;
       if constexpr (FW) stW = wB;
-      if constexpr (HYPER) stH = hB;
       // (finite width, a launch that ends in a re-slicing sweep: fw_reslice_kernel closes that sweep)
       const bool close_sweep = !FW || tail_last != 0 || step != nsteps32 - 1;
       if (close_sweep && partB < cold.min_cost) {
@@ -588,9 +584,9 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       gXlo = xa[0];
       gXhi = xa[1];
     }
-    M gH = mzero<K>();  // own legs (HYD) / hyper legs (HYS) of node yN
+    M gH = mzero<K>();  // own legs of node yN
     if constexpr (HYPER) {
-      if (yN >= 0) gH = HYD ? v.mask_staged(yN) : v.hyper(yN);
+      if (yN >= 0) gH = v.mask_staged(yN);
     }
     if (rng.room()) rng.request();
     TNCO_PROF_F(3);
@@ -605,7 +601,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
 
       // ---- one move evaluation (optimizer.hpp:117-192) -----------------------
       // hyper[A] | hyper[B] (optimizer.hpp:145-147); derived: hyper[B] = B & c0 & c1, hyper[A] = A & B & C
-      const M hy = HYD ? mand<K>(hB, mor<K>(mand<K>(hA, mC), mand<K>(m0, m1))) : (HYS ? mor<K>(hA, hB) : mzero<K>());
+      const M hy = HYD ? mand<K>(hB, mor<K>(mand<K>(hA, mC), mand<K>(m0, m1))) : mzero<K>();
       // both candidate (D, E) assignments evaluated at once:
       //   cand0: D = child0, E = child1;  cand1: D = child1, E = child0
       // new legs of B: (D ^ C) | hyper_A | hyper_B   (optimizer.hpp:147)
@@ -688,12 +684,6 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
         // Tree::swap_with_nn(E): include/tnco/tree.hpp:176-184
         if (pick0) br = C; else bl = C;
         if (c_is_right) ar = E; else al = E;
-        if constexpr (HYS) {
-          // :171 with legs(A) = (legs(B) ^ legs(C)) | hyper(A) before the move, legs(B) = (child ^ child) | hyper(B)
-          const M iA = mor<K>(mxor<K>(mor<K>(mxor<K>(m0, m1), hB), mC), hA);
-          hA = mand<K>(mand<K>(iA, newB), mE);
-          hB = mand<K>(mand<K>(newB, mD), mC);  // :172
-        }
         if constexpr (HYD) hB = newB;  // (B's own legs; A's stay)
         ccB = nB;
         ccA = nA;
@@ -703,7 +693,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
         mBnow = newB;
         mX = mE;
       } else {
-        mBnow = HYD ? hB : (HYS ? mor<K>(mxor<K>(m0, m1), hB) : mxor<K>(m0, m1));
+        mBnow = HYD ? hB : mxor<K>(m0, m1);
         mX = mC;
       }
       // :185-188
@@ -711,7 +701,6 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       const double partA = rnd_cost(rnd_cost(partB + pCcur, f32) + ccA, f32);
       // what B's record becomes (written in the store phase); the B <- A shift (:191) follows it
       stL = bl; stR = br; stCC = ccB; stPart = partB;
-      if constexpr (HYPER) stH = hB;
       b_is_left_of_a = c_is_right;
       x_al = al; x_ar = ar; x_aP = aP; x_ccA = ccA; x_partA = partA; x_pCcur = pCcur;
       // :191, legs only (registers: the scalars follow after the store phase).  B becomes a child
@@ -772,13 +761,8 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       // hold it, so the short write never reaches HBM on its own; the extra store only costs issue.
 #ifdef TNCO_FIRST64
       if (!(did_move && acc))
-        v.set_mask_first(stB, did_move ? msel<K>(b_is_left_of_a, m0, m1) : (HYD ? hB : (HYS ? mor<K>(mxor<K>(m0, m1), hB) : mxor<K>(m0, m1))));
+        v.set_mask_first(stB, did_move ? msel<K>(b_is_left_of_a, m0, m1) : (HYD ? hB : mxor<K>(m0, m1)));
 #endif
-      // (B's hyper legs change when this move was accepted -- or the one a level below, which made them as hyper[A]: a
-      //  node that neither touched keeps what memory holds: one move in ten, two sectors each)
-      if constexpr (HYS) {
-        if ((did_move && acc) || hB_dirty) v.set_hyper(stB, stH);
-      }
       if (improved && lane0) cold.jmin = jtail;
       if (state < 0) break;
     }
@@ -791,7 +775,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       if (b_is_left_of_a) { p0 = stPart; p1 = x_pCcur; }
       else                { p1 = stPart; p0 = x_pCcur; }
       B = stA; bl = x_al; br = x_ar; ccB = x_ccA; partB = x_partA;
-      if constexpr (HYPER) { hB = hA; hA = gH; hB_dirty = acc; }
+      if constexpr (HYPER) { hB = hA; hA = gH; }
       A = x_aP;
       raL = rnL; raR = rnR; raP = rnP; raC = rnC;
       rnL = gL; rnR = gR; rnP = gP; rnC = gC;
@@ -812,7 +796,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       total = __hiloint2double((int)gXhi, (int)gXlo);
       raL = gL; raR = gR; raP = gP; raC = gC;
       if constexpr (FW) raW = gW;
-      if constexpr (HYPER) { hB = gH; hB_dirty = false; }
+      if constexpr (HYPER) { hB = gH; }
       state = S_GOT_B1;
     } else if (state == S_GOT_B1) {
       m1 = gM; p1 = gMp;

@@ -586,21 +586,15 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   Params& P = h->P;
   P.n = n; P.N = N; P.I = I; P.W = W; P.R = R;
   P.BS = (32 + 8 * W + 31) / 32 * 32;
-  P.hoff = 0;
-  P.hyper_stored = 0;
-  if (h->hyper && fw) {  // finite width keeps the hyper legs, behind the legs (the split layout below sets the offsets)
-    P.hyper_stored = 1;
-  }
-  // (infinite memory with hyper-indices, round 5: hyper[p] = legs(p) & legs(c0) & legs(c1) is derived by the sweep
-  //  kernel from legs it holds anyway, so the blocks are those of a network without hyper-indices)
+  // (Networks with hyper-indices, round 5: hyper[p] = legs(p) & legs(c0) & legs(c1) is derived by the kernels from legs
+  //  they hold anyway, so no layout stores hyper legs: the blocks are those of a network without hyper-indices.)
   // Blocks longer than a line are PACKED (a 224-byte block at 24 mask words straddles two or three 128-byte lines
   // depending on where it starts): padding them to whole lines costs as many lines as it saves (round 3), and splitting
   // them into headers + [partial copy | legs] records loses 5-30 % to the second dirty line per move (round 5).
   P.WS = P.BS; P.WOFF = 32; P.RB = (int64_t)(n - 1) * P.BS;
   if (fw) {  // split layout (sa_kernels.h, Params)
     P.BS = 32;
-    P.hoff = h->hyper ? 8 * W : 0;
-    P.WS = ((h->hyper ? 16 : 8) * W + 63) / 64 * 64;
+    P.WS = (8 * W + 63) / 64 * 64;
     P.WOFF = ((n - 1) * 32 + 127) / 128 * 128;
     P.RB = ((int64_t)P.WOFF + (int64_t)(n - 1) * P.WS + 127) / 128 * 128;
   }
@@ -809,7 +803,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     a.scratch = reinterpret_cast<int32_t*>(P.minlinks);  // 16 B * N per replica = 4N int32
     a.out_total = dtotal; a.out_sum = dsum; a.out_status = dstatus;
     a.r0 = 0; a.count = R;
-    if (h->hyper && !P.hyper_stored && !d->node_masks) {  // (the second mask per node build_kernel derives the legs with)
+    if (h->hyper && !d->node_masks) {  // (the second mask per node build_kernel derives the legs with)
       uint64_t* dhy = nullptr;
       HIP_TRY(tmp.alloc(&dhy, R * (int64_t)(n - 1) * W));
       a.hyper_tmp = dhy;
@@ -1035,7 +1029,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     HIP_TRY(tmp.alloc(&ttot, chunk));
     HIP_TRY(tmp.alloc(&tsum, chunk));
     uint64_t* thy = nullptr;
-    if (h->hyper && !P.hyper_stored) HIP_TRY(tmp.alloc(&thy, chunk * (int64_t)(n - 1) * W));
+    if (h->hyper) HIP_TRY(tmp.alloc(&thy, chunk * (int64_t)(n - 1) * W));
     std::vector<int32_t> hs((size_t)chunk), hb((size_t)chunk);
     std::vector<double> hsum((size_t)chunk);
     for (int64_t r0 = 0; r0 < R; r0 += chunk) {
@@ -1457,9 +1451,7 @@ int tnco_hip_get_caches(tnco_hip_handle h, int64_t r, double* ccost, double* par
     if (ccost) ccost[i] = i < n ? 0.0 : hd.ccost;
     if (partial) partial[i] = i < n ? 0.0 : hd.partial;
     if (hyper && h->hyper && i >= n) {
-      if (h->P.hyper_stored) {
-        std::memcpy(hyper + (size_t)i * W, blk.data() + ((int64_t)h->P.WOFF + (int64_t)(i - n) * h->P.WS + h->P.hoff), (size_t)W * 8);
-      } else {  // HyperCache (infinite_memory/utils.hpp:82-91): legs(p) & legs(c0) & legs(c1), from the stored legs
+      {  // HyperCache (infinite_memory/utils.hpp:82-91): legs(p) & legs(c0) & legs(c1), from the stored legs
         auto legs = [&](int x) -> const uint64_t* {
           return x < n ? h->leafmask_w.data() + (size_t)x * W
                        : reinterpret_cast<const uint64_t*>(blk.data() + ((int64_t)h->P.WOFF + (int64_t)(x - n) * h->P.WS));
@@ -1495,7 +1487,7 @@ int tnco_hip_validate(tnco_hip_handle h, double atol, int64_t* n_bad, int64_t* f
   HIP_TRY(tmp.alloc(&ttot, chunk));
   HIP_TRY(tmp.alloc(&tsum, chunk));
   uint64_t* thy = nullptr;
-  if (h->hyper && !P.hyper_stored) HIP_TRY(tmp.alloc(&thy, chunk * (int64_t)(n - 1) * h->P.W));
+  if (h->hyper) HIP_TRY(tmp.alloc(&thy, chunk * (int64_t)(n - 1) * h->P.W));
   int64_t bad = 0, first = -1;
   std::vector<ReplicaState> rs;
   if (int rc = fetch_rs(h, rs)) return rc;
