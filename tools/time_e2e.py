@@ -20,8 +20,8 @@ def spec_of(n, seed):
     return [(2, *[f"t{t}" for t in range(n) if k in ts[t]]) for k in range(n_inds)]
 
 
-def timed(label, spec, **kw):
-    opt = Optimizer(method="sa", seed=0)
+def timed(label, spec, max_width=None, **kw):
+    opt = Optimizer(method="sa", seed=0, max_width=max_width)
     t0 = time.perf_counter()
     tn, res = opt.optimize(spec, betas=(0, 100), **kw)
     dt = time.perf_counter() - t0
@@ -39,6 +39,19 @@ timed("512 leaves, 65536 runs x 1000 steps, fuse=4", spec_of(512, 11), n_steps=1
 timed("  same, fuse=None, initial_trees='kruskal'", spec_of(512, 11), n_steps=1000, n_runs=65536, top_k=16, fuse=None,
       initial_trees="kruskal")
 timed("  same, fuse=None, top_k=1024 (default)", spec_of(512, 11), n_steps=1000, n_runs=65536, fuse=None)
+
+
+def spec_of_cz(depth, fuse):
+    """index-list spec of the CZ (hyper-index) circuit network: what the reference's loader makes of a circuit by default"""
+    ts, _d, _o = syn.sycamore53_cz_tn(depth, fuse)
+    n_inds = max(max(x) for x in ts if x) + 1
+    return [(2, *[f"t{t}" for t in range(len(ts)) if k in ts[t]]) for k in range(n_inds)]
+
+
+timed("CZ circuit depth 20 fused (hyper-indices), 65536 runs x 1000 steps", spec_of_cz(20, 4), n_steps=1000, n_runs=65536, top_k=16, fuse=None)
+timed("  same once more", spec_of_cz(20, 4), n_steps=1000, n_runs=65536, top_k=16, fuse=None)
+timed("CZ circuit depth 12 raw, 1000 tensors, 65536 runs x 1000 steps", spec_of_cz(12, None), n_steps=1000, n_runs=65536, top_k=16, fuse=None)
+timed("CZ circuit depth 20 fused, max_width 42, 32768 runs x 1000 steps", spec_of_cz(20, 4), n_steps=1000, n_runs=32768, top_k=16, fuse=None, max_width=42)
 
 
 def phases(n=512, R=65536, k=1024, sweeps=1000):
