@@ -214,13 +214,27 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
   }
   if (!graph && !(std::getenv("TNCO_HIP_GREEDY_LDS_QUEUE") && std::atoi(std::getenv("TNCO_HIP_GREEDY_LDS_QUEUE")) != 0)) {
     const int need = (I + 63) / 64 * m1;
-    for (int rw : {4, 8, 12, 16})  // (24 rows: 200 VGPRs, two wavefronts per SIMD -- fewer trees per CU than with the queue in LDS)
+    for (int rw : {4, 8, 12, 16})
       if (set_rows == 0 && need <= rw) set_rows = rw;
+    // 24 rows: two wavefronts per SIMD, eight trees per CU -- taken where the queue in LDS would leave fewer than that
+    // (round 5: 1 000 tensors / 689 indices of the raw CZ circuit: 28 KB of LDS per tree with the queue, five per CU)
+    if (set_rows == 0 && need <= 24 && (size_t)(160 * 1024) / lds_bytes(W, SMAX, I, QC, TS) < 8) set_rows = 24;
   }
   const int Qa = set_rows ? set_rows * 64 : Q;  // rows of the stored results (one per queue cell)
   const size_t lds = graph ? graph_lds_bytes(n, gh.CAP) : lds_bytes(W, SMAX, I, set_rows ? 0 : QC, TS);
   int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (size_t)(160 * 1024) / lds));
   if (per_cu > 12) per_cu &= ~3;  // (13 per CU measured a third slower than 12; 9, 10, 11 each faster than the one before)
+  if (!graph) {
+    // ... and no more wavefronts than the kernel's registers let a CU hold: every wavefront works through R / G trees, and
+    // the ones that only start when the first have finished are a second round of almost the same length (round 5: the
+    // 16-row instantiation, 166 VGPRs, was launched 16 per CU where 12 fit)
+    const void* kp = set_rows == 4 ? (const void*)greedy_kernel<4> : set_rows == 8 ? (const void*)greedy_kernel<8>
+                   : set_rows == 12 ? (const void*)greedy_kernel<12> : set_rows == 16 ? (const void*)greedy_kernel<16>
+                   : set_rows == 24 ? (const void*)greedy_kernel<24> : (const void*)greedy_kernel<0>;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kp, 64, lds) == hipSuccess && nb > 0) per_cu = std::min(per_cu, nb);
+    else (void)hipGetLastError();
+  }
   const int G = (int)std::min<int64_t>(R, (int64_t)cus * per_cu);
 
   std::lock_guard<std::mutex> pool_lock(g_pool.mu);
@@ -336,6 +350,7 @@ extern "C" int tnco_hip_greedy_trees_device(int32_t device, int32_t n_leaves, in
       case 8: TNCO_SET_LAUNCH(8); break;
       case 12: TNCO_SET_LAUNCH(12); break;
       case 16: TNCO_SET_LAUNCH(16); break;
+      case 24: TNCO_SET_LAUNCH(24); break;
       default: TNCO_SET_LAUNCH(0); break;
     }
 #undef TNCO_SET_LAUNCH

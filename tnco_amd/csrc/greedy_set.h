@@ -35,8 +35,10 @@ struct GreedyParams {
 // initial candidates of a dim stay in its lane, a push goes into the cell just popped.  ROWS = 0: the queue in LDS
 // (networks whose dims x candidates per dim need more than 16 rows: beyond that the registers cost more trees per CU
 // than the LDS did).
+// (three wavefronts per SIMD asked for: the 16-row instantiation sits at the edge of 168 VGPRs, and twelve trees per CU
+//  against eight is a third of this latency-bound kernel's throughput)
 template <int ROWS>
-__global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
+__global__ __launch_bounds__(64, ROWS == 24 ? 2 : 3) void greedy_kernel(const GreedyParams p) {
   extern __shared__ uint64_t lds_raw[];
   const int lane = threadIdx.x;
   const int n = p.n, I = p.I, W = p.W, NW = p.NW, SMAX = p.SMAX, Q = p.Q, TS = p.TS;
@@ -412,14 +414,28 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
       if (lane == (s12 >> 6)) un &= ~(1ull << (s12 & 63));
       const uint64_t n12 = un | n12m;
       if (innw) nbr[(size_t)s12 * NW + lane] = n12;
+      // the list of the result's neighbours (round 5: made BEFORE their rows are updated, so that the update is one
+      // neighbour per lane -- one memory round trip -- instead of a lane's neighbours one after the other; the members of
+      // `un`, whose rows change, come first, the neighbours a live equal set brought along behind them)
+      int total = (int)wsum((uint32_t)__popcll(un));
+      if (total > GREEDY_LCAP) {
+        status = 7;
+        break;
+      }
+      {
+        int at = (int)wscan_excl((uint32_t)__popcll(un), lane);
+        uint64_t u = un;
+        while (u) {
+          lst[at++] = (uint16_t)(lane * 64 + __ffsll((unsigned long long)u) - 1);
+          u &= u - 1;
+        }
+      }
+      __syncthreads();
       {
         const int w1 = s1 >> 6, w2 = s2 >> 6, w12 = s12 >> 6;
         const uint64_t m1 = 1ull << (s1 & 63), m2 = 1ull << (s2 & 63), m12 = 1ull << (s12 & 63);
-        uint64_t u = un;
-        while (u) {
-          const int y = lane * 64 + __ffsll((unsigned long long)u) - 1;
-          u &= u - 1;
-          uint64_t* ry = nbr + (size_t)y * NW;
+        for (int j = lane; j < total; j += 64) {
+          uint64_t* ry = nbr + (size_t)lst[j] * NW;
           uint64_t v1 = ry[w1], v2 = ry[w2], v12 = ry[w12];  // (three reads in flight; equal words: equal values)
           v1 &= ~m1;
           if (w2 == w1) v1 &= ~m2;
@@ -433,24 +449,25 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
           if (w12 != w1 && w12 != w2) ry[w12] = v12 | m12;
         }
       }
-      GP_T(7);
-      // push the cheapest (k12, neighbour)
-      const uint32_t pc = (uint32_t)__popcll(n12);
-      const int total = (int)wsum(pc);
-      if (total > GREEDY_LCAP) {
-        status = 7;
-        break;
-      }
-      if (total > 0) {
-        {
-          int at = (int)wscan_excl(pc, lane);
-          uint64_t u = n12;
-          while (u) {
-            lst[at++] = (uint16_t)(lane * 64 + __ffsll((unsigned long long)u) - 1);
-            u &= u - 1;
-          }
+      if (merged) {  // (rare: the neighbours the live equal set brought along join the list)
+        const uint64_t extra = n12m & ~un;
+        const int at0 = total + (int)wscan_excl((uint32_t)__popcll(extra), lane);
+        total += (int)wsum((uint32_t)__popcll(extra));
+        if (total > GREEDY_LCAP) {
+          status = 7;
+          break;
+        }
+        int at = at0;
+        uint64_t u = extra;
+        while (u) {
+          lst[at++] = (uint16_t)(lane * 64 + __ffsll((unsigned long long)u) - 1);
+          u &= u - 1;
         }
         __syncthreads();
+      }
+      GP_T(7);
+      // push the cheapest (k12, neighbour)
+      if (total > 0) {
         GP_T(8);
         // one neighbour per lane.  Per word the result keeps, of the legs the neighbour b does NOT hold,
         // P = k12 & (output | ref2), and of those it holds Q = output | (k12 & ref3) | (~k12 & ref2):
@@ -488,7 +505,8 @@ __global__ __launch_bounds__(64) void greedy_kernel(const GreedyParams p) {
         GP_T(9);
         // (keys of distinct neighbours differ in an id: exactly one lane holds the minimum)
         const uint64_t wk = wmin64(bestk);
-        const int sbest = uni(__shfl(bests, __ffsll((unsigned long long)__ballot(bestk == wk)) - 1));
+        const int wlane = __ffsll((unsigned long long)__ballot(bestk == wk)) - 1;
+        const int sbest = uni(__shfl(bests, wlane));
         const uint64_t bb = inw ? keys[(size_t)sbest * W + lane] : 0;
         const uint64_t res = (bb & qmask) | (~bb & pmask);
         // into the cell (and the arena row) of the candidate popped in this iteration: the queue never
