@@ -2,7 +2,7 @@ cd /tmp && export TMPDIR=/tmp
 ROOT=$GRAFT_REPO_ROOT
 for C in "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_LDS"; do
   N=$(echo $C | tr ' ' '_')
-  timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pg_$N -o pmc -- python3 $ROOT/tools/time_greedy.py 512 65536 > /tmp/pg_$N.log 2>&1
+  timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pg_$N -o pmc -- python3 $ROOT/tools/${GREEDY_SCRIPT:-time_greedy.py} ${GREEDY_ARGS-512 65536} > /tmp/pg_$N.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob
