@@ -176,7 +176,9 @@ int tnco_hip_get_tree(tnco_hip_handle h, int64_t replica, int which, int32_t* le
 
 /* CostCache / HyperCache contents of one replica (what is_valid() rebuilds and
  * compares, optimizer.hpp:223-251); ccost/partial [N], hyper [N][W]; any may
- * be NULL. */
+ * be NULL.  The device does not store a HyperCache: hyper[p] = legs(p) & legs(c0) & legs(c1)
+ * (infinite_memory/utils.hpp:82-91) is a function of the legs, derived by the kernels where
+ * they need it and here on the host. */
 int tnco_hip_get_caches(tnco_hip_handle h, int64_t replica, double* ccost, double* partial,
                         uint64_t* hyper);
 

@@ -265,6 +265,16 @@ def test_invalid_inputs(core):
     with pytest.raises(ValueError, match="Contraction is not valid"):
         core.BatchedOptimizer(lm, lk, [1], n_inds=3)
     core.BatchedOptimizer(lm, lk, [1], n_inds=3, disable_shared_inds=True).close()
+    # per-index dims: a power-of-two part up to 2^32 is taken (the exponent classes live in LDS), a larger one refused
+    dims = np.full(prob.n_inds, 2, np.uint64)
+    dims[3] = 3 << 32
+    g = core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, dims=dims)
+    g.run(H.linear_betas(0, 10, 5))
+    assert g.validate() == (0, -1)
+    g.close()
+    dims[3] = 1 << 40
+    with pytest.raises(NotImplementedError, match="2\\^32"):
+        core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, dims=dims)
 
 
 def test_c3_full_size_properties(core, oracle_lib):
