@@ -410,3 +410,31 @@ def test_config4_shards_of_eight(monkeypatch):
     head = np.lexsort((np.arange(n_runs), cost))[:top_k]
     assert [(c, g) for c, g, _ in merged] == [(float(cost[g]), int(g)) for g in head]
     assert min(float(cost[lo:hi].min()) for lo, hi in bounds) == float(cost.min()) == merged[0][0]
+
+
+def test_wire_format_round_trips_what_the_ranks_exchange():
+    """The fixed wire format of the exchanges (no pickle): everything merge_heads / the bench send survives a
+    round trip with its types -- Decimals, tuples inside lists, frozensets of index names, infinities, numpy arrays and
+    scalars, bytes, nested dicts -- and what it cannot carry is refused, not smuggled."""
+    from decimal import Decimal
+    sys.path.insert(0, str(ROOT))
+    from tnco_amd import parallel
+    head = [(Decimal("7.49888E+7"), 12345, [Decimal("1.5E+3"), 0], [[(0, 1), (0, 1)], []], [frozenset({"a", "b"}), frozenset()],
+             [(2, 3), (0, 1)]),
+            (Decimal("Infinity"), 7, [], [], [frozenset({("q", 1), 5})], [])]
+    back = parallel._decode(parallel._encode(head))
+    assert back == head and type(back[0]) is tuple and type(back[0][3][0][0]) is tuple and type(back[0][4][0]) is frozenset
+    assert type(back[0][0]) is Decimal
+    obj = {"rank": 3, "x": float("inf"), "y": -0.0, "z": float("1e-320"), "a": np.arange(6, dtype=np.int32).reshape(2, 3),
+           "b": b"\x00\xff", "n": None, "t": True, "np": np.float64(2.5), "i": np.int64(-9), "s": {1, 2}}
+    out = parallel._decode(parallel._encode(obj))
+    assert out["rank"] == 3 and out["x"] == float("inf") and str(out["y"]) == "-0.0" and out["z"] == float("1e-320")
+    assert np.array_equal(out["a"], obj["a"]) and out["a"].dtype == np.int32 and out["b"] == b"\x00\xff"
+    assert out["n"] is None and out["t"] is True and out["np"] == 2.5 and out["i"] == -9 and out["s"] == {1, 2}
+    assert np.isnan(parallel._decode(parallel._encode(float("nan"))))
+    with pytest.raises(TypeError):
+        parallel._encode(object())
+    with pytest.raises(TypeError):
+        parallel._encode(np.array([object()], dtype=object))
+    with pytest.raises(ConnectionError):
+        parallel._decode(b'{"!":"a","t":"|O","s":[1],"v":"00"}')
