@@ -442,8 +442,9 @@ def end_to_end(args):
 
 
 def config2(local_rank):
-    """BASELINE configs[1] (64-leaf 3-regular TN, 4 096 replicas) -- the small, latency-bound end of the path: 4 096
-    replicas are 256 wavefronts, one per CU, and every replica advances one dependent memory round trip at a time.
+    """BASELINE configs[1] (64-leaf 3-regular TN, 4 096 replicas) -- the small end of the path: 4 096 replicas are 256
+    wavefronts, one per CU; the library runs them LDS-resident (csrc/sa_small.h: the trees of a wavefront's 16 replicas stay
+    in LDS for a launch, x1.8 the HBM kernel here, whose replicas advance one dependent memory round trip at a time).
     Informational (N = 1): move-evals/s over 1 000 sweeps, every replica validated, 64 of them against the oracle."""
     try:
         from tnco_amd import core, synthetic
@@ -463,11 +464,13 @@ def config2(local_rank):
             moves = opt.counters()["moves"] - m0
             bad = int(opt.validate()[0])
             mn = opt.costs()[1]
+            lds = opt.launch_groups == 0
         from oracle import oracle as orc
         orc.build()
         _dt, _tot, omn, _mv = orc.run_batch(links[:64], prob.leaf_masks, seeds[:64], betas, n_inds=prob.n_inds, dims=2)
         return {"workload": "C2: 64-leaf 3-regular TN d=2, 4096 replicas, MH, f64, 1000 sweeps (one launch)", "value": moves / dt,
                 "unit": "move-evals/s", "seconds": dt, "validated_bad_replicas": bad,
+                "kernel": "sa_small_kernel (LDS-resident)" if lds else "sa_run_kernel",
                 "cpu_sample_min_cost_bit_exact": bool(np.array_equal(omn, mn[:64])), "best_log10_flops": float(np.log10(mn.min()))}
     except Exception as e:  # (informational: never fails the bench line)
         return {"error": f"{type(e).__name__}: {e}"}

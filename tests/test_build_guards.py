@@ -44,3 +44,20 @@ def test_sweep_loops_have_one_landing_fence_and_no_scratch(report):
 def test_waves_per_simd_rule():
     import code_objects
     assert [code_objects.waves_per_simd(v) for v in (64, 96, 127, 128, 129, 168, 169, 215, 256, 257)] == [8, 5, 4, 4, 3, 3, 2, 2, 2, 1]
+
+
+def test_lds_budget_of_the_small_tree_kernels(report):
+    """csrc/sa_small.h: the host decides from small_replicas_per_cu() (64 up to 64 leaves, 32 beyond) whether every replica
+    of a handle is LDS-resident at once -- that is the kernels' static LDS (38.5 and 72.5 KiB per 16-replica block: four and
+    two blocks in a CU's 160 KiB), which only the code object knows; and neither kernel may use scratch."""
+    import code_objects
+    seen = {}
+    for elf in code_objects.code_objects():
+        for name, meta in code_objects.kernel_table(elf).items():
+            if "sa_small_kernel" in name:
+                seen[63 if "ILi63E" in name else 127] = meta
+    assert sorted(seen) == [63, 127]
+    for ni, per_cu in ((63, 64), (127, 32)):
+        lds = seen[ni]["group_segment_fixed_size"]
+        assert (160 * 1024 // lds) * 16 == per_cu, (ni, lds)
+        assert seen[ni]["private_segment_fixed_size"] == 0 and seen[ni]["vgpr_count"] <= 256

@@ -277,6 +277,54 @@ def test_invalid_inputs(core):
         core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, dims=dims)
 
 
+def test_few_small_trees_run_lds_resident(core, oracle_lib):
+    """csrc/sa_small.h: a handle of few small trees (<= 128 leaves, <= 2 mask words, the fast cost path, no more replicas
+    than the CUs hold at once) keeps every replica's tree in LDS during a launch -- launch_groups == 0 says so.
+    (a) Same bits as the oracle with launches of 1, 7 and 40 sweeps: 64 leaves (the 63-node instantiation), 84 leaves (the
+    127-node one), 10 leaves, 2 leaves.  (b) The same replicas at the head of a batch too large to stay resident run through
+    the HBM kernel (launch_groups >= 1) and end in the same state bit for bit: trees, best trees, costs, generator state."""
+    for n, gs, R in ((64, 7, 96), (84, 11, 40), (10, 2, 70), (2, 1, 5)):
+        prob = H.regular_problem(n, graph_seed=gs, degree=3 if n > 2 else 1)
+        R_big = 20000 if n == 64 else 0
+        seeds = H.replica_seeds(max(R, R_big), S=n)
+        links = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds) if R_big else prob.links(seeds)
+        betas = H.linear_betas(0, 60, 48)
+        gpu = core.BatchedOptimizer(prob.leaf_masks, links[:R], seeds[:R], n_inds=prob.n_inds)
+        assert gpu.launch_groups == 0
+        gpu.run(betas[:1]); gpu.run(betas[1:8]); gpu.run(betas[8:])
+        tot, mn = gpu.costs()
+        for r in range(0, R, 3):
+            o = H.make_oracle(oracle_lib, prob, links[r], seeds[r])
+            o.run(oracle_lib.PROB_MH, betas)
+            H.assert_replica_equal(gpu, r, o)
+            assert tot[r] == o.total_cost and mn[r] == o.min_total_cost
+        assert gpu.validate() == (0, -1)
+        if R_big:
+            big = core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds)
+            assert big.launch_groups >= 1
+            big.run(betas[:1]); big.run(betas[1:8]); big.run(betas[8:])
+            tb, mb = big.costs()
+            assert np.array_equal(tb[:R], tot) and np.array_equal(mb[:R], mn)
+            assert np.array_equal(big.moves_per_replica()[:R], gpu.moves_per_replica())
+            for r in range(R):
+                for which in (False, True):
+                    for x, y in zip(gpu.tree(r, which_min=which), big.tree(r, which_min=which)):
+                        assert np.array_equal(x, y)
+                assert np.array_equal(gpu.prng_state(r), big.prng_state(r))
+            assert big.validate() == (0, -1)
+            big.close()
+        gpu.close()
+    # not resident: a general cost model; three mask words
+    prob = H.regular_problem(64, graph_seed=7)
+    seeds = H.replica_seeds(8)
+    links = prob.links(seeds)
+    with core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, cost_type="float32") as g:
+        assert g.launch_groups == 1
+    prob = H.regular_problem(100, graph_seed=3)
+    with core.BatchedOptimizer(prob.leaf_masks, prob.links(seeds), seeds, n_inds=prob.n_inds) as g:
+        assert g.launch_groups == 1
+
+
 def test_c3_full_size_properties(core, oracle_lib):
     """BASELINE config 3 at FULL size (512 leaves, 65 536 replicas): size-independent properties
     the reference's own tests assert (tests/test_utils.py:575-769) -- every replica is_valid() on the

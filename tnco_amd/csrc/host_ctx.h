@@ -11,6 +11,7 @@
 #include "sa_kernels.h"
 #include "sa_sweep.h"
 #include "fw_kernels.h"
+#include "sa_small.h"
 
 struct EventPair {
   hipEvent_t a, b;
@@ -48,6 +49,7 @@ struct tnco_hip_ctx {
   int64_t fw_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool fw_probed = false;  // the first re-slice interval of the handle has run on its own (tnco_hip_run_fw)
   unsigned long long fw_slow_pending = 0, fw_slow_wide_pending = 0;  // fall-backs collected since tnco_hip_run_fw last chose a form
+  bool small_tree = false;  // few small trees (the latency regime): LDS-resident sweeps, sa_small.h
   tnco::FwParams F{};
   std::vector<void*> allocs;
   std::vector<size_t> alloc_bytes;  // (destroy hands the blocks to tnco::DevCache)

@@ -32,6 +32,17 @@ template <int LOG2L, int K>
 void launch_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, hipStream_t s, int block0,
                    int nblocks) {
   const Params& P = h->P;
+  if constexpr (LOG2L == 2 && K == 1) {
+    if (h->small_tree) {  // (one launch for all the replicas: such a handle has one group)
+      if (P.n - 1 <= 63)
+        hipLaunchKernelGGL((sa_small_kernel<63, SMALL_TPB>), dim3((unsigned)((P.R + SMALL_TPB / 4 - 1) / (SMALL_TPB / 4))), dim3(SMALL_TPB), 0, s, P, betas, n_steps,
+                           prob_kind);
+      else
+        hipLaunchKernelGGL((sa_small_kernel<127, SMALL_TPB>), dim3((unsigned)((P.R + SMALL_TPB / 4 - 1) / (SMALL_TPB / 4))), dim3(SMALL_TPB), 0, s, P, betas, n_steps,
+                           prob_kind);
+      return;
+    }
+  }
   const int gpb = SWT >> LOG2L;
   dim3 grid((unsigned)(nblocks >= 0 ? nblocks : (P.R + gpb - 1) / gpb));
   if (h->hyper) {

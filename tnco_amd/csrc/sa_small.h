@@ -1,0 +1,328 @@
+// sa_small.h -- the sweep kernel for FEW SMALL trees (BASELINE config 2: 64 leaves; the latency regime of README.md): every
+// replica's whole tree lives in LDS for the duration of a launch, HBM is touched when the launch starts and ends, by
+// the mt19937 state stream and by the rotation log (one 64-byte piece per 16 accepted moves).
+//
+// Same algorithm, same arithmetic and the same draws as sa_run_kernel (Optimizer::update,
+// include/tnco/optimize/infinite_memory/optimizer.hpp:90-221): what differs is where the operands come
+// from.  With the node blocks in HBM a replica advances one memory round trip (~2 microseconds under load, ~3.7 at
+// 4096 replicas) per move and the kernel is a state machine that overlaps the round trips of 192 replicas per CU; here
+// an operand is one LDS access (~100 cycles) away, so the loop is the plain walk: [sweep begin] [move]* [sweep end] per
+// replica, every replica of a wavefront at its own place of its own sweep.  What bounds it is the instruction stream of
+// the wavefront (~900 vector instructions per iteration, one wavefront per SIMD: LDS holds 64 replicas of 64 leaves per
+// CU): 2.1 microseconds per move and replica whatever the number of replicas -- x1.6 ... x1.8 the HBM kernel while one
+// round of blocks holds all the replicas, slower beyond (65536 replicas of 64 leaves: 7.4e9 against 9.0e9 move-evals/s).
+// The host picks accordingly (tnco_hip_create; profiles/r05_small_tree_ab.txt).  History: round 2 had this kernel as an
+// opt-in and measured only the 65536-replica case, round 3 removed it, round 5 re-measured it where it can win.
+//
+// Conditions (host: launch_run_lk<2, 1>): no hyper-indices, uniform power-of-two dims, float64 cost,
+// no sparse legs (the fast cost path), at most 2 mask words (4 lanes x 1 word layout), at most 254
+// nodes, a log that starts at the checkpoint (no min_links given).  LDS record of an internal node, 32 bytes:
+//     [ left right parent - | cost exponent (u16) - | partial cost f64 | legs: 2 words ]
+// (links fit a byte; a contraction cost is 2^e exactly -- or +inf, e = 1024 -- so e is kept).
+#pragma once
+#include "sa_sweep.h"
+
+namespace tnco {
+
+struct __attribute__((aligned(32))) SmallRec {
+  uint32_t links;   // left | right << 8 | parent << 16   (0xFF: null)
+  uint32_t cexp;    // exponent of the contraction cost
+  double partial;
+  uint64_t legs[2];
+};
+static_assert(sizeof(SmallRec) == 32, "SmallRec");
+constexpr int SMALL_MAX_INTERNAL = 127;  // (links are bytes, 0xFF = null: at most 254 nodes)
+constexpr int SMALL_TPB = 64;            // one wavefront = 16 replicas per block: few replicas still spread over the CUs
+// LDS of a block of sa_small_kernel<NI, SMALL_TPB> (the __shared__ arrays below) and the replicas one CU (160 KiB) holds
+constexpr int small_lds_bytes(int NI) {
+  return (SMALL_TPB / 4) * (NI * 32 + (NI + 1) + 64 * 4 + 16 * 4) + (NI + 1) * 16;
+}
+constexpr int small_replicas_per_cu(int ni) { return (160 * 1024 / small_lds_bytes(ni <= 63 ? 63 : 127)) * (SMALL_TPB / 4); }
+static_assert(small_replicas_per_cu(63) == 64 && small_replicas_per_cu(127) == 32, "LDS budget of the small-tree kernel");
+
+__device__ __forceinline__ uint32_t small_exp_of(double c) {
+  return (uint32_t)((__double2hiint(c) >> 20) & 0x7ff) - 1023u;  // c = 2^e exactly (or +inf -> 1024)
+}
+
+// NI: internal nodes per replica the LDS arrays are sized for (n - 1 <= NI); TPB threads = TPB / 4
+// replicas per block.  <63, 64>: 38.5 KiB of LDS, four blocks per CU; <127, 64>: 72.5 KiB, two.
+template <int NI, int TPB>
+__global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const double* __restrict__ betas,
+                                                       const int64_t n_steps, const int prob_kind) {
+  constexpr int LOG2L = 2, K = 1, L = 4, GPB = TPB / 4;
+  using M = Mask<K>;
+  using R = Rng<LOG2L, 64>;
+  typedef TNCO_LDS volatile uint64_t lvu64;
+  typedef TNCO_LDS volatile uint8_t lvu8;
+  __shared__ SmallRec recbuf[GPB * NI];
+  __shared__ uint8_t lparbuf[GPB * (NI + 1)];
+  __shared__ uint64_t leafbuf[(NI + 1) * 2];
+  __shared__ uint32_t rngbuf[GPB * R::RING];
+  __shared__ int32_t jbuf[GPB * 16];
+
+  const int tid = threadIdx.x;
+  const int lig = tid & 3;
+  const int gib = tid >> 2;
+  const int64_t r = (int64_t)blockIdx.x * GPB + gib;
+  const int n = P.n, N = P.N, ni = n - 1;
+  // the leaf legs, shared by the replicas of the block (words 0, 1 of every row of the padded table)
+  for (int i = tid; i < n * 2; i += TPB) leafbuf[i] = P.leafmask[(int64_t)(i >> 1) * L + (i & 1)];
+  __syncthreads();
+  if (r >= P.R || n_steps <= 0) return;
+  const bool lane0 = lig == 0;
+  TNCO_LDS volatile SmallRec* rec = (TNCO_LDS volatile SmallRec*)recbuf + gib * NI;
+  lvu8* lpar = (lvu8*)lparbuf + gib * (NI + 1);
+  lvu64* leaf = (lvu64*)leafbuf;
+
+  // ---- HBM -> LDS -------------------------------------------------------------------------------
+  {
+    const uint8_t* blk = P.blocks + r * P.RB;
+    for (int i = lig; i < ni; i += L) {
+      const NodeRec* q = reinterpret_cast<const NodeRec*>(blk + (int64_t)i * P.BS);
+      const uint64_t* lg = reinterpret_cast<const uint64_t*>(blk + (int64_t)i * P.BS + 32);
+      rec[i].links = (uint32_t)(q->left & 0xFF) | ((uint32_t)(q->right & 0xFF) << 8) | ((uint32_t)(q->parent & 0xFF) << 16);
+      rec[i].cexp = small_exp_of(q->ccost);
+      rec[i].partial = q->partial;
+      rec[i].legs[0] = lg[0];
+      rec[i].legs[1] = P.W > 1 ? lg[1] : 0ull;
+    }
+    const int32_t* lp = P.lpar + r * (int64_t)n * LPS;
+    for (int i = lig; i < n; i += L) lpar[i] = (uint8_t)lp[(int64_t)i * LPS];
+  }
+  // (LDS operations of one wavefront are executed in order: no barrier between a group's own writes and reads)
+  auto legs_of = [&](int x) -> M {  // this lane's word of the legs of node x (lanes 2, 3: nothing)
+    M m;
+    m.w[0] = 0ull;
+    if (lig < 2) m.w[0] = x < n ? leaf[2 * x + lig] : rec[x - n].legs[lig];
+    return m;
+  };
+  auto partial_of = [&](int x) -> double { return x < n ? 0.0 : (double)rec[x - n].partial; };
+  auto set_parent = [&](int x, int p) {
+    if (!lane0) return;
+    if (x < n) lpar[x] = (uint8_t)p;
+    else ((lvu8*)&rec[x - n].links)[2] = (uint8_t)p;
+  };
+
+  R rng;
+  const ReplicaState* rs0 = P.rs + r;
+  rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs0->mti, rs0->mtw, lig);
+  int pend_age = 0;
+  double min_cost = rs0->min_cost;
+  uint32_t jmin = rs0->jmin, jtail = rs0->jtail;
+  bool jinvalid = rs0->jinvalid != 0;
+  uint32_t n_moves = 0, n_acc = 0, n_impr = 0, n_full = 0, n_rpick = 0;
+  const uint32_t jcap = (uint32_t)P.jcap;
+  int32_t* jlog = P.jlog + r * (int64_t)P.jcap;
+  auto jb = [&](int i) -> lds_vi32& { return *((lds_vi32*)jbuf + gib * 16 + i); };
+  if ((jtail & 15u) != 0u) {
+    const int4 t = *reinterpret_cast<const int4*>(jlog + (jtail & ~15u) + 4 * lig);
+    jb(4 * lig + 0) = t.x; jb(4 * lig + 1) = t.y; jb(4 * lig + 2) = t.z; jb(4 * lig + 3) = t.w;
+  }
+  const int log2d = P.log2d;
+  const bool disable_shared = P.disable_shared != 0;
+  const int root = N - 1;
+
+  // ---- carried state (as in sa_run_kernel): B, its children's legs / partial costs ----------------
+  int step = 0;
+  int B = -1, bl = 0, br = 0, A = -1;
+  uint32_t eB = 0;
+  double partB = 0, total = 0, beta = 0;
+  M m0 = mzero<K>(), m1 = mzero<K>();
+  double p0 = 0, p1 = 0;
+  bool active = true;
+  // (one loop for the wavefront, left when no replica of it has sweeps to do: a per-replica `break`
+  // made the compiler run the sweeps of the sixteen replicas in step)
+  while (__ballot(active) != 0ull) {  // (B < 0: between two sweeps)
+    if (active) {
+    // the generator: loads of the next block are issued when there is room and consumed a few
+    // iterations later, when they have surely landed (a wait here would stall sixteen replicas)
+    if (rng.pend) {
+      if (++pend_age >= 6 || rng.avail() < 6u) {
+        rng.produce();
+        pend_age = 0;
+      }
+    } else if (rng.room()) {
+      rng.request();
+    }
+    if (B < 0) {
+      // optimizer.hpp:103-112: a random leaf, its parent is B; the total cost is the root's partial cost
+      const uint32_t x = rng.next_sync();
+      B = lpar[x % (uint32_t)n];
+      const uint32_t lk = rec[B - n].links;
+      bl = (int)(lk & 0xFF); br = (int)((lk >> 8) & 0xFF);
+      A = (int)((lk >> 16) & 0xFF);
+      if (A == 0xFF) A = -1;
+      eB = rec[B - n].cexp;
+      partB = rec[B - n].partial;
+      total = rec[root - n].partial;
+      beta = betas[step];
+      m0 = legs_of(bl); m1 = legs_of(br);
+      p0 = partial_of(bl); p1 = partial_of(br);
+#ifdef TNCO_SMALL_DEBUG
+      if (lane0 && r < 2) printf("r%d begin step %d leaf %u B %d A %d bl %d br %d\n", (int)r, step, x % (uint32_t)n, B, A, bl, br);
+#endif
+    }
+    if (A >= 0) {
+      // ---- one move evaluation (optimizer.hpp:117-192) --------------------------------------------
+      const uint32_t lkA = rec[A - n].links;
+      int al = (int)(lkA & 0xFF), ar = (int)((lkA >> 8) & 0xFF);
+      int aP = (int)((lkA >> 16) & 0xFF);
+      if (aP == 0xFF) aP = -1;
+      uint32_t eA = rec[A - n].cexp;
+      const bool c_is_right = (al == B);
+      const int C = c_is_right ? ar : al;
+      const M mC = legs_of(C);
+      const double pC = partial_of(C);
+      uint32_t w0 = mpopc<K>(mor<K>(mxor<K>(m0, mC), m1)) | (mpopc<K>(mor<K>(m0, mC)) << 13) |
+                    ((mnonzero<K>(mand<K>(m0, mC)) ? 1u : 0u) << 26);
+      uint32_t w1 = mpopc<K>(mor<K>(mxor<K>(m1, mC), m0)) | (mpopc<K>(mor<K>(m1, mC)) << 13) |
+                    ((mnonzero<K>(mand<K>(m1, mC)) ? 1u : 0u) << 26);
+      w0 = gsum<LOG2L>(w0);
+      w1 = gsum<LOG2L>(w1);
+      const bool inter0 = (w0 >> 26) != 0, inter1 = (w1 >> 26) != 0;
+      bool pick0;  // get_ctree_nn, optimize/optimizer.hpp:128-144
+      if (disable_shared || (inter0 && inter1)) {
+        pick0 = (rng.next_sync() & 1u) != 0;
+        ++n_rpick;
+      } else {
+        pick0 = inter0;
+      }
+      const M mD = msel<K>(pick0, m0, m1), mE = msel<K>(pick0, m1, m0);
+      const M newB = mxor<K>(mD, mC);
+      const double pD = pick0 ? p0 : p1, pE = pick0 ? p1 : p0;
+      const int E = pick0 ? br : bl;
+      const uint32_t enA = (uint32_t)log2d * ((pick0 ? w0 : w1) & 0x1fffu);
+      const uint32_t enB = (uint32_t)log2d * (((pick0 ? w0 : w1) >> 13) & 0x1fffu);
+      const double nA = pow2_cost((int)enA, 0), nB = pow2_cost((int)enB, 0);
+      double ccB = pow2_cost((int)eB, 0), ccA = pow2_cost((int)eA, 0);
+      const double delta = (nB - ccB) + (nA - ccA);  // :158
+      ++n_moves;
+      const uint32_t x1 = rng.next_sync(), x2 = rng.next_sync();  // :162 generate_canonical<double, 53>
+      double u = ((double)x1 + (double)x2 * 4294967296.0) * 5.421010862427522170037e-20;
+      if (u >= 1.0) u = 0.99999999999999988897769753748;
+      const bool acc = accept_move(prob_kind, beta, delta, total, u, 0);
+      double pEcur = pE, pCcur = pC;
+      M mBnow, mX;
+      if (acc) {
+        ++n_acc;
+        // Tree::swap_with_nn(E), include/tnco/tree.hpp:176-184
+        if (pick0) br = C; else bl = C;
+        if (c_is_right) ar = E; else al = E;
+        set_parent(C, B);
+        set_parent(E, A);
+        if (lig < 2) rec[B - n].legs[lig] = newB.w[0];
+        if (lane0) rec[A - n].links = (uint32_t)al | ((uint32_t)ar << 8) | ((uint32_t)(aP & 0xFF) << 16);
+        eB = enB; ccB = nB;
+        eA = enA; ccA = nA;
+        total = total + delta;  // :177
+        pEcur = pC;
+        pCcur = pE;
+        mBnow = newB;
+        mX = mE;
+        if (!jinvalid) {  // rotation log (best tree = checkpoint + log prefix)
+          if (jtail == jcap) {
+            jinvalid = true;
+          } else {
+            if (lane0) jb((int)(jtail & 15u)) = E;
+            ++jtail;
+            if ((jtail & 15u) == 0u)
+              *reinterpret_cast<int4*>(jlog + (jtail - 16u) + 4 * lig) =
+                  make_int4(jb(4 * lig + 0), jb(4 * lig + 1), jb(4 * lig + 2), jb(4 * lig + 3));
+          }
+        }
+      } else {
+        mBnow = mxor<K>(m0, m1);
+        mX = mC;
+      }
+      // :185-188
+      partB = (pD + pEcur) + ccB;
+      const double partA = (partB + pCcur) + ccA;
+      if (lane0) {
+        rec[B - n].links = (uint32_t)bl | ((uint32_t)br << 8) | ((uint32_t)A << 16);
+        rec[B - n].cexp = eB;
+        rec[B - n].partial = partB;
+        rec[A - n].cexp = eA;
+      }
+      // :191  B <- A
+      if (c_is_right) { m0 = mBnow; m1 = mX; p0 = partB; p1 = pCcur; }
+      else            { m1 = mBnow; m0 = mX; p1 = partB; p0 = pCcur; }
+      B = A; bl = al; br = ar; eB = eA; partB = partA;
+      A = aP;
+    }
+    if (A < 0) {
+      // ---- B is the root: end of the sweep (optimizer.hpp:194-201) ---------------------------------
+      if (lane0) rec[B - n].partial = partB;
+      if (partB < min_cost) {
+        min_cost = partB;
+        ++n_impr;
+        if (jinvalid) {  // the log overflowed: re-base the checkpoint on the current tree
+          Links* __restrict__ ml = P.minlinks + r * (int64_t)N;
+          for (int i = lig; i < N; i += L) {
+            Links o;
+            if (i < n) {
+              o.left = -1; o.right = -1; o.parent = lpar[i];
+            } else {
+              const uint32_t lk = rec[i - n].links;
+              o.left = (int)(lk & 0xFF); o.right = (int)((lk >> 8) & 0xFF);
+              o.parent = (int)((lk >> 16) & 0xFF);
+            }
+            if (o.parent == 0xFF) o.parent = -1;
+            o.pad = 0;
+            ml[i] = o;
+          }
+          jtail = 0;
+          jinvalid = false;
+          ++n_full;
+        }
+        jmin = jtail;
+      }
+#ifdef TNCO_SMALL_DEBUG
+      if (lane0 && r < 2) printf("r%d end step %d moves %u\n", (int)r, step, n_moves);
+#endif
+      B = -1;
+      if (++step >= (int)n_steps) active = false;
+    }
+    }
+  }
+
+  // ---- LDS -> HBM -------------------------------------------------------------------------------
+  {
+    uint8_t* blk = P.blocks + r * P.RB;
+    for (int i = lig; i < ni; i += L) {
+      NodeRec o;
+      const uint32_t lk = rec[i].links;
+      o.left = (int)(lk & 0xFF); o.right = (int)((lk >> 8) & 0xFF);
+      o.parent = (int)((lk >> 16) & 0xFF);
+      if (o.parent == 0xFF) o.parent = -1;
+      o.pad = 0;
+      o.ccost = pow2_cost((int)rec[i].cexp, 0);
+      o.partial = rec[i].partial;
+      *reinterpret_cast<NodeRec*>(blk + (int64_t)i * P.BS) = o;
+      uint64_t* lg = reinterpret_cast<uint64_t*>(blk + (int64_t)i * P.BS + 32);
+      lg[0] = rec[i].legs[0];
+      if (P.W > 1) lg[1] = rec[i].legs[1];
+    }
+    int32_t* lp = P.lpar + r * (int64_t)n * LPS;
+    for (int i = lig; i < n; i += L) lp[(int64_t)i * LPS] = (int32_t)lpar[i];
+  }
+  if ((jtail & 15u) != 0u)
+    *reinterpret_cast<int4*>(jlog + (jtail & ~15u) + 4 * lig) =
+        make_int4(jb(4 * lig + 0), jb(4 * lig + 1), jb(4 * lig + 2), jb(4 * lig + 3));
+  int mti, mtw;
+  rng.finish(mti, mtw);
+  if (lane0) {
+    ReplicaState* rs = P.rs + r;
+    rs->jmin = jmin; rs->jtail = jtail;
+    rs->jinvalid = jinvalid ? 1 : 0;
+    rs->n_fullcopy += n_full;
+    rs->min_cost = min_cost;
+    rs->n_moves += n_moves;
+    rs->n_accepted += n_acc;
+    rs->n_improved += n_impr;
+    rs->n_randpick += n_rpick;
+    rs->mti = mti;
+    rs->mtw = mtw;
+  }
+}
+
+}  // namespace tnco

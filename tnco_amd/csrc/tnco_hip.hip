@@ -583,6 +583,12 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
   const bool f32 = d->cost_dtype == TNCO_HIP_F32;
   const bool pow2u = uniform && (dim_u & (dim_u - 1)) == 0;
   h->generic = !(pow2u && !d->sparse_mask && !f32);
+  // Few small trees: every replica's whole tree in LDS during a launch (sa_small.h) -- if all the replicas are resident
+  // at once (decided below, where the device is known).
+  h->small_tree = !fw && !h->hyper && !h->generic && W <= 2 && n >= 2 && n - 1 <= SMALL_MAX_INTERNAL && LPS == 1;
+#ifdef TNCO_NO_SMALL_TREE  // (the A/B library of tools/small_tree_ab.py: `make nosmall`)
+  h->small_tree = false;
+#endif
   Params& P = h->P;
   P.n = n; P.N = N; P.I = I; P.W = W; P.R = R;
   P.BS = (32 + 8 * W + 31) / 32 * 32;
@@ -1010,6 +1016,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       hipLaunchKernelGGL(set_minlinks_kernel, dim3((unsigned)R), dim3(64), 0, h->stream, P, dmin, d->min_links_stride == 0 ? (int64_t)0 : 3 * (int64_t)N);
       HIP_TRY(hipGetLastError());
       HIP_TRY(h->sync_all());
+      h->small_tree = false;  // (the LDS-resident kernel assumes the log starts at the checkpoint)
     }
     if (fw && d->min_slices) {  // row 1 of every replica's [2][L] slices record
       std::vector<uint64_t> rows((size_t)R * LKw, 0);
@@ -1067,6 +1074,10 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     if (!fw) {
       hipDeviceProp_t prop;
       HIP_TRY(hipGetDeviceProperties(&prop, d->device));
+      // The LDS-resident kernel is bound by the instructions of one wavefront per SIMD (16 replicas), the HBM kernel by
+      // memory latency per replica: LDS wins x1.6 ... x1.8 as long as one round of its blocks holds every replica (16384
+      // replicas up to 64 leaves, 8192 up to 128), and loses beyond (profiles/r05_small_tree_ab.txt).
+      if (h->small_tree && R > (int64_t)small_replicas_per_cu(n - 1) * prop.multiProcessorCount) h->small_tree = false;
       h->run_slots = run_blocks_per_cu(h) * prop.multiProcessorCount;
       if (h->run_slots > 0 && nblocks > h->run_slots) {
         const double rounds = (double)nblocks / (double)h->run_slots, part = rounds - std::floor(rounds);
@@ -1080,7 +1091,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       G = 2;
     }
     if (const char* e = std::getenv("TNCO_HIP_GROUPS")) G = std::max(1, std::min((int)tnco_hip_ctx::MAX_GROUPS, std::atoi(e)));
-    if (nblocks < 2 * G) G = 1;
+    if (h->small_tree || nblocks < 2 * G) G = 1;
     if (G > 1) {
       for (int q = 0; q < G; ++q) {
         HIP_TRY(tnco::StreamCache::get().take(&h->gstream[q], h->device));
@@ -1341,7 +1352,7 @@ int tnco_hip_diag_kernel_times(tnco_hip_handle h, double* ms4, int64_t* launches
   return TNCO_HIP_OK;
 }
 
-int tnco_hip_diag_launch_groups(tnco_hip_handle h) { return h ? h->n_groups : 0; }
+int tnco_hip_diag_launch_groups(tnco_hip_handle h) { return h ? (h->small_tree ? 0 : h->n_groups) : 0; }
 
 int64_t tnco_hip_diag_device_bytes(tnco_hip_handle h) { return h ? h->bytes : 0; }
 

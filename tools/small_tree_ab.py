@@ -1,0 +1,82 @@
+"""A/B of the LDS-resident small-tree kernel (csrc/sa_small.h) against the HBM kernel, sweeps only.
+
+For {64, 84}-leaf 3-regular networks (<= 2 mask words) and a range of replica counts: the same seeded runs once through
+the library in the tree (which picks the LDS kernel while one round of its blocks holds every replica) and once through
+build_variants/lib_nosmall.so (`make -C tnco_amd/csrc nosmall`: the same sources with -DTNCO_NO_SMALL_TREE, always the HBM
+kernel) -- move-evals/s of the sweeps, which kernel the tree's library chose, and whether the two end states are the same
+bit for bit (counters, current and minimum costs of every replica, the best tree).
+Run on the GPU box: python tools/small_tree_ab.py > gpurun_out/r05/small_tree_ab.txt
+"""
+import argparse
+import hashlib
+import json
+import os
+import pathlib
+import subprocess
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+
+def child(a):
+    import numpy as np
+    from tnco_amd import core, synthetic as syn
+    for n in [int(x) for x in a.leaves.split(",")]:
+        prob = syn.regular_problem(n, graph_seed=7 if n == 64 else 11)
+        betas = syn.linear_betas(0.0, 100.0, a.sweeps)
+        for R in [int(x) for x in a.runs.split(",")]:
+            seeds = syn.replica_seeds(R)
+            links = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds)
+            with core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds) as gpu:
+                gpu.run(betas[:10]); gpu.sync()
+                m0 = gpu.counters()["moves"]
+                t0 = time.perf_counter()
+                for s in range(10, len(betas), 1000):
+                    gpu.run(betas[s:s + 1000])
+                gpu.sync()
+                dt = time.perf_counter() - t0
+                c = gpu.counters()
+                cur, mn = gpu.costs()
+                hs = hashlib.sha256()
+                for x in (np.asarray(cur), np.asarray(mn), *gpu.tree(int(np.argmin(mn)), which_min=True)):
+                    hs.update(np.ascontiguousarray(x).tobytes())
+                hs.update(repr((c["moves"], c["accepted"], c["improved"], c["random_picks"])).encode())
+                print(json.dumps(dict(n=n, W=int(prob.leaf_masks.shape[1]), R=R, rate=(c["moves"] - m0) / dt, lds=gpu.launch_groups == 0,
+                                      state=hs.hexdigest(), bad=int(gpu.validate()[0]))), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sweeps", type=int, default=2010)
+    ap.add_argument("--runs", default="64,512,2048,4096,8192,16384,32768,65536")
+    ap.add_argument("--leaves", default="64,84")
+    ap.add_argument("--child", action="store_true")
+    a = ap.parse_args()
+    if a.child:
+        return child(a)
+    variant = ROOT / "build_variants" / "lib_nosmall.so"
+    assert variant.exists(), "make -C tnco_amd/csrc nosmall"
+    res = {}
+    for name, lib in (("tree", None), ("hbm", str(variant))):
+        env = dict(os.environ)
+        env.pop("TNCO_HIP_LIB", None)
+        if lib:
+            env["TNCO_HIP_LIB"] = lib
+        out = subprocess.run([sys.executable, __file__, "--child", "--sweeps", str(a.sweeps), "--runs", a.runs, "--leaves", a.leaves],
+                             env=env, capture_output=True, text=True, stdin=subprocess.DEVNULL)
+        if out.returncode:
+            sys.exit(out.stderr[-3000:])
+        res[name] = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+    print(f"# {a.sweeps} sweeps, beta 0 -> 100, Metropolis, float64, 3-regular networks; 'library' = tnco_amd/libtnco_hip.so, 'HBM' = the same sources with -DTNCO_NO_SMALL_TREE")
+    print("| leaves | mask words | replicas | HBM kernel move-evals/s | library move-evals/s | library's kernel | library / HBM | same end state | replicas failing validate |")
+    print("|---|---|---|---|---|---|---|---|---|")
+    for t, h in zip(res["tree"], res["hbm"]):
+        assert (t["n"], t["R"]) == (h["n"], h["R"]) and not h["lds"]
+        print(f"| {t['n']} | {t['W']} | {t['R']} | {h['rate']:.3e} | {t['rate']:.3e} | {'LDS-resident' if t['lds'] else 'HBM'} | {t['rate'] / h['rate']:.2f} | "
+              f"{t['state'] == h['state']} | {t['bad'] + h['bad']} |")
+
+
+if __name__ == "__main__":
+    main()
