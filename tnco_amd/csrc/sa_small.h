@@ -32,6 +32,7 @@ struct __attribute__((aligned(32))) SmallRec {
 };
 static_assert(sizeof(SmallRec) == 32, "SmallRec");
 constexpr int SMALL_MAX_INTERNAL = 127;  // (links are bytes, 0xFF = null: at most 254 nodes)
+constexpr uint32_t SMALL_RNG_LOW = 12;  // draws left in a replica's ring below which the wavefront refills (see the loop)
 constexpr int SMALL_TPB = 64;            // one wavefront = 16 replicas per block: few replicas still spread over the CUs
 // LDS of a block of sa_small_kernel<NI, SMALL_TPB> (the __shared__ arrays below) and the replicas one CU (160 KiB) holds
 constexpr int small_lds_bytes(int NI) {
@@ -90,13 +91,19 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
     for (int i = lig; i < n; i += L) lpar[i] = (uint8_t)lp[(int64_t)i * LPS];
   }
   // (LDS operations of one wavefront are executed in order: no barrier between a group's own writes and reads)
+  // (no branches around the reads: a divergent branch costs the sixteen replicas of the wavefront more than a read does)
   auto legs_of = [&](int x) -> M {  // this lane's word of the legs of node x (lanes 2, 3: nothing)
     M m;
-    m.w[0] = 0ull;
-    if (lig < 2) m.w[0] = x < n ? leaf[2 * x + lig] : rec[x - n].legs[lig];
+    lvu64* a = x < n ? leaf + 2 * x + (lig & 1) : (lvu64*)&rec[x - n].legs[lig & 1];
+    const uint64_t v = *a;
+    m.w[0] = lig < 2 ? v : 0ull;
     return m;
   };
-  auto partial_of = [&](int x) -> double { return x < n ? 0.0 : (double)rec[x - n].partial; };
+  auto partial_of = [&](int x) -> double {
+    const double v = rec[x < n ? 0 : x - n].partial;
+    return x < n ? 0.0 : v;
+  };
+  auto head_of = [&](int i) -> uint64_t { return *(lvu64*)&rec[i]; };  // links | cexp << 32: one read
   auto set_parent = [&](int x, int p) {
     if (!lane0) return;
     if (x < n) lpar[x] = (uint8_t)p;
@@ -106,7 +113,6 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
   R rng;
   const ReplicaState* rs0 = P.rs + r;
   rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs0->mti, rs0->mtw, lig);
-  int pend_age = 0;
   double min_cost = rs0->min_cost;
   uint32_t jmin = rs0->jmin, jtail = rs0->jtail;
   bool jinvalid = rs0->jinvalid != 0;
@@ -130,45 +136,71 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
   M m0 = mzero<K>(), m1 = mzero<K>();
   double p0 = 0, p1 = 0;
   bool active = true;
+  // the beta of the NEXT sweep is loaded while this one runs (see the schedule below)
+  double beta_next = betas[0], beta_tmp = 0;
+  bool bpend = false;
+  TNCO_PROF_DECL;  // (diagnostic builds: cycles of [generator | sweep begin | move | sweep end] per iteration)
   // (one loop for the wavefront, left when no replica of it has sweeps to do: a per-replica `break`
   // made the compiler run the sweeps of the sixteen replicas in step)
   while (__ballot(active) != 0ull) {  // (B < 0: between two sweeps)
-    if (active) {
-    // the generator: loads of the next block are issued when there is room and consumed a few
-    // iterations later, when they have surely landed (a wait here would stall sixteen replicas)
-    if (rng.pend) {
-      if (++pend_age >= 6 || rng.avail() < 6u) {
-        rng.produce();
-        pend_age = 0;
+    TNCO_PROF_T(0);
+    // The generator and the schedule.  Every global load of the loop is issued HERE and consumed HERE one iteration
+    // later: vmcnt retires in order, so a wait anywhere else waits for the youngest load of sixteen replicas (a beta
+    // loaded where the sweep begins and used by its first move cost ~700 cycles per iteration).  A block of 16 draws is
+    // requested by every replica that has room for one as soon as ANY replica of the wavefront runs low: the replicas
+    // draw at about the same rate, so the wavefront executes this section in two iterations out of ~4.5 instead of
+    // in every one (it was 28 % of the loop, profiles/r05_small_stage_cycles.txt).
+    if (__ballot(active && (rng.pend || bpend)) != 0ull) {
+      if (active && rng.pend) rng.produce();
+      if (active && bpend) {
+        beta_next = beta_tmp;
+        bpend = false;
       }
-    } else if (rng.room()) {
-      rng.request();
     }
+    if (__ballot(active && rng.avail() < SMALL_RNG_LOW) != 0ull) {
+      if (active && rng.room()) rng.request();
+    }
+    if (active) {
+    // (an iteration draws at most 4 numbers and a requested block arrives one iteration later: with SMALL_RNG_LOW = 12
+    //  the ring never runs dry -- kept so that the plain next() below is backed whatever the constants)
+    while (rng.avail() < 4u) {
+      if (!rng.pend) rng.request();
+      rng.produce();
+    }
+    TNCO_PROF_T(1);
     if (B < 0) {
       // optimizer.hpp:103-112: a random leaf, its parent is B; the total cost is the root's partial cost
-      const uint32_t x = rng.next_sync();
+      const uint32_t x = rng.next();
+      total = rec[root - n].partial;
       B = lpar[x % (uint32_t)n];
-      const uint32_t lk = rec[B - n].links;
+      const uint64_t hd = head_of(B - n);
+      partB = rec[B - n].partial;
+      const uint32_t lk = (uint32_t)hd;
       bl = (int)(lk & 0xFF); br = (int)((lk >> 8) & 0xFF);
       A = (int)((lk >> 16) & 0xFF);
       if (A == 0xFF) A = -1;
-      eB = rec[B - n].cexp;
-      partB = rec[B - n].partial;
-      total = rec[root - n].partial;
-      beta = betas[step];
+      eB = (uint32_t)(hd >> 32);
+      beta = beta_next;
+      beta_tmp = betas[step + 1 < (int)n_steps ? step + 1 : step];
+      bpend = true;
       m0 = legs_of(bl); m1 = legs_of(br);
       p0 = partial_of(bl); p1 = partial_of(br);
 #ifdef TNCO_SMALL_DEBUG
       if (lane0 && r < 2) printf("r%d begin step %d leaf %u B %d A %d bl %d br %d\n", (int)r, step, x % (uint32_t)n, B, A, bl, br);
 #endif
     }
+    TNCO_PROF_T(2);
     if (A >= 0) {
       // ---- one move evaluation (optimizer.hpp:117-192) --------------------------------------------
-      const uint32_t lkA = rec[A - n].links;
+      const uint64_t hdA = head_of(A - n);
+      // the draws of this move -- [pick] x1 x2 -- read together: one LDS round trip instead of three
+      const uint32_t d0 = rng.ring[rng.cons & (R::RING - 1)], d1 = rng.ring[(rng.cons + 1u) & (R::RING - 1)],
+                     d2 = rng.ring[(rng.cons + 2u) & (R::RING - 1)];
+      const uint32_t lkA = (uint32_t)hdA;
       int al = (int)(lkA & 0xFF), ar = (int)((lkA >> 8) & 0xFF);
       int aP = (int)((lkA >> 16) & 0xFF);
       if (aP == 0xFF) aP = -1;
-      uint32_t eA = rec[A - n].cexp;
+      uint32_t eA = (uint32_t)(hdA >> 32);
       const bool c_is_right = (al == B);
       const int C = c_is_right ? ar : al;
       const M mC = legs_of(C);
@@ -180,13 +212,10 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
       w0 = gsum<LOG2L>(w0);
       w1 = gsum<LOG2L>(w1);
       const bool inter0 = (w0 >> 26) != 0, inter1 = (w1 >> 26) != 0;
-      bool pick0;  // get_ctree_nn, optimize/optimizer.hpp:128-144
-      if (disable_shared || (inter0 && inter1)) {
-        pick0 = (rng.next_sync() & 1u) != 0;
-        ++n_rpick;
-      } else {
-        pick0 = inter0;
-      }
+      // get_ctree_nn, optimize/optimizer.hpp:128-144
+      const bool rpick = disable_shared || (inter0 && inter1);
+      const bool pick0 = rpick ? (d0 & 1u) != 0 : inter0;
+      n_rpick += rpick ? 1u : 0u;
       const M mD = msel<K>(pick0, m0, m1), mE = msel<K>(pick0, m1, m0);
       const M newB = mxor<K>(mD, mC);
       const double pD = pick0 ? p0 : p1, pE = pick0 ? p1 : p0;
@@ -197,7 +226,8 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
       double ccB = pow2_cost((int)eB, 0), ccA = pow2_cost((int)eA, 0);
       const double delta = (nB - ccB) + (nA - ccA);  // :158
       ++n_moves;
-      const uint32_t x1 = rng.next_sync(), x2 = rng.next_sync();  // :162 generate_canonical<double, 53>
+      const uint32_t x1 = rpick ? d1 : d0, x2 = rpick ? d2 : d1;  // :162 generate_canonical<double, 53>
+      rng.cons += rpick ? 3u : 2u;
       double u = ((double)x1 + (double)x2 * 4294967296.0) * 5.421010862427522170037e-20;
       if (u >= 1.0) u = 0.99999999999999988897769753748;
       const bool acc = accept_move(prob_kind, beta, delta, total, u, 0);
@@ -249,6 +279,7 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
       B = A; bl = al; br = ar; eB = eA; partB = partA;
       A = aP;
     }
+    TNCO_PROF_T(3);
     if (A < 0) {
       // ---- B is the root: end of the sweep (optimizer.hpp:194-201) ---------------------------------
       if (lane0) rec[B - n].partial = partB;
@@ -282,6 +313,8 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
       B = -1;
       if (++step >= (int)n_steps) active = false;
     }
+    TNCO_PROF_T(4);
+    TNCO_PROF_ACC;
     }
   }
 
@@ -322,6 +355,7 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
     rs->n_randpick += n_rpick;
     rs->mti = mti;
     rs->mtw = mtw;
+    TNCO_PROF_OUT(rs);
   }
 }
 

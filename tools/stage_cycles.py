@@ -51,6 +51,8 @@ def main():
     names = ["mt19937", "state branches", "landing fence", "store phase"]
     if a.fine:  # library built with -DTNCO_PROFILE=2
         names = ["end-of-sweep blk", "addresses", "load issue", "move evaluation"]
+    if opt.launch_groups == 0:  # few small trees: the LDS-resident kernel (csrc/sa_small.h)
+        names = ["mt19937", "sweep begin", "move", "sweep end"]
     tot = cyc[:4].sum()
     print(f"replica-iterations {it:.3e}  moves {moves:.3e}  moves/iteration {moves / it:.3f}")
     for k in range(4):
