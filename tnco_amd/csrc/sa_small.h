@@ -24,6 +24,19 @@
 
 namespace tnco {
 
+// Stage timing (diagnostic builds, tools/stage_cycles.py): -DTNCO_PROFILE=1 the sections of an iteration
+// [generator | move | sweep end | sweep begin], -DTNCO_PROFILE=2 the parts of a move [operands | costs | acceptance | update].
+#if defined(TNCO_PROFILE) && TNCO_PROFILE == 2
+#define SMALL_PROF_C(i) do { if ((i) == 0) { pt_[0] = pt_[1] = pt_[2] = pt_[3] = pt_[4] = __builtin_amdgcn_s_memtime(); } } while (0)
+#define SMALL_PROF_M(i) pt_[i] = __builtin_amdgcn_s_memtime()
+#elif defined(TNCO_PROFILE)
+#define SMALL_PROF_C(i) pt_[i] = __builtin_amdgcn_s_memtime()
+#define SMALL_PROF_M(i)
+#else
+#define SMALL_PROF_C(i)
+#define SMALL_PROF_M(i)
+#endif
+
 struct __attribute__((aligned(32))) SmallRec {
   uint32_t links;   // left | right << 8 | parent << 16   (0xFF: null)
   uint32_t cexp;    // exponent of the contraction cost
@@ -40,6 +53,31 @@ constexpr int small_lds_bytes(int NI) {
 }
 constexpr int small_replicas_per_cu(int ni) { return (160 * 1024 / small_lds_bytes(ni <= 63 ? 63 : 127)) * (SMALL_TPB / 4); }
 static_assert(small_replicas_per_cu(63) == 64 && small_replicas_per_cu(127) == 32, "LDS budget of the small-tree kernel");
+
+// accept_move (sa_sweep.h: same rule, same filter, same margin, same decision) without its early returns: one branch, taken
+// when some replica of the wavefront needs the double-precision pow.
+__device__ __forceinline__ bool small_accept(int kind, double beta, double delta, double total, double u) {
+  const bool yes = kind == 0 || delta <= 0;        // base.hpp; greedy.hpp / mh.hpp: p = 1
+  const bool zero = kind == 1 || total == 0;       // greedy.hpp: p = 0; mh.hpp:55-57
+  const double x = 1.0 + delta / total;
+  const float uf = (float)u, xf = (float)x, bf = (float)beta;
+  const float lu = __log2f(uf), lx = __log2f(xf);
+  const float lp = -bf * lx;
+  const float margin = (fabsf(lp) + fabsf(lu)) * 2e-6f + fabsf(bf) * 3e-7f + 1e-5f;
+  const bool ok = uf > 1e-30f && xf < 1e30f && fabsf(lp) < 1e30f && beta >= 0.0;
+  const bool sure_yes = ok && lu < lp - margin, sure_no = ok && lu > lp + margin;
+  bool acc = yes || (zero ? u <= 0.0 : sure_yes);
+  if (!yes && !zero && !sure_yes && !sure_no) acc = accept_exact(x, beta, u, 0);
+  return acc;
+}
+
+// x % n through the reciprocal (n <= 128; the quotient estimate is off by one at most)
+__device__ __forceinline__ uint32_t small_mod(uint32_t x, uint32_t n, double inv_n) {
+  const uint32_t q = (uint32_t)((double)x * inv_n);
+  uint32_t r = x - q * n;
+  r = (int32_t)r < 0 ? r + n : r;
+  return r >= n ? r - n : r;
+}
 
 __device__ __forceinline__ uint32_t small_exp_of(double c) {
   return (uint32_t)((__double2hiint(c) >> 20) & 0x7ff) - 1023u;  // c = 2^e exactly (or +inf -> 1024)
@@ -104,11 +142,7 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
     return x < n ? 0.0 : v;
   };
   auto head_of = [&](int i) -> uint64_t { return *(lvu64*)&rec[i]; };  // links | cexp << 32: one read
-  auto set_parent = [&](int x, int p) {
-    if (!lane0) return;
-    if (x < n) lpar[x] = (uint8_t)p;
-    else ((lvu8*)&rec[x - n].links)[2] = (uint8_t)p;
-  };
+  auto parent_byte = [&](int x) -> lvu8* { return x < n ? lpar + x : (lvu8*)&rec[x - n].links + 2; };
 
   R rng;
   const ReplicaState* rs0 = P.rs + r;
@@ -132,18 +166,24 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
   int step = 0;
   int B = -1, bl = 0, br = 0, A = -1;
   uint32_t eB = 0;
-  double partB = 0, total = 0, beta = 0;
+  double partB = 0, beta = 0;
+  double total = rec[root - n].partial;  // (optimizer.hpp:103: the root's partial cost where a sweep begins)
+  const double inv_n = 1.0 / (double)n;
   M m0 = mzero<K>(), m1 = mzero<K>();
   double p0 = 0, p1 = 0;
+  // ... and, read one iteration ahead: A's record (links | cost exponent << 32), the legs and the partial cost of B's sibling
+  uint64_t hdA = 0;
+  M mC = mzero<K>();
+  double pC = 0;
   bool active = true;
   // the beta of the NEXT sweep is loaded while this one runs (see the schedule below)
   double beta_next = betas[0], beta_tmp = 0;
   bool bpend = false;
-  TNCO_PROF_DECL;  // (diagnostic builds: cycles of [generator | sweep begin | move | sweep end] per iteration)
+  TNCO_PROF_DECL;  // (diagnostic builds: cycles of [generator | move | sweep end | sweep begin] per iteration)
   // (one loop for the wavefront, left when no replica of it has sweeps to do: a per-replica `break`
   // made the compiler run the sweeps of the sixteen replicas in step)
   while (__ballot(active) != 0ull) {  // (B < 0: between two sweeps)
-    TNCO_PROF_T(0);
+    SMALL_PROF_C(0);
     // The generator and the schedule.  Every global load of the loop is issued HERE and consumed HERE one iteration
     // later: vmcnt retires in order, so a wait anywhere else waits for the youngest load of sixteen replicas (a beta
     // loaded where the sweep begins and used by its first move cost ~700 cycles per iteration).  A block of 16 draws is
@@ -167,50 +207,36 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
       if (!rng.pend) rng.request();
       rng.produce();
     }
-    TNCO_PROF_T(1);
-    if (B < 0) {
-      // optimizer.hpp:103-112: a random leaf, its parent is B; the total cost is the root's partial cost
-      const uint32_t x = rng.next();
-      total = rec[root - n].partial;
-      B = lpar[x % (uint32_t)n];
-      const uint64_t hd = head_of(B - n);
-      partB = rec[B - n].partial;
-      const uint32_t lk = (uint32_t)hd;
-      bl = (int)(lk & 0xFF); br = (int)((lk >> 8) & 0xFF);
-      A = (int)((lk >> 16) & 0xFF);
-      if (A == 0xFF) A = -1;
-      eB = (uint32_t)(hd >> 32);
-      beta = beta_next;
-      beta_tmp = betas[step + 1 < (int)n_steps ? step + 1 : step];
-      bpend = true;
-      m0 = legs_of(bl); m1 = legs_of(br);
-      p0 = partial_of(bl); p1 = partial_of(br);
-#ifdef TNCO_SMALL_DEBUG
-      if (lane0 && r < 2) printf("r%d begin step %d leaf %u B %d A %d bl %d br %d\n", (int)r, step, x % (uint32_t)n, B, A, bl, br);
-#endif
-    }
-    TNCO_PROF_T(2);
+    // the draws this iteration may use -- a move's [pick] x1 x2, then the leaf of the next sweep -- read together, ahead
+    // of their use: one LDS round trip instead of four, none of them inside a dependent chain
+    const uint32_t d0 = rng.ring[rng.cons & (R::RING - 1)], d1 = rng.ring[(rng.cons + 1u) & (R::RING - 1)],
+                   d2 = rng.ring[(rng.cons + 2u) & (R::RING - 1)], d3 = rng.ring[(rng.cons + 3u) & (R::RING - 1)];
+    uint32_t drawn = 0;  // ... and how many of them the move took
+    SMALL_PROF_C(1);
     if (A >= 0) {
-      // ---- one move evaluation (optimizer.hpp:117-192) --------------------------------------------
-      const uint64_t hdA = head_of(A - n);
-      // the draws of this move -- [pick] x1 x2 -- read together: one LDS round trip instead of three
-      const uint32_t d0 = rng.ring[rng.cons & (R::RING - 1)], d1 = rng.ring[(rng.cons + 1u) & (R::RING - 1)],
-                     d2 = rng.ring[(rng.cons + 2u) & (R::RING - 1)];
+      // ---- one move evaluation (optimizer.hpp:117-192); its operands -- A's record, the legs and the partial cost of
+      // C, B's sibling -- were read during the previous iteration ---------------------------------------------------
+      SMALL_PROF_M(0);
       const uint32_t lkA = (uint32_t)hdA;
       int al = (int)(lkA & 0xFF), ar = (int)((lkA >> 8) & 0xFF);
       int aP = (int)((lkA >> 16) & 0xFF);
       if (aP == 0xFF) aP = -1;
-      uint32_t eA = (uint32_t)(hdA >> 32);
+      const uint32_t eA = (uint32_t)(hdA >> 32);
       const bool c_is_right = (al == B);
       const int C = c_is_right ? ar : al;
-      const M mC = legs_of(C);
-      const double pC = partial_of(C);
+      // next iteration's operands, first half: the record of A's parent (nothing of it changes in this move)
+      const uint64_t hdN = head_of(aP < 0 ? 0 : aP - n);
       uint32_t w0 = mpopc<K>(mor<K>(mxor<K>(m0, mC), m1)) | (mpopc<K>(mor<K>(m0, mC)) << 13) |
                     ((mnonzero<K>(mand<K>(m0, mC)) ? 1u : 0u) << 26);
       uint32_t w1 = mpopc<K>(mor<K>(mxor<K>(m1, mC), m0)) | (mpopc<K>(mor<K>(m1, mC)) << 13) |
                     ((mnonzero<K>(mand<K>(m1, mC)) ? 1u : 0u) << 26);
+      SMALL_PROF_M(1);
       w0 = gsum<LOG2L>(w0);
       w1 = gsum<LOG2L>(w1);
+      // ... second half: A's sibling under that parent (another subtree: untouched by this move)
+      const int CN = (int)((uint32_t)hdN & 0xFF) == A ? (int)(((uint32_t)hdN >> 8) & 0xFF) : (int)((uint32_t)hdN & 0xFF);
+      const M mCN = legs_of(CN);
+      const double pCN = partial_of(CN);
       const bool inter0 = (w0 >> 26) != 0, inter1 = (w1 >> 26) != 0;
       // get_ctree_nn, optimize/optimizer.hpp:128-144
       const bool rpick = disable_shared || (inter0 && inter1);
@@ -223,97 +249,120 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
       const uint32_t enA = (uint32_t)log2d * ((pick0 ? w0 : w1) & 0x1fffu);
       const uint32_t enB = (uint32_t)log2d * (((pick0 ? w0 : w1) >> 13) & 0x1fffu);
       const double nA = pow2_cost((int)enA, 0), nB = pow2_cost((int)enB, 0);
-      double ccB = pow2_cost((int)eB, 0), ccA = pow2_cost((int)eA, 0);
-      const double delta = (nB - ccB) + (nA - ccA);  // :158
+      const double ccB0 = pow2_cost((int)eB, 0), ccA0 = pow2_cost((int)eA, 0);
+      const double delta = (nB - ccB0) + (nA - ccA0);  // :158
       ++n_moves;
+      SMALL_PROF_M(2);
       const uint32_t x1 = rpick ? d1 : d0, x2 = rpick ? d2 : d1;  // :162 generate_canonical<double, 53>
-      rng.cons += rpick ? 3u : 2u;
+      drawn = rpick ? 3u : 2u;
       double u = ((double)x1 + (double)x2 * 4294967296.0) * 5.421010862427522170037e-20;
       if (u >= 1.0) u = 0.99999999999999988897769753748;
-      const bool acc = accept_move(prob_kind, beta, delta, total, u, 0);
-      double pEcur = pE, pCcur = pC;
-      M mBnow, mX;
-      if (acc) {
-        ++n_acc;
-        // Tree::swap_with_nn(E), include/tnco/tree.hpp:176-184
-        if (pick0) br = C; else bl = C;
-        if (c_is_right) ar = E; else al = E;
-        set_parent(C, B);
-        set_parent(E, A);
-        if (lig < 2) rec[B - n].legs[lig] = newB.w[0];
-        if (lane0) rec[A - n].links = (uint32_t)al | ((uint32_t)ar << 8) | ((uint32_t)(aP & 0xFF) << 16);
-        eB = enB; ccB = nB;
-        eA = enA; ccA = nA;
-        total = total + delta;  // :177
-        pEcur = pC;
-        pCcur = pE;
-        mBnow = newB;
-        mX = mE;
-        if (!jinvalid) {  // rotation log (best tree = checkpoint + log prefix)
-          if (jtail == jcap) {
-            jinvalid = true;
-          } else {
-            if (lane0) jb((int)(jtail & 15u)) = E;
-            ++jtail;
-            if ((jtail & 15u) == 0u)
-              *reinterpret_cast<int4*>(jlog + (jtail - 16u) + 4 * lig) =
-                  make_int4(jb(4 * lig + 0), jb(4 * lig + 1), jb(4 * lig + 2), jb(4 * lig + 3));
-          }
-        }
-      } else {
-        mBnow = mxor<K>(m0, m1);
-        mX = mC;
-      }
+      const bool acc = small_accept(prob_kind, beta, delta, total, u);
+      SMALL_PROF_M(3);
+      // Tree::swap_with_nn(E), include/tnco/tree.hpp:176-184 -- the values by selection, the stores under one branch
+      n_acc += acc ? 1u : 0u;
+      br = (acc && pick0) ? C : br;
+      bl = (acc && !pick0) ? C : bl;
+      ar = (acc && c_is_right) ? E : ar;
+      al = (acc && !c_is_right) ? E : al;
+      const uint32_t eBn = acc ? enB : eB, eAn = acc ? enA : eA;
+      const double ccB = acc ? nB : ccB0, ccA = acc ? nA : ccA0;
+      total = acc ? total + delta : total;  // :177
+      const double pEcur = acc ? pC : pE, pCcur = acc ? pE : pC;
+      const M mBnow = msel<K>(acc, newB, mxor<K>(m0, m1)), mX = msel<K>(acc, mE, mC);
       // :185-188
       partB = (pD + pEcur) + ccB;
       const double partA = (partB + pCcur) + ccA;
+      // rotation log (best tree = checkpoint + log prefix): full -> the next improvement re-bases the checkpoint
+      const bool logged = acc && !jinvalid && jtail != jcap;
+      jinvalid = jinvalid || (acc && jtail == jcap);
       if (lane0) {
-        rec[B - n].links = (uint32_t)bl | ((uint32_t)br << 8) | ((uint32_t)A << 16);
-        rec[B - n].cexp = eB;
+        if (acc) {
+          *parent_byte(C) = (uint8_t)B;
+          *parent_byte(E) = (uint8_t)A;
+          if (logged) jb((int)(jtail & 15u)) = E;
+        }
+        // (A's own record is written when A is B -- in the next move, or where the sweep ends)
+        *(lvu64*)&rec[B - n] = (uint64_t)((uint32_t)bl | ((uint32_t)br << 8) | ((uint32_t)A << 16)) | ((uint64_t)eBn << 32);
         rec[B - n].partial = partB;
-        rec[A - n].cexp = eA;
       }
+      if (acc && lig < 2) rec[B - n].legs[lig] = newB.w[0];
+      jtail += logged ? 1u : 0u;
+      if (logged && (jtail & 15u) == 0u)  // a 64-byte piece of the log is complete
+        *reinterpret_cast<int4*>(jlog + (jtail - 16u) + 4 * lig) =
+            make_int4(jb(4 * lig + 0), jb(4 * lig + 1), jb(4 * lig + 2), jb(4 * lig + 3));
       // :191  B <- A
       if (c_is_right) { m0 = mBnow; m1 = mX; p0 = partB; p1 = pCcur; }
       else            { m1 = mBnow; m0 = mX; p1 = partB; p0 = pCcur; }
-      B = A; bl = al; br = ar; eB = eA; partB = partA;
+      B = A; bl = al; br = ar; eB = eAn; partB = partA;
       A = aP;
+      hdA = hdN; mC = mCN; pC = pCN;
+      SMALL_PROF_M(4);
     }
-    TNCO_PROF_T(3);
+    SMALL_PROF_C(2);
+    SMALL_PROF_C(3);
     if (A < 0) {
-      // ---- B is the root: end of the sweep (optimizer.hpp:194-201) ---------------------------------
-      if (lane0) rec[B - n].partial = partB;
-      if (partB < min_cost) {
-        min_cost = partB;
-        ++n_impr;
-        if (jinvalid) {  // the log overflowed: re-base the checkpoint on the current tree
-          Links* __restrict__ ml = P.minlinks + r * (int64_t)N;
-          for (int i = lig; i < N; i += L) {
-            Links o;
-            if (i < n) {
-              o.left = -1; o.right = -1; o.parent = lpar[i];
-            } else {
-              const uint32_t lk = rec[i - n].links;
-              o.left = (int)(lk & 0xFF); o.right = (int)((lk >> 8) & 0xFF);
-              o.parent = (int)((lk >> 16) & 0xFF);
-            }
-            if (o.parent == 0xFF) o.parent = -1;
-            o.pad = 0;
-            ml[i] = o;
-          }
-          jtail = 0;
-          jinvalid = false;
-          ++n_full;
+      // ---- between two sweeps: the end of one (B is the root, optimizer.hpp:194-201) and the begin of the next
+      // (:103-112) in one section -- the loads of the second overlap the stores of the first ------------------------
+      const uint32_t x = drawn == 0u ? d0 : (drawn == 2u ? d2 : d3);
+      if (B >= 0) {
+        if (lane0) {
+          *(lvu64*)&rec[B - n] = (uint64_t)((uint32_t)bl | ((uint32_t)br << 8) | (0xFFu << 16)) | ((uint64_t)eB << 32);
+          rec[B - n].partial = partB;
         }
-        jmin = jtail;
+        if (partB < min_cost) {
+          min_cost = partB;
+          ++n_impr;
+          if (jinvalid) {  // the log overflowed: re-base the checkpoint on the current tree
+            Links* __restrict__ ml = P.minlinks + r * (int64_t)N;
+            for (int i = lig; i < N; i += L) {
+              Links o;
+              if (i < n) {
+                o.left = -1; o.right = -1; o.parent = lpar[i];
+              } else {
+                const uint32_t lk = rec[i - n].links;
+                o.left = (int)(lk & 0xFF); o.right = (int)((lk >> 8) & 0xFF);
+                o.parent = (int)((lk >> 16) & 0xFF);
+              }
+              if (o.parent == 0xFF) o.parent = -1;
+              o.pad = 0;
+              ml[i] = o;
+            }
+            jtail = 0;
+            jinvalid = false;
+            ++n_full;
+          }
+          jmin = jtail;
+        }
+        total = partB;  // (the next sweep's total cost: the root's partial cost)
+        B = -1;
+        if (++step >= (int)n_steps) active = false;
       }
-#ifdef TNCO_SMALL_DEBUG
-      if (lane0 && r < 2) printf("r%d end step %d moves %u\n", (int)r, step, n_moves);
-#endif
-      B = -1;
-      if (++step >= (int)n_steps) active = false;
+      SMALL_PROF_C(3);
+      if (active) {
+        // a random leaf, its parent is B; the total cost is the root's partial cost
+        ++drawn;
+        B = lpar[small_mod(x, (uint32_t)n, inv_n)];
+        const uint64_t hd = head_of(B - n);
+        partB = rec[B - n].partial;
+        const uint32_t lk = (uint32_t)hd;
+        bl = (int)(lk & 0xFF); br = (int)((lk >> 8) & 0xFF);
+        A = (int)((lk >> 16) & 0xFF);
+        if (A == 0xFF) A = -1;
+        eB = (uint32_t)(hd >> 32);
+        beta = beta_next;
+        beta_tmp = betas[step + 1 < (int)n_steps ? step + 1 : step];
+        bpend = true;
+        hdA = head_of(A < 0 ? 0 : A - n);  // the first move's operands
+        m0 = legs_of(bl); m1 = legs_of(br);
+        p0 = partial_of(bl); p1 = partial_of(br);
+        const int C = (int)((uint32_t)hdA & 0xFF) == B ? (int)(((uint32_t)hdA >> 8) & 0xFF) : (int)((uint32_t)hdA & 0xFF);
+        mC = legs_of(C);
+        pC = partial_of(C);
+      }
     }
-    TNCO_PROF_T(4);
+    rng.cons += drawn;
+    SMALL_PROF_C(4);
     TNCO_PROF_ACC;
     }
   }

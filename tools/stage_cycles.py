@@ -52,7 +52,9 @@ def main():
     if a.fine:  # library built with -DTNCO_PROFILE=2
         names = ["end-of-sweep blk", "addresses", "load issue", "move evaluation"]
     if opt.launch_groups == 0:  # few small trees: the LDS-resident kernel (csrc/sa_small.h)
-        names = ["mt19937", "sweep begin", "move", "sweep end"]
+        names = ["mt19937", "move", "sweep end", "sweep begin"]
+        if a.fine:  # (-DTNCO_PROFILE=2: inside the move)
+            names = ["move: operands", "move: costs", "move: acceptance", "move: update"]
     tot = cyc[:4].sum()
     print(f"replica-iterations {it:.3e}  moves {moves:.3e}  moves/iteration {moves / it:.3f}")
     for k in range(4):
