@@ -278,14 +278,15 @@ def test_invalid_inputs(core):
 
 
 def test_few_small_trees_run_lds_resident(core, oracle_lib):
-    """csrc/sa_small.h: a handle of few small trees (<= 128 leaves, <= 2 mask words, the fast cost path, no more replicas
-    than the CUs hold at once) keeps every replica's tree in LDS during a launch -- launch_groups == 0 says so.
+    """csrc/sa_small.h: a handle of small trees (<= 128 leaves, <= 2 mask words, the fast cost path; above 64 leaves: no
+    more replicas than the CUs hold in two rounds) keeps every replica's tree in LDS during a launch -- launch_groups == 0
+    says so.
     (a) Same bits as the oracle with launches of 1, 7 and 40 sweeps: 64 leaves (the 63-node instantiation), 84 leaves (the
     127-node one), 10 leaves, 2 leaves.  (b) The same replicas at the head of a batch too large to stay resident run through
     the HBM kernel (launch_groups >= 1) and end in the same state bit for bit: trees, best trees, costs, generator state."""
     for n, gs, R in ((64, 7, 96), (84, 11, 40), (10, 2, 70), (2, 1, 5)):
         prob = H.regular_problem(n, graph_seed=gs, degree=3 if n > 2 else 1)
-        R_big = 20000 if n == 64 else 0
+        R_big = 20000 if n == 84 else 0
         seeds = H.replica_seeds(max(R, R_big), S=n)
         links = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds) if R_big else prob.links(seeds)
         betas = H.linear_betas(0, 60, 48)

@@ -1,18 +1,26 @@
-// sa_small.h -- the sweep kernel for FEW SMALL trees (BASELINE config 2: 64 leaves; the latency regime of README.md): every
+// sa_small.h -- the sweep kernel for SMALL trees (BASELINE config 2: 64 leaves; the latency regime of README.md): every
 // replica's whole tree lives in LDS for the duration of a launch, HBM is touched when the launch starts and ends, by
-// the mt19937 state stream and by the rotation log (one 64-byte piece per 16 accepted moves).
+// the mt19937 state stream, by one beta per sweep and by the rotation log (one 64-byte piece per 16 accepted moves).
 //
 // Same algorithm, same arithmetic and the same draws as sa_run_kernel (Optimizer::update,
-// include/tnco/optimize/infinite_memory/optimizer.hpp:90-221): what differs is where the operands come
-// from.  With the node blocks in HBM a replica advances one memory round trip (~2 microseconds under load, ~3.7 at
-// 4096 replicas) per move and the kernel is a state machine that overlaps the round trips of 192 replicas per CU; here
-// an operand is one LDS access (~100 cycles) away, so the loop is the plain walk: [sweep begin] [move]* [sweep end] per
-// replica, every replica of a wavefront at its own place of its own sweep.  What bounds it is the instruction stream of
-// the wavefront (~900 vector instructions per iteration, one wavefront per SIMD: LDS holds 64 replicas of 64 leaves per
-// CU): 2.1 microseconds per move and replica whatever the number of replicas -- x1.6 ... x1.8 the HBM kernel while one
-// round of blocks holds all the replicas, slower beyond (65536 replicas of 64 leaves: 7.4e9 against 9.0e9 move-evals/s).
-// The host picks accordingly (tnco_hip_create; profiles/r05_small_tree_ab.txt).  History: round 2 had this kernel as an
-// opt-in and measured only the 65536-replica case, round 3 removed it, round 5 re-measured it where it can win.
+// include/tnco/optimize/infinite_memory/optimizer.hpp:90-221): what differs is where the operands come from.  With the
+// node blocks in HBM a replica advances one memory round trip per move (~2 microseconds under load, 3.7 at 4096 replicas)
+// and the kernel is a state machine that overlaps the round trips of 192 replicas per CU.  Here an operand is one LDS
+// access (~130 cycles) away and the loop is the plain walk, every replica of a wavefront at its own place of its own
+// sweep: per iteration [generator] [one move] [end of a sweep + begin of the next].  What bounds it is the instruction
+// stream of the wavefront -- 16 replicas, one wavefront per SIMD because LDS holds 64 replicas of 64 leaves per CU: ~3250
+// cycles = 1.35 microseconds per move and replica whatever the number of replicas (tools/stage_cycles.py:
+// profiles/r05_small_stage_cycles.txt).  Hence the rules of the loop:
+//   * every global load is issued at ONE point of the iteration and consumed there one iteration later (vmcnt retires in
+//     order: a wait elsewhere waits for the youngest load of sixteen replicas);
+//   * the operands of a move (A's record, the legs and partial cost of B's sibling) are read during the previous
+//     iteration, the draws of an iteration together at its top: no LDS round trip inside a dependent chain of the move;
+//   * values by selection, stores under as few branches as possible (a divergent branch costs all sixteen replicas).
+// Measured (profiles/r05_small_tree_ab.txt): x2.3 ... x2.5 the HBM kernel up to 16 384 replicas of 64 leaves (config 2:
+// 2.7e9 move-evals/s against 1.1e9), 1.07e10 from there on (the HBM kernel: 9.0e9 at 65 536 replicas); above 64 leaves a
+// CU holds 32 replicas and the kernel wins while two rounds of blocks hold them.  The host picks accordingly
+// (tnco_hip_create).  History: round 2 had a first version as an opt-in and measured only the 65 536-replica case (6.8e9
+// against 7.4e9), round 3 removed it, round 5 re-measured it where it can win and rebuilt the loop around the rules above.
 //
 // Conditions (host: launch_run_lk<2, 1>): no hyper-indices, uniform power-of-two dims, float64 cost,
 // no sparse legs (the fast cost path), at most 2 mask words (4 lanes x 1 word layout), at most 254

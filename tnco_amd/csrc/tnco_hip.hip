@@ -1074,10 +1074,14 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
     if (!fw) {
       hipDeviceProp_t prop;
       HIP_TRY(hipGetDeviceProperties(&prop, d->device));
-      // The LDS-resident kernel is bound by the instructions of one wavefront per SIMD (16 replicas), the HBM kernel by
-      // memory latency per replica: LDS wins x1.6 ... x1.8 as long as one round of its blocks holds every replica (16384
-      // replicas up to 64 leaves, 8192 up to 128), and loses beyond (profiles/r05_small_tree_ab.txt).
-      if (h->small_tree && R > (int64_t)small_replicas_per_cu(n - 1) * prop.multiProcessorCount) h->small_tree = false;
+      // The LDS-resident kernel is bound by the instruction stream of one wavefront per SIMD (16 replicas; 1.35 us per
+      // move whatever the load), the HBM kernel by memory latency per replica (3.7 us) until ~50 000 replicas saturate it
+      // at 8-9e9 move-evals/s.  Up to 64 leaves a CU holds 64 LDS-resident replicas and the LDS kernel wins at every
+      // replica count (1.07e10 from 16 384 replicas on); beyond, a CU holds 32 and it wins (x2.3 ... x1.15) while two
+      // rounds of its blocks hold the replicas (profiles/r05_small_tree_ab.txt).
+#ifndef TNCO_SMALL_TREE_ALWAYS  // (the other A/B library of tools/small_tree_ab.py: `make allsmall`)
+      if (h->small_tree && n - 1 > 63 && R > 2 * (int64_t)small_replicas_per_cu(n - 1) * prop.multiProcessorCount) h->small_tree = false;
+#endif
       h->run_slots = run_blocks_per_cu(h) * prop.multiProcessorCount;
       if (h->run_slots > 0 && nblocks > h->run_slots) {
         const double rounds = (double)nblocks / (double)h->run_slots, part = rounds - std::floor(rounds);

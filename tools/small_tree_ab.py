@@ -2,8 +2,9 @@
 
 For {64, 84}-leaf 3-regular networks (<= 2 mask words) and a range of replica counts: the same seeded runs once through
 the library in the tree (which picks the LDS kernel while one round of its blocks holds every replica) and once through
-build_variants/lib_nosmall.so (`make -C tnco_amd/csrc nosmall`: the same sources with -DTNCO_NO_SMALL_TREE, always the HBM
-kernel) -- move-evals/s of the sweeps, which kernel the tree's library chose, and whether the two end states are the same
+build_variants/lib_nosmall.so and lib_allsmall.so (`make -C tnco_amd/csrc nosmall allsmall`: the same sources with
+-DTNCO_NO_SMALL_TREE, always the HBM kernel, and with -DTNCO_SMALL_TREE_ALWAYS, the LDS kernel whatever the number of
+replicas) -- move-evals/s of the sweeps, which kernel the tree's library chose, and whether the two end states are the same
 bit for bit (counters, current and minimum costs of every replica, the best tree).
 Run on the GPU box: python tools/small_tree_ab.py > gpurun_out/r05/small_tree_ab.txt
 """
@@ -57,9 +58,10 @@ def main():
     if a.child:
         return child(a)
     variant = ROOT / "build_variants" / "lib_nosmall.so"
-    assert variant.exists(), "make -C tnco_amd/csrc nosmall"
+    always = ROOT / "build_variants" / "lib_allsmall.so"
+    assert variant.exists() and always.exists(), "make -C tnco_amd/csrc nosmall allsmall"
     res = {}
-    for name, lib in (("tree", None), ("hbm", str(variant))):
+    for name, lib in (("tree", None), ("hbm", str(variant)), ("lds", str(always))):
         env = dict(os.environ)
         env.pop("TNCO_HIP_LIB", None)
         if lib:
@@ -69,13 +71,13 @@ def main():
         if out.returncode:
             sys.exit(out.stderr[-3000:])
         res[name] = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
-    print(f"# {a.sweeps} sweeps, beta 0 -> 100, Metropolis, float64, 3-regular networks; 'library' = tnco_amd/libtnco_hip.so, 'HBM' = the same sources with -DTNCO_NO_SMALL_TREE")
-    print("| leaves | mask words | replicas | HBM kernel move-evals/s | library move-evals/s | library's kernel | library / HBM | same end state | replicas failing validate |")
-    print("|---|---|---|---|---|---|---|---|---|")
-    for t, h in zip(res["tree"], res["hbm"]):
-        assert (t["n"], t["R"]) == (h["n"], h["R"]) and not h["lds"]
-        print(f"| {t['n']} | {t['W']} | {t['R']} | {h['rate']:.3e} | {t['rate']:.3e} | {'LDS-resident' if t['lds'] else 'HBM'} | {t['rate'] / h['rate']:.2f} | "
-              f"{t['state'] == h['state']} | {t['bad'] + h['bad']} |")
+    print(f"# {a.sweeps} sweeps, beta 0 -> 100, Metropolis, float64, 3-regular networks; 'library' = tnco_amd/libtnco_hip.so, 'HBM' / 'LDS' = the same sources with -DTNCO_NO_SMALL_TREE / -DTNCO_SMALL_TREE_ALWAYS")
+    print("| leaves | mask words | replicas | HBM kernel move-evals/s | LDS kernel move-evals/s | library move-evals/s | library's kernel | library / HBM | same end states | replicas failing validate |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
+    for t, h, l in zip(res["tree"], res["hbm"], res["lds"]):
+        assert (t["n"], t["R"]) == (h["n"], h["R"]) == (l["n"], l["R"]) and not h["lds"] and l["lds"]
+        print(f"| {t['n']} | {t['W']} | {t['R']} | {h['rate']:.3e} | {l['rate']:.3e} | {t['rate']:.3e} | {'LDS-resident' if t['lds'] else 'HBM'} | {t['rate'] / h['rate']:.2f} | "
+              f"{t['state'] == h['state'] == l['state']} | {t['bad'] + h['bad'] + l['bad']} |")
 
 
 if __name__ == "__main__":
