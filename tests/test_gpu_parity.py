@@ -315,15 +315,49 @@ def test_few_small_trees_run_lds_resident(core, oracle_lib):
             assert big.validate() == (0, -1)
             big.close()
         gpu.close()
-    # not resident: a general cost model; three mask words
+    # not resident: a general cost model
     prob = H.regular_problem(64, graph_seed=7)
     seeds = H.replica_seeds(8)
     links = prob.links(seeds)
     with core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, cost_type="float32") as g:
         assert g.launch_groups == 1
-    prob = H.regular_problem(100, graph_seed=3)
-    with core.BatchedOptimizer(prob.leaf_masks, prob.links(seeds), seeds, n_inds=prob.n_inds) as g:
-        assert g.launch_groups == 1
+
+
+@pytest.mark.parametrize("n,deg,R", [(100, 3, 48), (200, 4, 33), (256, 3, 40), (512, 3, 24), (680, 3, 9)])
+def test_larger_trees_that_fit_the_lds_run_resident(core, oracle_lib, n, deg, R):
+    """csrc/sa_small.h, sa_lds_kernel<K>: up to 16 mask words (4 lanes x K = 1 ... 4 words) a handle whose replicas all fit
+    the CUs' LDS at once keeps them there during a launch (16-bit links, the leaf legs as index lists) -- the latency
+    regime of the larger networks; a 512-leaf tree is 58 KiB.  Same bits as the oracle, launches of 1, 7 and 40 sweeps;
+    and the same replicas in a batch too large for the LDS (the HBM kernel) end in the same state."""
+    prob = H.regular_problem(n, graph_seed=n % 89, degree=deg)
+    R_big = 3000 if n == 512 else 0
+    seeds = H.replica_seeds(max(R, R_big), S=n)
+    links = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds) if R_big else prob.links(seeds)
+    betas = H.linear_betas(0, 60, 48)
+    gpu = core.BatchedOptimizer(prob.leaf_masks, links[:R], seeds[:R], n_inds=prob.n_inds)
+    assert gpu.launch_groups == 0
+    gpu.run(betas[:1]); gpu.run(betas[1:8]); gpu.run(betas[8:])
+    tot, mn = gpu.costs()
+    for r in range(0, R, 4):
+        o = H.make_oracle(oracle_lib, prob, links[r], seeds[r])
+        o.run(oracle_lib.PROB_MH, betas)
+        H.assert_replica_equal(gpu, r, o)
+        assert tot[r] == o.total_cost and mn[r] == o.min_total_cost
+    assert gpu.validate() == (0, -1)
+    if R_big:
+        big = core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds)
+        assert big.launch_groups >= 1
+        big.run(betas[:1]); big.run(betas[1:8]); big.run(betas[8:])
+        tb, mb = big.costs()
+        assert np.array_equal(tb[:R], tot) and np.array_equal(mb[:R], mn)
+        for r in range(R):
+            for which in (False, True):
+                for x, y in zip(gpu.tree(r, which_min=which), big.tree(r, which_min=which)):
+                    assert np.array_equal(x, y)
+            assert np.array_equal(gpu.prng_state(r), big.prng_state(r))
+        assert big.validate() == (0, -1)
+        big.close()
+    gpu.close()
 
 
 def test_c3_full_size_properties(core, oracle_lib):

@@ -49,7 +49,11 @@ struct tnco_hip_ctx {
   int64_t fw_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool fw_probed = false;  // the first re-slice interval of the handle has run on its own (tnco_hip_run_fw)
   unsigned long long fw_slow_pending = 0, fw_slow_wide_pending = 0;  // fall-backs collected since tnco_hip_run_fw last chose a form
-  bool small_tree = false;  // few small trees (the latency regime): LDS-resident sweeps, sa_small.h
+  bool small_tree = false;  // small trees: LDS-resident sweeps (sa_small.h, sa_small_kernel)
+  bool lds_tree = false;    // any tree whose replicas fit the CUs' LDS in two rounds: sa_lds_kernel with the plan below
+  bool lds_attr_set = false;
+  tnco::LdsPlan lds_plan{};
+  uint64_t* leaf_idx = nullptr;  // [n][2] the leaves' index positions (8 x 16 bits), device
   tnco::FwParams F{};
   std::vector<void*> allocs;
   std::vector<size_t> alloc_bytes;  // (destroy hands the blocks to tnco::DevCache)

@@ -43,6 +43,18 @@ void launch_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int pr
       return;
     }
   }
+  if constexpr (LOG2L == 2) {
+    if (h->lds_tree) {
+      const LdsPlan& pl = h->lds_plan;
+      if (!h->lds_attr_set) {  // (more dynamic LDS than the 64 KiB a kernel gets by default)
+        (void)hipFuncSetAttribute((const void*)sa_lds_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, pl.total);
+        h->lds_attr_set = true;
+      }
+      hipLaunchKernelGGL((sa_lds_kernel<K>), dim3((unsigned)((P.R + pl.seats - 1) / pl.seats)), dim3(SMALL_TPB), (size_t)pl.total, s, P,
+                         betas, n_steps, prob_kind, pl, h->leaf_idx);
+      return;
+    }
+  }
   const int gpb = SWT >> LOG2L;
   dim3 grid((unsigned)(nblocks >= 0 ? nblocks : (P.R + gpb - 1) / gpb));
   if (h->hyper) {

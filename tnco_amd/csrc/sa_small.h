@@ -91,77 +91,146 @@ __device__ __forceinline__ uint32_t small_exp_of(double c) {
   return (uint32_t)((__double2hiint(c) >> 20) & 0x7ff) - 1023u;  // c = 2^e exactly (or +inf -> 1024)
 }
 
-// NI: internal nodes per replica the LDS arrays are sized for (n - 1 <= NI); TPB threads = TPB / 4
-// replicas per block.  <63, 64>: 38.5 KiB of LDS, four blocks per CU; <127, 64>: 72.5 KiB, two.
-template <int NI, int TPB>
-__global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const double* __restrict__ betas,
-                                                       const int64_t n_steps, const int prob_kind) {
-  constexpr int LOG2L = 2, K = 1, L = 4, GPB = TPB / 4;
-  using M = Mask<K>;
-  using R = Rng<LOG2L, 64>;
-  typedef TNCO_LDS volatile uint64_t lvu64;
-  typedef TNCO_LDS volatile uint8_t lvu8;
-  __shared__ SmallRec recbuf[GPB * NI];
-  __shared__ uint8_t lparbuf[GPB * (NI + 1)];
-  __shared__ uint64_t leafbuf[(NI + 1) * 2];
-  __shared__ uint32_t rngbuf[GPB * R::RING];
-  __shared__ int32_t jbuf[GPB * 16];
+// ---------------------------------------------------------------------------------------------------------------
+// Where a block keeps its replicas' trees.  Two layouts, one loop (small_sweeps below):
+//   SmallStore<NI>: up to 128 leaves and 2 mask words -- links are bytes, a node is one 32-byte record, the leaf legs a
+//     table of the block; static LDS, 16 replicas per block.  <63>: 38.5 KiB, four blocks per CU; <127>: 72.5 KiB, two.
+//   WideStore<K>: any tree whose replicas fit -- 16-bit links, up to 16 mask words (4 lanes x K words), separate arrays
+//     for [links | cost exponent], partial costs and legs, the leaf legs as lists of index positions (at most 8 per
+//     leaf; expanded where a leaf's legs are needed); dynamic LDS carved by the host (LdsPlan), 1 ... 16 replicas per
+//     block: a 512-leaf tree of 12 words is 58 KiB, two per CU.
+// ---------------------------------------------------------------------------------------------------------------
+typedef TNCO_LDS volatile uint64_t lvu64;
+typedef TNCO_LDS volatile uint16_t lvu16;
+typedef TNCO_LDS volatile uint8_t lvu8;
+typedef TNCO_LDS volatile double lvf64;
 
-  const int tid = threadIdx.x;
-  const int lig = tid & 3;
-  const int gib = tid >> 2;
-  const int64_t r = (int64_t)blockIdx.x * GPB + gib;
-  const int n = P.n, N = P.N, ni = n - 1;
-  // the leaf legs, shared by the replicas of the block (words 0, 1 of every row of the padded table)
-  for (int i = tid; i < n * 2; i += TPB) leafbuf[i] = P.leafmask[(int64_t)(i >> 1) * L + (i & 1)];
-  __syncthreads();
-  if (r >= P.R || n_steps <= 0) return;
-  const bool lane0 = lig == 0;
-  TNCO_LDS volatile SmallRec* rec = (TNCO_LDS volatile SmallRec*)recbuf + gib * NI;
-  lvu8* lpar = (lvu8*)lparbuf + gib * (NI + 1);
-  lvu64* leaf = (lvu64*)leafbuf;
-
-  // ---- HBM -> LDS -------------------------------------------------------------------------------
-  {
-    const uint8_t* blk = P.blocks + r * P.RB;
-    for (int i = lig; i < ni; i += L) {
-      const NodeRec* q = reinterpret_cast<const NodeRec*>(blk + (int64_t)i * P.BS);
-      const uint64_t* lg = reinterpret_cast<const uint64_t*>(blk + (int64_t)i * P.BS + 32);
-      rec[i].links = (uint32_t)(q->left & 0xFF) | ((uint32_t)(q->right & 0xFF) << 8) | ((uint32_t)(q->parent & 0xFF) << 16);
-      rec[i].cexp = small_exp_of(q->ccost);
-      rec[i].partial = q->partial;
-      rec[i].legs[0] = lg[0];
-      rec[i].legs[1] = P.W > 1 ? lg[1] : 0ull;
-    }
-    const int32_t* lp = P.lpar + r * (int64_t)n * LPS;
-    for (int i = lig; i < n; i += L) lpar[i] = (uint8_t)lp[(int64_t)i * LPS];
+template <int NI_>
+struct SmallStore {
+  static constexpr int K = 1, NI = NI_, GPB = SMALL_TPB / 4, NULLID = 0xFF;
+  TNCO_LDS volatile SmallRec* rec;
+  lvu8* lpar;
+  lvu64* leaf;
+  int n, lig;
+  // links | cost exponent << 32
+  static __device__ __forceinline__ uint64_t pack(int l, int r, int p, uint32_t e) {
+    return (uint64_t)((uint32_t)l | ((uint32_t)r << 8) | ((uint32_t)(p & 0xFF) << 16)) | ((uint64_t)e << 32);
   }
-  // (LDS operations of one wavefront are executed in order: no barrier between a group's own writes and reads)
-  // (no branches around the reads: a divergent branch costs the sixteen replicas of the wavefront more than a read does)
-  auto legs_of = [&](int x) -> M {  // this lane's word of the legs of node x (lanes 2, 3: nothing)
-    M m;
+  static __device__ __forceinline__ int left_of(uint64_t h) { return (int)((uint32_t)h & 0xFF); }
+  static __device__ __forceinline__ int right_of(uint64_t h) { return (int)(((uint32_t)h >> 8) & 0xFF); }
+  static __device__ __forceinline__ int parent_of(uint64_t h) {
+    const int p = (int)(((uint32_t)h >> 16) & 0xFF);
+    return p == NULLID ? -1 : p;
+  }
+  static __device__ __forceinline__ uint32_t exp_of(uint64_t h) { return (uint32_t)(h >> 32); }
+  __device__ __forceinline__ uint64_t head(int i) const { return *(lvu64*)&rec[i]; }
+  __device__ __forceinline__ void set_head(int i, uint64_t h) const { *(lvu64*)&rec[i] = h; }
+  __device__ __forceinline__ double partial(int i) const { return rec[i].partial; }
+  __device__ __forceinline__ void set_partial(int i, double v) const { rec[i].partial = v; }
+  // (no branch around the read: the address is selected -- a divergent branch costs the sixteen replicas of the wavefront
+  // more than a read does; lanes 2, 3 hold nothing)
+  __device__ __forceinline__ Mask<1> legs(int x) const {
+    Mask<1> m;
     lvu64* a = x < n ? leaf + 2 * x + (lig & 1) : (lvu64*)&rec[x - n].legs[lig & 1];
     const uint64_t v = *a;
     m.w[0] = lig < 2 ? v : 0ull;
     return m;
-  };
-  auto partial_of = [&](int x) -> double {
-    const double v = rec[x < n ? 0 : x - n].partial;
+  }
+  __device__ __forceinline__ void set_legs(int i, const Mask<1>& m) const {
+    if (lig < 2) rec[i].legs[lig] = m.w[0];
+  }
+  __device__ __forceinline__ int leaf_parent(int x) const { return lpar[x]; }
+  __device__ __forceinline__ void set_parent(int x, int p) const {  // (lane 0 of the group calls)
+    lvu8* a = x < n ? lpar + x : (lvu8*)&rec[x - n].links + 2;
+    *a = (uint8_t)p;
+  }
+};
+
+// The host's carve of a block's dynamic LDS for WideStore (bytes; tnco_hip_create).
+struct LdsPlan {
+  int seats;        // replicas per block (1 ... 16): lane groups beyond them idle
+  int deg;          // index positions per leaf at most (<= 8)
+  int seat0, seat_stride;                       // first seat, bytes per seat
+  int o_part, o_legs, o_lpar, o_ring, o_jb;     // inside a seat ([links | exponent] first)
+  int total;        // bytes of the block
+  int blocks_per_cu;
+};
+
+template <int K_>
+struct WideStore {
+  static constexpr int K = K_, NULLID = 0xFFFF;
+  lvu64* hdr;       // left | right << 16 | parent << 32 | cost exponent << 48
+  lvf64* part;
+  lvu64* leg;       // [node][4 K]: word k * 4 + lane of node i at i * 4 K + k * 4 + lane (the lanes' k-major layout)
+  lvu16* lpar;
+  lvu64* leaf;      // [leaf][2]: eight 16-bit index positions, 0xFFFF: none
+  int n, lig, deg;
+  static __device__ __forceinline__ uint64_t pack(int l, int r, int p, uint32_t e) {
+    return (uint64_t)(uint32_t)l | ((uint64_t)(uint32_t)r << 16) | ((uint64_t)((uint32_t)p & 0xFFFFu) << 32) | ((uint64_t)e << 48);
+  }
+  static __device__ __forceinline__ int left_of(uint64_t h) { return (int)(h & 0xFFFF); }
+  static __device__ __forceinline__ int right_of(uint64_t h) { return (int)((h >> 16) & 0xFFFF); }
+  static __device__ __forceinline__ int parent_of(uint64_t h) {
+    const int p = (int)((h >> 32) & 0xFFFF);
+    return p == NULLID ? -1 : p;
+  }
+  static __device__ __forceinline__ uint32_t exp_of(uint64_t h) { return (uint32_t)(h >> 48); }
+  __device__ __forceinline__ uint64_t head(int i) const { return hdr[i]; }
+  __device__ __forceinline__ void set_head(int i, uint64_t h) const { hdr[i] = h; }
+  __device__ __forceinline__ double partial(int i) const { return part[i]; }
+  __device__ __forceinline__ void set_partial(int i, double v) const { part[i] = v; }
+  __device__ __forceinline__ Mask<K> legs(int x) const {
+    Mask<K> m = mzero<K>();
+    if (x < n) {  // a leaf: its index positions, expanded into this lane's words
+      const uint64_t lo = leaf[2 * x], hi = leaf[2 * x + 1];
+      for (int j = 0; j < deg; ++j) {
+        const uint32_t idx = (uint32_t)((j < 4 ? lo >> (16 * j) : hi >> (16 * (j - 4))) & 0xFFFF);
+        const int w = (int)(idx >> 6);
+        const uint64_t bit = idx == 0xFFFFu ? 0ull : 1ull << (idx & 63u);
+#pragma unroll
+        for (int k = 0; k < K; ++k) m.w[k] |= w == k * 4 + lig ? bit : 0ull;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; ++k) m.w[k] = leg[(x - n) * (4 * K) + k * 4 + lig];
+    }
+    return m;
+  }
+  __device__ __forceinline__ void set_legs(int i, const Mask<K>& m) const {
+#pragma unroll
+    for (int k = 0; k < K; ++k) leg[i * (4 * K) + k * 4 + lig] = m.w[k];
+  }
+  __device__ __forceinline__ int leaf_parent(int x) const { return lpar[x]; }
+  __device__ __forceinline__ void set_parent(int x, int p) const {
+    lvu16* a = x < n ? lpar + x : (lvu16*)(hdr + (x - n)) + 2;
+    *a = (uint16_t)p;
+  }
+};
+
+// The sweeps of one replica group (4 lanes) on a tree held by store `st` (copied in by the caller, copied out by it).
+template <class Store>
+__device__ __forceinline__ void small_sweeps(const Params& P, const Store& st, const int64_t r, const int lig,
+                                             lds_vu32* ringbuf, lds_vi32* jbuf, const double* __restrict__ betas,
+                                             const int64_t n_steps, const int prob_kind) {
+  constexpr int LOG2L = 2, K = Store::K, L = 4;
+  using M = Mask<K>;
+  using R = Rng<LOG2L, 64>;
+  const int n = P.n, N = P.N;
+  const bool lane0 = lig == 0;
+  auto partial_of = [&](int x) -> double {  // (a leaf: 0; the read is unconditional, the address selected)
+    const double v = st.partial(x < n ? 0 : x - n);
     return x < n ? 0.0 : v;
   };
-  auto head_of = [&](int i) -> uint64_t { return *(lvu64*)&rec[i]; };  // links | cexp << 32: one read
-  auto parent_byte = [&](int x) -> lvu8* { return x < n ? lpar + x : (lvu8*)&rec[x - n].links + 2; };
-
   R rng;
   const ReplicaState* rs0 = P.rs + r;
-  rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs0->mti, rs0->mtw, lig);
+  rng.init(P, r, ringbuf, rs0->mti, rs0->mtw, lig);
   double min_cost = rs0->min_cost;
   uint32_t jmin = rs0->jmin, jtail = rs0->jtail;
   bool jinvalid = rs0->jinvalid != 0;
   uint32_t n_moves = 0, n_acc = 0, n_impr = 0, n_full = 0, n_rpick = 0;
   const uint32_t jcap = (uint32_t)P.jcap;
   int32_t* jlog = P.jlog + r * (int64_t)P.jcap;
-  auto jb = [&](int i) -> lds_vi32& { return *((lds_vi32*)jbuf + gib * 16 + i); };
+  auto jb = [&](int i) -> lds_vi32& { return jbuf[i]; };
   if ((jtail & 15u) != 0u) {
     const int4 t = *reinterpret_cast<const int4*>(jlog + (jtail & ~15u) + 4 * lig);
     jb(4 * lig + 0) = t.x; jb(4 * lig + 1) = t.y; jb(4 * lig + 2) = t.z; jb(4 * lig + 3) = t.w;
@@ -175,7 +244,7 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
   int B = -1, bl = 0, br = 0, A = -1;
   uint32_t eB = 0;
   double partB = 0, beta = 0;
-  double total = rec[root - n].partial;  // (optimizer.hpp:103: the root's partial cost where a sweep begins)
+  double total = st.partial(root - n);  // (optimizer.hpp:103: the root's partial cost where a sweep begins)
   const double inv_n = 1.0 / (double)n;
   M m0 = mzero<K>(), m1 = mzero<K>();
   double p0 = 0, p1 = 0;
@@ -225,15 +294,13 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
       // ---- one move evaluation (optimizer.hpp:117-192); its operands -- A's record, the legs and the partial cost of
       // C, B's sibling -- were read during the previous iteration ---------------------------------------------------
       SMALL_PROF_M(0);
-      const uint32_t lkA = (uint32_t)hdA;
-      int al = (int)(lkA & 0xFF), ar = (int)((lkA >> 8) & 0xFF);
-      int aP = (int)((lkA >> 16) & 0xFF);
-      if (aP == 0xFF) aP = -1;
-      const uint32_t eA = (uint32_t)(hdA >> 32);
+      int al = Store::left_of(hdA), ar = Store::right_of(hdA);
+      const int aP = Store::parent_of(hdA);
+      const uint32_t eA = Store::exp_of(hdA);
       const bool c_is_right = (al == B);
       const int C = c_is_right ? ar : al;
       // next iteration's operands, first half: the record of A's parent (nothing of it changes in this move)
-      const uint64_t hdN = head_of(aP < 0 ? 0 : aP - n);
+      const uint64_t hdN = st.head(aP < 0 ? 0 : aP - n);
       uint32_t w0 = mpopc<K>(mor<K>(mxor<K>(m0, mC), m1)) | (mpopc<K>(mor<K>(m0, mC)) << 13) |
                     ((mnonzero<K>(mand<K>(m0, mC)) ? 1u : 0u) << 26);
       uint32_t w1 = mpopc<K>(mor<K>(mxor<K>(m1, mC), m0)) | (mpopc<K>(mor<K>(m1, mC)) << 13) |
@@ -242,8 +309,8 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
       w0 = gsum<LOG2L>(w0);
       w1 = gsum<LOG2L>(w1);
       // ... second half: A's sibling under that parent (another subtree: untouched by this move)
-      const int CN = (int)((uint32_t)hdN & 0xFF) == A ? (int)(((uint32_t)hdN >> 8) & 0xFF) : (int)((uint32_t)hdN & 0xFF);
-      const M mCN = legs_of(CN);
+      const int CN = Store::left_of(hdN) == A ? Store::right_of(hdN) : Store::left_of(hdN);
+      const M mCN = st.legs(CN);
       const double pCN = partial_of(CN);
       const bool inter0 = (w0 >> 26) != 0, inter1 = (w1 >> 26) != 0;
       // get_ctree_nn, optimize/optimizer.hpp:128-144
@@ -286,15 +353,15 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
       jinvalid = jinvalid || (acc && jtail == jcap);
       if (lane0) {
         if (acc) {
-          *parent_byte(C) = (uint8_t)B;
-          *parent_byte(E) = (uint8_t)A;
+          st.set_parent(C, B);
+          st.set_parent(E, A);
           if (logged) jb((int)(jtail & 15u)) = E;
         }
         // (A's own record is written when A is B -- in the next move, or where the sweep ends)
-        *(lvu64*)&rec[B - n] = (uint64_t)((uint32_t)bl | ((uint32_t)br << 8) | ((uint32_t)A << 16)) | ((uint64_t)eBn << 32);
-        rec[B - n].partial = partB;
+        st.set_head(B - n, Store::pack(bl, br, A, eBn));
+        st.set_partial(B - n, partB);
       }
-      if (acc && lig < 2) rec[B - n].legs[lig] = newB.w[0];
+      if (acc) st.set_legs(B - n, newB);
       jtail += logged ? 1u : 0u;
       if (logged && (jtail & 15u) == 0u)  // a 64-byte piece of the log is complete
         *reinterpret_cast<int4*>(jlog + (jtail - 16u) + 4 * lig) =
@@ -315,8 +382,8 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
       const uint32_t x = drawn == 0u ? d0 : (drawn == 2u ? d2 : d3);
       if (B >= 0) {
         if (lane0) {
-          *(lvu64*)&rec[B - n] = (uint64_t)((uint32_t)bl | ((uint32_t)br << 8) | (0xFFu << 16)) | ((uint64_t)eB << 32);
-          rec[B - n].partial = partB;
+          st.set_head(B - n, Store::pack(bl, br, Store::NULLID, eB));
+          st.set_partial(B - n, partB);
         }
         if (partB < min_cost) {
           min_cost = partB;
@@ -326,13 +393,12 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
             for (int i = lig; i < N; i += L) {
               Links o;
               if (i < n) {
-                o.left = -1; o.right = -1; o.parent = lpar[i];
+                o.left = -1; o.right = -1; o.parent = st.leaf_parent(i);
               } else {
-                const uint32_t lk = rec[i - n].links;
-                o.left = (int)(lk & 0xFF); o.right = (int)((lk >> 8) & 0xFF);
-                o.parent = (int)((lk >> 16) & 0xFF);
+                const uint64_t hd = st.head(i - n);
+                o.left = Store::left_of(hd); o.right = Store::right_of(hd);
+                o.parent = Store::parent_of(hd);
               }
-              if (o.parent == 0xFF) o.parent = -1;
               o.pad = 0;
               ml[i] = o;
             }
@@ -350,22 +416,20 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
       if (active) {
         // a random leaf, its parent is B; the total cost is the root's partial cost
         ++drawn;
-        B = lpar[small_mod(x, (uint32_t)n, inv_n)];
-        const uint64_t hd = head_of(B - n);
-        partB = rec[B - n].partial;
-        const uint32_t lk = (uint32_t)hd;
-        bl = (int)(lk & 0xFF); br = (int)((lk >> 8) & 0xFF);
-        A = (int)((lk >> 16) & 0xFF);
-        if (A == 0xFF) A = -1;
-        eB = (uint32_t)(hd >> 32);
+        B = st.leaf_parent((int)small_mod(x, (uint32_t)n, inv_n));
+        const uint64_t hd = st.head(B - n);
+        partB = st.partial(B - n);
+        bl = Store::left_of(hd); br = Store::right_of(hd);
+        A = Store::parent_of(hd);
+        eB = Store::exp_of(hd);
         beta = beta_next;
         beta_tmp = betas[step + 1 < (int)n_steps ? step + 1 : step];
         bpend = true;
-        hdA = head_of(A < 0 ? 0 : A - n);  // the first move's operands
-        m0 = legs_of(bl); m1 = legs_of(br);
+        hdA = st.head(A < 0 ? 0 : A - n);  // the first move's operands
+        m0 = st.legs(bl); m1 = st.legs(br);
         p0 = partial_of(bl); p1 = partial_of(br);
-        const int C = (int)((uint32_t)hdA & 0xFF) == B ? (int)(((uint32_t)hdA >> 8) & 0xFF) : (int)((uint32_t)hdA & 0xFF);
-        mC = legs_of(C);
+        const int C = Store::left_of(hdA) == B ? Store::right_of(hdA) : Store::left_of(hdA);
+        mC = st.legs(C);
         pC = partial_of(C);
       }
     }
@@ -375,26 +439,6 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
     }
   }
 
-  // ---- LDS -> HBM -------------------------------------------------------------------------------
-  {
-    uint8_t* blk = P.blocks + r * P.RB;
-    for (int i = lig; i < ni; i += L) {
-      NodeRec o;
-      const uint32_t lk = rec[i].links;
-      o.left = (int)(lk & 0xFF); o.right = (int)((lk >> 8) & 0xFF);
-      o.parent = (int)((lk >> 16) & 0xFF);
-      if (o.parent == 0xFF) o.parent = -1;
-      o.pad = 0;
-      o.ccost = pow2_cost((int)rec[i].cexp, 0);
-      o.partial = rec[i].partial;
-      *reinterpret_cast<NodeRec*>(blk + (int64_t)i * P.BS) = o;
-      uint64_t* lg = reinterpret_cast<uint64_t*>(blk + (int64_t)i * P.BS + 32);
-      lg[0] = rec[i].legs[0];
-      if (P.W > 1) lg[1] = rec[i].legs[1];
-    }
-    int32_t* lp = P.lpar + r * (int64_t)n * LPS;
-    for (int i = lig; i < n; i += L) lp[(int64_t)i * LPS] = (int32_t)lpar[i];
-  }
   if ((jtail & 15u) != 0u)
     *reinterpret_cast<int4*>(jlog + (jtail & ~15u) + 4 * lig) =
         make_int4(jb(4 * lig + 0), jb(4 * lig + 1), jb(4 * lig + 2), jb(4 * lig + 3));
@@ -414,6 +458,112 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
     rs->mtw = mtw;
     TNCO_PROF_OUT(rs);
   }
+}
+
+// The kernels: copy the replicas' trees HBM -> LDS, sweep, copy back.
+// <NI, TPB>: internal nodes the static arrays are sized for (n - 1 <= NI); TPB / 4 = 16 replicas per block.
+template <int NI, int TPB>
+__global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const double* __restrict__ betas,
+                                                       const int64_t n_steps, const int prob_kind) {
+  constexpr int L = 4, GPB = TPB / 4;
+  using R = Rng<2, 64>;
+  __shared__ SmallRec recbuf[GPB * NI];
+  __shared__ uint8_t lparbuf[GPB * (NI + 1)];
+  __shared__ uint64_t leafbuf[(NI + 1) * 2];
+  __shared__ uint32_t rngbuf[GPB * R::RING];
+  __shared__ int32_t jbuf[GPB * 16];
+
+  const int tid = threadIdx.x;
+  const int lig = tid & 3;
+  const int gib = tid >> 2;
+  const int64_t r = (int64_t)blockIdx.x * GPB + gib;
+  const int n = P.n, ni = n - 1;
+  // the leaf legs, shared by the replicas of the block (words 0, 1 of every row of the padded table)
+  for (int i = tid; i < n * 2; i += TPB) leafbuf[i] = P.leafmask[(int64_t)(i >> 1) * L + (i & 1)];
+  __syncthreads();
+  if (r >= P.R || n_steps <= 0) return;
+  SmallStore<NI> st;
+  st.rec = (TNCO_LDS volatile SmallRec*)recbuf + gib * NI;
+  st.lpar = (lvu8*)lparbuf + gib * (NI + 1);
+  st.leaf = (lvu64*)leafbuf;
+  st.n = n; st.lig = lig;
+  uint8_t* blk = P.blocks + r * P.RB;
+  int32_t* lp = P.lpar + r * (int64_t)n * LPS;
+  for (int i = lig; i < ni; i += L) {
+    const NodeRec* q = reinterpret_cast<const NodeRec*>(blk + (int64_t)i * P.BS);
+    const uint64_t* lg = reinterpret_cast<const uint64_t*>(blk + (int64_t)i * P.BS + 32);
+    st.set_head(i, SmallStore<NI>::pack(q->left, q->right, q->parent, small_exp_of(q->ccost)));
+    st.rec[i].partial = q->partial;
+    st.rec[i].legs[0] = lg[0];
+    st.rec[i].legs[1] = P.W > 1 ? lg[1] : 0ull;
+  }
+  for (int i = lig; i < n; i += L) st.lpar[i] = (uint8_t)lp[(int64_t)i * LPS];
+  // (LDS operations of one wavefront are executed in order: no barrier between a group's own writes and reads)
+  small_sweeps(P, st, r, lig, (lds_vu32*)rngbuf + gib * R::RING, (lds_vi32*)jbuf + gib * 16, betas, n_steps, prob_kind);
+  for (int i = lig; i < ni; i += L) {
+    const uint64_t hd = st.head(i);
+    NodeRec o;
+    o.left = SmallStore<NI>::left_of(hd); o.right = SmallStore<NI>::right_of(hd);
+    o.parent = SmallStore<NI>::parent_of(hd);
+    o.pad = 0;
+    o.ccost = pow2_cost((int)SmallStore<NI>::exp_of(hd), 0);
+    o.partial = st.rec[i].partial;
+    *reinterpret_cast<NodeRec*>(blk + (int64_t)i * P.BS) = o;
+    uint64_t* lg = reinterpret_cast<uint64_t*>(blk + (int64_t)i * P.BS + 32);
+    lg[0] = st.rec[i].legs[0];
+    if (P.W > 1) lg[1] = st.rec[i].legs[1];
+  }
+  for (int i = lig; i < n; i += L) lp[(int64_t)i * LPS] = (int32_t)st.lpar[i];
+}
+
+// <K>: 4 lanes x K words per replica; the block's LDS as the host carved it (LdsPlan), leaf_idx = [n][8] index positions.
+template <int K>
+__global__ __launch_bounds__(SMALL_TPB) void sa_lds_kernel(const Params P, const double* __restrict__ betas, const int64_t n_steps,
+                                                           const int prob_kind, const LdsPlan pl,
+                                                           const uint64_t* __restrict__ leaf_idx) {
+  constexpr int L = 4;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+  TNCO_LDS uint8_t* lds = (TNCO_LDS uint8_t*)lds_raw;
+  const int tid = threadIdx.x;
+  const int lig = tid & 3;
+  const int gib = tid >> 2;
+  const int64_t r = (int64_t)blockIdx.x * pl.seats + gib;
+  const int n = P.n, ni = n - 1, W = P.W;
+  for (int i = tid; i < n * 2; i += SMALL_TPB) ((lvu64*)lds)[i] = leaf_idx[i];
+  __syncthreads();
+  if (gib >= pl.seats || r >= P.R || n_steps <= 0) return;
+  TNCO_LDS uint8_t* seat = lds + pl.seat0 + gib * pl.seat_stride;
+  WideStore<K> st;
+  st.hdr = (lvu64*)seat;
+  st.part = (lvf64*)(seat + pl.o_part);
+  st.leg = (lvu64*)(seat + pl.o_legs);
+  st.lpar = (lvu16*)(seat + pl.o_lpar);
+  st.leaf = (lvu64*)lds;
+  st.n = n; st.lig = lig; st.deg = pl.deg;
+  uint8_t* blk = P.blocks + r * P.RB;
+  int32_t* lp = P.lpar + r * (int64_t)n * LPS;
+  for (int i = lig; i < ni; i += L) {
+    const NodeRec* q = reinterpret_cast<const NodeRec*>(blk + (int64_t)i * P.BS);
+    const uint64_t* lg = reinterpret_cast<const uint64_t*>(blk + (int64_t)i * P.BS + 32);
+    st.set_head(i, WideStore<K>::pack(q->left, q->right, q->parent, small_exp_of(q->ccost)));
+    st.part[i] = q->partial;
+    for (int w = 0; w < 4 * K; ++w) st.leg[i * (4 * K) + w] = w < W ? lg[w] : 0ull;
+  }
+  for (int i = lig; i < n; i += L) st.lpar[i] = (uint16_t)lp[(int64_t)i * LPS];
+  small_sweeps(P, st, r, lig, (lds_vu32*)(seat + pl.o_ring), (lds_vi32*)(seat + pl.o_jb), betas, n_steps, prob_kind);
+  for (int i = lig; i < ni; i += L) {
+    const uint64_t hd = st.head(i);
+    NodeRec o;
+    o.left = WideStore<K>::left_of(hd); o.right = WideStore<K>::right_of(hd);
+    o.parent = WideStore<K>::parent_of(hd);
+    o.pad = 0;
+    o.ccost = pow2_cost((int)WideStore<K>::exp_of(hd), 0);
+    o.partial = st.part[i];
+    *reinterpret_cast<NodeRec*>(blk + (int64_t)i * P.BS) = o;
+    uint64_t* lg = reinterpret_cast<uint64_t*>(blk + (int64_t)i * P.BS + 32);
+    for (int w = 0; w < W; ++w) lg[w] = st.leg[i * (4 * K) + w];
+  }
+  for (int i = lig; i < n; i += L) lp[(int64_t)i * LPS] = (int32_t)st.lpar[i];
 }
 
 }  // namespace tnco

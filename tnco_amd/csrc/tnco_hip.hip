@@ -1082,6 +1082,60 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
 #ifndef TNCO_SMALL_TREE_ALWAYS  // (the other A/B library of tools/small_tree_ab.py: `make allsmall`)
       if (h->small_tree && n - 1 > 63 && R > 2 * (int64_t)small_replicas_per_cu(n - 1) * prop.multiProcessorCount) h->small_tree = false;
 #endif
+      // Any other tree of the fast cost path whose replicas fit the CUs' LDS at once (the latency regime of the larger
+      // networks: 512 leaves of 12 words are 58 KiB, two per CU, up to 512 replicas): sa_lds_kernel.
+      if (!h->small_tree && !h->hyper && !h->generic && LPS == 1 && !d->min_links && n >= 2 && h->log2l == 2 && I <= 65535 &&
+          N <= 65534 && (int64_t)P.log2d * 64 * W <= 65535) {
+        std::vector<uint64_t> idx((size_t)n * 2, ~0ull);
+        int deg = 0;
+        for (int t = 0; t < n && deg <= 8; ++t) {
+          int c = 0;
+          for (int p = 0; p < I; ++p)
+            if ((h->leafmask_w[(size_t)t * W + (p >> 6)] >> (p & 63)) & 1) {
+              if (c < 8) idx[(size_t)t * 2 + (c >> 2)] = (idx[(size_t)t * 2 + (c >> 2)] & ~(0xFFFFull << (16 * (c & 3)))) | ((uint64_t)p << (16 * (c & 3)));
+              ++c;
+            }
+          deg = std::max(deg, c);
+        }
+        if (deg <= 8) {
+          const int K = h->K, ni = n - 1;
+          LdsPlan pl{};
+          pl.deg = deg;
+          pl.seat0 = (n * 16 + 15) / 16 * 16;
+          pl.o_part = 8 * ni;
+          pl.o_legs = 16 * ni;
+          pl.o_lpar = pl.o_legs + 32 * K * ni;
+          pl.o_ring = pl.o_lpar + (2 * n + 7) / 8 * 8;
+          pl.o_jb = pl.o_ring + 64 * 4;
+          pl.seat_stride = (pl.o_jb + 16 * 4 + 15) / 16 * 16;
+          // One block (one wavefront of up to 16 replicas) per CU if that holds the batch, else two, else four: the fewest
+          // wavefronts that hold it -- 512 or 1024 wavefronts of one or two replicas each run up to twice slower per
+          // replica than 256 of them (profiles/experiments_r05.md) --, and as few replicas per wavefront as spreads the
+          // batch over all the CUs.  x1.3 ... x2.3 the HBM kernel per replica, so a second round of blocks would lose.
+          int best = 0;
+          for (int b = 1; b <= 4 && best == 0; b <<= 1) {
+            const int seats = std::min(SMALL_TPB / 4, (160 * 1024 / b - pl.seat0) / pl.seat_stride);
+            if (seats > 0 && (R <= (int64_t)b * seats * prop.multiProcessorCount || b == 4)) { best = b * seats; pl.seats = seats; pl.blocks_per_cu = b; }
+          }
+#ifdef TNCO_NO_SMALL_TREE
+          best = 0;
+#endif
+#ifdef TNCO_SMALL_TREE_ALWAYS
+          const bool fits = best > 0;
+#else
+          const bool fits = best > 0 && R <= (int64_t)best * prop.multiProcessorCount;
+#endif
+          if (fits) {
+            const int64_t waves = (int64_t)pl.blocks_per_cu * prop.multiProcessorCount;
+            pl.seats = (int)std::max<int64_t>(1, std::min<int64_t>(pl.seats, (R + waves - 1) / waves));
+            pl.total = pl.seat0 + pl.seats * pl.seat_stride;
+            HIP_TRY(h->alloc(&h->leaf_idx, (int64_t)n * 2));
+            HIP_TRY(hipMemcpy(h->leaf_idx, idx.data(), idx.size() * 8, hipMemcpyHostToDevice));
+            h->lds_plan = pl;
+            h->lds_tree = true;
+          }
+        }
+      }
       h->run_slots = run_blocks_per_cu(h) * prop.multiProcessorCount;
       if (h->run_slots > 0 && nblocks > h->run_slots) {
         const double rounds = (double)nblocks / (double)h->run_slots, part = rounds - std::floor(rounds);
@@ -1095,7 +1149,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       G = 2;
     }
     if (const char* e = std::getenv("TNCO_HIP_GROUPS")) G = std::max(1, std::min((int)tnco_hip_ctx::MAX_GROUPS, std::atoi(e)));
-    if (h->small_tree || nblocks < 2 * G) G = 1;
+    if (h->small_tree || h->lds_tree || nblocks < 2 * G) G = 1;
     if (G > 1) {
       for (int q = 0; q < G; ++q) {
         HIP_TRY(tnco::StreamCache::get().take(&h->gstream[q], h->device));
@@ -1356,7 +1410,7 @@ int tnco_hip_diag_kernel_times(tnco_hip_handle h, double* ms4, int64_t* launches
   return TNCO_HIP_OK;
 }
 
-int tnco_hip_diag_launch_groups(tnco_hip_handle h) { return h ? (h->small_tree ? 0 : h->n_groups) : 0; }
+int tnco_hip_diag_launch_groups(tnco_hip_handle h) { return h ? (h->small_tree || h->lds_tree ? 0 : h->n_groups) : 0; }
 
 int64_t tnco_hip_diag_device_bytes(tnco_hip_handle h) { return h ? h->bytes : 0; }
 

@@ -1,6 +1,7 @@
 """A/B of the LDS-resident small-tree kernel (csrc/sa_small.h) against the HBM kernel, sweeps only.
 
-For {64, 84}-leaf 3-regular networks (<= 2 mask words) and a range of replica counts: the same seeded runs once through
+For 3-regular networks of 64 and 84 leaves (<= 2 mask words: sa_small_kernel) -- or `--leaves 128,256,512`: sa_lds_kernel --
+and a range of replica counts: the same seeded runs once through
 the library in the tree (which picks the LDS kernel while one round of its blocks holds every replica) and once through
 build_variants/lib_nosmall.so and lib_allsmall.so (`make -C tnco_amd/csrc nosmall allsmall`: the same sources with
 -DTNCO_NO_SMALL_TREE, always the HBM kernel, and with -DTNCO_SMALL_TREE_ALWAYS, the LDS kernel whatever the number of
@@ -75,8 +76,9 @@ def main():
     print("| leaves | mask words | replicas | HBM kernel move-evals/s | LDS kernel move-evals/s | library move-evals/s | library's kernel | library / HBM | same end states | replicas failing validate |")
     print("|---|---|---|---|---|---|---|---|---|---|")
     for t, h, l in zip(res["tree"], res["hbm"], res["lds"]):
-        assert (t["n"], t["R"]) == (h["n"], h["R"]) == (l["n"], l["R"]) and not h["lds"] and l["lds"]
-        print(f"| {t['n']} | {t['W']} | {t['R']} | {h['rate']:.3e} | {l['rate']:.3e} | {t['rate']:.3e} | {'LDS-resident' if t['lds'] else 'HBM'} | {t['rate'] / h['rate']:.2f} | "
+        assert (t["n"], t["R"]) == (h["n"], h["R"]) == (l["n"], l["R"]) and not h["lds"]
+        lds_rate = f"{l['rate']:.3e}" if l["lds"] else "(a tree does not fit)"
+        print(f"| {t['n']} | {t['W']} | {t['R']} | {h['rate']:.3e} | {lds_rate} | {t['rate']:.3e} | {'LDS-resident' if t['lds'] else 'HBM'} | {t['rate'] / h['rate']:.2f} | "
               f"{t['state'] == h['state'] == l['state']} | {t['bad'] + h['bad'] + l['bad']} |")
 
 
