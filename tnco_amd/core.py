@@ -530,8 +530,8 @@ class BatchedOptimizer:
     @property
     def launch_groups(self) -> int:
         """Concurrent launches (streams) a step of run() is split into: 1, or 2 when the replicas do not fill
-        whole rounds of resident workgroups (tnco_hip_run); 0 for a handle of few small trees, whose sweeps run
-        LDS-resident (csrc/sa_small.h)."""
+        whole rounds of resident workgroups (tnco_hip_run); 0 for a handle whose sweeps run LDS-resident (small trees;
+        larger ones when the whole batch fits the CUs' LDS: csrc/sa_small.h)."""
         return int(self._L.tnco_hip_diag_launch_groups(self._h))
 
     @property

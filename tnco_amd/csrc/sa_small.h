@@ -22,11 +22,18 @@
 // (tnco_hip_create).  History: round 2 had a first version as an opt-in and measured only the 65 536-replica case (6.8e9
 // against 7.4e9), round 3 removed it, round 5 re-measured it where it can win and rebuilt the loop around the rules above.
 //
-// Conditions (host: launch_run_lk<2, 1>): no hyper-indices, uniform power-of-two dims, float64 cost,
-// no sparse legs (the fast cost path), at most 2 mask words (4 lanes x 1 word layout), at most 254
-// nodes, a log that starts at the checkpoint (no min_links given).  LDS record of an internal node, 32 bytes:
-//     [ left right parent - | cost exponent (u16) - | partial cost f64 | legs: 2 words ]
-// (links fit a byte; a contraction cost is 2^e exactly -- or +inf, e = 1024 -- so e is kept).
+// Two kernels around one loop (small_sweeps<Store>), differing in where a block keeps its trees (the stores below):
+//   sa_small_kernel<NI, 64>: up to 128 leaves and 2 mask words -- byte links, one 32-byte record per node
+//     [ left right parent - | cost exponent | partial cost f64 | legs: 2 words ], the leaf legs a table of the block; static
+//     LDS, 16 replicas per block, 64 (<= 64 leaves) or 32 replicas per CU.  Picked for every batch up to 64 leaves, beyond
+//     while two rounds of blocks hold the batch.
+//   sa_lds_kernel<K>: any other tree of up to 16 mask words whose whole BATCH fits the CUs' LDS at once (the latency regime of
+//     the larger networks: a 512-leaf tree of 12 words is 58 KiB, two per CU, 512 replicas) -- 16-bit links, arrays of
+//     [links | exponent], partial costs, legs; the leaf legs as lists of at most 8 index positions, expanded where needed;
+//     dynamic LDS carved by the host (LdsPlan).  x1.3 ... x2.3 the HBM kernel per replica (profiles/r05_small_tree_ab.txt).
+// Conditions of both: the fast cost path (no hyper-indices, uniform power-of-two dims, float64 cost, no sparse legs), four
+// lanes per replica, a log that starts at the checkpoint (no min_links given).  A contraction cost is 2^e exactly -- or
+// +inf, e >= 1024 -- so the exponent is what the records keep.
 #pragma once
 #include "sa_sweep.h"
 
