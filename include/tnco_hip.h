@@ -259,9 +259,9 @@ int tnco_hip_diag_kernel_times(tnco_hip_handle h, double* ms4, int64_t* launches
 
 /* Concurrent launches a step of tnco_hip_run is split into (1, or 2 when there are more workgroups than resident ones: see
  * tnco_hip_run).  0: the handle keeps its trees in LDS during a launch (csrc/sa_small.h; the fast cost path only: uniform
- * power-of-two dims, float64, no hyper-indices, no sparse legs, no best trees handed in) -- trees of up to 64 leaves and 128
- * indices whatever the number of replicas, up to 128 leaves while the CUs hold the replicas in two rounds of 32 per CU, and
- * any tree of up to 1024 indices (at most 8 per tensor) when the whole batch fits the CUs' LDS at once (512 leaves: 512
+ * power-of-two dims, float64, no sparse legs, no best trees handed in) -- without hyper-indices trees of up to 64 leaves and
+ * 128 indices whatever the number of replicas, up to 128 leaves while the CUs hold the replicas in two rounds of 32 per CU, and
+ * any tree of up to 1024 indices (at most 32 per tensor) when the whole batch fits the CUs' LDS at once (512 leaves: 512
  * replicas).  There are no workgroups of node blocks to split.  Same results either way, bit for bit. */
 int tnco_hip_diag_launch_groups(tnco_hip_handle h);
 

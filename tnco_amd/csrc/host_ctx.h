@@ -53,7 +53,7 @@ struct tnco_hip_ctx {
   bool lds_tree = false;    // any tree whose replicas fit the CUs' LDS in two rounds: sa_lds_kernel with the plan below
   bool lds_attr_set = false;
   tnco::LdsPlan lds_plan{};
-  uint64_t* leaf_idx = nullptr;  // [n][2] the leaves' index positions (8 x 16 bits), device
+  uint64_t* leaf_idx = nullptr;  // [n][lds_plan.leaf_stride] the leaves' index positions (16 bits each), device
   tnco::FwParams F{};
   std::vector<void*> allocs;
   std::vector<size_t> alloc_bytes;  // (destroy hands the blocks to tnco::DevCache)

@@ -46,12 +46,16 @@ void launch_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int pr
   if constexpr (LOG2L == 2) {
     if (h->lds_tree) {
       const LdsPlan& pl = h->lds_plan;
+      const void* kern = h->hyper ? (const void*)sa_lds_kernel<K, true> : (const void*)sa_lds_kernel<K, false>;
       if (!h->lds_attr_set) {  // (more dynamic LDS than the 64 KiB a kernel gets by default)
-        (void)hipFuncSetAttribute((const void*)sa_lds_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, pl.total);
+        (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, pl.total);
         h->lds_attr_set = true;
       }
-      hipLaunchKernelGGL((sa_lds_kernel<K>), dim3((unsigned)((P.R + pl.seats - 1) / pl.seats)), dim3(SMALL_TPB), (size_t)pl.total, s, P,
-                         betas, n_steps, prob_kind, pl, h->leaf_idx);
+      const dim3 lgrid((unsigned)((P.R + pl.seats - 1) / pl.seats));
+      if (h->hyper)
+        hipLaunchKernelGGL((sa_lds_kernel<K, true>), lgrid, dim3(SMALL_TPB), (size_t)pl.total, s, P, betas, n_steps, prob_kind, pl, h->leaf_idx);
+      else
+        hipLaunchKernelGGL((sa_lds_kernel<K, false>), lgrid, dim3(SMALL_TPB), (size_t)pl.total, s, P, betas, n_steps, prob_kind, pl, h->leaf_idx);
       return;
     }
   }

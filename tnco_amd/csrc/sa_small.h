@@ -29,7 +29,7 @@
 //     while two rounds of blocks hold the batch.
 //   sa_lds_kernel<K>: any other tree of up to 16 mask words whose whole BATCH fits the CUs' LDS at once (the latency regime of
 //     the larger networks: a 512-leaf tree of 12 words is 58 KiB, two per CU, 512 replicas) -- 16-bit links, arrays of
-//     [links | exponent], partial costs, legs; the leaf legs as lists of at most 8 index positions, expanded where needed;
+//     [links | exponent], partial costs, legs; the leaf legs as lists of at most 32 index positions, expanded where needed;
 //     dynamic LDS carved by the host (LdsPlan).  x1.3 ... x2.3 the HBM kernel per replica (profiles/r05_small_tree_ab.txt).
 // Conditions of both: the fast cost path (no hyper-indices, uniform power-of-two dims, float64 cost, no sparse legs), four
 // lanes per replica, a log that starts at the checkpoint (no min_links given).  A contraction cost is 2^e exactly -- or
@@ -103,8 +103,8 @@ __device__ __forceinline__ uint32_t small_exp_of(double c) {
 //   SmallStore<NI>: up to 128 leaves and 2 mask words -- links are bytes, a node is one 32-byte record, the leaf legs a
 //     table of the block; static LDS, 16 replicas per block.  <63>: 38.5 KiB, four blocks per CU; <127>: 72.5 KiB, two.
 //   WideStore<K>: any tree whose replicas fit -- 16-bit links, up to 16 mask words (4 lanes x K words), separate arrays
-//     for [links | cost exponent], partial costs and legs, the leaf legs as lists of index positions (at most 8 per
-//     leaf; expanded where a leaf's legs are needed); dynamic LDS carved by the host (LdsPlan), 1 ... 16 replicas per
+//     for [links | cost exponent], partial costs and legs, the leaf legs as a table while that is small (<= 16 KiB), else as lists
+//     of index positions (at most 32 per leaf; expanded where a leaf's legs are needed); dynamic LDS carved by the host (LdsPlan), 1 ... 16 replicas per
 //     block: a 512-leaf tree of 12 words is 58 KiB, two per CU.
 // ---------------------------------------------------------------------------------------------------------------
 typedef TNCO_LDS volatile uint64_t lvu64;
@@ -156,7 +156,8 @@ struct SmallStore {
 // The host's carve of a block's dynamic LDS for WideStore (bytes; tnco_hip_create).
 struct LdsPlan {
   int seats;        // replicas per block (1 ... 16): lane groups beyond them idle
-  int deg;          // index positions per leaf at most (<= 8)
+  int leaf_stride;  // 64-bit words per leaf in the index lists: four 16-bit index positions each (1 ... 8); 0: a table of legs
+  int leaf_words;   // 64-bit words of the leaf lists / table
   int seat0, seat_stride;                       // first seat, bytes per seat
   int o_part, o_legs, o_lpar, o_ring, o_jb;     // inside a seat ([links | exponent] first)
   int total;        // bytes of the block
@@ -170,8 +171,8 @@ struct WideStore {
   lvf64* part;
   lvu64* leg;       // [node][4 K]: word k * 4 + lane of node i at i * 4 K + k * 4 + lane (the lanes' k-major layout)
   lvu16* lpar;
-  lvu64* leaf;      // [leaf][2]: eight 16-bit index positions, 0xFFFF: none
-  int n, lig, deg;
+  lvu64* leaf;      // [leaf][stride]: 4 x stride 16-bit index positions, 0xFFFF: none; stride 0: [leaf][4 K] the legs themselves
+  int n, lig, stride;
   static __device__ __forceinline__ uint64_t pack(int l, int r, int p, uint32_t e) {
     return (uint64_t)(uint32_t)l | ((uint64_t)(uint32_t)r << 16) | ((uint64_t)((uint32_t)p & 0xFFFFu) << 32) | ((uint64_t)e << 48);
   }
@@ -188,14 +189,21 @@ struct WideStore {
   __device__ __forceinline__ void set_partial(int i, double v) const { part[i] = v; }
   __device__ __forceinline__ Mask<K> legs(int x) const {
     Mask<K> m = mzero<K>();
-    if (x < n) {  // a leaf: its index positions, expanded into this lane's words
-      const uint64_t lo = leaf[2 * x], hi = leaf[2 * x + 1];
-      for (int j = 0; j < deg; ++j) {
-        const uint32_t idx = (uint32_t)((j < 4 ? lo >> (16 * j) : hi >> (16 * (j - 4))) & 0xFFFF);
-        const int w = (int)(idx >> 6);
-        const uint64_t bit = idx == 0xFFFFu ? 0ull : 1ull << (idx & 63u);
+    if (stride == 0) {  // the leaf legs as a table of rows like the nodes': one read sequence, the address selected
+      lvu64* a = x < n ? leaf + x * (4 * K) : leg + (x - n) * (4 * K);
 #pragma unroll
-        for (int k = 0; k < K; ++k) m.w[k] |= w == k * 4 + lig ? bit : 0ull;
+      for (int k = 0; k < K; ++k) m.w[k] = a[k * 4 + lig];
+    } else if (x < n) {  // a leaf: its index positions, expanded into this lane's words
+      for (int q = 0; q < stride; ++q) {
+        const uint64_t v = leaf[x * stride + q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t idx = (uint32_t)(v >> (16 * j)) & 0xFFFFu;
+          const int w = (int)(idx >> 6);
+          const uint64_t bit = idx == 0xFFFFu ? 0ull : 1ull << (idx & 63u);
+#pragma unroll
+          for (int k = 0; k < K; ++k) m.w[k] |= w == k * 4 + lig ? bit : 0ull;
+        }
       }
     } else {
 #pragma unroll
@@ -215,7 +223,9 @@ struct WideStore {
 };
 
 // The sweeps of one replica group (4 lanes) on a tree held by store `st` (copied in by the caller, copied out by it).
-template <class Store>
+// HYPER: networks with hyper-indices -- hyper[p] = legs(p) & legs(c0) & legs(c1) (infinite_memory/utils.hpp:82-91) is derived
+// from the own legs of B and A, which are carried (and A's parent's read ahead) next to the children's, as in sa_run_kernel.
+template <bool HYPER, class Store>
 __device__ __forceinline__ void small_sweeps(const Params& P, const Store& st, const int64_t r, const int lig,
                                              lds_vu32* ringbuf, lds_vi32* jbuf, const double* __restrict__ betas,
                                              const int64_t n_steps, const int prob_kind) {
@@ -258,6 +268,7 @@ __device__ __forceinline__ void small_sweeps(const Params& P, const Store& st, c
   // ... and, read one iteration ahead: A's record (links | cost exponent << 32), the legs and the partial cost of B's sibling
   uint64_t hdA = 0;
   M mC = mzero<K>();
+  [[maybe_unused]] M hB = mzero<K>(), hA = mzero<K>();  // (HYPER) the own legs of B and of A
   double pC = 0;
   bool active = true;
   // the beta of the NEXT sweep is loaded while this one runs (see the schedule below)
@@ -308,9 +319,13 @@ __device__ __forceinline__ void small_sweeps(const Params& P, const Store& st, c
       const int C = c_is_right ? ar : al;
       // next iteration's operands, first half: the record of A's parent (nothing of it changes in this move)
       const uint64_t hdN = st.head(aP < 0 ? 0 : aP - n);
-      uint32_t w0 = mpopc<K>(mor<K>(mxor<K>(m0, mC), m1)) | (mpopc<K>(mor<K>(m0, mC)) << 13) |
+      // hyper[A] | hyper[B] (optimizer.hpp:145-147)
+      const M hy = HYPER ? mand<K>(hB, mor<K>(mand<K>(hA, mC), mand<K>(m0, m1))) : mzero<K>();
+      [[maybe_unused]] M hN = mzero<K>();
+      if constexpr (HYPER) hN = st.legs(aP < 0 ? n : aP);  // (the own legs of A's parent: the next move's hA)
+      uint32_t w0 = mpopc<K>(mor<K>(mor<K>(mxor<K>(m0, mC), hy), m1)) | (mpopc<K>(mor<K>(m0, mC)) << 13) |
                     ((mnonzero<K>(mand<K>(m0, mC)) ? 1u : 0u) << 26);
-      uint32_t w1 = mpopc<K>(mor<K>(mxor<K>(m1, mC), m0)) | (mpopc<K>(mor<K>(m1, mC)) << 13) |
+      uint32_t w1 = mpopc<K>(mor<K>(mor<K>(mxor<K>(m1, mC), hy), m0)) | (mpopc<K>(mor<K>(m1, mC)) << 13) |
                     ((mnonzero<K>(mand<K>(m1, mC)) ? 1u : 0u) << 26);
       SMALL_PROF_M(1);
       w0 = gsum<LOG2L>(w0);
@@ -325,7 +340,7 @@ __device__ __forceinline__ void small_sweeps(const Params& P, const Store& st, c
       const bool pick0 = rpick ? (d0 & 1u) != 0 : inter0;
       n_rpick += rpick ? 1u : 0u;
       const M mD = msel<K>(pick0, m0, m1), mE = msel<K>(pick0, m1, m0);
-      const M newB = mxor<K>(mD, mC);
+      const M newB = mor<K>(mxor<K>(mD, mC), hy);  // (optimizer.hpp:147)
       const double pD = pick0 ? p0 : p1, pE = pick0 ? p1 : p0;
       const int E = pick0 ? br : bl;
       const uint32_t enA = (uint32_t)log2d * ((pick0 ? w0 : w1) & 0x1fffu);
@@ -351,7 +366,7 @@ __device__ __forceinline__ void small_sweeps(const Params& P, const Store& st, c
       const double ccB = acc ? nB : ccB0, ccA = acc ? nA : ccA0;
       total = acc ? total + delta : total;  // :177
       const double pEcur = acc ? pC : pE, pCcur = acc ? pE : pC;
-      const M mBnow = msel<K>(acc, newB, mxor<K>(m0, m1)), mX = msel<K>(acc, mE, mC);
+      const M mBnow = msel<K>(acc, newB, HYPER ? hB : mxor<K>(m0, m1)), mX = msel<K>(acc, mE, mC);
       // :185-188
       partB = (pD + pEcur) + ccB;
       const double partA = (partB + pCcur) + ccA;
@@ -379,6 +394,7 @@ __device__ __forceinline__ void small_sweeps(const Params& P, const Store& st, c
       B = A; bl = al; br = ar; eB = eAn; partB = partA;
       A = aP;
       hdA = hdN; mC = mCN; pC = pCN;
+      if constexpr (HYPER) { hB = hA; hA = hN; }
       SMALL_PROF_M(4);
     }
     SMALL_PROF_C(2);
@@ -434,6 +450,7 @@ __device__ __forceinline__ void small_sweeps(const Params& P, const Store& st, c
         bpend = true;
         hdA = st.head(A < 0 ? 0 : A - n);  // the first move's operands
         m0 = st.legs(bl); m1 = st.legs(br);
+        if constexpr (HYPER) { hB = st.legs(B); hA = st.legs(A < 0 ? n : A); }
         p0 = partial_of(bl); p1 = partial_of(br);
         const int C = Store::left_of(hdA) == B ? Store::right_of(hdA) : Store::left_of(hdA);
         mC = st.legs(C);
@@ -506,7 +523,7 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
   }
   for (int i = lig; i < n; i += L) st.lpar[i] = (uint8_t)lp[(int64_t)i * LPS];
   // (LDS operations of one wavefront are executed in order: no barrier between a group's own writes and reads)
-  small_sweeps(P, st, r, lig, (lds_vu32*)rngbuf + gib * R::RING, (lds_vi32*)jbuf + gib * 16, betas, n_steps, prob_kind);
+  small_sweeps<false>(P, st, r, lig, (lds_vu32*)rngbuf + gib * R::RING, (lds_vi32*)jbuf + gib * 16, betas, n_steps, prob_kind);
   for (int i = lig; i < ni; i += L) {
     const uint64_t hd = st.head(i);
     NodeRec o;
@@ -523,8 +540,9 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
   for (int i = lig; i < n; i += L) lp[(int64_t)i * LPS] = (int32_t)st.lpar[i];
 }
 
-// <K>: 4 lanes x K words per replica; the block's LDS as the host carved it (LdsPlan), leaf_idx = [n][8] index positions.
-template <int K>
+// <K>: 4 lanes x K words per replica; the block's LDS as the host carved it (LdsPlan), leaf_idx = [n][4 x leaf_stride] index
+// positions.
+template <int K, bool HYPER>
 __global__ __launch_bounds__(SMALL_TPB) void sa_lds_kernel(const Params P, const double* __restrict__ betas, const int64_t n_steps,
                                                            const int prob_kind, const LdsPlan pl,
                                                            const uint64_t* __restrict__ leaf_idx) {
@@ -536,7 +554,7 @@ __global__ __launch_bounds__(SMALL_TPB) void sa_lds_kernel(const Params P, const
   const int gib = tid >> 2;
   const int64_t r = (int64_t)blockIdx.x * pl.seats + gib;
   const int n = P.n, ni = n - 1, W = P.W;
-  for (int i = tid; i < n * 2; i += SMALL_TPB) ((lvu64*)lds)[i] = leaf_idx[i];
+  for (int i = tid; i < pl.leaf_words; i += SMALL_TPB) ((lvu64*)lds)[i] = leaf_idx[i];
   __syncthreads();
   if (gib >= pl.seats || r >= P.R || n_steps <= 0) return;
   TNCO_LDS uint8_t* seat = lds + pl.seat0 + gib * pl.seat_stride;
@@ -546,7 +564,7 @@ __global__ __launch_bounds__(SMALL_TPB) void sa_lds_kernel(const Params P, const
   st.leg = (lvu64*)(seat + pl.o_legs);
   st.lpar = (lvu16*)(seat + pl.o_lpar);
   st.leaf = (lvu64*)lds;
-  st.n = n; st.lig = lig; st.deg = pl.deg;
+  st.n = n; st.lig = lig; st.stride = pl.leaf_stride;
   uint8_t* blk = P.blocks + r * P.RB;
   int32_t* lp = P.lpar + r * (int64_t)n * LPS;
   for (int i = lig; i < ni; i += L) {
@@ -557,7 +575,7 @@ __global__ __launch_bounds__(SMALL_TPB) void sa_lds_kernel(const Params P, const
     for (int w = 0; w < 4 * K; ++w) st.leg[i * (4 * K) + w] = w < W ? lg[w] : 0ull;
   }
   for (int i = lig; i < n; i += L) st.lpar[i] = (uint16_t)lp[(int64_t)i * LPS];
-  small_sweeps(P, st, r, lig, (lds_vu32*)(seat + pl.o_ring), (lds_vi32*)(seat + pl.o_jb), betas, n_steps, prob_kind);
+  small_sweeps<HYPER>(P, st, r, lig, (lds_vu32*)(seat + pl.o_ring), (lds_vi32*)(seat + pl.o_jb), betas, n_steps, prob_kind);
   for (int i = lig; i < ni; i += L) {
     const uint64_t hd = st.head(i);
     NodeRec o;

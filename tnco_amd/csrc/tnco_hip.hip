@@ -1084,24 +1084,36 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
 #endif
       // Any other tree of the fast cost path whose replicas fit the CUs' LDS at once (the latency regime of the larger
       // networks: 512 leaves of 12 words are 58 KiB, two per CU, up to 512 replicas): sa_lds_kernel.
-      if (!h->small_tree && !h->hyper && !h->generic && LPS == 1 && !d->min_links && n >= 2 && h->log2l == 2 && I <= 65535 &&
+      if (!h->small_tree && !h->generic && LPS == 1 && !d->min_links && n >= 2 && h->log2l == 2 && I <= 65535 &&
           N <= 65534 && (int64_t)P.log2d * 64 * W <= 65535) {
-        std::vector<uint64_t> idx((size_t)n * 2, ~0ull);
-        int deg = 0;
-        for (int t = 0; t < n && deg <= 8; ++t) {
+        int deg = 0;  // index positions per leaf at most
+        for (int t = 0; t < n; ++t) {
           int c = 0;
-          for (int p = 0; p < I; ++p)
-            if ((h->leafmask_w[(size_t)t * W + (p >> 6)] >> (p & 63)) & 1) {
-              if (c < 8) idx[(size_t)t * 2 + (c >> 2)] = (idx[(size_t)t * 2 + (c >> 2)] & ~(0xFFFFull << (16 * (c & 3)))) | ((uint64_t)p << (16 * (c & 3)));
-              ++c;
-            }
+          for (int w = 0; w < W; ++w) c += __builtin_popcountll(h->leafmask_w[(size_t)t * W + w]);
           deg = std::max(deg, c);
         }
-        if (deg <= 8) {
+        const bool table = (int64_t)n * 32 * h->K <= 16384;  // the leaf legs themselves, [n][4 K] words
+        if (table || deg <= 32) {
+          const int stride = table ? 0 : std::max(1, (deg + 3) / 4);
+          std::vector<uint64_t> idx(table ? (size_t)n * 4 * h->K : (size_t)n * stride, table ? 0ull : ~0ull);
+          for (int t = 0; t < n; ++t) {
+            if (table) {
+              for (int w = 0; w < W; ++w) idx[(size_t)t * 4 * h->K + w] = h->leafmask_w[(size_t)t * W + w];
+              continue;
+            }
+            int c = 0;
+            for (int p = 0; p < I; ++p)
+              if ((h->leafmask_w[(size_t)t * W + (p >> 6)] >> (p & 63)) & 1) {
+                uint64_t& q = idx[(size_t)t * stride + (c >> 2)];
+                q = (q & ~(0xFFFFull << (16 * (c & 3)))) | ((uint64_t)p << (16 * (c & 3)));
+                ++c;
+              }
+          }
           const int K = h->K, ni = n - 1;
           LdsPlan pl{};
-          pl.deg = deg;
-          pl.seat0 = (n * 16 + 15) / 16 * 16;
+          pl.leaf_stride = stride;
+          pl.leaf_words = (int)idx.size();
+          pl.seat0 = (pl.leaf_words * 8 + 15) / 16 * 16;
           pl.o_part = 8 * ni;
           pl.o_legs = 16 * ni;
           pl.o_lpar = pl.o_legs + 32 * K * ni;
@@ -1129,7 +1141,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
             const int64_t waves = (int64_t)pl.blocks_per_cu * prop.multiProcessorCount;
             pl.seats = (int)std::max<int64_t>(1, std::min<int64_t>(pl.seats, (R + waves - 1) / waves));
             pl.total = pl.seat0 + pl.seats * pl.seat_stride;
-            HIP_TRY(h->alloc(&h->leaf_idx, (int64_t)n * 2));
+            HIP_TRY(h->alloc(&h->leaf_idx, (int64_t)idx.size()));
             HIP_TRY(hipMemcpy(h->leaf_idx, idx.data(), idx.size() * 8, hipMemcpyHostToDevice));
             h->lds_plan = pl;
             h->lds_tree = true;

@@ -26,7 +26,10 @@ def child(a):
     import numpy as np
     from tnco_amd import core, synthetic as syn
     for n in [int(x) for x in a.leaves.split(",")]:
-        prob = syn.regular_problem(n, graph_seed=7 if n == 64 else 11)
+        if a.hyper:  # a network with hyper-indices: n tensors of 3 indices each out of 1.5 n, 5 of them open
+            prob = syn.Problem(*(lambda ts, d, out: (ts, 2, out))(*syn.random_hyper_tn(n, 3 * n // 2, k=3, n_output=5, seed=n)))
+        else:
+            prob = syn.regular_problem(n, graph_seed=7 if n == 64 else 11)
         betas = syn.linear_betas(0.0, 100.0, a.sweeps)
         for R in [int(x) for x in a.runs.split(",")]:
             seeds = syn.replica_seeds(R)
@@ -54,6 +57,7 @@ def main():
     ap.add_argument("--sweeps", type=int, default=2010)
     ap.add_argument("--runs", default="64,512,2048,4096,8192,16384,32768,65536")
     ap.add_argument("--leaves", default="64,84")
+    ap.add_argument("--hyper", action="store_true", help="networks with hyper-indices (random_hyper_tn) instead of 3-regular ones")
     ap.add_argument("--child", action="store_true")
     a = ap.parse_args()
     if a.child:
@@ -67,12 +71,12 @@ def main():
         env.pop("TNCO_HIP_LIB", None)
         if lib:
             env["TNCO_HIP_LIB"] = lib
-        out = subprocess.run([sys.executable, __file__, "--child", "--sweeps", str(a.sweeps), "--runs", a.runs, "--leaves", a.leaves],
+        out = subprocess.run([sys.executable, __file__, "--child", "--sweeps", str(a.sweeps), "--runs", a.runs, "--leaves", a.leaves] + (["--hyper"] if a.hyper else []),
                              env=env, capture_output=True, text=True, stdin=subprocess.DEVNULL)
         if out.returncode:
             sys.exit(out.stderr[-3000:])
         res[name] = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
-    print(f"# {a.sweeps} sweeps, beta 0 -> 100, Metropolis, float64, 3-regular networks; 'library' = tnco_amd/libtnco_hip.so, 'HBM' / 'LDS' = the same sources with -DTNCO_NO_SMALL_TREE / -DTNCO_SMALL_TREE_ALWAYS")
+    print(f"# {a.sweeps} sweeps, beta 0 -> 100, Metropolis, float64, {'networks with hyper-indices (n tensors x 3 indices out of 1.5 n)' if a.hyper else '3-regular networks'}; 'library' = tnco_amd/libtnco_hip.so, 'HBM' / 'LDS' = the same sources with -DTNCO_NO_SMALL_TREE / -DTNCO_SMALL_TREE_ALWAYS")
     print("| leaves | mask words | replicas | HBM kernel move-evals/s | LDS kernel move-evals/s | library move-evals/s | library's kernel | library / HBM | same end states | replicas failing validate |")
     print("|---|---|---|---|---|---|---|---|---|---|")
     for t, h, l in zip(res["tree"], res["hbm"], res["lds"]):
