@@ -61,3 +61,17 @@ def test_lds_budget_of_the_small_tree_kernels(report):
         lds = seen[ni]["group_segment_fixed_size"]
         assert (160 * 1024 // lds) * 16 == per_cu, (ni, lds)
         assert seen[ni]["private_segment_fixed_size"] == 0 and seen[ni]["vgpr_count"] <= 256
+
+
+def test_the_lds_kernels_of_larger_trees_use_no_scratch(report):
+    """sa_lds_kernel<K, HYPER> (csrc/sa_small.h): one wavefront per block and at most four blocks per CU -- registers do not
+    bound its occupancy (LDS does, and the host carves that), scratch would: none, in all eight instantiations."""
+    import code_objects
+    seen = {}
+    for elf in code_objects.code_objects():
+        for name, meta in code_objects.kernel_table(elf).items():
+            if "sa_lds_kernel" in name:
+                seen[name] = meta
+    assert len(seen) == 8, sorted(seen)
+    for name, meta in seen.items():
+        assert meta["private_segment_fixed_size"] == 0 and meta["vgpr_spill_count"] == 0 and meta["vgpr_count"] <= 256, (name, meta)
