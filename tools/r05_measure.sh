@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/r05_measure.sh PART -- the round-5 measurement set on the GPU box, from the library in the tree, in parts
 # (one gpurun call each; everything lands in gpurun_out/r05/ and is copied into profiles/r05_*):
-#   bench     tools/profile_round.sh: bench.py with its PMC passes + rocprofv3 --kernel-trace --stats of the same command
+#   bench     tools/profile_round.sh: bench.py --gpus 1 --steps 20 --warmup 5 (the command the driver runs) with its PMC passes + rocprofv3 --kernel-trace --stats of the same command
 #   other     tools/r05_other.sh: cost models, circuit networks, network sizes
 #   widths    the finite-width leg at max_width 28 / 32 / 40
 #   e2e       tools/time_e2e.py, tools/latency_regime.py
@@ -15,7 +15,7 @@ mkdir -p "$OUT"
 cd "$ROOT"
 case $PART in
 bench)
-  timeout 1200 bash tools/profile_round.sh r05 < /dev/null > "$OUT/profile_round.log" 2>&1
+  timeout 1200 bash tools/profile_round.sh r05 --gpus 1 --steps 20 --warmup 5 < /dev/null > "$OUT/profile_round.log" 2>&1
   cp gpurun_out/prof_r05/bench.json gpurun_out/prof_r05/pmc_traffic.json gpurun_out/prof_r05/kernel_stats.csv "$OUT/" 2>/dev/null
   tail -14 "$OUT/profile_round.log" ;;
 other)
