@@ -34,12 +34,12 @@ void launch_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int pr
   const Params& P = h->P;
   if constexpr (LOG2L == 2 && K == 1) {
     if (h->small_tree) {  // (one launch for all the replicas: such a handle has one group)
+      const int seats = h->small_seats;
+      const dim3 sgrid((unsigned)((P.R + seats - 1) / seats));
       if (P.n - 1 <= 63)
-        hipLaunchKernelGGL((sa_small_kernel<63, SMALL_TPB>), dim3((unsigned)((P.R + SMALL_TPB / 4 - 1) / (SMALL_TPB / 4))), dim3(SMALL_TPB), 0, s, P, betas, n_steps,
-                           prob_kind);
+        hipLaunchKernelGGL((sa_small_kernel<63, SMALL_TPB>), sgrid, dim3(SMALL_TPB), 0, s, P, betas, n_steps, prob_kind, seats);
       else
-        hipLaunchKernelGGL((sa_small_kernel<127, SMALL_TPB>), dim3((unsigned)((P.R + SMALL_TPB / 4 - 1) / (SMALL_TPB / 4))), dim3(SMALL_TPB), 0, s, P, betas, n_steps,
-                           prob_kind);
+        hipLaunchKernelGGL((sa_small_kernel<127, SMALL_TPB>), sgrid, dim3(SMALL_TPB), 0, s, P, betas, n_steps, prob_kind, seats);
       return;
     }
   }

@@ -228,19 +228,23 @@ struct WideStore {
 template <bool HYPER, class Store>
 __device__ __forceinline__ void small_sweeps(const Params& P, const Store& st, const int64_t r, const int lig,
                                              lds_vu32* ringbuf, lds_vi32* jbuf, const double* __restrict__ betas,
-                                             const int64_t n_steps, const int prob_kind) {
+                                             const int64_t n_steps, const int prob_kind, const bool master) {
   constexpr int LOG2L = 2, K = Store::K, L = 4;
   using M = Mask<K>;
   using R = Rng<LOG2L, 64>;
   const int n = P.n, N = P.N;
-  const bool lane0 = lig == 0;
+  // `master`: a wavefront with fewer replicas than lane groups runs the spare groups as SHADOWS of its replicas -- same
+  // replica, same LDS seat, same reads, hence the same values and the same control flow, no store of their own.  A CU
+  // with fewer than 64 active lanes runs its wavefronts markedly slower (and one after the other: tools/few_lanes.hip,
+  // profiles/r05_few_lanes.txt); shadows cost no instruction and keep every lane active.
+  const bool lane0 = lig == 0 && master;
   auto partial_of = [&](int x) -> double {  // (a leaf: 0; the read is unconditional, the address selected)
     const double v = st.partial(x < n ? 0 : x - n);
     return x < n ? 0.0 : v;
   };
   R rng;
   const ReplicaState* rs0 = P.rs + r;
-  rng.init(P, r, ringbuf, rs0->mti, rs0->mtw, lig);
+  rng.init(P, r, ringbuf, rs0->mti, rs0->mtw, master ? lig : 64);  // (lane index 64: neither loads nor stores of the generator)
   double min_cost = rs0->min_cost;
   uint32_t jmin = rs0->jmin, jtail = rs0->jtail;
   bool jinvalid = rs0->jinvalid != 0;
@@ -248,7 +252,7 @@ __device__ __forceinline__ void small_sweeps(const Params& P, const Store& st, c
   const uint32_t jcap = (uint32_t)P.jcap;
   int32_t* jlog = P.jlog + r * (int64_t)P.jcap;
   auto jb = [&](int i) -> lds_vi32& { return jbuf[i]; };
-  if ((jtail & 15u) != 0u) {
+  if (master && (jtail & 15u) != 0u) {
     const int4 t = *reinterpret_cast<const int4*>(jlog + (jtail & ~15u) + 4 * lig);
     jb(4 * lig + 0) = t.x; jb(4 * lig + 1) = t.y; jb(4 * lig + 2) = t.z; jb(4 * lig + 3) = t.w;
   }
@@ -383,9 +387,9 @@ __device__ __forceinline__ void small_sweeps(const Params& P, const Store& st, c
         st.set_head(B - n, Store::pack(bl, br, A, eBn));
         st.set_partial(B - n, partB);
       }
-      if (acc) st.set_legs(B - n, newB);
+      if (acc && master) st.set_legs(B - n, newB);
       jtail += logged ? 1u : 0u;
-      if (logged && (jtail & 15u) == 0u)  // a 64-byte piece of the log is complete
+      if (master && logged && (jtail & 15u) == 0u)  // a 64-byte piece of the log is complete
         *reinterpret_cast<int4*>(jlog + (jtail - 16u) + 4 * lig) =
             make_int4(jb(4 * lig + 0), jb(4 * lig + 1), jb(4 * lig + 2), jb(4 * lig + 3));
       // :191  B <- A
@@ -413,7 +417,7 @@ __device__ __forceinline__ void small_sweeps(const Params& P, const Store& st, c
           ++n_impr;
           if (jinvalid) {  // the log overflowed: re-base the checkpoint on the current tree
             Links* __restrict__ ml = P.minlinks + r * (int64_t)N;
-            for (int i = lig; i < N; i += L) {
+            for (int i = master ? lig : N; i < N; i += L) {
               Links o;
               if (i < n) {
                 o.left = -1; o.right = -1; o.parent = st.leaf_parent(i);
@@ -463,7 +467,7 @@ __device__ __forceinline__ void small_sweeps(const Params& P, const Store& st, c
     }
   }
 
-  if ((jtail & 15u) != 0u)
+  if (master && (jtail & 15u) != 0u)
     *reinterpret_cast<int4*>(jlog + (jtail & ~15u) + 4 * lig) =
         make_int4(jb(4 * lig + 0), jb(4 * lig + 1), jb(4 * lig + 2), jb(4 * lig + 3));
   int mti, mtw;
@@ -488,7 +492,7 @@ __device__ __forceinline__ void small_sweeps(const Params& P, const Store& st, c
 // <NI, TPB>: internal nodes the static arrays are sized for (n - 1 <= NI); TPB / 4 = 16 replicas per block.
 template <int NI, int TPB>
 __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const double* __restrict__ betas,
-                                                       const int64_t n_steps, const int prob_kind) {
+                                                       const int64_t n_steps, const int prob_kind, const int seats) {
   constexpr int L = 4, GPB = TPB / 4;
   using R = Rng<2, 64>;
   __shared__ SmallRec recbuf[GPB * NI];
@@ -499,8 +503,11 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
 
   const int tid = threadIdx.x;
   const int lig = tid & 3;
-  const int gib = tid >> 2;
-  const int64_t r = (int64_t)blockIdx.x * GPB + gib;
+  // (`seats` replicas per block, 1 ... 16 -- a small batch is spread over the chip's wavefront slots --; lane groups beyond
+  // them shadow the replicas: small_sweeps)
+  const int gib = (tid >> 2) % seats;
+  const bool master = (tid >> 2) < seats;
+  const int64_t r = (int64_t)blockIdx.x * seats + gib;
   const int n = P.n, ni = n - 1;
   // the leaf legs, shared by the replicas of the block (words 0, 1 of every row of the padded table)
   for (int i = tid; i < n * 2; i += TPB) leafbuf[i] = P.leafmask[(int64_t)(i >> 1) * L + (i & 1)];
@@ -513,7 +520,8 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
   st.n = n; st.lig = lig;
   uint8_t* blk = P.blocks + r * P.RB;
   int32_t* lp = P.lpar + r * (int64_t)n * LPS;
-  for (int i = lig; i < ni; i += L) {
+  const int lig0 = master ? lig : (1 << 30);  // (shadows copy nothing)
+  for (int i = lig0; i < ni; i += L) {
     const NodeRec* q = reinterpret_cast<const NodeRec*>(blk + (int64_t)i * P.BS);
     const uint64_t* lg = reinterpret_cast<const uint64_t*>(blk + (int64_t)i * P.BS + 32);
     st.set_head(i, SmallStore<NI>::pack(q->left, q->right, q->parent, small_exp_of(q->ccost)));
@@ -521,10 +529,10 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
     st.rec[i].legs[0] = lg[0];
     st.rec[i].legs[1] = P.W > 1 ? lg[1] : 0ull;
   }
-  for (int i = lig; i < n; i += L) st.lpar[i] = (uint8_t)lp[(int64_t)i * LPS];
+  for (int i = lig0; i < n; i += L) st.lpar[i] = (uint8_t)lp[(int64_t)i * LPS];
   // (LDS operations of one wavefront are executed in order: no barrier between a group's own writes and reads)
-  small_sweeps<false>(P, st, r, lig, (lds_vu32*)rngbuf + gib * R::RING, (lds_vi32*)jbuf + gib * 16, betas, n_steps, prob_kind);
-  for (int i = lig; i < ni; i += L) {
+  small_sweeps<false>(P, st, r, lig, (lds_vu32*)rngbuf + gib * R::RING, (lds_vi32*)jbuf + gib * 16, betas, n_steps, prob_kind, master);
+  for (int i = lig0; i < ni; i += L) {
     const uint64_t hd = st.head(i);
     NodeRec o;
     o.left = SmallStore<NI>::left_of(hd); o.right = SmallStore<NI>::right_of(hd);
@@ -537,7 +545,7 @@ __global__ __launch_bounds__(TPB) void sa_small_kernel(const Params P, const dou
     lg[0] = st.rec[i].legs[0];
     if (P.W > 1) lg[1] = st.rec[i].legs[1];
   }
-  for (int i = lig; i < n; i += L) lp[(int64_t)i * LPS] = (int32_t)st.lpar[i];
+  for (int i = lig0; i < n; i += L) lp[(int64_t)i * LPS] = (int32_t)st.lpar[i];
 }
 
 // <K>: 4 lanes x K words per replica; the block's LDS as the host carved it (LdsPlan), leaf_idx = [n][4 x leaf_stride] index
@@ -551,12 +559,13 @@ __global__ __launch_bounds__(SMALL_TPB) void sa_lds_kernel(const Params P, const
   TNCO_LDS uint8_t* lds = (TNCO_LDS uint8_t*)lds_raw;
   const int tid = threadIdx.x;
   const int lig = tid & 3;
-  const int gib = tid >> 2;
+  const int gib = (tid >> 2) % pl.seats;   // (lane groups beyond the seats shadow the replicas: small_sweeps)
+  const bool master = (tid >> 2) < pl.seats;
   const int64_t r = (int64_t)blockIdx.x * pl.seats + gib;
   const int n = P.n, ni = n - 1, W = P.W;
   for (int i = tid; i < pl.leaf_words; i += SMALL_TPB) ((lvu64*)lds)[i] = leaf_idx[i];
   __syncthreads();
-  if (gib >= pl.seats || r >= P.R || n_steps <= 0) return;
+  if (r >= P.R || n_steps <= 0) return;
   TNCO_LDS uint8_t* seat = lds + pl.seat0 + gib * pl.seat_stride;
   WideStore<K> st;
   st.hdr = (lvu64*)seat;
@@ -567,16 +576,17 @@ __global__ __launch_bounds__(SMALL_TPB) void sa_lds_kernel(const Params P, const
   st.n = n; st.lig = lig; st.stride = pl.leaf_stride;
   uint8_t* blk = P.blocks + r * P.RB;
   int32_t* lp = P.lpar + r * (int64_t)n * LPS;
-  for (int i = lig; i < ni; i += L) {
+  const int lig0 = master ? lig : (1 << 30);  // (shadows copy nothing)
+  for (int i = lig0; i < ni; i += L) {
     const NodeRec* q = reinterpret_cast<const NodeRec*>(blk + (int64_t)i * P.BS);
     const uint64_t* lg = reinterpret_cast<const uint64_t*>(blk + (int64_t)i * P.BS + 32);
     st.set_head(i, WideStore<K>::pack(q->left, q->right, q->parent, small_exp_of(q->ccost)));
     st.part[i] = q->partial;
     for (int w = 0; w < 4 * K; ++w) st.leg[i * (4 * K) + w] = w < W ? lg[w] : 0ull;
   }
-  for (int i = lig; i < n; i += L) st.lpar[i] = (uint16_t)lp[(int64_t)i * LPS];
-  small_sweeps<HYPER>(P, st, r, lig, (lds_vu32*)(seat + pl.o_ring), (lds_vi32*)(seat + pl.o_jb), betas, n_steps, prob_kind);
-  for (int i = lig; i < ni; i += L) {
+  for (int i = lig0; i < n; i += L) st.lpar[i] = (uint16_t)lp[(int64_t)i * LPS];
+  small_sweeps<HYPER>(P, st, r, lig, (lds_vu32*)(seat + pl.o_ring), (lds_vi32*)(seat + pl.o_jb), betas, n_steps, prob_kind, master);
+  for (int i = lig0; i < ni; i += L) {
     const uint64_t hd = st.head(i);
     NodeRec o;
     o.left = WideStore<K>::left_of(hd); o.right = WideStore<K>::right_of(hd);
@@ -588,7 +598,7 @@ __global__ __launch_bounds__(SMALL_TPB) void sa_lds_kernel(const Params P, const
     uint64_t* lg = reinterpret_cast<uint64_t*>(blk + (int64_t)i * P.BS + 32);
     for (int w = 0; w < W; ++w) lg[w] = st.leg[i * (4 * K) + w];
   }
-  for (int i = lig; i < n; i += L) lp[(int64_t)i * LPS] = (int32_t)st.lpar[i];
+  for (int i = lig0; i < n; i += L) lp[(int64_t)i * LPS] = (int32_t)st.lpar[i];
 }
 
 }  // namespace tnco

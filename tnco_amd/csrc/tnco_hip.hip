@@ -1082,6 +1082,13 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
 #ifndef TNCO_SMALL_TREE_ALWAYS  // (the other A/B library of tools/small_tree_ab.py: `make allsmall`)
       if (h->small_tree && n - 1 > 63 && R > 2 * (int64_t)small_replicas_per_cu(n - 1) * prop.multiProcessorCount) h->small_tree = false;
 #endif
+      if (h->small_tree) {
+        // A batch that leaves wavefront slots empty gets fewer replicas per wavefront (the spare lane groups shadow them,
+        // sa_small.h): an iteration then runs only the sections its few replicas are in -- 8.5-8.8e5 move-evals/s per
+        // replica at one per wavefront (up to 1024 replicas of <= 64 leaves), 7.5e5 at four, 6.7e5 at sixteen.
+        const int64_t slots = (int64_t)small_replicas_per_cu(n - 1) / (SMALL_TPB / 4) * prop.multiProcessorCount;
+        while (h->small_seats > 1 && (R + h->small_seats / 2 - 1) / (h->small_seats / 2) <= slots) h->small_seats /= 2;
+      }
       // Any other tree of the fast cost path whose replicas fit the CUs' LDS at once (the latency regime of the larger
       // networks: 512 leaves of 12 words are 58 KiB, two per CU, up to 512 replicas): sa_lds_kernel.
       if (!h->small_tree && !h->generic && LPS == 1 && !d->min_links && n >= 2 && h->log2l == 2 && I <= 65535 &&
