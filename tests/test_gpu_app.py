@@ -184,7 +184,8 @@ def test_fused_network_runs_on_the_gpu():
 def test_timeout_and_top_k():
     ts, dims, out = __import__("tnco_amd.synthetic", fromlist=["x"]).random_regular_tn(64, 3, 7)
     spec = [(2, *[f"t{t}" for t in range(64) if k in ts[t]]) for k in range(96)]
-    tn, res = Optimizer(method="sa", seed=1).optimize(spec, betas=(0, 100), n_steps=20000, n_runs=64,
+    # (200 000 sweeps: ten times the 0.2 s -- round 5's LDS-resident kernel runs 20 000 of them in 0.17 s)
+    tn, res = Optimizer(method="sa", seed=1).optimize(spec, betas=(0, 100), n_steps=200000, n_runs=64,
                                                       timeout=0.2, top_k=5, sweeps_per_launch=50, fuse=None)
     assert len(res) == 5 and tn.tags["timed_out"] and tn.tags["n_runs"] == 64
 

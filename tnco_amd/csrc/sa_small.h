@@ -16,8 +16,11 @@
 //   * the operands of a move (A's record, the legs and partial cost of B's sibling) are read during the previous
 //     iteration, the draws of an iteration together at its top: no LDS round trip inside a dependent chain of the move;
 //   * values by selection, stores under as few branches as possible (a divergent branch costs all sixteen replicas).
-// Measured (profiles/r05_small_tree_ab.txt): x2.3 ... x2.5 the HBM kernel up to 16 384 replicas of 64 leaves (config 2:
-// 2.7e9 move-evals/s against 1.1e9), 1.07e10 from there on (the HBM kernel: 9.0e9 at 65 536 replicas); above 64 leaves a
+//   * a wavefront with fewer replicas than lane groups (a small batch is spread over the chip's wavefront slots; big trees
+//     leave few seats per block) runs the spare groups as SHADOWS of its replicas: a CU with fewer than 64 active lanes
+//     runs its wavefronts slower and one after the other (tools/few_lanes.hip), shadows cost no instruction.
+// Measured (profiles/r05_small_tree_ab.txt): x2.4 ... x3.3 the HBM kernel up to 16 384 replicas of 64 leaves (config 2:
+// 3.0e9 move-evals/s against 1.1e9), 1.05e10 from there on (the HBM kernel: 9.0-9.7e9 at 65 536 replicas); above 64 leaves a
 // CU holds 32 replicas and the kernel wins while two rounds of blocks hold them.  The host picks accordingly
 // (tnco_hip_create).  History: round 2 had a first version as an opt-in and measured only the 65 536-replica case (6.8e9
 // against 7.4e9), round 3 removed it, round 5 re-measured it where it can win and rebuilt the loop around the rules above.
