@@ -30,13 +30,14 @@
 //     [ left right parent - | cost exponent | partial cost f64 | legs: 2 words ], the leaf legs a table of the block; static
 //     LDS, 16 replicas per block, 64 (<= 64 leaves) or 32 replicas per CU.  Picked for every batch up to 64 leaves, beyond
 //     while two rounds of blocks hold the batch.
-//   sa_lds_kernel<K>: any other tree of up to 16 mask words whose whole BATCH fits the CUs' LDS at once (the latency regime of
-//     the larger networks: a 512-leaf tree of 12 words is 58 KiB, two per CU, 512 replicas) -- 16-bit links, arrays of
-//     [links | exponent], partial costs, legs; the leaf legs as lists of at most 32 index positions, expanded where needed;
-//     dynamic LDS carved by the host (LdsPlan).  x1.3 ... x2.3 the HBM kernel per replica (profiles/r05_small_tree_ab.txt).
-// Conditions of both: the fast cost path (no hyper-indices, uniform power-of-two dims, float64 cost, no sparse legs), four
-// lanes per replica, a log that starts at the checkpoint (no min_links given).  A contraction cost is 2^e exactly -- or
-// +inf, e >= 1024 -- so the exponent is what the records keep.
+//   sa_lds_kernel<K, HYPER>: any other tree of up to 16 mask words, with or without hyper-indices, whose whole BATCH fits the
+//     CUs' LDS at once (the latency regime of the larger networks: a 512-leaf tree of 12 words is 58 KiB, two per CU, 512
+//     replicas) -- 16-bit links, arrays of [links | exponent], partial costs, legs; the leaf legs as a table while that is
+//     small, else as lists of at most 32 index positions, expanded where needed; dynamic LDS carved by the host (LdsPlan).
+//     x1.6 ... x2.8 the HBM kernel per replica (profiles/r05_small_tree_ab.txt).
+// Conditions of both: the fast cost path (uniform power-of-two dims, float64 cost, no sparse legs), four lanes per replica,
+// a log that starts at the checkpoint (no min_links given).  A contraction cost is 2^e exactly -- or +inf, e >= 1024 -- so
+// the exponent is what the records keep.
 #pragma once
 #include "sa_sweep.h"
 
@@ -89,7 +90,7 @@ __device__ __forceinline__ bool small_accept(int kind, double beta, double delta
   return acc;
 }
 
-// x % n through the reciprocal (n <= 128; the quotient estimate is off by one at most)
+// x % n through the reciprocal (n < 2^16, x < 2^32: the quotient estimate is off by one at most)
 __device__ __forceinline__ uint32_t small_mod(uint32_t x, uint32_t n, double inv_n) {
   const uint32_t q = (uint32_t)((double)x * inv_n);
   uint32_t r = x - q * n;
@@ -106,9 +107,9 @@ __device__ __forceinline__ uint32_t small_exp_of(double c) {
 //   SmallStore<NI>: up to 128 leaves and 2 mask words -- links are bytes, a node is one 32-byte record, the leaf legs a
 //     table of the block; static LDS, 16 replicas per block.  <63>: 38.5 KiB, four blocks per CU; <127>: 72.5 KiB, two.
 //   WideStore<K>: any tree whose replicas fit -- 16-bit links, up to 16 mask words (4 lanes x K words), separate arrays
-//     for [links | cost exponent], partial costs and legs, the leaf legs as a table while that is small (<= 16 KiB), else as lists
-//     of index positions (at most 32 per leaf; expanded where a leaf's legs are needed); dynamic LDS carved by the host (LdsPlan), 1 ... 16 replicas per
-//     block: a 512-leaf tree of 12 words is 58 KiB, two per CU.
+//     for [links | cost exponent], partial costs and legs, the leaf legs as a table while that is small (<= 16 KiB), else
+//     as lists of index positions (at most 32 per leaf; expanded where a leaf's legs are needed); dynamic LDS carved by
+//     the host (LdsPlan), 1 ... 16 replicas per block: a 512-leaf tree of 12 words is 58 KiB, two per CU.
 // ---------------------------------------------------------------------------------------------------------------
 typedef TNCO_LDS volatile uint64_t lvu64;
 typedef TNCO_LDS volatile uint16_t lvu16;
@@ -158,7 +159,7 @@ struct SmallStore {
 
 // The host's carve of a block's dynamic LDS for WideStore (bytes; tnco_hip_create).
 struct LdsPlan {
-  int seats;        // replicas per block (1 ... 16): lane groups beyond them idle
+  int seats;        // replicas per block (1 ... 16): the lane groups beyond them shadow them (small_sweeps)
   int leaf_stride;  // 64-bit words per leaf in the index lists: four 16-bit index positions each (1 ... 8); 0: a table of legs
   int leaf_words;   // 64-bit words of the leaf lists / table
   int seat0, seat_stride;                       // first seat, bytes per seat
