@@ -44,7 +44,7 @@ class Optimizer(BaseOptimizer):
 
     def optimize(self, tn: Any, betas, n_steps: int | None = None, n_runs: int = 1,
                  n_projs: int | None = None, timeout: float | None = None, *, top_k: int | None = None,
-                 sweeps_per_launch: int = 100, prob: str = "mh", device: int | None = None,
+                 sweeps_per_launch: int | None = None, prob: str = "mh", device: int | None = None,
                  initial_trees: str = "greedy", progress=None, **load_tn_options) -> Any:
         tn = self._load_tn(tn, **load_tn_options)
         merged, runtime = run_sa(self, tn, betas, n_steps, n_runs, n_projs, timeout, top_k=top_k,
