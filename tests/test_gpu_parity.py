@@ -323,6 +323,27 @@ def test_few_small_trees_run_lds_resident(core, oracle_lib):
         assert g.launch_groups == 1
 
 
+@pytest.mark.parametrize("R", [1030, 2050, 4099, 16390])
+def test_small_tree_batches_that_do_not_fill_their_last_wavefront(core, oracle_lib, R):
+    """csrc/sa_small.h: a batch is spread over the chip's wavefront slots -- 1, 2, 4, 8 or 16 replicas per wavefront, the other
+    lane groups shadowing them -- and the last wavefront may hold fewer: the first, some middle and the last replicas of
+    1030 (two per wavefront), 2050 (four), 4099 (eight) and 16 390 (sixteen) against the oracle."""
+    prob = H.regular_problem(64, graph_seed=7)
+    seeds = H.replica_seeds(R, S=R)
+    links = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds)
+    betas = H.linear_betas(0, 60, 30)
+    with core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds) as gpu:
+        assert gpu.launch_groups == 0
+        gpu.run(betas[:11]); gpu.run(betas[11:])
+        tot, mn = gpu.costs()
+        for r in [0, 1, 2, 3, 15, 16, 17, R // 2, R - 18, R - 17, R - 3, R - 2, R - 1]:
+            o = H.make_oracle(oracle_lib, prob, links[r], seeds[r])
+            o.run(oracle_lib.PROB_MH, betas)
+            H.assert_replica_equal(gpu, r, o)
+            assert tot[r] == o.total_cost and mn[r] == o.min_total_cost
+        assert gpu.validate() == (0, -1)
+
+
 @pytest.mark.parametrize("n,deg,R", [(100, 3, 48), (200, 4, 33), (256, 3, 40), (512, 3, 24), (680, 3, 9)])
 def test_larger_trees_that_fit_the_lds_run_resident(core, oracle_lib, n, deg, R):
     """csrc/sa_small.h, sa_lds_kernel<K>: up to 16 mask words (4 lanes x K = 1 ... 4 words) a handle whose replicas all fit
