@@ -51,6 +51,7 @@ struct tnco_hip_ctx {
   unsigned long long fw_slow_pending = 0, fw_slow_wide_pending = 0;  // fall-backs collected since tnco_hip_run_fw last chose a form
   bool small_tree = false;  // small trees: LDS-resident sweeps (sa_small.h, sa_small_kernel)
   int small_seats = 16;     // ... replicas per wavefront (a batch smaller than the chip's wavefront slots is spread)
+  int run_seats = 0;        // > 0: the HBM sweep kernel's SPREAD form, that many replicas per wavefront (a batch smaller than the wavefront slots)
   bool lds_tree = false;    // any tree whose replicas fit the CUs' LDS in two rounds: sa_lds_kernel with the plan below
   bool lds_attr_set = false;
   tnco::LdsPlan lds_plan{};

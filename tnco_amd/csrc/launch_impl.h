@@ -11,6 +11,11 @@ using namespace tnco;
 // The sweep kernel this handle runs (infinite memory), or nullptr for the LDS-resident small-tree kernel.
 template <int LOG2L, int K>
 static const void* run_kernel_ptr(const tnco_hip_ctx* h) {
+  if (h->run_seats > 0) {  // (a spread batch: sa_sweep.h, SPREAD)
+    if (h->hyper)
+      return h->generic ? (const void*)sa_run_kernel<LOG2L, K, true, true, false, true> : (const void*)sa_run_kernel<LOG2L, K, true, false, false, true>;
+    return h->generic ? (const void*)sa_run_kernel<LOG2L, K, false, true, false, true> : (const void*)sa_run_kernel<LOG2L, K, false, false, false, true>;
+  }
   if (h->hyper)
     return h->generic ? (const void*)sa_run_kernel<LOG2L, K, true, true, false> : (const void*)sa_run_kernel<LOG2L, K, true, false, false>;
   return h->generic ? (const void*)sa_run_kernel<LOG2L, K, false, true, false> : (const void*)sa_run_kernel<LOG2L, K, false, false, false>;
@@ -58,6 +63,22 @@ void launch_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int pr
         hipLaunchKernelGGL((sa_lds_kernel<K, false>), lgrid, dim3(SMALL_TPB), (size_t)pl.total, s, P, betas, n_steps, prob_kind, pl, h->leaf_idx);
       return;
     }
+  }
+  if (h->run_seats > 0) {  // a batch spread over the wavefront slots: run_seats replicas per wavefront, one launch
+    const int per_block = (SWT / 64) * h->run_seats;
+    const dim3 sgrid((unsigned)((P.R + per_block - 1) / per_block));
+    if (h->hyper) {
+      if (h->generic)
+        hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, true, false, true>), sgrid, dim3(SWT), 0, s, P, betas, n_steps, prob_kind, FwParams{}, h->run_seats, 0);
+      else
+        hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, false, false, true>), sgrid, dim3(SWT), 0, s, P, betas, n_steps, prob_kind, FwParams{}, h->run_seats, 0);
+    } else {
+      if (h->generic)
+        hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, true, false, true>), sgrid, dim3(SWT), 0, s, P, betas, n_steps, prob_kind, FwParams{}, h->run_seats, 0);
+      else
+        hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, false, false, true>), sgrid, dim3(SWT), 0, s, P, betas, n_steps, prob_kind, FwParams{}, h->run_seats, 0);
+    }
+    return;
   }
   const int gpb = SWT >> LOG2L;
   dim3 grid((unsigned)(nblocks >= 0 ? nblocks : (P.R + gpb - 1) / gpb));

@@ -320,7 +320,7 @@ constexpr int SWT = TNCO_SWEEP_THREADS;
 #ifndef TNCO_FW_STAGED_WAVES
 #define TNCO_FW_STAGED_WAVES 2
 #endif
-template <int LOG2L, int K, bool HYPER, bool GENERIC, bool FW = false>
+template <int LOG2L, int K, bool HYPER, bool GENERIC, bool FW = false, bool SPREAD = false>
 // (hyper-indices: six more masks are carried -- at 3 wavefronts per SIMD the K = 3 kernel spilled 51 VGPRs)
 #ifndef TNCO_HYPER_WAVES
 #define TNCO_HYPER_WAVES 2
@@ -339,6 +339,11 @@ template <int LOG2L, int K, bool HYPER, bool GENERIC, bool FW = false>
 __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES : (HYPER ? TNCO_HYPER_WAVES : (GENERIC ? TNCO_GENERIC_WAVES : (K >= 4 ? TNCO_K4_WAVES : TNCO_WAVES_PER_SIMD)))))) void sa_run_kernel(
     const Params P, const double* __restrict__ betas, const int64_t n_steps, const int prob_kind,
     const FwParams F, const int tail_last, const int block0) {
+  // SPREAD (infinite memory, a batch that leaves wavefront slots empty): `tail_last` replicas per wavefront instead of
+  // 64 / L, the other lane groups SHADOW them -- same replica, same reads, hence the same values and control flow, no
+  // store of their own (csrc/sa_small.h has the why: sixteen replicas in sixteen states make a wavefront run every
+  // state's code in every iteration, 5 300 cycles of it at 512 leaves; and a CU wants 64 active lanes).
+  static_assert(!(SPREAD && FW), "spread: infinite memory only");
   constexpr int L = 1 << LOG2L;
   constexpr int GPB = SWT >> LOG2L;  // groups (replicas) per block
   using M = Mask<K>;
@@ -369,13 +374,19 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
 
   const int tid = threadIdx.x;
   const int lig = tid & (L - 1);
-  const int gib = tid >> LOG2L;
   const int gbase = (tid & 63) & ~(L - 1);  // first lane of the group inside the wave
   // (block0: the launch covers the replicas of blocks block0 .. block0 + gridDim.x - 1 -- a handle may split a
   // step over several streams, launch_run_lk)
-  const int64_t r = ((int64_t)blockIdx.x + block0) * GPB + gib;
+  const int seats = SPREAD ? tail_last : (64 >> LOG2L);          // replicas per wavefront
+  const int gw = (tid & 63) >> LOG2L;                            // lane group inside the wavefront
+  const bool master = !SPREAD || gw < seats;
+  const int seat = SPREAD ? (gw & (seats - 1)) : gw;
+  const int gib = SPREAD ? (tid >> 6) * (64 >> LOG2L) + seat : tid >> LOG2L;  // the replica's slot in the block's LDS arrays
+  const int64_t r = SPREAD ? (((int64_t)blockIdx.x + block0) * (SWT / 64) + (tid >> 6)) * seats + seat
+                           : ((int64_t)blockIdx.x + block0) * GPB + gib;
   if (r >= P.R || n_steps <= 0) return;
-  const bool lane0 = (lig == 0);
+  const bool lane0 = (lig == 0) && master;
+  const int slig = master ? lig : (1 << 20);  // (the lane index of loops that store)
 
   const int n = P.n, N = P.N;
   View<LOG2L, K, HYPER, !FW> v;  // (finite width: the split layout)
@@ -393,7 +404,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
   R rng;
   {
     const ReplicaState* rs = P.rs + r;
-    rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, lig);
+    rng.init(P, r, (lds_vu32*)rngbuf + gib * R::RING, rs->mti, rs->mtw, master ? lig : 64);  // (64: no loads, no stores)
     if (lane0) {
       cold.min_cost = rs->min_cost;
       cold.jmin = rs->jmin;
@@ -406,7 +417,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
   bool jinvalid = P.rs[r].jinvalid != 0;
   // The tail of the rotation log is assembled in LDS and written 16 entries at a time: HBM writes
   // whole 64-byte pieces, a 4-byte append evicted on its own is a read-modify-write there.
-  auto jb = [&](int i) -> lds_vi32& { return *((lds_vi32*)jbuf + (threadIdx.x >> LOG2L) * 16 + i); };
+  auto jb = [&](int i) -> lds_vi32& { return *((lds_vi32*)jbuf + gib * 16 + i); };
   // (recomputed at every use, opaquely: as a loop invariant it would be spilled and its reload
   // would put a vmcnt(0) wait into the store phase)
   auto jlog = [&]() -> int32_t* {
@@ -415,7 +426,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
     return P.jlog + (int64_t)rr * (int64_t)P.jcap;
   };
   if ((jtail & 15u) != 0u) {
-    for (int q = lig; q < 4; q += L) {
+    for (int q = slig; q < 4; q += L) {
       const int4 t = *reinterpret_cast<const int4*>(jlog() + (jtail & ~15u) + 4 * q);
       jb(4 * q + 0) = t.x; jb(4 * q + 1) = t.y; jb(4 * q + 2) = t.z; jb(4 * q + 3) = t.w;
     }
@@ -500,7 +511,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
           v.lpar = lpar();
           // (the sixteen replicas of the wavefront wait for this copy: four nodes per lane in flight)
           Links* __restrict__ ml = P.minlinks + r * (int64_t)N;
-          for (int i0 = lig; i0 < N; i0 += 4 * L) {
+          for (int i0 = slig; i0 < N; i0 += 4 * L) {
             int4 h4[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -735,16 +746,18 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
           if (lane0) jb((int)(jtail & 15u)) = stE;
           ++jtail;
           if ((jtail & 15u) == 0u) {  // a 64-byte piece is complete: 16 bytes per lane
-            for (int q = lig; q < 4; q += L)
+            for (int q = slig; q < 4; q += L)
               *reinterpret_cast<int4*>(jlog() + (jtail - 16u) + 4 * q) =
                   make_int4(jb(4 * q + 0), jb(4 * q + 1), jb(4 * q + 2), jb(4 * q + 3));
           }
         }
       }
       v.lpar = lpar();
-      v.set_parent_group(stC, stB);
-      v.set_parent_group(stE, stA);
-      v.set_mask(stB, msel<K>(b_is_left_of_a, m0, m1));  // :170 (accepted: B's legs are the new legs)
+      if (master) {
+        v.set_parent_group(stC, stB);
+        v.set_parent_group(stE, stA);
+        v.set_mask(stB, msel<K>(b_is_left_of_a, m0, m1));  // :170 (accepted: B's legs are the new legs)
+      }
     }
     if (did_move || did_end) {
       if (lane0) {
@@ -812,7 +825,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
   }
 
   if ((jtail & 15u) != 0u) {  // the unfinished piece of the rotation log (entries past jtail: don't care)
-    for (int q = lig; q < 4; q += L)
+    for (int q = slig; q < 4; q += L)
       *reinterpret_cast<int4*>(jlog() + (jtail & ~15u) + 4 * q) =
           make_int4(jb(4 * q + 0), jb(4 * q + 1), jb(4 * q + 2), jb(4 * q + 3));
   }

@@ -1155,6 +1155,21 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
           }
         }
       }
+      // A batch that leaves wavefront slots of the HBM kernel empty is spread (sa_sweep.h, SPREAD): as few replicas per
+      // wavefront as fill the slots, the other lane groups shadowing them.
+      if (!h->small_tree && !h->lds_tree) {
+        const int full = 64 / h->L;
+        h->run_seats = full;  // (the occupancy of the spread form)
+        const int64_t wslots = (int64_t)run_blocks_per_cu(h) * prop.multiProcessorCount * (SWT / 64);
+        int seats = full;
+        while (seats > 1 && (R + seats / 2 - 1) / (seats / 2) <= wslots) seats /= 2;
+        // (one or two replicas per wavefront: x1.6 ... x1.15 the full wavefronts at 512 leaves; four: the same; eight: two
+        //  half-filled wavefronts per SIMD lose 9 % to one full one -- profiles/r05_small_tree_ab.txt, fourth table)
+        h->run_seats = (wslots > 0 && seats <= 2 && seats < full) ? seats : 0;
+#ifdef TNCO_NO_SMALL_TREE  // (the A/B library: the batch as it was, 64 / L replicas per wavefront)
+        h->run_seats = 0;
+#endif
+      }
       h->run_slots = run_blocks_per_cu(h) * prop.multiProcessorCount;
       if (h->run_slots > 0 && nblocks > h->run_slots) {
         const double rounds = (double)nblocks / (double)h->run_slots, part = rounds - std::floor(rounds);
@@ -1168,7 +1183,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
       G = 2;
     }
     if (const char* e = std::getenv("TNCO_HIP_GROUPS")) G = std::max(1, std::min((int)tnco_hip_ctx::MAX_GROUPS, std::atoi(e)));
-    if (h->small_tree || h->lds_tree || nblocks < 2 * G) G = 1;
+    if (h->small_tree || h->lds_tree || h->run_seats > 0 || nblocks < 2 * G) G = 1;
     if (G > 1) {
       for (int q = 0; q < G; ++q) {
         HIP_TRY(tnco::StreamCache::get().take(&h->gstream[q], h->device));
