@@ -339,10 +339,11 @@ template <int LOG2L, int K, bool HYPER, bool GENERIC, bool FW = false, bool SPRE
 __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES : (HYPER ? TNCO_HYPER_WAVES : (GENERIC ? TNCO_GENERIC_WAVES : (K >= 4 ? TNCO_K4_WAVES : TNCO_WAVES_PER_SIMD)))))) void sa_run_kernel(
     const Params P, const double* __restrict__ betas, const int64_t n_steps, const int prob_kind,
     const FwParams F, const int tail_last, const int block0) {
-  // SPREAD (infinite memory, a batch that leaves wavefront slots empty): `tail_last` replicas per wavefront instead of
-  // 64 / L, the other lane groups SHADOW them -- same replica, same reads, hence the same values and control flow, no
-  // store of their own (csrc/sa_small.h has the why: sixteen replicas in sixteen states make a wavefront run every
-  // state's code in every iteration, 5 300 cycles of it at 512 leaves; and a CU wants 64 active lanes).
+  // SPREAD (infinite memory, a batch smaller than the kernel's wavefront slots): `tail_last` replicas per wavefront -- the
+  // host passes 1 -- instead of 64 / L, the other lane groups SHADOW them: same replica, same reads, hence the same values
+  // and control flow, no store of their own.  Sixteen replicas in sixteen states make a wavefront run every state's code
+  // in every iteration -- 5 300 cycles at 512 leaves, of which the landing fence waits 13: a small batch is bound by this
+  // instruction stream, not by memory --, and a CU wants 64 active lanes (tools/few_lanes.hip; csrc/sa_small.h).
   static_assert(!(SPREAD && FW), "spread: infinite memory only");
   constexpr int L = 1 << LOG2L;
   constexpr int GPB = SWT >> LOG2L;  // groups (replicas) per block

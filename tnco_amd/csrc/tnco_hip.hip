@@ -1155,17 +1155,17 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
           }
         }
       }
-      // A batch that leaves wavefront slots of the HBM kernel empty is spread (sa_sweep.h, SPREAD): as few replicas per
-      // wavefront as fill the slots, the other lane groups shadowing them.
+      // A batch of no more replicas than two thirds of the HBM kernel's wavefront slots is spread (sa_sweep.h, SPREAD): one
+      // replica per wavefront, the other lane groups shadowing it.
       if (!h->small_tree && !h->lds_tree) {
         const int full = 64 / h->L;
-        h->run_seats = full;  // (the occupancy of the spread form)
+        h->run_seats = 1;  // (the occupancy of the spread form)
         const int64_t wslots = (int64_t)run_blocks_per_cu(h) * prop.multiProcessorCount * (SWT / 64);
-        int seats = full;
-        while (seats > 1 && (R + seats / 2 - 1) / (seats / 2) <= wslots) seats /= 2;
-        // (one or two replicas per wavefront: x1.6 ... x1.15 the full wavefronts at 512 leaves; four: the same; eight: two
-        //  half-filled wavefronts per SIMD lose 9 % to one full one -- profiles/r05_small_tree_ab.txt, fourth table)
-        h->run_seats = (wslots > 0 && seats <= 2 && seats < full) ? seats : 0;
+        const int seats = 3 * R <= 2 * wslots ? 1 : full;  // (up to two thirds of the slots: at all of them x1.15 ... x0.92)
+        // (ONE replica per wavefront: x1.65 / x1.41 the full wavefronts at 1024 / 2048 replicas of 512 leaves, x1.5 ... x1.08 at
+        //  1024 and 2048 leaves; two per wavefront: x1.14 ... x0.87 depending on how full the SIMDs get; four and more: none --
+        //  profiles/r05_small_tree_ab.txt, fourth table)
+        h->run_seats = (wslots > 0 && seats == 1 && full > 1) ? 1 : 0;
 #ifdef TNCO_NO_SMALL_TREE  // (the A/B library: the batch as it was, 64 / L replicas per wavefront)
         h->run_seats = 0;
 #endif
