@@ -4,10 +4,11 @@
 //
 // Same algorithm, same arithmetic and the same draws as sa_run_kernel (Optimizer::update,
 // include/tnco/optimize/infinite_memory/optimizer.hpp:90-221): what differs is where the operands come from.  With the
-// node blocks in HBM a replica advances one memory round trip per move (~2 microseconds under load, 3.7 at 4096 replicas)
-// and the kernel is a state machine that overlaps the round trips of 192 replicas per CU.  Here an operand is one LDS
-// access (~130 cycles) away and the loop is the plain walk, every replica of a wavefront at its own place of its own
-// sweep: per iteration [generator] [one move] [end of a sweep + begin of the next].  What bounds it is the instruction
+// node blocks in HBM the kernel is a state machine that overlaps the memory round trips of 192 replicas per CU, one
+// landing fence per iteration, and a wavefront runs the code of every state its sixteen replicas are in (2.7 microseconds
+// per move and replica in a small batch).  Here an operand is one LDS access (~130 cycles) away and the loop is the plain
+// walk, every replica of a wavefront at its own place of its own sweep: per iteration [generator] [one move] [end of a
+// sweep + begin of the next].  What bounds it is the instruction
 // stream of the wavefront -- 16 replicas, one wavefront per SIMD because LDS holds 64 replicas of 64 leaves per CU: ~3250
 // cycles = 1.35 microseconds per move and replica whatever the number of replicas (tools/stage_cycles.py:
 // profiles/r05_small_stage_cycles.txt).  Hence the rules of the loop:
