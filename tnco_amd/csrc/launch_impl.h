@@ -11,6 +11,16 @@ using namespace tnco;
 // The sweep kernel this handle runs (infinite memory), or nullptr for the LDS-resident small-tree kernel.
 template <int LOG2L, int K>
 static const void* run_kernel_ptr(const tnco_hip_ctx* h) {
+  if (h->fw) {  // (finite width: the staged moves; the spread form is asked about its own occupancy)
+    if (h->run_seats > 0) {
+      if (h->hyper)
+        return h->generic ? (const void*)sa_run_kernel<LOG2L, K, true, true, true, true> : (const void*)sa_run_kernel<LOG2L, K, true, false, true, true>;
+      return h->generic ? (const void*)sa_run_kernel<LOG2L, K, false, true, true, true> : (const void*)sa_run_kernel<LOG2L, K, false, false, true, true>;
+    }
+    if (h->hyper)
+      return h->generic ? (const void*)sa_run_kernel<LOG2L, K, true, true, true> : (const void*)sa_run_kernel<LOG2L, K, true, false, true>;
+    return h->generic ? (const void*)sa_run_kernel<LOG2L, K, false, true, true> : (const void*)sa_run_kernel<LOG2L, K, false, false, true>;
+  }
   if (h->run_seats > 0) {  // (a spread batch: sa_sweep.h, SPREAD)
     if (h->hyper)
       return h->generic ? (const void*)sa_run_kernel<LOG2L, K, true, true, false, true> : (const void*)sa_run_kernel<LOG2L, K, true, false, false, true>;
@@ -145,9 +155,15 @@ void launch_fw_move_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, in
   dim3 grid((unsigned)((h->P.R + gpb - 1) / gpb)), grid_staged((unsigned)((h->P.R + gpb_staged - 1) / gpb_staged));
   const bool maxnew = h->F.max_new_slices > 0;
   if (!maxnew) {  // the staged state machine (sa_sweep.h, FW = true)
-#define TNCO_FW_STAGED(HY, GE)                                                                                          \
-  hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, HY, GE, true>), grid_staged, dim3(SWT), 0, h->stream, h->P, betas, n_steps, \
-                     prob_kind, h->F, tail_last, 0)
+#define TNCO_FW_STAGED(HY, GE)                                                                                             \
+  do {                                                                                                                     \
+    if (h->run_seats > 0) /* a small batch: one replica per wavefront (sa_sweep.h, SPREAD) */                              \
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, HY, GE, true, true>), dim3((unsigned)((h->P.R + SWT / 64 - 1) / (SWT / 64))), \
+                         dim3(SWT), 0, h->stream, h->P, betas, n_steps, prob_kind, h->F, tail_last, 0);                    \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, HY, GE, true>), grid_staged, dim3(SWT), 0, h->stream, h->P, betas, n_steps, \
+                         prob_kind, h->F, tail_last, 0);                                                                   \
+  } while (0)
     if (h->hyper) {
       if (h->generic) TNCO_FW_STAGED(true, true); else TNCO_FW_STAGED(true, false);
     } else {

@@ -1177,6 +1177,17 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
         //  wavefronts per SIMD, 1024 blocks on 512 slots: +2 ... +8 % on two streams, profiles/r03_other_configs.md)
         if (part < 0.85) G = 2;
       }
+    } else if (nblocks < 64 && h->F.max_new_slices == 0) {
+      // finite width, a small batch: the staged moves one replica per wavefront (sa_sweep.h, SPREAD) -- they are 90 % of
+      // such a step (a full wavefront: 5.2 microseconds per move and replica)
+      hipDeviceProp_t prop;
+      HIP_TRY(hipGetDeviceProperties(&prop, d->device));
+      h->run_seats = 1;  // (the occupancy of the spread form)
+      const int64_t wslots = (int64_t)run_blocks_per_cu(h) * prop.multiProcessorCount * (SWT / 64);
+      h->run_seats = (64 / h->L > 1 && 3 * R <= 2 * wslots) ? 1 : 0;
+#ifdef TNCO_NO_SMALL_TREE
+      h->run_seats = 0;
+#endif
     } else if (nblocks >= 64 && h->F.max_new_slices == 0) {
       // finite width: two halves on two streams whatever the rounds -- what overlaps are KERNELS of different
       // bounds (the moves wait on memory requests, get_slices and the tree kernel on LDS / instruction latency)
