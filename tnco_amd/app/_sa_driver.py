@@ -243,9 +243,11 @@ def run_sa(opt, tn, betas, n_steps, n_runs, n_projs, timeout, *, top_k, sweeps_p
         if ci == len(comps) - 1 or all(len(c.tensors) <= 1 for c in comps[ci + 1:]):
             core.greedy_release()  # the last batch of device-drawn trees has been consumed: return its memory
         # sweeps per kernel launch (launches queue up on the device; a launch is also the grain of `timeout` and of the
-        # progress series).  Default: 100; 1000 for a handle whose trees stay in LDS during a launch (csrc/sa_small.h) -- a
-        # launch there ends when the slowest replica of a wavefront ends, and 1000 sweeps of such trees are ~10 ms.
-        spl = sweeps_per_launch if sweeps_per_launch is not None else (1000 if (not finite and h.launch_groups == 0) else 100)
+        # progress series).  Default: 100; 1000 for a small batch or a handle whose trees stay in LDS during a launch
+        # (csrc/sa_small.h) -- with few replicas per wavefront a launch ends when the slowest replica ends (100 sweeps: ~10 %
+        # of idle tail, 1000: ~3 %), and 1000 sweeps of such a batch are 10-30 ms.
+        spl = sweeps_per_launch if sweeps_per_launch is not None else (
+            1000 if (not finite and (h.launch_groups == 0 or n_local <= 4096)) else 100)
         spl = max(1, int(spl))
         starts = list(range(0, len(betas), spl))
         report_every = max(1, -(-len(starts) // PROGRESS_POINTS)) if (opt.verbose or progress is not None) else 0
