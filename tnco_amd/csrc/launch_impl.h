@@ -79,14 +79,14 @@ void launch_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int pr
     const dim3 sgrid((unsigned)((P.R + per_block - 1) / per_block));
     if (h->hyper) {
       if (h->generic)
-        hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, true, false, true>), sgrid, dim3(SWT), 0, s, P, betas, n_steps, prob_kind, FwParams{}, h->run_seats, 0);
+        hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, true, false, true>), sgrid, dim3(SWT), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1, h->run_seats);
       else
-        hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, false, false, true>), sgrid, dim3(SWT), 0, s, P, betas, n_steps, prob_kind, FwParams{}, h->run_seats, 0);
+        hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, true, false, false, true>), sgrid, dim3(SWT), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1, h->run_seats);
     } else {
       if (h->generic)
-        hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, true, false, true>), sgrid, dim3(SWT), 0, s, P, betas, n_steps, prob_kind, FwParams{}, h->run_seats, 0);
+        hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, true, false, true>), sgrid, dim3(SWT), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1, h->run_seats);
       else
-        hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, false, false, true>), sgrid, dim3(SWT), 0, s, P, betas, n_steps, prob_kind, FwParams{}, h->run_seats, 0);
+        hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, false, false, true>), sgrid, dim3(SWT), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1, h->run_seats);
     }
     return;
   }

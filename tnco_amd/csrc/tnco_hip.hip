@@ -1155,17 +1155,19 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
           }
         }
       }
-      // A batch of no more replicas than two thirds of the HBM kernel's wavefront slots is spread (sa_sweep.h, SPREAD): one
-      // replica per wavefront, the other lane groups shadowing it.
+      // A batch that leaves wavefront slots of the HBM kernel empty is spread (sa_sweep.h, SPREAD): fewer replicas per
+      // wavefront, the other lane groups shadowing them.  Per-replica move-evals/s at 512 leaves, 16 (full) / 1 / 2 / 4 / 8
+      // replicas per wavefront: 1024 replicas 3.2 / 5.3 / 4.4 / 3.8 / 3.5e5; 4096: 3.2 / - / 3.7 / 3.8 / 3.5; 8192: 3.2 / - /
+      // 2.1 / 3.2 / 3.5; 16384: 3.2 / - / - / 1.8 / 2.9 -- one replica per wavefront while that takes at most two thirds of
+      // the slots, else as few as leave ONE wavefront per SIMD (two half-filled ones lose to a full one).
       if (!h->small_tree && !h->lds_tree) {
         const int full = 64 / h->L;
         h->run_seats = 1;  // (the occupancy of the spread form)
         const int64_t wslots = (int64_t)run_blocks_per_cu(h) * prop.multiProcessorCount * (SWT / 64);
-        const int seats = 3 * R <= 2 * wslots ? 1 : full;  // (up to two thirds of the slots: at all of them x1.15 ... x0.92)
-        // (ONE replica per wavefront: x1.65 / x1.41 the full wavefronts at 1024 / 2048 replicas of 512 leaves, x1.5 ... x1.08 at
-        //  1024 and 2048 leaves; two per wavefront: x1.14 ... x0.87 depending on how full the SIMDs get; four and more: none --
-        //  profiles/r05_small_tree_ab.txt, fourth table)
-        h->run_seats = (wslots > 0 && seats == 1 && full > 1) ? 1 : 0;
+        int seats = 1;
+        if (3 * R > 2 * wslots)
+          while (seats < full && (R + seats - 1) / seats > 4 * (int64_t)prop.multiProcessorCount) seats *= 2;
+        h->run_seats = (wslots > 0 && seats < full) ? seats : 0;
 #ifdef TNCO_NO_SMALL_TREE  // (the A/B library: the batch as it was, 64 / L replicas per wavefront)
         h->run_seats = 0;
 #endif
