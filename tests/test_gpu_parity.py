@@ -323,6 +323,58 @@ def test_few_small_trees_run_lds_resident(core, oracle_lib):
         assert g.launch_groups == 1
 
 
+@pytest.mark.parametrize("n,deg,R", [(130, 3, 12300), (200, 4, 12300), (512, 3, 12300), (900, 3, 8200), (1300, 3, 8200),
+                                     (2048, 3, 4100)])
+def test_full_wavefronts_of_the_lane_layouts(core, oracle_lib, n, deg, R):
+    """Small batches run the sweep kernel's SPREAD form or an LDS-resident kernel (round 5), so the parity tests above no
+    longer reach the full wavefronts of `sa_run_kernel<L, K, ...>` that big batches run: here batches too large for either,
+    4 x 1 / 4 x 2 / 4 x 3 / 8 x 3 / 8 x 4 / 16 x 3 lanes x words, the first, some middle and the last replicas against the
+    oracle."""
+    prob = H.regular_problem(n, graph_seed=n % 89, degree=deg)
+    seeds = H.replica_seeds(R, S=n)
+    links = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds)
+    betas = H.linear_betas(0, 60, 12)
+    with core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds) as gpu:
+        assert gpu.launch_groups >= 1
+        gpu.run(betas[:5]); gpu.run(betas[5:])
+        tot, mn = gpu.costs()
+        for r in [0, 1, 63, 64, R // 2, R - 65, R - 2, R - 1]:
+            o = H.make_oracle(oracle_lib, prob, links[r], seeds[r])
+            o.run(oracle_lib.PROB_MH, betas)
+            H.assert_replica_equal(gpu, r, o)
+            assert tot[r] == o.total_cost and mn[r] == o.min_total_cost
+        assert gpu.validate() == (0, -1)
+
+
+@pytest.mark.parametrize("kind", ["hyper", "dims 3", "hyper, dims 3", "float32"])
+def test_full_wavefronts_of_the_other_instantiations(core, oracle_lib, kind):
+    """... and the hyper-index / general-cost-model instantiations the same way: 12 300 replicas, eight of them against the oracle."""
+    from tnco_amd import synthetic as syn
+    if kind.startswith("hyper"):
+        ts, _dims, out = syn.random_hyper_tn(120, 200, k=3, n_output=5, seed=12)
+        prob = H.Problem(ts, 3 if "dims 3" in kind else 2, out)
+    else:
+        prob = H.regular_problem(128, graph_seed=5)
+        if kind == "dims 3":
+            prob = H.Problem(prob.ts_inds, 3, [])
+    kw = dict(cost_type="float32") if kind == "float32" else {}
+    R = 12300
+    seeds = H.replica_seeds(R, S=77)
+    links = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds)
+    betas = H.linear_betas(0, 40, 12)
+    with core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, dims=prob.dims, output_mask=prob.output_mask,
+                               **kw) as gpu:
+        assert gpu.launch_groups >= 1
+        gpu.run(betas[:5]); gpu.run(betas[5:])
+        tot, mn = gpu.costs()
+        for r in [0, 1, 63, 64, R // 2, R - 65, R - 2, R - 1]:
+            o = H.make_oracle(oracle_lib, prob, links[r], seeds[r], **kw)
+            o.run(oracle_lib.PROB_MH, betas)
+            H.assert_replica_equal(gpu, r, o)
+            assert tot[r] == o.total_cost and mn[r] == o.min_total_cost
+        assert gpu.validate() == (0, -1)
+
+
 @pytest.mark.parametrize("R", [1030, 2050, 4099, 16390])
 def test_small_tree_batches_that_do_not_fill_their_last_wavefront(core, oracle_lib, R):
     """csrc/sa_small.h: a batch is spread over the chip's wavefront slots -- 1, 2, 4, 8 or 16 replicas per wavefront, the other
