@@ -588,3 +588,27 @@ def test_fw_more_than_1024_tensors_on_the_one_wavefront_path(core, oracle_lib, m
     a, b = res
     assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1])
     assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1]) and np.array_equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("n,deg,frac", [(48, 3, 0.6), (200, 4, 0.7), (520, 3, 0.8), (900, 3, 0.85)])
+def test_fw_full_wavefronts_of_the_staged_moves(core, oracle_lib, n, deg, frac):
+    """Small finite-width batches run the staged moves one replica per wavefront (sa_sweep.h, SPREAD; round 5), so the tests
+    above no longer reach their full wavefronts for layouts other than config 5's: 2 100 replicas (too many to spread, too
+    few to split over two streams), 4 x 1 / 4 x 2 / 4 x 4 / 8 x 3 lanes x words, the first, some middle and the last replicas
+    against the oracle incl. their slices."""
+    prob = H.regular_problem(n, graph_seed=n % 97, degree=deg)
+    R = 2100
+    seeds = H.replica_seeds(R, S=n)
+    links = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds)
+    max_width = max(2, int(_initial_max_width(prob, links[0]) * frac))
+    betas = H.linear_betas(0, 60, 25)
+    with core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, max_width=max_width) as gpu:
+        gpu.run(betas, "mh", update_slices_every=10)
+        tot, mn = gpu.costs()
+        for r in [0, 1, 63, 64, R // 2, R - 2, R - 1]:
+            o = H.make_oracle(oracle_lib, prob, links[r], seeds[r], max_width=max_width)
+            o.run(oracle_lib.PROB_MH, betas, update_slices_every=10)
+            H.assert_replica_equal(gpu, r, o)
+            assert all(np.array_equal(a, b) for a, b in zip(gpu.slices(r), o.slices()))
+            assert tot[r] == o.total_cost and mn[r] == o.min_total_cost
+        assert gpu.validate() == (0, -1)
