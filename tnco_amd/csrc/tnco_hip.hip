@@ -1127,14 +1127,15 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
           pl.o_ring = pl.o_lpar + (2 * n + 7) / 8 * 8;
           pl.o_jb = pl.o_ring + 64 * 4;
           pl.seat_stride = (pl.o_jb + 16 * 4 + 15) / 16 * 16;
-          // One block (one wavefront of up to 16 replicas) per CU if that holds the batch, else two, else four: the fewest
-          // wavefronts that hold it -- 512 or 1024 wavefronts of one or two replicas each run up to twice slower per
-          // replica than 256 of them (profiles/experiments_r05.md) --, and as few replicas per wavefront as spreads the
-          // batch over all the CUs.  x1.3 ... x2.3 the HBM kernel per replica, so a second round of blocks would lose.
+          // Four blocks (wavefronts of up to 16 replicas) per CU -- one per SIMD -- if they hold the batch, else two, else
+          // one, and as few replicas per wavefront as spread the batch over all of them, the other lane groups shadowing
+          // (sa_small.h): per-replica move-evals/s at 128 leaves, four blocks / one block per CU: 1024 replicas 7.8 / 7.1e5,
+          // 2048: 7.4 / 6.6e5; 256 leaves, 1024: 7.6 / 7.0e5.  (Before the shadows it was the other way round: few active
+          // lanes per CU.)  x1.6 ... x2.8 the HBM kernel per replica, so a second round of blocks would lose.
           int best = 0;
-          for (int b = 1; b <= 4 && best == 0; b <<= 1) {
+          for (int b = 4; b >= 1 && best == 0; b >>= 1) {
             const int seats = std::min(SMALL_TPB / 4, (160 * 1024 / b - pl.seat0) / pl.seat_stride);
-            if (seats > 0 && (R <= (int64_t)b * seats * prop.multiProcessorCount || b == 4)) { best = b * seats; pl.seats = seats; pl.blocks_per_cu = b; }
+            if (seats > 0 && (R <= (int64_t)b * seats * prop.multiProcessorCount || b == 1)) { best = b * seats; pl.seats = seats; pl.blocks_per_cu = b; }
           }
 #ifdef TNCO_NO_SMALL_TREE
           best = 0;
