@@ -590,22 +590,23 @@ def test_fw_more_than_1024_tensors_on_the_one_wavefront_path(core, oracle_lib, m
     assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1]) and np.array_equal(a[2], b[2])
 
 
+@pytest.mark.parametrize("R", [2100, 5000, 8400])
 @pytest.mark.parametrize("n,deg,frac", [(48, 3, 0.6), (200, 4, 0.7), (520, 3, 0.8), (900, 3, 0.85)])
-def test_fw_full_wavefronts_of_the_staged_moves(core, oracle_lib, n, deg, frac):
-    """Small finite-width batches run the staged moves one replica per wavefront (sa_sweep.h, SPREAD; round 5), so the tests
-    above no longer reach their full wavefronts for layouts other than config 5's: 2 100 replicas (too many to spread, too
-    few to split over two streams), 4 x 1 / 4 x 2 / 4 x 4 / 8 x 3 lanes x words, the first, some middle and the last replicas
-    against the oracle incl. their slices."""
+def test_fw_full_wavefronts_of_the_staged_moves(core, oracle_lib, n, deg, frac, R):
+    """Small finite-width batches run the staged moves with few replicas per wavefront (sa_sweep.h, SPREAD; round 5), so the
+    tests above no longer reach their full wavefronts for layouts other than config 5's: 8 400 replicas (too many to spread:
+    two halves on two streams), 4 x 1 / 4 x 2 / 4 x 4 / 8 x 3 lanes x words, the first, some middle and the last replicas
+    against the oracle incl. their slices -- and 2 100 / 5 000 replicas: four / eight replicas per wavefront."""
     prob = H.regular_problem(n, graph_seed=n % 97, degree=deg)
-    R = 2100
     seeds = H.replica_seeds(R, S=n)
     links = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds)
     max_width = max(2, int(_initial_max_width(prob, links[0]) * frac))
     betas = H.linear_betas(0, 60, 25)
     with core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, max_width=max_width) as gpu:
+        assert gpu.launch_groups == 2 or R < 8400  # (8 400: two halves in full wavefronts; smaller: spread, or halves at 8 x 3)
         gpu.run(betas, "mh", update_slices_every=10)
         tot, mn = gpu.costs()
-        for r in [0, 1, 63, 64, R // 2, R - 2, R - 1]:
+        for r in [0, 1, 63, 64, R // 2 - 1, R // 2, R - 2, R - 1]:
             o = H.make_oracle(oracle_lib, prob, links[r], seeds[r], max_width=max_width)
             o.run(oracle_lib.PROB_MH, betas, update_slices_every=10)
             H.assert_replica_equal(gpu, r, o)

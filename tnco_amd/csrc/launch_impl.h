@@ -158,8 +158,9 @@ void launch_fw_move_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, in
 #define TNCO_FW_STAGED(HY, GE)                                                                                             \
   do {                                                                                                                     \
     if (h->run_seats > 0) /* a small batch: one replica per wavefront (sa_sweep.h, SPREAD) */                              \
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, HY, GE, true, true>), dim3((unsigned)((h->P.R + SWT / 64 - 1) / (SWT / 64))), \
-                         dim3(SWT), 0, h->stream, h->P, betas, n_steps, prob_kind, h->F, tail_last, 0);                    \
+      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, HY, GE, true, true>),                                                    \
+                         dim3((unsigned)((h->P.R + (SWT / 64) * h->run_seats - 1) / ((SWT / 64) * h->run_seats))),         \
+                         dim3(SWT), 0, h->stream, h->P, betas, n_steps, prob_kind, h->F, tail_last, h->run_seats);         \
     else                                                                                                                   \
       hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, HY, GE, true>), grid_staged, dim3(SWT), 0, h->stream, h->P, betas, n_steps, \
                          prob_kind, h->F, tail_last, 0);                                                                   \

@@ -339,9 +339,9 @@ template <int LOG2L, int K, bool HYPER, bool GENERIC, bool FW = false, bool SPRE
 __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES : (HYPER ? TNCO_HYPER_WAVES : (GENERIC ? TNCO_GENERIC_WAVES : (K >= 4 ? TNCO_K4_WAVES : TNCO_WAVES_PER_SIMD)))))) void sa_run_kernel(
     const Params P, const double* __restrict__ betas, const int64_t n_steps, const int prob_kind,
     const FwParams F, const int tail_last, const int block0) {
-  // SPREAD (a batch smaller than the kernel's wavefront slots): fewer replicas per wavefront than 64 / L -- infinite memory:
-  // `block0` of them, the host's choice; finite width: one --, the other lane groups SHADOW them: same replica, same
-  // reads, hence the same values and control flow, no store of their own.  Sixteen replicas in sixteen states make a wavefront run every state's code
+  // SPREAD (a batch smaller than the kernel's wavefront slots): fewer replicas per wavefront than 64 / L -- `block0` of
+  // them, the host's choice --, the other lane groups SHADOW them: same replica, same reads, hence the same values and
+  // control flow, no store of their own.  Sixteen replicas in sixteen states make a wavefront run every state's code
   // in every iteration -- 5 300 cycles at 512 leaves, of which the landing fence waits 13: a small batch is bound by this
   // instruction stream, not by memory --, and a CU wants 64 active lanes (tools/few_lanes.hip; csrc/sa_small.h).
   constexpr int L = 1 << LOG2L;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
   const int gbase = (tid & 63) & ~(L - 1);  // first lane of the group inside the wave
   // (block0: the launch covers the replicas of blocks block0 .. block0 + gridDim.x - 1 -- a handle may split a
   // step over several streams, launch_run_lk)
-  const int seats = SPREAD ? (FW ? 1 : block0) : (64 >> LOG2L);  // replicas per wavefront (SPREAD, infinite memory: `block0` carries them)
+  const int seats = SPREAD ? block0 : (64 >> LOG2L);             // replicas per wavefront (SPREAD: `block0` carries them)
   const int gw = (tid & 63) >> LOG2L;                            // lane group inside the wavefront
   const bool master = !SPREAD || gw < seats;
   const int seat = SPREAD ? (gw & (seats - 1)) : gw;

@@ -1180,21 +1180,24 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
         //  wavefronts per SIMD, 1024 blocks on 512 slots: +2 ... +8 % on two streams, profiles/r03_other_configs.md)
         if (part < 0.85) G = 2;
       }
-    } else if (nblocks < 64 && h->F.max_new_slices == 0) {
-      // finite width, a small batch: the staged moves one replica per wavefront (sa_sweep.h, SPREAD) -- they are 90 % of
-      // such a step (a full wavefront: 5.2 microseconds per move and replica)
+    } else if (h->F.max_new_slices == 0) {
+      // finite width, a batch that leaves wavefront slots of the staged moves empty: their SPREAD form, by the rule of the
+      // infinite-memory kernel above -- the moves are 90 % of such a step (full wavefronts: 5.2 microseconds per move and
+      // replica); otherwise two halves on two streams whatever the rounds -- what overlaps then are KERNELS of different
+      // bounds (the moves wait on memory requests, get_slices and the tree kernel on LDS / instruction latency)
       hipDeviceProp_t prop;
       HIP_TRY(hipGetDeviceProperties(&prop, d->device));
+      const int full = 64 / h->L;
       h->run_seats = 1;  // (the occupancy of the spread form)
       const int64_t wslots = (int64_t)run_blocks_per_cu(h) * prop.multiProcessorCount * (SWT / 64);
-      h->run_seats = (64 / h->L > 1 && 3 * R <= 2 * wslots) ? 1 : 0;
+      int seats = 1;
+      if (3 * R > 2 * wslots)
+        while (seats < full && (R + seats - 1) / seats > 4 * (int64_t)prop.multiProcessorCount) seats *= 2;
+      h->run_seats = (wslots > 0 && seats < full) ? seats : 0;
 #ifdef TNCO_NO_SMALL_TREE
       h->run_seats = 0;
 #endif
-    } else if (nblocks >= 64 && h->F.max_new_slices == 0) {
-      // finite width: two halves on two streams whatever the rounds -- what overlaps are KERNELS of different
-      // bounds (the moves wait on memory requests, get_slices and the tree kernel on LDS / instruction latency)
-      G = 2;
+      if (h->run_seats == 0 && nblocks >= 64) G = 2;
     }
     if (const char* e = std::getenv("TNCO_HIP_GROUPS")) G = std::max(1, std::min((int)tnco_hip_ctx::MAX_GROUPS, std::atoi(e)));
     if (h->small_tree || h->lds_tree || h->run_seats > 0 || nblocks < 2 * G) G = 1;
