@@ -324,12 +324,13 @@ def test_few_small_trees_run_lds_resident(core, oracle_lib):
 
 
 @pytest.mark.parametrize("n,deg,R", [(130, 3, 12300), (200, 4, 12300), (512, 3, 12300), (900, 3, 8200), (1300, 3, 8200),
-                                     (2048, 3, 4100)])
+                                     (2048, 3, 4100), (512, 3, 3000), (512, 3, 6000), (900, 3, 3000), (2048, 3, 2500)])
 def test_full_wavefronts_of_the_lane_layouts(core, oracle_lib, n, deg, R):
     """Small batches run the sweep kernel's SPREAD form or an LDS-resident kernel (round 5), so the parity tests above no
     longer reach the full wavefronts of `sa_run_kernel<L, K, ...>` that big batches run: here batches too large for either,
     4 x 1 / 4 x 2 / 4 x 3 / 8 x 3 / 8 x 4 / 16 x 3 lanes x words, the first, some middle and the last replicas against the
-    oracle."""
+    oracle -- and the SPREAD form with four, eight, four and two replicas per wavefront (3 000 / 6 000 replicas of 512
+    leaves, 3 000 of 900, 2 500 of 2 048)."""
     prob = H.regular_problem(n, graph_seed=n % 89, degree=deg)
     seeds = H.replica_seeds(R, S=n)
     links = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds)
