@@ -34,28 +34,100 @@ def _pair_lists(a: np.ndarray) -> list:
     return [pairs[j * steps:(j + 1) * steps] for j in range(k)]
 
 
+class _LivePositions:
+    """Positions of the live tensors of a linear (einsum) path: a Fenwick tree over creation order.
+
+    A linear path names a tensor by its position in a list from which contracted tensors are removed and to
+    which results are appended.  Creation order never changes, so "position -> tensor" is a rank query and
+    "tensor -> position" a prefix count over alive flags: O(log n) each instead of list.index + list.pop."""
+
+    def __init__(self, n_initial: int, n_total: int):
+        self.size = 1
+        while self.size < max(n_total, 1):
+            self.size *= 2
+        self.tree = [0] * (self.size + 1)
+        for slot in range(1, self.size + 1):  # O(n) build: the first n_initial slots alive
+            self.tree[slot] += 1 if slot <= n_initial else 0
+            up = slot + (slot & -slot)
+            if up <= self.size:
+                self.tree[up] += self.tree[slot]
+        self.alive = [True] * n_initial + [False] * (n_total - n_initial)
+        self.n_alive = n_initial
+        self.n_slots = n_initial
+
+    def _add(self, slot: int, delta: int) -> None:
+        slot += 1
+        while slot <= self.size:
+            self.tree[slot] += delta
+            slot += slot & -slot
+
+    def slot_at(self, position: int) -> int:
+        """The creation slot of the live tensor at `position`."""
+        if not 0 <= position < self.n_alive:
+            raise IndexError(position)
+        at, step, remaining = 0, self.size, position + 1
+        while step:
+            if at + step <= self.size and self.tree[at + step] < remaining:
+                at += step
+                remaining -= self.tree[at]
+            step //= 2
+        return at
+
+    def position_of(self, slot: int) -> int:
+        """The position of live slot `slot` (number of live slots before it)."""
+        if not (0 <= slot < self.n_slots and self.alive[slot]):
+            raise KeyError(slot)
+        count, at = 0, slot
+        while at:
+            count += self.tree[at]
+            at -= at & -at
+        return count
+
+    def remove(self, slot: int) -> None:
+        self.alive[slot] = False
+        self.n_alive -= 1
+        self._add(slot, -1)
+
+    def append(self) -> int:
+        slot = self.n_slots
+        self.alive[slot] = True
+        self.n_slots += 1
+        self.n_alive += 1
+        self._add(slot, 1)
+        return slot
+
+
 def merge_contraction_paths(n_tensors: int, paths: Iterable[list], *, autocomplete: bool = True) -> list:
-    """tnco/utils/tn.py:334-401."""
-    merged_pos = list(range(n_tensors))
-    merged_path = []
-    for i, path in enumerate(paths):
-        pos = list(range(n_tensors))
-        for x, y in path:
-            x, y = sorted((x, y))
-            y = pos.pop(y)
-            x = pos.pop(x)
-            pos.append((i, len(pos)))
+    """Several linear paths over the same `n_tensors` tensors, each touching tensors of its own -> ONE linear path
+    that runs them one after the other (contract: tnco/utils/tn.py:334-361; `autocomplete` appends the (0, 1)
+    steps that join what is left).  A path that contracts a tensor another path consumed is refused.
+
+    Built as: every path replayed over its own position structure to learn WHICH tensors a step joins (the
+    originals keep their slots; a result is tied to the slot the merged structure gives it), the same step then
+    read back as positions of the merged structure."""
+    paths = [list(p) for p in paths]
+    n_steps = sum(len(p) for p in paths)
+    merged = _LivePositions(n_tensors, n_tensors + n_steps)
+    out = []
+    for path in paths:
+        own = _LivePositions(n_tensors, n_tensors + len(path))
+        to_merged = {}  # slots of this path's results -> their slots in the merged structure
+        for step in path:
             try:
-                mx, my = sorted((merged_pos.index(x), merged_pos.index(y)))
-            except ValueError as e:
+                slots = [own.slot_at(int(q)) for q in step]
+                if len(slots) != 2 or slots[0] == slots[1]:
+                    raise IndexError(step)
+                where = sorted(merged.position_of(to_merged.get(s, s)) for s in slots)
+            except (IndexError, KeyError, TypeError) as e:
                 raise ValueError("'paths' are not valid or not disconnected.") from e
-            merged_path.append((mx, my))
-            merged_pos.pop(my)
-            merged_pos.pop(mx)
-            merged_pos.append(pos[-1])
+            for s in slots:
+                own.remove(s)
+                merged.remove(to_merged.get(s, s))
+            to_merged[own.append()] = merged.append()
+            out.append((where[0], where[1]))
     if autocomplete:
-        merged_path += [(0, 1)] * (len(merged_pos) - 1)
-    return merged_path
+        out.extend([(0, 1)] * (merged.n_alive - 1))
+    return out
 
 
 def split_contraction_path(n_tensors: int, path: Iterable[tuple[int, int]]) -> list:
@@ -93,32 +165,36 @@ def split_contraction_path(n_tensors: int, path: Iterable[tuple[int, int]]) -> l
     return [paths[c] for c in order if paths[c]]
 
 
+def _positive_int(n_steps):
+    try:
+        whole = int(n_steps)
+    except (TypeError, ValueError):
+        whole = None
+    if whole is None or whole != n_steps or whole <= 0:
+        raise ValueError("'n_steps' must be a positive number.")
+    return whole
+
+
 def expand_betas(betas, n_steps):
-    """Argument checks and schedule of sa.py:141-156 (more_itertools.numeric_range(b0, b1, step)
-    yields b0 + k*step while < b1 for step > 0, > b1 for step < 0)."""
-    if n_steps is not None:
-        if int(n_steps) != n_steps or n_steps <= 0:
-            raise ValueError("'n_steps' must be a positive number.")
-        n_steps = int(n_steps)
+    """The inverse temperatures of a call as one float64 array (contract and messages: sa.py:141-156, 201).
+
+    A pair (beta_ini, beta_end) is the arithmetic schedule the reference takes from
+    more_itertools.numeric_range(b0, b1, step), step = (b1 - b0) / n_steps computed once: the values
+    b0 + k * step, k = 0, 1, ... that have not reached b1 -- of which the step loop uses at most n_steps.  Anything
+    else is a list of betas, cut at n_steps when that is given."""
+    limit = None if n_steps is None else _positive_int(n_steps)
     if isinstance(betas, tuple) and len(betas) == 2:
-        if n_steps is None:
+        if limit is None:
             raise ValueError("'n_steps' must be provided if 'betas' has the format '(beta_min, beta_max)'.")
-        if betas[0] == betas[1]:
+        first, last = betas
+        if first == last:
             raise ValueError("'betas' must use the format '(beta_ini, beta_end)', with 'beta_ini != beta_end'.")
-        b0, b1 = betas
-        step = (b1 - b0) / n_steps
-        out, k = [], 0
-        while True:
-            v = b0 + k * step
-            if (step > 0 and v >= b1) or (step < 0 and v <= b1):
-                break
-            out.append(v)
-            k += 1
-        betas = out
-    betas = [float(b) for b in betas]
-    if n_steps is not None:
-        betas = betas[:n_steps]  # `if n == n_steps: break`, sa.py:201
-    return np.asarray(betas, np.float64)
+        step = (last - first) / limit
+        ramp = float(first) + np.arange(limit, dtype=np.float64) * float(step)  # (same IEEE product and sum as b0 + k * step)
+        reached = (ramp >= last) if step > 0 else (ramp <= last)
+        return ramp[:int(np.argmax(reached))] if reached.any() else ramp
+    schedule = np.asarray([float(b) for b in betas], np.float64)
+    return schedule if limit is None else schedule[:limit]
 
 
 def replica_seeds(rng, k: int) -> list:

@@ -8,7 +8,6 @@ from __future__ import annotations
 
 import bz2
 import gzip
-import io
 import json
 import pickle
 from dataclasses import dataclass
@@ -24,14 +23,20 @@ __all__ = ["Optimizer", "BaseOptimizer", "BaseContractionResults", "dump_results
 
 
 class JSONEncoder(json.JSONEncoder):
+    """Results as JSON objects of the fields their class lists in `_json_fields` (the keys the reference's
+    encoders emit: app.py:47-61, infinite_memory/sa.py:47-60, finite_width/sa.py:42-70), costs as strings,
+    index sets as sorted lists."""
+
     def default(self, obj):
+        fields = getattr(type(obj), "_json_fields", None)
+        if fields is not None:
+            return {name: getattr(obj, name) for name in fields}
         if isinstance(obj, Decimal):
             return str(obj)
-        if isinstance(obj, BaseContractionResults):
-            return dict(cost=obj.cost, runtime_s=obj.runtime_s, path=obj.path)
-        if hasattr(obj, "to_json"):
-            return obj.to_json()
-        return super().default(obj)
+        if isinstance(obj, (set, frozenset)):
+            return sorted(obj, key=str)
+        to_json = getattr(obj, "to_json", None)
+        return to_json() if callable(to_json) else super().default(obj)
 
 
 @dataclass(repr=False, frozen=True, eq=False)
@@ -40,6 +45,7 @@ class BaseContractionResults:
     cost: float
     runtime_s: float
     path: list
+    _json_fields = ("cost", "runtime_s", "path")
 
     def __lt__(self, other):
         if not isinstance(other, BaseContractionResults):
@@ -60,37 +66,55 @@ def cost_to_decimal(x: float) -> Decimal:
     return Decimal("%g" % x)
 
 
+_FORMATS = ("raw", "json")
+_COMPRESSIONS = {"auto": None, "none": None, "bz2": bz2.compress, "gzip": gzip.compress}
+
+
+def _choice(option: str, value, allowed) -> str:
+    """The lower-cased option value, or the reference's ValueError text for one it does not know."""
+    text = str(value).lower()
+    if text not in allowed:
+        raise ValueError(f'"{option}={text!r}" not supported.')
+    return text
+
+
+def _file_bytes(tn, res, as_json: bool) -> bytes:
+    """What a results file holds before compression: the JSON text, or the pickle of (tn, res)."""
+    return _json_text(tn, res).encode() if as_json else pickle.dumps((tn, res))
+
+
+def _json_text(tn, res) -> str:
+    return '{"tn" : ' + tn.to_json() + ', "res" : [' + ", ".join(r.to_json() for r in res) + "]}"
+
+
 def dump_results(tn, res, *, output_format=None, output_filename=None, output_compression="auto",
-                 overwrite_output_file=False, **kwargs):
-    """(tn, res) | JSON string | file, as app.py:573-712."""
-    check_only = kwargs.pop("check_only", False)
-    if kwargs:
+                 overwrite_output_file=False, check_only=False, **unexpected):
+    """Hand the results back, or put them in a file (contract: tnco/app/app.py:573-637).
+
+    No file name: returns (tn, res) for `output_format` None / 'raw', the JSON text for 'json'.  With a file name:
+    writes the JSON text, or the pickle of (tn, res), compressed as `output_compression` says ('auto': by the
+    file's suffix, .gzip / .bz2), and returns None.  `check_only` validates the options and does nothing else.
+
+    One serialisation to bytes, one optional compressor, one write -- the compressed files read back with
+    gzip.open / bz2.open exactly as the reference's do."""
+    if unexpected:
         raise TypeError("Unexpected extra keyword arguments.")
-    output_format = "raw" if output_format is None else str(output_format).lower()
-    if output_format not in ("raw", "json"):
-        raise ValueError(f'"{output_format=}" not supported.')
-    output_filename = None if output_filename is None else Path(output_filename).expanduser()
-    if output_filename and not overwrite_output_file and output_filename.exists():
-        raise FileExistsError("'{}' already exists. Please use 'overwrite_output_file=True'.".format(output_filename))
-    output_compression = str(output_compression).lower()
-    if output_compression not in ("auto", "none", "bz2", "gzip"):
-        raise ValueError(f'"{output_compression=}" not supported.')
+    fmt = _choice("output_format", "raw" if output_format is None else output_format, _FORMATS)
+    scheme = _choice("output_compression", output_compression, _COMPRESSIONS)
+    target = Path(output_filename).expanduser() if output_filename is not None and str(output_filename) else None
+    if target is not None and target.exists() and not overwrite_output_file:
+        raise FileExistsError(f"'{target}' already exists. Please use 'overwrite_output_file=True'.")
     if check_only:
         return None
-    output = (tn, res)
-    if output_format == "json":
-        output = '{{"tn" : {}, "res" : {}}}'.format(tn.to_json(), "[" + ", ".join(r.to_json() for r in res) + "]")
-    if output_filename:
-        suffix = output_filename.suffix[1:] if output_compression == "auto" else output_compression
-        open_, compress = (gzip.open, True) if suffix == "gzip" else (bz2.open, True) if suffix == "bz2" else (io.open, False)
-        if isinstance(output, str):
-            with open_(output_filename, "w") as f:
-                f.write(output.encode() if compress else output)
-            return None
-        with open_(output_filename, "w" if compress else "bw") as f:
-            pickle.dump(output, f)
-        return None
-    return output
+    as_json = fmt == "json"
+    if target is None:
+        return _json_text(tn, res) if as_json else (tn, res)
+    if scheme == "auto":
+        scheme = target.suffix.lstrip(".")
+    squeeze = _COMPRESSIONS.get(scheme)
+    blob = _file_bytes(tn, res, as_json)
+    target.write_bytes(squeeze(blob) if squeeze else blob)
+    return None
 
 
 @dataclass(frozen=True)

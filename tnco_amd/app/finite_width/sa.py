@@ -6,25 +6,14 @@ tnco_amd/app/_sa_driver.py, the kernels tnco_amd/csrc/fw_kernels.h.
 """
 from __future__ import annotations
 
-import json
 from dataclasses import dataclass
 from functools import reduce
 from typing import Any
 
 from .._sa_driver import merge_contraction_paths, run_sa
-from ..app import BaseContractionResults, BaseOptimizer, JSONEncoder as BaseJSONEncoder
+from ..app import BaseContractionResults, BaseOptimizer
 
 __all__ = ["Optimizer", "ContractionResults"]
-
-
-class JSONEncoder(BaseJSONEncoder):
-    def default(self, obj):
-        if isinstance(obj, ContractionResults):
-            return dict(**BaseJSONEncoder().default(obj), disconnected_paths=obj.disconnected_paths,
-                        disconnected_slices=obj.disconnected_slices, slices=obj.slices)
-        if isinstance(obj, frozenset):
-            return sorted(obj, key=str)
-        return super().default(obj)
 
 
 @dataclass(repr=False, frozen=True, eq=False)
@@ -34,9 +23,7 @@ class ContractionResults(BaseContractionResults):
     disconnected_paths: list
     disconnected_slices: list
     slices: frozenset
-
-    def to_json(self):
-        return json.dumps(self, cls=JSONEncoder)
+    _json_fields = BaseContractionResults._json_fields + ("disconnected_paths", "disconnected_slices", "slices")
 
 
 class Optimizer(BaseOptimizer):

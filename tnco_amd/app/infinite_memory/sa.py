@@ -12,21 +12,13 @@ tnco_amd/app/_sa_driver.py.  Differences a caller can observe (see DESIGN.md sec
 """
 from __future__ import annotations
 
-import json
 from dataclasses import dataclass
 from typing import Any
 
 from .._sa_driver import expand_betas, merge_contraction_paths, run_sa  # noqa: F401 (re-exported)
-from ..app import BaseContractionResults, BaseOptimizer, JSONEncoder as BaseJSONEncoder
+from ..app import BaseContractionResults, BaseOptimizer, JSONEncoder  # noqa: F401 (re-exported)
 
 __all__ = ["Optimizer", "ContractionResults", "merge_contraction_paths", "expand_betas"]
-
-
-class JSONEncoder(BaseJSONEncoder):
-    def default(self, obj):
-        if isinstance(obj, ContractionResults):
-            return dict(**BaseJSONEncoder().default(obj), disconnected_paths=obj.disconnected_paths)
-        return super().default(obj)
 
 
 @dataclass(repr=False, frozen=True, eq=False)
@@ -34,9 +26,7 @@ class ContractionResults(BaseContractionResults):
     """sa.py:63-90: + per-component costs and paths (each path over ALL original tensors)."""
     disconnected_costs: list
     disconnected_paths: list
-
-    def to_json(self):
-        return json.dumps(self, cls=JSONEncoder)
+    _json_fields = BaseContractionResults._json_fields + ("disconnected_paths",)
 
 
 class Optimizer(BaseOptimizer):

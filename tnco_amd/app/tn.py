@@ -89,18 +89,23 @@ class TensorNetwork:
 
 
 def read_inds(inds_map: dict, *, output_index_token="*", sparse_index_token="/"):
-    """index -> (dim, tensor names...)  ==>  tensor map, dims, output, sparse (tn.py:520-569)."""
+    """The index-list form {index: (dim, tensor, tensor, ...)} turned around into {tensor: (index, ...)}, with the
+    dims, the open indices (those listed under the output token) and the sparse ones (contract:
+    tnco/utils/tn.py:520-546).  Tensors appear in order of first mention, their indices in the order of the map."""
     if output_index_token == sparse_index_token:
         raise ValueError("'output_index_token' and 'sparse_index_token' must differ.")
-    tensor_map = defaultdict(list)
-    dims = {}
-    for i, (d, *ts) in inds_map.items():
-        dims[i] = int(d)
-        for t in ts:
-            tensor_map[t].append(i)
-    output_inds = frozenset(tensor_map.pop(output_index_token, ()))
-    sparse_inds = frozenset(tensor_map.pop(sparse_index_token, ()))
-    return {k: tuple(v) for k, v in tensor_map.items()}, dims, output_inds, sparse_inds
+    marked = {output_index_token: set(), sparse_index_token: set()}
+    dims, held = {}, {}
+    for index, entry in inds_map.items():
+        entry = tuple(entry)
+        dims[index] = int(entry[0])
+        for name in entry[1:]:
+            if name in marked:
+                marked[name].add(index)
+            else:
+                held.setdefault(name, []).append(index)
+    tensor_map = {name: tuple(inds) for name, inds in held.items()}
+    return tensor_map, dims, frozenset(marked[output_index_token]), frozenset(marked[sparse_index_token])
 
 
 def get_connected_components(ts_inds) -> list[tuple[int, ...]]:
