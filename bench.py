@@ -273,7 +273,7 @@ def reduce_legs(res, world, dist, torch, grouped=None):
     the line itself shows how many ranks took part."""
     names = KERNELS
     mine = [res["dt"], float(res["moves"]), float(res["accepted"]), float(res["random_picks"]),
-            float(res["improved"]), float(res["full_copies"])] + [res["kt"][k][0] for k in names]
+            float(res["improved"]), float(res["full_copies"])] + [res["kt"][k][0] for k in names] + [float(res.get("n_bad", -1))]
     per_rank = [mine]
     from tnco_amd import parallel
     if (world > 1 if grouped is None else grouped) and parallel._native is not None:
@@ -290,7 +290,13 @@ def reduce_legs(res, world, dist, torch, grouped=None):
     for j, k in enumerate(("moves", "accepted", "random_picks", "improved", "full_copies")):
         out[k] = float(arr[:, 1 + j].sum())
     out["kt"] = {k: (float(arr[:, 6 + j].max()), res["kt"][k][1]) for j, k in enumerate(names)}
-    out["per_rank"] = [dict(rank=i, wall_s=v[0], moves=v[1], kernel_ms=sum(v[6:])) for i, v in enumerate(per_rank)]
+    nb = arr[:, 6 + len(names)]
+    if (nb >= 0).all():  # (every rank validated its replicas: the line reports the sum over all of them)
+        out["n_bad"] = int(nb.sum())
+    else:
+        out.pop("n_bad", None)
+    out["per_rank"] = [dict(rank=i, wall_s=v[0], moves=v[1], kernel_ms=sum(v[6:6 + len(names)]), bad_replicas=int(v[6 + len(names)]))
+                       for i, v in enumerate(per_rank)]
     return out
 
 
@@ -441,24 +447,27 @@ def end_to_end(args):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-def config2(local_rank):
-    """BASELINE configs[1] (64-leaf 3-regular TN, 4 096 replicas) -- the small end of the path: 4 096 replicas are 256
-    wavefronts, one per CU; the library runs them LDS-resident (csrc/sa_small.h: the trees of a wavefront's 16 replicas stay
-    in LDS for a launch, x1.8 the HBM kernel here, whose replicas advance one dependent memory round trip at a time).
-    Informational (N = 1): move-evals/s over 1 000 sweeps, every replica validated, 64 of them against the oracle."""
+def side_leg(label, prob, R, sweeps, local_rank, *, warm=50, cpu_n=64, dims=2, sparse_n_projs=None, init_seed_S=0):
+    """One informational leg beside the two timed ones (N = 1): `sweeps` sweeps of R replicas of `prob` in ONE call,
+    wall time around it; afterwards is_valid() of every replica on the device and `cpu_n` of the same replicas through
+    the oracle, whole schedule, best costs compared bit for bit.  Never fails the bench line."""
     try:
-        from tnco_amd import core, synthetic
-        prob = synthetic.regular_problem(64, graph_seed=7)
-        R, sweeps = 4096, 1000
-        seeds = synthetic.replica_seeds(R)
-        links = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds)
-        betas = synthetic.linear_betas(0.0, 100.0, sweeps + 50)
-        with core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, device=local_rank) as opt:
-            opt.run(betas[:50])
+        from concurrent.futures import ThreadPoolExecutor
+
+        from tnco_amd import core, ctree, synthetic
+        seeds = synthetic.replica_seeds(R, S=init_seed_S)
+        om = prob.output_mask if prob.output_mask.any() else None
+        links = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds, output_mask=om, device=local_rank)
+        betas = synthetic.linear_betas(0.0, 100.0, sweeps + warm)
+        kw = dict(n_inds=prob.n_inds, dims=dims, output_mask=om)
+        if prob.sparse_mask is not None:
+            kw.update(sparse_mask=prob.sparse_mask, n_projs=sparse_n_projs)
+        with core.BatchedOptimizer(prob.leaf_masks, links, seeds, device=local_rank, **kw) as opt:
+            opt.run(betas[:warm])
             opt.sync()
             m0 = opt.counters()["moves"]
             t0 = time.perf_counter()
-            opt.run(betas[50:])
+            opt.run(betas[warm:])
             opt.sync()
             dt = time.perf_counter() - t0
             moves = opt.counters()["moves"] - m0
@@ -467,12 +476,74 @@ def config2(local_rank):
             lds = opt.launch_groups == 0
         from oracle import oracle as orc
         orc.build()
-        _dt, _tot, omn, _mv = orc.run_batch(links[:64], prob.leaf_masks, seeds[:64], betas, n_inds=prob.n_inds, dims=2)
-        return {"workload": "C2: 64-leaf 3-regular TN d=2, 4096 replicas, MH, f64, 1000 sweeps (one launch)", "value": moves / dt,
-                "unit": "move-evals/s", "seconds": dt, "validated_bad_replicas": bad,
-                "kernel": "sa_small_kernel (LDS-resident)" if lds else "sa_run_kernel",
-                "cpu_sample_min_cost_bit_exact": bool(np.array_equal(omn, mn[:64])), "best_log10_flops": float(np.log10(mn.min()))}
+        cpu_n = min(cpu_n, R)
+
+        def one(r):
+            l, rr, p = (np.ascontiguousarray(links[r, j]) for j in range(3))
+            inds = ctree.derive_inds(l, rr, prob.leaf_masks, om)
+            o = orc.Oracle(l, rr, p, inds, n_inds=prob.n_inds, dims=dims, seed=int(seeds[r]), sparse=prob.sparse_mask,
+                           n_projs=sparse_n_projs or 0)
+            o.run(orc.PROB_MH, betas)
+            return o.min_total_cost
+
+        with ThreadPoolExecutor(usable_cores()) as ex:
+            omn = np.array(list(ex.map(one, range(cpu_n))))
+        return {"workload": label, "value": moves / dt, "unit": "move-evals/s", "seconds": dt, "replicas": R, "sweeps": sweeps,
+                "n_leaves": prob.n, "n_inds": prob.n_inds, "mask_words": prob.W, "validated_bad_replicas": bad,
+                "kernel": "LDS-resident (sa_small_kernel / sa_lds_kernel)" if lds else "sa_run_kernel (trees in HBM)",
+                "cpu_sample": cpu_n, "cpu_sample_min_cost_bit_exact": bool(np.array_equal(omn, mn[:cpu_n])),
+                "best_log10_flops": float(np.log10(mn.min()))}
     except Exception as e:  # (informational: never fails the bench line)
+        return {"workload": label, "error": f"{type(e).__name__}: {e}"}
+
+
+def side_legs(local_rank, which):
+    """The configurations the two timed legs do not show (N = 1, a few seconds each): BASELINE configs[1]; the reference
+    loader's default for circuits, hyper-indices (tnco/app/app.py:351-358); per-index dims
+    (infinite_memory/cost_model/simple.hpp:51-53); batches too small to fill the chip (the LDS-resident and the spread
+    form); a network of 24 mask words."""
+    from tnco_amd import synthetic
+    out = {}
+    if "c2" in which:
+        out["c2"] = side_leg("C2: 64-leaf 3-regular TN d=2, 4096 replicas, MH, f64, 1000 sweeps (one launch)",
+                             synthetic.regular_problem(64, graph_seed=7), 4096, 1000, local_rank)
+    if "hyper" in which:
+        hts, hd, hout = synthetic.random_hyper_tn(512, 768, k=3, n_output=8, seed=3)
+        out["hyper"] = side_leg("hyper-index network: 512 tensors, 768 indices (3 tensors each) d=2, 8 open; 65536 replicas, 400 sweeps",
+                                synthetic.Problem(hts, hd, hout, n_inds=768), 65536, 400, local_rank)
+    if "dims" in which:
+        prob = synthetic.regular_problem(512, graph_seed=11)
+        dv = np.random.RandomState(0).choice([2, 3, 4], size=prob.n_inds).astype(np.uint64)
+        out["dims"] = side_leg("C3's network with per-index dims in {2, 3, 4}; 65536 replicas, 400 sweeps", prob, 65536, 400, local_rank, dims=dv)
+    if "small_batch" in which:
+        prob = synthetic.regular_problem(512, graph_seed=11)
+        out["small_batch"] = {
+            "512_runs": side_leg("C3's network, 512 replicas, 1000 sweeps (one launch)", prob, 512, 1000, local_rank),
+            "2048_runs": side_leg("C3's network, 2048 replicas, 1000 sweeps (one launch)", prob, 2048, 1000, local_rank)}
+    if "wide" in which:
+        out["wide"] = side_leg("1024-leaf 3-regular TN d=2 (24 mask words), 65536 replicas, 200 sweeps",
+                               synthetic.regular_problem(1024, graph_seed=11), 65536, 200, local_rank)
+    return out
+
+
+def calibration(local_rank):
+    """This box's memory system under the sweep kernels' access pattern (tools/box_probe.hip, built by
+    __graft_entry__.build() as tools/libbox_probe.so), measured in this process: fresh boxes of the pool differ by ~10 %."""
+    import ctypes
+    try:
+        L = ctypes.CDLL(str(ROOT / "tools" / "libbox_probe.so"))
+        L.box_probe.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
+        out = (ctypes.c_double * 3)()
+        t0 = time.perf_counter()
+        rc = L.box_probe(local_rank, 8.0, out)
+        if rc:
+            return {"error": f"box_probe: hip error {rc}"}
+        return {"random_lines_per_s": out[0], "move_pattern_per_s": out[1], "stream_read_GBs": out[2] / 1e9,
+                "seconds": time.perf_counter() - t0,
+                "what": "tools/box_probe.hip in this process, 8 GiB working set: random 128-byte lines read (4 lanes per line, 4 in "
+                        "flight per group); the memory side of one infinite-memory move alone (2 random lines read, 1 header "
+                        "sector written, 3 of 4 moves the rest of the line + two 4-byte parent words); streaming read"}
+    except OSError as e:
         return {"error": f"{type(e).__name__}: {e}"}
 
 
@@ -506,6 +577,9 @@ def main() -> None:
     ap.add_argument("--e2e", type=int, default=1,
                     help="1 (N = 1): also time app.Optimizer(method='sa').optimize() of the headline network end to end "
                          "(spec -> initial trees -> sweeps -> best paths): the `end_to_end` object, informational")
+    ap.add_argument("--extras", default="c2,hyper,dims,small_batch,wide",
+                    help="informational side legs of the line (N = 1; with --e2e 1): any of c2, hyper, dims, small_batch, wide; '' = none")
+    ap.add_argument("--calibrate", type=int, default=1, help="1: measure this box's random-request rates in this process (`calibration`)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -583,16 +657,19 @@ def main() -> None:
 
     legs = {"both": ("im", "fw"), "im": ("im",), "fw": ("fw",)}[args.workload]
     results, objs = {}, {}
+    calib = calibration(local_rank) if (args.calibrate and rank == 0 and world == 1) else None
     for kind in legs:
         leg = Leg(kind, args, rank, world, local_rank, grouped)
-        res = reduce_legs(leg.run(barrier, dist), world, dist, torch, grouped)
+        res = leg.run(barrier, dist)
         # after the timed region: is_valid(atol) of EVERY replica, recomputed on the device from the trees alone
         # (ContractionTree::is_valid + both caches against a from-scratch rebuild, infinite_memory/optimizer.hpp:223-251)
-        # -- the line certifies the work it counted; --no-validate skips it
+        # -- the line certifies the work it counted: every rank validates its own replicas, the counts are summed
+        # with the moves (reduce_legs); --no-validate skips it
         if args.validate:
             tv = time.perf_counter()
             res["n_bad"] = int(leg.opt.validate()[0])
             res["validate_s"] = time.perf_counter() - tv
+        res = reduce_legs(res, world, dist, torch, grouped)
         results[kind], objs[kind] = res, leg
         if not (rank == 0 and world == 1 and args.cpu_sample != 0):
             leg.opt.close()
@@ -725,6 +802,12 @@ def main() -> None:
                 roof["achieved"] = roof["traffic"] / (step_ms / 1e3) / 1e9
                 roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
                 roof["frac_of_achievable"] = roof["achieved"] / HBM_RANDOM_LINE_GBS
+                if calib and calib.get("random_lines_per_s"):
+                    # the same two fractions against what THIS box retires (the `calibration` object), not the constants
+                    # measured on one box rounds ago: comparable between boxes
+                    roof["frac_of_achievable_this_box"] = roof["achieved"] * 1e9 / (128.0 * calib["random_lines_per_s"])
+                    if roof.get("request_rate"):
+                        roof["request_rate_frac_this_box"] = roof["request_rate"] / calib["random_lines_per_s"]
                 roof["frac_source"] = "measured traffic (this run's PMC passes)" if not pmc_note else f"measured traffic ({pmc_note})"
             else:  # no counters (rocprofv3 missing, --pmc 0, N > 1): the model of the compulsory traffic, said so
                 roof["achieved"] = comp_per_step / (step_ms / 1e3) / 1e9
@@ -758,7 +841,7 @@ def main() -> None:
                     "random_pick_rate": q, "best_log10_flops": float(np.log10(res["best"])),
                     "improvements_timed": res["improved"], "full_tree_copies_timed": res["full_copies"],
                     "validated_bad_replicas": res.get("n_bad"),
-                    "validated": (f"tnco_hip_validate(atol=1e-5) over all {R} replicas after the timed region, "
+                    "validated": (f"tnco_hip_validate(atol=1e-5) over all {R * world} replicas (every rank its own, counts summed) after the timed region, "
                                   f"{res.get('validate_s', 0.0):.2f} s (untimed)") if res.get("n_bad") is not None else None,
                     "library": lib_version,
                     "initial_trees": "random Kruskal (tnco_hip_random_trees)" if args.init == "kruskal" else
@@ -822,7 +905,17 @@ def main() -> None:
             out[kind] = leg_object(kind)
         if args.e2e and world == 1 and args.replicas <= 131072:  # (beside the legs' own handles: not for the 100-GB batches)
             out["end_to_end"] = end_to_end(args)
-            out["c2"] = config2(local_rank)
+            out.update(side_legs(local_rank, [x for x in args.extras.split(",") if x]))
+        if calib is not None:
+            out["calibration"] = calib
+            if calib.get("move_pattern_per_s"):
+                # the headline against the memory side of its own moves on this box (1.0 = the kernel costs nothing but
+                # its memory requests); a second probe after everything else shows how far the box drifted meanwhile
+                out["calibration"]["value_over_move_pattern"] = (results["im"]["moves"] / results["im"]["dt"] / calib["move_pattern_per_s"]
+                                                                 if "im" in results else None)
+                again = calibration(local_rank)
+                out["calibration"]["after"] = {k: again.get(k) for k in ("random_lines_per_s", "move_pattern_per_s", "stream_read_GBs", "error")
+                                               if again.get(k) is not None}
         print(json.dumps(out), flush=True)
     for leg in objs.values():
         if leg.opt is not None:

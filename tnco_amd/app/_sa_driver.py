@@ -321,9 +321,19 @@ def run_sa(opt, tn, betas, n_steps, n_runs, n_projs, timeout, *, top_k, sweeps_p
         # sweeps per kernel launch (launches queue up on the device; a launch is also the grain of `timeout` and of the
         # progress series).  Default: 100; 1000 for a small batch or a handle whose trees stay in LDS during a launch
         # (csrc/sa_small.h) -- with few replicas per wavefront a launch ends when the slowest replica ends (100 sweeps: ~10 %
-        # of idle tail, 1000: ~3 %), and 1000 sweeps of such a batch are 10-30 ms.
-        spl = sweeps_per_launch if sweeps_per_launch is not None else (
-            1000 if (not finite and (h.launch_groups == 0 or n_local <= 4096)) else 100)
+        # of idle tail, 1000: ~3 %), and 1000 sweeps of LDS-resident trees are 10-30 ms.  A small batch in the HBM kernel
+        # (spread over the wavefronts) advances at ~4e5 move-evals/s per run, a sweep is ~ n_leaves moves: the launch is
+        # sized to ~0.25 s so that `timeout` and the progress series keep their grain on large trees.
+        if sweeps_per_launch is not None:
+            spl = sweeps_per_launch
+        elif finite:
+            spl = 100
+        elif h.launch_groups == 0:
+            spl = 1000
+        elif n_local <= 4096:
+            spl = min(1000, max(100, int(1e5 / max(1, len(comp.tensors)))))
+        else:
+            spl = 100
         spl = max(1, int(spl))
         starts = list(range(0, len(betas), spl))
         report_every = max(1, -(-len(starts) // PROGRESS_POINTS)) if (opt.verbose or progress is not None) else 0
@@ -384,10 +394,11 @@ def run_sa(opt, tn, betas, n_steps, n_runs, n_projs, timeout, *, top_k, sweeps_p
         for ci, comp in enumerate(comps):
             if handles[ci] is None:
                 paths.append([])
-                slices.append(frozenset())
+                slices.append(())
             else:
                 paths.append(paths_by_comp[ci][j])
-                slices.append(comp.names(slices_by_comp[ci][j]) if finite else frozenset())
+                # (bit positions, not the user's index names -- any hashable: only plain data crosses ranks)
+                slices.append(tuple(unpack_mask(slices_by_comp[ci][j])) if finite else ())
         local.append((totals[r], lo + r, dec[r], paths, slices, list(merged_all[j])))
     best_raw = float(raw_total.min()) if n_local else float("inf")
     for h in handles:
@@ -395,6 +406,9 @@ def run_sa(opt, tn, betas, n_steps, n_runs, n_projs, timeout, *, top_k, sweeps_p
             h.close()
 
     merged = parallel.merge_heads(local, top_k, rank, world)
+    # positions -> names on this side of the exchange: `comps` is the same on every rank
+    merged = [(c, gid, dc, paths, [frozenset(comp.inds_order[p] for p in pos) for comp, pos in zip(comps, sl)], mp)
+              for c, gid, dc, paths, sl, mp in merged]
     tn.tags["best_raw_cost"] = parallel.global_best(best_raw, rank, world, device)
     tn.tags["n_runs"] = n_runs
     tn.tags["timed_out"] = timed_out

@@ -53,7 +53,6 @@ struct tnco_hip_ctx {
   int small_seats = 16;     // ... replicas per wavefront (a batch smaller than the chip's wavefront slots is spread)
   int run_seats = 0;        // > 0: the HBM sweep kernel's SPREAD form, that many replicas per wavefront (a batch smaller than the wavefront slots)
   bool lds_tree = false;    // any tree whose replicas fit the CUs' LDS in two rounds: sa_lds_kernel with the plan below
-  bool lds_attr_set = false;
   tnco::LdsPlan lds_plan{};
   uint64_t* leaf_idx = nullptr;  // [n][lds_plan.leaf_stride] the leaves' index positions (16 bits each), device
   tnco::FwParams F{};
@@ -237,6 +236,8 @@ template <int LOG2L, int K>
 void launch_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int prob_kind, hipStream_t s, int block0, int nblocks);
 template <int LOG2L, int K>
 int run_blocks_per_cu_lk(tnco_hip_ctx* h);
+template <int LOG2L, int K>
+int lds_kernel_prepare_lk(tnco_hip_ctx* h, int device_lds_bytes);
 template <int LOG2L, int K>
 void launch_build_lk(tnco_hip_ctx* h, const tnco::BuildArgs& a);
 template <int LOG2L, int K>

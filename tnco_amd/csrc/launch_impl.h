@@ -62,10 +62,7 @@ void launch_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int pr
     if (h->lds_tree) {
       const LdsPlan& pl = h->lds_plan;
       const void* kern = h->hyper ? (const void*)sa_lds_kernel<K, true> : (const void*)sa_lds_kernel<K, false>;
-      if (!h->lds_attr_set) {  // (more dynamic LDS than the 64 KiB a kernel gets by default)
-        (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, pl.total);
-        h->lds_attr_set = true;
-      }
+      (void)kern;  // (its dynamic-LDS limit was raised at create: lds_kernel_prepare_lk)
       const dim3 lgrid((unsigned)((P.R + pl.seats - 1) / pl.seats));
       if (h->hyper)
         hipLaunchKernelGGL((sa_lds_kernel<K, true>), lgrid, dim3(SMALL_TPB), (size_t)pl.total, s, P, betas, n_steps, prob_kind, pl, h->leaf_idx);
@@ -103,6 +100,24 @@ void launch_run_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, int pr
     else
       hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, false, false, false>), grid, dim3(SWT), 0, s, P, betas, n_steps, prob_kind, FwParams{}, 1, block0);
   }
+}
+
+// More dynamic LDS than the 64 KiB a kernel gets by default.  hipFuncAttributeMaxDynamicSharedMemorySize belongs to the
+// FUNCTION, process-wide, not to a handle: it is raised to what the device allows (the same value from every handle, so
+// two live handles with different plans cannot lower it under one another), at create, and a handle whose plan does not
+// fit -- or a runtime that refuses -- runs the HBM kernel instead.  0 = ready.
+template <int LOG2L, int K>
+int lds_kernel_prepare_lk(tnco_hip_ctx* h, int device_lds_bytes) {
+  if constexpr (LOG2L == 2) {
+    const void* kern = h->hyper ? (const void*)sa_lds_kernel<K, true> : (const void*)sa_lds_kernel<K, false>;
+    hipFuncAttributes fa{};
+    if (hipFuncGetAttributes(&fa, kern) != hipSuccess) { (void)hipGetLastError(); return 1; }
+    const int dyn = device_lds_bytes - (int)fa.sharedSizeBytes;
+    if (h->lds_plan.total > dyn) return 1;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess) { (void)hipGetLastError(); return 1; }
+    return 0;
+  }
+  return 1;
 }
 
 template <int LOG2L, int K>
@@ -241,6 +256,7 @@ void launch_fw_reslice_lk(tnco_hip_ctx* h, int prewalked) {
 
 template void launch_run_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const double*, int64_t, int, hipStream_t, int, int);
 template int run_blocks_per_cu_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*);
+template int lds_kernel_prepare_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, int);
 template void launch_build_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const BuildArgs&);
 template void launch_compare_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, const BuildArgs&, double, int32_t*);
 template void launch_fw_leaf_bits_lk<TNCO_INST_L, TNCO_INST_K>(tnco_hip_ctx*, uint32_t*, int32_t*);

@@ -103,6 +103,19 @@ int run_blocks_per_cu(tnco_hip_ctx* h) {
 #undef CALL_OCC
   return nb;
 }
+int lds_kernel_prepare(tnco_hip_ctx* h, int device_lds_bytes) {
+  int rc = 1;
+#define CALL_LDSP(LL, KK) rc = lds_kernel_prepare_lk<LL, KK>(h, device_lds_bytes)
+  DISPATCH_LK(h, CALL_LDSP)
+#undef CALL_LDSP
+  return rc;
+}
+// LDS a workgroup may use on this device (gfx950: 160 KiB per CU; a runtime that reports less for it is not believed).
+static int device_lds_bytes(const hipDeviceProp_t& prop) {
+  int v = (int)std::max<size_t>(prop.maxSharedMemoryPerMultiProcessor, prop.sharedMemPerBlock);
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) v = std::max(v, 160 * 1024);
+  return v;
+}
 void launch_build(tnco_hip_ctx* h, const BuildArgs& a) {
 #define CALL_BUILD(LL, KK) launch_build_lk<LL, KK>(h, a)
   DISPATCH_LK(h, CALL_BUILD)
@@ -1134,7 +1147,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
           // lanes per CU.)  x1.6 ... x2.8 the HBM kernel per replica, so a second round of blocks would lose.
           int best = 0;
           for (int b = 4; b >= 1 && best == 0; b >>= 1) {
-            const int seats = std::min(SMALL_TPB / 4, (160 * 1024 / b - pl.seat0) / pl.seat_stride);
+            const int seats = std::min(SMALL_TPB / 4, (device_lds_bytes(prop) / b - pl.seat0) / pl.seat_stride);
             if (seats > 0 && (R <= (int64_t)b * seats * prop.multiProcessorCount || b == 1)) { best = b * seats; pl.seats = seats; pl.blocks_per_cu = b; }
           }
 #ifdef TNCO_NO_SMALL_TREE
@@ -1152,7 +1165,7 @@ int tnco_hip_create(const tnco_hip_desc* d, tnco_hip_handle* out) {
             HIP_TRY(h->alloc(&h->leaf_idx, (int64_t)idx.size()));
             HIP_TRY(hipMemcpy(h->leaf_idx, idx.data(), idx.size() * 8, hipMemcpyHostToDevice));
             h->lds_plan = pl;
-            h->lds_tree = true;
+            h->lds_tree = lds_kernel_prepare(h, device_lds_bytes(prop)) == 0;  // (else: the HBM kernel below)
           }
         }
       }

@@ -168,12 +168,30 @@ def _is_loopback(addr: str) -> bool:
         return False
 
 
+def _single_node(addr: str) -> bool:
+    """True when every rank of the job is on this machine: a loopback address, a launcher that says so
+    (LOCAL_WORLD_SIZE == WORLD_SIZE: torchrun --standalone exports the node's FQDN as MASTER_ADDR), or a host name
+    that resolves to loopback addresses only."""
+    if _is_loopback(addr):
+        return True
+    lws, ws = os.environ.get("LOCAL_WORLD_SIZE"), os.environ.get("WORLD_SIZE")
+    if lws and ws and lws == ws:
+        return True
+    try:
+        found = {info[4][0] for info in socket.getaddrinfo(addr, None)}
+    except OSError:
+        return False
+    return bool(found) and all(_is_loopback(a) for a in found)
+
+
 def _encode(obj) -> bytes:
     """Fixed wire format of the side channel: JSON with tagged containers, numpy arrays as (dtype, shape, hex).
     Nothing received over a socket is ever unpickled."""
     def enc(x):
         if x is None or isinstance(x, (bool, str)):
             return x
+        if isinstance(x, np.bool_):
+            return bool(x)
         if isinstance(x, (int, np.integer)):
             return int(x)
         if isinstance(x, (float, np.floating)):
@@ -256,6 +274,8 @@ class SocketComm:
         addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
         port = int(port or os.environ.get("TNCO_COMM_SIDE_PORT") or int(os.environ.get("MASTER_PORT", "29533")) + 18)
         token = os.environ.get("TNCO_COMM_TOKEN", "")
+        if not token and _single_node(str(addr)):
+            addr = "127.0.0.1"  # (bind and connect on loopback, whatever name the launcher exported)
         if not token and not _is_loopback(str(addr)):
             raise RuntimeError(f"the side channel would listen on {addr}, which is not a loopback address: set TNCO_COMM_TOKEN "
                                "to a secret shared by the ranks of this job (the launch parameters alone can be guessed)")
@@ -361,7 +381,7 @@ class SocketComm:
             blob = _encode(parts)
             for k in range(1, self.world):
                 self._send_msg(self._peers[k], blob)
-            return parts
+            return _decode(blob)  # (what the other ranks see: the same types on every rank)
         self._send_msg(self._up, _encode(obj))
         return _decode(self._recv_msg(self._up))
 
