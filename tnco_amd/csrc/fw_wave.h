@@ -299,6 +299,10 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
     }
   };
   FWW_T(w1_);
+#if defined(TNCO_FWW_STOP) && TNCO_FWW_STOP == 1  // (diagnostic builds, tools/pmc_fw_insts.sh: the phases' instruction counts by difference)
+  leave_to_a();
+  return;
+#endif
   // ---- the node table; the too-wide tensors
   auto build_table = [&]() {
 #pragma unroll
@@ -370,6 +374,10 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
     }
   }
   FWW_T(w2_);
+#if defined(TNCO_FWW_STOP) && TNCO_FWW_STOP == 2
+  leave_to_a();
+  return;
+#endif
   // ---- get_slices (the ordering's keys and the node table are dead: their memory is the legs' now)
   __builtin_amdgcn_wave_barrier();
   const uint8_t* legs = P.blocks + r * P.RB + P.WOFF;
@@ -433,6 +441,11 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
     }
   }
   FWW_T(w3_);
+#if defined(TNCO_FWW_STOP) && TNCO_FWW_STOP == 3
+  if (lane == 0) rs->mtw = (int)rng.tw;  // (the fill above twisted words of the state array: nothing was consumed)
+  leave_to_a();
+  return;
+#endif
 #pragma unroll
   for (int step = T; step <= 32; step <<= 1) {
     uint64_t o[NPL];
@@ -704,6 +717,9 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
       uint64_t* prop = reinterpret_cast<uint64_t*>(const_cast<int16_t*>(sc.pos));
       if (g == 0 && w < LK) prop[w] = ns;
     }
+#if defined(TNCO_FWW_STOP) && TNCO_FWW_STOP == 4
+    unsup = true;  // (the full rebuild takes the proposal from here)
+#endif
     // the parents of the leaves from the node table, not from the replica's (cold) parent array: one round trip less
     TNCO_LDS volatile uint16_t* lparL = (TNCO_LDS volatile uint16_t*)U;  // [n] (the path masks' memory: cleared below)
     for (int i = lane; i < ni; i += GW) {
@@ -759,6 +775,9 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
     }
   }
   FWW_T(w5_);
+#if defined(TNCO_FWW_STOP) && TNCO_FWW_STOP == 5
+  return;
+#endif
   // ---- the re-priced costs: path masks cleared, arrival counters = internal children
   uint32_t startmask = 0;
   bool bad = false;
@@ -881,6 +900,9 @@ static __global__ __launch_bounds__(64) void fw_wave_kernel(const Params P, cons
     }
   }
   FWW_T(w6_);
+#if defined(TNCO_FWW_STOP) && TNCO_FWW_STOP == 6
+  return;
+#endif
   // ---- is the proposal worth its partial sums?  The rebuilt cache is kept only if its root sum is below the current one
   // (greedy/optimizer.hpp:371-374) -- about half of the proposals are not.  The new costs are powers of two >= 2^emin,
   // so every sum over them is a multiple of 2^emin, and one below 2^(emin + 53) is a double whatever the order it was

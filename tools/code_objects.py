@@ -77,6 +77,36 @@ def kernel_table(elf: bytes) -> dict[str, dict]:
     return table
 
 
+def short_kernel_name(demangled: str) -> str:
+    """`void tnco::sa_run_kernel<2, 3, false>(tnco::Params, ...)` -> `sa_run_kernel<2, 3, false>`: what a rocprofv3 trace
+    row and a code object's symbol have in common."""
+    s = demangled.strip().strip('"')
+    depth, cut = 0, len(s)
+    for i, ch in enumerate(s):  # (the argument list opens at the first "(" outside the template brackets)
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0 and not s.startswith("(anonymous namespace)", i):
+            cut = i
+            break
+    s = s[:cut]
+    for junk in ("void ", "tnco::", "(anonymous namespace)::"):
+        s = s.replace(junk, "")
+    return s.replace(".kd", "").strip()
+
+
+def kernel_names(lib: pathlib.Path = LIB) -> set[str]:
+    """Short names of every gfx950 kernel the library ships."""
+    mangled = set()
+    for elf in code_objects(lib):
+        mangled.update(kernel_table(elf))
+    import shutil
+    filt = shutil.which("c++filt") or str(LLVM / "llvm-cxxfilt")
+    out = subprocess.run([filt], input="\n".join(sorted(mangled)), capture_output=True, text=True).stdout
+    return {short_kernel_name(ln) for ln in out.splitlines() if ln.strip()}
+
+
 def waves_per_simd(vgprs: int) -> int:
     """gfx950: 512 registers per lane and SIMD (VGPRs + AGPRs, one file), allocated in blocks of 8, at most 8 wavefronts."""
     return min(8, 512 // max(8, -(-vgprs // 8) * 8))
