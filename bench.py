@@ -97,13 +97,13 @@ def algorithmic_bytes_per_move(W: int, a: float, q: float) -> float:
 
 
 def algorithmic_bytes_per_move_fw(W: int, a: float, q: float) -> float:
-    """The same move of the finite-width optimizer (DESIGN.md section 6): + the slices mask read
+    """The same move of the finite-width optimizer (DESIGN.md section 3.3): + the slices mask read
     (8W, finite_width/greedy/optimizer.hpp:177,191-193) + the cached width written on accept (4a, :216)."""
     return algorithmic_bytes_per_move(W, a, q) + 8 * W + 4 * a
 
 
 def compulsory_bytes_per_move(W: int, a: float, q: float, depth: float, fw: bool) -> dict:
-    """HBM traffic per move evaluation the sweep kernel AS BUILT cannot avoid (DESIGN.md section 5): every read is a
+    """HBM traffic per move evaluation the sweep kernel AS BUILT cannot avoid (DESIGN.md section 3.1): every read is a
     128-byte line (profiles/r04_pmc_calibration.md), dirty data leaves the L2 in 64-byte sectors (a 4-byte update of a
     parent link: 32).  The working set (65 536 replicas x ~100 KB) is hundreds of times the L2, so every node first
     met is fetched and every line a move dirties is written back once.
@@ -127,7 +127,7 @@ def compulsory_bytes_per_move(W: int, a: float, q: float, depth: float, fw: bool
 
 
 def algorithmic_bytes_per_reslice_repriced(n: int) -> float:
-    """The re-slice in its re-priced form (DESIGN.md section 2: no leg mask is read): the width cache (4N) and
+    """The re-slice in its re-priced form (DESIGN.md section 3.3: no leg mask is read): the width cache (4N) and
     node links (12 per internal node) read by get_slices' ordering, and per internal node the old cost (8) and
     the two children's partial sums (16) read by the re-pricing.  The (cost, partial) pairs a KEPT re-slice
     writes back (16 per node, 25-55 % of the re-slices) and the too-wide tensors' masks are left out."""

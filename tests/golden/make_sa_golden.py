@@ -3,7 +3,7 @@
 
     python tests/golden/make_sa_golden.py
 
-They do not pin the oracle to the reference (nothing in this image can: DESIGN.md section 3) -- they
+They do not pin the oracle to the reference (nothing in this image can: DESIGN.md section 5) -- they
 pin BOTH the oracle and the HIP path to the state of the round they were generated in, so that a
 later change to either that alters a single bit of a tree, a cost or the PRNG stream is caught even
 if the two were changed together.  A case = inputs by recipe (synthetic generator + seeds, all in

@@ -1,6 +1,6 @@
 """The compiler-dependent properties the measured numbers lean on, asserted on the gfx950 code objects inside the
 libtnco_hip.so of the tree (tools/code_objects.py; no GPU, a few seconds): register budgets -> wavefronts per SIMD,
-scratch, and the shape of the sweep kernels' main loop -- ONE landing fence (DESIGN.md section 2.1: "the single
+scratch, and the shape of the sweep kernels' main loop -- ONE landing fence (DESIGN.md section 3.1: "the single
 s_waitcnt vmcnt of the loop"), no scratch access inside it.  A toolchain bump that breaks one of them fails here, not
 in a benchmark."""
 import sys

@@ -554,3 +554,22 @@ def test_caterpillar_trees_deeper_than_the_build_kernels_lds_stack(core, oracle_
     seeds = H.replica_seeds(6, S=11)
     links = np.repeat(tree[None], len(seeds), axis=0)
     _run_both(core, oracle_lib, prob, seeds, H.linear_betas(0, 30, 6), links=links)
+
+
+def test_general_cost_model_on_22_mask_words(core, oracle_lib):
+    """dims = 3 on a 900-leaf network: the cost-table kernels at 8 lanes x 3 words, full wavefronts."""
+    prob = H.regular_problem(900, graph_seed=900 % 89, degree=3)
+    prob.dims = 3
+    R = 4200
+    seeds = H.replica_seeds(R, S=900)
+    links = core.greedy_trees(prob.ts_inds, prob.n_inds, seeds)
+    betas = H.linear_betas(0, 60, 10)
+    with core.BatchedOptimizer(prob.leaf_masks, links, seeds, n_inds=prob.n_inds, dims=3) as gpu:
+        gpu.run(betas)
+        tot, mn = gpu.costs()
+        for r in [0, 63, R // 2, R - 1]:
+            o = H.make_oracle(oracle_lib, prob, links[r], seeds[r])
+            o.run(oracle_lib.PROB_MH, betas)
+            H.assert_replica_equal(gpu, r, o)
+            assert tot[r] == o.total_cost and mn[r] == o.min_total_cost
+        assert gpu.validate() == (0, -1)

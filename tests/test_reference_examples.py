@@ -4,7 +4,7 @@ build's restatements of the same interfaces, doctest style: the statements of an
 with the reference's names bound to the build's functions, and every checked expression must print
 what the reference's docstring says.  These are the only worked input / output pairs the reference
 holds for the hot path's host side; the optimizer's update() itself has none
-(DESIGN.md section 3: parity unpinned by reference execution)."""
+(DESIGN.md section 5: parity unpinned by reference execution)."""
 import json
 from pathlib import Path
 

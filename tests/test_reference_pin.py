@@ -4,7 +4,7 @@ Optimizer::update / cost models / get_slices against the REAL reference module, 
 `make -C oracle ref_core` compiles /root/reference/include/tnco/main.cpp where it lies into oracle/_ref/ -- ONLY when a
 genuine <boost/dynamic_bitset.hpp> is on the compiler's system include path (oracle/Makefile; this image has none,
 and no stand-in header is written: a module built against one pins nothing).  Without that module every test here is
-SKIPPED, and DESIGN.md section 3 keeps saying "parity unpinned by reference execution".
+SKIPPED, and DESIGN.md section 5 keeps saying "parity unpinned by reference execution".
 
 What is compared after every chunk of sweeps, bit for bit: the links of ctree and min_ctree, every leg mask, the text of
 the mt19937 state, log2 of total_cost / min_total_cost (doubles), slices / min_slices -- on the cases of SURVEY 8(c)

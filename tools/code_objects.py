@@ -2,7 +2,7 @@
 
     python tools/code_objects.py              # budgets + the sweep loop's wait / scratch check, a few seconds
 
-The measured numbers lean on three things the source cannot promise (DESIGN.md section 2): the register budgets that set
+The measured numbers lean on three things the source cannot promise (DESIGN.md section 3.1): the register budgets that set
 the wavefronts per SIMD (168 VGPRs -> 3 for the headline kernel; fw_wave_kernel lost 20 % twice at 129 instead of 127),
 the ONE landing fence of the sweep loop (a second `s_waitcnt vmcnt` in the loop body serialises the walk of sixteen
 replicas), and no scratch access inside that loop.  tests/test_build_guards.py asserts them on the library in the tree:

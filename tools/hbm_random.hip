@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void move_pattern_kernel(uint8_t* buf, uint64_
 
 // The memory side of one move of the FINITE-WIDTH sweep kernel in the split layout (headers 32 B each in one array, legs
 // 128 B each in another): read A's header, C's header (CHDR = 1; 0: a parent that carried its children's partial sums would
-// make this read unnecessary -- DESIGN section 9, "next"), C's legs line; write B's header (a 32-byte partial sector) and, for
+// make this read unnecessary -- profiles/design_notes_r01_r05.md section 9, "next"), C's legs line; write B's header (a 32-byte partial sector) and, for
 // an accepted move (ACC of 4), B's legs line and two 4-byte parent words.
 template <int UNROLL, int ACC, int CHDR>
 __global__ __launch_bounds__(256) void fw_pattern_kernel(uint8_t* hdr, uint8_t* legs, uint64_t n_nodes, int iters, uint64_t* sink) {
