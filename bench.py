@@ -533,16 +533,19 @@ def calibration(local_rank):
     try:
         L = ctypes.CDLL(str(ROOT / "tools" / "libbox_probe.so"))
         L.box_probe.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
-        out = (ctypes.c_double * 3)()
+        out = (ctypes.c_double * 5)()
         t0 = time.perf_counter()
         rc = L.box_probe(local_rank, 8.0, out)
         if rc:
             return {"error": f"box_probe: hip error {rc}"}
         return {"random_lines_per_s": out[0], "move_pattern_per_s": out[1], "stream_read_GBs": out[2] / 1e9,
+                "valu_wave_insts_per_s_per_simd": out[3], "dependent_load_ns": out[4] * 1e9,
                 "seconds": time.perf_counter() - t0,
                 "what": "tools/box_probe.hip in this process, 8 GiB working set: random 128-byte lines read (4 lanes per line, 4 in "
                         "flight per group); the memory side of one infinite-memory move alone (2 random lines read, 1 header "
-                        "sector written, 3 of 4 moves the rest of the line + two 4-byte parent words); streaming read"}
+                        "sector written, 3 of 4 moves the rest of the line + two 4-byte parent words); streaming read; 32-bit shift-add "
+                        "wave-instructions per second and SIMD under a full VALU load (clock / 4); one lane's dependent loads of cold lines on "
+                        "an idle chip"}
     except OSError as e:
         return {"error": f"{type(e).__name__}: {e}"}
 
@@ -914,7 +917,8 @@ def main() -> None:
                 out["calibration"]["value_over_move_pattern"] = (results["im"]["moves"] / results["im"]["dt"] / calib["move_pattern_per_s"]
                                                                  if "im" in results else None)
                 again = calibration(local_rank)
-                out["calibration"]["after"] = {k: again.get(k) for k in ("random_lines_per_s", "move_pattern_per_s", "stream_read_GBs", "error")
+                out["calibration"]["after"] = {k: again.get(k) for k in ("random_lines_per_s", "move_pattern_per_s", "stream_read_GBs",
+                                                                          "valu_wave_insts_per_s_per_simd", "dependent_load_ns", "error")
                                                if again.get(k) is not None}
         print(json.dumps(out), flush=True)
     for leg in objs.values():

@@ -7,6 +7,8 @@
 //   [1] the memory side of one infinite-memory move and nothing else: two random lines read, one header sector
 //       written, on 3 of 4 moves the rest of the line and two 4-byte parent words       (moves/s)
 //   [2] a streaming read of the same buffer                                              (bytes/s)
+//   [3] VALU wave-instructions per second and SIMD under a full load (the clock the chip holds, / 4)
+//   [4] seconds per dependent load of a cold line on an idle chip
 // bench.py divides its request rate by [0] and its move rate by [1] of the box it runs on.
 //
 //   hipcc -O3 --offload-arch=gfx950 -shared -fPIC -o tools/libbox_probe.so tools/box_probe.hip
@@ -85,9 +87,34 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const uint4* buf, uint
   if (acc == 0x1234567) sink[0] = acc;
 }
 
+// [3] the clock the chip holds under a full VALU load: every wavefront runs shift-adds (8 registers per lane, one
+// v_lshl_add_u32 each per round), 8 wavefronts per SIMD -- wave-instructions retired per second and SIMD = clock / 4 when the VALU is
+// saturated (a wave64 instruction holds its SIMD for four clocks).
+__global__ __launch_bounds__(256) void valu_kernel(uint32_t* sink, int iters, uint32_t seed) {
+  uint32_t a[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = seed + threadIdx.x * 8 + k;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = (a[k] << 1) + a[(k + 1) & 7];  // (one v_lshl_add_u32 each)
+  }
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s ^= a[k];
+  if (s == 0x12345u) sink[0] = s;
+}
+
+// [4] the latency of a dependent load from cold memory on an otherwise idle chip: ONE lane chases pointers through the
+// buffer (every hop a random 128-byte line of 8 GiB).
+__global__ void chase_kernel(const uint64_t* buf, uint64_t n_lines, int hops, uint64_t* sink) {
+  uint64_t x = 12345;
+  for (int h = 0; h < hops; ++h) x = mix(x + buf[(x % n_lines) * 16]);
+  sink[1] = x;
+}
+
 }  // namespace
 
-// out[0..2] as in the header; returns 0, or a hipError_t.
+// out[0..4] as in the header ([3] VALU wave-instructions / s / SIMD, [4] seconds per dependent load); returns 0, or a hipError_t.
 extern "C" int box_probe(int device, double gib, double* out) {
 #define TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { if (buf) (void)hipFree(buf); if (sink) (void)hipFree(sink); return (int)e_; } } while (0)
   uint8_t* buf = nullptr;
@@ -105,6 +132,28 @@ extern "C" int box_probe(int device, double gib, double* out) {
   const int blocks = prop.multiProcessorCount * 8;  // 8 wavefronts per SIMD
   const uint64_t n_lines = bytes / 128;
   float ms = 0;
+  {  // [3], [4]
+    const int simds = prop.multiProcessorCount * 4, iters = 1 << 15;
+    double best = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+      TRY(hipEventRecord(a));
+      valu_kernel<<<prop.multiProcessorCount * 8, 256>>>(reinterpret_cast<uint32_t*>(sink), iters, (uint32_t)rep);
+      TRY(hipEventRecord(b));
+      TRY(hipEventSynchronize(b));
+      TRY(hipEventElapsedTime(&ms, a, b));
+      // wave-instructions: blocks x 4 wavefronts x iters x 8 shift-adds
+      const double rate = (double)prop.multiProcessorCount * 8 * 4 * (double)iters * 8.0 / ((double)ms * 1e-3) / simds;
+      if (rep > 0 && rate > best) best = rate;
+    }
+    out[3] = best;
+    const int hops = 4096;
+    TRY(hipEventRecord(a));
+    chase_kernel<<<1, 1>>>(reinterpret_cast<const uint64_t*>(buf), n_lines, hops, sink);
+    TRY(hipEventRecord(b));
+    TRY(hipEventSynchronize(b));
+    TRY(hipEventElapsedTime(&ms, a, b));
+    out[4] = (double)ms * 1e-3 / hops;
+  }
   for (int which = 0; which < 3; ++which) {
     double best = 0;
     for (int rep = 0; rep < 3; ++rep) {  // (the first repetition also warms the clocks up)

@@ -45,6 +45,11 @@ def code_objects(lib: pathlib.Path = LIB) -> list[bytes]:
         fat = pathlib.Path(td) / "fatbin"
         subprocess.check_call([str(LLVM / "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", str(lib), str(fat)])
         d = fat.read_bytes()
+    return bundle_objects(d)
+
+
+def bundle_objects(d: bytes) -> list[bytes]:
+    """The gfx950 ELF images inside clang offload bundles found in `d` (a .hip_fatbin section, or a --cuda-device-only object)."""
     out = []
     for m in re.finditer(MAGIC, d):
         o = m.start()
