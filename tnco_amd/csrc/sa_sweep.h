@@ -616,9 +616,14 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       // both candidate (D, E) assignments evaluated at once:
       //   cand0: D = child0, E = child1;  cand1: D = child1, E = child0
       // new legs of B: (D ^ C) | hyper_A | hyper_B   (optimizer.hpp:147)
+      // PICK_FIRST (round 6; the finite-width moves, which are bound by their instruction stream): decide (D, E) from the
+      // two intersect flags first, then price the ONE chosen candidate -- 786 -> 722 VALU instructions per iteration for
+      // one more dependent DPP sum, +2.5 % on config 5 (profiles/experiments_r06.md).  The infinite-memory instantiations
+      // (bound by memory requests; the headline one at the edge of three wavefronts per SIMD) keep pricing both at once.
+      constexpr bool PICK_FIRST = !GENERIC && FW;
       bool inter0, inter1;
       int pcA0 = 0, pcB0 = 0, pcA1 = 0, pcB1 = 0;
-      if constexpr (!GENERIC) {
+      if constexpr (!GENERIC && !PICK_FIRST) {
         // (finite width: both costs are over in1 | in2 | slices, finite_width/cost_model/simple.hpp:139-144;
         // sl is zero otherwise)
         uint32_t w0 = mpopc<K>(mor<K>(mor<K>(mor<K>(mxor<K>(m0, mC), hy), m1), sl)) |
@@ -648,6 +653,11 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       const M newB = mor<K>(mxor<K>(mD, mC), hy);
       const double pD = pick0 ? p0 : p1, pE = pick0 ? p1 : p0;
       const int E = pick0 ? br : bl;
+      if constexpr (PICK_FIRST) {  // the chosen candidate's two costs: A over newB | E | slices, B over D | C | slices
+        const uint32_t w = gsum<LOG2L>(mpopc<K>(mor<K>(mor<K>(newB, mE), sl)) | (mpopc<K>(mor<K>(mor<K>(mD, mC), sl)) << 13));
+        pcA0 = pcA1 = (int)(w & 0x1fffu);
+        pcB0 = pcB1 = (int)((w >> 13) & 0x1fffu);
+      }
 
       // finite width (greedy/optimizer.hpp:174-190): the width of the new B (cached on accept) and
       // its width without the sliced indices, which gates the move
@@ -655,7 +665,13 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       bool fits = true;
       if constexpr (FW) {
         double sliced_width;
-        if (!GENERIC || (F.log2dims == nullptr && P.sparse == nullptr)) {  // log2(d) * count (simple.hpp:43-47)
+        if constexpr (!GENERIC) {
+          // log2(d) * count (simple.hpp:43-47) with d = 2^k: whole numbers, exact in either width type, and
+          // `k * count <= max_width` is a comparison of integers
+          const uint32_t x = gsum<LOG2L>(mpopc<K>(newB) | (mpopc<K>(mandn<K>(newB, sl)) << 16));
+          new_width_B = (double)(log2d * (int)(x & 0xffffu));
+          sliced_width = (double)(log2d * (int)(x >> 16));
+        } else if (F.log2dims == nullptr && P.sparse == nullptr) {
           const uint32_t x = gsum<LOG2L>(mpopc<K>(newB) | (mpopc<K>(mandn<K>(newB, sl)) << 16));
           new_width_B = fw_wr(F, F.log2d * (double)(x & 0xffffu));
           sliced_width = fw_wr(F, F.log2d * (double)(x >> 16));

@@ -28,11 +28,17 @@ def main():
         for name, meta in co.kernel_table(elf).items():
             if "sa_run_kernel" not in name:
                 continue
-            rep = co.main_loop_report(co.disassemble(elf, name))
+            ins = co.disassemble(elf, name)
+            rep = co.main_loop_report(ins)
+            t, a = max(co.loops(ins), key=lambda x: x[1] - x[0])  # the outer loop: the widest backward branch
+            outer = [i for i in ins if t <= i[0] <= a]
+            kinds = {"VALU": "v_", "SALU": "s_", "LDS": "ds_", "VMEM": ("global_", "buffer_", "scratch_")}
+            mix = {k: sum(1 for i in outer if i[1].startswith(v)) for k, v in kinds.items()}
             print(f"VGPRs {meta['vgpr_count']}  spilled {meta['vgpr_spill_count']}  scratch {meta['private_segment_fixed_size']} B/lane  LDS {meta['group_segment_fixed_size']} B  "
                   f"waves/SIMD {co.waves_per_simd(meta['vgpr_count'])}")
             print(f"loop: {rep['instructions']} instructions, fences {rep['fences']}, vm waits {len(rep['vm_waits'])}, scratch in loop {len(rep['scratch_in_loop'])}, "
                   f"loads {rep['loads']}, stores {rep['stores']}")
+            print(f"outer loop (static): {len(outer)} instructions: {mix}")
 
 
 if __name__ == "__main__":
