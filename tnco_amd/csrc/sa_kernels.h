@@ -215,6 +215,15 @@ struct View {
     }
     return r;
   }
+  // mask_staged into registers that live across iterations: only the loads -- a word that is not loaded (beyond W of an
+  // internal node) keeps what it held, which is the zero it started from or the zero of a leaf row's padding
+  __device__ __forceinline__ void mask_stage_into(Mask<K>& r, int x) const {
+    const bool leaf = x < n;
+    const uint64_t* s = leaf ? leafmask + (int64_t)x * LK : words(x);
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (leaf || widx(k) < W) r.w[k] = s[widx(k)];
+  }
   __device__ __forceinline__ void set_mask(int p, const Mask<K>& v) const {
     uint64_t* s = words(p);
 #pragma unroll

@@ -456,8 +456,12 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
   [[maybe_unused]] int wB = 0, raW = 0, rnW = 0;  // finite width: the spare header word (cached width) of B, A, parent(A)
   double ccB = 0, partB = 0, total = 0, beta = 0;
   // (hyper-indices: hB / hA = the OWN legs of B / A)
-  M m0 = mzero<K>(), m1 = mzero<K>(), hB = mzero<K>();
-  double p0 = 0, p1 = 0;
+  // The legs of B's two children, by ROLE, not by slot: mP = the child the walk came up through (after a move: the old B,
+  // with its new legs), mO = the other one; `pl`: mP is the LEFT child (child 0).  The slots only matter to the (D, E)
+  // rule -- cand0 is D = child0 -- so a move ends with two plain assignments instead of a left / right select of four masks.
+  M mP = mzero<K>(), mO = mzero<K>(), hB = mzero<K>();
+  bool pl = true;
+  double pP = 0, pO = 0;  // partial costs of the two children, by role like their legs
   // ---- operands of the coming moves (landed in earlier iterations) -----------
   int raL = -1, raR = -1, raP = -1;  // header of A
   double raC = 0;
@@ -467,6 +471,22 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
   double pC = 0;
   int step = 0;
   int state = S_BEGIN;
+
+  // What the store phase needs (written by END / MOVE, read behind the fence under the same conditions) and the staging
+  // registers of the loads live ACROSS iterations: an iteration that does not write them keeps stale values nobody
+  // reads, instead of re-initialising some forty registers per iteration (a third of this loop's VALU instructions were
+  // moves).  The words of a mask beyond W are never loaded for an internal node and zero in the leaf table: they stay
+  // zero.  gMp alone is reset: a leaf's partial cost is the zero it starts from.
+  // (B's record is written from the carried B, A, bl, br, ccB, partB, wB themselves: the B <- A shift follows the stores)
+  int stC = 0, stE = 0;
+  [[maybe_unused]] double stW64 = 0;
+  int x_al = 0, x_ar = 0, x_aP = -1;
+  double x_ccA = 0, x_partA = 0, x_pCcur = 0;
+  int gL = -1, gR = -1, gP = -1;
+  [[maybe_unused]] int gW = 0;
+  double gC = 0;
+  M gM = mzero<K>(), gH = mzero<K>();
+  uint32_t gXlo = 0, gXhi = 0;
 
   TNCO_PROF_DECL;
   for (;;) {
@@ -479,19 +499,11 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
     TNCO_PROF_T(1);
 
     // what the store phase needs
-    bool acc = false, did_move = false, did_end = false, improved = false, b_is_left_of_a = false;
-    int stB = 0, stA = -1, stC = 0, stE = 0, stL = 0, stR = 0;
-    [[maybe_unused]] int stW = 0;
-    [[maybe_unused]] double stW64 = 0;
-    double stCC = 0, stPart = 0;
-    int x_al = 0, x_ar = 0, x_aP = -1;
-    double x_ccA = 0, x_partA = 0, x_pCcur = 0;
+    bool acc = false, did_move = false, did_end = false, improved = false;
 
     if (state == S_END) {
       // ---- B is the root: end of sweep (optimizer.hpp:194-201) ------------
       did_end = true;
-      stB = B; stA = -1; stL = bl; stR = br; stCC = ccB; stPart = partB;
-      if constexpr (FW) stW = wB;
       // (finite width, a launch that ends in a re-slicing sweep: fw_reslice_kernel closes that sweep)
       const bool close_sweep = !FW || tail_last != 0 || step != nsteps32 - 1;
       if (close_sweep && partB < cold.min_cost) {
@@ -576,28 +588,22 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
     TNCO_PROF_F(2);
     // ======================= requests (staging registers) ====================
     // Nothing below reads these registers before the landing fence.
-    int gL = -1, gR = -1, gP = -1;
-    [[maybe_unused]] int gW = 0;
-    double gC = 0;
     if (hN >= 0) {
       const NodeRec* q = v.hdr(hN);
       gL = q->left; gR = q->right; gP = q->parent; gC = q->ccost;
       if constexpr (FW) gW = q->pad;
     }
-    M gM = mzero<K>();
     double gMp = 0;
     if (x1 >= 0) {
-      gM = v.mask_staged(x1);
+      v.mask_stage_into(gM, x1);
       if (x1 >= n) gMp = v.hdr(x1)->partial;
     }
-    uint32_t gXlo = 0, gXhi = 0;
     if (xa != nullptr) {
       gXlo = xa[0];
       gXhi = xa[1];
     }
-    M gH = mzero<K>();  // own legs of node yN
-    if constexpr (HYPER) {
-      if (yN >= 0) gH = v.mask_staged(yN);
+    if constexpr (HYPER) {  // own legs of node yN
+      if (yN >= 0) v.mask_stage_into(gH, yN);
     }
     if (rng.room()) rng.request();
     TNCO_PROF_F(3);
@@ -612,7 +618,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
 
       // ---- one move evaluation (optimizer.hpp:117-192) -----------------------
       // hyper[A] | hyper[B] (optimizer.hpp:145-147); derived: hyper[B] = B & c0 & c1, hyper[A] = A & B & C
-      const M hy = HYD ? mand<K>(hB, mor<K>(mand<K>(hA, mC), mand<K>(m0, m1))) : mzero<K>();
+      const M hy = HYD ? mand<K>(hB, mor<K>(mand<K>(hA, mC), mand<K>(mP, mO))) : mzero<K>();
       // both candidate (D, E) assignments evaluated at once:
       //   cand0: D = child0, E = child1;  cand1: D = child1, E = child0
       // new legs of B: (D ^ C) | hyper_A | hyper_B   (optimizer.hpp:147)
@@ -621,42 +627,44 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       // one more dependent DPP sum, +2.5 % on config 5 (profiles/experiments_r06.md).  The infinite-memory instantiations
       // (bound by memory requests; the headline one at the edge of three wavefronts per SIMD) keep pricing both at once.
       constexpr bool PICK_FIRST = !GENERIC && FW;
-      bool inter0, inter1;
-      int pcA0 = 0, pcB0 = 0, pcA1 = 0, pcB1 = 0;
+      // (the candidates by role: P = D is the path child, O = D is the other child; cand0 of the reference is D = child0)
+      bool interP, interO;
+      int pcAP = 0, pcBP = 0, pcAO = 0, pcBO = 0;
       if constexpr (!GENERIC && !PICK_FIRST) {
         // (finite width: both costs are over in1 | in2 | slices, finite_width/cost_model/simple.hpp:139-144;
         // sl is zero otherwise)
-        uint32_t w0 = mpopc<K>(mor<K>(mor<K>(mor<K>(mxor<K>(m0, mC), hy), m1), sl)) |
-                      (mpopc<K>(mor<K>(mor<K>(m0, mC), sl)) << 13) | ((mnonzero<K>(mand<K>(m0, mC)) ? 1u : 0u) << 26);
-        uint32_t w1 = mpopc<K>(mor<K>(mor<K>(mor<K>(mxor<K>(m1, mC), hy), m0), sl)) |
-                      (mpopc<K>(mor<K>(mor<K>(m1, mC), sl)) << 13) | ((mnonzero<K>(mand<K>(m1, mC)) ? 1u : 0u) << 26);
-        w0 = gsum<LOG2L>(w0);
-        w1 = gsum<LOG2L>(w1);
-        inter0 = (w0 >> 26) != 0;
-        inter1 = (w1 >> 26) != 0;
-        pcA0 = (int)(w0 & 0x1fffu); pcB0 = (int)((w0 >> 13) & 0x1fffu);
-        pcA1 = (int)(w1 & 0x1fffu); pcB1 = (int)((w1 >> 13) & 0x1fffu);
+        uint32_t wP = mpopc<K>(mor<K>(mor<K>(mor<K>(mxor<K>(mP, mC), hy), mO), sl)) |
+                      (mpopc<K>(mor<K>(mor<K>(mP, mC), sl)) << 13) | ((mnonzero<K>(mand<K>(mP, mC)) ? 1u : 0u) << 26);
+        uint32_t wO = mpopc<K>(mor<K>(mor<K>(mor<K>(mxor<K>(mO, mC), hy), mP), sl)) |
+                      (mpopc<K>(mor<K>(mor<K>(mO, mC), sl)) << 13) | ((mnonzero<K>(mand<K>(mO, mC)) ? 1u : 0u) << 26);
+        wP = gsum<LOG2L>(wP);
+        wO = gsum<LOG2L>(wO);
+        interP = (wP >> 26) != 0;
+        interO = (wO >> 26) != 0;
+        pcAP = (int)(wP & 0x1fffu); pcBP = (int)((wP >> 13) & 0x1fffu);
+        pcAO = (int)(wO & 0x1fffu); pcBO = (int)((wO >> 13) & 0x1fffu);
       } else {
-        const uint32_t w = gsum<LOG2L>((mnonzero<K>(mand<K>(m0, mC)) ? 1u : 0u) |
-                                       ((mnonzero<K>(mand<K>(m1, mC)) ? 1u : 0u) << 8));
-        inter0 = (w & 0xffu) != 0;
-        inter1 = (w >> 8) != 0;
+        const uint32_t w = gsum<LOG2L>((mnonzero<K>(mand<K>(mP, mC)) ? 1u : 0u) |
+                                       ((mnonzero<K>(mand<K>(mO, mC)) ? 1u : 0u) << 8));
+        interP = (w & 0xffu) != 0;
+        interO = (w >> 8) != 0;
       }
       bool pick0;  // true: (D, E) = (child0, child1)   -- get_ctree_nn, optimize/optimizer.hpp:128-144
-      if (disable_shared || (inter0 && inter1)) {
+      if (disable_shared || (interP && interO)) {
         pick0 = (rng.next() & 1u) != 0;  // optimize/optimizer.hpp:139
         if (lane0) cold.n_rpick = cold.n_rpick + 1;
       } else {
-        pick0 = inter0;
+        pick0 = pl ? interP : interO;  // (inter0: child0 intersects C)
       }
-      const M mD = msel<K>(pick0, m0, m1), mE = msel<K>(pick0, m1, m0);
+      const bool pickP = pick0 == pl;  // D is the path child
+      const M mD = msel<K>(pickP, mP, mO), mE = msel<K>(pickP, mO, mP);
       const M newB = mor<K>(mxor<K>(mD, mC), hy);
-      const double pD = pick0 ? p0 : p1, pE = pick0 ? p1 : p0;
+      const double pD = pickP ? pP : pO, pE = pickP ? pO : pP;
       const int E = pick0 ? br : bl;
       if constexpr (PICK_FIRST) {  // the chosen candidate's two costs: A over newB | E | slices, B over D | C | slices
         const uint32_t w = gsum<LOG2L>(mpopc<K>(mor<K>(mor<K>(newB, mE), sl)) | (mpopc<K>(mor<K>(mor<K>(mD, mC), sl)) << 13));
-        pcA0 = pcA1 = (int)(w & 0x1fffu);
-        pcB0 = pcB1 = (int)((w >> 13) & 0x1fffu);
+        pcAP = pcAO = (int)(w & 0x1fffu);
+        pcBP = pcBO = (int)((w >> 13) & 0x1fffu);
       }
 
       // finite width (greedy/optimizer.hpp:174-190): the width of the new B (cached on accept) and
@@ -683,8 +691,8 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       }
       double nA, nB;  // optimizer.hpp:152-155
       if constexpr (!GENERIC) {
-        nA = pow2_cost(log2d * (pick0 ? pcA0 : pcA1), 0);
-        nB = pow2_cost(log2d * (pick0 ? pcB0 : pcB1), 0);
+        nA = pow2_cost(log2d * (pickP ? pcAP : pcAO), 0);
+        nB = pow2_cost(log2d * (pickP ? pcBP : pcBO), 0);
       } else {
         nA = generic_cost_t<LOG2L, K>(P, tabs, mor<K>(mor<K>(newB, mE), sl), lig, gbase);
         nB = generic_cost_t<LOG2L, K>(P, tabs, mor<K>(mor<K>(mD, mC), sl), lig, gbase);
@@ -700,12 +708,11 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
 
       double pEcur = pE, pCcur = pC;  // partials of B's / A's other child after the move
       M mBnow, mX;                     // legs of B / of A's other child after the move
-      stB = B; stA = A; stC = C; stE = E;
-      if constexpr (FW) stW = wB;
+      stC = C; stE = E;
       if (acc) {
         ++n_acc;
         if constexpr (FW) {  // :216  width_B = new_width_B
-          if (F.width_f32) stW = __float_as_int((float)new_width_B);
+          if (F.width_f32) wB = __float_as_int((float)new_width_B);
           stW64 = new_width_B;
         }
         // Tree::swap_with_nn(E): include/tnco/tree.hpp:176-184
@@ -720,19 +727,17 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
         mBnow = newB;
         mX = mE;
       } else {
-        mBnow = HYD ? hB : mxor<K>(m0, m1);
+        mBnow = HYD ? hB : mxor<K>(mP, mO);
         mX = mC;
       }
       // :185-188
       partB = rnd_cost(rnd_cost(pD + pEcur, f32) + ccB, f32);
       const double partA = rnd_cost(rnd_cost(partB + pCcur, f32) + ccA, f32);
       // what B's record becomes (written in the store phase); the B <- A shift (:191) follows it
-      stL = bl; stR = br; stCC = ccB; stPart = partB;
-      b_is_left_of_a = c_is_right;
       x_al = al; x_ar = ar; x_aP = aP; x_ccA = ccA; x_partA = partA; x_pCcur = pCcur;
       // :191, legs only (registers: the scalars follow after the store phase).  B becomes a child
       // of the next B: its legs, and those of A's other child, are what the next move starts from.
-      if (c_is_right) { m0 = mBnow; m1 = mX; } else { m1 = mBnow; m0 = mX; }
+      mP = mBnow; mO = mX; pl = c_is_right;
     }
 
     TNCO_PROF_T(2);
@@ -770,18 +775,18 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       }
       v.lpar = lpar();
       if (master) {
-        v.set_parent_group(stC, stB);
-        v.set_parent_group(stE, stA);
-        v.set_mask(stB, msel<K>(b_is_left_of_a, m0, m1));  // :170 (accepted: B's legs are the new legs)
+        v.set_parent_group(stC, B);
+        v.set_parent_group(stE, A);
+        v.set_mask(B, mP);  // :170 (accepted: B's legs are the new legs -- B is the path child of the next level)
       }
     }
     if (did_move || did_end) {
       if (lane0) {
         NodeRec o;
-        o.left = stL; o.right = stR; o.parent = stA; o.pad = FW ? stW : 0; o.ccost = stCC; o.partial = stPart;
-        *v.hdr(stB) = o;
+        o.left = bl; o.right = br; o.parent = A; o.pad = FW ? wB : 0; o.ccost = ccB; o.partial = partB;  // (END: A == -1)
+        *v.hdr(B) = o;
         if constexpr (FW) {
-          if (did_move && acc && !F.width_f32) F.width64[(int64_t)rng.r32 * N + stB] = stW64;
+          if (did_move && acc && !F.width_f32) F.width64[(int64_t)rng.r32 * N + B] = stW64;
         }
       }
       // Experiment (off): HBM writes whole 64-byte pieces and a shorter write is a read-modify-write
@@ -790,7 +795,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       // hold it, so the short write never reaches HBM on its own; the extra store only costs issue.
 #ifdef TNCO_FIRST64
       if (!(did_move && acc))
-        v.set_mask_first(stB, did_move ? msel<K>(b_is_left_of_a, m0, m1) : (HYD ? hB : mxor<K>(m0, m1)));
+        v.set_mask_first(B, did_move ? mP : (HYD ? hB : mxor<K>(mP, mO)));
 #endif
       if (improved && lane0) cold.jmin = jtail;
       if (state < 0) break;
@@ -801,9 +806,8 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
     // ======================= what landed goes where ==========================
     if (did_move) {
       // :191  B <- A, carrying what is already known about A's children
-      if (b_is_left_of_a) { p0 = stPart; p1 = x_pCcur; }
-      else                { p1 = stPart; p0 = x_pCcur; }
-      B = stA; bl = x_al; br = x_ar; ccB = x_ccA; partB = x_partA;
+      pP = partB; pO = x_pCcur;
+      B = A; bl = x_al; br = x_ar; ccB = x_ccA; partB = x_partA;
       if constexpr (HYPER) { hB = hA; hA = gH; }
       A = x_aP;
       raL = rnL; raR = rnR; raP = rnP; raC = rnC;
@@ -821,14 +825,14 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       partB = __hiloint2double((int)gXhi, (int)gXlo);
       state = S_GOT_HB;
     } else if (state == S_GOT_HB) {
-      m0 = gM; p0 = gMp;
+      mP = gM; pl = true; pP = gMp;  // (the left child takes the path slot: the first move has no path child yet)
       total = __hiloint2double((int)gXhi, (int)gXlo);
       raL = gL; raR = gR; raP = gP; raC = gC;
       if constexpr (FW) raW = gW;
       if constexpr (HYPER) { hB = gH; }
       state = S_GOT_B1;
     } else if (state == S_GOT_B1) {
-      m1 = gM; p1 = gMp;
+      mO = gM; pO = gMp;
       beta = __hiloint2double((int)gXhi, (int)gXlo);
       rnL = gL; rnR = gR; rnP = gP; rnC = gC;
       if constexpr (FW) rnW = gW;
