@@ -69,7 +69,8 @@ FW_RESLICE_LAUNCHES = lambda sps, every: (sps + every - 1) // every   # noqa: E7
 # what the library's four timers (tnco_hip_diag_kernel_times) cover, by the kernels' names in a rocprofv3 trace
 TRACE_NAMES = {
     "sa_run_kernel": "sa_run_kernel<LOG2L, K, HYPER, GENERIC, false> (infinite-memory sweeps)",
-    "fw_move_kernel": "sa_run_kernel<LOG2L, K, HYPER, GENERIC, true> (the finite-width moves; fw_move_kernel<> with max_number_new_slices > 0)",
+    "fw_move_kernel": "sa_run_fw_kernel<LOG2L, K, SPREAD> (the finite-width moves of the plain cost model, 192 VGPRs; other cost models: "
+                      "sa_run_kernel<LOG2L, K, HYPER, GENERIC, true>; fw_move_kernel<> with max_number_new_slices > 0)",
     "fw_reslice_kernel": "fw_wave_kernel<J, LOGT> + fw_reslice_a_kernel<> + fw_reslice_b_kernel<> (one wavefront per replica, "
                          "stragglers, end of sweep); fw_reslice_kernel<> in the walk + full-rebuild form",
     "fw_walk_kernel": "fw_walk2_kernel (walk + full-rebuild form only)",
@@ -79,6 +80,8 @@ TRACE_NAMES = {
 def kernel_of(name: str):
     """Kernel name of a rocprofv3 row -> the library's timer it belongs to.  The staged sweep kernel also runs the
     moves of the finite-width optimizer: sa_run_kernel<LOG2L, K, HYPER, GENERIC, FW = true>."""
+    if "sa_run_fw_kernel<" in name:
+        return "fw_move_kernel"
     if "sa_run_kernel<" in name:
         targs = name.split("sa_run_kernel<", 1)[1].split(">", 1)[0].split(",")
         return "fw_move_kernel" if len(targs) >= 5 and targs[4].strip() == "true" else "sa_run_kernel"
@@ -796,7 +799,7 @@ def main() -> None:
                     roof["trace_names_seen"] = {k: pmc["trace_names"].get(k) for k in kernels}
                     seen = pmc["trace_names"].get(roof["kernel"]) or []
                     # (the dominant kernel by its name in the trace: profiles/r04_kernel_stats.csv has this row)
-                    dom = [x for x in seen if "fw_wave_kernel" in x or "sa_run_kernel" in x]
+                    dom = [x for x in seen if "fw_wave_kernel" in x or "sa_run_kernel" in x or "sa_run_fw_kernel" in x]
                     if dom:
                         roof["kernel"] = dom[0].replace("void ", "")
             else:

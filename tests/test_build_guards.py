@@ -36,7 +36,8 @@ def test_sweep_loops_have_one_landing_fence_and_no_scratch(report):
     assert len(staged) == 5
     for what, rep in staged.items():
         assert rep["fences"] == 1, (what, rep["vm_waits"], rep["memory_between_waits"])
-        assert rep["scratch_in_loop"] == [], (what, rep["scratch_in_loop"])
+        import code_objects
+        assert code_objects.scratch_ok(what, rep), (what, rep["scratch_in_loop"])
         # (the loop of the state machine: one load sequence, one store sequence -- a duplicated body would double these)
         assert rep["loads"] <= 20 and 5 <= rep["stores"] <= 16, (what, rep["loads"], rep["stores"])
 

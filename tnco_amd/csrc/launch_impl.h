@@ -14,12 +14,12 @@ static const void* run_kernel_ptr(const tnco_hip_ctx* h) {
   if (h->fw) {  // (finite width: the staged moves; the spread form is asked about its own occupancy)
     if (h->run_seats > 0) {
       if (h->hyper)
-        return h->generic ? (const void*)sa_run_kernel<LOG2L, K, true, true, true, true> : (const void*)sa_run_kernel<LOG2L, K, true, false, true, true>;
-      return h->generic ? (const void*)sa_run_kernel<LOG2L, K, false, true, true, true> : (const void*)sa_run_kernel<LOG2L, K, false, false, true, true>;
+        return h->generic ? (const void*)fw_staged_kernel<LOG2L, K, true, true, true>() : (const void*)fw_staged_kernel<LOG2L, K, true, false, true>();
+      return h->generic ? (const void*)fw_staged_kernel<LOG2L, K, false, true, true>() : (const void*)fw_staged_kernel<LOG2L, K, false, false, true>();
     }
     if (h->hyper)
-      return h->generic ? (const void*)sa_run_kernel<LOG2L, K, true, true, true> : (const void*)sa_run_kernel<LOG2L, K, true, false, true>;
-    return h->generic ? (const void*)sa_run_kernel<LOG2L, K, false, true, true> : (const void*)sa_run_kernel<LOG2L, K, false, false, true>;
+      return h->generic ? (const void*)fw_staged_kernel<LOG2L, K, true, true, false>() : (const void*)fw_staged_kernel<LOG2L, K, true, false, false>();
+    return h->generic ? (const void*)fw_staged_kernel<LOG2L, K, false, true, false>() : (const void*)fw_staged_kernel<LOG2L, K, false, false, false>();
   }
   if (h->run_seats > 0) {  // (a spread batch: sa_sweep.h, SPREAD)
     if (h->hyper)
@@ -173,11 +173,11 @@ void launch_fw_move_lk(tnco_hip_ctx* h, const double* betas, int64_t n_steps, in
 #define TNCO_FW_STAGED(HY, GE)                                                                                             \
   do {                                                                                                                     \
     if (h->run_seats > 0) /* a small batch: one replica per wavefront (sa_sweep.h, SPREAD) */                              \
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, HY, GE, true, true>),                                                    \
+      hipLaunchKernelGGL((fw_staged_kernel<LOG2L, K, HY, GE, true>()),                                                     \
                          dim3((unsigned)((h->P.R + (SWT / 64) * h->run_seats - 1) / ((SWT / 64) * h->run_seats))),         \
                          dim3(SWT), 0, h->stream, h->P, betas, n_steps, prob_kind, h->F, tail_last, h->run_seats);         \
     else                                                                                                                   \
-      hipLaunchKernelGGL((sa_run_kernel<LOG2L, K, HY, GE, true>), grid_staged, dim3(SWT), 0, h->stream, h->P, betas, n_steps, \
+      hipLaunchKernelGGL((fw_staged_kernel<LOG2L, K, HY, GE, false>()), grid_staged, dim3(SWT), 0, h->stream, h->P, betas, n_steps, \
                          prob_kind, h->F, tail_last, 0);                                                                   \
   } while (0)
     if (h->hyper) {

@@ -272,6 +272,16 @@ __device__ __forceinline__ bool accept_move(int kind, double beta, double delta,
 #endif
 enum : int { S_BEGIN = 0, S_GOT_B = 1, S_GOT_HB = 2, S_GOT_B1 = 3, S_GOT_HA = 4, S_MOVE = 5, S_END = 6 };
 
+// Scalars of a replica's walk.  A LEAN instantiation (the finite-width moves) keeps them in LDS instead of registers, one
+// slot per replica -- the lanes of a group hold the same values: the Metropolis operands, the partial costs of the children,
+// the headers of A and of A's parent that wait for their move, the counters.  With them (and the sliced-index mask) out
+// of the register file the moves need at most 192 VGPRs: two of their wavefronts leave room on a SIMD for one wavefront
+// of the OTHER stream's re-slice kernel (127 VGPRs), which is bound by instruction issue while the moves wait on memory.
+struct WalkScal {
+  double total, beta, pP, pO, pC, raC, rnC;
+  int raL, raR, raP, rnL, rnR, rnP, raW, rnW;
+  uint32_t n_moves, n_acc;
+};
 // Rarely touched per-replica state lives in LDS, not in registers (VGPRs bound the occupancy).
 struct ColdState {
   double min_cost;
@@ -320,6 +330,10 @@ constexpr int SWT = TNCO_SWEEP_THREADS;
 #ifndef TNCO_FW_STAGED_WAVES
 #define TNCO_FW_STAGED_WAVES 2
 #endif
+// which instantiations keep WalkScal and the slices in LDS
+#ifndef TNCO_LEAN_RULE
+#define TNCO_LEAN_RULE (FW && !GENERIC && !HYPER && LOG2L == 2)
+#endif
 template <int LOG2L, int K, bool HYPER, bool GENERIC, bool FW = false, bool SPREAD = false>
 // (hyper-indices: six more masks are carried -- at 3 wavefronts per SIMD the K = 3 kernel spilled 51 VGPRs)
 #ifndef TNCO_HYPER_WAVES
@@ -336,9 +350,9 @@ template <int LOG2L, int K, bool HYPER, bool GENERIC, bool FW = false, bool SPRE
 #ifndef TNCO_K4_WAVES
 #define TNCO_K4_WAVES 2
 #endif
-__global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES : (HYPER ? TNCO_HYPER_WAVES : (GENERIC ? TNCO_GENERIC_WAVES : (K >= 4 ? TNCO_K4_WAVES : TNCO_WAVES_PER_SIMD)))))) void sa_run_kernel(
-    const Params P, const double* __restrict__ betas, const int64_t n_steps, const int prob_kind,
-    const FwParams F, const int tail_last, const int block0) {
+__device__ __forceinline__ void sa_run_body(
+    const Params& P, const double* __restrict__ betas, const int64_t n_steps, const int prob_kind,
+    const FwParams& F, const int tail_last, const int block0) {
   // SPREAD (a batch smaller than the kernel's wavefront slots): fewer replicas per wavefront than 64 / L -- `block0` of
   // them, the host's choice --, the other lane groups SHADOW them: same replica, same reads, hence the same values and
   // control flow, no store of their own.  Sixteen replicas in sixteen states make a wavefront run every state's code
@@ -351,6 +365,9 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
   __shared__ uint32_t rngbuf[GPB * R::RING];
   __shared__ ColdState coldbuf[GPB];
   __shared__ int32_t jbuf[GPB * 16];
+  constexpr bool LEAN = TNCO_LEAN_RULE;
+  __shared__ WalkScal scalbuf[LEAN ? GPB : 1];
+  __shared__ uint64_t slbuf[LEAN ? GPB * L * K : 1];  // (LEAN: the sliced indices, constant during a launch)
   // The general cost models read their tables from LDS (sa_kernels.h, TabsLds): the cost table d^k (uniform dims that
   // are not a power of two; the one-odd-part chain) or the odd parts of per-index dims -- one buffer, a cost mode uses
   // one of them --, the exponent classes, the odd-part mask; the sparse mask sits in registers.
@@ -411,7 +428,6 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       cold.n_impr = 0; cold.n_full = 0; cold.n_rpick = 0;
     }
   }
-  uint32_t n_moves = 0, n_acc = 0;
   const uint32_t jcap = (uint32_t)P.jcap;
   uint32_t jtail = P.rs[r].jtail;
   bool jinvalid = P.rs[r].jinvalid != 0;
@@ -432,12 +448,16 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
     }
   }
   // finite width: the sliced indices (constant during this kernel), this lane's words
-  M sl = mzero<K>();
+  M sl_regs = mzero<K>();
+  typedef TNCO_LDS volatile uint64_t lds_vu64;
+  [[maybe_unused]] lds_vu64* slw = (lds_vu64*)slbuf + (LEAN ? gib * (L * K) : 0);
   [[maybe_unused]] bool impr_any = false;
   if constexpr (FW) {
     const uint64_t* s0 = F.slices + r * 2 * (int64_t)(L * K);
 #pragma unroll
-    for (int k = 0; k < K; ++k) sl.w[k] = s0[v.widx(k)];
+    for (int k = 0; k < K; ++k) {
+      if constexpr (LEAN) slw[v.widx(k)] = s0[v.widx(k)]; else sl_regs.w[k] = s0[v.widx(k)];
+    }
   }
   [[maybe_unused]] TabsLds<K> tabs{P, (lds_cdouble*)tabbuf, (lds_cu64*)clsbuf, (lds_cu64*)oddbuf, mzero<K>()};
   if constexpr (GENERIC) {
@@ -453,22 +473,26 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
 
   // ---- carried state: B and what is known about its two children ----------
   int B = 0, bl = 0, br = 0, A = -1;
-  [[maybe_unused]] int wB = 0, raW = 0, rnW = 0;  // finite width: the spare header word (cached width) of B, A, parent(A)
-  double ccB = 0, partB = 0, total = 0, beta = 0;
+  [[maybe_unused]] int wB = 0;  // finite width: the spare header word (cached width) of B (A's and parent(A)'s: S.raW, S.rnW)
+  double ccB = 0, partB = 0;
+  WalkScal scal_regs{0, 0, 0, 0, 0, 0, 0, -1, -1, -1, -1, -1, -1, 0, 0, 0, 0};
+  TNCO_LDS volatile WalkScal* scal_lds = (TNCO_LDS volatile WalkScal*)scalbuf + (LEAN ? gib : 0);
+  auto& S = *[&]() {
+    if constexpr (LEAN) return scal_lds; else return &scal_regs;
+  }();
+  if constexpr (LEAN) {
+    S.total = 0; S.beta = 0; S.pP = 0; S.pO = 0; S.pC = 0; S.raC = 0; S.rnC = 0;
+    S.raL = -1; S.raR = -1; S.raP = -1; S.rnL = -1; S.rnR = -1; S.rnP = -1; S.raW = 0; S.rnW = 0; S.n_moves = 0; S.n_acc = 0;
+  }
   // (hyper-indices: hB / hA = the OWN legs of B / A)
   // The legs of B's two children, by ROLE, not by slot: mP = the child the walk came up through (after a move: the old B,
   // with its new legs), mO = the other one; `pl`: mP is the LEFT child (child 0).  The slots only matter to the (D, E)
   // rule -- cand0 is D = child0 -- so a move ends with two plain assignments instead of a left / right select of four masks.
   M mP = mzero<K>(), mO = mzero<K>(), hB = mzero<K>();
   bool pl = true;
-  double pP = 0, pO = 0;  // partial costs of the two children, by role like their legs
-  // ---- operands of the coming moves (landed in earlier iterations) -----------
-  int raL = -1, raR = -1, raP = -1;  // header of A
-  double raC = 0;
-  int rnL = -1, rnR = -1, rnP = -1;  // header of parent(A)
-  double rnC = 0;
+  // (S.pP / S.pO: the partial costs of the two children, by role like their legs; S.ra* / S.rn*: the headers of A and of
+  //  A's parent, landed in earlier iterations, that wait for their move)
   M mC = mzero<K>(), hA = mzero<K>();
-  double pC = 0;
   int step = 0;
   int state = S_BEGIN;
 
@@ -574,14 +598,14 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
     } else if (state == S_GOT_B1) {
       x1 = br;
       xa = reinterpret_cast<const uint32_t*>(betas + step);
-      if (A >= 0) { hN = raP; yN = A; }
+      if (A >= 0) { hN = S.raP; yN = A; }
     } else if (state == S_GOT_HA) {
-      x1 = (raL == B) ? raR : raL;  // C, the sibling of B
+      x1 = (S.raL == B) ? S.raR : S.raL;  // C, the sibling of B
     } else if (state == S_MOVE) {
-      if (raP >= 0) {
-        x1 = (rnL == A) ? rnR : rnL;  // the sibling of A: C of the next move
-        hN = rnP;
-        yN = raP;
+      if (S.raP >= 0) {
+        x1 = (S.rnL == A) ? S.rnR : S.rnL;  // the sibling of A: C of the next move
+        hN = S.rnP;
+        yN = S.raP;
       }
     }
 
@@ -610,15 +634,20 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
 
     if (state == S_MOVE) {
       did_move = true;
-      int al = raL, ar = raR;
-      const int aP = raP;
-      double ccA = raC;
+      int al = S.raL, ar = S.raR;
+      const int aP = S.raP;
+      double ccA = S.raC;
       const bool c_is_right = (al == B);
       const int C = c_is_right ? ar : al;
 
       // ---- one move evaluation (optimizer.hpp:117-192) -----------------------
       // hyper[A] | hyper[B] (optimizer.hpp:145-147); derived: hyper[B] = B & c0 & c1, hyper[A] = A & B & C
       const M hy = HYD ? mand<K>(hB, mor<K>(mand<K>(hA, mC), mand<K>(mP, mO))) : mzero<K>();
+      M sl = sl_regs;
+      if constexpr (LEAN) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) sl.w[k] = slw[v.widx(k)];
+      }
       // both candidate (D, E) assignments evaluated at once:
       //   cand0: D = child0, E = child1;  cand1: D = child1, E = child0
       // new legs of B: (D ^ C) | hyper_A | hyper_B   (optimizer.hpp:147)
@@ -659,7 +688,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       const bool pickP = pick0 == pl;  // D is the path child
       const M mD = msel<K>(pickP, mP, mO), mE = msel<K>(pickP, mO, mP);
       const M newB = mor<K>(mxor<K>(mD, mC), hy);
-      const double pD = pickP ? pP : pO, pE = pickP ? pO : pP;
+      const double pD = pickP ? S.pP : S.pO, pE = pickP ? S.pO : S.pP;
       const int E = pick0 ? br : bl;
       if constexpr (PICK_FIRST) {  // the chosen candidate's two costs: A over newB | E | slices, B over D | C | slices
         const uint32_t w = gsum<LOG2L>(mpopc<K>(mor<K>(mor<K>(newB, mE), sl)) | (mpopc<K>(mor<K>(mor<K>(mD, mC), sl)) << 13));
@@ -698,19 +727,19 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
         nB = generic_cost_t<LOG2L, K>(P, tabs, mor<K>(mor<K>(mD, mC), sl), lig, gbase);
       }
       const double delta = rnd_cost(rnd_cost(nB - ccB, f32) + rnd_cost(nA - ccA, f32), f32);  // :158
-      ++n_moves;
+      ++S.n_moves;
 
       // :162 (always drawn; finite width: only for a move that fits, greedy/optimizer.hpp:188-201)
       if (fits) {
         const double u = rng.uniform01();
-        acc = accept_move(prob_kind, beta, delta, total, u, f32);
+        acc = accept_move(prob_kind, S.beta, delta, S.total, u, f32);
       }
 
-      double pEcur = pE, pCcur = pC;  // partials of B's / A's other child after the move
+      double pEcur = pE, pCcur = S.pC;  // partials of B's / A's other child after the move
       M mBnow, mX;                     // legs of B / of A's other child after the move
       stC = C; stE = E;
       if (acc) {
-        ++n_acc;
+        ++S.n_acc;
         if constexpr (FW) {  // :216  width_B = new_width_B
           if (F.width_f32) wB = __float_as_int((float)new_width_B);
           stW64 = new_width_B;
@@ -721,8 +750,8 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
         if constexpr (HYD) hB = newB;  // (B's own legs; A's stay)
         ccB = nB;
         ccA = nA;
-        total = rnd_cost(total + delta, f32);  // :177
-        pEcur = pC;
+        S.total = rnd_cost(S.total + delta, f32);  // :177
+        pEcur = S.pC;
         pCcur = pE;
         mBnow = newB;
         mX = mE;
@@ -806,15 +835,15 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
     // ======================= what landed goes where ==========================
     if (did_move) {
       // :191  B <- A, carrying what is already known about A's children
-      pP = partB; pO = x_pCcur;
+      S.pP = partB; S.pO = x_pCcur;
       B = A; bl = x_al; br = x_ar; ccB = x_ccA; partB = x_partA;
       if constexpr (HYPER) { hB = hA; hA = gH; }
       A = x_aP;
-      raL = rnL; raR = rnR; raP = rnP; raC = rnC;
-      rnL = gL; rnR = gR; rnP = gP; rnC = gC;
-      if constexpr (FW) { wB = raW; raW = rnW; rnW = gW; }
+      S.raL = S.rnL; S.raR = S.rnR; S.raP = S.rnP; S.raC = S.rnC;
+      S.rnL = gL; S.rnR = gR; S.rnP = gP; S.rnC = gC;
+      if constexpr (FW) { wB = S.raW; S.raW = S.rnW; S.rnW = gW; }
       mC = gM;
-      pC = gMp;
+      S.pC = gMp;
       state = (A < 0) ? S_END : S_MOVE;
     } else if (state == S_BEGIN) {
       B = (int)gXlo;
@@ -825,21 +854,21 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       partB = __hiloint2double((int)gXhi, (int)gXlo);
       state = S_GOT_HB;
     } else if (state == S_GOT_HB) {
-      mP = gM; pl = true; pP = gMp;  // (the left child takes the path slot: the first move has no path child yet)
-      total = __hiloint2double((int)gXhi, (int)gXlo);
-      raL = gL; raR = gR; raP = gP; raC = gC;
-      if constexpr (FW) raW = gW;
+      mP = gM; pl = true; S.pP = gMp;  // (the left child takes the path slot: the first move has no path child yet)
+      S.total = __hiloint2double((int)gXhi, (int)gXlo);
+      S.raL = gL; S.raR = gR; S.raP = gP; S.raC = gC;
+      if constexpr (FW) S.raW = gW;
       if constexpr (HYPER) { hB = gH; }
       state = S_GOT_B1;
     } else if (state == S_GOT_B1) {
-      mO = gM; pO = gMp;
-      beta = __hiloint2double((int)gXhi, (int)gXlo);
-      rnL = gL; rnR = gR; rnP = gP; rnC = gC;
-      if constexpr (FW) rnW = gW;
+      mO = gM; S.pO = gMp;
+      S.beta = __hiloint2double((int)gXhi, (int)gXlo);
+      S.rnL = gL; S.rnR = gR; S.rnP = gP; S.rnC = gC;
+      if constexpr (FW) S.rnW = gW;
       if constexpr (HYPER) { hA = gH; }
       state = (A < 0) ? S_END : S_GOT_HA;
     } else if (state == S_GOT_HA) {
-      mC = gM; pC = gMp;
+      mC = gM; S.pC = gMp;
       state = S_MOVE;
     }
   }
@@ -854,7 +883,7 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
       uint64_t* s1 = F.slices + r * 2 * (int64_t)(L * K) + L * K;
 #pragma unroll
       for (int k = 0; k < K; ++k)
-        if (master) s1[v.widx(k)] = sl.w[k];
+        if (master) s1[v.widx(k)] = LEAN ? (uint64_t)slw[v.widx(k)] : sl_regs.w[k];
     }
   }
   int mti, mtw;
@@ -865,14 +894,42 @@ __global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES :
     rs->jinvalid = jinvalid ? 1 : 0;
     rs->n_fullcopy += cold.n_full;
     rs->min_cost = cold.min_cost;
-    rs->n_moves += n_moves;
-    rs->n_accepted += n_acc;
+    rs->n_moves += S.n_moves;
+    rs->n_accepted += S.n_acc;
     rs->n_improved += cold.n_impr;
     rs->n_randpick += cold.n_rpick;
     rs->mti = mti;
     rs->mtw = mtw;
     if constexpr (!FW) { TNCO_PROF_OUT(rs); }
   }
+}
+
+// The kernels.  `sa_run_kernel`: every instantiation but the plain finite-width moves.
+template <int LOG2L, int K, bool HYPER, bool GENERIC, bool FW = false, bool SPREAD = false>
+__global__ __launch_bounds__(SWT, (LOG2L == 1 ? 2 : (FW ? TNCO_FW_STAGED_WAVES : (HYPER ? TNCO_HYPER_WAVES : (GENERIC ? TNCO_GENERIC_WAVES : (K >= 4 ? TNCO_K4_WAVES : TNCO_WAVES_PER_SIMD)))))) void sa_run_kernel(
+    const Params P, const double* __restrict__ betas, const int64_t n_steps, const int prob_kind,
+    const FwParams F, const int tail_last, const int block0) {
+  sa_run_body<LOG2L, K, HYPER, GENERIC, FW, SPREAD>(P, betas, n_steps, prob_kind, F, tail_last, block0);
+}
+
+// `sa_run_fw_kernel`: the finite-width moves of the plain cost model in four lanes per replica (config 5) under a ceiling
+// of 192 VGPRs -- a register attribute cannot depend on a template argument, hence a kernel of its own around the same
+// body (its LEAN form: WalkScal and the slices in LDS; four registers spilled outside the loop).  Two of its wavefronts
+// then leave a SIMD 128 registers: room for one wavefront of the OTHER stream's `fw_wave_kernel` (127), which is bound by
+// instruction issue while these moves wait on memory -- the re-slice of one half of the batch runs in the shadow of the
+// moves of the other (+3.9 % on config 5, same box, alternating: profiles/experiments_r06.md).  The attribute counts
+// HALVES of the unified register file: 96 -> 192.
+template <int LOG2L, int K, bool SPREAD = false>
+__global__ __launch_bounds__(SWT, 2) __attribute__((amdgpu_num_vgpr(96))) void sa_run_fw_kernel(
+    const Params P, const double* __restrict__ betas, const int64_t n_steps, const int prob_kind,
+    const FwParams F, const int tail_last, const int block0) {
+  sa_run_body<LOG2L, K, false, false, true, SPREAD>(P, betas, n_steps, prob_kind, F, tail_last, block0);
+}
+// which of the two a finite-width handle launches
+template <int LOG2L, int K, bool HYPER, bool GENERIC, bool SPREAD>
+__host__ inline auto fw_staged_kernel() {
+  if constexpr (!HYPER && !GENERIC && LOG2L == 2) return &sa_run_fw_kernel<LOG2L, K, SPREAD>;
+  else return &sa_run_kernel<LOG2L, K, HYPER, GENERIC, true, SPREAD>;
 }
 
 }  // namespace tnco

@@ -15,7 +15,7 @@ CSRC = ROOT / "tnco_amd" / "csrc"
 # mangled-name fragment -> (what, max VGPRs, min waves per SIMD)
 BUDGET = {
     ("inst_2_3.hip", "sa_run_kernelILi2ELi3ELb0ELb0ELb0E"): ("sa_run_kernel<2, 3, false, false, false> (headline leg)", 168, 3),
-    ("inst_2_4.hip", "sa_run_kernelILi2ELi4ELb0ELb0ELb1E"): ("sa_run_kernel<2, 4, false, false, true> (finite-width moves)", 256, 2),
+    ("inst_2_4.hip", "sa_run_fw_kernelILi2ELi4ELb0E"): ("sa_run_fw_kernel<2, 4, false> (finite-width moves)", 192, 2),
     ("inst_2_4.hip", "fw_wave_kernelILi9ELi4ELb0ELb0E"): ("fw_wave_kernel<9, 4, false, false> (config 5 re-slice)", 128, 4),
     ("inst_2_4.hip", "fw_wave_kernelILi6ELi4ELb1ELb0E"): ("fw_wave_kernel<6, 4, true, false> (hyper-index networks up to 384 nodes)", 128, 4),
 }

@@ -26,12 +26,12 @@ MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 # mangled-name fragment -> (what, max VGPRs, min wavefronts per SIMD, max scratch bytes per lane)
 BUDGET = {
     "sa_run_kernelILi2ELi3ELb0ELb0ELb0E": ("sa_run_kernel<2, 3, false, false, false> (headline leg)", 168, 3, 16),
-    "sa_run_kernelILi2ELi4ELb0ELb0ELb1E": ("sa_run_kernel<2, 4, false, false, true> (finite-width moves)", 256, 2, 0),
+    "sa_run_fw_kernelILi2ELi4ELb0E": ("sa_run_fw_kernel<2, 4, false> (finite-width moves: 192 VGPRs leave a SIMD room for a fw_wave_kernel wavefront)", 192, 2, 48),
     "fw_wave_kernelILi9ELi4ELb0ELb0E": ("fw_wave_kernel<9, 4, false, false> (config 5 re-slice)", 128, 4, 0),
     "fw_wave_kernelILi6ELi4ELb1ELb0E": ("fw_wave_kernel<6, 4, true, false> (hyper-index networks up to 384 nodes)", 128, 4, 0),
 }
 # kernels whose main loop must hold one landing fence and no scratch access (the last two: not in BUDGET, loop check only)
-STAGED = ("sa_run_kernelILi2ELi3ELb0ELb0ELb0E", "sa_run_kernelILi2ELi4ELb0ELb0ELb1E")
+STAGED = ("sa_run_kernelILi2ELi3ELb0ELb0ELb0E", "sa_run_fw_kernelILi2ELi4ELb0E")
 STAGED_ONLY = {
     "sa_run_kernelILi2ELi3ELb1ELb0ELb0E": "sa_run_kernel<2, 3, true, false, false> (hyper-indices)",
     "sa_run_kernelILi2ELi3ELb0ELb1ELb0E": "sa_run_kernel<2, 3, false, true, false> (general cost models: tables in LDS)",
@@ -209,6 +209,15 @@ def report(lib: pathlib.Path = LIB):
     return rows, staged
 
 
+def scratch_ok(what: str, rep: dict) -> bool:
+    """No scratch access inside a sweep loop -- but for the finite-width moves under their 192-register ceiling: ONE
+    reload (no store) just ahead of the landing fence, the form that was measured (+3.9 %, profiles/experiments_r06.md)."""
+    acc = rep["scratch_in_loop"]
+    if what.startswith("sa_run_fw_kernel"):
+        return len(acc) <= 1 and all(op.startswith("scratch_load") for _a, op in acc)
+    return not acc
+
+
 def main():
     rows, staged = report()
     bad = 0
@@ -216,7 +225,7 @@ def main():
         bad += not ok
         print(("ok   " if ok else "OVER ") + line)
     for what, rep in staged.items():
-        ok = rep["fences"] == 1 and not rep["scratch_in_loop"]
+        ok = rep["fences"] == 1 and scratch_ok(what, rep)
         bad += not ok
         print(("ok   " if ok else "BAD  ") + f"{what}: main loop of {rep['instructions']} instructions, {rep['loads']} loads / "
               f"{rep['stores']} stores, landing fences {rep['fences']} (vmcnt waits {rep['vm_waits']}), scratch accesses in the loop "

@@ -16,17 +16,20 @@ import code_objects as co  # noqa: E402
 def main():
     targs = sys.argv[1] if len(sys.argv) > 1 else "2, 4, false, false, true, false"
     flags = sys.argv[2:]
+    kernel = "sa_run_kernel"
+    if targs.startswith("fw:"):  # "fw:2, 4, false" = sa_run_fw_kernel<2, 4, false>
+        kernel, targs = "sa_run_fw_kernel", targs[3:]
     with tempfile.TemporaryDirectory() as td:
         src = pathlib.Path(td) / "probe.hip"
-        src.write_text('#include "sa_sweep.h"\nnamespace tnco {\ntemplate __global__ void sa_run_kernel<%s>(const Params, const double* __restrict__, '
-                       'const int64_t, const int, const FwParams, const int, const int);\n}\n' % targs)
+        src.write_text('#include "sa_sweep.h"\nnamespace tnco {\ntemplate __global__ void %s<%s>(const Params, const double* __restrict__, '
+                       'const int64_t, const int, const FwParams, const int, const int);\n}\n' % (kernel, targs))
         obj = pathlib.Path(td) / "probe.o"
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
                                "-Wno-unused-function", "-I", str(ROOT / "tnco_amd" / "csrc"), "--cuda-device-only", "-c", "-o", str(obj), str(src), *flags])
         raw = obj.read_bytes()
         elf = raw if raw[:4] == b"\x7fELF" else co.bundle_objects(raw)[0]
         for name, meta in co.kernel_table(elf).items():
-            if "sa_run_kernel" not in name:
+            if kernel not in name:
                 continue
             ins = co.disassemble(elf, name)
             rep = co.main_loop_report(ins)
