@@ -367,7 +367,7 @@ __device__ __forceinline__ void sa_run_body(
   __shared__ int32_t jbuf[GPB * 16];
   constexpr bool LEAN = TNCO_LEAN_RULE;
   __shared__ WalkScal scalbuf[LEAN ? GPB : 1];
-  __shared__ uint64_t slbuf[LEAN ? GPB * L * K : 1];  // (LEAN: the sliced indices, constant during a launch)
+  __shared__ uint64_t slbuf[LEAN && FW ? GPB * L * K : 1];  // (LEAN: the sliced indices, constant during a launch)
   // The general cost models read their tables from LDS (sa_kernels.h, TabsLds): the cost table d^k (uniform dims that
   // are not a power of two; the one-odd-part chain) or the odd parts of per-index dims -- one buffer, a cost mode uses
   // one of them --, the exponent classes, the odd-part mask; the sparse mask sits in registers.
@@ -450,13 +450,13 @@ __device__ __forceinline__ void sa_run_body(
   // finite width: the sliced indices (constant during this kernel), this lane's words
   M sl_regs = mzero<K>();
   typedef TNCO_LDS volatile uint64_t lds_vu64;
-  [[maybe_unused]] lds_vu64* slw = (lds_vu64*)slbuf + (LEAN ? gib * (L * K) : 0);
+  [[maybe_unused]] lds_vu64* slw = (lds_vu64*)slbuf + (LEAN && FW ? gib * (L * K) : 0);
   [[maybe_unused]] bool impr_any = false;
   if constexpr (FW) {
     const uint64_t* s0 = F.slices + r * 2 * (int64_t)(L * K);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      if constexpr (LEAN) slw[v.widx(k)] = s0[v.widx(k)]; else sl_regs.w[k] = s0[v.widx(k)];
+      if constexpr (LEAN && FW) slw[v.widx(k)] = s0[v.widx(k)]; else sl_regs.w[k] = s0[v.widx(k)];
     }
   }
   [[maybe_unused]] TabsLds<K> tabs{P, (lds_cdouble*)tabbuf, (lds_cu64*)clsbuf, (lds_cu64*)oddbuf, mzero<K>()};
@@ -644,7 +644,7 @@ __device__ __forceinline__ void sa_run_body(
       // hyper[A] | hyper[B] (optimizer.hpp:145-147); derived: hyper[B] = B & c0 & c1, hyper[A] = A & B & C
       const M hy = HYD ? mand<K>(hB, mor<K>(mand<K>(hA, mC), mand<K>(mP, mO))) : mzero<K>();
       M sl = sl_regs;
-      if constexpr (LEAN) {
+      if constexpr (LEAN && FW) {
 #pragma unroll
         for (int k = 0; k < K; ++k) sl.w[k] = slw[v.widx(k)];
       }
@@ -883,7 +883,7 @@ __device__ __forceinline__ void sa_run_body(
       uint64_t* s1 = F.slices + r * 2 * (int64_t)(L * K) + L * K;
 #pragma unroll
       for (int k = 0; k < K; ++k)
-        if (master) s1[v.widx(k)] = LEAN ? (uint64_t)slw[v.widx(k)] : sl_regs.w[k];
+        if (master) s1[v.widx(k)] = (LEAN && FW) ? (uint64_t)slw[v.widx(k)] : sl_regs.w[k];
     }
   }
   int mti, mtw;
