@@ -27,12 +27,12 @@ class Tensor:
     tags: dict = field(default_factory=dict)
 
     def __post_init__(self):
-        object.__setattr__(self, "inds", tuple(self.inds))
-        object.__setattr__(self, "dims", tuple(int(d) for d in self.dims))
-        if len(self.inds) != len(self.dims):
-            raise ValueError("Wrong number of 'inds'.")
-        if any(d < 1 for d in self.dims):
-            raise ValueError("Every dimension must be a positive integers.")
+        inds, dims = tuple(self.inds), tuple(int(d) for d in self.dims)
+        problem = ("Wrong number of 'inds'." if len(inds) != len(dims) else
+                   "Every dimension must be a positive integers." if min(dims, default=1) < 1 else None)
+        if problem:
+            raise ValueError(problem)
+        self.__dict__.update(inds=inds, dims=dims)  # (a frozen dataclass: normalised in place)
 
     @property
     def ndim(self) -> int:
