@@ -14,11 +14,11 @@
 //                        [this iteration's stores]
 //                        [per state: staging registers -> carried state]
 //
-//   states:  BEGIN   draw the leaf, request its parent B                  (optimizer.hpp:103)
+//   states:  BEGIN   draw the leaf, request its parent B and its own legs -- the leaf is the child the walk comes up
+//                    through                                               (optimizer.hpp:103)
 //            GOT_B   request the header of B                              (:107)
-//            GOT_HB  request legs + partial cost of B's left child, header of A, total cost (:112)
-//            GOT_B1  request legs + partial cost of B's right child, header of parent(A), beta
-//            GOT_HA  request the block of C (sibling of B)
+//            GOT_HB  request legs + partial cost of the leaf's sibling, header of A, total cost (:112)
+//            GOT_B1  request the block of C (sibling of B), header of parent(A), beta
 //            MOVE    one move evaluation per iteration (:117-192), requesting the sibling and the
 //                    grandparent header of the next level
 //            END     B is the root: best-tree update (:198-201), then BEGIN of the next sweep
@@ -584,23 +584,28 @@ __device__ __forceinline__ void sa_run_body(
     int hN = -1, x1 = -1, yN = -1;
     const uint32_t* xa = nullptr;
     if (state == S_BEGIN) {
-      // optimizer.hpp:103-107: a random leaf; its parent is B
+      // optimizer.hpp:103-107: a random leaf; its parent is B.  The leaf IS the child the walk comes up through: its legs
+      // (the shared leaf table) are asked for right here, so that the walk starts one iteration earlier (round 6: four
+      // iterations before the first move instead of five).  x_al keeps the leaf until B's header says which child it is.
       const uint32_t x = rng.next();
-      xa = reinterpret_cast<const uint32_t*>(lpar() + (int64_t)(x % (uint32_t)n) * LPS);
+      x_al = (int)(x % (uint32_t)n);
+      x1 = x_al;
+      xa = reinterpret_cast<const uint32_t*>(lpar() + (int64_t)x_al * LPS);
     } else if (state == S_GOT_B) {
       hN = B;
       xa = reinterpret_cast<const uint32_t*>(&v.hdr(B)->partial);
     } else if (state == S_GOT_HB) {
-      x1 = bl;
+      x1 = pl ? br : bl;  // the leaf's sibling
       hN = A;
       yN = B;
       xa = reinterpret_cast<const uint32_t*>(&v.hdr(N - 1)->partial);  // optimizer.hpp:112
     } else if (state == S_GOT_B1) {
-      x1 = br;
       xa = reinterpret_cast<const uint32_t*>(betas + step);
-      if (A >= 0) { hN = S.raP; yN = A; }
-    } else if (state == S_GOT_HA) {
-      x1 = (S.raL == B) ? S.raR : S.raL;  // C, the sibling of B
+      if (A >= 0) {
+        hN = S.raP;
+        yN = A;
+        x1 = (S.raL == B) ? S.raR : S.raL;  // C, the sibling of B (A's header landed with the leaf's sibling)
+      }
     } else if (state == S_MOVE) {
       if (S.raP >= 0) {
         x1 = (S.rnL == A) ? S.rnR : S.rnL;  // the sibling of A: C of the next move
@@ -847,29 +852,28 @@ __device__ __forceinline__ void sa_run_body(
       state = (A < 0) ? S_END : S_MOVE;
     } else if (state == S_BEGIN) {
       B = (int)gXlo;
+      mP = gM; S.pP = gMp;  // (the leaf: the path child of the first move; its partial cost is the zero gMp starts from)
       state = S_GOT_B;
     } else if (state == S_GOT_B) {
       bl = gL; br = gR; A = gP; ccB = gC;
       if constexpr (FW) wB = gW;
       partB = __hiloint2double((int)gXhi, (int)gXlo);
+      pl = gL == x_al;  // the leaf is B's left child
       state = S_GOT_HB;
     } else if (state == S_GOT_HB) {
-      mP = gM; pl = true; S.pP = gMp;  // (the left child takes the path slot: the first move has no path child yet)
+      mO = gM; S.pO = gMp;
       S.total = __hiloint2double((int)gXhi, (int)gXlo);
       S.raL = gL; S.raR = gR; S.raP = gP; S.raC = gC;
       if constexpr (FW) S.raW = gW;
       if constexpr (HYPER) { hB = gH; }
       state = S_GOT_B1;
     } else if (state == S_GOT_B1) {
-      mO = gM; S.pO = gMp;
+      mC = gM; S.pC = gMp;
       S.beta = __hiloint2double((int)gXhi, (int)gXlo);
       S.rnL = gL; S.rnR = gR; S.rnP = gP; S.rnC = gC;
       if constexpr (FW) S.rnW = gW;
       if constexpr (HYPER) { hA = gH; }
-      state = (A < 0) ? S_END : S_GOT_HA;
-    } else if (state == S_GOT_HA) {
-      mC = gM; S.pC = gMp;
-      state = S_MOVE;
+      state = (A < 0) ? S_END : S_MOVE;
     }
   }
 
