@@ -158,11 +158,13 @@ def main_loop_report(ins) -> dict:
         b = [i for i in ins if t <= i[0] <= a]
         return sum(1 for i in b if is_ld(i[1])), sum(1 for i in b if is_st(i[1]))
 
-    good = [(a - t, t, a) for t, a in lp if counts(t, a)[0] >= 8 and counts(t, a)[1] >= 5]
+    # (sixteen loads and twelve stores: the rare full copy of the best tree, a loop inside the main one, has 13 and 8)
+    good = [(a - t, t, a) for t, a in lp if counts(t, a)[0] >= 16 and counts(t, a)[1] >= 12]
     if good:
         _, head, tail = min(good)
-        # (several back edges to one head: the loop is the widest of them)
-        tail = max(a for t, a in lp if t == head or (head <= t and a >= tail and t - head < 64))
+        # (several back edges to about one head: the loop is the widest of them)
+        tail = max(a for t, a in lp if abs(t - head) < 64 and a >= tail)
+        head = min(t for t, a in lp if abs(t - head) < 64 and a == tail)
     else:
         head, tail = max(lp, key=lambda x: x[1] - x[0])
     nested = [(t, a) for t, a in lp if head < t and a < tail]
@@ -210,11 +212,11 @@ def report(lib: pathlib.Path = LIB):
 
 
 def scratch_ok(what: str, rep: dict) -> bool:
-    """No scratch access inside a sweep loop -- but for the finite-width moves under their 192-register ceiling: ONE
-    reload (no store) just ahead of the landing fence, the form that was measured (+3.9 %, profiles/experiments_r06.md)."""
+    """No scratch access inside a sweep loop -- but for the finite-width moves under their 192-register ceiling: at most one
+    spill and one reload ahead of the landing fence, the forms that were measured (profiles/experiments_r06.md)."""
     acc = rep["scratch_in_loop"]
     if what.startswith("sa_run_fw_kernel"):
-        return len(acc) <= 1 and all(op.startswith("scratch_load") for _a, op in acc)
+        return len(acc) <= 2 and sum(1 for _a, op in acc if op.startswith("scratch_store")) <= 1
     return not acc
 
 
