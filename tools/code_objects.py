@@ -158,13 +158,11 @@ def main_loop_report(ins) -> dict:
         b = [i for i in ins if t <= i[0] <= a]
         return sum(1 for i in b if is_ld(i[1])), sum(1 for i in b if is_st(i[1]))
 
-    # (sixteen loads and twelve stores: the rare full copy of the best tree, a loop inside the main one, has 13 and 8)
-    good = [(a - t, t, a) for t, a in lp if counts(t, a)[0] >= 16 and counts(t, a)[1] >= 12]
+    good = [(a - t, t, a) for t, a in lp if counts(t, a)[0] >= 8 and counts(t, a)[1] >= 5]
     if good:
         _, head, tail = min(good)
-        # (several back edges to about one head: the loop is the widest of them)
-        tail = max(a for t, a in lp if abs(t - head) < 64 and a >= tail)
-        head = min(t for t, a in lp if abs(t - head) < 64 and a == tail)
+        # (several back edges to one head: the loop is the widest of them)
+        tail = max(a for t, a in lp if t == head or (head <= t and a >= tail and t - head < 64))
     else:
         head, tail = max(lp, key=lambda x: x[1] - x[0])
     nested = [(t, a) for t, a in lp if head < t and a < tail]
